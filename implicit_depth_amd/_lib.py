@@ -1,0 +1,117 @@
+"""ctypes binding of liblidf_hip.so — the C ABI declared in include/lidf_hip.h.
+
+This module is the only place that touches the shared library. It never falls back to a CPU
+implementation: if the library is missing, `lib()` raises, and every op raises on non-CUDA input
+(mirroring the reference extension's CHECK_CUDA, extensions/ray_aabb/ray_aabb_cuda.cpp:16-18).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblidf_hip.so")
+
+LIDF_OK = 0
+
+
+class LidfDecoder(C.Structure):
+    """struct LidfDecoder (include/lidf_hip.h)."""
+    _fields_ = [
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("w3", C.c_void_p), ("b3", C.c_void_p), ("w4", C.c_void_p), ("b4", C.c_void_p),
+        ("wenc", C.c_void_p), ("benc", C.c_void_p),
+        ("is_ief", C.c_int32), ("n_iter", C.c_int32), ("init_offset", C.c_float),
+        ("use_sigmoid", C.c_int32),
+    ]
+
+
+class LidfQueryArgs(C.Structure):
+    """struct LidfQueryArgs (include/lidf_hip.h)."""
+    _fields_ = [
+        ("n_rays", C.c_int64), ("ray_dir", C.c_void_p), ("ray_pix", C.c_void_p),
+        ("ray_bid", C.c_void_p), ("ray_flat", C.c_void_p),
+        ("n_pairs", C.c_int64), ("pair_off", C.c_void_p), ("pair_ray", C.c_void_p),
+        ("pair_vox", C.c_void_p), ("pair_t", C.c_void_p),
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("feat_grid", C.c_void_p),
+        ("n_vox", C.c_int64), ("vox_feat", C.c_void_p), ("vox_center", C.c_void_p),
+        ("prob", C.POINTER(LidfDecoder)), ("off", C.POINTER(LidfDecoder)),
+        ("multires", C.c_int32), ("multires_views", C.c_int32), ("roi_inp_bbox", C.c_int32),
+        ("pos_rel", C.c_int32),
+        ("offset_range0", C.c_float), ("offset_range1", C.c_float), ("part_size", C.c_float),
+        ("pred_offset", C.c_void_p), ("pred_prob", C.c_void_p), ("pair_pred_pos", C.c_void_p),
+        ("pred_prob_softmax", C.c_void_p), ("max_pair_id", C.c_void_p), ("pred_pos", C.c_void_p),
+        ("depth", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_P, _I64, _I, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/lidf_hip.h declares
+SIGNATURES = {
+    "lidf_version": (C.c_int, []),
+    "lidf_strerror": (C.c_char_p, [C.c_int]),
+    "lidf_embed_f32": (C.c_int, [_P, _I64, _I, _P, _P]),
+    "lidf_decoders_workspace_bytes": (_SZ, [_I64, _I]),
+    "lidf_decoders_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder),
+                                    C.POINTER(LidfDecoder), _P, _P, _P, _SZ, _P]),
+    "lidf_query_workspace_bytes": (_SZ, [_I64, _I64]),
+    "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
+    "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P]),
+    "lidf_ray_reduce_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "lidf_ray_dirs_f32": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "lidf_ray_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "lidf_ray_aabb_count_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "lidf_ray_aabb_fill_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "lidf_exclusive_scan_workspace_bytes": (_SZ, [_I64]),
+    "lidf_exclusive_scan_i32": (C.c_int, [_P, _I64, _P, _P, _SZ, _P]),
+    "lidf_pcl_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "lidf_pcl_aabb_last_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load liblidf_hip.so (built by implicit_depth_amd/csrc/build.py). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liblidf_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    """Turn a non-zero lidf_status into RuntimeError (the reference's TORCH_CHECK behaviour)."""
+    if status != LIDF_OK:
+        raise RuntimeError(lib().lidf_strerror(status).decode())
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors, names=None):
+    """CHECK_INPUT of the reference bindings: CUDA + contiguous, else RuntimeError."""
+    for i, t in enumerate(tensors):
+        if t is None:
+            continue
+        name = names[i] if names else "tensor %d" % i
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)

@@ -1,0 +1,436 @@
+// lidf_api.hip — the extern "C" surface declared in include/lidf_hip.h: argument checks,
+// workspace carving, kernel sequencing. No allocation, no synchronisation, no global state.
+#include "lidf_device.h"
+#include "lidf_hip.h"
+
+extern "C" {
+hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
+                            float*, hipStream_t);
+hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_embed(const float*, long long, int, float*, hipStream_t);
+hipError_t lidf_launch_rayfeat(const float*, int, int, int, const float*, const int*, const int*,
+                               long long, int, int, float*, int, hipStream_t);
+hipError_t lidf_launch_ray_reduce(const float*, const float*, const int*, long long, long long,
+                                  const int*, const int*, long long, float*, long long*, float*,
+                                  float*, hipStream_t);
+hipError_t lidf_launch_ray_dirs(const float*, int, int, int, float*, hipStream_t);
+hipError_t lidf_launch_ray_aabb_dense(const float*, const float*, const int*, const int*,
+                                      long long, long long, int*, float*, hipStream_t);
+hipError_t lidf_launch_ray_aabb_compact(bool, const float*, const float*, const int*, const int*,
+                                        long long, long long, int*, const int*, int*, int*, float*,
+                                        hipStream_t);
+hipError_t lidf_launch_pcl_aabb_dense(const float*, const float*, const int*, const int*,
+                                      long long, long long, int*, hipStream_t);
+hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, const int*,
+                                     long long, long long, int*, hipStream_t);
+hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
+}
+
+#define LIDF_ABI_VERSION 1
+#define LIDF_API extern "C" __attribute__((visibility("default")))
+#define CHECK_HIP(x)                       \
+    do {                                   \
+        if ((x) != hipSuccess) return LIDF_ERR_HIP; \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int cu_count(int* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return LIDF_ERR_HIP;
+    if (hipDeviceGetAttribute(out, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return LIDF_ERR_HIP;
+    if (*out <= 0) *out = 256;
+    return LIDF_OK;
+}
+
+static int check_decoder(const LidfDecoder* d) {
+    if (!d) return LIDF_OK;
+    if (!d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->w3 || !d->b3 || !d->w4 || !d->b4)
+        return LIDF_ERR_BAD_ARG;
+    if (d->is_ief && (!d->wenc || !d->benc || d->n_iter < 1 || d->n_iter > 64))
+        return LIDF_ERR_BAD_ARG;
+    return LIDF_OK;
+}
+
+static NetW to_netw(const LidfDecoder* d, int dcore) {
+    NetW n;
+    n.w1 = d->w1; n.b1 = d->b1; n.w2 = d->w2; n.b2 = d->b2;
+    n.w3 = d->w3; n.b3 = d->b3; n.w4 = d->w4; n.b4 = d->b4;
+    n.wenc = d->wenc; n.benc = d->benc;
+    n.is_ief = d->is_ief ? 1 : 0;
+    n.dcore = dcore;
+    n.ld1 = dcore + (d->is_ief ? 16 : 0);
+    return n;
+}
+
+static L1Map rows_map(int n0, int c0, int n1, int c1, int add_bias) {
+    L1Map m = {};
+    m.n0 = n0; m.c0 = c0; m.n1 = n1; m.c1 = c1;
+    m.D = n0 + n1;
+    m.KH = (m.D + 1) / 2;
+    m.KQ1 = (m.KH + 1 + 3) / 4;
+    m.add_bias = add_bias;
+    return m;
+}
+
+static void fill_net_args(PointsArgs& a, int i, const LidfDecoder* d, float* out, int is_offset) {
+    a.npass[i] = d->is_ief ? d->n_iter : 1;
+    a.init[i] = d->is_ief ? d->init_offset : 0.f;
+    a.sigmoid[i] = d->use_sigmoid;
+    a.out[i] = out;
+    a.is_offset[i] = is_offset;
+}
+
+LIDF_API int lidf_version(void) { return LIDF_ABI_VERSION; }
+
+LIDF_API const char* lidf_strerror(int status) {
+    switch (status) {
+        case LIDF_OK: return "ok";
+        case LIDF_ERR_BAD_ARG: return "lidf_hip: bad argument (null pointer, negative size or inconsistent sizes)";
+        case LIDF_ERR_UNSUPPORTED: return "lidf_hip: unsupported dimension";
+        case LIDF_ERR_WORKSPACE: return "lidf_hip: workspace too small";
+        case LIDF_ERR_HIP: return "lidf_hip: HIP runtime error";
+        default: return "lidf_hip: unknown status";
+    }
+}
+
+LIDF_API int lidf_embed_f32(const float* x, int64_t n, int multires, float* out,
+                              lidf_stream_t stream) {
+    if (n < 0 || multires < 0 || multires > 16) return LIDF_ERR_BAD_ARG;
+    if (n == 0) return LIDF_OK;
+    if (!x || !out) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_embed(x, n, multires, out, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- decoders on materialised rows ---------------------------------------------------------------
+LIDF_API size_t lidf_decoders_workspace_bytes(int64_t n, int d) {
+    (void)n;
+    if (d <= 0) return 0;
+    L1Map m = rows_map(d, 0, 0, 0, 1);
+    StreamLayout lay = lidf_make_layout(2, LIDF_MODE_ROWS, m);
+    return align_up((size_t)lay.total * 4, 256) + align_up(2 * LIDF_AUX_FLOATS * 4, 256);
+}
+
+LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
+                                 const LidfDecoder* prob, const LidfDecoder* off, float* out_prob,
+                                 float* out_off, void* workspace, size_t workspace_bytes,
+                                 lidf_stream_t stream) {
+    if (n < 0 || d <= 0 || ld_inp < d) return LIDF_ERR_BAD_ARG;
+    if (d > (1 << 20)) return LIDF_ERR_UNSUPPORTED;
+    if (!prob && !off) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(prob)) || (rc = check_decoder(off))) return rc;
+    if (n == 0) return LIDF_OK;  // empty input: nothing to write (reference returns [0,1])
+    if ((prob && !out_prob) || (off && !out_off)) return LIDF_ERR_BAD_ARG;
+    if (!inp) return LIDF_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < lidf_decoders_workspace_bytes(n, d))
+        return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+
+    const int nets = (prob ? 1 : 0) + (off ? 1 : 0);
+    const LidfDecoder* ds[2] = {prob ? prob : off, off};
+    float* outs[2] = {prob ? out_prob : out_off, out_off};
+    L1Map m = rows_map(d, 0, 0, 0, 1);
+    StreamLayout lay = lidf_make_layout(nets, LIDF_MODE_ROWS, m);
+    float* stream_buf = (float*)workspace;
+    float* aux = (float*)((char*)workspace + align_up((size_t)lidf_make_layout(2, LIDF_MODE_ROWS, m).total * 4, 256));
+    NetW n0 = to_netw(ds[0], d);
+    NetW n1 = nets == 2 ? to_netw(ds[1], d) : n0;
+    CHECK_HIP(lidf_launch_pack(lay, n0, n1, m, stream_buf, aux, st));
+
+    PointsArgs a = {};
+    a.stream = stream_buf;
+    a.aux = aux;
+    a.nets = nets;
+    a.l1_floats = lay.l1_floats;
+    a.net_floats = lay.net_floats;
+    a.n = n;
+    for (int i = 0; i < nets; ++i) fill_net_args(a, i, ds[i], outs[i], 0);
+    a.X = inp;
+    a.ldx = ld_inp;
+    a.D = m.D; a.KH = m.KH; a.KQ1 = m.KQ1; a.has_bias = 1;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    long long ntile = (n + 127) / 128;
+    int grid = (int)(ntile < cus ? ntile : cus);
+    CHECK_HIP(lidf_launch_points(LIDF_MODE_ROWS, a, grid, st));
+    return LIDF_OK;
+}
+
+// ---- per-ray features ---------------------------------------------------------------------------
+LIDF_API int lidf_ray_features_f32(const float* feat_grid, int batch, int height, int width,
+                                     const float* ray_dir, const int32_t* ray_pix,
+                                     const int32_t* ray_bid, int64_t n_rays, int roi_inp_bbox,
+                                     int multires_views, float* rayfeat, lidf_stream_t stream) {
+    if (n_rays < 0 || batch <= 0 || height <= 0 || width <= 0 || roi_inp_bbox < 0 ||
+        multires_views < 0 || multires_views > 16)
+        return LIDF_ERR_BAD_ARG;
+    if (n_rays == 0) return LIDF_OK;
+    if (!feat_grid || !ray_dir || !ray_pix || !ray_bid || !rayfeat) return LIDF_ERR_BAD_ARG;
+    const int ld = 128 + 3 + 6 * multires_views;
+    CHECK_HIP(lidf_launch_rayfeat(feat_grid, batch, height, width, ray_dir, ray_pix, ray_bid,
+                                  n_rays, roi_inp_bbox / 2, multires_views, rayfeat, ld,
+                                  (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_pos,
+                                   const int32_t* pair_off, int64_t n_rays, int64_t n_pairs,
+                                   const int32_t* ray_bid, const int32_t* ray_flat, int64_t hw,
+                                   float* softmax, int64_t* max_pair_id, float* pred_pos,
+                                   float* depth, lidf_stream_t stream) {
+    if (n_rays < 0 || n_pairs < 0) return LIDF_ERR_BAD_ARG;
+    if (n_rays == 0) return LIDF_OK;
+    if (!pair_off || (n_pairs > 0 && !pred_prob)) return LIDF_ERR_BAD_ARG;
+    if (pred_pos && n_pairs > 0 && !pair_pred_pos) return LIDF_ERR_BAD_ARG;
+    if (depth && (!ray_bid || !ray_flat || !pair_pred_pos)) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_ray_reduce(pred_prob, pair_pred_pos, pair_off, n_rays, n_pairs, ray_bid,
+                                     ray_flat, hw, softmax, (long long*)max_pair_id, pred_pos,
+                                     depth, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- fused query ---------------------------------------------------------------------------------
+struct QueryWs {
+    size_t stream_pts, aux_pts, stream_vox, stream_ray, voxpart, raypart, rayfeat, total;
+};
+
+static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv) {
+    QueryWs w;
+    L1Map mf = {};
+    mf.L = L;
+    const int Ed = 3 + 6 * Lv;
+    size_t o = 0;
+    w.stream_pts = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_FUSED, mf).total * 4, 256);
+    w.aux_pts = o;    o += align_up(2 * LIDF_AUX_FLOATS * 4, 256);
+    w.stream_vox = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, 0, 0, 1)).total * 4, 256);
+    w.stream_ray = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, Ed, 0, 0)).total * 4, 256);
+    w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
+    w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
+    w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox) {
+    // sized for the largest supported embedding (multires = multires_views = 16)
+    return query_ws(n_rays, n_vox, 16, 16).total;
+}
+
+LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
+    if (!q) return LIDF_ERR_BAD_ARG;
+    const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
+    if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
+    if (P > 0x7fffffffLL || R > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (q->multires < 0 || q->multires > 16 || q->multires_views < 0 || q->multires_views > 16)
+        return LIDF_ERR_UNSUPPORTED;
+    int rc;
+    if (!q->prob || !q->off) return LIDF_ERR_BAD_ARG;
+    if ((rc = check_decoder(q->prob)) || (rc = check_decoder(q->off))) return rc;
+    if (q->prob->is_ief) return LIDF_ERR_UNSUPPORTED;  // prob_dec is an IMNet (pipeline.py:82)
+    hipStream_t st = (hipStream_t)stream;
+    const int L = q->multires, Lv = q->multires_views;
+    const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
+    const int D = 256 + 2 * E + Ed;
+
+    if (R == 0) return LIDF_OK;  // nothing to write (pipeline.py:686-687 early exit)
+    if (!q->ray_dir || !q->ray_pix || !q->ray_bid || !q->pair_off) return LIDF_ERR_BAD_ARG;
+    if (q->depth && !q->ray_flat) return LIDF_ERR_BAD_ARG;
+    if (P > 0) {
+        if (V == 0) return LIDF_ERR_BAD_ARG;
+        if (!q->pair_ray || !q->pair_vox || !q->pair_t || !q->feat_grid || !q->vox_feat ||
+            !q->pred_offset || !q->pred_prob || !q->pair_pred_pos)
+            return LIDF_ERR_BAD_ARG;
+        if (q->pos_rel && !q->vox_center) return LIDF_ERR_BAD_ARG;
+        if (q->batch <= 0 || q->height <= 0 || q->width <= 0) return LIDF_ERR_BAD_ARG;
+        QueryWs w = query_ws(R, V, L, Lv);
+        if (!q->workspace || q->workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+        char* ws = (char*)q->workspace;
+        float* stream_pts = (float*)(ws + w.stream_pts);
+        float* aux_pts = (float*)(ws + w.aux_pts);
+        float* stream_vox = (float*)(ws + w.stream_vox);
+        float* stream_ray = (float*)(ws + w.stream_ray);
+        float* voxpart = (float*)(ws + w.voxpart);
+        float* raypart = (float*)(ws + w.raypart);
+        float* rayfeat = (float*)(ws + w.rayfeat);
+        int cus;
+        if ((rc = cu_count(&cus))) return rc;
+
+        NetW np = to_netw(q->prob, D), no = to_netw(q->off, D);
+
+        // 1. weight streams
+        L1Map mf = {};
+        mf.L = L;
+        mf.enter_c0 = 256;
+        mf.leave_c0 = 256 + E;
+        StreamLayout lf = lidf_make_layout(2, LIDF_MODE_FUSED, mf);
+        CHECK_HIP(lidf_launch_pack(lf, np, no, mf, stream_pts, aux_pts, st));
+        L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
+        StreamLayout lv = lidf_make_layout(2, LIDF_MODE_L1ONLY, mv);
+        CHECK_HIP(lidf_launch_pack(lv, np, no, mv, stream_vox, aux_pts, st));
+        L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
+        StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
+        CHECK_HIP(lidf_launch_pack(lr, np, no, mr, stream_ray, aux_pts, st));
+
+        // 2. per-voxel partial  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c)
+        {
+            PointsArgs a = {};
+            a.stream = stream_vox; a.aux = aux_pts;
+            a.nets = 2; a.l1_floats = lv.l1_floats; a.net_floats = lv.net_floats;
+            a.n = V; a.X = q->vox_feat; a.ldx = 128;
+            a.D = mv.D; a.KH = mv.KH; a.KQ1 = mv.KQ1; a.has_bias = 1;
+            a.out_base = voxpart;
+            long long nt = (V + 127) / 128;
+            CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
+        }
+        // 3. per-ray features and partial  raypart[r] = W1[:, rgb|dir] rayfeat[r]
+        CHECK_HIP(lidf_launch_rayfeat(q->feat_grid, q->batch, q->height, q->width, q->ray_dir,
+                                      q->ray_pix, q->ray_bid, R, q->roi_inp_bbox / 2, Lv, rayfeat,
+                                      128 + Ed, st));
+        {
+            PointsArgs a = {};
+            a.stream = stream_ray; a.aux = aux_pts;
+            a.nets = 2; a.l1_floats = lr.l1_floats; a.net_floats = lr.net_floats;
+            a.n = R; a.X = rayfeat; a.ldx = 128 + Ed;
+            a.D = mr.D; a.KH = mr.KH; a.KQ1 = mr.KQ1; a.has_bias = 0;
+            a.out_base = raypart;
+            long long nt = (R + 127) / 128;
+            CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
+        }
+        // 4. per-point kernel
+        {
+            PointsArgs a = {};
+            a.stream = stream_pts; a.aux = aux_pts;
+            a.nets = 2; a.l1_floats = lf.l1_floats; a.net_floats = lf.net_floats;
+            a.n = P;
+            fill_net_args(a, 0, q->prob, q->pred_prob, 0);
+            fill_net_args(a, 1, q->off, q->pred_offset, 1);
+            a.pair_ray = q->pair_ray; a.pair_vox = q->pair_vox; a.pair_t = q->pair_t;
+            a.ray_dir = q->ray_dir; a.voxpart = voxpart; a.raypart = raypart;
+            a.vox_center = q->vox_center; a.pos_rel = q->pos_rel; a.L = L;
+            a.r0 = q->offset_range0;
+            a.rscale = q->offset_range1 - q->offset_range0;
+            a.sqrt3 = (float)1.7320508075688772;  // np.sqrt(3) rounded to f32 (pipeline.py:438)
+            a.part_size = q->part_size;
+            a.pair_pred_pos = q->pair_pred_pos;
+            long long nt = (P + 127) / 128;
+            CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
+        }
+    }
+    // 5. per-ray softmax / argmax / select / depth
+    if (q->pred_prob_softmax || q->max_pair_id || q->pred_pos || q->depth) {
+        CHECK_HIP(lidf_launch_ray_reduce(q->pred_prob, q->pair_pred_pos, q->pair_off, R, P,
+                                         q->ray_bid, q->ray_flat,
+                                         (long long)q->height * q->width, q->pred_prob_softmax,
+                                         (long long*)q->max_pair_id, q->pred_pos, q->depth, st));
+    }
+    return LIDF_OK;
+}
+
+// ---- rays, boxes, scan ---------------------------------------------------------------------------
+LIDF_API int lidf_ray_dirs_f32(const float* intr, int batch, int height, int width,
+                                 float* ray_dir, lidf_stream_t stream) {
+    if (batch < 0 || height < 0 || width < 0) return LIDF_ERR_BAD_ARG;
+    if ((long long)batch * height * width == 0) return LIDF_OK;
+    if (!intr || !ray_dir) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_ray_dirs(intr, batch, height, width, ray_dir, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+static int check_box_args(const void* a, const void* b, const void* c, const void* d, int64_t n,
+                          int64_t v) {
+    if (n < 0 || v < 0) return LIDF_ERR_BAD_ARG;
+    if (n > 0x7fffffffLL || v > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n > 0 && (!a || !c)) return LIDF_ERR_BAD_ARG;
+    if (v > 0 && (!b || !d)) return LIDF_ERR_BAD_ARG;
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_aabb_dense_f32(const float* ray_dir, const float* voxel_bound,
+                                       const int32_t* ray_bid, const int32_t* voxel_bid,
+                                       int64_t n_rays, int64_t n_vox, int32_t* mask, float* dist,
+                                       lidf_stream_t stream) {
+    int rc = check_box_args(ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays, n_vox);
+    if (rc) return rc;
+    if (n_rays == 0 || n_vox == 0) return LIDF_OK;
+    if (!mask || !dist) return LIDF_ERR_BAD_ARG;
+    if (n_vox > 65535) return LIDF_ERR_UNSUPPORTED;  // grid.y limit, as in the reference launch
+    CHECK_HIP(lidf_launch_ray_aabb_dense(ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays, n_vox,
+                                         mask, dist, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_aabb_count_f32(const float* ray_dir, const float* voxel_bound,
+                                       const int32_t* ray_bid, const int32_t* voxel_bid,
+                                       int64_t n_rays, int64_t n_vox, int32_t* count,
+                                       lidf_stream_t stream) {
+    int rc = check_box_args(ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays, n_vox);
+    if (rc) return rc;
+    if (n_rays == 0) return LIDF_OK;
+    if (!count) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_ray_aabb_compact(false, ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays,
+                                           n_vox, count, nullptr, nullptr, nullptr, nullptr,
+                                           (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_aabb_fill_f32(const float* ray_dir, const float* voxel_bound,
+                                      const int32_t* ray_bid, const int32_t* voxel_bid,
+                                      int64_t n_rays, int64_t n_vox, const int32_t* pair_off,
+                                      int32_t* pair_ray, int32_t* pair_vox, float* pair_t,
+                                      lidf_stream_t stream) {
+    int rc = check_box_args(ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays, n_vox);
+    if (rc) return rc;
+    if (n_rays == 0 || n_vox == 0) return LIDF_OK;
+    if (!pair_off) return LIDF_ERR_BAD_ARG;
+    // pair_ray/pair_vox/pair_t may be NULL only when there is no pair; not knowable here
+    CHECK_HIP(lidf_launch_ray_aabb_compact(true, ray_dir, voxel_bound, ray_bid, voxel_bid, n_rays,
+                                           n_vox, nullptr, pair_off, pair_ray, pair_vox, pair_t,
+                                           (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API size_t lidf_exclusive_scan_workspace_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    return align_up((size_t)((n + 1023) / 1024 + 1) * 4, 256);
+}
+
+LIDF_API int lidf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* workspace,
+                                       size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || !out) return LIDF_ERR_BAD_ARG;
+    if (n > 0x7ffffffeLL) return LIDF_ERR_UNSUPPORTED;
+    if (n > 0 && !in) return LIDF_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < lidf_exclusive_scan_workspace_bytes(n))
+        return LIDF_ERR_WORKSPACE;
+    CHECK_HIP(lidf_launch_scan(in, n, out, (int*)workspace, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_pcl_aabb_dense_f32(const float* pcl_pos, const float* voxel_bound,
+                                       const int32_t* pcl_bid, const int32_t* voxel_bid,
+                                       int64_t n_pts, int64_t n_vox, int32_t* mask,
+                                       lidf_stream_t stream) {
+    int rc = check_box_args(pcl_pos, voxel_bound, pcl_bid, voxel_bid, n_pts, n_vox);
+    if (rc) return rc;
+    if (n_pts == 0 || n_vox == 0) return LIDF_OK;
+    if (!mask) return LIDF_ERR_BAD_ARG;
+    if (n_vox > 65535) return LIDF_ERR_UNSUPPORTED;
+    CHECK_HIP(lidf_launch_pcl_aabb_dense(pcl_pos, voxel_bound, pcl_bid, voxel_bid, n_pts, n_vox,
+                                         mask, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_pcl_aabb_last_f32(const float* pcl_pos, const float* voxel_bound,
+                                      const int32_t* pcl_bid, const int32_t* voxel_bid,
+                                      int64_t n_pts, int64_t n_vox, int32_t* last_vox,
+                                      lidf_stream_t stream) {
+    int rc = check_box_args(pcl_pos, voxel_bound, pcl_bid, voxel_bid, n_pts, n_vox);
+    if (rc) return rc;
+    if (n_pts == 0) return LIDF_OK;
+    if (!last_vox) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_pcl_aabb_last(pcl_pos, voxel_bound, pcl_bid, voxel_bid, n_pts, n_vox,
+                                        last_vox, (hipStream_t)stream));
+    return LIDF_OK;
+}

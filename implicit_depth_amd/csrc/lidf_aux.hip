@@ -1,0 +1,520 @@
+// lidf_aux.hip — the small kernels around the per-point decoder kernel (gfx950 / CDNA4):
+// positional encoding, per-ray ROIAlign + direction embedding, per-ray softmax/argmax/select,
+// ray generation, ray/voxel and point/voxel box tests, exclusive scan.
+// Built with -ffp-contract=off: these restate f32 arithmetic of the reference op by op.
+#include "lidf_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// Positional encoding — Embedder.embed (models/implicit_net.py:38-39), one thread per output float.
+// out[i, :] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], each block 3 wide.
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_embed_kernel(const float* __restrict__ x, long long n, int L,
+                                  float* __restrict__ out) {
+    const int E = 3 + 6 * L;
+    const long long total = n * E;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long row = e / E;
+        const int j = (int)(e % E);
+        float v;
+        if (j < 3) {
+            v = x[3 * row + j];
+        } else {
+            const int o = (j - 3) / 6, r = (j - 3) % 6;
+            const float arg = x[3 * row + (r % 3)] * (float)(1 << o);  // exact: power of two
+            v = r < 3 ? sinf(arg) : cosf(arg);
+        }
+        out[e] = v;
+    }
+}
+
+extern "C" hipError_t lidf_launch_embed(const float* x, long long n, int L, float* out,
+                                        hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long long total = n * (3 + 6 * L);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(lidf_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, L, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-ray features: ROIAlign(output 2x2, spatial_scale 1, sampling_ratio -1, aligned=True) of the
+// box built at models/pipeline.py:374-383 (pixel +- roi_inp_bbox//2, corners clamped on integers),
+// restating torchvision 0.7.0 roi_align (source not in the reference tree; parity unpinned), plus
+// embed(dir). blockDim = (64 rays, 4 channel groups of 8 channels).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bilinear(const float* __restrict__ img, int H, int W, float y,
+                                          float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) {
+        y_high = y_low = H - 1;
+        y = (float)y_low;
+    } else {
+        y_high = y_low + 1;
+    }
+    if (x_low >= W - 1) {
+        x_high = x_low = W - 1;
+        x = (float)x_low;
+    } else {
+        x_high = x_low + 1;
+    }
+    const float ly = y - (float)y_low, lx = x - (float)x_low;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float v1 = img[y_low * W + x_low], v2 = img[y_low * W + x_high];
+    const float v3 = img[y_high * W + x_low], v4 = img[y_high * W + x_high];
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+__global__ void lidf_rayfeat_kernel(const float* __restrict__ feat, int B, int H, int W,
+                                    const float* __restrict__ ray_dir,
+                                    const int* __restrict__ ray_pix,
+                                    const int* __restrict__ ray_bid, long long R, int half,
+                                    int Lv, float* __restrict__ out, int ld) {
+    const long long r = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int cg = threadIdx.y;
+    if (r >= R) return;
+    const int px = ray_pix[2 * r], py = ray_pix[2 * r + 1], b = ray_bid[r];
+    const int x1 = min(max(px - half, 0), W - 1), x2 = min(max(px + half, 0), W - 1);
+    const int y1 = min(max(py - half, 0), H - 1), y2 = min(max(py + half, 0), H - 1);
+    const float rsw = (float)x1 - 0.5f, rsh = (float)y1 - 0.5f;
+    const float rew = (float)x2 - 0.5f, reh = (float)y2 - 0.5f;
+    const float roi_w = rew - rsw, roi_h = reh - rsh;
+    const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+    const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+    const float count = (float)max(gh * gw, 1);
+    float* o = out + (size_t)r * ld;
+    for (int c = cg * 8; c < cg * 8 + 8; ++c) {
+        const float* img = feat + ((size_t)b * 32 + c) * H * W;
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int pw = 0; pw < 2; ++pw) {
+                float acc = 0.f;
+                for (int iy = 0; iy < gh; ++iy) {
+                    const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const float x =
+                            rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                        acc += bilinear(img, H, W, y, x);
+                    }
+                }
+                o[c * 4 + ph * 2 + pw] = acc / count;
+            }
+        }
+    }
+    if (cg == 0) {
+        const float d[3] = {ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]};
+        float* e = o + 128;
+        for (int i = 0; i < 3; ++i) e[i] = d[i];
+        for (int l = 0; l < Lv; ++l) {
+            const float f = (float)(1 << l);
+            for (int i = 0; i < 3; ++i) {
+                e[3 + 6 * l + i] = sinf(d[i] * f);
+                e[3 + 6 * l + 3 + i] = cosf(d[i] * f);
+            }
+        }
+    }
+}
+
+extern "C" hipError_t lidf_launch_rayfeat(const float* feat, int B, int H, int W,
+                                          const float* ray_dir, const int* ray_pix,
+                                          const int* ray_bid, long long R, int half, int Lv,
+                                          float* out, int ld, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4), 0, st,
+                       feat, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-ray softmax / argmax / select — scatter_softmax + scatter_max + dummy-row gather
+// (models/pipeline.py:442-454) on ray-major CSR pairs: one wavefront per ray, wave-level
+// shuffles for max, sum and arg-max. Ties: lowest pair index. Empty ray: id = P, pos = 0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+__global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
+                                       const float* __restrict__ pos,
+                                       const int* __restrict__ off, long long R, long long P,
+                                       const int* __restrict__ ray_bid,
+                                       const int* __restrict__ ray_flat, long long hw,
+                                       float* __restrict__ softmax, long long* __restrict__ maxid,
+                                       float* __restrict__ pred_pos, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int beg = off[ray], end = off[ray + 1];
+    float m = -INFINITY;
+    for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, prob[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = beg + lane; i < end; i += 64) s += expf(prob[i] - m);
+    s = wave_sum(s);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = beg + lane; i < end; i += 64) {
+        const float v = expf(prob[i] - m) / s;
+        if (softmax) softmax[i] = v;
+        if (v > bv) {  // ascending i per lane: strict > keeps the first on ties
+            bv = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const float ov = __shfl_xor(bv, sh);
+        const int oi = __shfl_xor(bi, sh);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        const bool empty = end <= beg;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (!empty && pos) {
+            x = pos[3 * (size_t)bi];
+            y = pos[3 * (size_t)bi + 1];
+            z = pos[3 * (size_t)bi + 2];
+        }
+        if (maxid) maxid[ray] = empty ? P : (long long)bi;
+        if (pred_pos) {
+            pred_pos[3 * ray] = x;
+            pred_pos[3 * ray + 1] = y;
+            pred_pos[3 * ray + 2] = z;
+        }
+        if (depth) depth[(size_t)ray_bid[ray] * hw + ray_flat[ray]] = z;
+    }
+}
+
+extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos, const int* off,
+                                             long long R, long long P, const int* ray_bid,
+                                             const int* ray_flat, long long hw, float* softmax,
+                                             long long* maxid, float* pred_pos, float* depth,
+                                             hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_ray_reduce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st,
+                       prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos,
+                       depth);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray directions — models/pipeline.py:215-219.
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_ray_dirs_kernel(const float* __restrict__ intr, int B, int H, int W,
+                                     float* __restrict__ dir) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W;
+    if (i >= total) return;
+    const int b = (int)(i / ((long long)H * W));
+    const int rem = (int)(i % ((long long)H * W));
+    const int y = rem / W, x = rem % W;
+    const float fx = intr[4 * b], fy = intr[4 * b + 1], cx = intr[4 * b + 2], cy = intr[4 * b + 3];
+    const float vx = (float)x - cx;
+    const float vy = ((float)y - cy) * fx / fy;
+    const float vz = fx;
+    const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+    dir[3 * i] = vx / nrm;
+    dir[3 * i + 1] = vy / nrm;
+    dir[3 * i + 2] = vz / nrm;
+}
+
+extern "C" hipError_t lidf_launch_ray_dirs(const float* intr, int B, int H, int W, float* dir,
+                                           hipStream_t st) {
+    long long total = (long long)B * H * W;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_ray_dirs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       st, intr, B, H, W, dir);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray / voxel slab test — extensions/ray_aabb/ray_aabb_cuda_kernel.cu:24-88, same arithmetic:
+// origin 0, inv = 1/(d + 1e-12) evaluated in double then rounded to float, near/far bound by the
+// sign of inv, no t >= 0 test.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool slab_test(float dx, float dy, float dz, const float* vb,
+                                          float& t_enter, float& t_leave) {
+    const float ix = (float)(1 / ((double)dx + 1e-12));
+    const float iy = (float)(1 / ((double)dy + 1e-12));
+    const float iz = (float)(1 / ((double)dz + 1e-12));
+    float tmin_max = (ix >= 0 ? vb[0] : vb[3]) * ix;
+    float tmax_min = (ix >= 0 ? vb[3] : vb[0]) * ix;
+    const float tymin = (iy >= 0 ? vb[1] : vb[4]) * iy;
+    const float tymax = (iy >= 0 ? vb[4] : vb[1]) * iy;
+    if ((tmin_max > tymax) || (tmax_min < tymin)) return false;
+    tmin_max = fmaxf(tmin_max, tymin);
+    tmax_min = fminf(tmax_min, tymax);
+    const float tzmin = (iz >= 0 ? vb[2] : vb[5]) * iz;
+    const float tzmax = (iz >= 0 ? vb[5] : vb[2]) * iz;
+    if ((tmin_max > tzmax) || (tmax_min < tzmin)) return false;
+    t_enter = fmaxf(tmin_max, tzmin);
+    t_leave = fminf(tmax_min, tzmax);
+    return true;
+}
+
+// dense form: mask [V,R], dist [V,R,2]; grid (ceil(R/256), V) like the reference's (R/1024, V)
+__global__ void lidf_ray_aabb_dense_kernel(const float* __restrict__ ray_dir,
+                                           const float* __restrict__ vbound,
+                                           const int* __restrict__ ray_bid,
+                                           const int* __restrict__ vox_bid, long long R,
+                                           int* __restrict__ mask, float* __restrict__ dist) {
+    const long long v = blockIdx.y;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    if (ray_bid[r] != vox_bid[v]) return;
+    float vb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vb[i] = vbound[6 * v + i];
+    float t0, t1;
+    if (!slab_test(ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2], vb, t0, t1)) return;
+    mask[v * R + r] = 1;
+    *(f32x2*)(dist + (v * R + r) * 2) = f32x2{t0, t1};
+}
+
+extern "C" hipError_t lidf_launch_ray_aabb_dense(const float* ray_dir, const float* vbound,
+                                                 const int* ray_bid, const int* vox_bid,
+                                                 long long R, long long V, int* mask, float* dist,
+                                                 hipStream_t st) {
+    if (R <= 0 || V <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_ray_aabb_dense_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)V),
+                       dim3(256), 0, st, ray_dir, vbound, ray_bid, vox_bid, R, mask, dist);
+    return hipGetLastError();
+}
+
+// compact ray-major form: one thread per ray walks every voxel (bounds staged through LDS in
+// chunks of 256 voxels); FILL = false counts hits, FILL = true writes them at pair_off[ray]...
+// in ascending voxel order.
+template <bool FILL>
+__global__ void lidf_ray_aabb_compact_kernel(const float* __restrict__ ray_dir,
+                                             const float* __restrict__ vbound,
+                                             const int* __restrict__ ray_bid,
+                                             const int* __restrict__ vox_bid, long long R,
+                                             long long V, int* __restrict__ count,
+                                             const int* __restrict__ pair_off,
+                                             int* __restrict__ pair_ray,
+                                             int* __restrict__ pair_vox,
+                                             float* __restrict__ pair_t) {
+    __shared__ float s_vb[256 * 6];
+    __shared__ int s_bid[256];
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < R;
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    int bid = -1;
+    if (live) {
+        dx = ray_dir[3 * r];
+        dy = ray_dir[3 * r + 1];
+        dz = ray_dir[3 * r + 2];
+        bid = ray_bid[r];
+    }
+    int n = 0;
+    const int base = (FILL && live) ? pair_off[r] : 0;
+    for (long long v0 = 0; v0 < V; v0 += 256) {
+        const int nv = (int)min((long long)256, V - v0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * 6; i += blockDim.x) s_vb[i] = vbound[6 * v0 + i];
+        for (int i = threadIdx.x; i < nv; i += blockDim.x) s_bid[i] = vox_bid[v0 + i];
+        __syncthreads();
+        if (!live) continue;
+        for (int j = 0; j < nv; ++j) {
+            if (s_bid[j] != bid) continue;
+            float t0, t1;
+            if (!slab_test(dx, dy, dz, s_vb + 6 * j, t0, t1)) continue;
+            if (FILL) {
+                const size_t p = (size_t)base + n;
+                pair_ray[p] = (int)r;
+                pair_vox[p] = (int)(v0 + j);
+                *(f32x2*)(pair_t + 2 * p) = f32x2{t0, t1};
+            }
+            ++n;
+        }
+    }
+    if (!FILL && live) count[r] = n;
+}
+
+extern "C" hipError_t lidf_launch_ray_aabb_compact(bool fill, const float* ray_dir,
+                                                   const float* vbound, const int* ray_bid,
+                                                   const int* vox_bid, long long R, long long V,
+                                                   int* count, const int* pair_off, int* pair_ray,
+                                                   int* pair_vox, float* pair_t, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    dim3 grid((unsigned)((R + 255) / 256)), block(256);
+    if (fill)
+        hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<true>, grid, block, 0, st, ray_dir, vbound,
+                           ray_bid, vox_bid, R, V, count, pair_off, pair_ray, pair_vox, pair_t);
+    else
+        hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<false>, grid, block, 0, st, ray_dir,
+                           vbound, ray_bid, vox_bid, R, V, count, pair_off, pair_ray, pair_vox,
+                           pair_t);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point / voxel inside test — extensions/pcl_aabb/pcl_aabb_cuda_kernel.cu:23-44 (inclusive bounds).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inside_test(float x, float y, float z, const float* vb) {
+    if ((x < vb[0]) || (x > vb[3])) return false;
+    if ((y < vb[1]) || (y > vb[4])) return false;
+    if ((z < vb[2]) || (z > vb[5])) return false;
+    return true;
+}
+
+__global__ void lidf_pcl_aabb_dense_kernel(const float* __restrict__ pos,
+                                           const float* __restrict__ vbound,
+                                           const int* __restrict__ pcl_bid,
+                                           const int* __restrict__ vox_bid, long long N,
+                                           int* __restrict__ mask) {
+    const long long v = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (pcl_bid[i] != vox_bid[v]) return;
+    float vb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vb[k] = vbound[6 * v + k];
+    if (inside_test(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], vb)) mask[v * N + i] = 1;
+}
+
+extern "C" hipError_t lidf_launch_pcl_aabb_dense(const float* pos, const float* vbound,
+                                                 const int* pcl_bid, const int* vox_bid,
+                                                 long long N, long long V, int* mask,
+                                                 hipStream_t st) {
+    if (N <= 0 || V <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_pcl_aabb_dense_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)V),
+                       dim3(256), 0, st, pos, vbound, pcl_bid, vox_bid, N, mask);
+    return hipGetLastError();
+}
+
+__global__ void lidf_pcl_aabb_last_kernel(const float* __restrict__ pos,
+                                          const float* __restrict__ vbound,
+                                          const int* __restrict__ pcl_bid,
+                                          const int* __restrict__ vox_bid, long long N,
+                                          long long V, int* __restrict__ last) {
+    __shared__ float s_vb[256 * 6];
+    __shared__ int s_bid[256];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int bid = -1, best = -1;
+    if (live) {
+        x = pos[3 * i];
+        y = pos[3 * i + 1];
+        z = pos[3 * i + 2];
+        bid = pcl_bid[i];
+    }
+    for (long long v0 = 0; v0 < V; v0 += 256) {
+        const int nv = (int)min((long long)256, V - v0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nv * 6; k += blockDim.x) s_vb[k] = vbound[6 * v0 + k];
+        for (int k = threadIdx.x; k < nv; k += blockDim.x) s_bid[k] = vox_bid[v0 + k];
+        __syncthreads();
+        if (!live) continue;
+        for (int j = 0; j < nv; ++j)
+            if (s_bid[j] == bid && inside_test(x, y, z, s_vb + 6 * j)) best = (int)(v0 + j);
+    }
+    if (live) last[i] = best;
+}
+
+extern "C" hipError_t lidf_launch_pcl_aabb_last(const float* pos, const float* vbound,
+                                                const int* pcl_bid, const int* vox_bid,
+                                                long long N, long long V, int* last,
+                                                hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_pcl_aabb_last_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                       st, pos, vbound, pcl_bid, vox_bid, N, V, last);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan of int32 counts (pair_off): block sums -> serial scan of sums -> block rescan.
+// ------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 1024  // per block: 256 threads x 4
+
+__device__ __forceinline__ int block_scan_256(int v, int* s_tmp, int& total) {
+    // inclusive scan of one value per thread over 256 threads; returns exclusive prefix
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(inc, s);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int wpre = 0;
+    for (int w = 0; w < wave; ++w) wpre += s_tmp[w];
+    total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    __syncthreads();
+    return wpre + inc - v;
+}
+
+__global__ void lidf_scan_sums_kernel(const int* __restrict__ in, long long n,
+                                      int* __restrict__ sums) {
+    __shared__ int s_tmp[4];
+    const long long b0 = (long long)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    int v = 0;
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < n) v += in[b0 + k];
+    int total;
+    block_scan_256(v, s_tmp, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void lidf_scan_top_kernel(int* __restrict__ sums, long long nb) {
+    // single block: exclusive scan of the block sums, 256 at a time with a running carry
+    __shared__ int s_tmp[4];
+    int carry = 0;
+    for (long long b = 0; b < nb; b += 256) {
+        const long long i = b + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        int total;
+        const int ex = block_scan_256(v, s_tmp, total);
+        if (i < nb) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void lidf_scan_final_kernel(const int* __restrict__ in, long long n,
+                                       const int* __restrict__ sums, int* __restrict__ out) {
+    __shared__ int s_tmp[4];
+    const long long b0 = (long long)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    int x[4], v = 0;
+    for (int k = 0; k < 4; ++k) {
+        x[k] = b0 + k < n ? in[b0 + k] : 0;
+        v += x[k];
+    }
+    int total;
+    int run = sums[blockIdx.x] + block_scan_256(v, s_tmp, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+    for (int k = 0; k < 4; ++k) {
+        run += x[k];
+        if (b0 + k < n) out[b0 + k + 1] = run;
+    }
+}
+
+extern "C" hipError_t lidf_launch_scan(const int* in, long long n, int* out, int* sums,
+                                       hipStream_t st) {
+    if (n <= 0) {
+        hipLaunchKernelGGL(lidf_scan_final_kernel, dim3(1), dim3(256), 0, st, in, (long long)0,
+                           sums, out);
+        return hipGetLastError();
+    }
+    const long long nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(lidf_scan_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums);
+    hipLaunchKernelGGL(lidf_scan_top_kernel, dim3(1), dim3(256), 0, st, sums, nb);
+    hipLaunchKernelGGL(lidf_scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums,
+                       out);
+    return hipGetLastError();
+}

@@ -1,0 +1,114 @@
+// lidf_device.h — shared device-side definitions for liblidf_hip (gfx950 only).
+//
+// Weight-stream format
+// --------------------
+// The decoders run as a chain of v_mfma_f32_32x32x2_f32 instructions computed TRANSPOSED:
+//   D[out feature][point] += A[out feature][k] * B[k][point]
+// so that the accumulator registers of layer l are, without any data movement, the B operands of
+// layer l+1 (lane l holds column `l&31` = one point; register r of a 32x32 tile holds feature row
+// (r&3) + 8*(r>>2) + 4*(l>>5)).  The k order of every layer is therefore dictated by the register
+// layout, and the nn.Linear weights are re-packed on the device, every call, into a "stream" of A
+// fragments in exactly the order the kernel consumes them:
+//   fragment = 64 floats, lane l holds W[32*tile + (l&31)][in(kstep, l>>5)]
+//   quad     = 4 consecutive k-steps of one output tile, stored lane-major (float4 per lane)
+//   pair     = 2 consecutive k-steps (float2 per lane), used by the positional-encoding section
+// Biases ride along as one extra k-step whose B operand is 1.0 in lanes 0..31 and 0 in 32..63.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define LIDF_H1 256   // gf_dim*4
+#define LIDF_H2 128   // gf_dim*2
+#define LIDF_H3 64    // gf_dim
+#define LIDF_L2_QUADS 33   // (128 k-steps + 1 bias k-step) / 4, rounded up
+#define LIDF_L3_QUADS 17   // (64 k-steps + 1 bias k-step) / 4, rounded up
+#define LIDF_L2_FLOATS (LIDF_L2_QUADS * 4 * 256)   // 4 output tiles
+#define LIDF_L3_FLOATS (LIDF_L3_QUADS * 2 * 256)   // 2 output tiles
+#define LIDF_SEC_FLOATS (LIDF_L2_FLOATS + LIDF_L3_FLOATS)
+#define LIDF_U_FLOATS 512   // 8 fragments (one per layer-1 tile of the offset net)
+#define LIDF_AUX_FLOATS 72  // per net: w4 by (half, reg) [2][32], b4 at [64]
+
+enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2 };
+
+// One decoder's parameters as the packer sees them.
+struct NetW {
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *wenc, *benc;
+    int ld1;     // row stride of w1 (= d_in)
+    int is_ief;  // w1 has 16 extra columns at [dcore, dcore+16)
+    int dcore;   // D: number of "real" input columns
+};
+
+// How the columns of the layer-1 operand map onto w1 columns.
+struct L1Map {
+    // rows modes: operand column x in [0,n0) -> w1 column c0+x ; x in [n0,n0+n1) -> c1+(x-n0)
+    int n0, c0, n1, c1;
+    int D;         // n0+n1
+    int KH;        // ceil(D/2): lanes 0..31 take columns [0,KH), lanes 32..63 take [KH,D)
+    int KQ1;       // quads per tile = ceil((KH+1)/4)
+    int add_bias;  // bias k-step carries b1 (+ IEF constant) ; else 0
+    // fused mode
+    int L;         // octaves
+    int enter_c0;  // w1 column of enter-position embedding
+    int leave_c0;  // w1 column of leave-position embedding
+};
+
+// Stream = nets consecutive per-net blocks, each [layer-1 (8 tiles) | u (8 fragments) | layer 2 |
+// layer 3] in consumption order. L1ONLY blocks hold the layer-1 section only.
+struct StreamLayout {
+    int nets;       // 1 or 2
+    int mode;       // LIDF_MODE_*
+    int l1_floats;  // per net
+    int net_floats; // per-net block size
+    int total;
+};
+
+static inline int lidf_l1_floats(int mode, const L1Map& m) {
+    if (mode == LIDF_MODE_FUSED) return 8 * 64 * (6 * m.L + 4);
+    return m.KQ1 * 8 * 256;
+}
+
+static inline StreamLayout lidf_make_layout(int nets, int mode, const L1Map& m) {
+    StreamLayout s;
+    s.nets = nets;
+    s.mode = mode;
+    s.l1_floats = lidf_l1_floats(mode, m);
+    s.net_floats = s.l1_floats + (mode == LIDF_MODE_L1ONLY ? 0 : LIDF_U_FLOATS + LIDF_SEC_FLOATS);
+    s.total = nets * s.net_floats;
+    return s;
+}
+
+// Arguments of the per-point kernel (all three modes).
+struct PointsArgs {
+    const float* stream;
+    const float* aux;
+    int nets;           // per-net blocks in the stream
+    int l1_floats, net_floats;
+    long long n;        // points (fused) or rows
+    // per net: passes (n_iter for IEF, 1 for IMNet), initial value (0.001 IEF / 0 IMNet),
+    // output activation, output pointer ([n] or NULL), whether it is the offset net
+    int npass[2];
+    float init[2];
+    int sigmoid[2];
+    float* out[2];
+    int is_offset[2];   // fused: net whose output drives pair_pred_pos
+    // rows modes
+    const float* X;
+    long long ldx;
+    int D, KH, KQ1, has_bias;
+    float* out_base;    // L1ONLY: [n, nets*256]
+    // fused mode
+    const int* pair_ray;
+    const int* pair_vox;
+    const float* pair_t;
+    const float* ray_dir;
+    const float* voxpart;   // [V, nets*256]
+    const float* raypart;   // [R, nets*256]
+    const float* vox_center;
+    int pos_rel, L;
+    float r0, rscale, sqrt3, part_size;
+    float* pair_pred_pos;   // [n,3]
+};

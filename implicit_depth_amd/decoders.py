@@ -1,0 +1,239 @@
+"""decoders.py — host-side mirror of the reference's models/implicit_net.py for the MI355X path.
+
+Same public names, constructor signatures, forward signatures and state-dict keys
+(`linear_{1..4}.{weight,bias}`, `offset_enc.{weight,bias}`) as the reference
+(models/implicit_net.py:42-57 get_embedder, :60-98 IMNet, :100-152 IEF), so checkpoints restore
+with the reference's `restore()` (utils/training_utils.py:27-63) and the modules drop into
+`LIDF.build_model` (models/pipeline.py:69-85).
+
+Execution:
+  * CUDA f32 input, no autograd needed  -> liblidf_hip.so (hand-written gfx950 kernels);
+  * autograd needed (training)          -> composite torch ops on the SAME device (the HIP
+    backward is not written yet; this is the differentiable definition, not a fallback for a
+    missing library);
+  * CPU input                           -> RuntimeError. There is no CPU product path.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------------
+# Positional encoding
+# --------------------------------------------------------------------------------------------
+class Embedder:
+    """Counterpart of the reference Embedder (models/implicit_net.py:9-39) for the one
+    configuration get_embedder builds: include_input, log-sampled 2^0..2^(L-1), [sin, cos]."""
+
+    def __init__(self, multires, input_dims=3):
+        if input_dims != 3:
+            raise ValueError("lidf_hip embedder supports input_dims == 3")
+        self.multires = int(multires)
+        self.out_dim = 3 + 6 * self.multires
+
+    def embed(self, inputs):
+        if not inputs.is_cuda:
+            raise RuntimeError("embed: inputs must be a CUDA tensor (no CPU path)")
+        if torch.is_grad_enabled() and inputs.requires_grad:
+            return self.embed_composite(inputs)
+        x = inputs.detach()
+        if x.dtype != torch.float32:
+            raise RuntimeError("embed: float32 required")
+        lead = x.shape[:-1]
+        if x.shape[-1] != 3:
+            raise RuntimeError("embed: last dim must be 3")
+        x2 = x.reshape(-1, 3).contiguous()
+        out = torch.empty((x2.shape[0], self.out_dim), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_embed_f32(_lib.ptr(x2), x2.shape[0], self.multires,
+                                                 _lib.ptr(out), _lib.current_stream(x.device)))
+        return out.reshape(*lead, self.out_dim)
+
+    def embed_composite(self, inputs):
+        """Differentiable definition in torch ops (same formula, same order)."""
+        outs = [inputs]
+        for o in range(self.multires):
+            f = float(2 ** o)
+            outs.append(torch.sin(inputs * f))
+            outs.append(torch.cos(inputs * f))
+        return torch.cat(outs, -1)
+
+
+def get_embedder(multires, i=0):
+    """models/implicit_net.py:42-57 — returns (embed_fn, out_dim)."""
+    if i == -1:
+        return nn.Identity(), 3
+    embedder_obj = Embedder(multires)
+    embed = lambda x, eo=embedder_obj: eo.embed(x)  # noqa: E731
+    return embed, embedder_obj.out_dim
+
+
+# --------------------------------------------------------------------------------------------
+# Decoders
+# --------------------------------------------------------------------------------------------
+def _leaky_clamp(y):
+    return torch.max(torch.min(y, y * 0.01 + 0.99), y * 0.01)
+
+
+def _decoder_struct(mod, keep):
+    """Fill a LidfDecoder from a module's parameters; `keep` collects the contiguous tensors
+    whose storage the struct borrows for the duration of the call."""
+    def p(t):
+        t = t.detach()
+        if t.dtype != torch.float32:
+            raise RuntimeError("lidf_hip: float32 parameters required")
+        t = t.contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    d = _lib.LidfDecoder()
+    d.w1, d.b1 = p(mod.linear_1.weight), p(mod.linear_1.bias)
+    d.w2, d.b2 = p(mod.linear_2.weight), p(mod.linear_2.bias)
+    d.w3, d.b3 = p(mod.linear_3.weight), p(mod.linear_3.bias)
+    d.w4, d.b4 = p(mod.linear_4.weight), p(mod.linear_4.bias)
+    is_ief = isinstance(mod, IEF)
+    if is_ief:
+        d.wenc, d.benc = p(mod.offset_enc.weight), p(mod.offset_enc.bias)
+        d.n_iter = int(mod.n_iter)
+        d.init_offset = float(mod.init_offset.reshape(-1)[0].item()) if torch.is_tensor(
+            mod.init_offset) else float(mod.init_offset)
+    else:
+        d.wenc, d.benc = None, None
+        d.n_iter = 1
+        d.init_offset = 0.0
+    d.is_ief = 1 if is_ief else 0
+    d.use_sigmoid = 1 if mod.use_sigmoid else 0
+    return d
+
+
+def _check_supported(mod):
+    if mod.gf_dim != 64 or mod.linear_4.out_features != 1:
+        raise RuntimeError("lidf_hip decoders are built for gf_dim=64, out_dim=1 "
+                           "(every shipped config); got gf_dim=%d out_dim=%d"
+                           % (mod.gf_dim, mod.linear_4.out_features))
+
+
+def decoders_forward(inp_feat, prob_dec=None, offset_dec=None):
+    """Run one or both decoders on a materialised [n, D] input through liblidf_hip
+    (lidf_decoders_f32). Returns (pred_prob or None, pred_offset or None), each [n,1]."""
+    if prob_dec is None and offset_dec is None:
+        raise ValueError("need at least one decoder")
+    if not inp_feat.is_cuda:
+        raise RuntimeError("inp_feat must be a CUDA tensor (no CPU path)")
+    if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2:
+        raise RuntimeError("inp_feat must be float32 [n, D]")
+    x = inp_feat.detach()
+    if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    n, d = x.shape
+    ld = x.stride(0) if n > 1 else d
+    keep = []
+    dp = do = None
+    for m in (prob_dec, offset_dec):
+        if m is not None:
+            _check_supported(m)
+            if m.inp_dim != d:
+                raise RuntimeError("decoder inp_dim %d != input width %d" % (m.inp_dim, d))
+    if prob_dec is not None:
+        dp = _decoder_struct(prob_dec, keep)
+    if offset_dec is not None:
+        do = _decoder_struct(offset_dec, keep)
+    out_p = torch.empty((n, 1), dtype=torch.float32, device=x.device) if dp is not None else None
+    out_o = torch.empty((n, 1), dtype=torch.float32, device=x.device) if do is not None else None
+    L = _lib.lib()
+    wsb = L.lidf_decoders_workspace_bytes(n, d)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.lidf_decoders_f32(
+            _lib.ptr(x), n, d, ld,
+            C.byref(dp) if dp is not None else None, C.byref(do) if do is not None else None,
+            _lib.ptr(out_p), _lib.ptr(out_o), _lib.ptr(ws), wsb, _lib.current_stream(x.device)))
+    return out_p, out_o
+
+
+class _DecoderBase(nn.Module):
+    def _needs_autograd(self, inp_feat):
+        if not torch.is_grad_enabled():
+            return False
+        return inp_feat.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def _trunk(self, x):
+        # linear_1..3 with leaky_relu(0.02), then linear_4 (no activation)
+        for lin in (self.linear_1, self.linear_2, self.linear_3):
+            x = F.leaky_relu(lin(x), negative_slope=0.02)
+        return self.linear_4(x)
+
+
+class IMNet(_DecoderBase):
+    """models/implicit_net.py:60-98 — 4-layer MLP inp_dim -> 4gf -> 2gf -> gf -> out_dim."""
+
+    def __init__(self, inp_dim, out_dim, gf_dim=64, use_sigmoid=False):
+        super(IMNet, self).__init__()
+        self.inp_dim = inp_dim
+        self.gf_dim = gf_dim
+        self.use_sigmoid = use_sigmoid
+        self.linear_1 = nn.Linear(self.inp_dim, self.gf_dim * 4, bias=True)
+        self.linear_2 = nn.Linear(self.gf_dim * 4, self.gf_dim * 2, bias=True)
+        self.linear_3 = nn.Linear(self.gf_dim * 2, self.gf_dim * 1, bias=True)
+        self.linear_4 = nn.Linear(self.gf_dim * 1, out_dim, bias=True)
+        if self.use_sigmoid:
+            self.sigmoid = nn.Sigmoid()
+        # same initialisation as the reference (:72-79)
+        for lin, mean in ((self.linear_1, 0.0), (self.linear_2, 0.0), (self.linear_3, 0.0),
+                          (self.linear_4, 1e-5)):
+            nn.init.normal_(lin.weight, mean=mean, std=0.02)
+            nn.init.constant_(lin.bias, 0)
+
+    def forward(self, inp_feat):
+        if not inp_feat.is_cuda:
+            raise RuntimeError("IMNet.forward: CUDA tensor required (no CPU path)")
+        if self._needs_autograd(inp_feat):
+            return self.forward_composite(inp_feat)
+        return decoders_forward(inp_feat, prob_dec=self)[0]
+
+    def forward_composite(self, inp_feat):
+        """Differentiable definition in torch ops (used only when autograd is required)."""
+        y = self._trunk(inp_feat)
+        return torch.sigmoid(y) if self.use_sigmoid else _leaky_clamp(y)
+
+
+class IEF(_DecoderBase):
+    """models/implicit_net.py:100-152 — iterative error feedback decoder."""
+
+    def __init__(self, device, inp_dim, out_dim, gf_dim=64, n_iter=3, use_sigmoid=False):
+        super(IEF, self).__init__()
+        self.device = device
+        self.init_offset = torch.Tensor([0.001]).float().to(self.device)
+        self.inp_dim = inp_dim
+        self.gf_dim = gf_dim
+        self.n_iter = n_iter
+        self.use_sigmoid = use_sigmoid
+        self.offset_enc = nn.Linear(1, 16, bias=True)
+        self.linear_1 = nn.Linear(self.inp_dim + 16, self.gf_dim * 4, bias=True)
+        self.linear_2 = nn.Linear(self.gf_dim * 4, self.gf_dim * 2, bias=True)
+        self.linear_3 = nn.Linear(self.gf_dim * 2, self.gf_dim * 1, bias=True)
+        self.linear_4 = nn.Linear(self.gf_dim * 1, out_dim, bias=True)
+        if self.use_sigmoid:
+            self.sigmoid = nn.Sigmoid()
+        for lin, mean in ((self.offset_enc, 0.0), (self.linear_1, 0.0), (self.linear_2, 0.0),
+                          (self.linear_3, 0.0), (self.linear_4, 1e-5)):
+            nn.init.normal_(lin.weight, mean=mean, std=0.02)
+            nn.init.constant_(lin.bias, 0)
+
+    def forward(self, inp_feat):
+        if not inp_feat.is_cuda:
+            raise RuntimeError("IEF.forward: CUDA tensor required (no CPU path)")
+        if self._needs_autograd(inp_feat):
+            return self.forward_composite(inp_feat)
+        return decoders_forward(inp_feat, offset_dec=self)[1]
+
+    def forward_composite(self, inp_feat):
+        """Differentiable definition in torch ops (used only when autograd is required)."""
+        off = self.init_offset.to(inp_feat.device).expand(inp_feat.shape[0], -1)
+        for _ in range(self.n_iter):
+            off = off + self._trunk(torch.cat([inp_feat, self.offset_enc(off)], 1))
+        return torch.sigmoid(off) if self.use_sigmoid else _leaky_clamp(off)

@@ -1,0 +1,190 @@
+"""query.py — host-side mirror of the LIDF query methods for the MI355X path.
+
+Reference counterparts (paths relative to /root/reference/src):
+  ray_dirs            <- LIDF.get_miss_ray, dense part         models/pipeline.py:208-220
+  compute_ray_aabb    <- LIDF.compute_ray_aabb                 models/pipeline.py:271-296
+  lidf_query          <- LIDF.get_embedding + LIDF.get_pred    models/pipeline.py:338-466
+                         + depth write-back                     models/pipeline.py:593-596
+Outputs use the reference's data_dict key names. Pairs are kept RAY-MAJOR (CSR over rays, voxels
+ascending inside a ray) instead of the reference's voxel-major nonzero() order; `to_reference_order`
+gives the permutation back for code that needs the reference's order.
+
+All compute is in liblidf_hip.so; torch is used for device memory and the current stream only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .decoders import _check_supported, _decoder_struct
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError("%s must be int32 (got %s)" % (name, t.dtype))
+    return t
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t
+
+
+def ray_dirs(fx, fy, cx, cy, h, w):
+    """Unit ray direction of every pixel: [bs, h*w, 3] (models/pipeline.py:215-220)."""
+    intr = torch.stack((fx.float(), fy.float(), cx.float(), cy.float()), 1).contiguous()
+    _lib.require_cuda(intr, names=["intrinsics"])
+    bs = intr.shape[0]
+    out = torch.empty((bs, h * w, 3), dtype=torch.float32, device=intr.device)
+    with torch.cuda.device(intr.device):
+        _lib.check(_lib.lib().lidf_ray_dirs_f32(_lib.ptr(intr), bs, h, w, _lib.ptr(out),
+                                                _lib.current_stream(intr.device)))
+    return out
+
+
+def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid):
+    """Compact ray-major ray/voxel intersection list (replaces the dense ray_aabb.forward +
+    torch.nonzero of models/pipeline.py:277-285).
+
+    Returns (pair_off [R+1] i32, pair_ray [P] i32, pair_vox [P] i32, pair_t [P,2] f32); inside a
+    ray the voxels ascend, which is the reference's order restricted to that ray.  P == 0 is the
+    reference's "no intersection pair" early exit (pipeline.py:287-289)."""
+    _lib.require_cuda(ray_dir, voxel_bound, ray_bid, voxel_bid,
+                      names=["ray_dir", "voxel_bound", "ray_bid", "voxel_bid"])
+    _f32(ray_dir, "ray_dir"), _f32(voxel_bound, "voxel_bound")
+    _i32(ray_bid, "ray_bid"), _i32(voxel_bid, "voxel_bid")
+    R, V = ray_dir.shape[0], voxel_bound.shape[0]
+    dev = ray_dir.device
+    L = _lib.lib()
+    count = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
+    pair_off = torch.zeros((R + 1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.current_stream(dev)
+        if R > 0:
+            _lib.check(L.lidf_ray_aabb_count_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
+                                                 _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
+                                                 _lib.ptr(count), st))
+            wsb = L.lidf_exclusive_scan_workspace_bytes(R)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            _lib.check(L.lidf_exclusive_scan_i32(_lib.ptr(count), R, _lib.ptr(pair_off),
+                                                 _lib.ptr(ws), wsb, st))
+        P = int(pair_off[-1].item())  # host needs P to size the outputs (as nonzero() does)
+        pair_ray = torch.empty((P,), dtype=torch.int32, device=dev)
+        pair_vox = torch.empty((P,), dtype=torch.int32, device=dev)
+        pair_t = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        if P > 0:
+            _lib.check(L.lidf_ray_aabb_fill_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
+                                                _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
+                                                _lib.ptr(pair_off), _lib.ptr(pair_ray),
+                                                _lib.ptr(pair_vox), _lib.ptr(pair_t), st))
+    return pair_off, pair_ray, pair_vox, pair_t
+
+
+def to_reference_order(pair_ray, pair_vox):
+    """Permutation `perm` such that ray-major arrays indexed by `perm` are in the reference's
+    voxel-major nonzero() order (models/pipeline.py:283)."""
+    key = pair_vox.long() * (int(pair_ray.max().item()) + 1 if pair_ray.numel() else 1) + pair_ray.long()
+    return torch.argsort(key, stable=True)
+
+
+def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
+               vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
+               offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
+               ray_flat=None, depth=None, want_softmax=True, workspace=None):
+    """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
+
+    ray_dir [R,3] f32, ray_pix [R,2] i32 (x,y), ray_bid [R] i32, pair_* ray-major (see
+    compute_ray_aabb), feat_grid [B,32,h,w] f32 (full_rgb_feat), vox_feat [V,128] f32
+    (occ_voxel_feat), prob_dec: IMNet, offset_dec: IEF or IMNet (decoders.py).
+    Returns a dict with the reference's data_dict keys (models/pipeline.py:460-466):
+    pred_offset [P,1], pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
+    max_pair_id [R] i64, pred_pos [R,3]; `depth` [B,h,w] is updated in place if given."""
+    tensors = [ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
+               vox_feat, vox_center, ray_flat, depth]
+    names = ["ray_dir", "ray_pix", "ray_bid", "pair_off", "pair_ray", "pair_vox", "pair_t",
+             "feat_grid", "vox_feat", "vox_center", "ray_flat", "depth"]
+    _lib.require_cuda(*tensors, names=names)
+    for t, n in ((ray_dir, "ray_dir"), (pair_t, "pair_t"), (feat_grid, "feat_grid"),
+                 (vox_feat, "vox_feat")):
+        _f32(t, n)
+    for t, n in ((ray_pix, "ray_pix"), (ray_bid, "ray_bid"), (pair_off, "pair_off"),
+                 (pair_ray, "pair_ray"), (pair_vox, "pair_vox")):
+        _i32(t, n)
+    if feat_grid.dim() != 4 or feat_grid.shape[1] != 32:
+        raise RuntimeError("feat_grid must be [B,32,h,w] (rgb_out=32)")
+    if vox_feat.dim() != 2 or vox_feat.shape[1] != 128:
+        raise RuntimeError("vox_feat must be [V,128] (pnet_out=128)")
+    _check_supported(prob_dec), _check_supported(offset_dec)
+    E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
+    D = 256 + 2 * E + Ed
+    if prob_dec.inp_dim != D or offset_dec.inp_dim != D:
+        raise RuntimeError("decoder inp_dim must be %d for this configuration" % D)
+    dev = ray_dir.device
+    R, P, V = ray_dir.shape[0], pair_ray.shape[0], vox_feat.shape[0]
+    B, _, h, w = feat_grid.shape
+    if pair_off.shape[0] != R + 1:
+        raise RuntimeError("pair_off must have R+1 entries")
+    if depth is not None and ray_flat is None:
+        raise RuntimeError("depth needs ray_flat")
+
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {
+        "pred_offset": torch.empty((P, 1), **f32),
+        "pred_prob_end": torch.empty((P, 1), **f32),
+        "pair_pred_pos": torch.empty((P, 3), **f32),
+        "pred_prob_end_softmax": torch.empty((P,), **f32) if want_softmax else None,
+        "max_pair_id": torch.empty((R,), dtype=torch.int64, device=dev),
+        "pred_pos": torch.empty((R, 3), **f32),
+    }
+    L = _lib.lib()
+    wsb = L.lidf_query_workspace_bytes(R, V)
+    if workspace is None or workspace.numel() < wsb:
+        workspace = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    keep = []
+    dp = _decoder_struct(prob_dec, keep)
+    do = _decoder_struct(offset_dec, keep)
+    q = _lib.LidfQueryArgs()
+    q.n_rays, q.ray_dir, q.ray_pix, q.ray_bid = R, ray_dir.data_ptr(), ray_pix.data_ptr(), ray_bid.data_ptr()
+    q.ray_flat = ray_flat.data_ptr() if ray_flat is not None else None
+    q.n_pairs, q.pair_off = P, pair_off.data_ptr()
+    q.pair_ray, q.pair_vox, q.pair_t = pair_ray.data_ptr(), pair_vox.data_ptr(), pair_t.data_ptr()
+    q.batch, q.height, q.width, q.feat_grid = B, h, w, feat_grid.data_ptr()
+    q.n_vox, q.vox_feat = V, vox_feat.data_ptr()
+    q.vox_center = vox_center.data_ptr() if vox_center is not None else None
+    q.prob, q.off = C.pointer(dp), C.pointer(do)
+    q.multires, q.multires_views, q.roi_inp_bbox = multires, multires_views, roi_inp_bbox
+    q.pos_rel = 1 if pos_rel else 0
+    q.offset_range0, q.offset_range1 = float(offset_range[0]), float(offset_range[1])
+    q.part_size = float(part_size)
+    q.pred_offset = out["pred_offset"].data_ptr()
+    q.pred_prob = out["pred_prob_end"].data_ptr()
+    q.pair_pred_pos = out["pair_pred_pos"].data_ptr()
+    q.pred_prob_softmax = out["pred_prob_end_softmax"].data_ptr() if want_softmax else None
+    q.max_pair_id = out["max_pair_id"].data_ptr()
+    q.pred_pos = out["pred_pos"].data_ptr()
+    q.depth = depth.data_ptr() if depth is not None else None
+    q.workspace, q.workspace_bytes = workspace.data_ptr(), wsb
+    with torch.cuda.device(dev):
+        _lib.check(L.lidf_query_f32(C.byref(q), _lib.current_stream(dev)))
+    out["workspace"] = workspace
+    return out
+
+
+def ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox=8, multires_views=4):
+    """Per-ray [ROIAlign 2x2 of the rgb feature map | embed(dir)] (models/pipeline.py:367-397,
+    :947-969): [R, 128 + 3 + 6*multires_views]."""
+    _lib.require_cuda(feat_grid, ray_dir, ray_pix, ray_bid,
+                      names=["feat_grid", "ray_dir", "ray_pix", "ray_bid"])
+    _f32(feat_grid, "feat_grid"), _f32(ray_dir, "ray_dir")
+    _i32(ray_pix, "ray_pix"), _i32(ray_bid, "ray_bid")
+    B, c, h, w = feat_grid.shape
+    if c != 32:
+        raise RuntimeError("feat_grid must have 32 channels")
+    R = ray_dir.shape[0]
+    out = torch.empty((R, 128 + 3 + 6 * multires_views), dtype=torch.float32, device=ray_dir.device)
+    with torch.cuda.device(ray_dir.device):
+        _lib.check(_lib.lib().lidf_ray_features_f32(
+            _lib.ptr(feat_grid), B, h, w, _lib.ptr(ray_dir), _lib.ptr(ray_pix), _lib.ptr(ray_bid),
+            R, roi_inp_bbox, multires_views, _lib.ptr(out), _lib.current_stream(ray_dir.device)))
+    return out

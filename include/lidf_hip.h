@@ -1,0 +1,196 @@
+/*
+ * lidf_hip.h — C ABI of liblidf_hip.so: the MI355X (gfx950) implementation of the
+ * LIDF per-point implicit-depth query path of NVlabs/implicit_depth.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer borrowed for the call unless marked "host";
+ *   - nothing is allocated, nothing is synchronised: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value 0 = LIDF_OK, negative = lidf_status (see lidf_strerror); never throws;
+ *   - scratch memory comes from the caller: ask lidf_*_workspace_bytes first;
+ *   - re-entrant, no global mutable state (safe for 8 processes x 1 GPU, many streams).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/src).
+ */
+#ifndef LIDF_HIP_H
+#define LIDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lidf_stream_t; /* hipStream_t */
+
+enum lidf_status {
+    LIDF_OK = 0,
+    LIDF_ERR_BAD_ARG = -1,      /* NULL pointer / negative size / inconsistent arguments   */
+    LIDF_ERR_UNSUPPORTED = -2,  /* dimension outside what the kernels are built for        */
+    LIDF_ERR_WORKSPACE = -3,    /* workspace too small                                     */
+    LIDF_ERR_HIP = -4           /* a HIP runtime call failed (launch, attribute query)     */
+};
+
+/* ABI version, bumped on any signature change. */
+int lidf_version(void);
+/* Static string for a status code. */
+const char* lidf_strerror(int status);
+
+/*
+ * One implicit decoder: IMNet (models/implicit_net.py:60-98) or IEF (:100-152).
+ * Weights are nn.Linear storage, row-major [out,in], borrowed (never cached across calls:
+ * parameters change every optimizer step). Hidden widths are fixed to gf_dim=64
+ * (256 -> 128 -> 64 -> 1), the value of every shipped config.
+ */
+typedef struct LidfDecoder {
+    const float* w1; /* [256, d_in]  (IEF: d_in = D + 16; IMNet: d_in = D) */
+    const float* b1; /* [256] */
+    const float* w2; /* [128, 256] */
+    const float* b2; /* [128] */
+    const float* w3; /* [64, 128] */
+    const float* b3; /* [64] */
+    const float* w4; /* [1, 64] */
+    const float* b4; /* [1] */
+    const float* wenc; /* IEF offset_enc.weight [16,1]; NULL for IMNet */
+    const float* benc; /* IEF offset_enc.bias   [16];   NULL for IMNet */
+    int32_t is_ief;    /* 0 = IMNet, 1 = IEF */
+    int32_t n_iter;    /* IEF iterations (implicit_net.py:133); ignored for IMNet */
+    float init_offset; /* IEF.init_offset (implicit_net.py:104) = 0.001 */
+    int32_t use_sigmoid; /* output activation: 0 = leaky clamp (implicit_net.py:96,151), 1 = sigmoid */
+} LidfDecoder;
+
+/* ---- Positional encoding -------------------------------------------------------------
+ * Replaces Embedder.embed / get_embedder(multires)[0] (models/implicit_net.py:9-57):
+ * out[i] = cat(x[i], sin(2^0 x[i]), cos(2^0 x[i]), ..., sin(2^(L-1) x[i]), cos(2^(L-1) x[i])).
+ * x: [n,3] f32, out: [n, 3+6*multires] f32. multires in [0,16].                          */
+int lidf_embed_f32(const float* x, int64_t n, int multires, float* out, lidf_stream_t stream);
+
+/* ---- Decoders on a materialised input --------------------------------------------------
+ * Replaces IMNet.forward / IEF.forward (models/implicit_net.py:81-98, 129-152) and the pair
+ * of calls at models/pipeline.py:434-435 (offset_dec + prob_dec on the same inp_embed).
+ * inp: [n, d] f32 row-major (row stride ld_inp floats). prob/off may each be NULL
+ * (then the matching output is not written). out_*: [n] f32 (= [n,1]).                    */
+size_t lidf_decoders_workspace_bytes(int64_t n, int d);
+int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
+                      const LidfDecoder* prob, const LidfDecoder* off,
+                      float* out_prob, float* out_off,
+                      void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
+/* ---- Fused per-point query -------------------------------------------------------------
+ * Replaces LIDF.get_embedding (positional encoding + ROIAlign gather + voxel feature gather,
+ * models/pipeline.py:338-425) + LIDF.get_pred (decoders, scaling, per-ray softmax / argmax /
+ * select, models/pipeline.py:427-466) + the depth write-back (models/pipeline.py:593-596).
+ * Pairs ("points") are (ray, occupied voxel) intersections.  The per-ray reduction needs the
+ * pairs grouped by ray: pair_off is the CSR row pointer over rays (pairs of ray r are
+ * [pair_off[r], pair_off[r+1]) ), which is what lidf_ray_aabb_compact_* emits.              */
+typedef struct LidfQueryArgs {
+    /* rays (models/pipeline.py:203-269 outputs) */
+    int64_t n_rays;            /* R */
+    const float* ray_dir;      /* [R,3] unit directions (miss_ray_dir)            */
+    const int32_t* ray_pix;    /* [R,2] integer pixel (x,y) (miss_img_ind)        */
+    const int32_t* ray_bid;    /* [R]   image index in the batch (miss_bid)       */
+    const int32_t* ray_flat;   /* [R]   y*w+x (miss_flat_img_id); may be NULL if depth==NULL */
+    /* pairs, ray-major CSR (models/pipeline.py:271-296 outputs, re-ordered)                  */
+    int64_t n_pairs;           /* P */
+    const int32_t* pair_off;   /* [R+1] */
+    const int32_t* pair_ray;   /* [P] ray of each pair  (miss_ray_intersect_idx)  */
+    const int32_t* pair_vox;   /* [P] voxel of each pair (occ_vox_intersect_idx)  */
+    const float* pair_t;       /* [P,2] (t_enter, t_leave) (dist[vox,ray])        */
+    /* feature sources */
+    int32_t batch, height, width; /* feat_grid [B,32,h,w] NCHW (full_rgb_feat)    */
+    const float* feat_grid;
+    int64_t n_vox;             /* V */
+    const float* vox_feat;     /* [V,128] occ_voxel_feat (models/pipeline.py:408) */
+    const float* vox_center;   /* [V,3] voxel centres; only read if pos_rel != 0  */
+    /* model */
+    const LidfDecoder* prob;   /* prob_dec  (IMNet)                               */
+    const LidfDecoder* off;    /* offset_dec (IEF or IMNet)                       */
+    int32_t multires;          /* opt.model.multires (8); 0 = identity (pos_encode False) */
+    int32_t multires_views;    /* opt.model.multires_views (4); 0 = identity      */
+    int32_t roi_inp_bbox;      /* opt.model.roi_inp_bbox (8)                      */
+    int32_t pos_rel;           /* opt.model.intersect_pos_type == 'rel'           */
+    float offset_range0, offset_range1; /* opt.grid.offset_range                  */
+    float part_size;           /* data_dict['part_size'] (0.25)                   */
+    /* outputs (any may be NULL except pred_offset/pred_prob/pair_pred_pos)       */
+    float* pred_offset;        /* [P]   offset_dec output, before scaling         */
+    float* pred_prob;          /* [P]   pred_prob_end                             */
+    float* pair_pred_pos;      /* [P,3]                                           */
+    float* pred_prob_softmax;  /* [P]   pred_prob_end_softmax                     */
+    int64_t* max_pair_id;      /* [R]   argmax pair per ray, P for an empty ray   */
+    float* pred_pos;           /* [R,3] (0,0,0) for an empty ray                  */
+    float* depth;              /* [B,h,w] depth[bid, flat] = pred_pos.z; untouched elsewhere */
+    /* scratch */
+    void* workspace;
+    size_t workspace_bytes;
+} LidfQueryArgs;
+
+size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox);
+int lidf_query_f32(const LidfQueryArgs* args, lidf_stream_t stream);
+
+/* Per-ray ROIAlign feature (torchvision.ops.roi_align, output 2x2, aligned=True, called at
+ * models/pipeline.py:374-387 and :954-967) + direction embedding, exposed on its own because
+ * stage 2 (RefineNet.get_pred_refine) re-uses it. rayfeat: [R, 128 + 3 + 6*multires_views],
+ * row = [c*4 + ph*2 + pw for 32 channels | embed(dir)].                                    */
+int lidf_ray_features_f32(const float* feat_grid, int batch, int height, int width,
+                          const float* ray_dir, const int32_t* ray_pix, const int32_t* ray_bid,
+                          int64_t n_rays, int roi_inp_bbox, int multires_views,
+                          float* rayfeat, lidf_stream_t stream);
+
+/* Per-ray softmax / argmax / select on its own (torch_scatter.scatter_softmax + scatter_max at
+ * models/pipeline.py:442-454). Ties: lowest pair index. Empty ray: id = P, pos = 0.          */
+int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_pos,
+                        const int32_t* pair_off, int64_t n_rays, int64_t n_pairs,
+                        const int32_t* ray_bid, const int32_t* ray_flat, int64_t hw,
+                        float* softmax, int64_t* max_pair_id, float* pred_pos, float* depth,
+                        lidf_stream_t stream);
+
+/* ---- Ray generation ----------------------------------------------------------------------
+ * Replaces the dense part of LIDF.get_miss_ray (models/pipeline.py:208-220):
+ * ray_dir[b,y,x] = normalize(x-cx, (y-cy)*fx/fy, fx). intr: [B,4] = (fx,fy,cx,cy) f32.       */
+int lidf_ray_dirs_f32(const float* intr, int batch, int height, int width, float* ray_dir,
+                      lidf_stream_t stream);
+
+/* ---- Ray / voxel slab test ---------------------------------------------------------------
+ * Dense drop-in for extensions/ray_aabb (ray_aabb_cuda_kernel.cu:10-126): mask [V,R] i32 and
+ * dist [V,R,2] f32 must be zero-filled by the caller (reference: torch::zeros).             */
+int lidf_ray_aabb_dense_f32(const float* ray_dir, const float* voxel_bound,
+                            const int32_t* ray_bid, const int32_t* voxel_bid,
+                            int64_t n_rays, int64_t n_vox, int32_t* mask, float* dist,
+                            lidf_stream_t stream);
+/* Compact ray-major form of the same test: pass 1 writes the hit count per ray, the caller
+ * turns counts into pair_off (exclusive scan, lidf_exclusive_scan_i32), pass 2 fills the
+ * pairs of each ray in ascending voxel order (= the reference's nonzero() order within a ray,
+ * models/pipeline.py:283).                                                                  */
+int lidf_ray_aabb_count_f32(const float* ray_dir, const float* voxel_bound,
+                            const int32_t* ray_bid, const int32_t* voxel_bid,
+                            int64_t n_rays, int64_t n_vox, int32_t* count,
+                            lidf_stream_t stream);
+int lidf_ray_aabb_fill_f32(const float* ray_dir, const float* voxel_bound,
+                           const int32_t* ray_bid, const int32_t* voxel_bid,
+                           int64_t n_rays, int64_t n_vox, const int32_t* pair_off,
+                           int32_t* pair_ray, int32_t* pair_vox, float* pair_t,
+                           lidf_stream_t stream);
+/* out[0]=0, out[i+1]=out[i]+in[i]; out has n+1 entries. Single-launch (n up to 2^31-1).      */
+size_t lidf_exclusive_scan_workspace_bytes(int64_t n);
+int lidf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out,
+                            void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
+/* ---- Point / voxel inside test -------------------------------------------------------------
+ * Dense drop-in for extensions/pcl_aabb (pcl_aabb_cuda_kernel.cu:10-80): mask [V,Np] i32,
+ * zero-filled by the caller.                                                                 */
+int lidf_pcl_aabb_dense_f32(const float* pcl_pos, const float* voxel_bound,
+                            const int32_t* pcl_bid, const int32_t* voxel_bid,
+                            int64_t n_pts, int64_t n_vox, int32_t* mask, lidf_stream_t stream);
+/* Compact form used by stage 2 (models/pipeline.py:939-944): for every point the LARGEST index
+ * of a voxel of the same image that contains it (inclusive bounds), or -1.                  */
+int lidf_pcl_aabb_last_f32(const float* pcl_pos, const float* voxel_bound,
+                           const int32_t* pcl_bid, const int32_t* voxel_bid,
+                           int64_t n_pts, int64_t n_vox, int32_t* last_vox,
+                           lidf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDF_HIP_H */

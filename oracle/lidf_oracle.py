@@ -1,0 +1,434 @@
+"""lidf_oracle.py — CPU restatement of the LIDF per-point query path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the parity oracle and the `cpu_baseline` of bench.py. Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; nothing under
+implicit_depth_amd/ does. It is written with plain torch-CPU / numpy ops of the same kind the
+reference uses (nn.functional.linear, leaky_relu, cat, sin/cos, gathers), in the reference's
+operation order, each function citing the reference lines it follows (paths relative to
+/root/reference/src).
+
+Pinning status:
+  * embed / IMNet / IEF / get_miss_ray / get_embedding / get_pred: PINNED against the reference
+    itself — tests/golden/*.npz are produced by tests/golden/make_golden.py, which imports the
+    reference's models/implicit_net.py and models/pipeline.py in the authoring container.
+  * ray_aabb / pcl_aabb: pinned by source (the two .cu files are in the reference tree; no nvcc
+    here, so they cannot be executed); also restated in C in oracle/aabb_ref.c.
+  * roi_align (torchvision 0.7.0) and torch_scatter: sources are NOT in the reference tree and
+    neither package is installed -> PARITY UNPINNED for those two; restated from their documented
+    semantics and property-tested.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  Embedder / get_embedder — models/implicit_net.py:9-57
+# ----------------------------------------------------------------------------------------------
+def embed(x, multires):
+    """cat[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] (implicit_net.py:17-39;
+    freq_bands = 2**linspace(0, L-1, L) are exact powers of two)."""
+    outs = [x]
+    freqs = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires) if multires > 0 else []
+    for f in freqs:
+        outs.append(torch.sin(x * f))
+        outs.append(torch.cos(x * f))
+    return torch.cat(outs, -1)
+
+
+def embed_dim(multires):
+    return 3 + 6 * multires
+
+
+# ----------------------------------------------------------------------------------------------
+# a2/a3  IMNet / IEF — models/implicit_net.py:81-98, 129-152
+# params: dict with linear_{1..4}.{weight,bias} (+ offset_enc.{weight,bias}) as torch f32 tensors
+# ----------------------------------------------------------------------------------------------
+def _out_act(y, use_sigmoid):
+    if use_sigmoid:
+        return torch.sigmoid(y)
+    return torch.max(torch.min(y, y * 0.01 + 0.99), y * 0.01)  # implicit_net.py:96
+
+
+def _mlp4(p, x):
+    l1 = F.leaky_relu(F.linear(x, p["linear_1.weight"], p["linear_1.bias"]), 0.02)
+    l2 = F.leaky_relu(F.linear(l1, p["linear_2.weight"], p["linear_2.bias"]), 0.02)
+    l3 = F.leaky_relu(F.linear(l2, p["linear_3.weight"], p["linear_3.bias"]), 0.02)
+    return F.linear(l3, p["linear_4.weight"], p["linear_4.bias"])
+
+
+def imnet_forward(p, x, use_sigmoid=False):
+    return _out_act(_mlp4(p, x), use_sigmoid)
+
+
+def ief_forward(p, x, n_iter, use_sigmoid=False, init_offset=0.001):
+    off = torch.full((x.shape[0], 1), init_offset, dtype=torch.float32)  # implicit_net.py:104,132
+    for _ in range(n_iter):
+        feat = F.linear(off, p["offset_enc.weight"], p["offset_enc.bias"])
+        off = off + _mlp4(p, torch.cat([x, feat], 1))
+    return _out_act(off, use_sigmoid)
+
+
+def decoder_forward(p, x, kind, n_iter=2, use_sigmoid=False):
+    return ief_forward(p, x, n_iter, use_sigmoid) if kind == "IEF" else imnet_forward(p, x, use_sigmoid)
+
+
+def init_decoder(kind, inp_dim, seed, scale=1.0, gf=64):
+    """Reference initialisation (implicit_net.py:72-79 / :118-127): N(0,0.02) weights, zero bias,
+    linear_4.weight mean 1e-5; optionally scaled (SURVEY §8d uses x5) — deterministic from seed."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    dims = [(inp_dim + (16 if kind == "IEF" else 0), 4 * gf), (4 * gf, 2 * gf), (2 * gf, gf), (gf, 1)]
+    if kind == "IEF":
+        p["offset_enc.weight"] = torch.randn(16, 1, generator=g) * 0.02 * scale
+        p["offset_enc.bias"] = torch.zeros(16)
+    for i, (din, dout) in enumerate(dims, 1):
+        w = torch.randn(dout, din, generator=g) * 0.02
+        if i == 4:
+            w = w + 1e-5
+        p["linear_%d.weight" % i] = w * scale
+        p["linear_%d.bias" % i] = torch.zeros(dout)
+    return p
+
+
+def randomize_biases(p, seed, std=0.05):
+    """Tests only: non-zero biases so bias handling is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * std
+    return p
+
+
+# ----------------------------------------------------------------------------------------------
+# a4  LIDF.get_miss_ray (dense part) — models/pipeline.py:208-220
+# ----------------------------------------------------------------------------------------------
+def ray_dirs(fx, fy, cx, cy, h, w):
+    """fx..cy: [bs] f32 tensors. Returns ray_dir [bs,h,w,3] and integer pixel grid [bs,h*w,2]."""
+    bs = fx.shape[0]
+    y_ind, x_ind = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    x_ind = x_ind.unsqueeze(0).repeat(bs, 1, 1).float()
+    y_ind = y_ind.unsqueeze(0).repeat(bs, 1, 1).float()
+    img_ind_flat = torch.stack((x_ind, y_ind), -1).reshape(bs, h * w, 2).long()
+    cam_x = x_ind - cx.reshape(-1, 1, 1)
+    cam_y = (y_ind - cy.reshape(-1, 1, 1)) * fx.reshape(-1, 1, 1) / fy.reshape(-1, 1, 1)
+    cam_z = fx.reshape(-1, 1, 1).repeat(1, h, w)
+    d = torch.stack((cam_x, cam_y, cam_z), -1)
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    return d, img_ind_flat
+
+
+# ----------------------------------------------------------------------------------------------
+# a5  ray_aabb — extensions/ray_aabb/ray_aabb_cuda_kernel.cu:24-88 (numpy, same arithmetic)
+# ----------------------------------------------------------------------------------------------
+def ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid):
+    """Returns mask [V,R] int32 and dist [V,R,2] f32, zero where no hit (cu:105-106)."""
+    d = np.asarray(ray_dir, dtype=np.float32)
+    vb = np.asarray(voxel_bound, dtype=np.float32)
+    rb = np.asarray(ray_bid).astype(np.int64)
+    vbid = np.asarray(voxel_bid).astype(np.int64)
+    R, V = d.shape[0], vb.shape[0]
+    mask = np.zeros((V, R), np.int32)
+    dist = np.zeros((V, R, 2), np.float32)
+    if R == 0 or V == 0:
+        return mask, dist
+    # 1 / (dir + 1e-12): double add and divide, rounded to float (cu:32,48,67)
+    inv = (1.0 / (d.astype(np.float64) + 1e-12)).astype(np.float32)  # [R,3]
+    pos = inv >= 0
+    for v in range(V):
+        lo, hi = vb[v, :3], vb[v, 3:]
+        near = np.where(pos, lo[None, :], hi[None, :]).astype(np.float32)
+        far = np.where(pos, hi[None, :], lo[None, :]).astype(np.float32)
+        tmin = near * inv
+        tmax = far * inv
+        ok = rb == vbid[v]
+        tmin_max = tmin[:, 0].copy()
+        tmax_min = tmax[:, 0].copy()
+        ok &= ~((tmin_max > tmax[:, 1]) | (tmax_min < tmin[:, 1]))
+        tmin_max = np.maximum(tmin_max, tmin[:, 1])
+        tmax_min = np.minimum(tmax_min, tmax[:, 1])
+        ok &= ~((tmin_max > tmax[:, 2]) | (tmax_min < tmin[:, 2]))
+        tmin_max = np.maximum(tmin_max, tmin[:, 2])
+        tmax_min = np.minimum(tmax_min, tmax[:, 2])
+        mask[v, ok] = 1
+        dist[v, ok, 0] = tmin_max[ok]
+        dist[v, ok, 1] = tmax_min[ok]
+    return mask, dist
+
+
+def pcl_aabb(pcl_pos, voxel_bound, pcl_bid, voxel_bid):
+    """extensions/pcl_aabb/pcl_aabb_cuda_kernel.cu:23-44 — inclusive inside test, mask [V,Np]."""
+    p = np.asarray(pcl_pos, dtype=np.float32)
+    vb = np.asarray(voxel_bound, dtype=np.float32)
+    pb = np.asarray(pcl_bid).astype(np.int64)
+    vbid = np.asarray(voxel_bid).astype(np.int64)
+    V, N = vb.shape[0], p.shape[0]
+    mask = np.zeros((V, N), np.int32)
+    for v in range(V):
+        ok = pb == vbid[v]
+        for a in range(3):
+            ok &= ~((p[:, a] < vb[v, a]) | (p[:, a] > vb[v, 3 + a]))
+        mask[v, ok] = 1
+    return mask
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  torchvision.ops.roi_align(output_size=2, spatial_scale=1.0, sampling_ratio=-1, aligned=True)
+# torchvision 0.7.0 (pin: reference README.md:45, Dockerfile:29); source not in the reference tree
+# -> PARITY UNPINNED. Restated from the published algorithm (RoIAlign forward + bilinear_interpolate).
+# ----------------------------------------------------------------------------------------------
+def _bilinear(img, y, x):
+    """img [C,H,W] f32 numpy; y,x python floats (f32 semantics kept with np.float32)."""
+    C, H, W = img.shape
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return np.zeros(C, np.float32)
+    y = np.float32(max(y, 0.0))
+    x = np.float32(max(x, 0.0))
+    y_low, x_low = int(y), int(x)
+    if y_low >= H - 1:
+        y_high = y_low = H - 1
+        y = np.float32(y_low)
+    else:
+        y_high = y_low + 1
+    if x_low >= W - 1:
+        x_high = x_low = W - 1
+        x = np.float32(x_low)
+    else:
+        x_high = x_low + 1
+    ly = np.float32(y - np.float32(y_low))
+    lx = np.float32(x - np.float32(x_low))
+    hy = np.float32(1.0) - ly
+    hx = np.float32(1.0) - lx
+    w1, w2, w3, w4 = hy * hx, hy * lx, ly * hx, ly * lx
+    return (w1 * img[:, y_low, x_low] + w2 * img[:, y_low, x_high]
+            + w3 * img[:, y_high, x_low] + w4 * img[:, y_high, x_high]).astype(np.float32)
+
+
+def roi_align(feat, boxes, output_size=2, spatial_scale=1.0, aligned=True):
+    """feat [B,C,H,W] torch f32; boxes [K,5] (bid,x1,y1,x2,y2) f32. Returns [K,C,out,out]."""
+    f = feat.detach().numpy().astype(np.float32)
+    b = boxes.detach().numpy().astype(np.float32)
+    K = b.shape[0]
+    C = f.shape[1]
+    out = np.zeros((K, C, output_size, output_size), np.float32)
+    offset = np.float32(0.5 if aligned else 0.0)
+    cache = {}
+    for k in range(K):
+        key = tuple(b[k].tolist())
+        if key in cache:
+            out[k] = cache[key]
+            continue
+        bid = int(b[k, 0])
+        rsw = np.float32(b[k, 1] * np.float32(spatial_scale) - offset)
+        rsh = np.float32(b[k, 2] * np.float32(spatial_scale) - offset)
+        rew = np.float32(b[k, 3] * np.float32(spatial_scale) - offset)
+        reh = np.float32(b[k, 4] * np.float32(spatial_scale) - offset)
+        roi_w = np.float32(rew - rsw)
+        roi_h = np.float32(reh - rsh)
+        if not aligned:
+            roi_w = max(roi_w, np.float32(1.0))
+            roi_h = max(roi_h, np.float32(1.0))
+        bin_h = np.float32(roi_h / np.float32(output_size))
+        bin_w = np.float32(roi_w / np.float32(output_size))
+        gh = int(math.ceil(roi_h / output_size))
+        gw = int(math.ceil(roi_w / output_size))
+        count = np.float32(max(gh * gw, 1))
+        for ph in range(output_size):
+            for pw in range(output_size):
+                acc = np.zeros(C, np.float32)
+                for iy in range(gh):
+                    y = np.float32(np.float32(rsh + np.float32(ph) * bin_h)
+                                   + np.float32(np.float32(iy + 0.5) * bin_h) / np.float32(gh))
+                    for ix in range(gw):
+                        x = np.float32(np.float32(rsw + np.float32(pw) * bin_w)
+                                       + np.float32(np.float32(ix + 0.5) * bin_w) / np.float32(gw))
+                        acc = acc + _bilinear(f[bid], y, x)
+                out[k, :, ph, pw] = acc / count
+        cache[key] = out[k].copy()
+    return torch.from_numpy(out)
+
+
+def roi_boxes(img_ind, bid, h, w, roi_inp_bbox=8):
+    """models/pipeline.py:374-383 — pixel +- roi_inp_bbox//2, corners clamped on int64, .float()."""
+    ul = img_ind - roi_inp_bbox // 2
+    br = img_ind + roi_inp_bbox // 2
+    ul = torch.stack((ul[:, 0].clamp(0, w - 1), ul[:, 1].clamp(0, h - 1)), 1)
+    br = torch.stack((br[:, 0].clamp(0, w - 1), br[:, 1].clamp(0, h - 1)), 1)
+    return torch.cat((bid.unsqueeze(-1), ul, br), -1).float()
+
+
+# ----------------------------------------------------------------------------------------------
+# torch_scatter — source not in the reference tree, version unpinned -> PARITY UNPINNED.
+# scatter_softmax: exp(x - segmax) / segsum.  scatter_max: (max, argmax) with empty -> len(src);
+# ties -> lowest index (torch_scatter's CPU loop keeps the first maximum).
+# ----------------------------------------------------------------------------------------------
+def scatter_softmax(src, index, dim_size=None):
+    n = int(index.max()) + 1 if dim_size is None and index.numel() else (dim_size or 0)
+    mx = torch.full((n,), -float("inf"), dtype=src.dtype)
+    mx = mx.scatter_reduce(0, index, src, reduce="amax", include_self=True)
+    e = (src - mx[index]).exp()
+    s = torch.zeros(n, dtype=src.dtype).index_add_(0, index, e)
+    return e / s[index]
+
+
+def scatter_max(src, index, dim_size):
+    out = torch.zeros(dim_size, dtype=src.dtype)
+    arg = torch.full((dim_size,), src.shape[0], dtype=torch.long)
+    s = src.numpy()
+    idx = index.numpy()
+    best = {}
+    for i in range(s.shape[0]):
+        r = int(idx[i])
+        if r not in best or s[i] > best[r][0]:
+            best[r] = (s[i], i)
+    for r, (v, i) in best.items():
+        out[r] = float(v)
+        arg[r] = i
+    return out, arg
+
+
+# ----------------------------------------------------------------------------------------------
+# a5..a10  the query itself on ray-major pairs
+# ----------------------------------------------------------------------------------------------
+def pairs_from_dense(mask, dist):
+    """models/pipeline.py:283-285 then re-ordered ray-major (stable): within a ray, pairs stay in
+    ascending voxel order. Returns pair_ray, pair_vox (int64), pair_t [P,2], pair_off [R+1]."""
+    m = torch.as_tensor(mask).long()
+    idx = torch.nonzero(m, as_tuple=False)  # voxel-major
+    vox, ray = idx[:, 0], idx[:, 1]
+    order = torch.argsort(ray, stable=True)
+    vox, ray = vox[order], ray[order]
+    t = torch.as_tensor(dist)[vox, ray]
+    R = m.shape[1]
+    cnt = torch.bincount(ray, minlength=R)
+    off = torch.zeros(R + 1, dtype=torch.long)
+    off[1:] = torch.cumsum(cnt, 0)
+    return ray, vox, t.float(), off
+
+
+def build_inp_embed(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, feat_grid, vox_feat,
+                    multires, multires_views, roi_inp_bbox=8, vox_center=None, pos_rel=False):
+    """LIDF.get_embedding (models/pipeline.py:343-410) + the concat of get_pred (:431-433).
+    Returns inp_embed [P, D], enter_pos [P,3], dir [P,3]."""
+    h, w = feat_grid.shape[2], feat_grid.shape[3]
+    d = ray_dir[pair_ray]
+    enter = d * pair_t[:, 0:1]
+    leave = d * pair_t[:, 1:2]
+    if pos_rel:
+        c = vox_center[pair_vox]
+        inp_enter, inp_leave = enter - c, leave - c
+    else:
+        inp_enter, inp_leave = enter, leave
+    e_enter = embed(inp_enter, multires)
+    e_leave = embed(inp_leave, multires)
+    e_dir = embed(d, multires_views)
+    # ROIAlign is keyed by the ray's pixel: compute once per ray, gather per pair
+    boxes = roi_boxes(ray_pix.long(), ray_bid.long(), h, w, roi_inp_bbox)
+    ray_rgb = roi_align(feat_grid, boxes).reshape(ray_pix.shape[0], -1)
+    rgb = ray_rgb[pair_ray]
+    vox = vox_feat[pair_vox]
+    inp = torch.cat((vox.contiguous(), rgb.contiguous(), e_enter, e_leave, e_dir), -1)
+    return inp, enter, d
+
+
+def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_grid, vox_feat,
+          prob_p, off_p, off_kind="IEF", n_iter=2, use_sigmoid=False, multires=8, multires_views=4,
+          roi_inp_bbox=8, offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
+          chunk=262144):
+    """get_embedding + get_pred (models/pipeline.py:338-466) + depth z. Pairs are ray-major."""
+    R = ray_dir.shape[0]
+    P = pair_ray.shape[0]
+    boxes = roi_boxes(ray_pix.long(), ray_bid.long(), feat_grid.shape[2], feat_grid.shape[3],
+                      roi_inp_bbox)
+    ray_rgb = roi_align(feat_grid, boxes).reshape(R, -1)
+    e_dir_ray = embed(ray_dir, multires_views)
+    pred_offset = torch.empty(P, 1)
+    pred_prob = torch.empty(P, 1)
+    pair_pred_pos = torch.empty(P, 3)
+    for s in range(0, P, chunk):
+        sl = slice(s, min(P, s + chunk))
+        pr, pv, pt = pair_ray[sl], pair_vox[sl], pair_t[sl]
+        d = ray_dir[pr]
+        enter = d * pt[:, 0:1]
+        leave = d * pt[:, 1:2]
+        if pos_rel:
+            c = vox_center[pv]
+            ie, il = enter - c, leave - c
+        else:
+            ie, il = enter, leave
+        inp = torch.cat((vox_feat[pv], ray_rgb[pr], embed(ie, multires), embed(il, multires),
+                         e_dir_ray[pr]), -1)
+        po = decoder_forward(off_p, inp, off_kind, n_iter, use_sigmoid)
+        pp = imnet_forward(prob_p, inp, use_sigmoid)
+        # pipeline.py:437-439
+        sc = po * (offset_range[1] - offset_range[0]) + offset_range[0]
+        sc = sc * np.sqrt(3) * part_size
+        pred_offset[sl], pred_prob[sl] = po, pp
+        pair_pred_pos[sl] = enter + sc * d
+    if P > 0:
+        sm = scatter_softmax(pred_prob[:, 0], pair_ray, dim_size=R)
+    else:
+        sm = torch.empty(0)
+    _, max_pair_id = scatter_max(sm, pair_ray, dim_size=R)
+    dummy = torch.cat((pair_pred_pos, torch.zeros(1, 3)), 0)  # pipeline.py:452-454
+    pred_pos = dummy[max_pair_id]
+    return {
+        "pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
+        "pred_prob_end_softmax": sm, "max_pair_id": max_pair_id, "pred_pos": pred_pos,
+        "ray_rgb": ray_rgb,
+    }
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic workload of SURVEY.md §8(d) — shared by tests and bench so both sides see the same data
+# ----------------------------------------------------------------------------------------------
+def synthetic_scene(B, h, w, N, seed, ragged=False, weight_scale=5.0):
+    g = torch.Generator().manual_seed(seed)
+    fx = torch.full((B,), 0.9 * w)
+    fy = torch.full((B,), 0.9 * w)
+    cx = torch.full((B,), w / 2 - 0.5)
+    cy = torch.full((B,), h / 2 - 0.5)
+    d, pix = ray_dirs(fx, fy, cx, cy, h, w)
+    R = B * h * w
+    ray_dir = d.reshape(R, 3).contiguous()
+    ray_pix = pix.reshape(R, 2).int().contiguous()
+    ray_bid = torch.arange(B).repeat_interleave(h * w).int()
+    ray_flat = torch.arange(h * w).repeat(B).int()
+    delta = 1.75 / N
+    k = torch.arange(N, dtype=torch.float32)
+    t_enter = (0.25 + k * delta).unsqueeze(0).expand(R, N)
+    t_leave = t_enter + delta
+    mid = ray_dir.unsqueeze(1) * ((t_enter + t_leave) * 0.5).unsqueeze(-1)  # [R,N,3]
+    xmin = torch.tensor([-1.125, -1.125, -0.125])
+    cell = torch.floor((mid - xmin) / 0.25).long().clamp(0, 8)
+    vox_local = (cell[..., 0] * 9 + cell[..., 1]) * 9 + cell[..., 2]
+    vox = vox_local + (ray_bid.long() * 729).unsqueeze(1)
+    if ragged:
+        cnt = torch.randint(0, N + 1, (R,), generator=g)
+    else:
+        cnt = torch.full((R,), N, dtype=torch.long)
+    keep = k.unsqueeze(0) < cnt.unsqueeze(1)
+    pair_ray = torch.arange(R).unsqueeze(1).expand(R, N)[keep].int()
+    pair_vox = vox[keep].int()
+    pair_t = torch.stack((t_enter[keep], t_leave[keep]), -1).contiguous()
+    pair_off = torch.zeros(R + 1, dtype=torch.int32)
+    pair_off[1:] = torch.cumsum(cnt, 0).int()
+    V = B * 729
+    vox_feat = torch.relu(torch.randn(V, 128, generator=g))
+    coarse = torch.randn(B, 32, max(h // 8, 1), max(w // 8, 1), generator=g)
+    feat_grid = F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+    ci = torch.arange(9, dtype=torch.float32)
+    cxyz = torch.stack(torch.meshgrid(ci, ci, ci, indexing="ij"), -1).reshape(-1, 3)
+    vox_center = (xmin + (cxyz + 0.5) * 0.25).repeat(B, 1).contiguous()
+    D = 256 + 2 * embed_dim(8) + embed_dim(4)
+    prob_p = init_decoder("IMNET", D, 7, weight_scale)
+    off_p = init_decoder("IEF", D, 8, weight_scale)
+    return {
+        "B": B, "h": h, "w": w, "N": N, "R": R, "P": int(pair_ray.shape[0]), "V": V,
+        "ray_dir": ray_dir, "ray_pix": ray_pix, "ray_bid": ray_bid, "ray_flat": ray_flat,
+        "pair_ray": pair_ray, "pair_vox": pair_vox, "pair_t": pair_t, "pair_off": pair_off,
+        "vox_feat": vox_feat, "feat_grid": feat_grid, "vox_center": vox_center,
+        "prob_p": prob_p, "off_p": off_p, "intr": torch.stack((fx, fy, cx, cy), 1).contiguous(),
+    }

@@ -1,0 +1,74 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import pytest
+import torch
+
+from util import TOL, make_module, oracle_query, orc, run_query
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("multires", [0, 4, 8])
+def test_embed(cuda, multires):
+    from implicit_depth_amd import get_embedder
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(1000, 3, generator=g) - 0.5) * 4.6
+    x[0] = 0.0
+    x[1] = torch.tensor([2.3, -2.3, 1e-7])
+    fn, dim = get_embedder(multires)
+    got = fn(x.to(cuda)).cpu()
+    ref = orc.embed(x, multires)
+    assert dim == ref.shape[1] == got.shape[1]
+    # sin/cos of arguments up to 2.3*128 rad: 1e-6 absolute leaves room for a few ulp at |v|<=1
+    assert (got - ref).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("kind,d,n,sig", [("IMNET", 385, 1000, False), ("IEF", 385, 1000, False),
+                                          ("IEF", 334, 777, False), ("IMNET", 265, 130, True),
+                                          ("IEF", 385, 31, True), ("IEF", 7, 64, False)])
+def test_decoder_modules(cuda, kind, d, n, sig):
+    p = orc.randomize_biases(orc.init_decoder(kind, d, 11, 5.0), 12)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, d, generator=g)
+    ref = orc.decoder_forward(p, x, kind, 2, sig)
+    m = make_module(kind, p, d, cuda, 2, sig)
+    with torch.no_grad():
+        got = m(x.to(cuda)).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= TOL
+
+
+def test_decoders_pair_and_empty(cuda):
+    from implicit_depth_amd import decoders_forward
+    d = 385
+    pp = orc.randomize_biases(orc.init_decoder("IMNET", d, 1, 5.0), 2)
+    po = orc.randomize_biases(orc.init_decoder("IEF", d, 3, 5.0), 4)
+    x = torch.randn(513, d, generator=torch.Generator().manual_seed(5))
+    mp, mo = make_module("IMNET", pp, d, cuda), make_module("IEF", po, d, cuda)
+    with torch.no_grad():
+        gp, go = decoders_forward(x.to(cuda), mp, mo)
+        ep, eo = decoders_forward(x[:0].to(cuda), mp, mo)
+    assert (gp.cpu() - orc.imnet_forward(pp, x)).abs().max().item() <= TOL
+    assert (go.cpu() - orc.ief_forward(po, x, 2)).abs().max().item() <= TOL
+    assert ep.shape == (0, 1) and eo.shape == (0, 1)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_query_small(cuda, ragged):
+    scene = orc.synthetic_scene(2, 16, 24, 16, seed=1234, ragged=ragged)
+    ref = oracle_query(scene)
+    got = run_query(scene, cuda)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        err = (got[k].cpu() - ref[k]).abs().max().item()
+        assert err <= TOL, (k, err)
+    assert (got["pred_prob_end_softmax"].cpu() - ref["pred_prob_end_softmax"]).abs().max().item() <= 1e-5
+    # arg-max: identical unless the oracle's two best softmax values are within float noise
+    gid, rid = got["max_pair_id"].cpu(), ref["max_pair_id"]
+    bad = (gid != rid).nonzero().flatten()
+    sm = ref["pred_prob_end_softmax"]
+    P = scene["P"]
+    for r in bad.tolist():
+        assert gid[r] < P and rid[r] < P
+        assert abs(sm[gid[r]] - sm[rid[r]]) <= 1e-6
+    depth_ref = ref["pred_pos"][:, 2].reshape(scene["B"], scene["h"], scene["w"])
+    l1 = (got["depth"].cpu() - depth_ref).abs().mean().item()
+    assert l1 <= TOL
