@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — LIDF per-point implicit-depth query throughput on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is
+launched under torch.distributed.run (one rank per GPU, RCCL). A "step" is one pass of the fused
+query (lidf_query_f32) over one synthetic 240x320 frame with 64 candidates per ray resident in HBM
+on every rank (BASELINE.json configs[1]; weak scaling: each rank owns one frame), followed — for
+N>1 — by the RCCL all-gather of the per-rank depth maps (the only collective on the path).
+Rank 0 prints ONE JSON line with the metric, the MFMA roofline of the dominant kernel (HIP events
+recorded by the library around lidf_points_kernel on the launch stream) and, at N=1, the CPU
+baseline (oracle port timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+F_ALG = 853952.0       # FLOP per point, reference formulation (SURVEY.md §8d / BASELINE.md §2)
+# MFMA FLOP actually issued per point by lidf_points_kernel: per 32-point wave-tile
+# 2 nets x (6*8+3) layer-1 k-steps x 8 tiles + 3 passes x (8 u + 129*4 layer-2 + 65*2 layer-3)
+# v_mfma_f32_32x32x2 instructions of 4096 FLOP each.
+F_EXEC = (2 * 51 * 8 + 3 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0  # = 355,584
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+
+
+class HipEvents:
+    """Minimal hipEvent wrapper over libamdhip64 (torch.cuda.Event hides its handle until it has
+    been recorded; the library needs raw hipEvent_t values to record on the launch stream)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def create(self):
+        e = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def elapsed_ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 hardware threads but the container quota is what bounds torch)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(scene, budget_s=15.0):
+    """Oracle port on the host cores over whole image rows of the same frame, sized to ~budget_s."""
+    from oracle import lidf_oracle as orc  # the checker, timed as the CPU baseline (port)
+    torch.set_num_threads(usable_cores())
+    h, w, N = scene["h"], scene["w"], scene["N"]
+
+    def run(rows):
+        R = rows * w
+        P = R * N
+        t0 = time.time()
+        orc.query(scene["ray_dir"][:R], scene["ray_pix"][:R], scene["ray_bid"][:R],
+                  scene["pair_ray"][:P].long(), scene["pair_vox"][:P].long(), scene["pair_t"][:P],
+                  scene["pair_off"][:R + 1], scene["feat_grid"], scene["vox_feat"],
+                  scene["prob_p"], scene["off_p"], fast_roi=True)
+        return P, time.time() - t0
+
+    run(1)  # warm-up (thread pool, allocator)
+    P1, t1 = run(4)
+    rows = int(max(4, min(h, 4 * budget_s / max(t1, 1e-3))))
+    P, t = run(rows)
+    return {"value": round(P / t / 1e6, 4), "unit": "Mpoints/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "first %d of %d image rows (%d points) of the same frame, oracle/lidf_oracle.py "
+                      "query() (torch CPU ops, vectorised ROIAlign), %.1f s" % (rows, h, P, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=64, help="candidates per ray (N)")
+    ap.add_argument("--frames", type=int, default=1, help="frames per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
+                         "--gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from implicit_depth_amd import IEF, IMNet
+    from implicit_depth_amd.dist import all_gather_depth
+    from implicit_depth_amd.query import lidf_query
+    from implicit_depth_amd.synthetic import synthetic_scene
+
+    h, w, N, B = 240, 320, args.samples, args.frames
+    scene = synthetic_scene(B, h, w, N, seed=1235 + rank)
+    P = scene["P"]
+    s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    prob = IMNet(scene["D"], 1, 64).to(dev).eval()
+    prob.load_state_dict(scene["prob_p"])
+    off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
+    off.load_state_dict(scene["off_p"])
+    depth = torch.zeros((B, h, w), device=dev)
+    gathered = torch.empty((world * B, h, w), device=dev) if world > 1 else None
+    ev = HipEvents()
+    pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
+    state = {"ws": None}
+
+    def step(events=None):
+        with torch.no_grad():
+            out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                             s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
+                             ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"],
+                             profile_events=events)
+        state["ws"] = out["workspace"]
+        if world > 1:
+            all_gather_depth(depth, gathered)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(pairs[i])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
+    if rank == 0:
+        value = world * P * args.steps / elapsed / 1e6
+        ach = F_ALG * P / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("lidf_points_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpoints/sec implicit-MLP query, 240x320x64 samples",
+            "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x 240x320 frame(s) per GPU, %d candidates/ray, LIDF "
+                                   "stage-1 fused query (ROI + PE + prob_dec IMNet + offset_dec IEF n_iter=2 "
+                                   "+ per-ray softmax/argmax + depth)%s" %
+                                   (B, N, "; RCCL all-gather of depth maps" if world > 1 else ""),
+                       "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
+                       "parallelism": "frames sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "lidf_points_kernel<FUSED>", "kernel_ms": round(kern_ms, 4),
+                         "flop_per_point_alg": F_ALG, "flop_per_point_exec": F_EXEC,
+                         "achieved_exec": round(F_EXEC * P / (kern_ms * 1e-3) / 1e12, 2),
+                         "frac_exec": round(F_EXEC * P / (kern_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ class LidfQueryArgs(C.Structure):
         ("pred_prob_softmax", C.c_void_p), ("max_pair_id", C.c_void_p), ("pred_pos", C.c_void_p),
         ("depth", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("ev_points_begin", C.c_void_p), ("ev_points_end", C.c_void_p),
     ]
 
 

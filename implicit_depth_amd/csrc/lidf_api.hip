@@ -316,7 +316,9 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
             long long nt = (P + 127) / 128;
+            if (q->ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_begin, st));
             CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
+            if (q->ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_end, st));
         }
     }
     // 5. per-ray softmax / argmax / select / depth

@@ -91,7 +91,7 @@ def to_reference_order(pair_ray, pair_vox):
 def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-               ray_flat=None, depth=None, want_softmax=True, workspace=None):
+               ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None):
     """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
 
     ray_dir [R,3] f32, ray_pix [R,2] i32 (x,y), ray_bid [R] i32, pair_* ray-major (see
@@ -165,6 +165,8 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     q.pred_pos = out["pred_pos"].data_ptr()
     q.depth = depth.data_ptr() if depth is not None else None
     q.workspace, q.workspace_bytes = workspace.data_ptr(), wsb
+    if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end) as integers
+        q.ev_points_begin, q.ev_points_end = profile_events
     with torch.cuda.device(dev):
         _lib.check(L.lidf_query_f32(C.byref(q), _lib.current_stream(dev)))
     out["workspace"] = workspace

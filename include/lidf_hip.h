@@ -124,6 +124,10 @@ typedef struct LidfQueryArgs {
     /* scratch */
     void* workspace;
     size_t workspace_bytes;
+    /* optional instrumentation: two hipEvent_t recorded on `stream` immediately before and after
+     * the per-point decoder kernel (the dominant launch); NULL = no recording.               */
+    void* ev_points_begin;
+    void* ev_points_end;
 } LidfQueryArgs;
 
 size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox);

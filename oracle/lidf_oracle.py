@@ -250,6 +250,62 @@ def roi_align(feat, boxes, output_size=2, spatial_scale=1.0, aligned=True):
     return torch.from_numpy(out)
 
 
+def _axis_taps(start, binsz, g, size):
+    """Per-axis bilinear taps of the RoIAlign sample points: start/binsz [n] f32, g samples per
+    bin. Returns (lo, hi) int64 [n,2,g] and (wlo, whi) f32 [n,2,g] following bilinear_interpolate's
+    edge rules (outside [-1, size] -> zero weight; clamp at 0; last row/col collapse)."""
+    ph = torch.arange(2, dtype=torch.float32).view(1, 2, 1)
+    i = (torch.arange(g, dtype=torch.float32) + 0.5).view(1, 1, g)
+    c = (start.view(-1, 1, 1) + ph * binsz.view(-1, 1, 1)) + (i * binsz.view(-1, 1, 1)) / float(g)
+    dead = (c < -1.0) | (c > float(size))
+    c = c.clamp(min=0.0)
+    lo = c.floor().long()
+    edge = lo >= size - 1
+    lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+    hi = torch.where(edge, lo, lo + 1)
+    c = torch.where(edge, lo.float(), c)
+    l = c - lo.float()
+    wlo, whi = 1.0 - l, l
+    wlo = torch.where(dead, torch.zeros_like(wlo), wlo)
+    whi = torch.where(dead, torch.zeros_like(whi), whi)
+    return lo, hi, wlo, whi
+
+
+def roi_align_fast(feat, boxes, chunk=4096):
+    """Vectorised torch-CPU form of roi_align above (output 2x2, aligned=True, scale 1): the
+    bilinear taps are separable per axis; rays are grouped by their (grid_h, grid_w). Sums are
+    re-associated, so it matches roi_align to float rounding (checked in tests). Used where the
+    per-box Python loop would dominate (cpu_baseline, larger tests)."""
+    B, C, H, W = feat.shape
+    K = boxes.shape[0]
+    out = torch.zeros(K, C, 2, 2)
+    bid = boxes[:, 0].long()
+    rsw, rsh = boxes[:, 1] - 0.5, boxes[:, 2] - 0.5
+    roi_w, roi_h = (boxes[:, 3] - 0.5) - rsw, (boxes[:, 4] - 0.5) - rsh
+    bw, bh = roi_w / 2.0, roi_h / 2.0
+    gw, gh = torch.ceil(roi_w / 2.0).long(), torch.ceil(roi_h / 2.0).long()
+    for g_h in torch.unique(gh).tolist():
+        for g_w in torch.unique(gw).tolist():
+            sel = ((gh == g_h) & (gw == g_w)).nonzero().flatten()
+            if sel.numel() == 0 or g_h == 0 or g_w == 0:
+                continue
+            for s0 in range(0, sel.numel(), chunk):
+                ids = sel[s0:s0 + chunk]
+                ylo, yhi, wyl, wyh = _axis_taps(rsh[ids], bh[ids], g_h, H)
+                xlo, xhi, wxl, wxh = _axis_taps(rsw[ids], bw[ids], g_w, W)
+                n = ids.numel()
+                bsel = bid[ids].view(n, 1, 1, 1)
+                csel = torch.arange(C).view(1, C, 1, 1)
+                acc = torch.zeros(n, C, 2, 2)
+                for yi, wy in ((ylo, wyl), (yhi, wyh)):
+                    for xi, wx in ((xlo, wxl), (xhi, wxh)):
+                        v = feat[bsel, csel, yi.reshape(n, 1, 2 * g_h, 1), xi.reshape(n, 1, 1, 2 * g_w)]
+                        v = v * wy.reshape(n, 1, 2 * g_h, 1) * wx.reshape(n, 1, 1, 2 * g_w)
+                        acc += v.reshape(n, C, 2, g_h, 2, g_w).sum((3, 5))
+                out[ids] = acc / float(max(g_h * g_w, 1))
+    return out
+
+
 def roi_boxes(img_ind, bid, h, w, roi_inp_bbox=8):
     """models/pipeline.py:374-383 — pixel +- roi_inp_bbox//2, corners clamped on int64, .float()."""
     ul = img_ind - roi_inp_bbox // 2
@@ -336,13 +392,13 @@ def build_inp_embed(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, feat_
 def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_grid, vox_feat,
           prob_p, off_p, off_kind="IEF", n_iter=2, use_sigmoid=False, multires=8, multires_views=4,
           roi_inp_bbox=8, offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-          chunk=262144):
+          chunk=262144, fast_roi=False):
     """get_embedding + get_pred (models/pipeline.py:338-466) + depth z. Pairs are ray-major."""
     R = ray_dir.shape[0]
     P = pair_ray.shape[0]
     boxes = roi_boxes(ray_pix.long(), ray_bid.long(), feat_grid.shape[2], feat_grid.shape[3],
                       roi_inp_bbox)
-    ray_rgb = roi_align(feat_grid, boxes).reshape(R, -1)
+    ray_rgb = (roi_align_fast if fast_roi else roi_align)(feat_grid, boxes).reshape(R, -1)
     e_dir_ray = embed(ray_dir, multires_views)
     pred_offset = torch.empty(P, 1)
     pred_prob = torch.empty(P, 1)
@@ -382,53 +438,14 @@ def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_
 
 
 # ----------------------------------------------------------------------------------------------
-# Synthetic workload of SURVEY.md §8(d) — shared by tests and bench so both sides see the same data
+# Synthetic workload of SURVEY.md §8(d): lives in implicit_depth_amd/synthetic.py (plain data
+# generation, no compute path) so that bench.py and the tests feed both sides the same tensors.
 # ----------------------------------------------------------------------------------------------
-def synthetic_scene(B, h, w, N, seed, ragged=False, weight_scale=5.0):
-    g = torch.Generator().manual_seed(seed)
-    fx = torch.full((B,), 0.9 * w)
-    fy = torch.full((B,), 0.9 * w)
-    cx = torch.full((B,), w / 2 - 0.5)
-    cy = torch.full((B,), h / 2 - 0.5)
-    d, pix = ray_dirs(fx, fy, cx, cy, h, w)
-    R = B * h * w
-    ray_dir = d.reshape(R, 3).contiguous()
-    ray_pix = pix.reshape(R, 2).int().contiguous()
-    ray_bid = torch.arange(B).repeat_interleave(h * w).int()
-    ray_flat = torch.arange(h * w).repeat(B).int()
-    delta = 1.75 / N
-    k = torch.arange(N, dtype=torch.float32)
-    t_enter = (0.25 + k * delta).unsqueeze(0).expand(R, N)
-    t_leave = t_enter + delta
-    mid = ray_dir.unsqueeze(1) * ((t_enter + t_leave) * 0.5).unsqueeze(-1)  # [R,N,3]
-    xmin = torch.tensor([-1.125, -1.125, -0.125])
-    cell = torch.floor((mid - xmin) / 0.25).long().clamp(0, 8)
-    vox_local = (cell[..., 0] * 9 + cell[..., 1]) * 9 + cell[..., 2]
-    vox = vox_local + (ray_bid.long() * 729).unsqueeze(1)
-    if ragged:
-        cnt = torch.randint(0, N + 1, (R,), generator=g)
-    else:
-        cnt = torch.full((R,), N, dtype=torch.long)
-    keep = k.unsqueeze(0) < cnt.unsqueeze(1)
-    pair_ray = torch.arange(R).unsqueeze(1).expand(R, N)[keep].int()
-    pair_vox = vox[keep].int()
-    pair_t = torch.stack((t_enter[keep], t_leave[keep]), -1).contiguous()
-    pair_off = torch.zeros(R + 1, dtype=torch.int32)
-    pair_off[1:] = torch.cumsum(cnt, 0).int()
-    V = B * 729
-    vox_feat = torch.relu(torch.randn(V, 128, generator=g))
-    coarse = torch.randn(B, 32, max(h // 8, 1), max(w // 8, 1), generator=g)
-    feat_grid = F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False).contiguous()
-    ci = torch.arange(9, dtype=torch.float32)
-    cxyz = torch.stack(torch.meshgrid(ci, ci, ci, indexing="ij"), -1).reshape(-1, 3)
-    vox_center = (xmin + (cxyz + 0.5) * 0.25).repeat(B, 1).contiguous()
-    D = 256 + 2 * embed_dim(8) + embed_dim(4)
-    prob_p = init_decoder("IMNET", D, 7, weight_scale)
-    off_p = init_decoder("IEF", D, 8, weight_scale)
-    return {
-        "B": B, "h": h, "w": w, "N": N, "R": R, "P": int(pair_ray.shape[0]), "V": V,
-        "ray_dir": ray_dir, "ray_pix": ray_pix, "ray_bid": ray_bid, "ray_flat": ray_flat,
-        "pair_ray": pair_ray, "pair_vox": pair_vox, "pair_t": pair_t, "pair_off": pair_off,
-        "vox_feat": vox_feat, "feat_grid": feat_grid, "vox_center": vox_center,
-        "prob_p": prob_p, "off_p": off_p, "intr": torch.stack((fx, fy, cx, cy), 1).contiguous(),
-    }
+def synthetic_scene(*args, **kw):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from implicit_depth_amd.synthetic import synthetic_scene as _impl
+    return _impl(*args, **kw)
