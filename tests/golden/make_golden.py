@@ -1,0 +1,207 @@
+"""make_golden.py — generate the golden vectors that pin oracle/lidf_oracle.py to the REFERENCE.
+
+Run in the authoring container only (it imports /root/reference/src, which does not exist on the
+GPU box):   python tests/golden/make_golden.py
+Writes small .npz fixtures next to this file. Nothing of the reference is copied: the reference's
+Python modules are imported and executed, and only their inputs/outputs are stored.
+
+  g1_embed.npz      get_embedder(8) / get_embedder(4) outputs          (models/implicit_net.py:42-57)
+  g2_decoders.npz   IMNet / IEF forward outputs on closed-form weights  (models/implicit_net.py:60-152)
+  g3_pipeline.npz   LIDF.get_miss_ray -> compute_ray_aabb -> get_embedding -> get_pred trace on a
+                    2 x 16 x 24 synthetic batch                           (models/pipeline.py:203-466)
+
+The reference's pipeline imports cv2, torchvision, torch_scatter and two JIT CUDA extensions, none
+of which exist here. They are replaced by stub modules whose bodies are oracle/lidf_oracle.py's
+restatements (roi_align, scatter_*, ray_aabb, pcl_aabb) — so g3 pins the reference's own Python
+(ray maths, gather/concat order, scaling constants, dummy-row handling), not those third-party ops.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, REF)
+
+from oracle import lidf_oracle as orc  # noqa: E402
+from util import closed_form, closed_form_params  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
+        assert dim == 0
+        if out is not None:  # in-place max into `out` (pipeline.py:944)
+            assert reduce == "max"
+            out.scatter_reduce_(0, index, src, reduce="amax", include_self=True)
+            return out
+        n = dim_size if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
+        shape = (n,) + tuple(src.shape[1:])
+        idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        if reduce == "sum":
+            return torch.zeros(shape, dtype=src.dtype).scatter_add_(0, idx, src)
+        if reduce == "max":  # torch_scatter fills untouched rows with 0
+            o = torch.full(shape, -float("inf"), dtype=src.dtype).scatter_reduce_(
+                0, idx, src, reduce="amax", include_self=True)
+            return torch.where(torch.isinf(o), torch.zeros_like(o), o)
+        raise NotImplementedError(reduce)
+
+    def scatter_softmax(src, index, dim=0, dim_size=None):
+        return orc.scatter_softmax(src, index, dim_size)
+
+    def scatter_max(src, index, dim=0, dim_size=None):
+        return orc.scatter_max(src, index, dim_size)
+
+    def scatter_log_softmax(src, index, dim=0, dim_size=None):
+        return torch.log(orc.scatter_softmax(src, index, dim_size))
+
+    def roi_align(inp, boxes, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+        return orc.roi_align(inp, boxes, output_size, spatial_scale, aligned)
+
+    class _RayAabb:
+        @staticmethod
+        def forward(ray_dir, voxel_bound, ray_bid, voxel_bid):
+            m, d = orc.ray_aabb(ray_dir.numpy(), voxel_bound.numpy(), ray_bid.numpy(), voxel_bid.numpy())
+            return torch.from_numpy(m), torch.from_numpy(d)
+
+    class _PclAabb:
+        @staticmethod
+        def forward(pos, voxel_bound, pcl_bid, voxel_bid):
+            return torch.from_numpy(orc.pcl_aabb(pos.numpy(), voxel_bound.numpy(), pcl_bid.numpy(),
+                                                 voxel_bid.numpy()))
+
+    _stub("cv2")
+    tv = _stub("torchvision")
+    tv.ops = _stub("torchvision.ops", roi_align=roi_align)
+    tv.transforms = _stub("torchvision.transforms")
+    _stub("torch_scatter", scatter=scatter, scatter_softmax=scatter_softmax, scatter_max=scatter_max,
+          scatter_log_softmax=scatter_log_softmax)
+    _stub("extensions")
+    _stub("extensions.ray_aabb")
+    _stub("extensions.ray_aabb.jit", ray_aabb=_RayAabb)
+    _stub("extensions.pcl_aabb")
+    _stub("extensions.pcl_aabb.jit", pcl_aabb=_PclAabb)
+
+
+def g1_embed():
+    import models.implicit_net as ref
+    x = torch.cat((torch.tensor([[0.0, 0.0, 0.0], [1e-7, -1e-7, 2.3], [-2.3, 2.3, -1.0],
+                                 [0.5, 0.25, 0.125]]),
+                   closed_form((60, 3), 0.7548776662, 0.3, 2.3)), 0)
+    out = {"x": x.numpy()}
+    for L in (8, 4):
+        fn, dim = ref.get_embedder(L)
+        y = fn(x)
+        assert y.shape[1] == dim
+        out["embed_L%d" % L] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_embed.npz"), **out)
+
+
+def g2_decoders():
+    import models.implicit_net as ref
+    out = {}
+    cases = [("IMNET", 385, False), ("IEF", 385, False), ("IEF", 334, False), ("IMNET", 385, True),
+             ("IEF", 385, True), ("IMNET", 265, False)]
+    for kind, d, sig in cases:
+        p = closed_form_params(kind, d, seed=len(out) + 1)
+        x = closed_form((256, d), 0.5698402910, 0.1 * d, 1.0)
+        if kind == "IEF":
+            m = ref.IEF(torch.device("cpu"), d, 1, 64, n_iter=2, use_sigmoid=sig)
+        else:
+            m = ref.IMNet(d, 1, 64, use_sigmoid=sig)
+        m.load_state_dict(p)
+        with torch.no_grad():
+            y = m(x)
+        key = "%s_%d_%d" % (kind, d, int(sig))
+        out[key] = y.numpy()
+        out[key + "_seed"] = np.array(len(out))  # bookkeeping: seed used for the params
+    np.savez_compressed(os.path.join(HERE, "g2_decoders.npz"), **out)
+
+
+def g3_pipeline():
+    install_stubs()
+    import models.pipeline as pl
+    from opt import Params
+    cfg = os.path.join(REF, "experiments", "implicit_depth")
+    opt = Params(os.path.join(cfg, "default_config.yaml"))
+    opt.update(os.path.join(cfg, "test_lidf.yaml"))
+    opt.grid.valid_sample_num = -1  # all valid points: no random sub-sampling in the trace
+    torch.manual_seed(1234)
+    dev = torch.device("cpu")
+    lidf = pl.LIDF(opt, dev).eval()
+    D = lidf.prob_dec.inp_dim
+    lidf.prob_dec.load_state_dict(closed_form_params("IMNET", D, seed=21))
+    lidf.offset_dec.load_state_dict(closed_form_params("IEF", D, seed=22))
+    B, h, w = 2, 16, 24
+    fx = torch.tensor([21.6, 20.0], dtype=torch.float64)
+    fy = torch.tensor([21.6, 22.0], dtype=torch.float64)
+    cx = torch.tensor([11.5, 12.25], dtype=torch.float64)
+    cy = torch.tensor([7.5, 7.0], dtype=torch.float64)
+    d, _ = orc.ray_dirs(fx.float(), fy.float(), cx.float(), cy.float(), h, w)  # [B,h,w,3]
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    depth = torch.stack((0.9 + 0.01 * xs + 0.005 * ys, 1.3 - 0.012 * xs + 0.02 * ys), 0)  # [B,h,w]
+    xyz = (d / d[..., 2:3] * depth.unsqueeze(-1)).permute(0, 3, 1, 2).contiguous()  # [B,3,h,w]
+    hole = torch.zeros(B, 1, h, w)
+    hole[0, :, 5:11, 8:17] = 1
+    hole[1, :, 2:9, 3:12] = 1
+    depth_corrupt = depth.unsqueeze(1) * (1 - hole)
+    xyz_corrupt = xyz * (1 - hole)
+    batch = {
+        "rgb": closed_form((B, 3, h, w), 0.3819660113, 0.2, 1.5),
+        "xyz": xyz, "xyz_corrupt": xyz_corrupt, "depth_corrupt": depth_corrupt,
+        "corrupt_mask": hole.clone(), "valid_mask": 1 - hole,
+        "fx": fx, "fy": fy, "cx": cx, "cy": cy, "item_path": ["a", "b"],
+    }
+    cap = {}
+    hk = lidf.pnet_model.register_forward_hook(lambda m, i, o: cap.__setitem__("occ_voxel_feat", o.detach().clone()))
+    with torch.no_grad():
+        dd = lidf.prepare_data(batch, "test", None)
+        lidf.get_valid_points(dd)
+        assert lidf.get_occ_vox_bound(dd)
+        lidf.get_miss_ray(dd, "test")
+        assert lidf.compute_ray_aabb(dd)
+        lidf.get_embedding(dd)
+        lidf.get_pred(dd, "test", 0)
+    hk.remove()
+    keep = ["miss_bid", "miss_flat_img_id", "miss_ray_dir", "miss_img_ind", "voxel_bound", "occ_vox_bid",
+            "occ_vox_intersect_idx", "miss_ray_intersect_idx", "intersect_enter_dist",
+            "intersect_leave_dist", "intersect_enter_pos", "full_rgb_feat", "intersect_rgb_feat",
+            "intersect_voxel_feat", "pair_pred_pos", "max_pair_id", "pred_prob_end",
+            "pred_prob_end_softmax", "pred_pos"]
+    out = {k: dd[k].detach().numpy() for k in keep}
+    out["occ_voxel_feat"] = cap["occ_voxel_feat"].numpy()
+    out["part_size"] = np.float32(dd["part_size"])
+    out["intr"] = torch.stack((dd["fx"], dd["fy"], dd["cx"], dd["cy"]), 1).numpy()
+    out["hw"] = np.array([h, w])
+    out["offset_range"] = np.array(opt.grid.offset_range, dtype=np.float32)
+    # the decoders' direct outputs on the reference's own inp_embed (pred_offset is not in data_dict)
+    with torch.no_grad():
+        inp = torch.cat((dd["intersect_voxel_feat"], dd["intersect_rgb_feat"],
+                         dd["intersect_enter_pos_embed"], dd["intersect_leave_pos_embed"],
+                         dd["intersect_dir_embed"]), -1)
+        out["pred_offset"] = lidf.offset_dec(inp).numpy()
+    print("g3: R=%d V=%d P=%d" % (out["miss_ray_dir"].shape[0], out["voxel_bound"].shape[0],
+                                   out["pair_pred_pos"].shape[0]))
+    np.savez_compressed(os.path.join(HERE, "g3_pipeline.npz"), **out)
+
+
+if __name__ == "__main__":
+    g1_embed()
+    g2_decoders()
+    g3_pipeline()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,121 @@
+"""GPU: edge cases of the fused query the reference handles by early exits (models/pipeline.py:
+181-183, 287-289, 686-687) and the alternative configurations of SURVEY.md §8a (iv)-(vi), plus
+size-independent properties at the full BASELINE size."""
+import pytest
+import torch
+
+from util import TOL, make_module, oracle_query, orc, run_query, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_no_pairs_and_no_rays(cuda):
+    from implicit_depth_amd.query import lidf_query
+    scene = orc.synthetic_scene(1, 8, 8, 4, seed=5)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob, off = make_module("IMNET", scene["prob_p"], D, cuda), make_module("IEF", scene["off_p"], D, cuda)
+    R = scene["R"]
+    zero_off = torch.zeros(R + 1, dtype=torch.int32, device=cuda)
+    e_i = torch.zeros(0, dtype=torch.int32, device=cuda)
+    depth = torch.full((1, 8, 8), 7.0, device=cuda)
+    with torch.no_grad():
+        out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], zero_off, e_i, e_i,
+                         torch.zeros(0, 2, device=cuda), s["feat_grid"], s["vox_feat"], prob, off,
+                         ray_flat=s["ray_flat"], depth=depth)
+    assert out["pair_pred_pos"].shape == (0, 3)
+    assert (out["max_pair_id"] == 0).all()            # P == 0 -> the dummy row index
+    assert (out["pred_pos"] == 0).all() and (depth == 0).all()
+    with torch.no_grad():
+        out = lidf_query(s["ray_dir"][:0], s["ray_pix"][:0], s["ray_bid"][:0], zero_off[:1], e_i, e_i,
+                         torch.zeros(0, 2, device=cuda), s["feat_grid"], s["vox_feat"], prob, off)
+    assert out["pred_pos"].shape == (0, 3)
+
+
+def test_relative_positions_and_offset_range(cuda):
+    scene = orc.synthetic_scene(1, 12, 16, 8, seed=6, ragged=True)
+    kw = dict(offset_range=(-0.2, 0.2), part_size=0.25)
+    ref = oracle_query(scene, vox_center=scene["vox_center"], pos_rel=True, **kw)
+    got = run_query(scene, cuda, vox_center=scene["vox_center"].to(cuda), pos_rel=True, **kw)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+
+
+def test_identity_embedder_and_imnet_offset(cuda):
+    """pos_encode False (D = 265) and offdec_type IMNET."""
+    from implicit_depth_amd.query import lidf_query
+    scene = orc.synthetic_scene(1, 12, 16, 8, seed=7, multires=0, multires_views=0)
+    D = 256 + 9
+    pp = orc.randomize_biases(orc.init_decoder("IMNET", D, 31, 5.0), 1)
+    po = orc.randomize_biases(orc.init_decoder("IMNET", D, 32, 5.0), 2)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"],
+                    scene["vox_feat"], pp, po, off_kind="IMNET", multires=0, multires_views=0)
+    s = to_dev(scene, cuda)
+    with torch.no_grad():
+        got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                         s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"],
+                         make_module("IMNET", pp, D, cuda), make_module("IMNET", po, D, cuda),
+                         multires=0, multires_views=0)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+
+
+def test_sigmoid_outputs_and_three_iterations(cuda):
+    from implicit_depth_amd.query import lidf_query
+    scene = orc.synthetic_scene(1, 10, 12, 6, seed=8)
+    D = scene["D"]
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"],
+                    scene["vox_feat"], scene["prob_p"], scene["off_p"], n_iter=3, use_sigmoid=True)
+    s = to_dev(scene, cuda)
+    with torch.no_grad():
+        got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                         s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"],
+                         make_module("IMNET", scene["prob_p"], D, cuda, use_sigmoid=True),
+                         make_module("IEF", scene["off_p"], D, cuda, n_iter=3, use_sigmoid=True))
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+
+
+def test_ray_features_border_pixels(cuda):
+    """ROIAlign near the image border: clamped boxes of width 4..7 give fractional sample points."""
+    from implicit_depth_amd.query import ray_features
+    scene = orc.synthetic_scene(2, 12, 16, 1, seed=9)
+    s = to_dev(scene, cuda)
+    for bbox in (8, 7, 4):
+        got = ray_features(s["feat_grid"], s["ray_dir"], s["ray_pix"], s["ray_bid"], bbox, 4).cpu()
+        boxes = orc.roi_boxes(scene["ray_pix"].long(), scene["ray_bid"].long(), 12, 16, bbox)
+        ref = orc.roi_align(scene["feat_grid"], boxes).reshape(scene["R"], -1)
+        assert (got[:, :128] - ref).abs().max().item() <= 2e-6
+        assert (got[:, 128:] - orc.embed(scene["ray_dir"], 4)).abs().max().item() <= 1e-6
+
+
+def test_full_size_properties(cuda):
+    """BASELINE configs[1] size (240x320x64): properties that need no full-size oracle run."""
+    scene = orc.synthetic_scene(1, 240, 320, 64, seed=1235)
+    got = run_query(scene, cuda)
+    P, R = scene["P"], scene["R"]
+    sm = got["pred_prob_end_softmax"]
+    assert torch.isfinite(got["pair_pred_pos"]).all() and torch.isfinite(sm).all()
+    ray = to_dev(scene, cuda)["pair_ray"].long()
+    sums = torch.zeros(R, device=cuda).index_add_(0, ray, sm)
+    assert (sums - 1).abs().max().item() <= 1e-5                      # softmax sums to 1 per ray
+    mid = got["max_pair_id"]
+    assert ((mid >= 0) & (mid < P)).all() and (ray[mid] == torch.arange(R, device=cuda)).all()
+    logit = got["pred_prob_end"][:, 0].reshape(R, 64)
+    assert (logit.gather(1, (mid - torch.arange(R, device=cuda) * 64).unsqueeze(1))[:, 0]
+            >= logit.max(1).values - 1e-6).all()                       # argmax(softmax) is a max logit
+    assert (got["pred_pos"] == got["pair_pred_pos"][mid]).all()          # select is a pure gather
+    assert (got["depth"].reshape(-1) == got["pred_pos"][:, 2]).all()
+    # a random subset of rays against the oracle (whole rays, so the per-ray reduction is covered)
+    g = torch.Generator().manual_seed(0)
+    rows = torch.randperm(R, generator=g)[:96].sort().values
+    pidx = (rows.unsqueeze(1) * 64 + torch.arange(64)).reshape(-1)
+    sub_ray = torch.arange(96).repeat_interleave(64)
+    ref = orc.query(scene["ray_dir"][rows], scene["ray_pix"][rows], scene["ray_bid"][rows], sub_ray,
+                    scene["pair_vox"][pidx].long(), scene["pair_t"][pidx], None, scene["feat_grid"],
+                    scene["vox_feat"], scene["prob_p"], scene["off_p"], fast_roi=True)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert (got[k][pidx.to(cuda)].cpu() - ref[k]).abs().max().item() <= TOL, k
+    assert (got["pred_pos"][rows.to(cuda)].cpu() - ref["pred_pos"]).abs().max().item() <= TOL

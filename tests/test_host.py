@@ -1,0 +1,135 @@
+"""CPU: host logic — the C-ABI library loads and exports every symbol include/lidf_hip.h declares,
+the drop-in modules keep the reference's constructor signatures and state-dict keys, CPU tensors
+are refused (no CPU product path), and the frame sharding + depth all-gather work under gloo."""
+import os
+import re
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from util import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "lidf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lidf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from implicit_depth_amd import _lib
+    names = header_functions()
+    assert len(names) >= 17
+    L = _lib.lib()  # loads without a GPU (no compute call is made here)
+    for n in names:
+        assert hasattr(L, n), n
+        assert n in _lib.SIGNATURES, "ctypes signature missing for " + n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert L.lidf_version() == 1
+    assert b"workspace" in L.lidf_strerror(-3)
+    assert L.lidf_query_workspace_bytes(76800, 729) > 76800 * 512 * 4
+    assert L.lidf_decoders_workspace_bytes(10, 385) > 0
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from implicit_depth_amd import _lib
+    # LidfDecoder: 10 pointers + 4 x 4-byte fields; LidfQueryArgs: as declared, natural alignment
+    assert C.sizeof(_lib.LidfDecoder) == 10 * 8 + 16
+    assert C.sizeof(_lib.LidfQueryArgs) % 8 == 0
+    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 16 == C.sizeof(_lib.LidfQueryArgs)
+
+
+def test_modules_keep_reference_interface():
+    from implicit_depth_amd import IEF, IMNet, get_embedder
+    fn, dim = get_embedder(8)
+    assert dim == 51 and callable(fn)
+    ident, d3 = get_embedder(8, i=-1)
+    assert d3 == 3 and isinstance(ident, torch.nn.Identity)
+    assert get_embedder(4)[1] == 27
+    m = IMNet(385, 1, gf_dim=64, use_sigmoid=False)
+    assert sorted(m.state_dict()) == sorted(
+        ["linear_%d.%s" % (i, k) for i in range(1, 5) for k in ("weight", "bias")])
+    assert m.linear_1.weight.shape == (256, 385) and m.linear_4.weight.shape == (1, 64)
+    e = IEF(torch.device("cpu"), 385, 1, gf_dim=64, n_iter=2)
+    assert "offset_enc.weight" in e.state_dict() and e.linear_1.weight.shape == (256, 401)
+    assert "init_offset" not in e.state_dict()  # plain attribute, as in the reference (:104)
+    assert float(e.init_offset) == pytest.approx(0.001)
+    assert float(m.linear_4.weight.mean()) != 0.0
+
+
+def test_cpu_tensors_are_refused():
+    from implicit_depth_amd import IEF, IMNet, get_embedder
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            IMNet(385, 1)(torch.zeros(4, 385))
+        with pytest.raises(RuntimeError):
+            IEF(torch.device("cpu"), 385, 1, n_iter=2)(torch.zeros(4, 385))
+        with pytest.raises(RuntimeError):
+            get_embedder(8)[0](torch.zeros(4, 3))
+    from implicit_depth_amd.extensions import pcl_aabb, ray_aabb
+    with pytest.raises(RuntimeError):
+        ray_aabb.forward(torch.zeros(4, 3), torch.zeros(2, 6), torch.zeros(4, dtype=torch.int32),
+                         torch.zeros(2, dtype=torch.int32))
+    with pytest.raises(RuntimeError):
+        pcl_aabb.forward(torch.zeros(4, 3), torch.zeros(2, 6), torch.zeros(4, dtype=torch.int32),
+                         torch.zeros(2, dtype=torch.int32))
+
+
+def test_shard_frames():
+    from implicit_depth_amd.dist import shard_frames
+    for n in (0, 1, 7, 8, 32, 33):
+        for world in (1, 2, 8):
+            spans = [shard_frames(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_frames(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, n_frames, q):
+    import torch.distributed as dist
+    from implicit_depth_amd.dist import all_gather_depth, all_gather_depth_ragged, shard_frames
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    try:
+        h, w = 6, 8
+        lo, hi = shard_frames(n_frames, world, rank)
+        # "depth" of global frame f is the constant f + 1 (stands in for the per-rank query result)
+        local = torch.stack([torch.full((h, w), float(f + 1)) for f in range(lo, hi)]) if hi > lo \
+            else torch.zeros((0, h, w))
+        if n_frames % world == 0:
+            full = all_gather_depth(local)
+        else:
+            full = all_gather_depth_ragged(local, n_frames)
+        ok = full.shape == (n_frames, h, w) and all(
+            bool((full[f] == f + 1).all()) for f in range(n_frames))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [4, 5])
+def test_depth_all_gather_gloo_world2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

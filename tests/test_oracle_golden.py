@@ -1,0 +1,106 @@
+"""CPU: the oracle against the golden vectors generated FROM THE REFERENCE (tests/golden/
+make_golden.py). This is what pins oracle/lidf_oracle.py; the GPU tests then compare the HIP path
+with the oracle and with the same fixtures."""
+import os
+
+import numpy as np
+import torch
+
+from util import closed_form, closed_form_params, orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: v for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def test_g1_embed():
+    g = load("g1_embed.npz")
+    x = torch.from_numpy(g["x"])
+    for L in (8, 4):
+        got = orc.embed(x, L).numpy()
+        assert got.shape == g["embed_L%d" % L].shape
+        assert np.abs(got - g["embed_L%d" % L]).max() == 0.0  # same torch ops, same order: bit-equal
+
+
+def g2_cases(g):
+    for key in sorted(k for k in g if not k.endswith("_seed")):
+        kind, d, sig = key.split("_")
+        yield key, kind, int(d), bool(int(sig)), int(g[key + "_seed"])
+
+
+def test_g2_decoders():
+    g = load("g2_decoders.npz")
+    n = 0
+    for key, kind, d, sig, seed in g2_cases(g):
+        p = closed_form_params(kind, d, seed=seed)
+        x = closed_form((256, d), 0.5698402910, 0.1 * d, 1.0)
+        got = orc.decoder_forward(p, x, kind, 2, sig).numpy()
+        assert np.abs(got - g[key]).max() <= 1e-6, key
+        n += 1
+    assert n == 6
+
+
+def g3_inputs(g):
+    """Ray-major oracle/product inputs rebuilt from the reference trace."""
+    h, w = [int(v) for v in g["hw"]]
+    ray_dir = torch.from_numpy(g["miss_ray_dir"])
+    ray_pix = torch.from_numpy(g["miss_img_ind"]).int()
+    ray_bid = torch.from_numpy(g["miss_bid"]).int()
+    ray_flat = torch.from_numpy(g["miss_flat_img_id"]).int()
+    vb = torch.from_numpy(g["voxel_bound"])
+    vbid = torch.from_numpy(g["occ_vox_bid"]).int()
+    return h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid
+
+
+def test_g3_rays_and_pairs():
+    g = load("g3_pipeline.npz")
+    h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid = g3_inputs(g)
+    intr = torch.from_numpy(g["intr"])
+    d, pix = orc.ray_dirs(intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], h, w)
+    assert np.abs(d.reshape(-1, 3).numpy() - g["miss_ray_dir"]).max() == 0.0  # mask_type 'all'
+    assert (pix.reshape(-1, 2).numpy() == g["miss_img_ind"]).all()
+    mask, dist = orc.ray_aabb(ray_dir.numpy(), vb.numpy(), ray_bid.numpy(), vbid.numpy())
+    idx = np.argwhere(mask)  # voxel-major, the reference's nonzero order
+    assert (idx[:, 0] == g["occ_vox_intersect_idx"]).all()
+    assert (idx[:, 1] == g["miss_ray_intersect_idx"]).all()
+    assert np.abs(dist[idx[:, 0], idx[:, 1], 0] - g["intersect_enter_dist"]).max() == 0.0
+    assert np.abs(dist[idx[:, 0], idx[:, 1], 1] - g["intersect_leave_dist"]).max() == 0.0
+
+
+def g3_oracle(g):
+    h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid = g3_inputs(g)
+    mask, dist = orc.ray_aabb(ray_dir.numpy(), vb.numpy(), ray_bid.numpy(), vbid.numpy())
+    pair_ray, pair_vox, pair_t, pair_off = orc.pairs_from_dense(mask, dist)
+    D = 385
+    res = orc.query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off,
+                    torch.from_numpy(g["full_rgb_feat"]), torch.from_numpy(g["occ_voxel_feat"]),
+                    closed_form_params("IMNET", D, seed=21), closed_form_params("IEF", D, seed=22),
+                    offset_range=tuple(float(v) for v in g["offset_range"]),
+                    part_size=float(g["part_size"]))
+    # permutation ray-major -> reference (voxel-major) order
+    R = ray_dir.shape[0]
+    perm = torch.argsort(pair_vox * R + pair_ray, stable=True)
+    return res, perm, (pair_ray, pair_vox, pair_t, pair_off)
+
+
+def test_g3_query_matches_reference_trace():
+    g = load("g3_pipeline.npz")
+    res, perm, _ = g3_oracle(g)
+    P = perm.shape[0]
+    assert P == g["pair_pred_pos"].shape[0]
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(P)
+    for k, ref in (("pred_offset", "pred_offset"), ("pred_prob_end", "pred_prob_end"),
+                   ("pair_pred_pos", "pair_pred_pos"), ("pred_prob_end_softmax", "pred_prob_end_softmax")):
+        got = res[k][perm].numpy()
+        assert np.abs(got - g[ref]).max() <= 2e-6, k
+    assert np.abs(res["pred_pos"].numpy() - g["pred_pos"]).max() <= 2e-6
+    ref_id = torch.from_numpy(g["max_pair_id"])
+    got_id = res["max_pair_id"]
+    got_ref_order = torch.where(got_id < P, inv[got_id.clamp(max=P - 1)], torch.full_like(got_id, P))
+    assert (got_ref_order == ref_id).all()
+    # ROI feature and voxel feature gathers as the reference saw them (per pair)
+    pr = torch.from_numpy(g["miss_ray_intersect_idx"])
+    assert np.abs(res["ray_rgb"][pr].numpy() - g["intersect_rgb_feat"]).max() == 0.0

@@ -51,3 +51,27 @@ def oracle_query(scene, **kw):
     return orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
                      scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"],
                      scene["feat_grid"], scene["vox_feat"], scene["prob_p"], scene["off_p"], **kw)
+
+
+def closed_form(shape, a, b, amp):
+    """Deterministic pseudo-random tensor amp*sin(i*a + b) (float64 sin, cast to f32): lets the
+    golden fixtures carry only outputs — weights and inputs are regenerated from this formula."""
+    n = 1
+    for s in shape:
+        n *= s
+    i = torch.arange(n, dtype=torch.float64)
+    return (amp * torch.sin(i * a + b)).float().reshape(shape)
+
+
+def closed_form_params(kind, inp_dim, seed, gf=64):
+    """State dict with reference parameter names, weights ~ amplitude 0.14 (std 0.1), biases 0.05."""
+    dims = [("linear_1", inp_dim + (16 if kind == "IEF" else 0), 4 * gf), ("linear_2", 4 * gf, 2 * gf),
+            ("linear_3", 2 * gf, gf), ("linear_4", gf, 1)]
+    p = {}
+    if kind == "IEF":
+        p["offset_enc.weight"] = closed_form((16, 1), 0.9, seed + 0.5, 0.3)
+        p["offset_enc.bias"] = closed_form((16,), 1.3, seed + 0.7, 0.1)
+    for j, (name, din, dout) in enumerate(dims):
+        p[name + ".weight"] = closed_form((dout, din), 0.6180339887 + 0.01 * j, seed + j, 0.14)
+        p[name + ".bias"] = closed_form((dout,), 0.7236067977, seed + 10 + j, 0.05)
+    return p
