@@ -27,7 +27,11 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [
         hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-ffp-contract=off", "-fvisibility=hidden", "-I", os.path.join(ROOT, "include"),
+        "-ffp-contract=off", "-fvisibility=hidden",
+        # the decoder pass is one 168-step fully unrolled software pipeline; clang's default
+        # 16k-instruction cap on `#pragma unroll` would silently leave it rolled (arrays in scratch)
+        "-mllvm", "-pragma-unroll-threshold=8000000",
+        "-I", os.path.join(ROOT, "include"),
         "-I", HERE, "-o", LIB,
     ] + [os.path.join(HERE, s) for s in SOURCES]
     if verbose:

@@ -144,8 +144,8 @@ LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_in
     a.stream = stream_buf;
     a.aux = aux;
     a.nets = nets;
-    a.l1_floats = lay.l1_floats;
-    a.net_floats = lay.net_floats;
+    a.l1_quads = lay.l1_quads;
+    a.net_quads = lay.net_quads;
     a.n = n;
     for (int i = 0; i < nets; ++i) fill_net_args(a, i, ds[i], outs[i], 0);
     a.X = inp;
@@ -216,7 +216,7 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv) {
 
 LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox) {
     // sized for the largest supported embedding (multires = multires_views = 16)
-    return query_ws(n_rays, n_vox, 16, 16).total;
+    return query_ws(n_rays, n_vox, LIDF_MAX_L_FUSED, 16).total;
 }
 
 LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
@@ -224,7 +224,8 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
     if (P > 0x7fffffffLL || R > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
-    if (q->multires < 0 || q->multires > 16 || q->multires_views < 0 || q->multires_views > 16)
+    if (q->multires < 0 || q->multires > LIDF_MAX_L_FUSED || q->multires_views < 0 ||
+        q->multires_views > 16)
         return LIDF_ERR_UNSUPPORTED;
     int rc;
     if (!q->prob || !q->off) return LIDF_ERR_BAD_ARG;
@@ -278,7 +279,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         {
             PointsArgs a = {};
             a.stream = stream_vox; a.aux = aux_pts;
-            a.nets = 2; a.l1_floats = lv.l1_floats; a.net_floats = lv.net_floats;
+            a.nets = 2; a.l1_quads = lv.l1_quads; a.net_quads = lv.net_quads;
             a.n = V; a.X = q->vox_feat; a.ldx = 128;
             a.D = mv.D; a.KH = mv.KH; a.KQ1 = mv.KQ1; a.has_bias = 1;
             a.out_base = voxpart;
@@ -292,7 +293,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         {
             PointsArgs a = {};
             a.stream = stream_ray; a.aux = aux_pts;
-            a.nets = 2; a.l1_floats = lr.l1_floats; a.net_floats = lr.net_floats;
+            a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
             a.n = R; a.X = rayfeat; a.ldx = 128 + Ed;
             a.D = mr.D; a.KH = mr.KH; a.KQ1 = mr.KQ1; a.has_bias = 0;
             a.out_base = raypart;
@@ -303,7 +304,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         {
             PointsArgs a = {};
             a.stream = stream_pts; a.aux = aux_pts;
-            a.nets = 2; a.l1_floats = lf.l1_floats; a.net_floats = lf.net_floats;
+            a.nets = 2; a.l1_quads = lf.l1_quads; a.net_quads = lf.net_quads;
             a.n = P;
             fill_net_args(a, 0, q->prob, q->pred_prob, 0);
             fill_net_args(a, 1, q->off, q->pred_offset, 1);
@@ -315,6 +316,9 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.sqrt3 = (float)1.7320508075688772;  // np.sqrt(3) rounded to f32 (pipeline.py:438)
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
+#ifdef LIDF_PROFILE
+            a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
+#endif
             long long nt = (P + 127) / 128;
             if (q->ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_begin, st));
             CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));

@@ -10,9 +10,16 @@
 // layout, and the nn.Linear weights are re-packed on the device, every call, into a "stream" of A
 // fragments in exactly the order the kernel consumes them:
 //   fragment = 64 floats, lane l holds W[32*tile + (l&31)][in(kstep, l>>5)]
-//   quad     = 4 consecutive k-steps of one output tile, stored lane-major (float4 per lane)
-//   pair     = 2 consecutive k-steps (float2 per lane), used by the positional-encoding section
+//   quad     = 4 consecutive k-steps of one output tile, stored lane-major (float4 per lane, 1 KiB)
 // Biases ride along as one extra k-step whose B operand is 1.0 in lanes 0..31 and 0 in 32..63.
+//
+// One block per decoder ("net"), consumed strictly front to back by an 8-deep register ring:
+//   [ layer 1 : NL1 quads ][ u : 2 quads ][ layer 2 : 4 tiles x 33 quads ][ layer 3 : 2 x 17 ]
+//   layer 1, fused mode : for octave pair it, tile t, jq<3 : quad (it*24 + t*3 + jq) = k-steps
+//                         4jq..4jq+3 of the 12 (sin x,y,z, cos x,y,z of octaves 2it, 2it+1);
+//                         then 8 tail quads (x, y, z, pad), one per tile
+//   layer 1, rows modes : for kq, tile t : quad (kq*8 + t)
+// Every section is a multiple of 8 quads so that the ring index is static at every code point.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,13 +31,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LIDF_H1 256   // gf_dim*4
 #define LIDF_H2 128   // gf_dim*2
 #define LIDF_H3 64    // gf_dim
-#define LIDF_L2_QUADS 33   // (128 k-steps + 1 bias k-step) / 4, rounded up
-#define LIDF_L3_QUADS 17   // (64 k-steps + 1 bias k-step) / 4, rounded up
-#define LIDF_L2_FLOATS (LIDF_L2_QUADS * 4 * 256)   // 4 output tiles
-#define LIDF_L3_FLOATS (LIDF_L3_QUADS * 2 * 256)   // 2 output tiles
-#define LIDF_SEC_FLOATS (LIDF_L2_FLOATS + LIDF_L3_FLOATS)
-#define LIDF_U_FLOATS 512   // 8 fragments (one per layer-1 tile of the offset net)
+#define LIDF_RING 8
+#define LIDF_L2_QUADS 33   // per output tile: (128 k-steps + 1 bias k-step) / 4, rounded up
+#define LIDF_L3_QUADS 17   // per output tile: (64 k-steps + 1 bias k-step) / 4, rounded up
+#define LIDF_U_QUADS 2     // 8 fragments: u vector of the IEF rank-1 term, one per layer-1 tile
+#define LIDF_PASS_QUADS (LIDF_U_QUADS + 4 * LIDF_L2_QUADS + 2 * LIDF_L3_QUADS)  // 168
 #define LIDF_AUX_FLOATS 72  // per net: w4 by (half, reg) [2][32], b4 at [64]
+#define LIDF_MAX_L_FUSED 16 // octaves of the in-kernel positional encoding
 
 enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2 };
 
@@ -56,28 +63,26 @@ struct L1Map {
     int leave_c0;  // w1 column of leave-position embedding
 };
 
-// Stream = nets consecutive per-net blocks, each [layer-1 (8 tiles) | u (8 fragments) | layer 2 |
-// layer 3] in consumption order. L1ONLY blocks hold the layer-1 section only.
 struct StreamLayout {
     int nets;       // 1 or 2
     int mode;       // LIDF_MODE_*
-    int l1_floats;  // per net
-    int net_floats; // per-net block size
-    int total;
+    int l1_quads;   // per net
+    int net_quads;  // per-net block size in quads (layer 1 only for L1ONLY)
+    int total;      // floats
 };
 
-static inline int lidf_l1_floats(int mode, const L1Map& m) {
-    if (mode == LIDF_MODE_FUSED) return 8 * 64 * (6 * m.L + 4);
-    return m.KQ1 * 8 * 256;
+static inline int lidf_l1_quads(int mode, const L1Map& m) {
+    if (mode == LIDF_MODE_FUSED) return 24 * ((m.L + 1) / 2) + 8;
+    return m.KQ1 * 8;
 }
 
 static inline StreamLayout lidf_make_layout(int nets, int mode, const L1Map& m) {
     StreamLayout s;
     s.nets = nets;
     s.mode = mode;
-    s.l1_floats = lidf_l1_floats(mode, m);
-    s.net_floats = s.l1_floats + (mode == LIDF_MODE_L1ONLY ? 0 : LIDF_U_FLOATS + LIDF_SEC_FLOATS);
-    s.total = nets * s.net_floats;
+    s.l1_quads = lidf_l1_quads(mode, m);
+    s.net_quads = s.l1_quads + (mode == LIDF_MODE_L1ONLY ? 0 : LIDF_PASS_QUADS);
+    s.total = nets * s.net_quads * 256;
     return s;
 }
 
@@ -86,7 +91,7 @@ struct PointsArgs {
     const float* stream;
     const float* aux;
     int nets;           // per-net blocks in the stream
-    int l1_floats, net_floats;
+    int l1_quads, net_quads;
     long long n;        // points (fused) or rows
     // per net: passes (n_iter for IEF, 1 for IMNet), initial value (0.001 IEF / 0 IMNet),
     // output activation, output pointer ([n] or NULL), whether it is the offset net

@@ -10,9 +10,42 @@
 //          `----- voxpart[v] ------'  `------ raypart[r] -------'  `--- in this kernel -----'
 //   IEF:  W1[:, D:D+16] (wenc*off + benc) = u*off + c   (u, c are [256] vectors; c joins the bias)
 // so per point only the 2*(3+6L) position-embedding columns go through MFMA in layer 1.
+//
+// Execution structure (one wavefront = 32 points, 1 wavefront per SIMD, see lidf_device.h for the
+// stream format): the A fragments of every layer / pass / net / tile are consumed strictly in
+// stream order through ONE 8-deep register ring that is refilled 8 quads ahead and never drains,
+// so no layer ever starts behind an L2 round trip.
+//
+// Measured fact that shapes everything else (scripts/mfma_valu_ubench.hip): on gfx950 the f32 MFMA
+// executes on the vector ALU itself — a VALU instruction issued by the same wavefront does NOT
+// overlap it, every one adds its ~4 issue cycles to the 64 cycles of the MFMA. So the kernel is
+// bound by (MFMA count x 64 + VALU instruction count x 4) cycles per wavefront, and the VALU side
+// is kept minimal: leaky-relu in 2 instructions per register, sin/cos on the transcendental unit
+// behind an exact range reduction in revolutions, the per-ray layer-1 partial added by a rank-1
+// MFMA instead of 128 v_add per net, no staging through LDS.
 #include "lidf_device.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Development-only phase timers (-DLIDF_PROFILE): wave 0 of block 0 accumulates s_memtime deltas
+// per phase into a.out_base[0..7] (as integers). The shipped library is built without it.
+#ifdef LIDF_PROFILE
+#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i) { long long t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
+#define PROF_DUMP if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_DUMP
+#endif
+
+// Weight-stream loads go through a buffer descriptor: the (wave-uniform) stream position lives in
+// an SGPR and the lane offset is one constant VGPR, so the unrolled layers need no per-load
+// 64-bit address registers (with flat pointers hipcc materialises and spills hundreds of them).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define LDQ(rs, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
 
 // ------------------------------------------------------------------------------------------------
 // Packer: one thread per stream float.
@@ -36,74 +69,63 @@ __device__ __forceinline__ float ief_c(const NetW& n, int out) {
 }
 
 __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L1Map& m, int e) {
-    const int net = e / lay.net_floats;
-    e %= lay.net_floats;
+    const int net = e / (lay.net_quads * 256);
+    e %= lay.net_quads * 256;
     const NetW& n = nets[net];
-    if (e < lay.l1_floats) {  // ---- layer 1 (8 tiles)
+    int quad = e / 256;
+    const int lane = (e % 256) / 4, jj = e & 3;
+    const int half = lane >> 5, c32 = lane & 31;
+    if (quad < lay.l1_quads) {  // ---- layer 1 (8 output tiles)
         if (lay.mode == LIDF_MODE_FUSED) {
-            const int per_oct = 8 * 384;
-            int t, lane, feat;  // feat: index inside the (3+6L)-wide embedding, -1 = pad
-            if (e < m.L * per_oct) {
-                int o = e / per_oct, rem = e % per_oct;
-                t = rem / 384;
-                int r2 = rem % 384;
-                int pair = r2 / 128;
-                lane = (r2 % 128) / 2;
-                int fr = 2 * pair + (r2 & 1);  // 0..5 = sin x,y,z, cos x,y,z
-                feat = 3 + 6 * o + fr;
+            const int Lp = (m.L + 1) / 2;
+            int t, feat;  // feat: index inside the (3+6L)-wide embedding, -1 = zero pad
+            if (quad < 24 * Lp) {
+                const int it = quad / 24, jq = quad % 3;
+                t = (quad % 24) / 3;
+                const int i = 4 * jq + jj;  // 0..11: sin xyz, cos xyz of octave 2it, then 2it+1
+                const int o = 2 * it + i / 6;
+                feat = o < m.L ? 3 + 6 * o + i % 6 : -1;
             } else {
-                e -= m.L * per_oct;
-                t = e / 256;
-                lane = (e % 256) / 4;
-                int jj = e & 3;
+                t = quad - 24 * Lp;
                 feat = jj < 3 ? jj : -1;
             }
             if (feat < 0) return 0.f;
-            int out = 32 * t + (lane & 31);
-            int col = ((lane >> 5) ? m.leave_c0 : m.enter_c0) + feat;
-            return n.w1[(size_t)out * n.ld1 + col];
-        } else {
-            int kq = e / (8 * 256), rem = e % (8 * 256);
-            int t = rem / 256;
-            int lane = (rem % 256) / 4;
-            int s = 4 * kq + (rem & 3);
-            int half = lane >> 5;
-            int out = 32 * t + (lane & 31);
-            int x = s + half * m.KH;  // operand column
-            int nvalid = half ? (m.D - m.KH) : m.KH;
-            if (s < nvalid) {
-                int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
-                return n.w1[(size_t)out * n.ld1 + col];
-            }
-            if (s == m.KH && half == 0 && m.add_bias) {
-                float b = n.b1[out];
-                if (n.is_ief) b += ief_c(n, out);
-                return b;
-            }
-            return 0.f;
+            const int col = (half ? m.leave_c0 : m.enter_c0) + feat;
+            return n.w1[(size_t)(32 * t + c32) * n.ld1 + col];
         }
+        const int kq = quad / 8, t = quad % 8;
+        const int s = 4 * kq + jj;
+        const int out = 32 * t + c32;
+        const int x = s + half * m.KH;  // operand column
+        const int nvalid = half ? (m.D - m.KH) : m.KH;
+        if (s < nvalid) {
+            const int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
+            return n.w1[(size_t)out * n.ld1 + col];
+        }
+        if (s == m.KH && half == 0 && m.add_bias) {
+            float b = n.b1[out];
+            if (n.is_ief) b += ief_c(n, out);
+            return b;
+        }
+        return 0.f;
     }
-    e -= lay.l1_floats;
-    if (e < LIDF_U_FLOATS) {  // ---- u fragments (zero for IMNet)
-        int q = e / 256, lane = (e % 256) / 4, jj = e & 3;
-        int to = 4 * q + jj;
-        if ((lane >> 5) != 0 || !n.is_ief) return 0.f;
-        return ief_u(n, 32 * to + (lane & 31));
+    quad -= lay.l1_quads;
+    if (quad < LIDF_U_QUADS) {  // ---- u fragments (zero for IMNet)
+        if (half != 0 || !n.is_ief) return 0.f;
+        return ief_u(n, 32 * (4 * quad + jj) + c32);
     }
-    e -= LIDF_U_FLOATS;
-    if (e < LIDF_L2_FLOATS) {
-        int kq = e / (4 * 256), t = (e / 256) % 4, lane = (e % 256) / 4;
-        int s = 4 * kq + (e & 3), half = lane >> 5;
-        int out = 32 * t + (lane & 31);
+    quad -= LIDF_U_QUADS;
+    if (quad < 4 * LIDF_L2_QUADS) {  // ---- layer 2, output tile major
+        const int t = quad / LIDF_L2_QUADS, s = 4 * (quad % LIDF_L2_QUADS) + jj;
+        const int out = 32 * t + c32;
         if (s < LIDF_H1 / 2) return n.w2[(size_t)out * LIDF_H1 + k_to_feature(s, half)];
         if (s == LIDF_H1 / 2 && half == 0) return n.b2[out];
         return 0.f;
     }
-    e -= LIDF_L2_FLOATS;
-    {
-        int kq = e / (2 * 256), t = (e / 256) % 2, lane = (e % 256) / 4;
-        int s = 4 * kq + (e & 3), half = lane >> 5;
-        int out = 32 * t + (lane & 31);
+    quad -= 4 * LIDF_L2_QUADS;
+    {  // ---- layer 3
+        const int t = quad / LIDF_L3_QUADS, s = 4 * (quad % LIDF_L3_QUADS) + jj;
+        const int out = 32 * t + c32;
         if (s < LIDF_H2 / 2) return n.w3[(size_t)out * LIDF_H2 + k_to_feature(s, half)];
         if (s == LIDF_H2 / 2 && half == 0) return n.b3[out];
         return 0.f;
@@ -140,11 +162,20 @@ extern "C" hipError_t lidf_launch_pack(const StreamLayout& lay, const NetW& n0, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-point kernel
+// Per-point kernel helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lrelu16(f32x16& v) {
+// leaky_relu(0.02) on registers [LO, HI) of one accumulator tile
+// (fmaxf would add a canonicalising v_max per input under the IEEE mode; one v_mul + one v_max
+// is the whole activation, implicit_net.py:83)
+template <int LO, int HI>
+__device__ __forceinline__ void lrelu_part(f32x16& v) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], v[i] * 0.02f);
+    for (int i = LO; i < HI; ++i) {
+        const float x = v[i], t = x * 0.02f;
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+        v[i] = r;
+    }
 }
 
 __device__ __forceinline__ float out_act(float y, int use_sigmoid) {
@@ -153,228 +184,319 @@ __device__ __forceinline__ float out_act(float y, int use_sigmoid) {
     return fmaxf(fminf(y, y * 0.01f + 0.99f), y * 0.01f);
 }
 
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// sin/cos of x*2^o for the positional encoding (implicit_net.py:30-32: freq bands are exact powers
+// of two). x/(2 pi) is formed once as hi + lo (fma residual + low part of 1/(2 pi)); scaling by
+// 2^o and v_fract are exact, so the argument handed to v_sin_f32 / v_cos_f32 (which take
+// revolutions) carries no octave-dependent error: |err| <= 4.2e-7 at every octave, measured
+// against double precision (scripts/hwsin_test.hip). 5 VALU per (coordinate, octave).
+struct Rev {
+    float hi, lo;
+};
+__device__ __forceinline__ Rev to_rev(float x) {
+    const float C_HI = 0.15915493667125702f;   // fl(1/(2 pi))
+    const float C_LO = 6.4206383e-09f;         // 1/(2 pi) - C_HI
+    Rev r;
+    r.hi = x * C_HI;
+    r.lo = fmaf(x, C_HI, -r.hi) + x * C_LO;
+    return r;
+}
+__device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, float& c) {
+    const float t = __builtin_amdgcn_fractf(r.hi * sc) + r.lo * sc;
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
+}
 
-// Weight-stream loads go through a buffer descriptor: the (wave-uniform) stream position lives in
-// an SGPR and the lane offset is one constant VGPR, so the unrolled layers need no per-load
-// 64-bit address registers (with flat pointers hipcc materialises and spills hundreds of them).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define LDQ(rs, voff, soff) \
-    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
-#define LDP(rs, voff, soff) \
-    __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rs), (voff), (soff), 0))
-
-// Dense layer whose B operands are the previous layer's accumulators (KT input tiles -> NT output
-// tiles), bias carried by k-step 16*KT.  The A fragments are streamed from L2 through an explicit
-// DEPTH-deep register ring; sched_barrier pins the software pipeline (left alone, hipcc hoists
-// every load of the unrolled layer to the top and spills them).
-template <int NT, int KT, int DEPTH>
-__device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t srs, int sec, int lane,
-                                            float one_b, const f32x16* __restrict__ Hin,
-                                            f32x16* Hout) {
-    constexpr int K = 16 * KT;     // k-steps: each consumes one register of both half-waves
-    constexpr int KQ = K / 4 + 1;  // + the bias k-step
-    const int vq = lane * 16;  // quad i of this lane lives at byte sec + 1024*i + 16*lane
-    f32x4 ring[DEPTH][NT];
+// One decoder pass on the 32 points of this wavefront:
+//   H1 = lrelu(base + u*val);  H2 = lrelu(W2 H1 + b2);  H3 = lrelu(W3 H2 + b3);  y = w4.H3 + b4
+// `ring` holds the next 8 quads of the stream on entry (u0, u1, first six layer-2 quads) and the
+// next 8 quads after the pass on exit: the pass's own first quads again when wrap_base ==
+// pass_base (another pass of the same net follows) or the first quads of the next block.
+__device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, const int vq,
+                                              f32x4 (&ring)[LIDF_RING], const int pass_base,
+                                              const int wrap_base, const f32x16 (&base)[8],
+                                              const float val, const int h, const float one_b,
+                                              const float* __restrict__ ax
+#ifdef LIDF_PROFILE
+                                              , long long& prof_t, long long (&prof_acc)[8]
+#endif
+                                              ) {
+    constexpr int S_L2 = LIDF_U_QUADS;
+    constexpr int S_L3 = S_L2 + 4 * LIDF_L2_QUADS;
+    // Stream offsets: one SGPR per group of four quads plus the instruction's immediate offset.
+    // The bases are made opaque so that the 168 offsets are formed next to their loads (s_add)
+    // instead of being hoisted out of the pass loop, where they overflow the SGPR file and come
+    // back through v_readlane — a VALU instruction per region.
+    int pb = pass_base, wb = wrap_base;
+    asm volatile("" : "+s"(pb), "+s"(wb));
+    const float ob = h ? 0.f : val;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                           0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 H1[8], H2[4], H3[2];
+    f32x4 u0, u1, w4[8];
+    float b4 = 0.f;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) ring[d][t] = LDQ(srs, vq, sec + (d * NT + t) * 1024);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Hout[t][i] = 0.f;
-    }
-    SCHED_FENCE();
-#pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) {
-        f32x4 cur[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[t] = ring[kq % DEPTH][t];
-        if (kq + DEPTH < KQ) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                ring[kq % DEPTH][t] = LDQ(srs, vq, sec + ((kq + DEPTH) * NT + t) * 1024);
+    for (int s = 0; s < LIDF_PASS_QUADS; ++s) {
+        const f32x4 a = ring[s % LIDF_RING];
+        {
+            const int nx = s + LIDF_RING;
+            const int rel = nx < LIDF_PASS_QUADS ? nx : nx - LIDF_PASS_QUADS;
+            ring[s % LIDF_RING] = LDQ(srs, vq + (rel & 3) * 1024,
+                                      (nx < LIDF_PASS_QUADS ? pb : wb) + (rel >> 2) * 4096);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        if (s == 0) {
+            u0 = a;
+        } else if (s == 1) {
+            u1 = a;
+            H1[0] = MFMA(u0[0], ob, base[0]);
+            lrelu_part<0, 16>(H1[0]);
+        } else if (s < S_L3) {
+            // ---- layer 2: output tile t, k-steps 4kq..4kq+3 (H1 tile kq/4)
+            const int t = (s - S_L2) / LIDF_L2_QUADS, kq = (s - S_L2) % LIDF_L2_QUADS;
+            if (t == 0 && (kq & 3) == 0 && kq / 4 + 1 < 8) {
+                // H1 tile needed four quads from now
+                const int T = kq / 4 + 1;
+                H1[T] = MFMA(T < 4 ? u0[T & 3] : u1[T & 3], ob, base[T]);
+                lrelu_part<0, 16>(H1[T]);
+            }
+            if (t >= 1 && kq == 0) lrelu_part<0, 8>(H2[t - 1]);
+            if (t >= 1 && kq == 1) lrelu_part<8, 16>(H2[t - 1]);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int s = 4 * kq + jj;
-                if (s < K)
-                    Hout[t] = MFMA(cur[t][jj], Hin[s / 16][s % 16], Hout[t]);
-                else if (s == K)
-                    Hout[t] = MFMA(cur[t][jj], one_b, Hout[t]);
+                const int k = 4 * kq + jj;
+                if (k == 0)
+                    H2[t] = MFMA(a[jj], H1[0][0], zero16);
+                else if (k < LIDF_H1 / 2)
+                    H2[t] = MFMA(a[jj], H1[k / 16][k % 16], H2[t]);
+                else if (k == LIDF_H1 / 2)
+                    H2[t] = MFMA(a[jj], one_b, H2[t]);
+            }
+        } else {
+            // ---- layer 3
+            const int t = (s - S_L3) / LIDF_L3_QUADS, kq = (s - S_L3) % LIDF_L3_QUADS;
+            if (s == S_L3) {
+                // operands of the tail, fetched here so that their latency hides behind layer 3
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w4[i] = *(const f32x4*)(ax + h * 32 + 4 * i);
+                b4 = ax[64];
+            }
+            if (t == 0 && kq == 0) lrelu_part<0, 8>(H2[3]);
+            if (t == 0 && kq == 1) lrelu_part<8, 16>(H2[3]);
+            if (t == 1 && kq == 0) lrelu_part<0, 8>(H3[0]);
+            if (t == 1 && kq == 1) lrelu_part<8, 16>(H3[0]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = 4 * kq + jj;
+                if (k == 0)
+                    H3[t] = MFMA(a[jj], H2[0][0], zero16);
+                else if (k < LIDF_H2 / 2)
+                    H3[t] = MFMA(a[jj], H2[k / 16][k % 16], H3[t]);
+                else if (k == LIDF_H2 / 2)
+                    H3[t] = MFMA(a[jj], one_b, H3[t]);
             }
         }
         SCHED_FENCE();
+#ifdef LIDF_PROFILE
+        if (s == 1) PROF(4)
+        if (s == S_L3 - 1) PROF(6)
+        if (s == LIDF_PASS_QUADS - 1) PROF(7)
+#endif
     }
+    lrelu_part<0, 16>(H3[1]);
+    // layer 4: 64 -> 1 on the VALU (4 partial sums), halves combined with one cross-half shuffle
+    float ys[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = 4 * i + k;
+            ys[k] = fmaf(w4[i][k], H3[s / 16][s % 16], ys[k]);
+        }
+    }
+    float y = (ys[0] + ys[1]) + (ys[2] + ys[3]);
+    y += __shfl_xor(y, 32);
+    return y + b4;
 }
+
+struct Geo {
+    int ray, vid;
+    float te, tl, dx, dy, dz;
+};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
-    extern __shared__ float pe_lds[];  // fused: [4 waves][6L+3 features][64 lanes]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
     const int col = lane & 31;
     const float one_b = h ? 0.f : 1.f;
-    const int NF = 6 * a.L + 3;
-    float* pe = pe_lds + wave * NF * 64 + lane;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.stream, 0, a.nets * a.net_floats * 4, 0x00020000);
-    const int vq = lane * 16, vp2 = lane * 8;
+        (void*)a.stream, 0, a.nets * a.net_quads * 1024, 0x00020000);
+    const int vq = lane * 16;
+    const int net_bytes = a.net_quads * 1024;
+    const int l1_bytes = a.l1_quads * 1024;
+    const int Lp = (a.L + 1) / 2;
 
     // contiguous range of 128-point tiles per workgroup; the 4 waves interleave inside it
     const long long ntile = (a.n + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
+    if (tb >= te_) return;
 
+    // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
+    f32x4 ring[LIDF_RING];
+#pragma unroll
+    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+
+    auto load_idx = [&](long long tile, Geo& g) {
+        long long pc = tile * 128 + wave * 32 + col;
+        pc = pc < a.n ? pc : a.n - 1;
+        g.ray = a.pair_ray[pc];
+        g.vid = a.pair_vox[pc];
+        const f32x2 tt = *(const f32x2*)(a.pair_t + 2 * pc);
+        g.te = tt[0];
+        g.tl = tt[1];
+    };
+    auto load_dir = [&](Geo& g) {
+        g.dx = a.ray_dir[3 * (size_t)g.ray + 0];
+        g.dy = a.ray_dir[3 * (size_t)g.ray + 1];
+        g.dz = a.ray_dir[3 * (size_t)g.ray + 2];
+    };
+
+    // two-stage geometry prefetch: `cur` complete, `nxt` has its indices (directions are fetched
+    // one tile ahead, indices two tiles ahead)
+    Geo cur = {}, nxt = {}, nx2 = {};
+    if constexpr (MODE == LIDF_MODE_FUSED) {
+        load_idx(tb, cur);
+        load_idx(tb + 1, nxt);
+        load_dir(cur);
+    }
+
+    PROF_DECL
     for (long long tile = tb; tile < te_; ++tile) {
-        if (tile * 128 + wave * 32 >= a.n) continue;  // whole wave out of range (wave-uniform)
+        if (tile * 128 + wave * 32 >= a.n) break;  // whole wave out of range (wave-uniform)
+        PROF(0)
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < a.n;
         const long long pc = valid ? p : a.n - 1;
 
-        float ex = 0.f, ey = 0.f, ez = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-        int ray = 0, vid = 0;
+        Rev rx = {}, ry = {}, rz = {};
+        float px = 0.f, py = 0.f, pz = 0.f;
         if constexpr (MODE == LIDF_MODE_FUSED) {
-            ray = a.pair_ray[pc];
-            vid = a.pair_vox[pc];
-            const f32x2 tt = *(const f32x2*)(a.pair_t + 2 * pc);
-            dx = a.ray_dir[3 * (size_t)ray + 0];
-            dy = a.ray_dir[3 * (size_t)ray + 1];
-            dz = a.ray_dir[3 * (size_t)ray + 2];
-            // enter position (needed again for the output) and this half's embedding input:
-            // lanes 0..31 embed the enter position, lanes 32..63 the leave position
-            ex = __fmul_rn(dx, tt[0]);
-            ey = __fmul_rn(dy, tt[0]);
-            ez = __fmul_rn(dz, tt[0]);
-            float px = h ? __fmul_rn(dx, tt[1]) : ex;
-            float py = h ? __fmul_rn(dy, tt[1]) : ey;
-            float pz = h ? __fmul_rn(dz, tt[1]) : ez;
+            load_dir(nxt);
+            load_idx(tile + 2, nx2);
+            // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the
+            // leave position (pipeline.py:349-360; 'rel' subtracts the voxel centre)
+            const float t = h ? cur.tl : cur.te;
+            px = __fmul_rn(cur.dx, t);
+            py = __fmul_rn(cur.dy, t);
+            pz = __fmul_rn(cur.dz, t);
             if (a.pos_rel) {
-                px -= a.vox_center[3 * (size_t)vid + 0];
-                py -= a.vox_center[3 * (size_t)vid + 1];
-                pz -= a.vox_center[3 * (size_t)vid + 2];
+                px -= a.vox_center[3 * (size_t)cur.vid + 0];
+                py -= a.vox_center[3 * (size_t)cur.vid + 1];
+                pz -= a.vox_center[3 * (size_t)cur.vid + 2];
             }
-            float sc = 1.f;
-            for (int o = 0; o < a.L; ++o) {
-                float s0, s1, s2, c0, c1, c2;
-                sincosf(px * sc, &s0, &c0);
-                sincosf(py * sc, &s1, &c1);
-                sincosf(pz * sc, &s2, &c2);
-                float* w = pe + (6 * o) * 64;
-                w[0] = s0; w[64] = s1; w[128] = s2; w[192] = c0; w[256] = c1; w[320] = c2;
-                sc *= 2.f;
-            }
-            float* w = pe + (6 * a.L) * 64;
-            w[0] = px; w[64] = py; w[128] = pz;
+            rx = to_rev(px);
+            ry = to_rev(py);
+            rz = to_rev(pz);
         }
+        PROF(1)
 
         for (int net = 0; net < a.nets; ++net) {
-            const int nsb = net * a.net_floats * 4;  // byte offset of this net's block
+            const int nsb = net * net_bytes;  // byte offset of this net's block
+            const int next_blk = net + 1 < a.nets ? nsb + net_bytes : 0;
             f32x16 base[8];
 
             // ---------------- layer 1 ----------------
             if constexpr (MODE == LIDF_MODE_FUSED) {
-                // accumulator init = voxpart[vid] + raypart[ray] (layer-1 bias inside voxpart),
-                // one tile per scheduling region, next tile's 8 loads in flight
-                const float* vp = a.voxpart + ((size_t)vid * a.nets + net) * 256 + 4 * h;
-                const float* rp = a.raypart + ((size_t)ray * a.nets + net) * 256 + 4 * h;
-                f32x2 wr[8][3];  // this octave's A pairs
+                // accumulator init = voxpart[vid] (carries the layer-1 bias), gathered per lane
+                // straight into the accumulator layout, + raypart[ray]: constant over the points
+                // of one ray, so it is a rank-1 update  A = raypart row (lanes 0..31: one ray,
+                // lanes 32..63: another), B = one-hot membership of the point.  Two distinct rays
+                // of the wave per MFMA round: ray-major pairs need one round (two when a tile
+                // straddles three rays); any pair order works. The loads of the first round are
+                // issued ahead of the voxpart gather so that the two latencies overlap.
+                unsigned todo = (unsigned)__ballot(h == 0);  // points still to be covered
+                float ar[8], bsel;
+                auto next_round = [&]() {
+                    const int p0 = __builtin_ctz(todo);
+                    const int r0 = __builtin_amdgcn_readlane(cur.ray, p0);
+                    const unsigned m0 = (unsigned)__ballot(cur.ray == r0) & todo;
+                    todo &= ~m0;
+                    int r1 = r0;
+                    unsigned m1 = 0;
+                    if (todo) {
+                        const int p1 = __builtin_ctz(todo);
+                        r1 = __builtin_amdgcn_readlane(cur.ray, p1);
+                        m1 = (unsigned)__ballot(cur.ray == r1) & todo;
+                        todo &= ~m1;
+                    }
+                    bsel = (((h ? m1 : m0) >> col) & 1u) ? 1.f : 0.f;
+                    const float* rp =
+                        a.raypart + ((size_t)(h ? r1 : r0) * a.nets + net) * 256 + col;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) ar[t] = rp[t * 32];
+                };
+                next_round();
+                const float* vp = a.voxpart + ((size_t)cur.vid * a.nets + net) * 256 + 4 * h;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) wr[t][i] = LDP(srs, vp2, nsb + (t * 3 + i) * 512);
-                }
-                {
-                    f32x4 v[4], r[4];
-#pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        v[g] = *(const f32x4*)(vp + 8 * g);
-                        r[g] = *(const f32x4*)(rp + 8 * g);
+                        const f32x4 v = *(const f32x4*)(vp + t * 32 + 8 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
                     }
-                    SCHED_FENCE();
+                }
+                for (;;) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        f32x4 vn[4], rn[4];
-                        if (t + 1 < 8) {
+                    for (int t = 0; t < 8; ++t) base[t] = MFMA(ar[t], bsel, base[t]);
+                    if (!todo) break;
+                    next_round();
+                }
+                PROF(2)
+                // octave pairs: 12 k-steps (sin xyz, cos xyz of octaves 2it, 2it+1) x 8 tiles per
+                // iteration; the embedding values are produced right here, in registers
+                float sc0 = 1.f;
+                for (int it = 0; it < Lp; ++it) {
+                    const float sc1 = sc0 * 2.f;
+                    float sb[12];
+                    rev_sincos(rx, sc0, sb[0], sb[3]);
+                    rev_sincos(ry, sc0, sb[1], sb[4]);
+                    rev_sincos(rz, sc0, sb[2], sb[5]);
+                    rev_sincos(rx, sc1, sb[6], sb[9]);
+                    rev_sincos(ry, sc1, sb[7], sb[10]);
+                    rev_sincos(rz, sc1, sb[8], sb[11]);
+                    const int qb = nsb + (it * 24 + LIDF_RING) * 1024;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                vn[g] = *(const f32x4*)(vp + (t + 1) * 32 + 8 * g);
-                                rn[g] = *(const f32x4*)(rp + (t + 1) * 32 + 8 * g);
-                            }
-                        }
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[g][i] + r[g][i];
-                        }
-                        if (t + 1 < 8) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                v[g] = vn[g];
-                                r[g] = rn[g];
-                            }
-                        }
+                    for (int s = 0; s < 24; ++s) {
+                        const int t = s / 3, jq = s % 3;
+                        const f32x4 q = ring[s % LIDF_RING];
+                        ring[s % LIDF_RING] = LDQ(srs, vq + (s & 3) * 1024, qb + (s >> 2) * 4096);
+                        f32x16 c = base[t];
+                        c = MFMA(q[0], sb[4 * jq + 0], c);
+                        c = MFMA(q[1], sb[4 * jq + 1], c);
+                        c = MFMA(q[2], sb[4 * jq + 2], c);
+                        c = MFMA(q[3], sb[4 * jq + 3], c);
+                        base[t] = c;
                         SCHED_FENCE();
                     }
-                }
-                float sb[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) sb[i] = pe[i * 64];
-                for (int o = 0; o < a.L; ++o) {
-                    // prefetch: next octave's embedding values (LDS) and A pairs (L2); after the
-                    // last octave this fetches the raw position and the tail quads' first half
-                    float nb[6];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) nb[i] = pe[((6 * (o + 1) + i) % NF) * 64];
-                    f32x2 wn[8][3];
-                    const int bpn = nsb + (o + 1 < a.L ? o + 1 : o) * (8 * 384 * 4);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) wn[t][i] = LDP(srs, vp2, bpn + (t * 3 + i) * 512);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        f32x16 c = base[t];
-                        c = MFMA(wr[t][0][0], sb[0], c);
-                        c = MFMA(wr[t][0][1], sb[1], c);
-                        c = MFMA(wr[t][1][0], sb[2], c);
-                        c = MFMA(wr[t][1][1], sb[3], c);
-                        c = MFMA(wr[t][2][0], sb[4], c);
-                        c = MFMA(wr[t][2][1], sb[5], c);
-                        base[t] = c;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) sb[i] = nb[i];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) wr[t][i] = wn[t][i];
-                    }
-                    SCHED_FENCE();
+                    sc0 = sc1 * 2.f;
                 }
                 {
-                    // after the loop sb[0..2] hold the raw position (features 6L..6L+2)
-                    const int bp = nsb + a.L * (8 * 384 * 4);
-                    f32x4 q[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) q[t] = LDQ(srs, vq, bp + t * 1024);
+                    // tail: raw x, y, z; the refills run on into the u / layer-2 quads of this block
+                    const int qb = nsb + (Lp * 24 + LIDF_RING) * 1024;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
+                        const f32x4 q = ring[t];
+                        ring[t] = LDQ(srs, vq, qb + t * 1024);
                         f32x16 c = base[t];
-                        c = MFMA(q[t][0], sb[0], c);
-                        c = MFMA(q[t][1], sb[1], c);
-                        c = MFMA(q[t][2], sb[2], c);
+                        c = MFMA(q[0], px, c);
+                        c = MFMA(q[1], py, c);
+                        c = MFMA(q[2], pz, c);
                         base[t] = c;
+                        SCHED_FENCE();
                     }
-                    SCHED_FENCE();
                 }
             } else {
 #pragma unroll
@@ -385,14 +507,12 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                 const float* xrow = a.X + (size_t)pc * a.ldx + (h ? a.KH : 0);
                 const int nvalid = h ? (a.D - a.KH) : a.KH;
                 const int sbias = (h == 0 && a.has_bias) ? a.KH : -1;
+                // where the stream continues after this layer-1 section
+                const int after_l1 = MODE == LIDF_MODE_L1ONLY ? next_blk : nsb + l1_bytes;
                 float bc[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     bc[jj] = jj < nvalid ? xrow[jj] : (jj == sbias ? 1.f : 0.f);
-                f32x4 qc[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) qc[t] = LDQ(srs, vq, nsb + t * 1024);
-                SCHED_FENCE();
                 for (int kq = 0; kq < a.KQ1; ++kq) {
                     float bn[4];
 #pragma unroll
@@ -400,24 +520,21 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                         const int s = 4 * (kq + 1) + jj;
                         bn[jj] = s < nvalid ? xrow[s] : (s == sbias ? 1.f : 0.f);
                     }
-                    f32x4 qn[8];
-                    const int kn = kq + 1 < a.KQ1 ? kq + 1 : kq;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) qn[t] = LDQ(srs, vq, nsb + (kn * 8 + t) * 1024);
+                    const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
+                        const f32x4 q = ring[t];
+                        ring[t] = LDQ(srs, vq, qb + t * 1024);
                         f32x16 c = base[t];
-                        c = MFMA(qc[t][0], bc[0], c);
-                        c = MFMA(qc[t][1], bc[1], c);
-                        c = MFMA(qc[t][2], bc[2], c);
-                        c = MFMA(qc[t][3], bc[3], c);
+                        c = MFMA(q[0], bc[0], c);
+                        c = MFMA(q[1], bc[1], c);
+                        c = MFMA(q[2], bc[2], c);
+                        c = MFMA(q[3], bc[3], c);
                         base[t] = c;
+                        SCHED_FENCE();
                     }
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) bc[jj] = bn[jj];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) qc[t] = qn[t];
-                    SCHED_FENCE();
                 }
             }
 
@@ -436,47 +553,21 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                     }
                 }
             } else {
+                PROF(3)
                 // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
                 float val = a.init[net];
-                const int us = nsb + a.l1_floats * 4;
-                const int sec = us + LIDF_U_FLOATS * 4;
+                const int pass_base = nsb + l1_bytes;
                 const float* ax = a.aux + net * LIDF_AUX_FLOATS;
                 const int npass = a.npass[net];
                 for (int pass = 0; pass < npass; ++pass) {
-                    // layer-1 activation: lrelu(base + u * val)  (u = 0 for IMNet)
-                    const float ob = h ? 0.f : val;
-                    const f32x4 u0 = LDQ(srs, vq, us);
-                    const f32x4 u1 = LDQ(srs, vq, us + 1024);
-                    f32x16 H1[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const float uf = t < 4 ? u0[t & 3] : u1[t & 3];
-                        H1[t] = MFMA(uf, ob, base[t]);
-                        lrelu16(H1[t]);
-                    }
-                    f32x16 H2[4];
-                    chain_layer<4, 8, 2>(srs, sec, lane, one_b, H1, H2);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) lrelu16(H2[t]);
-                    f32x16 H3[2];
-                    chain_layer<2, 4, 3>(srs, sec + LIDF_L2_FLOATS * 4, lane, one_b, H2, H3);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) lrelu16(H3[t]);
-                    // layer 4: 64 -> 1 on the VALU, halves combined with one cross-half shuffle
-                    float y = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 w = *(const f32x4*)(ax + h * 32 + 4 * i);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int s = 4 * i + k;
-                            y = fmaf(w[k], H3[s / 16][s % 16], y);
-                        }
-                    }
-                    y += __shfl_xor(y, 32);
-                    y += ax[64];
-                    val += y;
+                    const int wrap_base = pass + 1 < npass ? pass_base : next_blk;
+                    val += decoder_pass(srs, vq, ring, pass_base, wrap_base, base, val, h, one_b, ax
+#ifdef LIDF_PROFILE
+                                        , prof_t, prof_acc
+#endif
+                                        );
                 }
+                PROF(5)
                 // ---------------- outputs ----------------
                 if (valid && h == 0) {
                     const float o = out_act(val, a.sigmoid[net]);
@@ -484,23 +575,34 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                     if constexpr (MODE == LIDF_MODE_FUSED) {
                         if (a.is_offset[net]) {
                             // pipeline.py:437-439, same operation order in f32
+                            const float ex = __fmul_rn(cur.dx, cur.te);
+                            const float ey = __fmul_rn(cur.dy, cur.te);
+                            const float ez = __fmul_rn(cur.dz, cur.te);
                             float s = __fadd_rn(__fmul_rn(o, a.rscale), a.r0);
                             s = __fmul_rn(__fmul_rn(s, a.sqrt3), a.part_size);
-                            a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(s, dx));
-                            a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(s, dy));
-                            a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(s, dz));
+                            a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(s, cur.dx));
+                            a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(s, cur.dy));
+                            a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(s, cur.dz));
                         }
                     }
                 }
             }
         }
+        PROF(0)
+        if constexpr (MODE == LIDF_MODE_FUSED) {
+            cur = nxt;
+            nxt.ray = nx2.ray;
+            nxt.vid = nx2.vid;
+            nxt.te = nx2.te;
+            nxt.tl = nx2.tl;
+        }
     }
+    PROF_DUMP
 }
 
 template <int MODE>
 static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
-    size_t lds = MODE == LIDF_MODE_FUSED ? (size_t)4 * (6 * a.L + 3) * 64 * sizeof(float) : 0;
-    hipLaunchKernelGGL((lidf_points_kernel<MODE>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lidf_points_kernel<MODE>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

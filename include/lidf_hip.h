@@ -107,7 +107,7 @@ typedef struct LidfQueryArgs {
     /* model */
     const LidfDecoder* prob;   /* prob_dec  (IMNet)                               */
     const LidfDecoder* off;    /* offset_dec (IEF or IMNet)                       */
-    int32_t multires;          /* opt.model.multires (8); 0 = identity (pos_encode False) */
+    int32_t multires;          /* opt.model.multires (8); 0 = identity (pos_encode False); <= 16 */
     int32_t multires_views;    /* opt.model.multires_views (4); 0 = identity      */
     int32_t roi_inp_bbox;      /* opt.model.roi_inp_bbox (8)                      */
     int32_t pos_rel;           /* opt.model.intersect_pos_type == 'rel'           */
