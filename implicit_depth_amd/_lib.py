@@ -46,6 +46,30 @@ class LidfQueryArgs(C.Structure):
     ]
 
 
+class LidfPointNet(C.Structure):
+    """struct LidfPointNet (include/lidf_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "w_p1", "b_p1", "w_p2", "b_p2", "w_v1", "b_v1", "w_p3", "b_p3", "w_p4", "b_p4", "w_v2", "b_v2")]
+
+
+class LidfRefineArgs(C.Structure):
+    """struct LidfRefineArgs (include/lidf_hip.h)."""
+    _fields_ = [
+        ("n_rays", C.c_int64), ("ray_dir", C.c_void_p), ("ray_bid", C.c_void_p),
+        ("ray_flat", C.c_void_p), ("pred_pos", C.c_void_p), ("max_pair_id", C.c_void_p),
+        ("pair_vox", C.c_void_p), ("n_pairs", C.c_int64), ("n_vox", C.c_int64),
+        ("voxel_bound", C.c_void_p), ("voxel_bid", C.c_void_p), ("rgb_img", C.c_void_p),
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("rayfeat", C.c_void_p), ("n_valid", C.c_int64), ("valid_inp", C.c_void_p),
+        ("valid_vox", C.c_void_p), ("pnet", C.POINTER(LidfPointNet)),
+        ("off", C.POINTER(LidfDecoder)), ("multires", C.c_int32), ("multires_views", C.c_int32),
+        ("pos_rel", C.c_int32), ("pnet_pos_rel", C.c_int32),
+        ("offset_range0", C.c_float), ("offset_range1", C.c_float),
+        ("pred_pos_out", C.c_void_p), ("end_voxel_id", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 _P, _I64, _I, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/lidf_hip.h declares
@@ -68,6 +92,10 @@ SIGNATURES = {
     "lidf_exclusive_scan_i32": (C.c_int, [_P, _I64, _P, _P, _SZ, _P]),
     "lidf_pcl_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
     "lidf_pcl_aabb_last_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "lidf_pointnet_workspace_bytes": (_SZ, [_I64, _I64]),
+    "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
 }
 
 _lib = None

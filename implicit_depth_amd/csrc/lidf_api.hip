@@ -24,6 +24,14 @@ hipError_t lidf_launch_pcl_aabb_dense(const float*, const float*, const int*, co
 hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, const int*,
                                      long long, long long, int*, hipStream_t);
 hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
+hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, long long,
+                                   const float*, const int*, long long, const int*, const int*,
+                                   const float*, long long, const float*, int, int, int, int, int,
+                                   long long, float*, int*, float*, int, int*, hipStream_t);
+hipError_t lidf_launch_refine_gather(const float*, const int*, long long, float*, int, hipStream_t);
+hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, float, float,
+                                     long long, float*, hipStream_t);
 }
 
 #define LIDF_ABI_VERSION 1
@@ -71,6 +79,8 @@ static L1Map rows_map(int n0, int c0, int n1, int c1, int add_bias) {
     m.KH = (m.D + 1) / 2;
     m.KQ1 = (m.KH + 1 + 3) / 4;
     m.add_bias = add_bias;
+    m.nt = 8;
+    m.nout = 256;
     return m;
 }
 
@@ -438,5 +448,198 @@ LIDF_API int lidf_pcl_aabb_last_f32(const float* pcl_pos, const float* voxel_bou
     if (!last_vox) return LIDF_ERR_BAD_ARG;
     CHECK_HIP(lidf_launch_pcl_aabb_last(pcl_pos, voxel_bound, pcl_bid, voxel_bid, n_pts, n_vox,
                                         last_vox, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- PointNet2Stage --------------------------------------------------------------------------
+struct LinSpec {
+    const float *w, *b;    // [nout, ldw] weight, bias (nullable)
+    int nout, ldw, c0, k;  // uses weight columns [c0, c0+k)
+};
+
+static size_t lin_stream_bytes(int k, int nt) {
+    L1Map m = rows_map(k, 0, 0, 0, 1);
+    return align_up((size_t)m.KQ1 * nt * 1024, 256);
+}
+
+// one linear layer through lidf_linear_kernel; `stream_buf` must hold lin_stream_bytes(k, nt)
+static int run_linear(const LinSpec& L, const float* X, long long ldx, long long n,
+                      const float* addrows, const int* addidx, int relu, float* out,
+                      long long ld_out, float* pool, const int* poolidx, float* stream_buf,
+                      int cus, hipStream_t st) {
+    if (n <= 0) return LIDF_OK;
+    const int nt = L.nout / 32;
+    L1Map m = rows_map(L.k, L.c0, 0, 0, L.b ? 1 : 0);
+    m.nt = nt;
+    m.nout = L.nout;
+    StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
+    NetW nw = {};
+    nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.is_ief = 0; nw.dcore = L.ldw;
+    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    LinearArgs a = {};
+    a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
+    a.D = m.D; a.KH = m.KH; a.has_bias = L.b ? 1 : 0;
+    a.addrows = addrows; a.addidx = addidx; a.ld_add = L.nout; a.relu = relu;
+    a.out = out; a.ld_out = ld_out; a.pool = pool; a.poolidx = poolidx; a.ld_pool = L.nout;
+    long long nt128 = (n + 127) / 128;
+    int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
+    CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
+    return LIDF_OK;
+}
+
+struct PnetWs {
+    size_t s[7], f1, f2, pool1, g1, gpart, f4, pool2, total;
+};
+static PnetWs pnet_ws(int64_t n, int64_t v) {
+    PnetWs w;
+    size_t o = 0;
+    const int ks[7] = {6, 32, 64, 64, 64, 128, 128};
+    const int nts[7] = {1, 2, 2, 4, 4, 4, 4};
+    for (int i = 0; i < 7; ++i) { w.s[i] = o; o += lin_stream_bytes(ks[i], nts[i]); }
+    const size_t N = (size_t)(n > 0 ? n : 1), V = (size_t)(v > 0 ? v : 1);
+    w.f1 = o;    o += align_up(N * 32 * 4, 256);
+    w.f2 = o;    o += align_up(N * 64 * 4, 256);
+    w.pool1 = o; o += align_up(V * 64 * 4, 256);
+    w.g1 = o;    o += align_up(V * 64 * 4, 256);
+    w.gpart = o; o += align_up(V * 128 * 4, 256);
+    w.f4 = o;    o += align_up(N * 128 * 4, 256);
+    w.pool2 = o; o += align_up(V * 128 * 4, 256);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_pointnet_workspace_bytes(int64_t n_pts, int64_t n_vox) {
+    return pnet_ws(n_pts, n_vox).total;
+}
+
+LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
+                               int64_t n, int64_t n_vox, float* out, void* workspace,
+                               size_t workspace_bytes, lidf_stream_t stream) {
+    if (!w || n < 0 || n_vox < 0) return LIDF_ERR_BAD_ARG;
+    if (n_vox == 0) return LIDF_OK;
+    if (!out || (n > 0 && (!inp || !vox))) return LIDF_ERR_BAD_ARG;
+    if (!w->w_p1 || !w->b_p1 || !w->w_p2 || !w->b_p2 || !w->w_v1 || !w->b_v1 || !w->w_p3 ||
+        !w->b_p3 || !w->w_p4 || !w->b_p4 || !w->w_v2 || !w->b_v2)
+        return LIDF_ERR_BAD_ARG;
+    PnetWs ws = pnet_ws(n, n_vox);
+    if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    float* f1 = (float*)(base + ws.f1);
+    float* f2 = (float*)(base + ws.f2);
+    float* pool1 = (float*)(base + ws.pool1);
+    float* g1 = (float*)(base + ws.g1);
+    float* gpart = (float*)(base + ws.gpart);
+    float* f4 = (float*)(base + ws.f4);
+    float* pool2 = (float*)(base + ws.pool2);
+    int cus, rc;
+    if ((rc = cu_count(&cus))) return rc;
+    // torch_scatter fills voxels without points with 0; values are post-ReLU so 0 is the identity
+    CHECK_HIP(hipMemsetAsync(pool1, 0, (size_t)n_vox * 64 * 4, st));
+    CHECK_HIP(hipMemsetAsync(pool2, 0, (size_t)n_vox * 128 * 4, st));
+    auto S = [&](int i) { return (float*)(base + ws.s[i]); };
+    // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
+    if ((rc = run_linear({w->w_p1, w->b_p1, 32, 6, 0, 6}, inp, 6, n, nullptr, nullptr, 1, f1, 32,
+                         nullptr, nullptr, S(0), cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_p2, w->b_p2, 64, 32, 0, 32}, f1, 32, n, nullptr, nullptr, 1, f2, 64,
+                         pool1, vox, S(1), cus, st)))
+        return rc;
+    // occ_voxel_feat = relu(vox_lin1(pool1))
+    if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, n_vox, nullptr, nullptr, 1,
+                         g1, 64, nullptr, nullptr, S(2), cus, st)))
+        return rc;
+    // point_lin3(cat(voxel feat, point_feat2)) = W3[:, :64] g1[vox] + W3[:, 64:] f2 + b3
+    if ((rc = run_linear({w->w_p3, nullptr, 128, 128, 0, 64}, g1, 64, n_vox, nullptr, nullptr, 0,
+                         gpart, 128, nullptr, nullptr, S(3), cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 64, 64}, f2, 64, n, gpart, vox, 1, f4, 128,
+                         nullptr, nullptr, S(4), cus, st)))
+        return rc;
+    // point_feat5 = relu(point_lin4(.)) pooled per voxel; out = relu(vox_lin2(pool2))
+    if ((rc = run_linear({w->w_p4, w->b_p4, 128, 128, 0, 128}, f4, 128, n, nullptr, nullptr, 1,
+                         nullptr, 0, pool2, vox, S(5), cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, pool2, 128, n_vox, nullptr, nullptr,
+                         1, out, 128, nullptr, nullptr, S(6), cus, st)))
+        return rc;
+    return LIDF_OK;
+}
+
+// ---- stage-2 refinement ----------------------------------------------------------------------
+struct RefineWs {
+    size_t pnet_inp, pnet_vox, inp_embed, end_voxel, vox_feat, off, pnet, dec, total;
+};
+static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
+    RefineWs w;
+    size_t o = 0;
+    const size_t n = (size_t)(R + Nv > 0 ? R + Nv : 1), r = (size_t)(R > 0 ? R : 1);
+    w.pnet_inp = o;  o += align_up(n * 6 * 4, 256);
+    w.pnet_vox = o;  o += align_up(n * 4, 256);
+    w.inp_embed = o; o += align_up(r * D * 4, 256);
+    w.end_voxel = o; o += align_up(r * 4, 256);
+    w.vox_feat = o;  o += align_up((size_t)(V > 0 ? V : 1) * 128 * 4, 256);
+    w.off = o;       o += align_up(r * 4, 256);
+    w.pnet = o;      o += align_up(lidf_pointnet_workspace_bytes(R + Nv, V), 256);
+    w.dec = o;       o += align_up(lidf_decoders_workspace_bytes(R, D), 256);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox) {
+    return refine_ws(n_rays, n_valid, n_vox, 256 + 2 * (3 + 6 * 16)).total;
+}
+
+LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
+    if (!q) return LIDF_ERR_BAD_ARG;
+    const int64_t R = q->n_rays, Nv = q->n_valid, V = q->n_vox, P = q->n_pairs;
+    if (R < 0 || Nv < 0 || V < 0 || P < 0) return LIDF_ERR_BAD_ARG;
+    if (q->multires < 0 || q->multires > 16 || q->multires_views < 0 || q->multires_views > 16)
+        return LIDF_ERR_UNSUPPORTED;
+    if (R == 0) return LIDF_OK;
+    if (V == 0) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if (!q->off || !q->pnet) return LIDF_ERR_BAD_ARG;
+    if ((rc = check_decoder(q->off))) return rc;
+    if (!q->ray_dir || !q->ray_bid || !q->ray_flat || !q->pred_pos || !q->max_pair_id ||
+        !q->voxel_bound || !q->voxel_bid || !q->rgb_img || !q->rayfeat || !q->pred_pos_out ||
+        (P > 0 && !q->pair_vox) || (Nv > 0 && (!q->valid_inp || !q->valid_vox)))
+        return LIDF_ERR_BAD_ARG;
+    const int E = 3 + 6 * q->multires, Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E + Ed;
+    RefineWs w = refine_ws(R, Nv, V, D);
+    if (!q->workspace || q->workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)q->workspace;
+    float* pnet_inp = (float*)(ws + w.pnet_inp);
+    int* pnet_vox = (int*)(ws + w.pnet_vox);
+    float* inp_embed = (float*)(ws + w.inp_embed);
+    int* end_voxel = q->end_voxel_id ? q->end_voxel_id : (int*)(ws + w.end_voxel);
+    float* vox_feat = (float*)(ws + w.vox_feat);
+    float* off = (float*)(ws + w.off);
+    // final_pnet_inp = cat(valid points, predicted points), final_revidx likewise
+    // (pipeline.py:1007-1008)
+    if (Nv > 0) {
+        CHECK_HIP(hipMemcpyAsync(pnet_inp, q->valid_inp, (size_t)Nv * 6 * 4,
+                                 hipMemcpyDeviceToDevice, st));
+        CHECK_HIP(hipMemcpyAsync(pnet_vox, q->valid_vox, (size_t)Nv * 4, hipMemcpyDeviceToDevice,
+                                 st));
+    }
+    CHECK_HIP(lidf_launch_refine_prep(q->pred_pos, (const long long*)q->max_pair_id, q->pair_vox, P,
+                                      q->voxel_bound, q->voxel_bid, V, q->ray_bid, q->ray_flat,
+                                      q->rgb_img, (long long)q->height * q->width, q->rayfeat,
+                                      128 + Ed, q->multires_views, q->multires, q->pnet_pos_rel,
+                                      q->pos_rel, R, pnet_inp + (size_t)Nv * 6, pnet_vox + Nv,
+                                      inp_embed, D, end_voxel, st));
+    if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
+                                lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
+        return rc;
+    CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
+    if ((rc = lidf_decoders_f32(inp_embed, R, D, D, nullptr, q->off, nullptr, off, ws + w.dec,
+                                lidf_decoders_workspace_bytes(R, D), stream)))
+        return rc;
+    CHECK_HIP(lidf_launch_refine_finish(q->pred_pos, off, q->ray_dir, q->offset_range0,
+                                        q->offset_range1 - q->offset_range0, R, q->pred_pos_out,
+                                        st));
     return LIDF_OK;
 }

@@ -39,7 +39,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LIDF_AUX_FLOATS 72  // per net: w4 by (half, reg) [2][32], b4 at [64]
 #define LIDF_MAX_L_FUSED 16 // octaves of the in-kernel positional encoding
 
-enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2 };
+enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_LINEAR = 3 };
 
 // One decoder's parameters as the packer sees them.
 struct NetW {
@@ -57,6 +57,8 @@ struct L1Map {
     int KH;        // ceil(D/2): lanes 0..31 take columns [0,KH), lanes 32..63 take [KH,D)
     int KQ1;       // quads per tile = ceil((KH+1)/4)
     int add_bias;  // bias k-step carries b1 (+ IEF constant) ; else 0
+    int nt;        // output tiles per k-quad in the rows modes (8 for the decoders' layer 1)
+    int nout;      // rows of w1 (outputs); tiles beyond it are zero
     // fused mode
     int L;         // octaves
     int enter_c0;  // w1 column of enter-position embedding
@@ -73,7 +75,7 @@ struct StreamLayout {
 
 static inline int lidf_l1_quads(int mode, const L1Map& m) {
     if (mode == LIDF_MODE_FUSED) return 24 * ((m.L + 1) / 2) + 8;
-    return m.KQ1 * 8;
+    return m.KQ1 * m.nt;
 }
 
 static inline StreamLayout lidf_make_layout(int nets, int mode, const L1Map& m) {
@@ -81,7 +83,7 @@ static inline StreamLayout lidf_make_layout(int nets, int mode, const L1Map& m) 
     s.nets = nets;
     s.mode = mode;
     s.l1_quads = lidf_l1_quads(mode, m);
-    s.net_quads = s.l1_quads + (mode == LIDF_MODE_L1ONLY ? 0 : LIDF_PASS_QUADS);
+    s.net_quads = s.l1_quads + (mode == LIDF_MODE_L1ONLY || mode == LIDF_MODE_LINEAR ? 0 : LIDF_PASS_QUADS);
     s.total = nets * s.net_quads * 256;
     return s;
 }
@@ -116,4 +118,22 @@ struct PointsArgs {
     int pos_rel, L;
     float r0, rscale, sqrt3, part_size;
     float* pair_pred_pos;   // [n,3]
+};
+
+// Arguments of the generic linear-layer kernel (lidf_linear.hip): out = epilogue(X W^T + b).
+struct LinearArgs {
+    const float* stream;   // rows-mode layer-1 section with `nt` tiles: quad (kq*nt + t)
+    int kq1;
+    const float* X;        // [n, D] rows, row stride ldx
+    long long ldx, n;
+    int D, KH, has_bias;
+    const float* addrows;  // optional: += addrows[addidx[row], 0:32*nt]
+    const int* addidx;
+    int ld_add;
+    int relu;
+    float* out;            // optional store, row stride ld_out
+    long long ld_out;
+    float* pool;           // optional: pool[poolidx[row], f] = max(pool[..], value); needs relu
+    const int* poolidx;
+    int ld_pool;
 };

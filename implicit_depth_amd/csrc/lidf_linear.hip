@@ -1,0 +1,119 @@
+// lidf_linear.hip — generic f32 MFMA linear layer with fused epilogues, used by the PointNet2Stage
+// forward (models/pointnet.py:22-38) and by the stage-2 refinement query.
+//
+//   out[row, 0:32*NT] = epilogue( X[row, 0:D] W^T + b )
+//   epilogue: (+ addrows[addidx[row]])  ->  (relu)  ->  (store)  and/or  (atomic max into a pool)
+//
+// Same transposed 32x32x2 f32 MFMA formulation and the same packed weight-stream format as the
+// decoder kernel (lidf_device.h, rows mode with NT output tiles): one wavefront owns 32 rows, lane
+// = row, the two half-waves split the K columns. The max-pool epilogue replaces
+// torch_scatter.scatter(..., reduce='max') (models/pointnet.py:27,35): values are post-ReLU
+// (>= 0), so integer atomicMax on the bit pattern is an exact, order-independent float max, and a
+// zero-initialised pool reproduces torch_scatter's 0 for a voxel without points.
+#include "lidf_device.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define LDQ(rs, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
+
+template <int NT>
+__global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, a.kq1 * NT * 1024, 0x00020000);
+    const int vq = lane * 16;
+    const long long ntile = (a.n + 127) / 128;
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        if (tile * 128 + wave * 32 >= a.n) continue;
+        const long long p = tile * 128 + wave * 32 + col;
+        const bool valid = p < a.n;
+        const long long pc = valid ? p : a.n - 1;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        }
+        const float* xrow = a.X + (size_t)pc * a.ldx + (h ? a.KH : 0);
+        const int nvalid = h ? (a.D - a.KH) : a.KH;
+        const int sbias = (h == 0 && a.has_bias) ? a.KH : -1;
+        float bc[4];
+        f32x4 qc[NT];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bc[jj] = jj < nvalid ? xrow[jj] : (jj == sbias ? 1.f : 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qc[t] = LDQ(srs, vq, t * 1024);
+        for (int kq = 0; kq < a.kq1; ++kq) {
+            float bn[4];
+            f32x4 qn[NT];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int s = 4 * (kq + 1) + jj;
+                bn[jj] = s < nvalid ? xrow[s] : (s == sbias ? 1.f : 0.f);
+            }
+            const int kn = kq + 1 < a.kq1 ? kq + 1 : kq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qn[t] = LDQ(srs, vq, (kn * NT + t) * 1024);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 c = acc[t];
+                c = MFMA(qc[t][0], bc[0], c);
+                c = MFMA(qc[t][1], bc[1], c);
+                c = MFMA(qc[t][2], bc[2], c);
+                c = MFMA(qc[t][3], bc[3], c);
+                acc[t] = c;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bc[jj] = bn[jj];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qc[t] = qn[t];
+            SCHED_FENCE();
+        }
+        if (!valid) continue;
+        // ---- epilogue: this lane holds, per tile t and group g, features 32t + 8g + 4h + {0..3}
+        const float* ar = a.addrows ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
+        float* op = a.out ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
+        int* pp = a.pool ? (int*)a.pool + (size_t)a.poolidx[p] * a.ld_pool + 4 * h : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * g + i];
+                if (ar) {
+                    const f32x4 r = *(const f32x4*)(ar + t * 32 + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += r[i];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (op) *(f32x4*)(op + t * 32 + 8 * g) = v;
+                if (pp) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (v[i] > 0.f) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(v[i]));
+                }
+            }
+        }
+    }
+}
+
+extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a, int grid, hipStream_t st) {
+    if (a.n <= 0) return hipSuccess;
+    dim3 g(grid), b(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(lidf_linear_kernel<1>, g, b, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(lidf_linear_kernel<2>, g, b, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(lidf_linear_kernel<4>, g, b, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -93,9 +93,10 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
             const int col = (half ? m.leave_c0 : m.enter_c0) + feat;
             return n.w1[(size_t)(32 * t + c32) * n.ld1 + col];
         }
-        const int kq = quad / 8, t = quad % 8;
+        const int kq = quad / m.nt, t = quad % m.nt;
         const int s = 4 * kq + jj;
         const int out = 32 * t + c32;
+        if (out >= m.nout) return 0.f;
         const int x = s + half * m.KH;  // operand column
         const int nvalid = half ? (m.D - m.KH) : m.KH;
         if (s < nvalid) {
@@ -137,7 +138,7 @@ __global__ void lidf_pack_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m
     NetW nets[2] = {net0, net1};
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < lay.total) stream[e] = stream_value(lay, nets, m, e);
-    if (lay.mode != LIDF_MODE_L1ONLY && e < lay.nets * LIDF_AUX_FLOATS) {
+    if (lay.mode != LIDF_MODE_L1ONLY && lay.mode != LIDF_MODE_LINEAR && e < lay.nets * LIDF_AUX_FLOATS) {
         int sec = e / LIDF_AUX_FLOATS, i = e % LIDF_AUX_FLOATS;
         const NetW& n = nets[sec];
         float v = 0.f;

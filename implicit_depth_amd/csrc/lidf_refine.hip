@@ -1,0 +1,148 @@
+// lidf_refine.hip — per-ray kernels of the stage-2 refinement query
+// (RefineNet.get_pred_refine, models/pipeline.py:922-1030), built with -ffp-contract=off.
+#include "lidf_device.h"
+
+// inside test of extensions/pcl_aabb/pcl_aabb_cuda_kernel.cu:23-44 (inclusive bounds)
+__device__ __forceinline__ bool inside_box(float x, float y, float z, const float* vb) {
+    if ((x < vb[0]) || (x > vb[3])) return false;
+    if ((y < vb[1]) || (y > vb[4])) return false;
+    if ((z < vb[2]) || (z > vb[5])) return false;
+    return true;
+}
+
+// One thread per ray:
+//   end_voxel = max( voxel of the arg-max pair (0 for a ray without pairs: the dummy row,
+//                    pipeline.py:941-943), largest occupied voxel of the same image containing
+//                    pred_pos (pcl_aabb + scatter max, :939-944) )
+//   pnet_inp  = [pred_pos - centre(end_voxel) | rgb(pixel)]   (:975-986, pnet_pos_type 'rel')
+//   inp_embed[:, 128:] = [ROI feature | embed(pos) | embed(dir)]   (:947-969, :1019-1026);
+//   columns 0..127 (voxel feature) are filled after the PointNet pass.
+__global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
+                                        const long long* __restrict__ max_pair_id,
+                                        const int* __restrict__ pair_vox, long long P,
+                                        const float* __restrict__ vbound,
+                                        const int* __restrict__ vox_bid, long long V,
+                                        const int* __restrict__ ray_bid,
+                                        const int* __restrict__ ray_flat,
+                                        const float* __restrict__ rgb, long long hw,
+                                        const float* __restrict__ rayfeat, int ld_rf, int Lv,
+                                        int L, int pnet_rel, int pos_rel, long long R,
+                                        float* __restrict__ pnet_inp, int* __restrict__ pnet_vox,
+                                        float* __restrict__ inp_embed, int ld_e,
+                                        int* __restrict__ end_voxel) {
+    __shared__ float s_vb[256 * 6];
+    __shared__ int s_bid[256];
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < R;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int bid = -1, ev = 0;
+    if (live) {
+        x = pred_pos[3 * r];
+        y = pred_pos[3 * r + 1];
+        z = pred_pos[3 * r + 2];
+        bid = ray_bid[r];
+        const long long m = max_pair_id[r];
+        ev = (m >= 0 && m < P) ? pair_vox[m] : 0;
+    }
+    for (long long v0 = 0; v0 < V; v0 += 256) {
+        const int nv = (int)min((long long)256, V - v0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nv * 6; k += blockDim.x) s_vb[k] = vbound[6 * v0 + k];
+        for (int k = threadIdx.x; k < nv; k += blockDim.x) s_bid[k] = vox_bid[v0 + k];
+        __syncthreads();
+        if (!live) continue;
+        for (int j = 0; j < nv; ++j)
+            if (s_bid[j] == bid && inside_box(x, y, z, s_vb + 6 * j)) ev = max(ev, (int)(v0 + j));
+    }
+    if (!live) return;
+    const float* vb = vbound + 6 * (size_t)ev;
+    const float cx = (vb[0] + vb[3]) / 2.f, cy = (vb[1] + vb[4]) / 2.f, cz = (vb[2] + vb[5]) / 2.f;
+    end_voxel[r] = ev;
+    pnet_vox[r] = ev;
+    float* pi = pnet_inp + 6 * r;
+    pi[0] = pnet_rel ? x - cx : x;
+    pi[1] = pnet_rel ? y - cy : y;
+    pi[2] = pnet_rel ? z - cz : z;
+    const float* px = rgb + (size_t)bid * 3 * hw + ray_flat[r];
+    pi[3] = px[0];
+    pi[4] = px[hw];
+    pi[5] = px[2 * hw];
+    float* e = inp_embed + (size_t)r * ld_e;
+    const float* rf = rayfeat + (size_t)r * ld_rf;
+    for (int i = 0; i < 128; ++i) e[128 + i] = rf[i];
+    const float q[3] = {pos_rel ? x - cx : x, pos_rel ? y - cy : y, pos_rel ? z - cz : z};
+    float* pe = e + 256;
+    for (int i = 0; i < 3; ++i) pe[i] = q[i];
+    for (int l = 0; l < L; ++l) {
+        const float f = (float)(1 << l);
+        for (int i = 0; i < 3; ++i) {
+            pe[3 + 6 * l + i] = sinf(q[i] * f);
+            pe[3 + 6 * l + 3 + i] = cosf(q[i] * f);
+        }
+    }
+    const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
+    for (int i = 0; i < Ed; ++i) e[256 + E + i] = rf[128 + i];
+}
+
+extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long long* max_pair_id,
+                                              const int* pair_vox, long long P, const float* vbound,
+                                              const int* vox_bid, long long V, const int* ray_bid,
+                                              const int* ray_flat, const float* rgb, long long hw,
+                                              const float* rayfeat, int ld_rf, int Lv, int L,
+                                              int pnet_rel, int pos_rel, long long R,
+                                              float* pnet_inp, int* pnet_vox, float* inp_embed,
+                                              int ld_e, int* end_voxel, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
+                       st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid,
+                       ray_flat, rgb, hw, rayfeat, ld_rf, Lv, L, pnet_rel, pos_rel, R, pnet_inp,
+                       pnet_vox, inp_embed, ld_e, end_voxel);
+    return hipGetLastError();
+}
+
+// inp_embed[r, 0:128] = occ_voxel_feat[end_voxel[r]]  (pipeline.py:1016); one thread per float4
+__global__ void lidf_refine_gather_kernel(const float* __restrict__ vox_feat,
+                                          const int* __restrict__ end_voxel, long long R,
+                                          float* __restrict__ inp_embed, int ld_e) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 32) return;
+    const long long r = i / 32;
+    const int c = (int)(i % 32) * 4;
+    const f32x4 v = *(const f32x4*)(vox_feat + (size_t)end_voxel[r] * 128 + c);
+    float* e = inp_embed + (size_t)r * ld_e + c;
+    e[0] = v[0];
+    e[1] = v[1];
+    e[2] = v[2];
+    e[3] = v[3];
+}
+
+// pred_pos_refine = pred_pos + (off*(r1-r0) + r0) * ray_dir  (pipeline.py:1028-1029)
+__global__ void lidf_refine_finish_kernel(const float* __restrict__ pred_pos,
+                                          const float* __restrict__ off,
+                                          const float* __restrict__ ray_dir, float r0, float rs,
+                                          long long R, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float s = off[r] * rs + r0;
+    out[3 * r] = pred_pos[3 * r] + s * ray_dir[3 * r];
+    out[3 * r + 1] = pred_pos[3 * r + 1] + s * ray_dir[3 * r + 1];
+    out[3 * r + 2] = pred_pos[3 * r + 2] + s * ray_dir[3 * r + 2];
+}
+
+extern "C" hipError_t lidf_launch_refine_gather(const float* vox_feat, const int* end_voxel,
+                                                long long R, float* inp_embed, int ld_e,
+                                                hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_gather_kernel, dim3((unsigned)((R * 32 + 255) / 256)),
+                       dim3(256), 0, st, vox_feat, end_voxel, R, inp_embed, ld_e);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_refine_finish(const float* pred_pos, const float* off,
+                                                const float* ray_dir, float r0, float rs,
+                                                long long R, float* out, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_finish_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
+                       st, pred_pos, off, ray_dir, r0, rs, R, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,98 @@
+"""pointnet.py — host-side mirror of the reference's models/pointnet.py PointNet2Stage.
+
+Same constructor signature, forward signature `forward(inp_feat, vox2point_idx)` and parameter
+names (`point_lin1..4`, `vox_lin1..2`) as the reference (models/pointnet.py:7-38), so the
+checkpoints' `pnet_model` / `pnet_model_refine` entries load unchanged
+(trainers/train_lidf.py:74-75, train_refine.py:364-366). On CUDA f32 inputs without autograd the
+forward runs liblidf_hip.so's lidf_pointnet_f32 (MFMA linear layers with the two scatter-max
+poolings fused as atomic-max epilogues); with autograd it runs the same maths as torch ops on the
+same device; CPU tensors are refused.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _segment_max(x, idx, n):
+    """torch_scatter.scatter(x, idx, dim=0, reduce='max') for x >= 0: rows without points are 0."""
+    out = torch.zeros((n, x.shape[1]), dtype=x.dtype, device=x.device)
+    return out.scatter_reduce(0, idx.view(-1, 1).expand_as(x), x, reduce="amax", include_self=True)
+
+
+def pointnet_struct(mod, keep):
+    def p(t):
+        t = t.detach()
+        if t.dtype != torch.float32:
+            raise RuntimeError("lidf_hip: float32 parameters required")
+        t = t.contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    s = _lib.LidfPointNet()
+    s.w_p1, s.b_p1 = p(mod.point_lin1.weight), p(mod.point_lin1.bias)
+    s.w_p2, s.b_p2 = p(mod.point_lin2.weight), p(mod.point_lin2.bias)
+    s.w_v1, s.b_v1 = p(mod.vox_lin1.weight), p(mod.vox_lin1.bias)
+    s.w_p3, s.b_p3 = p(mod.point_lin3.weight), p(mod.point_lin3.bias)
+    s.w_p4, s.b_p4 = p(mod.point_lin4.weight), p(mod.point_lin4.bias)
+    s.w_v2, s.b_v2 = p(mod.vox_lin2.weight), p(mod.vox_lin2.bias)
+    return s
+
+
+def check_pointnet(mod):
+    if (mod.input_channels, mod.gf_dim, mod.point_lin4.out_features) != (6, 32, 128):
+        raise RuntimeError("lidf_hip PointNet2Stage is built for input_channels=6, gf_dim=32, "
+                           "output_channels=128 (every shipped config)")
+
+
+class PointNet2Stage(nn.Module):
+    def __init__(self, input_channels=6, output_channels=256, gf_dim=64):
+        super(PointNet2Stage, self).__init__()
+        self.input_channels = input_channels
+        self.gf_dim = gf_dim
+        half = output_channels // 2
+        self.point_lin1 = nn.Linear(self.input_channels, self.gf_dim, bias=True)
+        self.point_lin2 = nn.Linear(self.gf_dim, half, bias=True)
+        self.vox_lin1 = nn.Linear(half, half, bias=True)
+        self.point_lin3 = nn.Linear(output_channels, output_channels, bias=True)
+        self.point_lin4 = nn.Linear(output_channels, output_channels, bias=True)
+        self.vox_lin2 = nn.Linear(output_channels, output_channels, bias=True)
+
+    def forward(self, inp_feat, vox2point_idx, n_vox=None):
+        if not inp_feat.is_cuda:
+            raise RuntimeError("PointNet2Stage.forward: CUDA tensor required (no CPU path)")
+        if n_vox is None:
+            n_vox = int(vox2point_idx.max().item()) + 1 if vox2point_idx.numel() else 0
+        needs_grad = torch.is_grad_enabled() and (
+            inp_feat.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return self.forward_composite(inp_feat, vox2point_idx, n_vox)
+        check_pointnet(self)
+        x = inp_feat.detach()
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 6:
+            raise RuntimeError("inp_feat must be float32 [N,6]")
+        x = x.contiguous()
+        idx = vox2point_idx.detach().to(torch.int32).contiguous()
+        n = x.shape[0]
+        out = torch.empty((n_vox, 128), dtype=torch.float32, device=x.device)
+        keep = []
+        s = pointnet_struct(self, keep)
+        L = _lib.lib()
+        wsb = L.lidf_pointnet_workspace_bytes(n, n_vox)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.lidf_pointnet_f32(C.byref(s), _lib.ptr(x), _lib.ptr(idx), n, n_vox,
+                                           _lib.ptr(out), _lib.ptr(ws), wsb,
+                                           _lib.current_stream(x.device)))
+        return out
+
+    def forward_composite(self, inp_feat, vox2point_idx, n_vox):
+        """Differentiable definition in torch ops (used only when autograd is required)."""
+        idx = vox2point_idx.long()
+        f2 = F.relu(self.point_lin2(F.relu(self.point_lin1(inp_feat))))
+        g1 = F.relu(self.vox_lin1(_segment_max(f2, idx, n_vox)))
+        f5 = F.relu(self.point_lin4(F.relu(self.point_lin3(torch.cat((g1[idx], f2), -1)))))
+        return F.relu(self.vox_lin2(_segment_max(f5, idx, n_vox)))

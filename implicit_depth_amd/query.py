@@ -5,6 +5,7 @@ Reference counterparts (paths relative to /root/reference/src):
   compute_ray_aabb    <- LIDF.compute_ray_aabb                 models/pipeline.py:271-296
   lidf_query          <- LIDF.get_embedding + LIDF.get_pred    models/pipeline.py:338-466
                          + depth write-back                     models/pipeline.py:593-596
+  lidf_refine         <- RefineNet.forward / get_pred_refine   models/pipeline.py:922-1041
 Outputs use the reference's data_dict key names. Pairs are kept RAY-MAJOR (CSR over rays, voxels
 ascending inside a ray) instead of the reference's voxel-major nonzero() order; `to_reference_order`
 gives the permutation back for code that needs the reference's order.
@@ -190,3 +191,69 @@ def ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox=8, multires_
             _lib.ptr(feat_grid), B, h, w, _lib.ptr(ray_dir), _lib.ptr(ray_pix), _lib.ptr(ray_bid),
             R, roi_inp_bbox, multires_views, _lib.ptr(out), _lib.current_stream(ray_dir.device)))
     return out
+
+
+def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
+                voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
+                forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
+                offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None):
+    """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
+    `forward_times` iterations of get_pred_refine through lidf_refine_f32.
+
+    pred_pos [R,3], max_pair_id [R] i64, pair_vox [P] i32 come from lidf_query; voxel_bound [V,6],
+    voxel_bid [V] i32; rgb_img [B,3,h,w]; feat_grid [B,32,h,w] (data_dict['full_rgb_feat']);
+    valid_inp [Nv,6] = cat(valid_v_rel_coord, valid_v_rgb), valid_vox [Nv] i32 = revidx;
+    pnet_model: pointnet.PointNet2Stage (refine), offset_dec: decoders.IEF/IMNet (D = 334).
+    Returns pred_pos_refine [R,3] and the last iteration's end_voxel_id [R] i32."""
+    from .pointnet import check_pointnet, pointnet_struct
+    ts = [ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
+          voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox]
+    names = ["ray_dir", "ray_pix", "ray_bid", "ray_flat", "pred_pos", "max_pair_id", "pair_vox",
+             "voxel_bound", "voxel_bid", "rgb_img", "feat_grid", "valid_inp", "valid_vox"]
+    _lib.require_cuda(*ts, names=names)
+    for t, n in ((ray_dir, "ray_dir"), (pred_pos, "pred_pos"), (voxel_bound, "voxel_bound"),
+                 (rgb_img, "rgb_img"), (valid_inp, "valid_inp")):
+        _f32(t, n)
+    for t, n in ((ray_bid, "ray_bid"), (ray_flat, "ray_flat"), (pair_vox, "pair_vox"),
+                 (voxel_bid, "voxel_bid"), (valid_vox, "valid_vox")):
+        _i32(t, n)
+    if max_pair_id.dtype != torch.int64:
+        raise RuntimeError("max_pair_id must be int64")
+    _check_supported(offset_dec)
+    check_pointnet(pnet_model)
+    E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
+    if offset_dec.inp_dim != 256 + E + Ed:
+        raise RuntimeError("refine offset_dec inp_dim must be %d" % (256 + E + Ed))
+    dev = ray_dir.device
+    R, P, V, Nv = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0], valid_inp.shape[0]
+    B, _, h, w = rgb_img.shape
+    if rayfeat is None:
+        rayfeat = ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    L = _lib.lib()
+    wsb = L.lidf_refine_workspace_bytes(R, Nv, V)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    keep = []
+    pn = pointnet_struct(pnet_model, keep)
+    do = _decoder_struct(offset_dec, keep)
+    cur = pred_pos.contiguous()
+    end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
+    for _ in range(forward_times):
+        out = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        q = _lib.LidfRefineArgs()
+        q.n_rays, q.ray_dir, q.ray_bid, q.ray_flat = R, ray_dir.data_ptr(), ray_bid.data_ptr(), ray_flat.data_ptr()
+        q.pred_pos, q.max_pair_id = cur.data_ptr(), max_pair_id.data_ptr()
+        q.pair_vox, q.n_pairs = pair_vox.data_ptr(), P
+        q.n_vox, q.voxel_bound, q.voxel_bid = V, voxel_bound.data_ptr(), voxel_bid.data_ptr()
+        q.rgb_img, q.batch, q.height, q.width = rgb_img.data_ptr(), B, h, w
+        q.rayfeat = rayfeat.data_ptr()
+        q.n_valid, q.valid_inp, q.valid_vox = Nv, valid_inp.data_ptr(), valid_vox.data_ptr()
+        q.pnet, q.off = C.pointer(pn), C.pointer(do)
+        q.multires, q.multires_views = multires, multires_views
+        q.pos_rel, q.pnet_pos_rel = int(bool(pos_rel)), int(bool(pnet_pos_rel))
+        q.offset_range0, q.offset_range1 = float(offset_range[0]), float(offset_range[1])
+        q.pred_pos_out, q.end_voxel_id = out.data_ptr(), end_voxel.data_ptr()
+        q.workspace, q.workspace_bytes = ws.data_ptr(), wsb
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
+        cur = out
+    return cur, end_voxel

@@ -194,6 +194,62 @@ int lidf_pcl_aabb_last_f32(const float* pcl_pos, const float* voxel_bound,
                            int64_t n_pts, int64_t n_vox, int32_t* last_vox,
                            lidf_stream_t stream);
 
+/* ---- PointNet2Stage ------------------------------------------------------------------------
+ * Replaces PointNet2Stage.forward (models/pointnet.py:22-38) incl. its two
+ * torch_scatter.scatter(..., reduce='max') poolings, for the shipped dimensions
+ * (input_channels 6, gf_dim 32, output_channels 128). Weights: nn.Linear storage [out,in].
+ * inp [N,6] f32, vox [N] i32 (vox2point_idx: voxel of every point, < n_vox) -> out [n_vox,128]. */
+typedef struct LidfPointNet {
+    const float *w_p1, *b_p1; /* point_lin1 [32,6]    */
+    const float *w_p2, *b_p2; /* point_lin2 [64,32]   */
+    const float *w_v1, *b_v1; /* vox_lin1   [64,64]   */
+    const float *w_p3, *b_p3; /* point_lin3 [128,128] */
+    const float *w_p4, *b_p4; /* point_lin4 [128,128] */
+    const float *w_v2, *b_v2; /* vox_lin2   [128,128] */
+} LidfPointNet;
+size_t lidf_pointnet_workspace_bytes(int64_t n_pts, int64_t n_vox);
+int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_pts,
+                      int64_t n_vox, float* out, void* workspace, size_t workspace_bytes,
+                      lidf_stream_t stream);
+
+/* ---- Stage-2 refinement query -------------------------------------------------------------
+ * One iteration of RefineNet.get_pred_refine (models/pipeline.py:922-1030), eval flavour
+ * (no perturbation, mask_type 'all' with refine.use_all_pix): end voxel of every ray, PointNet
+ * over (valid points + predicted points), [voxel feature | ROI feature | embed(pos) | embed(dir)]
+ * -> IEF (D = 256 + 3+6*multires + 3+6*multires_views) -> pred_pos + offset * ray_dir.
+ * RefineNet.forward (:1032-1041) calls it refine.forward_times times, feeding pred_pos_out back. */
+typedef struct LidfRefineArgs {
+    int64_t n_rays;
+    const float* ray_dir;        /* [R,3] */
+    const int32_t* ray_bid;      /* [R]   */
+    const int32_t* ray_flat;     /* [R]  y*w+x */
+    const float* pred_pos;       /* [R,3] position to refine (stage-1 pred_pos, or previous output) */
+    const int64_t* max_pair_id;  /* [R]  stage-1 arg-max pair, n_pairs for a ray without pairs */
+    const int32_t* pair_vox;     /* [P]  */
+    int64_t n_pairs;
+    int64_t n_vox;
+    const float* voxel_bound;    /* [V,6] */
+    const int32_t* voxel_bid;    /* [V]   */
+    const float* rgb_img;        /* [B,3,h,w] */
+    int32_t batch, height, width;
+    const float* rayfeat;        /* [R, 128 + 3+6*multires_views] from lidf_ray_features_f32 */
+    int64_t n_valid;
+    const float* valid_inp;      /* [Nv,6] PointNet input of the valid points (rel coord | rgb) */
+    const int32_t* valid_vox;    /* [Nv]   revidx */
+    const LidfPointNet* pnet;    /* refine pnet_model */
+    const LidfDecoder* off;      /* refine offset_dec (IEF or IMNet), d_in D */
+    int32_t multires, multires_views;
+    int32_t pos_rel;             /* refine.intersect_pos_type == 'rel' */
+    int32_t pnet_pos_rel;        /* refine.pnet_pos_type == 'rel' */
+    float offset_range0, offset_range1; /* refine.offset_range */
+    float* pred_pos_out;         /* [R,3] pred_pos_refine */
+    int32_t* end_voxel_id;       /* [R] optional output */
+    void* workspace;
+    size_t workspace_bytes;
+} LidfRefineArgs;
+size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
+int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

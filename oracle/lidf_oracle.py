@@ -438,6 +438,73 @@ def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_
 
 
 # ----------------------------------------------------------------------------------------------
+# a11  stage-2 refinement: PointNet2Stage (models/pointnet.py:22-38) and
+#      RefineNet.get_pred_refine (models/pipeline.py:922-1030), eval flavour
+# ----------------------------------------------------------------------------------------------
+def _scatter_max_rows(x, idx, n):
+    """torch_scatter.scatter(x, idx, dim=0, reduce='max'); rows without points are 0 (x >= 0)."""
+    out = torch.zeros(n, x.shape[1], dtype=x.dtype)
+    return out.scatter_reduce(0, idx.view(-1, 1).expand_as(x), x, reduce="amax", include_self=True)
+
+
+def pointnet2stage(p, inp, vox, n_vox):
+    lin = lambda x, k: F.linear(x, p[k + ".weight"], p[k + ".bias"])  # noqa: E731
+    f1 = F.relu(lin(inp, "point_lin1"))
+    f2 = F.relu(lin(f1, "point_lin2"))
+    g1 = F.relu(lin(_scatter_max_rows(f2, vox, n_vox), "vox_lin1"))
+    f3 = torch.cat((g1[vox], f2), -1)
+    f4 = F.relu(lin(f3, "point_lin3"))
+    f5 = F.relu(lin(f4, "point_lin4"))
+    return F.relu(lin(_scatter_max_rows(f5, vox, n_vox), "vox_lin2"))
+
+
+def refine_step(pred_pos, ray_dir, ray_pix, ray_bid, ray_flat, max_pair_id, pair_vox, voxel_bound,
+                voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_p, off_p, off_kind="IEF",
+                n_iter=2, multires=8, multires_views=4, roi_inp_bbox=8, offset_range=(-0.2, 0.2),
+                pos_rel=False, pnet_pos_rel=True, ray_rgb=None):
+    """One get_pred_refine call. Returns (pred_pos_refine, end_voxel_id, occ_voxel_feat)."""
+    R, P, V = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0]
+    h, w = rgb_img.shape[2], rgb_img.shape[3]
+    # end voxel: arg-max pair's voxel (dummy row -> 0), raised to the largest containing voxel
+    pv = torch.cat((pair_vox.long(), torch.zeros(1, dtype=torch.long)))
+    end_voxel = pv[max_pair_id.clamp(max=P)].clone()
+    m = torch.from_numpy(pcl_aabb(pred_pos.numpy(), voxel_bound.numpy(), ray_bid.numpy(),
+                                  voxel_bid.numpy())).long()
+    idx = torch.nonzero(m, as_tuple=False)
+    end_voxel.scatter_reduce_(0, idx[:, 1], idx[:, 0], reduce="amax", include_self=True)
+    e_dir = embed(ray_dir, multires_views)
+    if ray_rgb is None:
+        boxes = roi_boxes(ray_pix.long(), ray_bid.long(), h, w, roi_inp_bbox)
+        ray_rgb = roi_align(feat_grid, boxes).reshape(R, -1)
+    rgb_flat = rgb_img.permute(0, 2, 3, 1).contiguous().reshape(rgb_img.shape[0], -1, 3)
+    miss_rgb = rgb_flat[ray_bid.long(), ray_flat.long()]
+    eb = voxel_bound[end_voxel]
+    center = (eb[:, :3] + eb[:, 3:]) / 2.0
+    pred_inp = torch.cat(((pred_pos - center) if pnet_pos_rel else pred_pos, miss_rgb), 1)
+    pn_inp = torch.cat((valid_inp, pred_inp), 0)
+    pn_vox = torch.cat((valid_vox.long(), end_voxel), 0)
+    occ_voxel_feat = pointnet2stage(pnet_p, pn_inp, pn_vox, V)
+    enter = (pred_pos - center) if pos_rel else pred_pos
+    inp = torch.cat((occ_voxel_feat[end_voxel], ray_rgb, embed(enter, multires), e_dir), -1)
+    off = decoder_forward(off_p, inp, off_kind, n_iter)
+    scaled = off * (offset_range[1] - offset_range[0]) + offset_range[0]
+    return pred_pos + scaled * ray_dir, end_voxel, occ_voxel_feat
+
+
+def init_pointnet(seed, scale=1.0):
+    """Deterministic PointNet2Stage(6, 128, 32) parameters (nn.Linear-like uniform init)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for name, (dout, din) in {"point_lin1": (32, 6), "point_lin2": (64, 32), "vox_lin1": (64, 64),
+                              "point_lin3": (128, 128), "point_lin4": (128, 128),
+                              "vox_lin2": (128, 128)}.items():
+        b = 1.0 / math.sqrt(din)
+        p[name + ".weight"] = (torch.rand(dout, din, generator=g) * 2 - 1) * b * scale
+        p[name + ".bias"] = (torch.rand(dout, generator=g) * 2 - 1) * b
+    return p
+
+
+# ----------------------------------------------------------------------------------------------
 # Synthetic workload of SURVEY.md §8(d): lives in implicit_depth_amd/synthetic.py (plain data
 # generation, no compute path) so that bench.py and the tests feed both sides the same tensors.
 # ----------------------------------------------------------------------------------------------

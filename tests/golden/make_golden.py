@@ -9,6 +9,8 @@ Python modules are imported and executed, and only their inputs/outputs are stor
   g2_decoders.npz   IMNet / IEF forward outputs on closed-form weights  (models/implicit_net.py:60-152)
   g3_pipeline.npz   LIDF.get_miss_ray -> compute_ray_aabb -> get_embedding -> get_pred trace on a
                     2 x 16 x 24 synthetic batch                           (models/pipeline.py:203-466)
+  g4_refine.npz     RefineNet.get_pred_refine x 2 on the same batch (stage 2), incl. the refine
+                    PointNet2Stage outputs                     (models/pipeline.py:922-1041, pointnet.py)
 
 The reference's pipeline imports cv2, torchvision, torch_scatter and two JIT CUDA extensions, none
 of which exist here. They are replaced by stub modules whose bodies are oracle/lidf_oracle.py's
@@ -31,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, REF)
 
 from oracle import lidf_oracle as orc  # noqa: E402
-from util import closed_form, closed_form_params  # noqa: E402
+from util import closed_form, closed_form_params, closed_form_pointnet  # noqa: E402
 
 
 def _stub(name, **attrs):
@@ -196,6 +198,32 @@ def g3_pipeline():
     print("g3: R=%d V=%d P=%d" % (out["miss_ray_dir"].shape[0], out["voxel_bound"].shape[0],
                                    out["pair_pred_pos"].shape[0]))
     np.savez_compressed(os.path.join(HERE, "g3_pipeline.npz"), **out)
+
+    # ---- g4: stage 2 on the same data_dict
+    opt2 = Params(os.path.join(cfg, "default_config.yaml"))
+    opt2.update(os.path.join(cfg, "test_refine.yaml"))
+    refine = pl.RefineNet(opt2, dev).eval()
+    Dr = refine.offset_dec.inp_dim
+    refine.offset_dec.load_state_dict(closed_form_params("IEF", Dr, seed=31))
+    refine.pnet_model.load_state_dict(closed_form_pointnet(41))
+    feats = []
+    hk = refine.pnet_model.register_forward_hook(lambda m, i, o: feats.append(o.detach().clone()))
+    with torch.no_grad():
+        p1 = refine.get_pred_refine(dd, dd["pred_pos"], "test", 0)
+        p2 = refine.get_pred_refine(dd, p1, "test", 1)
+    hk.remove()
+    valid_v_rgb = dd["valid_rgb"][dd["valid_v_pid"]]
+    g4 = {
+        "rgb_img": dd["rgb_img"].numpy(),
+        "valid_inp": torch.cat((dd["valid_v_rel_coord"], valid_v_rgb), -1).numpy(),
+        "valid_vox": dd["revidx"].numpy(),
+        "pred_pos_refine_1": p1.numpy(), "pred_pos_refine_2": p2.numpy(),
+        "occ_voxel_feat_1": feats[0].numpy(), "occ_voxel_feat_2": feats[1].numpy(),
+        "offset_range": np.array(opt2.refine.offset_range, dtype=np.float32),
+        "D": np.array(Dr),
+    }
+    print("g4: Nv=%d Dr=%d" % (g4["valid_inp"].shape[0], Dr))
+    np.savez_compressed(os.path.join(HERE, "g4_refine.npz"), **g4)
 
 
 if __name__ == "__main__":

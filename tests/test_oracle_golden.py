@@ -104,3 +104,31 @@ def test_g3_query_matches_reference_trace():
     # ROI feature and voxel feature gathers as the reference saw them (per pair)
     pr = torch.from_numpy(g["miss_ray_intersect_idx"])
     assert np.abs(res["ray_rgb"][pr].numpy() - g["intersect_rgb_feat"]).max() == 0.0
+
+
+def g4_oracle(g3, g4):
+    """Oracle refine iterations on the reference's stage-1 trace; returns per-iteration outputs."""
+    from util import closed_form_pointnet
+    h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid = g3_inputs(g3)
+    res, perm, (pair_ray, pair_vox, pair_t, pair_off) = g3_oracle(g3)
+    Dr = int(g4["D"])
+    pnet_p = closed_form_pointnet(41)
+    off_p = closed_form_params("IEF", Dr, seed=31)
+    pos = torch.from_numpy(g3["pred_pos"])
+    outs = []
+    for _ in range(2):
+        pos, ev, feat = orc.refine_step(
+            pos, ray_dir, ray_pix, ray_bid, ray_flat, res["max_pair_id"], pair_vox, vb, vbid,
+            torch.from_numpy(g4["rgb_img"]), torch.from_numpy(g3["full_rgb_feat"]),
+            torch.from_numpy(g4["valid_inp"]), torch.from_numpy(g4["valid_vox"]), pnet_p, off_p,
+            offset_range=tuple(float(v) for v in g4["offset_range"]), ray_rgb=res["ray_rgb"])
+        outs.append((pos, ev, feat))
+    return outs
+
+
+def test_g4_refine_matches_reference_trace():
+    g3, g4 = load("g3_pipeline.npz"), load("g4_refine.npz")
+    outs = g4_oracle(g3, g4)
+    for i, (pos, ev, feat) in enumerate(outs, 1):
+        assert np.abs(feat.numpy() - g4["occ_voxel_feat_%d" % i]).max() <= 2e-6
+        assert np.abs(pos.numpy() - g4["pred_pos_refine_%d" % i]).max() <= 2e-6

@@ -75,3 +75,22 @@ def closed_form_params(kind, inp_dim, seed, gf=64):
         p[name + ".weight"] = closed_form((dout, din), 0.6180339887 + 0.01 * j, seed + j, 0.14)
         p[name + ".bias"] = closed_form((dout,), 0.7236067977, seed + 10 + j, 0.05)
     return p
+
+
+def closed_form_pointnet(seed):
+    """PointNet2Stage(6, 128, 32) state dict from the closed-form filler."""
+    shapes = {"point_lin1": (32, 6), "point_lin2": (64, 32), "vox_lin1": (64, 64),
+              "point_lin3": (128, 128), "point_lin4": (128, 128), "vox_lin2": (128, 128)}
+    p = {}
+    for j, (name, (dout, din)) in enumerate(shapes.items()):
+        amp = 1.4 / (din ** 0.5)
+        p[name + ".weight"] = closed_form((dout, din), 0.6180339887 + 0.013 * j, seed + j, amp)
+        p[name + ".bias"] = closed_form((dout,), 0.7236067977, seed + 20 + j, 0.1)
+    return p
+
+
+def make_pointnet(params, device):
+    from implicit_depth_amd import PointNet2Stage
+    m = PointNet2Stage(input_channels=6, output_channels=128, gf_dim=32)
+    m.load_state_dict({k: v.clone() for k, v in params.items()})
+    return m.to(device).eval()
