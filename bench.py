@@ -92,6 +92,86 @@ def cpu_baseline(scene, budget_s=15.0):
                       "query() (torch CPU ops, vectorised ROIAlign), %.1f s" % (rows, h, P, t)}
 
 
+def refine_setup(scene, s, dev):
+    """Synthetic stage-2 inputs for configs[3]: 10,000 valid points (valid_sample_num), a refine
+    PointNet2Stage and IEF(D=334) with seeded weights, the occupied-voxel boxes of the 9^3 grid."""
+    from implicit_depth_amd import IEF, PointNet2Stage
+    from implicit_depth_amd.query import lidf_refine
+    from implicit_depth_amd.synthetic import init_decoder_params
+    g = torch.Generator().manual_seed(4321)
+    B, h, w, V = scene["B"], scene["h"], scene["w"], scene["V"]
+    vb = torch.cat((scene["vox_center"] - 0.125, scene["vox_center"] + 0.125), 1).to(dev)
+    vbid = torch.arange(B).repeat_interleave(V // B).int().to(dev)
+    rgb = torch.randn(B, 3, h, w, generator=g).to(dev)
+    nv = 10000 * B
+    valid_inp = (torch.randn(nv, 6, generator=g) * 0.2).to(dev)
+    valid_vox = torch.randint(0, V, (nv,), generator=g).int().to(dev)
+    torch.manual_seed(99)
+    pnet = PointNet2Stage(6, 128, 32).to(dev).eval()
+    offr = IEF(dev, 334, 1, 64, n_iter=2).to(dev).eval()
+    offr.load_state_dict(init_decoder_params("IEF", 334, 9, 5.0))
+
+    def run(out):
+        return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], out["pred_pos"],
+                           out["max_pair_id"], s["pair_vox"], vb, vbid, rgb, s["feat_grid"], valid_inp,
+                           valid_vox, pnet, offr, forward_times=2, rayfeat=out["rayfeat"])[0]
+    return run
+
+
+def secondary(args):
+    """Secondary single-GPU measurements with the same JSON schema (not the headline metric)."""
+    from implicit_depth_amd import IEF, IMNet, decoders_forward, get_embedder
+    from implicit_depth_amd.synthetic import init_decoder_params
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    P = 240 * 320 * args.samples
+    g = torch.Generator(device=dev).manual_seed(5)
+    if args.workload == "decoders":
+        x = torch.randn(P, 385, generator=g, device=dev)
+        prob = IMNet(385, 1, 64).to(dev).eval()
+        prob.load_state_dict(init_decoder_params("IMNET", 385, 7, 5.0))
+        off = IEF(dev, 385, 1, 64, n_iter=2).to(dev).eval()
+        off.load_state_dict(init_decoder_params("IEF", 385, 8, 5.0))
+
+        def step():
+            with torch.no_grad():
+                return decoders_forward(x, prob, off)
+        flop_alg, bytes_alg, name = F_ALG, 1548.0, "lidf_points_kernel<ROWS>"
+        what = "prob_dec (IMNet) + offset_dec (IEF n_iter=2) on a materialised [P,385] f32 input"
+    else:
+        x = (torch.rand(P, 3, generator=g, device=dev) - 0.5) * 4.6
+        fn, dim = get_embedder(8)
+
+        def step():
+            return fn(x)
+        flop_alg, bytes_alg, name = 0.0, 12.0 + 4.0 * dim, "lidf_embed_kernel"
+        what = "get_embedder(8) on [P,3] f32 -> [P,51]"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps  # one dominant kernel per step on torch's stream
+    hbm = args.workload == "embed"
+    ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_alg * P / (kern_ms * 1e-3) / 1e12)
+    peak = 8000.0 if hbm else PEAK_F32_TFLOPS
+    print(json.dumps({
+        "metric": "Mpoints/sec, %s" % args.workload, "value": round(P * args.steps / elapsed / 1e6, 2),
+        "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "secondary: %s, P = %d rows" % (what, P)},
+        "roofline": {"bound": "hbm" if hbm else "mfma", "achieved": round(ach, 2), "peak": peak,
+                     "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),
+                     "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4)}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +180,15 @@ def main():
     ap.add_argument("--samples", type=int, default=64, help="candidates per ray (N)")
     ap.add_argument("--frames", type=int, default=1, help="frames per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="query",
+                    choices=["query", "query+refine", "decoders", "embed"],
+                    help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
+                         "configs[3] (stage 1 + 2 x get_pred_refine); decoders = IMNet+IEF on a "
+                         "materialised [P,385] input (the reference's decoder boundary); embed = "
+                         "stand-alone positional encoding (the one HBM-bound kernel of the path)")
     args = ap.parse_args()
+    if args.workload in ("decoders", "embed"):
+        return secondary(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +218,9 @@ def main():
     off.load_state_dict(scene["off_p"])
     depth = torch.zeros((B, h, w), device=dev)
     gathered = torch.empty((world * B, h, w), device=dev) if world > 1 else None
+    refine = None
+    if args.workload == "query+refine":
+        refine = refine_setup(scene, s, dev)
     ev = HipEvents()
     pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
     state = {"ws": None}
@@ -139,7 +230,11 @@ def main():
             out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                              s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
                              ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"],
-                             profile_events=events)
+                             profile_events=events, want_rayfeat=refine is not None)
+            if refine is not None:
+                out["pred_pos_refine"] = refine(out)
+                depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
+                    out["pred_pos_refine"][:, 2]
         state["ws"] = out["workspace"]
         if world > 1:
             all_gather_depth(depth, gathered)
@@ -186,10 +281,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 240x320 frame(s) per GPU, %d candidates/ray, LIDF "
+            "config": {"workload": "%s: %d x 240x320 frame(s) per GPU, %d candidates/ray, LIDF "
                                    "stage-1 fused query (ROI + PE + prob_dec IMNet + offset_dec IEF n_iter=2 "
-                                   "+ per-ray softmax/argmax + depth)%s" %
-                                   (B, N, "; RCCL all-gather of depth maps" if world > 1 else ""),
+                                   "+ per-ray softmax/argmax + depth)%s%s" %
+                                   ("configs[3]" if refine is not None else "configs[1]", B, N,
+                                    " + stage 2 (2 x get_pred_refine: PointNet2Stage over 10,000 valid + "
+                                    "76,800 predicted points, IEF D=334)" if refine is not None else "",
+                                    "; RCCL all-gather of depth maps" if world > 1 else ""),
                        "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
                        "parallelism": "frames sharded over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,

@@ -43,6 +43,7 @@ class LidfQueryArgs(C.Structure):
         ("depth", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ev_points_begin", C.c_void_p), ("ev_points_end", C.c_void_p),
+        ("rayfeat_out", C.c_void_p),
     ]
 
 

@@ -265,7 +265,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         float* stream_ray = (float*)(ws + w.stream_ray);
         float* voxpart = (float*)(ws + w.voxpart);
         float* raypart = (float*)(ws + w.raypart);
-        float* rayfeat = (float*)(ws + w.rayfeat);
+        float* rayfeat = q->rayfeat_out ? q->rayfeat_out : (float*)(ws + w.rayfeat);
         int cus;
         if ((rc = cu_count(&cus))) return rc;
 

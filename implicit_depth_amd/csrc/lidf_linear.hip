@@ -97,9 +97,13 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 }
                 if (op) *(f32x4*)(op + t * 32 + 8 * g) = v;
                 if (pp) {
+                    // pool entries only ever grow: a plain (possibly stale) read can prove the
+                    // atomic unnecessary, never wrongly skip it. Removes almost all atomics when
+                    // many points share a voxel (the predicted points of stage 2).
+                    const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (v[i] > 0.f) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(v[i]));
+                        if (v[i] > seen[i]) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(v[i]));
                 }
             }
         }

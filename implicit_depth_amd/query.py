@@ -92,7 +92,8 @@ def to_reference_order(pair_ray, pair_vox):
 def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-               ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None):
+               ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None,
+               want_rayfeat=False):
     """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
 
     ray_dir [R,3] f32, ray_pix [R,2] i32 (x,y), ray_bid [R] i32, pair_* ray-major (see
@@ -166,6 +167,9 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     q.pred_pos = out["pred_pos"].data_ptr()
     q.depth = depth.data_ptr() if depth is not None else None
     q.workspace, q.workspace_bytes = workspace.data_ptr(), wsb
+    if want_rayfeat:  # keep the per-ray feature rows for stage 2 (lidf_refine(..., rayfeat=...))
+        out["rayfeat"] = torch.empty((R, 128 + Ed), **f32)
+        q.rayfeat_out = out["rayfeat"].data_ptr()
     if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end) as integers
         q.ev_points_begin, q.ev_points_end = profile_events
     with torch.cuda.device(dev):

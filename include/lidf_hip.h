@@ -128,6 +128,9 @@ typedef struct LidfQueryArgs {
      * the per-point decoder kernel (the dominant launch); NULL = no recording.               */
     void* ev_points_begin;
     void* ev_points_end;
+    /* optional output: the per-ray [ROI feature | embed(dir)] rows, [R, 128 + 3+6*multires_views]
+     * (what lidf_ray_features_f32 computes) so that stage 2 (lidf_refine_f32) can re-use them. */
+    float* rayfeat_out;
 } LidfQueryArgs;
 
 size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox);

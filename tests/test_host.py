@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     # LidfDecoder: 10 pointers + 4 x 4-byte fields; LidfQueryArgs: as declared, natural alignment
     assert C.sizeof(_lib.LidfDecoder) == 10 * 8 + 16
     assert C.sizeof(_lib.LidfQueryArgs) % 8 == 0
-    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 16 == C.sizeof(_lib.LidfQueryArgs)
+    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 24 == C.sizeof(_lib.LidfQueryArgs)
 
 
 def test_modules_keep_reference_interface():
