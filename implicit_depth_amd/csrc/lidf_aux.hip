@@ -264,11 +264,21 @@ extern "C" hipError_t lidf_launch_ray_dirs(const float* intr, int B, int H, int 
 // origin 0, inv = 1/(d + 1e-12) evaluated in double then rounded to float, near/far bound by the
 // sign of inv, no t >= 0 test.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool slab_test(float dx, float dy, float dz, const float* vb,
-                                          float& t_enter, float& t_leave) {
-    const float ix = (float)(1 / ((double)dx + 1e-12));
-    const float iy = (float)(1 / ((double)dy + 1e-12));
-    const float iz = (float)(1 / ((double)dz + 1e-12));
+struct RayInv {
+    float ix, iy, iz;
+};
+// 1 / (dir + 1e-12): double add and divide, rounded to float (ray_aabb_cuda_kernel.cu:32,48,67);
+// depends on the ray only, so it is formed once per ray, not once per (ray, voxel)
+__device__ __forceinline__ RayInv ray_inv(float dx, float dy, float dz) {
+    RayInv r;
+    r.ix = (float)(1 / ((double)dx + 1e-12));
+    r.iy = (float)(1 / ((double)dy + 1e-12));
+    r.iz = (float)(1 / ((double)dz + 1e-12));
+    return r;
+}
+__device__ __forceinline__ bool slab_test(const RayInv& r, const float* vb, float& t_enter,
+                                          float& t_leave) {
+    const float ix = r.ix, iy = r.iy, iz = r.iz;
     float tmin_max = (ix >= 0 ? vb[0] : vb[3]) * ix;
     float tmax_min = (ix >= 0 ? vb[3] : vb[0]) * ix;
     const float tymin = (iy >= 0 ? vb[1] : vb[4]) * iy;
@@ -298,7 +308,8 @@ __global__ void lidf_ray_aabb_dense_kernel(const float* __restrict__ ray_dir,
 #pragma unroll
     for (int i = 0; i < 6; ++i) vb[i] = vbound[6 * v + i];
     float t0, t1;
-    if (!slab_test(ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2], vb, t0, t1)) return;
+    if (!slab_test(ray_inv(ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]), vb, t0, t1))
+        return;
     mask[v * R + r] = 1;
     *(f32x2*)(dist + (v * R + r) * 2) = f32x2{t0, t1};
 }
@@ -339,6 +350,7 @@ __global__ void lidf_ray_aabb_compact_kernel(const float* __restrict__ ray_dir,
         bid = ray_bid[r];
     }
     int n = 0;
+    const RayInv inv = ray_inv(dx, dy, dz);
     const int base = (FILL && live) ? pair_off[r] : 0;
     for (long long v0 = 0; v0 < V; v0 += 256) {
         const int nv = (int)min((long long)256, V - v0);
@@ -350,7 +362,7 @@ __global__ void lidf_ray_aabb_compact_kernel(const float* __restrict__ ray_dir,
         for (int j = 0; j < nv; ++j) {
             if (s_bid[j] != bid) continue;
             float t0, t1;
-            if (!slab_test(dx, dy, dz, s_vb + 6 * j, t0, t1)) continue;
+            if (!slab_test(inv, s_vb + 6 * j, t0, t1)) continue;
             if (FILL) {
                 const size_t p = (size_t)base + n;
                 pair_ray[p] = (int)r;
