@@ -76,8 +76,7 @@ static L1Map rows_map(int n0, int c0, int n1, int c1, int add_bias) {
     L1Map m = {};
     m.n0 = n0; m.c0 = c0; m.n1 = n1; m.c1 = c1;
     m.D = n0 + n1;
-    m.KH = (m.D + 1) / 2;
-    m.KQ1 = (m.KH + 1 + 3) / 4;
+    m.KQ1 = (m.D + 1 + 7) / 8;
     m.add_bias = add_bias;
     m.nt = 8;
     m.nout = 256;
@@ -160,7 +159,7 @@ LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_in
     for (int i = 0; i < nets; ++i) fill_net_args(a, i, ds[i], outs[i], 0);
     a.X = inp;
     a.ldx = ld_inp;
-    a.D = m.D; a.KH = m.KH; a.KQ1 = m.KQ1; a.has_bias = 1;
+    a.D = m.D; a.KQ1 = m.KQ1; a.has_bias = 1;
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     long long ntile = (n + 127) / 128;
@@ -291,7 +290,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.stream = stream_vox; a.aux = aux_pts;
             a.nets = 2; a.l1_quads = lv.l1_quads; a.net_quads = lv.net_quads;
             a.n = V; a.X = q->vox_feat; a.ldx = 128;
-            a.D = mv.D; a.KH = mv.KH; a.KQ1 = mv.KQ1; a.has_bias = 1;
+            a.D = mv.D; a.KQ1 = mv.KQ1; a.has_bias = 1;
             a.out_base = voxpart;
             long long nt = (V + 127) / 128;
             CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
@@ -305,7 +304,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.stream = stream_ray; a.aux = aux_pts;
             a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
             a.n = R; a.X = rayfeat; a.ldx = 128 + Ed;
-            a.D = mr.D; a.KH = mr.KH; a.KQ1 = mr.KQ1; a.has_bias = 0;
+            a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0;
             a.out_base = raypart;
             long long nt = (R + 127) / 128;
             CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
@@ -478,7 +477,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
-    a.D = m.D; a.KH = m.KH; a.has_bias = L.b ? 1 : 0;
+    a.D = m.D; a.has_bias = L.b ? 1 : 0;
     a.addrows = addrows; a.addidx = addidx; a.ld_add = L.nout; a.relu = relu;
     a.out = out; a.ld_out = ld_out; a.pool = pool; a.poolidx = poolidx; a.ld_pool = L.nout;
     long long nt128 = (n + 127) / 128;

@@ -18,7 +18,9 @@
 //   layer 1, fused mode : for octave pair it, tile t, jq<3 : quad (it*24 + t*3 + jq) = k-steps
 //                         4jq..4jq+3 of the 12 (sin x,y,z, cos x,y,z of octaves 2it, 2it+1);
 //                         then 8 tail quads (x, y, z, pad), one per tile
-//   layer 1, rows modes : for kq, tile t : quad (kq*8 + t)
+//   layer 1, rows modes : for kq, tile t : quad (kq*nt + t); k-step jj of quad kq multiplies operand
+//                         column 8kq + 4*half + jj, so the two half-waves read adjacent 16-byte
+//                         pieces of the same row; column D carries the bias (operand 1.0)
 // Every section is a multiple of 8 quads so that the ring index is static at every code point.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,6 +29,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte load
 
 #define LIDF_H1 256   // gf_dim*4
 #define LIDF_H2 128   // gf_dim*2
@@ -54,8 +57,7 @@ struct L1Map {
     // rows modes: operand column x in [0,n0) -> w1 column c0+x ; x in [n0,n0+n1) -> c1+(x-n0)
     int n0, c0, n1, c1;
     int D;         // n0+n1
-    int KH;        // ceil(D/2): lanes 0..31 take columns [0,KH), lanes 32..63 take [KH,D)
-    int KQ1;       // quads per tile = ceil((KH+1)/4)
+    int KQ1;       // quads per tile = ceil((D+1)/8)
     int add_bias;  // bias k-step carries b1 (+ IEF constant) ; else 0
     int nt;        // output tiles per k-quad in the rows modes (8 for the decoders' layer 1)
     int nout;      // rows of w1 (outputs); tiles beyond it are zero
@@ -105,7 +107,7 @@ struct PointsArgs {
     // rows modes
     const float* X;
     long long ldx;
-    int D, KH, KQ1, has_bias;
+    int D, KQ1, has_bias;
     float* out_base;    // L1ONLY: [n, nets*256]
     // fused mode
     const int* pair_ray;
@@ -126,7 +128,7 @@ struct LinearArgs {
     int kq1;
     const float* X;        // [n, D] rows, row stride ldx
     long long ldx, n;
-    int D, KH, has_bias;
+    int D, has_bias;
     const float* addrows;  // optional: += addrows[addidx[row], 0:32*nt]
     const int* addidx;
     int ld_add;

@@ -39,23 +39,29 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         }
-        const float* xrow = a.X + (size_t)pc * a.ldx + (h ? a.KH : 0);
-        const int nvalid = h ? (a.D - a.KH) : a.KH;
-        const int sbias = (h == 0 && a.has_bias) ? a.KH : -1;
+        // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
+        const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+        auto load_b = [&](int kq, float (&b)[4]) {
+            const int x0 = 8 * kq + 4 * h;
+            if (x0 + 3 < a.D) {
+                const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+                b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
+                                          : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+            }
+        };
         float bc[4];
         f32x4 qc[NT];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) bc[jj] = jj < nvalid ? xrow[jj] : (jj == sbias ? 1.f : 0.f);
+        load_b(0, bc);
 #pragma unroll
         for (int t = 0; t < NT; ++t) qc[t] = LDQ(srs, vq, t * 1024);
         for (int kq = 0; kq < a.kq1; ++kq) {
-            float bn[4];
+            float bn[4] = {0.f, 0.f, 0.f, 0.f};
             f32x4 qn[NT];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int s = 4 * (kq + 1) + jj;
-                bn[jj] = s < nvalid ? xrow[s] : (s == sbias ? 1.f : 0.f);
-            }
+            if (kq + 1 < a.kq1) load_b(kq + 1, bn);
             const int kn = kq + 1 < a.kq1 ? kq + 1 : kq;
 #pragma unroll
             for (int t = 0; t < NT; ++t) qn[t] = LDQ(srs, vq, (kn * NT + t) * 1024);

@@ -97,13 +97,13 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         const int s = 4 * kq + jj;
         const int out = 32 * t + c32;
         if (out >= m.nout) return 0.f;
-        const int x = s + half * m.KH;  // operand column
-        const int nvalid = half ? (m.D - m.KH) : m.KH;
-        if (s < nvalid) {
+        const int x = 8 * kq + 4 * half + jj;  // operand column
+        (void)s;
+        if (x < m.D) {
             const int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
             return n.w1[(size_t)out * n.ld1 + col];
         }
-        if (s == m.KH && half == 0 && m.add_bias) {
+        if (x == m.D && m.add_bias) {
             float b = n.b1[out];
             if (n.is_ief) b += ief_c(n, out);
             return b;
@@ -505,22 +505,27 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) base[t][i] = 0.f;
                 }
-                const float* xrow = a.X + (size_t)pc * a.ldx + (h ? a.KH : 0);
-                const int nvalid = h ? (a.D - a.KH) : a.KH;
-                const int sbias = (h == 0 && a.has_bias) ? a.KH : -1;
+                // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
+                const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+                auto load_b = [&](int kq, float (&b)[4]) {
+                    const int x0 = 8 * kq + 4 * h;
+                    if (x0 + 3 < a.D) {
+                        const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+                        b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
+                                                  : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+                    }
+                };
                 // where the stream continues after this layer-1 section
                 const int after_l1 = MODE == LIDF_MODE_L1ONLY ? next_blk : nsb + l1_bytes;
                 float bc[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    bc[jj] = jj < nvalid ? xrow[jj] : (jj == sbias ? 1.f : 0.f);
+                load_b(0, bc);
                 for (int kq = 0; kq < a.KQ1; ++kq) {
-                    float bn[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int s = 4 * (kq + 1) + jj;
-                        bn[jj] = s < nvalid ? xrow[s] : (s == sbias ? 1.f : 0.f);
-                    }
+                    float bn[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (kq + 1 < a.KQ1) load_b(kq + 1, bn);
                     const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
