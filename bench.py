@@ -198,10 +198,12 @@ def main():
                          "--gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun even N=1 goes through RCCL
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from implicit_depth_amd import IEF, IMNet
     from implicit_depth_amd.dist import all_gather_depth
@@ -217,7 +219,7 @@ def main():
     off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
     off.load_state_dict(scene["off_p"])
     depth = torch.zeros((B, h, w), device=dev)
-    gathered = torch.empty((world * B, h, w), device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, h, w), device=dev) if use_dist else None
     refine = None
     if args.workload == "query+refine":
         refine = refine_setup(scene, s, dev)
@@ -236,7 +238,7 @@ def main():
                 depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
                     out["pred_pos_refine"][:, 2]
         state["ws"] = out["workspace"]
-        if world > 1:
+        if use_dist:
             all_gather_depth(depth, gathered)
         return out
 
@@ -244,7 +246,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
@@ -258,7 +260,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -276,7 +278,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "Mpoints/sec implicit-MLP query, 240x320x64 samples",
+            "metric": "Mpoints/sec implicit-MLP query, 240x320x%d samples" % N,
             "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -287,7 +289,7 @@ def main():
                                    ("configs[3]" if refine is not None else "configs[1]", B, N,
                                     " + stage 2 (2 x get_pred_refine: PointNet2Stage over 10,000 valid + "
                                     "76,800 predicted points, IEF D=334)" if refine is not None else "",
-                                    "; RCCL all-gather of depth maps" if world > 1 else ""),
+                                    "; RCCL all-gather of depth maps" if use_dist else ""),
                        "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
                        "parallelism": "frames sharded over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
@@ -300,7 +302,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -8,8 +8,8 @@ hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const
                             float*, hipStream_t);
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_embed(const float*, long long, int, float*, hipStream_t);
-hipError_t lidf_launch_rayfeat(const float*, int, int, int, const float*, const int*, const int*,
-                               long long, int, int, float*, int, hipStream_t);
+hipError_t lidf_launch_rayfeat(const float*, float*, int, int, int, const float*, const int*,
+                               const int*, long long, int, int, float*, int, hipStream_t);
 hipError_t lidf_launch_ray_reduce(const float*, const float*, const int*, long long, long long,
                                   const int*, const int*, long long, float*, long long*, float*,
                                   float*, hipStream_t);
@@ -179,8 +179,8 @@ LIDF_API int lidf_ray_features_f32(const float* feat_grid, int batch, int height
     if (n_rays == 0) return LIDF_OK;
     if (!feat_grid || !ray_dir || !ray_pix || !ray_bid || !rayfeat) return LIDF_ERR_BAD_ARG;
     const int ld = 128 + 3 + 6 * multires_views;
-    CHECK_HIP(lidf_launch_rayfeat(feat_grid, batch, height, width, ray_dir, ray_pix, ray_bid,
-                                  n_rays, roi_inp_bbox / 2, multires_views, rayfeat, ld,
+    CHECK_HIP(lidf_launch_rayfeat(feat_grid, nullptr, batch, height, width, ray_dir, ray_pix,
+                                  ray_bid, n_rays, roi_inp_bbox / 2, multires_views, rayfeat, ld,
                                   (hipStream_t)stream));
     return LIDF_OK;
 }
@@ -203,10 +203,10 @@ LIDF_API int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_
 
 // ---- fused query ---------------------------------------------------------------------------------
 struct QueryWs {
-    size_t stream_pts, aux_pts, stream_vox, stream_ray, voxpart, raypart, rayfeat, total;
+    size_t stream_pts, aux_pts, stream_vox, stream_ray, voxpart, raypart, rayfeat, box, total;
 };
 
-static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv) {
+static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats = 0) {
     QueryWs w;
     L1Map mf = {};
     mf.L = L;
@@ -219,13 +219,14 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv) {
     w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
     w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
     w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
+    w.box = o;        o += align_up((size_t)grid_floats * 4, 256);  // optional box-sum image (last)
     w.total = o;
     return w;
 }
 
-LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox) {
+LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_t grid_floats) {
     // sized for the largest supported embedding (multires = multires_views = 16)
-    return query_ws(n_rays, n_vox, LIDF_MAX_L_FUSED, 16).total;
+    return query_ws(n_rays, n_vox, LIDF_MAX_L_FUSED, 16, grid_floats > 0 ? grid_floats : 0).total;
 }
 
 LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
@@ -255,7 +256,11 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             return LIDF_ERR_BAD_ARG;
         if (q->pos_rel && !q->vox_center) return LIDF_ERR_BAD_ARG;
         if (q->batch <= 0 || q->height <= 0 || q->width <= 0) return LIDF_ERR_BAD_ARG;
-        QueryWs w = query_ws(R, V, L, Lv);
+        // the box-sum image (B*32*h*w floats) is used when the caller's workspace has room for it
+        const int64_t grid_floats = (int64_t)q->batch * 32 * q->height * q->width;
+        QueryWs w = query_ws(R, V, L, Lv, grid_floats);
+        bool use_box = q->workspace_bytes >= w.total;
+        if (!use_box) w = query_ws(R, V, L, Lv);
         if (!q->workspace || q->workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
         char* ws = (char*)q->workspace;
         float* stream_pts = (float*)(ws + w.stream_pts);
@@ -296,9 +301,10 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
         }
         // 3. per-ray features and partial  raypart[r] = W1[:, rgb|dir] rayfeat[r]
-        CHECK_HIP(lidf_launch_rayfeat(q->feat_grid, q->batch, q->height, q->width, q->ray_dir,
-                                      q->ray_pix, q->ray_bid, R, q->roi_inp_bbox / 2, Lv, rayfeat,
-                                      128 + Ed, st));
+        CHECK_HIP(lidf_launch_rayfeat(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
+                                      q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
+                                      q->ray_bid, R, q->roi_inp_bbox / 2, Lv, rayfeat, 128 + Ed,
+                                      st));
         {
             PointsArgs a = {};
             a.stream = stream_ray; a.aux = aux_pts;

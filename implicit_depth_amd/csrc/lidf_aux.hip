@@ -81,6 +81,8 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ img, int H, 
         x_high = x_low + 1;
     }
     const float ly = y - (float)y_low, lx = x - (float)x_low;
+    // sample on a pixel centre: weights are exactly (1,0,0,0) -> the value itself (finite maps)
+    if (ly == 0.f && lx == 0.f) return img[y_low * W + x_low];
     const float hy = 1.f - ly, hx = 1.f - lx;
     const float v1 = img[y_low * W + x_low], v2 = img[y_low * W + x_high];
     const float v3 = img[y_high * W + x_low], v4 = img[y_high * W + x_high];
@@ -88,44 +90,120 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ img, int H, 
     return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
 }
 
-__global__ void lidf_rayfeat_kernel(const float* __restrict__ feat, int B, int H, int W,
+// Box-sum image: box[b,c,y,x] = sum of feat[b,c,y..y+k-1,x..x+k-1] (k = roi_inp_bbox/2), zero where
+// the window leaves the image. For a ray whose 2k x 2k box is not clamped every RoIAlign sample
+// falls on a pixel centre (weights 1,0,0,0), so each of the 2x2 bins is exactly such a window
+// mean: 4 gathers per channel instead of (2k)^2 x 4 taps. Sums are formed row-wise
+// then column-wise (re-associated w.r.t. the sequential sample loop: <= a few ulp).
+__global__ void lidf_boxsum_kernel(const float* __restrict__ feat, int BC, int H, int W, int k,
+                                   float* __restrict__ box) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)BC * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    float acc = 0.f;
+    if (x + k <= W && y + k <= H) {
+        const float* p = feat + i;
+        for (int dy = 0; dy < k; ++dy) {
+            float row = 0.f;
+            for (int dx = 0; dx < k; ++dx) row += p[dy * W + dx];
+            acc += row;
+        }
+    }
+    box[i] = acc;
+}
+
+// Per-ray [ROI 2x2 x 32 channels | embed(dir)]. Workgroup = 64 rays x 4 channel groups.
+// Phase 1: rays whose 2k x 2k box is unclamped read 4 box sums per channel. Phase 2: the
+// workgroup's remaining (border / no box image) rays are compacted and their (ray, channel, bin)
+// items spread over all 256 threads, so a few clamped boxes do not serialise whole wavefronts.
+// The 64 x 128 block is staged in LDS (row stride 129) and leaves as coalesced row segments.
+__global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
+                                    const float* __restrict__ box, int B, int H, int W,
                                     const float* __restrict__ ray_dir,
                                     const int* __restrict__ ray_pix,
                                     const int* __restrict__ ray_bid, long long R, int half,
                                     int Lv, float* __restrict__ out, int ld) {
-    const long long r = (long long)blockIdx.x * 64 + threadIdx.x;
-    const int cg = threadIdx.y;
-    if (r >= R) return;
+    __shared__ float tile[64 * 129];
+    __shared__ int s_list[64];
+    __shared__ int s_nb;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int lx = threadIdx.x, cg = threadIdx.y;
+    const int tid = cg * 64 + lx;
+    const int nrow = (int)min((long long)64, R - r0);
+    const bool live = lx < nrow;
+    const long long r = r0 + (live ? lx : 0);
     const int px = ray_pix[2 * r], py = ray_pix[2 * r + 1], b = ray_bid[r];
     const int x1 = min(max(px - half, 0), W - 1), x2 = min(max(px + half, 0), W - 1);
     const int y1 = min(max(py - half, 0), H - 1), y2 = min(max(py + half, 0), H - 1);
-    const float rsw = (float)x1 - 0.5f, rsh = (float)y1 - 0.5f;
-    const float rew = (float)x2 - 0.5f, reh = (float)y2 - 0.5f;
-    const float roi_w = rew - rsw, roi_h = reh - rsh;
-    const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
-    const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
-    const float count = (float)max(gh * gw, 1);
-    float* o = out + (size_t)r * ld;
-    for (int c = cg * 8; c < cg * 8 + 8; ++c) {
-        const float* img = feat + ((size_t)b * 32 + c) * H * W;
-        for (int ph = 0; ph < 2; ++ph) {
-            for (int pw = 0; pw < 2; ++pw) {
-                float acc = 0.f;
-                for (int iy = 0; iy < gh; ++iy) {
-                    const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
-                    for (int ix = 0; ix < gw; ++ix) {
-                        const float x =
-                            rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
-                        acc += bilinear(img, H, W, y, x);
-                    }
-                }
-                o[c * 4 + ph * 2 + pw] = acc / count;
-            }
+    const bool fast = box && half > 0 && x2 - x1 == 2 * half && y2 - y1 == 2 * half;
+    if (cg == 0) {  // one wavefront compacts the rays that need the general path
+        const unsigned long long m = __ballot(live && !fast);
+        if (live && !fast) s_list[__popcll(m & ((1ull << lx) - 1))] = lx;
+        if (lx == 0) s_nb = __popcll(m);
+    }
+    if (live && fast) {
+        // unclamped box: bin (ph,pw) = mean of the half x half pixel block at (y1+ph*half, x1+pw*half)
+        const float count = (float)(half * half);
+        float* o = tile + lx * 129;
+        for (int c = cg * 8; c < cg * 8 + 8; ++c) {
+            const float* bi = box + ((size_t)b * 32 + c) * H * W + (size_t)y1 * W + x1;
+            o[c * 4 + 0] = bi[0] / count;
+            o[c * 4 + 1] = bi[half] / count;
+            o[c * 4 + 2] = bi[(size_t)half * W] / count;
+            o[c * 4 + 3] = bi[(size_t)half * W + half] / count;
         }
     }
-    if (cg == 0) {
+    __syncthreads();
+    const int nb = s_nb;
+    for (int item = tid; item < nb * 128; item += 256) {
+        const int row = s_list[item >> 7], cb = item & 127;
+        const int c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
+        const long long rr = r0 + row;
+        const int qx = ray_pix[2 * rr], qy = ray_pix[2 * rr + 1];
+        const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+        const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+        const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+        const float rew = (float)u2 - 0.5f, reh = (float)v2 - 0.5f;
+        const float roi_w = rew - rsw, roi_h = reh - rsh;
+        const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+        const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+        const float count = (float)max(gh * gw, 1);
+        const float* img = feat + ((size_t)ray_bid[rr] * 32 + c) * H * W;
+        // the samples of one bin are independent loads: blocks of 4 x 4 are evaluated with the
+        // loops unrolled (predicated) so that they issue back to back, then summed in the
+        // reference's (iy, ix) order
+        float acc = 0.f;
+        for (int iy0 = 0; iy0 < gh; iy0 += 4) {
+            for (int ix0 = 0; ix0 < gw; ix0 += 4) {
+                float v[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float y =
+                        rsh + (float)ph * bin_h + ((float)(iy0 + a) + .5f) * bin_h / (float)gh;
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const float x =
+                            rsw + (float)pw * bin_w + ((float)(ix0 + bb) + .5f) * bin_w / (float)gw;
+                        v[a][bb] = (iy0 + a < gh && ix0 + bb < gw) ? bilinear(img, H, W, y, x) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb)
+                        if (iy0 + a < gh && ix0 + bb < gw) acc += v[a][bb];
+                }
+            }
+        }
+        tile[row * 129 + cb] = acc / count;
+    }
+    __syncthreads();
+    for (int e = tid; e < nrow * 128; e += 256)
+        out[(size_t)(r0 + (e >> 7)) * ld + (e & 127)] = tile[(e >> 7) * 129 + (e & 127)];
+    if (cg == 0 && live) {
         const float d[3] = {ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]};
-        float* e = o + 128;
+        float* e = out + (size_t)r * ld + 128;
         for (int i = 0; i < 3; ++i) e[i] = d[i];
         for (int l = 0; l < Lv; ++l) {
             const float f = (float)(1 << l);
@@ -137,13 +215,19 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat, int B, int H
     }
 }
 
-extern "C" hipError_t lidf_launch_rayfeat(const float* feat, int B, int H, int W,
+// `box` (scratch, B*32*H*W floats) may be NULL: every ray then takes the general path.
+extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, int H, int W,
                                           const float* ray_dir, const int* ray_pix,
                                           const int* ray_bid, long long R, int half, int Lv,
                                           float* out, int ld, hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    if (box && half > 0) {
+        const long long total = (long long)B * 32 * H * W;
+        hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           st, feat, B * 32, H, W, half, box);
+    }
     hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4), 0, st,
-                       feat, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld);
+                       feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld);
     return hipGetLastError();
 }
 

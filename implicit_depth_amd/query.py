@@ -140,7 +140,7 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
         "pred_pos": torch.empty((R, 3), **f32),
     }
     L = _lib.lib()
-    wsb = L.lidf_query_workspace_bytes(R, V)
+    wsb = L.lidf_query_workspace_bytes(R, V, B * 32 * h * w)
     if workspace is None or workspace.numel() < wsb:
         workspace = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     keep = []

@@ -133,7 +133,9 @@ typedef struct LidfQueryArgs {
     float* rayfeat_out;
 } LidfQueryArgs;
 
-size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox);
+/* grid_floats = batch*32*height*width makes room for the optional 4x4 box-sum image that turns the
+ * ROIAlign of unclamped boxes into 4 gathers per channel; 0 = minimal workspace (general path). */
+size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_t grid_floats);
 int lidf_query_f32(const LidfQueryArgs* args, lidf_stream_t stream);
 
 /* Per-ray ROIAlign feature (torchvision.ops.roi_align, output 2x2, aligned=True, called at

@@ -19,7 +19,7 @@ ws = o["workspace"]
 import ctypes
 R = scene["R"]
 def al(x): return (x + 255) // 256 * 256
-total = _lib.lib().lidf_query_workspace_bytes(R, scene["V"])
+total = _lib.lib().lidf_query_workspace_bytes(R, scene["V"], 0)
 # workspace for actual L=8,Lv=4 is laid out with those sizes: recompute
 E=51; Ed=27
 def l1q_f(L): return 24*((L+1)//2)+8

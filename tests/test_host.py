@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(names)
     assert L.lidf_version() == 1
     assert b"workspace" in L.lidf_strerror(-3)
-    assert L.lidf_query_workspace_bytes(76800, 729) > 76800 * 512 * 4
+    assert L.lidf_query_workspace_bytes(76800, 729, 0) > 76800 * 512 * 4
+    assert (L.lidf_query_workspace_bytes(76800, 729, 32 * 240 * 320)
+            >= L.lidf_query_workspace_bytes(76800, 729, 0) + 32 * 240 * 320 * 4)
     assert L.lidf_decoders_workspace_bytes(10, 385) > 0
 
 
