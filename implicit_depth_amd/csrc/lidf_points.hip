@@ -521,26 +521,41 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                 };
                 // where the stream continues after this layer-1 section
                 const int after_l1 = MODE == LIDF_MODE_L1ONLY ? next_blk : nsb + l1_bytes;
-                float bc[4];
-                load_b(0, bc);
-                for (int kq = 0; kq < a.KQ1; ++kq) {
-                    float bn[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (kq + 1 < a.KQ1) load_b(kq + 1, bn);
-                    const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
+                // The operand rows stream from HBM, and VMEM loads return in order: an HBM-latency
+                // load would hold up every weight-ring load queued behind it, once per iteration.
+                // So the operands of up to 25 k-quads (100 VGPRs, free during layer 1) are fetched
+                // in one burst per chunk and the iterations run with only the L2-resident ring in
+                // the queue.
+                constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : 8;  // L1ONLY: keep 2 waves/SIMD
+                for (int k0 = 0; k0 < a.KQ1; k0 += XCH) {
+                    float xb[XCH][4];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const f32x4 q = ring[t];
-                        ring[t] = LDQ(srs, vq, qb + t * 1024);
-                        f32x16 c = base[t];
-                        c = MFMA(q[0], bc[0], c);
-                        c = MFMA(q[1], bc[1], c);
-                        c = MFMA(q[2], bc[2], c);
-                        c = MFMA(q[3], bc[3], c);
-                        base[t] = c;
-                        SCHED_FENCE();
+                    for (int i = 0; i < XCH; ++i) {
+                        if (k0 + i < a.KQ1) {
+                            load_b(k0 + i, xb[i]);
+                        } else {
+                            xb[i][0] = xb[i][1] = xb[i][2] = xb[i][3] = 0.f;
+                        }
                     }
+                    SCHED_FENCE();
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) bc[jj] = bn[jj];
+                    for (int i = 0; i < XCH; ++i) {
+                        const int kq = k0 + i;
+                        if (kq >= a.KQ1) break;
+                        const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const f32x4 q = ring[t];
+                            ring[t] = LDQ(srs, vq, qb + t * 1024);
+                            f32x16 c = base[t];
+                            c = MFMA(q[0], xb[i][0], c);
+                            c = MFMA(q[1], xb[i][1], c);
+                            c = MFMA(q[2], xb[i][2], c);
+                            c = MFMA(q[3], xb[i][3], c);
+                            base[t] = c;
+                            SCHED_FENCE();
+                        }
+                    }
                 }
             }
 
