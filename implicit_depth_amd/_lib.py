@@ -93,6 +93,9 @@ SIGNATURES = {
     "lidf_exclusive_scan_i32": (C.c_int, [_P, _I64, _P, _P, _SZ, _P]),
     "lidf_pcl_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
     "lidf_pcl_aabb_last_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "lidf_voxelize_workspace_bytes": (_SZ, [_I64, _I64]),
+    "lidf_voxelize_f32": (C.c_int, [_P, _P, _I64, _I, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                    C.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "lidf_pointnet_workspace_bytes": (_SZ, [_I64, _I64]),
     "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),

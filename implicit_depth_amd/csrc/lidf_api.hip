@@ -25,6 +25,18 @@ hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, con
                                      long long, long long, int*, hipStream_t);
 hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
+struct GridSpec {
+    float xmin[3];
+    float crop;
+    int r[3];
+    int B;
+};
+hipError_t lidf_launch_vox_mark(const float*, const int*, long long, const GridSpec&, int*, int*,
+                                int*, hipStream_t);
+hipError_t lidf_launch_vox_cells(const int*, const int*, long long, const GridSpec&, int*, float*,
+                                 hipStream_t);
+hipError_t lidf_launch_vox_points(const float*, const int*, const int*, const int*, long long,
+                                  const GridSpec&, int*, int*, float*, hipStream_t);
 hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, long long,
                                    const float*, const int*, long long, const int*, const int*,
                                    const float*, long long, const float*, int, int, int, int, int,
@@ -646,5 +658,63 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
     CHECK_HIP(lidf_launch_refine_finish(q->pred_pos, off, q->ray_dir, q->offset_range0,
                                         q->offset_range1 - q->offset_range0, R, q->pred_pos_out,
                                         st));
+    return LIDF_OK;
+}
+
+// ---- occupied-voxel build ----------------------------------------------------------------------
+struct VoxWs {
+    size_t cell_flag, cell_rank, pt_key, pt_valid, pt_rank, scan, total;
+};
+static VoxWs vox_ws(int64_t n, int64_t ncell) {
+    VoxWs w;
+    size_t o = 0;
+    const size_t N = (size_t)(n > 0 ? n : 1), C = (size_t)(ncell > 0 ? ncell : 1);
+    w.cell_flag = o; o += align_up(C * 4, 256);
+    w.cell_rank = o; o += align_up((C + 1) * 4, 256);
+    w.pt_key = o;    o += align_up(N * 4, 256);
+    w.pt_valid = o;  o += align_up(N * 4, 256);
+    w.pt_rank = o;   o += align_up((N + 1) * 4, 256);
+    w.scan = o;      o += align_up(lidf_exclusive_scan_workspace_bytes(N > C ? (int64_t)N : (int64_t)C), 256);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_voxelize_workspace_bytes(int64_t n_pts, int64_t n_cells) {
+    return vox_ws(n_pts, n_cells).total;
+}
+
+LIDF_API int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n, int batch,
+                               const float* xmin, const int32_t* res, float crop,
+                               int32_t* occ_bid_coord, float* voxel_bound, int32_t* valid_pid,
+                               int32_t* revidx, float* rel_coord, int32_t* counts, void* workspace,
+                               size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || batch <= 0 || !xmin || !res || !(crop > 0.f) || !counts) return LIDF_ERR_BAD_ARG;
+    if (res[0] <= 0 || res[1] <= 0 || res[2] <= 0) return LIDF_ERR_BAD_ARG;
+    const int64_t ncell = (int64_t)batch * res[0] * res[1] * res[2];
+    if (ncell > 0x7fffffffLL || n > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n > 0 && (!xyz || !bid || !valid_pid || !revidx || !rel_coord)) return LIDF_ERR_BAD_ARG;
+    if (!occ_bid_coord || !voxel_bound) return LIDF_ERR_BAD_ARG;
+    VoxWs w = vox_ws(n, ncell);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int* cell_flag = (int*)(ws + w.cell_flag);
+    int* cell_rank = (int*)(ws + w.cell_rank);
+    int* pt_key = (int*)(ws + w.pt_key);
+    int* pt_valid = (int*)(ws + w.pt_valid);
+    int* pt_rank = (int*)(ws + w.pt_rank);
+    GridSpec g;
+    for (int a = 0; a < 3; ++a) { g.xmin[a] = xmin[a]; g.r[a] = res[a]; }
+    g.crop = crop;
+    g.B = batch;
+    CHECK_HIP(hipMemsetAsync(cell_flag, 0, (size_t)ncell * 4, st));
+    CHECK_HIP(lidf_launch_vox_mark(xyz, bid, n, g, cell_flag, pt_key, pt_valid, st));
+    CHECK_HIP(lidf_launch_scan(cell_flag, ncell, cell_rank, (int*)(ws + w.scan), st));
+    CHECK_HIP(lidf_launch_scan(pt_valid, n, pt_rank, (int*)(ws + w.scan), st));
+    CHECK_HIP(lidf_launch_vox_cells(cell_flag, cell_rank, ncell, g, occ_bid_coord, voxel_bound, st));
+    CHECK_HIP(lidf_launch_vox_points(xyz, pt_key, pt_rank, cell_rank, n, g, valid_pid, revidx,
+                                     rel_coord, st));
+    CHECK_HIP(hipMemcpyAsync(counts, cell_rank + ncell, 4, hipMemcpyDeviceToDevice, st));
+    CHECK_HIP(hipMemcpyAsync(counts + 1, pt_rank + (n > 0 ? n : 0), 4, hipMemcpyDeviceToDevice, st));
     return LIDF_OK;
 }

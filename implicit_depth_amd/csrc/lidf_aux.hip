@@ -632,3 +632,121 @@ extern "C" hipError_t lidf_launch_scan(const int* in, long long n, int* out, int
                        out);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Occupied-voxel build — utils/point_utils.py:12-76 batch_get_occupied_idx (overlap=False) +
+// LIDF.get_occ_vox_bound (models/pipeline.py:162-201). The grid is tiny (B x rx x ry x rz cells),
+// so torch.unique(dim=0, return_inverse=True) — which sorts the (bid, x, y, z) rows — is a dense
+// mark -> exclusive scan -> compact: the scan order over cell keys IS the lexicographic order.
+//   pass A (points): cell of every point, validity, mark the cell, per-point key (-1 = outside)
+//   scans: cells -> voxel rank ; points -> rank among the valid points (order preserved)
+//   pass B (cells): occ_bid_coord [V,4] i32, voxel_bound [V,6]
+//   pass C (points): valid_v_pid, revidx, valid_v_rel_coord
+// f32 arithmetic follows the reference op by op: v - xmin ; / crop ; floor ; coord*crop + crop/2.
+// ------------------------------------------------------------------------------------------------
+struct GridSpec {
+    float xmin[3];
+    float crop;
+    int r[3];
+    int B;
+};
+
+__global__ void lidf_vox_mark_kernel(const float* __restrict__ xyz, const int* __restrict__ bid,
+                                     long long N, GridSpec g, int* __restrict__ cell_flag,
+                                     int* __restrict__ pt_key, int* __restrict__ pt_valid) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = xyz[3 * i + a] - g.xmin[a];
+        const float q = floorf(v / g.crop);
+        ok = ok && (q >= 0.f) && (q < (float)g.r[a]);
+        c[a] = (int)q;
+    }
+    const int b = bid[i];
+    ok = ok && b >= 0 && b < g.B;
+    int key = -1;
+    if (ok) {
+        key = ((b * g.r[0] + c[0]) * g.r[1] + c[1]) * g.r[2] + c[2];
+        cell_flag[key] = 1;
+    }
+    pt_key[i] = key;
+    pt_valid[i] = ok ? 1 : 0;
+}
+
+__global__ void lidf_vox_cells_kernel(const int* __restrict__ cell_flag,
+                                      const int* __restrict__ cell_rank, long long ncell, GridSpec g,
+                                      int* __restrict__ occ, float* __restrict__ vbound) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncell || !cell_flag[k]) return;
+    const int v = cell_rank[k];
+    int rem = (int)k;
+    const int cz = rem % g.r[2]; rem /= g.r[2];
+    const int cy = rem % g.r[1]; rem /= g.r[1];
+    const int cx = rem % g.r[0]; rem /= g.r[0];
+    occ[4 * v + 0] = rem;
+    occ[4 * v + 1] = cx;
+    occ[4 * v + 2] = cy;
+    occ[4 * v + 3] = cz;
+    const int c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = g.xmin[a] + (float)c[a] * g.crop;  // pipeline.py:186
+        vbound[6 * v + a] = lo;
+        vbound[6 * v + 3 + a] = lo + g.crop;               // :187
+    }
+}
+
+__global__ void lidf_vox_points_kernel(const float* __restrict__ xyz,
+                                       const int* __restrict__ pt_key,
+                                       const int* __restrict__ pt_rank,
+                                       const int* __restrict__ cell_rank, long long N, GridSpec g,
+                                       int* __restrict__ pid, int* __restrict__ revidx,
+                                       float* __restrict__ rel) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int key = pt_key[i];
+    if (key < 0) return;
+    const int j = pt_rank[i];
+    pid[j] = (int)i;
+    revidx[j] = cell_rank[key];
+    int rem = key;
+    int c[3];
+    c[2] = rem % g.r[2]; rem /= g.r[2];
+    c[1] = rem % g.r[1]; rem /= g.r[1];
+    c[0] = rem % g.r[0];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = xyz[3 * i + a] - g.xmin[a];
+        const float centre = (float)c[a] * g.crop + 0.5f * g.crop;  // point_utils.py:50
+        rel[3 * j + a] = v - centre;                                // :51
+    }
+}
+
+extern "C" hipError_t lidf_launch_vox_mark(const float* xyz, const int* bid, long long N,
+                                           const GridSpec& g, int* cell_flag, int* pt_key,
+                                           int* pt_valid, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_vox_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                       xyz, bid, N, g, cell_flag, pt_key, pt_valid);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_vox_cells(const int* cell_flag, const int* cell_rank,
+                                            long long ncell, const GridSpec& g, int* occ,
+                                            float* vbound, hipStream_t st) {
+    if (ncell <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_vox_cells_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0,
+                       st, cell_flag, cell_rank, ncell, g, occ, vbound);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_vox_points(const float* xyz, const int* pt_key,
+                                             const int* pt_rank, const int* cell_rank, long long N,
+                                             const GridSpec& g, int* pid, int* revidx, float* rel,
+                                             hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_vox_points_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                       xyz, pt_key, pt_rank, cell_rank, N, g, pid, revidx, rel);
+    return hipGetLastError();
+}

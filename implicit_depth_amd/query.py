@@ -6,6 +6,8 @@ Reference counterparts (paths relative to /root/reference/src):
   lidf_query          <- LIDF.get_embedding + LIDF.get_pred    models/pipeline.py:338-466
                          + depth write-back                     models/pipeline.py:593-596
   lidf_refine         <- RefineNet.forward / get_pred_refine   models/pipeline.py:922-1041
+  get_occ_vox_bound   <- batch_get_occupied_idx + LIDF.get_occ_vox_bound
+                                            utils/point_utils.py:12-76, models/pipeline.py:162-201
 Outputs use the reference's data_dict key names. Pairs are kept RAY-MAJOR (CSR over rays, voxels
 ascending inside a ray) instead of the reference's voxel-major nonzero() order; `to_reference_order`
 gives the permutation back for code that needs the reference's order.
@@ -261,3 +263,51 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
             _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out
     return cur, end_voxel
+
+
+def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=(1.0, 1.0, 2.0),
+                      res=8):
+    """Occupied voxels of the valid points (LIDF.get_occ_vox_bound, models/pipeline.py:162-201, with
+    utils/point_utils.py:12-76 batch_get_occupied_idx(overlap=False) inside), on the device.
+
+    valid_xyz [N,3] f32, valid_bid [N] i32. xmin/xmax are constants.XMIN/XMAX and res is
+    opt.grid.res: part_size = min(xmax-xmin)/res and the grid is widened by half a voxel on every
+    side, exactly as the reference does. Returns the reference's data_dict entries:
+    part_size, xmin (widened), revidx [Nv] i64, valid_v_pid [Nv] i64, valid_v_rel_coord [Nv,3],
+    occ_vox_bid [V] i64, occ_vox_global_coord [V,3] i64, voxel_bound [V,6]; V == 0 is the
+    reference's 'No occupied voxel' early exit."""
+    import math
+    _lib.require_cuda(valid_xyz, valid_bid, names=["valid_xyz", "valid_bid"])
+    _f32(valid_xyz, "valid_xyz"), _i32(valid_bid, "valid_bid")
+    t32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731  (the reference's f32 maths)
+    lo, hi = t32(xmin), t32(xmax)
+    part_size = float(torch.min(hi - lo).item()) / res
+    lo = lo - 0.5 * part_size
+    hi = hi + 0.5 * part_size
+    r = [int(v) for v in torch.ceil((hi - lo) / part_size).tolist()]
+    dev = valid_xyz.device
+    N = valid_xyz.shape[0]
+    ncell = batch * r[0] * r[1] * r[2]
+    occ = torch.empty((ncell, 4), dtype=torch.int32, device=dev)
+    vb = torch.empty((ncell, 6), dtype=torch.float32, device=dev)
+    pid = torch.empty((N,), dtype=torch.int32, device=dev)
+    rev = torch.empty((N,), dtype=torch.int32, device=dev)
+    rel = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    wsb = L.lidf_voxelize_workspace_bytes(N, ncell)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    xm = (C.c_float * 3)(*[float(v) for v in lo.tolist()])
+    rr = (C.c_int32 * 3)(*r)
+    with torch.cuda.device(dev):
+        _lib.check(L.lidf_voxelize_f32(_lib.ptr(valid_xyz), _lib.ptr(valid_bid), N, batch, xm, rr,
+                                       C.c_float(part_size), _lib.ptr(occ), _lib.ptr(vb),
+                                       _lib.ptr(pid), _lib.ptr(rev), _lib.ptr(rel), _lib.ptr(counts),
+                                       _lib.ptr(ws), wsb, _lib.current_stream(dev)))
+    V, Nv = [int(v) for v in counts.tolist()]  # host needs the sizes, as torch.unique does
+    occ = occ[:V].long()
+    return {
+        "part_size": part_size, "xmin": lo.to(dev), "revidx": rev[:Nv].long(),
+        "valid_v_pid": pid[:Nv].long(), "valid_v_rel_coord": rel[:Nv],
+        "occ_vox_bid": occ[:, 0], "occ_vox_global_coord": occ[:, 1:], "voxel_bound": vb[:V],
+    }

@@ -199,6 +199,23 @@ int lidf_pcl_aabb_last_f32(const float* pcl_pos, const float* voxel_bound,
                            int64_t n_pts, int64_t n_vox, int32_t* last_vox,
                            lidf_stream_t stream);
 
+/* ---- Occupied-voxel build -------------------------------------------------------------------
+ * Replaces utils/point_utils.py:12-76 batch_get_occupied_idx(overlap=False) and
+ * LIDF.get_occ_vox_bound (models/pipeline.py:162-201): points [N,3] f32 with image index [N] i32
+ * -> occupied voxels in torch.unique's sorted (bid,x,y,z) order and, for the points inside the
+ * grid (original order kept), their voxel (revidx), index (valid_v_pid) and voxel-relative
+ * coordinate. xmin: host float[3] lower grid corner (already widened by half a voxel,
+ * pipeline.py:170), res: host int[3] cells per axis, crop: voxel size.
+ * Outputs must be sized for the worst case: occ_bid_coord [batch*res0*res1*res2, 4] i32,
+ * voxel_bound [same, 6] f32, valid_pid / revidx [N] i32, rel_coord [N,3] f32.
+ * counts (device int32[2]) receives {V, number of points inside the grid}.                     */
+size_t lidf_voxelize_workspace_bytes(int64_t n_pts, int64_t n_cells);
+int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n_pts, int batch,
+                      const float* xmin, const int32_t* res, float crop, int32_t* occ_bid_coord,
+                      float* voxel_bound, int32_t* valid_pid, int32_t* revidx, float* rel_coord,
+                      int32_t* counts, void* workspace, size_t workspace_bytes,
+                      lidf_stream_t stream);
+
 /* ---- PointNet2Stage ------------------------------------------------------------------------
  * Replaces PointNet2Stage.forward (models/pointnet.py:22-38) incl. its two
  * torch_scatter.scatter(..., reduce='max') poolings, for the shipped dimensions

@@ -438,6 +438,33 @@ def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_
 
 
 # ----------------------------------------------------------------------------------------------
+# f4  occupied-voxel build — utils/point_utils.py:12-76 batch_get_occupied_idx (overlap=False)
+#     + LIDF.get_occ_vox_bound (models/pipeline.py:162-201)
+# ----------------------------------------------------------------------------------------------
+def occupied_voxels(valid_xyz, valid_bid, xmin=(-1.0, -1.0, 0.0), xmax=(1.0, 1.0, 2.0), res=8):
+    lo = torch.tensor(xmin, dtype=torch.float32)
+    hi = torch.tensor(xmax, dtype=torch.float32)
+    part_size = torch.min(hi - lo).item() / res
+    lo = lo - 0.5 * part_size
+    hi = hi + 0.5 * part_size
+    v = valid_xyz.clone() - lo.unsqueeze(0)
+    r = torch.ceil((hi - lo) / part_size).long()
+    coord = torch.floor(v / part_size).long()
+    center = coord * part_size + 0.5 * part_size
+    rel = v - center
+    ok = torch.ones(v.shape[0], dtype=torch.bool)
+    for i in range(3):
+        ok &= (coord[:, i] >= 0) & (coord[:, i] < r[i])
+    pid = torch.arange(v.shape[0])[ok]
+    key = torch.cat((valid_bid.long().unsqueeze(-1)[ok], coord[ok]), -1)
+    occ, revidx = torch.unique(key, dim=0, return_inverse=True)
+    bound_min = lo.unsqueeze(0) + occ[:, 1:] * part_size
+    return {"part_size": part_size, "xmin": lo, "revidx": revidx, "valid_v_pid": pid,
+            "valid_v_rel_coord": rel[ok], "occ_vox_bid": occ[:, 0], "occ_vox_global_coord": occ[:, 1:],
+            "voxel_bound": torch.cat((bound_min, bound_min + part_size), 1)}
+
+
+# ----------------------------------------------------------------------------------------------
 # a11  stage-2 refinement: PointNet2Stage (models/pointnet.py:22-38) and
 #      RefineNet.get_pred_refine (models/pipeline.py:922-1030), eval flavour
 # ----------------------------------------------------------------------------------------------

@@ -185,6 +185,9 @@ def g3_pipeline():
             "pred_prob_end_softmax", "pred_pos"]
     out = {k: dd[k].detach().numpy() for k in keep}
     out["occ_voxel_feat"] = cap["occ_voxel_feat"].numpy()
+    for k in ("valid_xyz", "valid_bid", "revidx", "valid_v_pid", "valid_v_rel_coord",
+              "occ_vox_global_coord", "xmin"):
+        out[k] = dd[k].detach().numpy()
     out["part_size"] = np.float32(dd["part_size"])
     out["intr"] = torch.stack((dd["fx"], dd["fy"], dd["cx"], dd["cy"]), 1).numpy()
     out["hw"] = np.array([h, w])

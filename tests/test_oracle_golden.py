@@ -132,3 +132,13 @@ def test_g4_refine_matches_reference_trace():
     for i, (pos, ev, feat) in enumerate(outs, 1):
         assert np.abs(feat.numpy() - g4["occ_voxel_feat_%d" % i]).max() <= 2e-6
         assert np.abs(pos.numpy() - g4["pred_pos_refine_%d" % i]).max() <= 2e-6
+
+
+def test_g3_occupied_voxels():
+    g = load("g3_pipeline.npz")
+    res = orc.occupied_voxels(torch.from_numpy(g["valid_xyz"]), torch.from_numpy(g["valid_bid"]))
+    assert abs(res["part_size"] - float(g["part_size"])) == 0.0
+    for k in ("revidx", "valid_v_pid", "occ_vox_bid", "occ_vox_global_coord"):
+        assert (res[k].numpy() == g[k]).all(), k
+    for k in ("valid_v_rel_coord", "voxel_bound", "xmin"):
+        assert np.abs(res[k].numpy() - g[k]).max() == 0.0, k
