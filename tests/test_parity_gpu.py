@@ -72,3 +72,45 @@ def test_query_small(cuda, ragged):
     depth_ref = ref["pred_pos"][:, 2].reshape(scene["B"], scene["h"], scene["w"])
     l1 = (got["depth"].cpu() - depth_ref).abs().mean().item()
     assert l1 <= TOL
+
+
+def test_decoders_strided_rows(cuda):
+    """inp_feat given as a view with a row stride larger than D (ld_inp of the C ABI)."""
+    from implicit_depth_amd import decoders_forward
+    d = 385
+    pp = orc.randomize_biases(orc.init_decoder("IMNET", d, 1, 5.0), 2)
+    po = orc.randomize_biases(orc.init_decoder("IEF", d, 3, 5.0), 4)
+    big = torch.randn(300, 400, generator=torch.Generator().manual_seed(6))
+    x = big[:, :d]
+    with torch.no_grad():
+        gp, go = decoders_forward(big.to(cuda)[:, :d], make_module("IMNET", pp, d, cuda),
+                                  make_module("IEF", po, d, cuda))
+    assert (gp.cpu() - orc.imnet_forward(pp, x.contiguous())).abs().max().item() <= TOL
+    assert (go.cpu() - orc.ief_forward(po, x.contiguous(), 2)).abs().max().item() <= TOL
+
+
+def test_autograd_path_matches_hip(cuda):
+    """With autograd enabled the modules run their differentiable torch definition on the same
+    GPU: same values as the HIP path, and gradients reach the parameters and the input."""
+    d = 385
+    p = orc.randomize_biases(orc.init_decoder("IEF", d, 5, 5.0), 6)
+    m = make_module("IEF", p, d, cuda)
+    x = torch.randn(64, d, generator=torch.Generator().manual_seed(7)).to(cuda)
+    with torch.no_grad():
+        y_hip = m(x)
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    assert y.requires_grad
+    assert (y.detach() - y_hip).abs().max().item() <= TOL
+    y.sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    assert m.linear_1.weight.grad is not None and m.offset_enc.weight.grad is not None
+    from implicit_depth_amd import get_embedder
+    fn, _ = get_embedder(4)
+    pts = torch.randn(10, 3, device=cuda, requires_grad=True)
+    e = fn(pts)
+    e.sum().backward()
+    assert pts.grad is not None
+    with torch.no_grad():
+        assert (fn(pts.detach()) - e.detach()).abs().max().item() <= 1e-6
