@@ -80,11 +80,10 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
             for (int t = 0; t < NT; ++t) qc[t] = qn[t];
             SCHED_FENCE();
         }
-        if (!valid) continue;
         // ---- epilogue: this lane holds, per tile t and group g, features 32t + 8g + 4h + {0..3}
-        const float* ar = a.addrows ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
-        float* op = a.out ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
-        int* pp = a.pool ? (int*)a.pool + (size_t)a.poolidx[p] * a.ld_pool + 4 * h : nullptr;
+        const float* ar =
+            (valid && a.addrows) ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
+        float* op = (valid && a.out) ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -102,14 +101,62 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                 }
                 if (op) *(f32x4*)(op + t * 32 + 8 * g) = v;
-                if (pp) {
-                    // pool entries only ever grow: a plain (possibly stale) read can prove the
-                    // atomic unnecessary, never wrongly skip it. Removes almost all atomics when
-                    // many points share a voxel (the predicted points of stage 2).
-                    const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (v[i] > seen[i]) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(v[i]));
+                for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = v[i];
+            }
+        }
+        if (a.pool) {
+            // max-pool into pool[poolidx[row]] (values are post-ReLU, >= 0, pool starts at 0).
+            // Neighbouring rows mostly share their voxel, so the wave first reduces per distinct
+            // voxel: members keep their value, the others contribute 0 (the identity), a 5-step
+            // shuffle max over the 32 row lanes of each half, and one lane issues the atomics —
+            // and only where a plain (possibly stale; entries only grow) read does not already
+            // prove them unnecessary. More than 4 distinct voxels: per-lane atomics.
+            const int vox = valid ? a.poolidx[p] : -1;
+            unsigned todo = (unsigned)__ballot(valid && h == 0);
+            int rounds = 0;
+            while (todo && rounds < 4) {
+                const int lead = __builtin_ctz(todo);
+                const int vv = __builtin_amdgcn_readlane(vox, lead);
+                const unsigned mem = (unsigned)__ballot(vox == vv) & todo;
+                todo &= ~mem;
+                ++rounds;
+                const bool mine = vox == vv;
+                int* pp = (int*)a.pool + (size_t)vv * a.ld_pool + 4 * h;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 m;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x = mine ? acc[t][4 * g + i] : 0.f;
+#pragma unroll
+                            for (int sft = 16; sft >= 1; sft >>= 1) x = fmaxf(x, __shfl_xor(x, sft));
+                            m[i] = x;
+                        }
+                        if (col == lead) {
+                            const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (m[i] > seen[i])
+                                    atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(m[i]));
+                        }
+                    }
+                }
+            }
+            if (todo && valid && ((todo >> col) & 1u)) {
+                int* pp = (int*)a.pool + (size_t)vox * a.ld_pool + 4 * h;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (acc[t][4 * g + i] > seen[i])
+                                atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(acc[t][4 * g + i]));
+                    }
                 }
             }
         }
