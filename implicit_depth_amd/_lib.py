@@ -44,6 +44,7 @@ class LidfQueryArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("ev_points_begin", C.c_void_p), ("ev_points_end", C.c_void_p),
         ("rayfeat_out", C.c_void_p),
+        ("precision", C.c_int32),
     ]
 
 

@@ -7,6 +7,9 @@ extern "C" {
 hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                             float*, hipStream_t);
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
+                              float*, hipStream_t);
+hipError_t lidf_launch_points_h(const PointsArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_embed(const float*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_rayfeat(const float*, float*, int, int, int, const float*, const int*,
                                const int*, long long, int, int, float*, int, hipStream_t);
@@ -224,7 +227,11 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats
     mf.L = L;
     const int Ed = 3 + 6 * Lv;
     size_t o = 0;
-    w.stream_pts = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_FUSED, mf).total * 4, 256);
+    {
+        const size_t f32 = (size_t)lidf_make_layout(2, LIDF_MODE_FUSED, mf).total * 4;
+        const size_t f16 = (size_t)lidf_make_layout_h(2, mf).total * 4;
+        w.stream_pts = o; o += align_up(f32 > f16 ? f32 : f16, 256);
+    }
     w.aux_pts = o;    o += align_up(2 * LIDF_AUX_FLOATS * 4, 256);
     w.stream_vox = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, 0, 0, 1)).total * 4, 256);
     w.stream_ray = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, Ed, 0, 0)).total * 4, 256);
@@ -253,6 +260,8 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
     if (!q->prob || !q->off) return LIDF_ERR_BAD_ARG;
     if ((rc = check_decoder(q->prob)) || (rc = check_decoder(q->off))) return rc;
     if (q->prob->is_ief) return LIDF_ERR_UNSUPPORTED;  // prob_dec is an IMNet (pipeline.py:82)
+    if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
+        return LIDF_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int L = q->multires, Lv = q->multires_views;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
@@ -292,8 +301,12 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         mf.L = L;
         mf.enter_c0 = 256;
         mf.leave_c0 = 256 + E;
-        StreamLayout lf = lidf_make_layout(2, LIDF_MODE_FUSED, mf);
-        CHECK_HIP(lidf_launch_pack(lf, np, no, mf, stream_pts, aux_pts, st));
+        const bool split = q->precision == LIDF_PRECISION_F16X3;
+        StreamLayout lf = split ? lidf_make_layout_h(2, mf) : lidf_make_layout(2, LIDF_MODE_FUSED, mf);
+        if (split)
+            CHECK_HIP(lidf_launch_pack_h(lf, np, no, mf, stream_pts, aux_pts, st));
+        else
+            CHECK_HIP(lidf_launch_pack(lf, np, no, mf, stream_pts, aux_pts, st));
         L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
         StreamLayout lv = lidf_make_layout(2, LIDF_MODE_L1ONLY, mv);
         CHECK_HIP(lidf_launch_pack(lv, np, no, mv, stream_vox, aux_pts, st));
@@ -348,7 +361,10 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
 #endif
             long long nt = (P + 127) / 128;
             if (q->ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_begin, st));
-            CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
+            if (split)
+                CHECK_HIP(lidf_launch_points_h(a, (int)(nt < cus ? nt : cus), st));
+            else
+                CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
             if (q->ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_end, st));
         }
     }

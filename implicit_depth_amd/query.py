@@ -91,12 +91,18 @@ def to_reference_order(pair_ray, pair_vox):
     return torch.argsort(key, stable=True)
 
 
+PRECISIONS = {"f32": 0, "f16x3": 1}
+
+
 def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
                ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None,
-               want_rayfeat=False):
+               want_rayfeat=False, precision="f32"):
     """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
+
+    precision: "f32" (default) or "f16x3" — the decoders' matrix products evaluated as three
+    f16-piece products per term with f32 accumulation (f32-level accuracy, see lidf_hip.h).
 
     ray_dir [R,3] f32, ray_pix [R,2] i32 (x,y), ray_bid [R] i32, pair_* ray-major (see
     compute_ray_aabb), feat_grid [B,32,h,w] f32 (full_rgb_feat), vox_feat [V,128] f32
@@ -172,6 +178,9 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if want_rayfeat:  # keep the per-ray feature rows for stage 2 (lidf_refine(..., rayfeat=...))
         out["rayfeat"] = torch.empty((R, 128 + Ed), **f32)
         q.rayfeat_out = out["rayfeat"].data_ptr()
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    q.precision = PRECISIONS[precision]
     if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end) as integers
         q.ev_points_begin, q.ev_points_end = profile_events
     with torch.cuda.device(dev):

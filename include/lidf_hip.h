@@ -85,6 +85,9 @@ int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
  * Pairs ("points") are (ray, occupied voxel) intersections.  The per-ray reduction needs the
  * pairs grouped by ray: pair_off is the CSR row pointer over rays (pairs of ray r are
  * [pair_off[r], pair_off[r+1]) ), which is what lidf_ray_aabb_compact_* emits.              */
+#define LIDF_PRECISION_F32 0
+#define LIDF_PRECISION_F16X3 1
+
 typedef struct LidfQueryArgs {
     /* rays (models/pipeline.py:203-269 outputs) */
     int64_t n_rays;            /* R */
@@ -131,6 +134,12 @@ typedef struct LidfQueryArgs {
     /* optional output: the per-ray [ROI feature | embed(dir)] rows, [R, 128 + 3+6*multires_views]
      * (what lidf_ray_features_f32 computes) so that stage 2 (lidf_refine_f32) can re-use them. */
     float* rayfeat_out;
+    /* arithmetic of the decoders' matrix products (layers 1-3 of the per-point kernel):
+     *   LIDF_PRECISION_F32    (0, default) f32 inputs on v_mfma_f32_32x32x2_f32
+     *   LIDF_PRECISION_F16X3  (1) every f32 operand split into two f16 pieces, three
+     *       v_mfma_f32_32x32x16_f16 products per term, f32 accumulation: f32-level accuracy
+     *       (relative error of a product <= 2^-22) as long as |activations| < 65504        */
+    int32_t precision;
 } LidfQueryArgs;
 
 /* grid_floats = batch*32*height*width makes room for the optional 4x4 box-sum image that turns the
