@@ -36,6 +36,17 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define LDQ(rs, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
 
+// development only: per-phase cycle counters of wavefront 0 of workgroup 0, written to a.out_base
+#ifdef LIDF_PROFILE
+#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i) { long long t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
+#define PROF_DUMP if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_DUMP
+#endif
+
 #define CH_QUADS 16
 #define CH_ELEMS (CH_QUADS * 64)  // f32x4 elements per chunk buffer
 #define NBUF 3
@@ -298,13 +309,17 @@ __device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb,
         f.ring[Q & 3] = sb[f.cur + (Q + 4) * 64];
     else
         f.ring[Q & 3] = sb[f.nxt + (Q + 4 - CH_QUADS) * 64];
-    if (Q == 8) {
+    if (Q == 6) {
         // The buffer written here last held the chunk before the previous one: every wavefront
         // finished reading it before it passed the previous barrier.
 #pragma unroll
         for (int j = 0; j < 4; ++j) sb[f.nb * CH_ELEMS + (4 * c.wave + j) * 64 + c.lane] = f.stage[j];
         feed_issue(f, c);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (Q == 8) {
+        // LDS operations complete in order: once at most two are outstanding (the ring reads of
+        // positions 7 and 8) the four writes of position 6 have landed; no need to drain the ring.
+        asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
     }
     if (Q == CH_QUADS - 1) {
         f.cur = f.nxt;
@@ -471,7 +486,9 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
     load_idx(tb + 1, nxt);
     load_dir(cur);
 
+    PROF_DECL
     for (long long tile = tb; tile < te_; ++tile) {
+        PROF(0)
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < a.n;
         load_dir(nxt);
@@ -488,6 +505,7 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
             pz -= a.vox_center[3 * (size_t)cur.vid + 2];
         }
         const RevH rv[3] = {to_rev_h(px), to_rev_h(py), to_rev_h(pz)};
+        PROF(1)
 
         for (int net = 0; net < a.nets; ++net) {
             f32x16 base[8];
@@ -532,6 +550,7 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
                 next_round();
             }
 
+            PROF(2)
             // positional-encoding k-steps: 4 (octave, coordinate) combos each; the operand of the
             // next k-step is produced behind the matrix instructions of the current one
             f32x4 ph, pl, nh, nl;
@@ -607,12 +626,14 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
                 }
             }
 
+            PROF(3)
             // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
             float val = a.init[net];
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
             const int npass = a.npass[net];
             for (int pass = 0; pass < npass; ++pass) val += decoder_pass_h(f, c, sb, base, val, h, ax);
 
+            PROF(4)
             // ---------------- outputs ----------------
             if (valid && h == 0) {
                 const float o = out_act_h(val, a.sigmoid[net]);
@@ -636,6 +657,7 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
         nxt.te = nx2.te;
         nxt.tl = nx2.tl;
     }
+    PROF_DUMP
 }
 
 extern "C" hipError_t lidf_launch_points_h(const PointsArgs& a, int grid, hipStream_t st) {

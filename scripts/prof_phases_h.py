@@ -1,0 +1,25 @@
+"""Development aid: per-phase cycle counters of the split-f16 per-point kernel. Needs a library
+built with -DLIDF_PROFILE (LIDF_HIP_LIB=<path>): wavefront 0 of workgroup 0 writes its counters
+into the rayfeat rows."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from util import orc, to_dev, make_module
+from implicit_depth_amd.query import lidf_query
+dev = torch.device("cuda:0")
+scene = orc.synthetic_scene(1, 240, 320, 64, seed=1235)
+s = to_dev(scene, dev)
+prob = make_module("IMNET", scene["prob_p"], 385, dev); off = make_module("IEF", scene["off_p"], 385, dev)
+with torch.no_grad():
+    for _ in range(3):
+        o = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"],
+                       s["feat_grid"], s["vox_feat"], prob, off, ray_flat=s["ray_flat"], want_rayfeat=True, precision="f16x3")
+torch.cuda.synchronize()
+t = o["rayfeat"].view(-1)[:16].view(torch.int64).cpu().tolist()
+names = ["loop top + stores", "geometry", "base init (gather + rank-1)", "layer 1 (PE k-steps)", "passes", "-", "-", "-"]
+tot = sum(t[:8])
+for n, v in zip(names, t[:8]):
+    print("%-30s %12d ticks  %5.1f%%  per tile %8.0f" % (n, v, 100.0 * v / max(tot, 1), v / 150.0))
+print("total ticks", tot, "per tile", tot / 150.0)
