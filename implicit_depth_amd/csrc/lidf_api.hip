@@ -9,7 +9,7 @@ hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
-hipError_t lidf_launch_points_h(const PointsArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
 hipError_t lidf_launch_embed(const float*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_rayfeat(const float*, float*, int, int, int, const float*, const int*,
                                const int*, long long, int, int, float*, int, hipStream_t);
@@ -262,6 +262,8 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
     if (q->prob->is_ief) return LIDF_ERR_UNSUPPORTED;  // prob_dec is an IMNet (pipeline.py:82)
     if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
         return LIDF_ERR_BAD_ARG;
+    // the split-f16 kernel is built for up to 8 octaves (opt.model.multires = 8)
+    if (q->precision == LIDF_PRECISION_F16X3 && q->multires > 8) return LIDF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int L = q->multires, Lv = q->multires_views;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
@@ -362,7 +364,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             long long nt = (P + 127) / 128;
             if (q->ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_begin, st));
             if (split)
-                CHECK_HIP(lidf_launch_points_h(a, (int)(nt < cus ? nt : cus), st));
+                CHECK_HIP(lidf_launch_points_h(a, cus, st));
             else
                 CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
             if (q->ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_end, st));

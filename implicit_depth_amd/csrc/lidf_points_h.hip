@@ -5,33 +5,36 @@
 //     w*x ~= wh*xh + wh*xl + wl*xh ,   w = wh + wl,  x = xh + xl   (f16 pieces, f32 accumulation)
 // on v_mfma_f32_32x32x16_f16: three instructions of 32 cycles per 16 k instead of eight f32
 // instructions of 64 cycles. The dropped wl*xl term is <= 2^-22 |w x|; measured end-to-end error
-// against an f64 evaluation is that of the plain f32 kernel. f16 subnormal
-// operands are honoured by the instruction (scripts/mfma_f16_ubench.hip), so small low parts are
-// not lost; |activations| must stay below the f16 range (65504).
+// against the oracle is that of the plain f32 kernel. f16 subnormal operands are
+// honoured by the instruction (scripts/mfma_f16_ubench.hip), so small low parts are not lost;
+// |activations| must stay below the f16 range (65504).
 //
 // Operand layout of the instruction: lane l supplies 8 consecutive k (8*(l>>5) .. +7) of row/column
 // l&31; the result layout is the 32x32 f32 one. A result tile (16 registers per lane, features
 // F(r,h) = (r&3) + 8(r>>2) + 4h) therefore splits into two k-sub-steps: registers 0..7 and 8..15.
 //
-// Weight stream ("H" layout), per decoder, in quads of 1 KiB (64 lanes x 8 halves):
-//   layer 1 : NK1 k-steps x [for tile t<8: hi(t), lo(t)]            (16 quads = one chunk each)
-//             k-step ks < NK1-1 holds 4 (octave, coordinate) combos 4ks..4ks+3, element 2c' = sin,
-//             2c'+1 = cos; lanes 0..31 the enter position, lanes 32..63 the leave position;
-//             the last k-step holds raw x, y, z
-//   pass    : 176 quads, order given by pass_desc() below (k-outer: each H1 / H2 tile is consumed
-//             by all output tiles as soon as it has been produced, so only one split tile is live)
-// The four wavefronts of a workgroup consume the same stream in lockstep; it is staged once per
-// workgroup through LDS in chunks of 16 quads (3 rotating buffers, one s_barrier per chunk,
+// Everything is k-outer: a layer-1 output tile (32 features x 32 points) is produced — voxel part
+// gathered as the accumulator's initial value, ray part as a rank-1 update, positional encoding
+// as NK1 k-steps, IEF term as one more instruction — then activated, split and consumed by all
+// layer-2 output tiles at once, so no tile of layer-1 or layer-2 outputs is ever held beyond its
+// use and a wavefront needs < 256 registers: two workgroups per CU, whose matrix, vector and memory
+// instructions overlap. The second IEF iteration recomputes layer 1 (+168 matrix instructions)
+// instead of holding 128 registers across the pass.
+//
+// Weight stream ("H" layout): one section of 288 quads (1 KiB: 64 lanes x 8 halves) per decoder,
+// in exactly the order pass_desc() gives; an IEF decoder's section is consumed once per
+// iteration. The four wavefronts of a workgroup consume the stream in lockstep; it is staged once
+// per workgroup through LDS in chunks of 16 quads (3 rotating buffers, one s_barrier per chunk,
 // global loads issued one chunk ahead), and each wavefront keeps a 4-quad register ring of
 // ds_read_b128 in flight.
 #include "lidf_device.h"
+#include <stdio.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 #define MFMAH(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
-#define MFMAF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define LDQ(rs, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
@@ -50,35 +53,47 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define CH_QUADS 16
 #define CH_ELEMS (CH_QUADS * 64)  // f32x4 elements per chunk buffer
 #define NBUF 3
+#define NK1 LIDF_H_NK1            // layer-1 k-steps of 16: 6 of sin/cos (8 octaves) + raw x,y,z
+#define PASS_QUADS LIDF_HPASS_QUADS
+#define LDS_STREAM_ELEMS (NBUF * CH_ELEMS)
+#define LDS_BYTES ((LDS_STREAM_ELEMS + 4 * NK1 * 64) * 16)
 
 // ------------------------------------------------------------------------------------------------
-// Order of the pass section (shared by the packer and the kernel)
+// Order of a decoder's section (shared by the packer and the kernel)
 // ------------------------------------------------------------------------------------------------
-enum { K_B2 = 0, K_U, K_L2, K_B3, K_L3, K_PAD };
+enum { K_B2 = 0, K_L1, K_U, K_L2, K_B3, K_L3, K_PAD };
 struct QD {
     int kind;
     int t;    // output tile
-    int T;    // input tile (H1 tile for layer 2 / u, H2 tile for layer 3)
-    int sub;  // k-sub-step inside the input tile
+    int T;    // layer 1 / u: the H1 tile produced; layers 2, 3: the input tile consumed
+    int sub;  // layer 1: k-step; layers 2, 3: k-sub-step inside the input tile
     int lo;   // 0: high pieces of the weights, 1: low pieces
-    int j;    // ordinal of the (hi, lo) pair inside its 16- or 8-quad segment
+    int j;    // ordinal of the (hi, lo) pair inside its segment
 };
+__host__ __device__ constexpr QD l1u_desc(int T, int r) {
+    if (r < 2 * NK1) return {K_L1, 0, T, r >> 1, r & 1, r >> 1};
+    return {K_U, 0, T, 0, 0, 0};
+}
 __host__ __device__ constexpr QD pass_desc(int s) {
+    constexpr int L1U = 2 * NK1 + 1;
     if (s < 4) return {K_B2, s, 0, 0, 0, 0};
-    if (s == 4) return {K_U, 0, 0, 0, 0, 0};
-    s -= 5;
-    if (s < 7 * 17 + 16) {
-        const int T = s / 17 < 7 ? s / 17 : 7;
-        int r = s - 17 * T;
-        if (T < 7) {
-            if (r == 0) return {K_U, 0, T + 1, 0, 0, 0};  // u of the NEXT tile, one segment early
-            r -= 1;
-        }
+    s -= 4;
+    if (s < L1U) return l1u_desc(0, s);
+    s -= L1U;
+    if (s < 7 * (L1U + 16)) {
+        const int T = s / (L1U + 16);
+        int r = s % (L1U + 16);
+        if (r < L1U) return l1u_desc(T + 1, r);  // layer 1 runs one tile ahead of layer 2
+        r -= L1U;
         const int lo = r & 1, j = r >> 1;
-        if (T < 7) return {K_L2, j & 3, T, j >> 2, lo, j};
-        return {K_L2, j >> 1, T, j & 1, lo, j};  // last segment: tile-major, tiles finish one by one
+        return {K_L2, j & 3, T, j >> 2, lo, j};
     }
-    s -= 7 * 17 + 16;
+    s -= 7 * (L1U + 16);
+    if (s < 16) {
+        const int lo = s & 1, j = s >> 1;
+        return {K_L2, j >> 1, 7, j & 1, lo, j};  // last segment: tile-major, tiles finish one by one
+    }
+    s -= 16;
     if (s < 2) return {K_B3, s, 0, 0, 0, 0};
     s -= 2;
     if (s < 32) {
@@ -88,6 +103,8 @@ __host__ __device__ constexpr QD pass_desc(int s) {
     }
     return {K_PAD, 0, 0, 0, 0, 0};
 }
+static_assert(4 + 8 * (2 * NK1 + 1) + 8 * 16 + 2 + 32 <= PASS_QUADS, "section size");
+static_assert(PASS_QUADS % CH_QUADS == 0, "sections are whole chunks");
 
 __host__ __device__ constexpr int tile_feature(int r, int half) {
     return (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -111,26 +128,26 @@ __device__ _Float16 stream_value_h(const StreamLayout& lay, const NetW* nets, co
     const int net = (int)(e / per_net);
     e %= per_net;
     const NetW& n = nets[net];
-    int quad = (int)(e / 512);
+    const int quad = (int)(e / 512);
     const int lane = (int)(e % 512) / 8, i = (int)(e & 7);
     const int half = lane >> 5, o = lane & 31;
-    if (quad < lay.l1_quads) {
-        const int ks = quad / 16, r = quad % 16, t = r >> 1, part = r & 1;
-        const int nk1 = lay.l1_quads / 16;
-        int feat = -1;
-        if (ks < nk1 - 1) {
-            const int c = 4 * ks + (i >> 1), oct = c / 3, d = c % 3;
-            if (oct < m.L) feat = 3 + 6 * oct + 3 * (i & 1) + d;
-        } else if (i < 3) {
-            feat = i;
-        }
-        if (feat < 0) return (_Float16)0.f;
-        const int col = (half ? m.leave_c0 : m.enter_c0) + feat;
-        return hpiece(n.w1[(size_t)(32 * t + o) * n.ld1 + col], part);
-    }
-    quad -= lay.l1_quads;
     const QD d = pass_desc(quad);
     switch (d.kind) {
+        case K_L1: {
+            // k-step ks < NK1-1: 4 (octave, coordinate) combos 4ks..4ks+3, element 2c' = sin,
+            // 2c'+1 = cos; lanes 0..31 weight the enter position's embedding, lanes 32..63 the
+            // leave position's; the last k-step holds raw x, y, z
+            int feat = -1;
+            if (d.sub < NK1 - 1) {
+                const int c = 4 * d.sub + (i >> 1), oct = c / 3, dd = c % 3;
+                if (oct < m.L) feat = 3 + 6 * oct + 3 * (i & 1) + dd;
+            } else if (i < 3) {
+                feat = i;
+            }
+            if (feat < 0) return (_Float16)0.f;
+            const int col = (half ? m.leave_c0 : m.enter_c0) + feat;
+            return hpiece(n.w1[(size_t)(32 * d.T + o) * n.ld1 + col], d.lo);
+        }
         case K_B2:
             return half == 0 && i < 3 ? hpiece(n.b2[32 * d.t + o], i) : (_Float16)0.f;
         case K_B3:
@@ -211,6 +228,13 @@ __device__ __forceinline__ void split2(const float x0, const float x1, float& hi
     lo = __builtin_bit_cast(float, ll);
 }
 
+// x -> one word holding (hi piece, lo piece) of x
+__device__ __forceinline__ float split1(const float x) {
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    return pack2(hi, lo);
+}
+
 __device__ __forceinline__ float lrelu1(const float x) {
     const float t = x * 0.02f;
     float r;
@@ -218,20 +242,10 @@ __device__ __forceinline__ float lrelu1(const float x) {
     return r;
 }
 
-// pairs [P0, P1) of a result tile: leaky-relu, split, store into the two k-sub-step fragments
-template <int P0, int P1>
-__device__ __forceinline__ void prep_pairs(const f32x16& pre, f32x4 (&bh)[2], f32x4 (&bl)[2]) {
-#pragma unroll
-    for (int p = P0; p < P1; ++p) {
-        float hi, lo;
-        split2(lrelu1(pre[2 * p]), lrelu1(pre[2 * p + 1]), hi, lo);
-        bh[p >> 2][p & 3] = hi;
-        bl[p >> 2][p & 3] = lo;
-    }
-}
-__device__ __forceinline__ void prep_pairs_dyn(const int p0, const int p1, const f32x16& pre,
-                                               f32x4 (&bh)[2], f32x4 (&bl)[2]) {
-    // p0, p1 are compile-time constants after unrolling
+// pairs [p0, p1) of a result tile: leaky-relu, split, store into the two k-sub-step fragments
+// (p0, p1 are compile-time constants after unrolling)
+__device__ __forceinline__ void prep_pairs(const int p0, const int p1, const f32x16& pre,
+                                           f32x4 (&bh)[2], f32x4 (&bl)[2]) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         if (p >= p0 && p < p1) {
@@ -280,22 +294,20 @@ struct FeedCfg {
     __amdgpu_buffer_rsrc_t srs;
     int vq;         // lane * 16
     int wave, lane;
-    int net_bytes, nk1, nets;
+    int net_bytes, nets;
     int npass0, npass1;
 };
 
 __device__ __forceinline__ void feed_issue(Feed& f, const FeedCfg& c) {
-    const int chunk = f.s_pass < 0 ? f.s_idx : c.nk1 + f.s_idx;
-    const int off = f.s_net * c.net_bytes + chunk * (CH_QUADS * 1024) + c.wave * 4096;
+    const int off = f.s_net * c.net_bytes + f.s_idx * (CH_QUADS * 1024) + c.wave * 4096;
 #pragma unroll
     for (int j = 0; j < 4; ++j) f.stage[j] = LDQ(c.srs, c.vq + j * 1024, off);
-    // advance the sequencer
-    const int lim = f.s_pass < 0 ? c.nk1 : LIDF_HPASS_QUADS / CH_QUADS;
-    if (++f.s_idx == lim) {
+    // advance the sequencer: a decoder's section is consumed once per pass
+    if (++f.s_idx == PASS_QUADS / CH_QUADS) {
         f.s_idx = 0;
         const int np = f.s_net ? c.npass1 : c.npass0;
         if (++f.s_pass == np) {
-            f.s_pass = -1;
+            f.s_pass = 0;
             if (++f.s_net == c.nets) f.s_net = 0;
         }
     }
@@ -317,9 +329,9 @@ __device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb,
         feed_issue(f, c);
     }
     if (Q == 8) {
-        // LDS operations complete in order: once at most two are outstanding (the ring reads of
-        // positions 7 and 8) the four writes of position 6 have landed; no need to drain the ring.
-        asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+        // All LDS operations of this wavefront issued so far must have completed before the
+        // barrier publishes its four writes of position 6.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (Q == CH_QUADS - 1) {
         f.cur = f.nxt;
@@ -329,16 +341,30 @@ __device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb,
     return a;
 }
 
-// One decoder pass on the 32 points of this wavefront (see lidf_points.hip:decoder_pass):
-//   H1 = lrelu(base + u*val);  H2 = lrelu(W2 H1 + b2);  H3 = lrelu(W3 H2 + b3);  y = w4.H3 + b4
+// What one pass needs to know about the points of this wavefront.
+struct TileCtx {
+    const float* vp;     // voxpart row of this lane's point (+ net, + 4*half)
+    const float* rp;     // raypart row of this half's ray of round 0 (+ net, + lane&31)
+    float rayB;          // packed (1,1) if this lane's point belongs to this half's ray
+    int ray;             // this lane's ray (for the extra rounds)
+    unsigned todo;       // points not covered by round 0 (0 in the common case)
+    const float* rbase;  // raypart + net*256 + lane&31 (extra rounds)
+    int ray_stride;      // nets*256
+    int pl;              // LDS element index of this lane's low pieces of the embedding operands
+};
+
+// One decoder pass on the 32 points of this wavefront:
+//   H1 = lrelu(W1 x + b1 [+ u*val]);  H2 = lrelu(W2 H1 + b2);  H3 = lrelu(W3 H2 + b3);  y = w4.H3 + b4
+// with W1 x = voxpart[voxel] + raypart[ray] + W1[:, enter|leave] PE(position).
 __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4* sb,
-                                                const f32x16 (&base)[8], const float val,
-                                                const int h, const float* __restrict__ ax) {
+                                                const TileCtx& tc, const f32x4 (&pbh)[NK1],
+                                                const float val, const int h, const int col,
+                                                const float* __restrict__ ax) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                            0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const _Float16 one = (_Float16)1.f, hz = (_Float16)0.f;
-    f32x4 onesB = zero4, offB = zero4;
+    f32x4 onesB = zero4, offB = zero4, rayB = zero4;
     if (!h) {
         onesB[0] = pack2(one, one);
         onesB[1] = pack2(one, hz);
@@ -347,34 +373,105 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
         offB[0] = pack2(vh, vl);
         offB[1] = pack2(vh, hz);
     }
-    f32x16 acc2[4], acc3[2], pre;
-    f32x4 bh[2][2], bl[2][2];      // split H1 tile, [parity of T][k-sub-step]
-    f32x4 gh[4][2], gl[4][2];      // split H2 tiles
+    rayB[0] = tc.rayB;
+
+    f32x16 a1[2];               // layer-1 tiles, ping-pong: accumulating / being split
+    float rpv[2];               // raypart value of this lane's row, same ping-pong
+    f32x16 acc2[4], acc3[2];
+    f32x4 bh[2][2], bl[2][2];   // split H1 tile, [parity of T][k-sub-step]
+    f32x4 gh[4][2], gl[4][2];   // split H2 tiles
+    f32x4 pl_cur = zero4, pl_nxt = zero4;  // low pieces of the embedding operand, from LDS
     f32x4 w4[8];
     float b4 = 0.f;
     float ys[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // voxel part of tile T straight into the accumulator layout; ray part of this lane's row
+    auto gather = [&](const int T) {
 #pragma unroll
-    for (int s = 0; s < LIDF_HPASS_QUADS; ++s) {
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *(const f32x4*)(tc.vp + T * 32 + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[T & 1][4 * g + i] = v[i];
+        }
+        rpv[T & 1] = tc.rp[T * 32];
+    };
+    gather(0);
+    gather(1);
+    pl_cur = sb[tc.pl];
+
+#pragma unroll
+    for (int s = 0; s < PASS_QUADS; ++s) {
         const int Q = s % CH_QUADS;
         const QD d = pass_desc(s);
         const f32x4 A = feed_take(f, c, sb, Q);
         if (d.kind == K_B2) {
             acc2[d.t] = MFMAH(A, onesB, zero16);
+        } else if (d.kind == K_L1) {
+            f32x16& acc = a1[d.T & 1];
+            if (!d.lo) {
+                if (d.sub == 0) {
+                    // ray part: rank-1 update, A = (hi, lo) of the raypart row of this half's ray,
+                    // B = membership of the point; two rays per instruction. Tiles that straddle
+                    // more than two rays (ragged scenes) take extra rounds.
+                    f32x4 rayA = zero4;
+                    rayA[0] = split1(rpv[d.T & 1]);
+                    acc = MFMAH(rayA, rayB, acc);
+                    if (tc.todo) {
+                        unsigned todo = tc.todo;
+                        while (todo) {
+                            const int p0 = __builtin_ctz(todo);
+                            const int r0 = __builtin_amdgcn_readlane(tc.ray, p0);
+                            const unsigned m0 = (unsigned)__ballot(tc.ray == r0) & todo;
+                            todo &= ~m0;
+                            int r1 = r0;
+                            unsigned m1 = 0;
+                            if (todo) {
+                                const int p1 = __builtin_ctz(todo);
+                                r1 = __builtin_amdgcn_readlane(tc.ray, p1);
+                                m1 = (unsigned)__ballot(tc.ray == r1) & todo;
+                                todo &= ~m1;
+                            }
+                            const float v = tc.rbase[(size_t)(h ? r1 : r0) * tc.ray_stride + d.T * 32];
+                            f32x4 xa = zero4, xb = zero4;
+                            xa[0] = split1(v);
+                            xb[0] = (((h ? m1 : m0) >> col) & 1u) ? pack2(one, one) : 0.f;
+                            acc = MFMAH(xa, xb, acc);
+                        }
+                    }
+                }
+                acc = MFMAH(A, pbh[d.sub], acc);
+                acc = MFMAH(A, pl_cur, acc);
+                // low pieces of the next k-step's operand (wraps to k-step 0 for the next tile)
+                pl_nxt = sb[tc.pl + ((d.sub + 1) % NK1) * 64];
+                // split the previous tile behind these matrix instructions
+                if (d.T >= 1) {
+                    const int par = (d.T - 1) & 1;
+                    if (d.sub < NK1 - 1)
+                        prep_pairs(d.sub, d.sub + 1, a1[par], bh[par], bl[par]);
+                    else
+                        prep_pairs(NK1 - 1, 8, a1[par], bh[par], bl[par]);
+                }
+            } else {
+                acc = MFMAH(A, pbh[d.sub], acc);
+                pl_cur = pl_nxt;
+            }
         } else if (d.kind == K_U) {
-            pre = MFMAH(A, offB, base[d.T]);
-            if (d.T == 0) prep_pairs<0, 8>(pre, bh[0], bl[0]);
+            a1[d.T & 1] = MFMAH(A, offB, a1[d.T & 1]);
         } else if (d.kind == K_L2) {
             const int par = d.T & 1;
             if (!d.lo) {
+                // the tile after next can start loading: its accumulator is free once the split
+                // of tile T (same parity) is done
+                if (d.j == 0 && d.T + 2 < 8) gather(d.T + 2);
                 acc2[d.t] = MFMAH(A, bh[par][d.sub], acc2[d.t]);
                 acc2[d.t] = MFMAH(A, bl[par][d.sub], acc2[d.t]);
-                if (d.T < 7) {
-                    // split pair j of the next H1 tile behind these matrix instructions
-                    prep_pairs_dyn(d.j, d.j + 1, pre, bh[par ^ 1], bl[par ^ 1]);
-                } else {
+                if (d.T == 6) {
+                    // tile 7 has no layer-1 segment after it to hide behind
+                    prep_pairs(d.j, d.j + 1, a1[1], bh[1], bl[1]);
+                } else if (d.T == 7) {
                     // last segment (tile-major): output tiles complete one by one
-                    if (d.j >= 2 && d.j < 6) prep_pairs_dyn(2 * (d.j - 2), 2 * (d.j - 2) + 2, acc2[0], gh[0], gl[0]);
-                    if (d.j >= 6) prep_pairs_dyn(2 * (d.j - 6), 2 * (d.j - 6) + 2, acc2[1], gh[1], gl[1]);
+                    if (d.j >= 2 && d.j < 6) prep_pairs(2 * (d.j - 2), 2 * (d.j - 2) + 2, acc2[0], gh[0], gl[0]);
+                    if (d.j >= 6) prep_pairs(2 * (d.j - 6), 2 * (d.j - 6) + 2, acc2[1], gh[1], gl[1]);
                 }
             } else {
                 acc2[d.t] = MFMAH(A, bh[par][d.sub], acc2[d.t]);
@@ -393,8 +490,8 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
                 acc3[d.t] = MFMAH(A, gl[d.T][d.sub], acc3[d.t]);
                 // pending splits: segment T handles the second half of H2[T+1] (first two pairs)
                 // and the first half of H2[T+2] (last two pairs)
-                if (d.T < 3 && d.j < 2) prep_pairs_dyn(4 + 2 * d.j, 6 + 2 * d.j, acc2[d.T + 1], gh[d.T + 1], gl[d.T + 1]);
-                if (d.T < 2 && d.j >= 2) prep_pairs_dyn(2 * (d.j - 2), 2 * (d.j - 2) + 2, acc2[d.T + 2], gh[d.T + 2], gl[d.T + 2]);
+                if (d.T < 3 && d.j < 2) prep_pairs(4 + 2 * d.j, 6 + 2 * d.j, acc2[d.T + 1], gh[d.T + 1], gl[d.T + 1]);
+                if (d.T < 2 && d.j >= 2) prep_pairs(2 * (d.j - 2), 2 * (d.j - 2) + 2, acc2[d.T + 2], gh[d.T + 2], gl[d.T + 2]);
                 if (d.T == 3 && d.j >= 2) {
                     // acc3[0] is complete: its half of layer 4 runs behind acc3[1]'s last steps
 #pragma unroll
@@ -423,8 +520,8 @@ struct GeoH {
     float te, tl, dx, dy, dz;
 };
 
-__global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
-    __shared__ f32x4 sb[NBUF * CH_ELEMS];
+__global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
+    extern __shared__ f32x4 sb[];  // [NBUF chunks of the stream][per wavefront: NK1 operand quads]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -437,11 +534,9 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
     c.wave = wave;
     c.lane = lane;
     c.net_bytes = a.net_quads * 1024;
-    c.nk1 = a.l1_quads / CH_QUADS;
     c.nets = a.nets;
     c.npass0 = a.npass[0];
     c.npass1 = a.npass[1];
-    const int G = (a.L + 3) / 4;  // groups of three layer-1 k-steps (four octaves)
 
     // contiguous range of 128-point tiles per workgroup; every wavefront of the workgroup runs
     // the same number of tiles (the stream is shared), out-of-range points are clamped
@@ -454,7 +549,7 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
     // prologue: chunk 0 into buffer 0, chunk 1 in flight
     Feed f;
     f.s_net = 0;
-    f.s_pass = -1;
+    f.s_pass = 0;
     f.s_idx = 0;
     feed_issue(f, c);
 #pragma unroll
@@ -486,6 +581,10 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
     load_idx(tb + 1, nxt);
     load_dir(cur);
 
+    TileCtx tc;
+    tc.pl = LDS_STREAM_ELEMS + wave * NK1 * 64 + lane;
+    tc.ray_stride = a.nets * 256;
+
     PROF_DECL
     for (long long tile = tb; tile < te_; ++tile) {
         PROF(0)
@@ -504,136 +603,70 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
             py -= a.vox_center[3 * (size_t)cur.vid + 1];
             pz -= a.vox_center[3 * (size_t)cur.vid + 2];
         }
-        const RevH rv[3] = {to_rev_h(px), to_rev_h(py), to_rev_h(pz)};
+        // operands of the layer-1 k-steps, shared by all passes of this tile: high pieces in
+        // registers, low pieces in this wavefront's LDS rows
+        f32x4 pbh[NK1];
+        {
+            const RevH rv[3] = {to_rev_h(px), to_rev_h(py), to_rev_h(pz)};
+#pragma unroll
+            for (int ks = 0; ks < NK1 - 1; ++ks) {
+                f32x4 lo4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = 4 * ks + i;  // combo: octave idx/3, coordinate idx%3
+                    float sv, cv, hi, lo;
+                    rev_sincos_h(rv[idx % 3], (float)(1 << (idx / 3)), sv, cv);
+                    split2(sv, cv, hi, lo);
+                    pbh[ks][i] = hi;
+                    lo4[i] = lo;
+                }
+                sb[tc.pl + ks * 64] = lo4;
+            }
+            f32x4 hi4 = {0.f, 0.f, 0.f, 0.f}, lo4 = {0.f, 0.f, 0.f, 0.f};
+            float hi, lo;
+            split2(px, py, hi, lo);
+            hi4[0] = hi;
+            lo4[0] = lo;
+            split2(pz, 0.f, hi, lo);
+            hi4[1] = hi;
+            lo4[1] = lo;
+            pbh[NK1 - 1] = hi4;
+            sb[tc.pl + (NK1 - 1) * 64] = lo4;
+        }
+        // rays of this wavefront's 32 points: round 0 covers the first two distinct rays
+        int my_ray;
+        {
+            unsigned todo = (unsigned)__ballot(h == 0);
+            const int p0 = __builtin_ctz(todo);
+            const int r0 = __builtin_amdgcn_readlane(cur.ray, p0);
+            const unsigned m0 = (unsigned)__ballot(cur.ray == r0) & todo;
+            todo &= ~m0;
+            int r1 = r0;
+            unsigned m1 = 0;
+            if (todo) {
+                const int p1 = __builtin_ctz(todo);
+                r1 = __builtin_amdgcn_readlane(cur.ray, p1);
+                m1 = (unsigned)__ballot(cur.ray == r1) & todo;
+                todo &= ~m1;
+            }
+            my_ray = h ? r1 : r0;
+            tc.rayB = (((h ? m1 : m0) >> col) & 1u) ? pack2((_Float16)1.f, (_Float16)1.f) : 0.f;
+            tc.todo = todo;
+            tc.ray = cur.ray;
+        }
         PROF(1)
 
         for (int net = 0; net < a.nets; ++net) {
-            f32x16 base[8];
-            // ---------------- layer 1 ----------------
-            // accumulator init = voxpart[vid] (+ layer-1 bias) gathered per lane, + raypart[ray] as
-            // rank-1 f32 updates, exactly as lidf_points.hip does
-            unsigned todo = (unsigned)__ballot(h == 0);
-            float ar[8], bsel;
-            auto next_round = [&]() {
-                const int p0 = __builtin_ctz(todo);
-                const int r0 = __builtin_amdgcn_readlane(cur.ray, p0);
-                const unsigned m0 = (unsigned)__ballot(cur.ray == r0) & todo;
-                todo &= ~m0;
-                int r1 = r0;
-                unsigned m1 = 0;
-                if (todo) {
-                    const int p1 = __builtin_ctz(todo);
-                    r1 = __builtin_amdgcn_readlane(cur.ray, p1);
-                    m1 = (unsigned)__ballot(cur.ray == r1) & todo;
-                    todo &= ~m1;
-                }
-                bsel = (((h ? m1 : m0) >> col) & 1u) ? 1.f : 0.f;
-                const float* rp = a.raypart + ((size_t)(h ? r1 : r0) * a.nets + net) * 256 + col;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) ar[t] = rp[t * 32];
-            };
-            next_round();
-            const float* vp = a.voxpart + ((size_t)cur.vid * a.nets + net) * 256 + 4 * h;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *(const f32x4*)(vp + t * 32 + 8 * g);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
-                }
-            }
-            for (;;) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) base[t] = MFMAF(ar[t], bsel, base[t]);
-                if (!todo) break;
-                next_round();
-            }
-
-            PROF(2)
-            // positional-encoding k-steps: 4 (octave, coordinate) combos each; the operand of the
-            // next k-step is produced behind the matrix instructions of the current one
-            f32x4 ph, pl, nh, nl;
-            {
-                float sv[4], cv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rev_sincos_h(rv[i % 3], (float)(1 << (i / 3)), sv[i], cv[i]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float hi, lo;
-                    split2(sv[i], cv[i], hi, lo);
-                    ph[i] = hi;
-                    pl[i] = lo;
-                }
-            }
-            float scg = 1.f;  // 2^(4g)
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    // next k-step: (g, j+1) or (g+1, 0)
-                    const int jn = (j + 1) % 3;
-                    const float scn = j == 2 ? scg * 16.f : scg;
-                    float sv[4], cv[4];
-#pragma unroll
-                    for (int q = 0; q < CH_QUADS; ++q) {
-                        const int t = q >> 1;
-                        const f32x4 A = feed_take(f, c, sb, q);
-                        if (!(q & 1)) {
-                            base[t] = MFMAH(A, ph, base[t]);
-                            base[t] = MFMAH(A, pl, base[t]);
-                            if (t < 4) {
-                                const int idx = 4 * jn + t;
-                                rev_sincos_h(rv[idx % 3], scn * (float)(1 << (idx / 3)), sv[t], cv[t]);
-                            } else {
-                                float hi, lo;
-                                split2(sv[t - 4], cv[t - 4], hi, lo);
-                                nh[t - 4] = hi;
-                                nl[t - 4] = lo;
-                            }
-                        } else {
-                            base[t] = MFMAH(A, ph, base[t]);
-                        }
-                        SCHED_FENCE();
-                    }
-                    ph = nh;
-                    pl = nl;
-                }
-                scg *= 16.f;
-            }
-            {
-                // tail k-step: raw x, y, z
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                ph = zero4;
-                pl = zero4;
-                float hi, lo;
-                split2(px, py, hi, lo);
-                ph[0] = hi;
-                pl[0] = lo;
-                split2(pz, 0.f, hi, lo);
-                ph[1] = hi;
-                pl[1] = lo;
-#pragma unroll
-                for (int q = 0; q < CH_QUADS; ++q) {
-                    const int t = q >> 1;
-                    const f32x4 A = feed_take(f, c, sb, q);
-                    if (!(q & 1)) {
-                        base[t] = MFMAH(A, ph, base[t]);
-                        base[t] = MFMAH(A, pl, base[t]);
-                    } else {
-                        base[t] = MFMAH(A, ph, base[t]);
-                    }
-                    SCHED_FENCE();
-                }
-            }
-
-            PROF(3)
-            // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
+            tc.vp = a.voxpart + ((size_t)cur.vid * a.nets + net) * 256 + 4 * h;
+            tc.rp = a.raypart + ((size_t)my_ray * a.nets + net) * 256 + col;
+            tc.rbase = a.raypart + net * 256 + col;
             float val = a.init[net];
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
             const int npass = a.npass[net];
-            for (int pass = 0; pass < npass; ++pass) val += decoder_pass_h(f, c, sb, base, val, h, ax);
+            for (int pass = 0; pass < npass; ++pass)
+                val += decoder_pass_h(f, c, sb, tc, pbh, val, h, col, ax);
+            PROF(2 + net)
 
-            PROF(4)
             // ---------------- outputs ----------------
             if (valid && h == 0) {
                 const float o = out_act_h(val, a.sigmoid[net]);
@@ -660,8 +693,25 @@ __global__ void __launch_bounds__(256) lidf_points_h_kernel(PointsArgs a) {
     PROF_DUMP
 }
 
-extern "C" hipError_t lidf_launch_points_h(const PointsArgs& a, int grid, hipStream_t st) {
+extern "C" hipError_t lidf_launch_points_h(const PointsArgs& a, int cus, hipStream_t st) {
     if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_points_h_kernel, dim3(grid), dim3(256), 0, st, a);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)lidf_points_h_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+#ifdef LIDF_PROFILE
+        for (int lds = 32768; lds <= LDS_BYTES + 8192; lds += 4096) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lidf_points_h_kernel, 256, lds);
+            fprintf(stderr, "occupancy with %d B of LDS per workgroup: %d workgroups per CU\n", lds, nb);
+        }
+#endif
+    }
+    // two workgroups per CU
+    const long long ntile = (a.n + 127) / 128;
+    const int grid = (int)(ntile < 2LL * cus ? ntile : 2LL * cus);
+    hipLaunchKernelGGL(lidf_points_h_kernel, dim3(grid), dim3(256), LDS_BYTES, st, a);
     return hipGetLastError();
 }

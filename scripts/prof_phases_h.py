@@ -12,14 +12,19 @@ dev = torch.device("cuda:0")
 scene = orc.synthetic_scene(1, 240, 320, 64, seed=1235)
 s = to_dev(scene, dev)
 prob = make_module("IMNET", scene["prob_p"], 385, dev); off = make_module("IEF", scene["off_p"], 385, dev)
+sys.path.insert(0, ROOT)
+from bench import HipEvents
+hev = HipEvents(); e0, e1 = hev.create(), hev.create()
 with torch.no_grad():
     for _ in range(3):
         o = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"],
-                       s["feat_grid"], s["vox_feat"], prob, off, ray_flat=s["ray_flat"], want_rayfeat=True, precision="f16x3")
+                       s["feat_grid"], s["vox_feat"], prob, off, ray_flat=s["ray_flat"], want_rayfeat=True, precision="f16x3", profile_events=(e0.value, e1.value))
 torch.cuda.synchronize()
 t = o["rayfeat"].view(-1)[:16].view(torch.int64).cpu().tolist()
-names = ["loop top + stores", "geometry", "base init (gather + rank-1)", "layer 1 (PE k-steps)", "passes", "-", "-", "-"]
+names = ["loop top + stores", "geometry + PE operands + rays", "net 0 (1 pass)", "net 1 (2 passes)", "-", "-", "-", "-"]
 tot = sum(t[:8])
 for n, v in zip(names, t[:8]):
-    print("%-30s %12d ticks  %5.1f%%  per tile %8.0f" % (n, v, 100.0 * v / max(tot, 1), v / 150.0))
-print("total ticks", tot, "per tile", tot / 150.0)
+    print("%-30s %12d ticks  %5.1f%%  per tile %8.0f" % (n, v, 100.0 * v / max(tot, 1), v / 75.0))
+ms = hev.elapsed_ms(e0, e1)
+print("points kernel %.3f ms -> %.2f GHz by the tick count of workgroup 0" % (ms, tot / ms / 1e6))
+print("total ticks", tot, "per tile", tot / 75.0)

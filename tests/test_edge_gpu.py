@@ -32,16 +32,19 @@ def test_no_pairs_and_no_rays(cuda):
     assert out["pred_pos"].shape == (0, 3)
 
 
-def test_relative_positions_and_offset_range(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_relative_positions_and_offset_range(cuda, precision):
     scene = orc.synthetic_scene(1, 12, 16, 8, seed=6, ragged=True)
     kw = dict(offset_range=(-0.2, 0.2), part_size=0.25)
     ref = oracle_query(scene, vox_center=scene["vox_center"], pos_rel=True, **kw)
-    got = run_query(scene, cuda, vox_center=scene["vox_center"].to(cuda), pos_rel=True, **kw)
+    got = run_query(scene, cuda, vox_center=scene["vox_center"].to(cuda), pos_rel=True,
+                    precision=precision, **kw)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
         assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
 
 
-def test_identity_embedder_and_imnet_offset(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_identity_embedder_and_imnet_offset(cuda, precision):
     """pos_encode False (D = 265) and offdec_type IMNET."""
     from implicit_depth_amd.query import lidf_query
     scene = orc.synthetic_scene(1, 12, 16, 8, seed=7, multires=0, multires_views=0)
@@ -56,12 +59,13 @@ def test_identity_embedder_and_imnet_offset(cuda):
         got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                          s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"],
                          make_module("IMNET", pp, D, cuda), make_module("IMNET", po, D, cuda),
-                         multires=0, multires_views=0)
+                         multires=0, multires_views=0, precision=precision)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
         assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
 
 
-def test_sigmoid_outputs_and_three_iterations(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_sigmoid_outputs_and_three_iterations(cuda, precision):
     from implicit_depth_amd.query import lidf_query
     scene = orc.synthetic_scene(1, 10, 12, 6, seed=8)
     D = scene["D"]
@@ -73,7 +77,8 @@ def test_sigmoid_outputs_and_three_iterations(cuda):
         got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                          s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"],
                          make_module("IMNET", scene["prob_p"], D, cuda, use_sigmoid=True),
-                         make_module("IEF", scene["off_p"], D, cuda, n_iter=3, use_sigmoid=True))
+                         make_module("IEF", scene["off_p"], D, cuda, n_iter=3, use_sigmoid=True),
+                         precision=precision)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
         assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
 
@@ -91,10 +96,11 @@ def test_ray_features_border_pixels(cuda):
         assert (got[:, 128:] - orc.embed(scene["ray_dir"], 4)).abs().max().item() <= 1e-6
 
 
-def test_full_size_properties(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_full_size_properties(cuda, precision):
     """BASELINE configs[1] size (240x320x64): properties that need no full-size oracle run."""
     scene = orc.synthetic_scene(1, 240, 320, 64, seed=1235)
-    got = run_query(scene, cuda)
+    got = run_query(scene, cuda, precision=precision)
     P, R = scene["P"], scene["R"]
     sm = got["pred_prob_end_softmax"]
     assert torch.isfinite(got["pair_pred_pos"]).all() and torch.isfinite(sm).all()

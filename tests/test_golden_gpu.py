@@ -29,7 +29,8 @@ def test_g2_decoders_hip(cuda):
         assert np.abs(got - g[key]).max() <= TOL, key
 
 
-def test_g3_pipeline_hip(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_g3_pipeline_hip(cuda, precision):
     """ray_dirs -> compact ray/voxel pairs -> fused query, compared with the reference's own
     data_dict (voxel-major order) through the ray-major -> reference permutation."""
     from implicit_depth_amd.query import compute_ray_aabb, lidf_query, ray_dirs, to_reference_order
@@ -57,7 +58,8 @@ def test_g3_pipeline_hip(cuda):
                          torch.from_numpy(g["full_rgb_feat"]).to(cuda),
                          torch.from_numpy(g["occ_voxel_feat"]).to(cuda), prob, offd,
                          offset_range=tuple(float(v) for v in g["offset_range"]),
-                         part_size=float(g["part_size"]), ray_flat=ray_flat.to(cuda), depth=depth)
+                         part_size=float(g["part_size"]), ray_flat=ray_flat.to(cuda), depth=depth,
+                         precision=precision)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_prob_end_softmax"):
         got = out[k][perm].cpu().numpy()
         assert np.abs(got - g[k]).max() <= TOL, k

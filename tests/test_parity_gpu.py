@@ -52,11 +52,12 @@ def test_decoders_pair_and_empty(cuda):
     assert ep.shape == (0, 1) and eo.shape == (0, 1)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("ragged", [False, True])
-def test_query_small(cuda, ragged):
+def test_query_small(cuda, ragged, precision):
     scene = orc.synthetic_scene(2, 16, 24, 16, seed=1234, ragged=ragged)
     ref = oracle_query(scene)
-    got = run_query(scene, cuda)
+    got = run_query(scene, cuda, precision=precision)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
         err = (got[k].cpu() - ref[k]).abs().max().item()
         assert err <= TOL, (k, err)

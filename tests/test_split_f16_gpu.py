@@ -1,0 +1,56 @@
+"""The split-f16 (f16x3, f32 accumulate) per-point kernel: cases specific to it. The generic
+query tests (small / ragged / golden g3 / edge options / full size) run for both precisions."""
+import pytest
+import torch
+
+from util import TOL, make_module, oracle_query, orc, run_query, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_pair_per_ray(cuda):
+    """N = 1: every point of a 32-point tile belongs to a different ray, so the ray part of layer 1
+    takes 16 rank-1 rounds per tile instead of one."""
+    scene = orc.synthetic_scene(1, 16, 24, 1, seed=41)
+    ref = oracle_query(scene)
+    got = run_query(scene, cuda, precision="f16x3")
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+
+
+def test_close_to_f32_kernel(cuda):
+    """Same inputs through both kernels: the split products must stay at f32 rounding level, far
+    inside the 1e-4 contract (a plain f16 product would be off by ~1e-3 here)."""
+    scene = orc.synthetic_scene(2, 24, 32, 16, seed=42, ragged=True)
+    a = run_query(scene, cuda, precision="f32")
+    b = run_query(scene, cuda, precision="f16x3")
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert (a[k] - b[k]).abs().max().item() <= 2e-5, k
+
+
+def test_large_activations(cuda):
+    """Weights scaled up 4x on top of the test scale: activations of a few hundred, still far
+    from the f16 range, relative accuracy unchanged."""
+    scene = orc.synthetic_scene(1, 12, 16, 8, seed=43, weight_scale=20.0)
+    ref = oracle_query(scene)
+    got = run_query(scene, cuda, precision="f16x3")
+    for k in ("pred_offset", "pred_prob_end"):
+        scale = max(1.0, ref[k].abs().max().item())
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL * scale, k
+
+
+def test_unsupported_and_bad_precision(cuda):
+    from implicit_depth_amd.query import lidf_query
+    scene = orc.synthetic_scene(1, 8, 8, 4, seed=44, multires=10)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob = make_module("IMNET", orc.init_decoder("IMNET", D, 1, 1.0), D, cuda)
+    off = make_module("IEF", orc.init_decoder("IEF", D, 2, 1.0), D, cuda)
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+            s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+    with torch.no_grad():
+        lidf_query(*args, multires=10)                      # the f32 kernel takes up to 16 octaves
+        with pytest.raises(RuntimeError):
+            lidf_query(*args, multires=10, precision="f16x3")
+        with pytest.raises(ValueError):
+            lidf_query(*args, multires=10, precision="bf16")
