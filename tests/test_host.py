@@ -41,7 +41,9 @@ def test_struct_layouts_match_header():
     # LidfDecoder: 10 pointers + 4 x 4-byte fields; LidfQueryArgs: as declared, natural alignment
     assert C.sizeof(_lib.LidfDecoder) == 10 * 8 + 16
     assert C.sizeof(_lib.LidfQueryArgs) % 8 == 0
-    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 24 == C.sizeof(_lib.LidfQueryArgs)
+    # workspace_bytes, two events, rayfeat_out, precision (+ padding to 8)
+    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 24 + 8 == C.sizeof(_lib.LidfQueryArgs)
+    assert _lib.LidfQueryArgs.precision.offset == _lib.LidfQueryArgs.rayfeat_out.offset + 8
 
 
 def test_modules_keep_reference_interface():
