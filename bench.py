@@ -28,6 +28,12 @@ F_ALG = 853952.0       # FLOP per point, reference formulation (SURVEY.md §8d /
 # v_mfma_f32_32x32x2 instructions of 4096 FLOP each.
 F_EXEC = (2 * 51 * 8 + 3 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0  # = 355,584
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+# split-f16 kernel (lidf_points_h.hip): per wave-tile 3 passes x 430 v_mfma_f32_32x32x16_f16
+# (8 tiles x (1 ray + 21 embedding + 1 IEF + 24 layer-2) + 6 bias + 48 layer-3) of 32,768 FLOP
+F_EXEC_H = 3 * 430 * 32768 / 32.0  # = 1,320,960
+PEAK_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (sustained under the power
+#                           cap with random operands: ~1.4-1.6 PFLOP/s, scripts/mfma_power_ubench.hip)
+DTYPE_F16X3 = "f16x3 (f32 operands split into two f16 pieces, 3 products per term, f32 accumulate)"
 
 
 class HipEvents:
@@ -180,6 +186,11 @@ def main():
     ap.add_argument("--samples", type=int, default=64, help="candidates per ray (N)")
     ap.add_argument("--frames", type=int, default=1, help="frames per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="arithmetic of the decoders' matrix products: f32 (default, the headline) or "
+                         "f16x3 = three f16-piece products per term with f32 accumulation (f32-level "
+                         "accuracy, LidfQueryArgs.precision); the default f32 run also reports the "
+                         "f16x3 rate and its deviation from the f32 outputs as \"split_f16\"")
     ap.add_argument("--workload", default="query",
                     choices=["query", "query+refine", "decoders", "embed"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
@@ -227,12 +238,13 @@ def main():
     pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
     state = {"ws": None}
 
-    def step(events=None):
+    def step(events=None, precision=args.precision):
         with torch.no_grad():
             out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                              s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
                              ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"],
-                             profile_events=events, want_rayfeat=refine is not None)
+                             profile_events=events, want_rayfeat=refine is not None,
+                             precision=precision)
             if refine is not None:
                 out["pred_pos_refine"] = refine(out)
                 depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
@@ -267,9 +279,33 @@ def main():
         elapsed = float(t.item())
 
     kern_ms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
+    split = None
+    if world == 1 and args.precision == "f32" and refine is None:
+        # the same workload through the split-f16 kernel: rate, and deviation from the f32 outputs
+        ref = step()
+        ref = {k: ref[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos")}
+        for _ in range(args.warmup):
+            step(precision="f16x3")
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(args.steps):
+            got = step(pairs[i], precision="f16x3")
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        kms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
+        split = {"value": round(P * args.steps / el / 1e6, 2), "unit": "Mpoints/s",
+                 "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": DTYPE_F16X3,
+                 "kernel": "lidf_points_h_kernel", "kernel_ms": round(kms, 4),
+                 "achieved_exec": round(F_EXEC_H * P / (kms * 1e-3) / 1e12, 2),
+                 "peak": PEAK_F16_TFLOPS, "unit_roofline": "TFLOP/s",
+                 "frac_exec": round(F_EXEC_H * P / (kms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                 "max_abs_diff_vs_f32": {k: float((got[k] - ref[k]).abs().max()) for k in ref}}
     if rank == 0:
         value = world * P * args.steps / elapsed / 1e6
         ach = F_ALG * P / (kern_ms * 1e-3) / 1e12
+        h16 = args.precision == "f16x3"
+        peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
+        f_exec = F_EXEC_H if h16 else F_EXEC
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
@@ -281,8 +317,8 @@ def main():
             "metric": "Mpoints/sec implicit-MLP query, 240x320x%d samples" % N,
             "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE_F16X3 if h16 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %d x 240x320 frame(s) per GPU, %d candidates/ray, LIDF "
                                    "stage-1 fused query (ROI + PE + prob_dec IMNet + offset_dec IEF n_iter=2 "
                                    "+ per-ray softmax/argmax + depth)%s%s" %
@@ -292,13 +328,17 @@ def main():
                                     "; RCCL all-gather of depth maps" if use_dist else ""),
                        "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
                        "parallelism": "frames sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "lidf_points_kernel<FUSED>", "kernel_ms": round(kern_ms, 4),
-                         "flop_per_point_alg": F_ALG, "flop_per_point_exec": F_EXEC,
-                         "achieved_exec": round(F_EXEC * P / (kern_ms * 1e-3) / 1e12, 2),
-                         "frac_exec": round(F_EXEC * P / (kern_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": None if h16 else traffic,
+                         "kernel": "lidf_points_h_kernel" if h16 else "lidf_points_kernel<FUSED>",
+                         "kernel_ms": round(kern_ms, 4),
+                         "flop_per_point_alg": F_ALG, "flop_per_point_exec": f_exec,
+                         "achieved_exec": round(f_exec * P / (kern_ms * 1e-3) / 1e12, 2),
+                         "frac_exec": round(f_exec * P / (kern_ms * 1e-3) / 1e12 / peak, 4)},
         }
+        if split is not None:
+            line["split_f16"] = split
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(line), flush=True)
