@@ -28,9 +28,9 @@ F_ALG = 853952.0       # FLOP per point, reference formulation (SURVEY.md §8d /
 # v_mfma_f32_32x32x2 instructions of 4096 FLOP each.
 F_EXEC = (2 * 51 * 8 + 3 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0  # = 355,584
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
-# split-f16 kernel (lidf_points_h.hip): per wave-tile 3 passes x 430 v_mfma_f32_32x32x16_f16
-# (8 tiles x (1 ray + 21 embedding + 1 IEF + 24 layer-2) + 6 bias + 48 layer-3) of 32,768 FLOP
-F_EXEC_H = 3 * 430 * 32768 / 32.0  # = 1,320,960
+# split-f16 kernel (lidf_points_h.hip): per wave-tile 3 passes x 406 v_mfma_f32_32x32x16_f16
+# (8 tiles x (18 embedding + 2 mixed xyz/ray/IEF + 24 layer-2) + 6 bias + 48 layer-3) of 32,768 FLOP
+F_EXEC_H = 3 * 406 * 32768 / 32.0  # = 1,247,232
 PEAK_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (sustained under the power
 #                           cap with random operands: ~1.4-1.6 PFLOP/s, scripts/mfma_power_ubench.hip)
 DTYPE_F16X3 = "f16x3 (f32 operands split into two f16 pieces, 3 products per term, f32 accumulate)"

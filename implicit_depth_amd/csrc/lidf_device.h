@@ -40,8 +40,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 #define LIDF_U_QUADS 2     // 8 fragments: u vector of the IEF rank-1 term, one per layer-1 tile
 #define LIDF_PASS_QUADS (LIDF_U_QUADS + 4 * LIDF_L2_QUADS + 2 * LIDF_L3_QUADS)  // 168
 #define LIDF_AUX_FLOATS 72  // per net: w4 by (half, reg) [2][32], b4 at [64]
-#define LIDF_H_NK1 7          // split-f16 kernel: layer-1 k-steps of 16 (6 x sin/cos for <= 8 octaves, 1 x xyz)
-#define LIDF_HPASS_QUADS 288  // split-f16 decoder section: 286 quads padded to 18 chunks of 16
+#define LIDF_H_NK1 6          // split-f16 kernel: sin/cos k-steps of 16 per layer-1 tile (<= 8 octaves)
+#define LIDF_HPASS_QUADS 288  // split-f16 decoder section: 278 quads padded to 18 chunks of 16
 #define LIDF_MAX_L_FUSED 16 // octaves of the in-kernel positional encoding
 
 enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_LINEAR = 3,

@@ -61,7 +61,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // Order of a decoder's section (shared by the packer and the kernel)
 // ------------------------------------------------------------------------------------------------
-enum { K_B2 = 0, K_L1, K_U, K_L2, K_B3, K_L3, K_PAD };
+enum { K_B2 = 0, K_L1, K_XA, K_XB, K_L2, K_B3, K_L3, K_PAD };
 struct QD {
     int kind;
     int t;    // output tile
@@ -72,10 +72,10 @@ struct QD {
 };
 __host__ __device__ constexpr QD l1u_desc(int T, int r) {
     if (r < 2 * NK1) return {K_L1, 0, T, r >> 1, r & 1, r >> 1};
-    return {K_U, 0, T, 0, 0, 0};
+    return {r == 2 * NK1 ? K_XA : K_XB, 0, T, 0, 0, 0};
 }
 __host__ __device__ constexpr QD pass_desc(int s) {
-    constexpr int L1U = 2 * NK1 + 1;
+    constexpr int L1U = 2 * NK1 + 2;
     if (s < 4) return {K_B2, s, 0, 0, 0, 0};
     s -= 4;
     if (s < L1U) return l1u_desc(0, s);
@@ -103,7 +103,7 @@ __host__ __device__ constexpr QD pass_desc(int s) {
     }
     return {K_PAD, 0, 0, 0, 0, 0};
 }
-static_assert(4 + 8 * (2 * NK1 + 1) + 8 * 16 + 2 + 32 <= PASS_QUADS, "section size");
+static_assert(4 + 8 * (2 * NK1 + 2) + 8 * 16 + 2 + 32 <= PASS_QUADS, "section size");
 static_assert(PASS_QUADS % CH_QUADS == 0, "sections are whole chunks");
 
 __host__ __device__ constexpr int tile_feature(int r, int half) {
@@ -134,31 +134,37 @@ __device__ _Float16 stream_value_h(const StreamLayout& lay, const NetW* nets, co
     const QD d = pass_desc(quad);
     switch (d.kind) {
         case K_L1: {
-            // k-step ks < NK1-1: 4 (octave, coordinate) combos 4ks..4ks+3, element 2c' = sin,
-            // 2c'+1 = cos; lanes 0..31 weight the enter position's embedding, lanes 32..63 the
-            // leave position's; the last k-step holds raw x, y, z
-            int feat = -1;
-            if (d.sub < NK1 - 1) {
-                const int c = 4 * d.sub + (i >> 1), oct = c / 3, dd = c % 3;
-                if (oct < m.L) feat = 3 + 6 * oct + 3 * (i & 1) + dd;
-            } else if (i < 3) {
-                feat = i;
-            }
-            if (feat < 0) return (_Float16)0.f;
-            const int col = (half ? m.leave_c0 : m.enter_c0) + feat;
+            // k-step ks: 4 (octave, coordinate) combos 4ks..4ks+3, element 2c' = sin, 2c'+1 = cos;
+            // lanes 0..31 weight the enter position's embedding, lanes 32..63 the leave position's
+            const int c = 4 * d.sub + (i >> 1), oct = c / 3, dd = c % 3;
+            if (oct >= m.L) return (_Float16)0.f;
+            const int col = (half ? m.leave_c0 : m.enter_c0) + 3 + 6 * oct + 3 * (i & 1) + dd;
             return hpiece(n.w1[(size_t)(32 * d.T + o) * n.ld1 + col], d.lo);
+        }
+        case K_XA: {
+            // raw x, y, z: high weight pieces twice, against (xh, yh, zh, xl, yl, zl, 0, 0)
+            if (i >= 6) return (_Float16)0.f;
+            const int col = (half ? m.leave_c0 : m.enter_c0) + i % 3;
+            return hpiece(n.w1[(size_t)(32 * d.T + o) * n.ld1 + col], 0);
+        }
+        case K_XB: {
+            // (wlx, wly, wlz, uh, ray_hi, ray_lo, uh, ul) against (xh, yh, zh, vh, m, m, vl, vh):
+            // low weight pieces of x, y, z; the IEF term u*val (lanes 0..31 only); elements 4, 5
+            // are filled in by the kernel with the raypart row of this half's ray
+            if (i < 3) {
+                const int col = (half ? m.leave_c0 : m.enter_c0) + i;
+                return hpiece(n.w1[(size_t)(32 * d.T + o) * n.ld1 + col], 1);
+            }
+            if (i == 4 || i == 5 || half != 0 || !n.is_ief) return (_Float16)0.f;
+            const int out = 32 * d.T + o;
+            float u = 0.f;
+            for (int j = 0; j < 16; ++j) u += n.w1[(size_t)out * n.ld1 + n.dcore + j] * n.wenc[j];
+            return hpiece(u, i == 7 ? 1 : 0);
         }
         case K_B2:
             return half == 0 && i < 3 ? hpiece(n.b2[32 * d.t + o], i) : (_Float16)0.f;
         case K_B3:
             return half == 0 && i < 3 ? hpiece(n.b3[32 * d.t + o], i) : (_Float16)0.f;
-        case K_U: {
-            if (half != 0 || i >= 3 || !n.is_ief) return (_Float16)0.f;
-            const int out = 32 * d.T + o;
-            float u = 0.f;
-            for (int j = 0; j < 16; ++j) u += n.w1[(size_t)out * n.ld1 + n.dcore + j] * n.wenc[j];
-            return hpiece(u, i == 2 ? 1 : 0);  // (uh, uh, ul) against (vh, vl, vh)
-        }
         case K_L2:
             return hpiece(n.w2[(size_t)(32 * d.t + o) * LIDF_H1 + 32 * d.T +
                                tile_feature(8 * d.sub + i, half)], d.lo);
@@ -358,22 +364,27 @@ struct TileCtx {
 // with W1 x = voxpart[voxel] + raypart[ray] + W1[:, enter|leave] PE(position).
 __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4* sb,
                                                 const TileCtx& tc, const f32x4 (&pbh)[NK1],
+                                                const f32x4 xaB, const float xyB, const _Float16 zh,
                                                 const float val, const int h, const int col,
                                                 const float* __restrict__ ax) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                            0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const _Float16 one = (_Float16)1.f, hz = (_Float16)0.f;
-    f32x4 onesB = zero4, offB = zero4, rayB = zero4;
+    f32x4 onesB = zero4, xbB = zero4;
+    xbB[0] = xyB;
     if (!h) {
         onesB[0] = pack2(one, one);
         onesB[1] = pack2(one, hz);
+    }
+    {
+        // (xh, yh, zh, vh, m, m, vl, vh): raw position, IEF input value, ray membership
         const _Float16 vh = (_Float16)val;
         const _Float16 vl = (_Float16)(val - (float)vh);
-        offB[0] = pack2(vh, vl);
-        offB[1] = pack2(vh, hz);
+        xbB[1] = pack2(zh, vh);
+        xbB[2] = tc.rayB;
+        xbB[3] = pack2(vl, vh);
     }
-    rayB[0] = tc.rayB;
 
     f32x16 a1[2];               // layer-1 tiles, ping-pong: accumulating / being split
     float rpv[2];               // raypart value of this lane's row, same ping-pong
@@ -409,54 +420,54 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
         } else if (d.kind == K_L1) {
             f32x16& acc = a1[d.T & 1];
             if (!d.lo) {
-                if (d.sub == 0) {
-                    // ray part: rank-1 update, A = (hi, lo) of the raypart row of this half's ray,
-                    // B = membership of the point; two rays per instruction. Tiles that straddle
-                    // more than two rays (ragged scenes) take extra rounds.
-                    f32x4 rayA = zero4;
-                    rayA[0] = split1(rpv[d.T & 1]);
-                    acc = MFMAH(rayA, rayB, acc);
-                    if (tc.todo) {
-                        unsigned todo = tc.todo;
-                        while (todo) {
-                            const int p0 = __builtin_ctz(todo);
-                            const int r0 = __builtin_amdgcn_readlane(tc.ray, p0);
-                            const unsigned m0 = (unsigned)__ballot(tc.ray == r0) & todo;
-                            todo &= ~m0;
-                            int r1 = r0;
-                            unsigned m1 = 0;
-                            if (todo) {
-                                const int p1 = __builtin_ctz(todo);
-                                r1 = __builtin_amdgcn_readlane(tc.ray, p1);
-                                m1 = (unsigned)__ballot(tc.ray == r1) & todo;
-                                todo &= ~m1;
-                            }
-                            const float v = tc.rbase[(size_t)(h ? r1 : r0) * tc.ray_stride + d.T * 32];
-                            f32x4 xa = zero4, xb = zero4;
-                            xa[0] = split1(v);
-                            xb[0] = (((h ? m1 : m0) >> col) & 1u) ? pack2(one, one) : 0.f;
-                            acc = MFMAH(xa, xb, acc);
-                        }
-                    }
-                }
                 acc = MFMAH(A, pbh[d.sub], acc);
                 acc = MFMAH(A, pl_cur, acc);
                 // low pieces of the next k-step's operand (wraps to k-step 0 for the next tile)
                 pl_nxt = sb[tc.pl + ((d.sub + 1) % NK1) * 64];
-                // split the previous tile behind these matrix instructions
+                // split the previous tile behind these matrix instructions (8 pairs over the
+                // NK1 k-steps and the two mixed steps that follow)
                 if (d.T >= 1) {
                     const int par = (d.T - 1) & 1;
-                    if (d.sub < NK1 - 1)
-                        prep_pairs(d.sub, d.sub + 1, a1[par], bh[par], bl[par]);
-                    else
-                        prep_pairs(NK1 - 1, 8, a1[par], bh[par], bl[par]);
+                    prep_pairs(d.sub, d.sub + 1, a1[par], bh[par], bl[par]);
                 }
             } else {
                 acc = MFMAH(A, pbh[d.sub], acc);
                 pl_cur = pl_nxt;
             }
-        } else if (d.kind == K_U) {
-            a1[d.T & 1] = MFMAH(A, offB, a1[d.T & 1]);
+        } else if (d.kind == K_XA) {
+            a1[d.T & 1] = MFMAH(A, xaB, a1[d.T & 1]);
+            if (d.T >= 1) prep_pairs(NK1, NK1 + 1, a1[(d.T - 1) & 1], bh[(d.T - 1) & 1], bl[(d.T - 1) & 1]);
+        } else if (d.kind == K_XB) {
+            // elements 4, 5 of the weights fragment <- (hi, lo) of the raypart row of this half's
+            // ray: the ray part of layer 1 is a rank-1 update, two rays per instruction. Tiles that
+            // straddle more than two rays (ragged scenes) take extra rounds.
+            f32x16& acc = a1[d.T & 1];
+            f32x4 Ar = A;
+            Ar[2] = split1(rpv[d.T & 1]);
+            acc = MFMAH(Ar, xbB, acc);
+            if (d.T >= 1) prep_pairs(NK1 + 1, 8, a1[(d.T - 1) & 1], bh[(d.T - 1) & 1], bl[(d.T - 1) & 1]);
+            if (tc.todo) {
+                unsigned todo = tc.todo;
+                while (todo) {
+                    const int p0 = __builtin_ctz(todo);
+                    const int r0 = __builtin_amdgcn_readlane(tc.ray, p0);
+                    const unsigned m0 = (unsigned)__ballot(tc.ray == r0) & todo;
+                    todo &= ~m0;
+                    int r1 = r0;
+                    unsigned m1 = 0;
+                    if (todo) {
+                        const int p1 = __builtin_ctz(todo);
+                        r1 = __builtin_amdgcn_readlane(tc.ray, p1);
+                        m1 = (unsigned)__ballot(tc.ray == r1) & todo;
+                        todo &= ~m1;
+                    }
+                    const float v = tc.rbase[(size_t)(h ? r1 : r0) * tc.ray_stride + d.T * 32];
+                    f32x4 xa = zero4, xb = zero4;
+                    xa[2] = split1(v);
+                    xb[2] = (((h ? m1 : m0) >> col) & 1u) ? pack2(one, one) : 0.f;
+                    acc = MFMAH(xa, xb, acc);
+                }
+            }
         } else if (d.kind == K_L2) {
             const int par = d.T & 1;
             if (!d.lo) {
@@ -609,7 +620,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
         {
             const RevH rv[3] = {to_rev_h(px), to_rev_h(py), to_rev_h(pz)};
 #pragma unroll
-            for (int ks = 0; ks < NK1 - 1; ++ks) {
+            for (int ks = 0; ks < NK1; ++ks) {
                 f32x4 lo4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -622,16 +633,21 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
                 }
                 sb[tc.pl + ks * 64] = lo4;
             }
-            f32x4 hi4 = {0.f, 0.f, 0.f, 0.f}, lo4 = {0.f, 0.f, 0.f, 0.f};
-            float hi, lo;
-            split2(px, py, hi, lo);
-            hi4[0] = hi;
-            lo4[0] = lo;
-            split2(pz, 0.f, hi, lo);
-            hi4[1] = hi;
-            lo4[1] = lo;
-            pbh[NK1 - 1] = hi4;
-            sb[tc.pl + (NK1 - 1) * 64] = lo4;
+        }
+        // raw position against the two mixed k-steps: (xh, yh, zh, xl, yl, zl, 0, 0) and the
+        // (xh, yh, zh, .) head of the second one. (zh travels as a scalar: extracting it from a
+        // packed word made hipcc 7.2 pick the low half of the wrong register.)
+        f32x4 xaB = {0.f, 0.f, 0.f, 0.f};
+        float xyB;
+        const _Float16 zh = (_Float16)pz;
+        {
+            const _Float16 xh = (_Float16)px, yh = (_Float16)py;
+            const _Float16 xl = (_Float16)(px - (float)xh), yl = (_Float16)(py - (float)yh),
+                           zl = (_Float16)(pz - (float)zh);
+            xaB[0] = pack2(xh, yh);
+            xaB[1] = pack2(zh, xl);
+            xaB[2] = pack2(yl, zl);
+            xyB = pack2(xh, yh);
         }
         // rays of this wavefront's 32 points: round 0 covers the first two distinct rays
         int my_ray;
@@ -664,7 +680,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
             const int npass = a.npass[net];
             for (int pass = 0; pass < npass; ++pass)
-                val += decoder_pass_h(f, c, sb, tc, pbh, val, h, col, ax);
+                val += decoder_pass_h(f, c, sb, tc, pbh, xaB, xyB, zh, val, h, col, ax);
             PROF(2 + net)
 
             // ---------------- outputs ----------------
