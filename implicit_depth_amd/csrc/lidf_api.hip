@@ -358,6 +358,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.sqrt3 = (float)1.7320508075688772;  // np.sqrt(3) rounded to f32 (pipeline.py:438)
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
+            a.tile_counter = (int*)aux_pts + 2 * LIDF_AUX_FLOATS;  // inside the aux slot's padding
 #ifdef LIDF_PROFILE
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif

@@ -134,6 +134,7 @@ struct PointsArgs {
     int pos_rel, L;
     float r0, rscale, sqrt3, part_size;
     float* pair_pred_pos;   // [n,3]
+    int* tile_counter;      // split-f16 kernel: dynamic tile hand-out (zeroed by its packer)
 };
 
 // Arguments of the generic linear-layer kernel (lidf_linear.hip): out = epilogue(X W^T + b).

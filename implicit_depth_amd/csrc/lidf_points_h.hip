@@ -41,9 +41,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 // development only: per-phase cycle counters of wavefront 0 of workgroup 0, written to a.out_base
 #ifdef LIDF_PROFILE
-#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long prof_w0 = wall_clock64(), prof_c0 = prof_t;
 #define PROF(i) { long long t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
-#define PROF_DUMP if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; }
+#define PROF_DUMP if (threadIdx.x == 0 && a.out_base) { long long* o_ = (long long*)a.out_base + 16 + 4 * blockIdx.x; o_[0] = prof_w0; o_[1] = wall_clock64(); o_[2] = __builtin_amdgcn_s_getreg(63492); o_[3] = __builtin_amdgcn_s_getreg(63508); } \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { prof_acc[6] = wall_clock64() - prof_w0; prof_acc[7] = clock64() - prof_c0; for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; }
 #else
 #define PROF_DECL
 #define PROF(i)
@@ -56,7 +57,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define NK1 LIDF_H_NK1            // layer-1 k-steps of 16: 6 of sin/cos (8 octaves) + raw x,y,z
 #define PASS_QUADS LIDF_HPASS_QUADS
 #define LDS_STREAM_ELEMS (NBUF * CH_ELEMS)
-#define LDS_BYTES ((LDS_STREAM_ELEMS + 4 * NK1 * 64) * 16)
+#define LDS_BYTES ((LDS_STREAM_ELEMS + 4 * NK1 * 64 + 1) * 16)  // + the tile-grab slot
+#define LIDF_H_GRAB 2
 
 // ------------------------------------------------------------------------------------------------
 // Order of a decoder's section (shared by the packer and the kernel)
@@ -193,6 +195,7 @@ __global__ void lidf_pack_h_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map
         }
         aux[e] = v;
     }
+    if (e == 0) ((int*)aux)[lay.nets * LIDF_AUX_FLOATS] = 0;  // tile counter of lidf_points_h_kernel
 }
 
 extern "C" hipError_t lidf_launch_pack_h(const StreamLayout& lay, const NetW& n0, const NetW& n1,
@@ -549,13 +552,13 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
     c.npass0 = a.npass[0];
     c.npass1 = a.npass[1];
 
-    // contiguous range of 128-point tiles per workgroup; every wavefront of the workgroup runs
-    // the same number of tiles (the stream is shared), out-of-range points are clamped
+    // 128-point tiles are handed out dynamically, LIDF_H_GRAB at a time, from a counter the packer
+    // zeroes: the two workgroups of a CU do not progress at the same rate (the older one wins the
+    // issue arbitration), and with a static split the younger one would run the tail alone.
+    // Every wavefront of the workgroup runs the same tiles (the stream is shared); out-of-range
+    // points are clamped.
     const long long ntile = (a.n + 127) / 128;
-    const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
-    const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
-    const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
-    if (tb >= te_) return;
+    int* const grab_slot = (int*)(sb + LDS_STREAM_ELEMS + 4 * NK1 * 64);
 
     // prologue: chunk 0 into buffer 0, chunk 1 in flight
     Feed f;
@@ -588,15 +591,21 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
         g.dz = a.ray_dir[3 * (size_t)g.ray + 2];
     };
     GeoH cur = {}, nxt = {}, nx2 = {};
-    load_idx(tb, cur);
-    load_idx(tb + 1, nxt);
-    load_dir(cur);
 
     TileCtx tc;
     tc.pl = LDS_STREAM_ELEMS + wave * NK1 * 64 + lane;
     tc.ray_stride = a.nets * 256;
 
     PROF_DECL
+    for (;;) {
+    if (threadIdx.x == 0) *grab_slot = atomicAdd(a.tile_counter, LIDF_H_GRAB);
+    __syncthreads();
+    const long long tb = __builtin_amdgcn_readfirstlane(*grab_slot);
+    if (tb >= ntile) break;
+    const long long te_ = tb + LIDF_H_GRAB < ntile ? tb + LIDF_H_GRAB : ntile;
+    load_idx(tb, cur);
+    load_idx(tb + 1, nxt);
+    load_dir(cur);
     for (long long tile = tb; tile < te_; ++tile) {
         PROF(0)
         const long long p = tile * 128 + wave * 32 + col;
@@ -705,6 +714,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
         nxt.vid = nx2.vid;
         nxt.te = nx2.te;
         nxt.tl = nx2.tl;
+    }
     }
     PROF_DUMP
 }
