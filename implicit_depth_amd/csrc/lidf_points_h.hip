@@ -338,9 +338,10 @@ __device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb,
         feed_issue(f, c);
     }
     if (Q == 8) {
-        // All LDS operations of this wavefront issued so far must have completed before the
-        // barrier publishes its four writes of position 6.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // LDS operations complete in order and at least two (the ring reads of positions 7 and 8)
+        // were issued after the four writes of position 6: once at most two are outstanding the
+        // writes have landed, and the ring need not drain.
+        asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
     }
     if (Q == CH_QUADS - 1) {
         f.cur = f.nxt;
@@ -403,11 +404,19 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
     auto gather = [&](const int T) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#if defined(DBG_VARIANT) && (DBG_VARIANT == 22 || DBG_VARIANT == 23)
+            const f32x4 v = {0.1f, 0.2f, 0.3f, 0.4f};
+#else
             const f32x4 v = *(const f32x4*)(tc.vp + T * 32 + 8 * g);
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) a1[T & 1][4 * g + i] = v[i];
         }
+#if defined(DBG_VARIANT) && (DBG_VARIANT == 21 || DBG_VARIANT == 23)
+        rpv[T & 1] = 0.25f;
+#else
         rpv[T & 1] = tc.rp[T * 32];
+#endif
     };
     gather(0);
     gather(1);
