@@ -101,6 +101,7 @@ SIGNATURES = {
     "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
+    "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

@@ -28,6 +28,8 @@ hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, con
                                      long long, long long, int*, hipStream_t);
 hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
+                                     int, float*, hipStream_t);
 struct GridSpec {
     float xmin[3];
     float crop;
@@ -735,5 +737,18 @@ LIDF_API int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n, 
                                      rel_coord, st));
     CHECK_HIP(hipMemcpyAsync(counts, cell_rank + ncell, 4, hipMemcpyDeviceToDevice, st));
     CHECK_HIP(hipMemcpyAsync(counts + 1, pt_rank + (n > 0 ? n : 0), 4, hipMemcpyDeviceToDevice, st));
+    return LIDF_OK;
+}
+
+// ---- eval depth metrics ---------------------------------------------------------------------------
+LIDF_API int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth,
+                                      const uint8_t* seg_mask, int32_t src_h, int32_t src_w,
+                                      int32_t dst_h, int32_t dst_w, float* out,
+                                      lidf_stream_t stream) {
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return LIDF_ERR_BAD_ARG;
+    if (!pred_depth || !gt_depth || !out) return LIDF_ERR_BAD_ARG;
+    if ((int64_t)dst_h * dst_w > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    CHECK_HIP(lidf_launch_depth_metrics(pred_depth, gt_depth, seg_mask, src_h, src_w, dst_h, dst_w,
+                                        out, (hipStream_t)stream));
     return LIDF_OK;
 }

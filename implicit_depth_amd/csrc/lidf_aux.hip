@@ -750,3 +750,83 @@ extern "C" hipError_t lidf_launch_vox_points(const float* xyz, const int* pt_key
                        xyz, pt_key, pt_rank, cell_rank, N, g, pid, revidx, rel);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Eval depth metrics (models/pipeline.py:577-627): nearest-neighbour resize of the predicted and
+// ground-truth depth maps and of the segmentation mask to dst_h x dst_w (cv2.resize
+// INTER_NEAREST: source index = min(floor(dst index * src/dst), src - 1), the factor formed in
+// double as 1/(dst/src)), non-finite ground truth -> 0, valid = gt > 0 and mask != 0, then the
+// nine ClearGrasp statistics over the valid pixels. One workgroup: the resized image has 36,864
+// pixels; sums are carried in double.
+// ------------------------------------------------------------------------------------------------
+#define METRIC_SUMS 10
+__global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
+    const float* __restrict__ pred, const float* __restrict__ gt, const unsigned char* __restrict__ seg,
+    int src_h, int src_w, int dst_h, int dst_w, float* __restrict__ out) {
+    __shared__ double red[METRIC_SUMS][16];
+    double acc[METRIC_SUMS];
+#pragma unroll
+    for (int i = 0; i < METRIC_SUMS; ++i) acc[i] = 0.0;
+    const double ifx = 1.0 / ((double)dst_w / (double)src_w);
+    const double ify = 1.0 / ((double)dst_h / (double)src_h);
+    const int n = dst_h * dst_w;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int dy = i / dst_w, dx = i % dst_w;
+        int sx = (int)floor(dx * ifx), sy = (int)floor(dy * ify);
+        sx = sx < src_w - 1 ? sx : src_w - 1;
+        sy = sy < src_h - 1 ? sy : src_h - 1;
+        const size_t si = (size_t)sy * src_w + sx;
+        float g = gt[si];
+        if (isnan(g) || isinf(g)) g = 0.f;
+        if (!(g > 0.f) || (seg && seg[si] == 0)) continue;
+        const float p = pred[si];
+        // same f32 operations as the torch expressions (pipeline.py:612-623)
+        const float thresh = fmaxf(g / p, p / g);
+        const float d = g - p;
+        const float lg = logf(fminf(fmaxf(g, 1e-6f), 1e6f)), lp = logf(fminf(fmaxf(p, 1e-6f), 1e6f));
+        acc[0] += thresh < 1.05f ? 1.0 : 0.0;
+        acc[1] += thresh < 1.10f ? 1.0 : 0.0;
+        acc[2] += thresh < 1.25f ? 1.0 : 0.0;
+        acc[3] += (double)(d * d);
+        acc[4] += (double)((lg - lp) * (lg - lp));
+        acc[5] += (double)fabsf(lg - lp);
+        acc[6] += (double)(fabsf(d) / g);
+        acc[7] += (double)fabsf(d);
+        acc[8] += (double)(d * d / g);
+        acc[9] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < METRIC_SUMS; ++i) {
+        double v = acc[i];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[i][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s[METRIC_SUMS];
+        for (int i = 0; i < METRIC_SUMS; ++i) {
+            s[i] = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s[i] += red[i][w];
+        }
+        const double c = s[9];  // 0 valid pixels: torch's mean of an empty tensor is NaN, so is 0/0
+        out[0] = (float)(s[0] / c);
+        out[1] = (float)(s[1] / c);
+        out[2] = (float)(s[2] / c);
+        out[3] = (float)sqrt(s[3] / c);
+        out[4] = (float)sqrt(s[4] / c);
+        out[5] = (float)(s[5] / c);
+        out[6] = (float)(s[6] / c);
+        out[7] = (float)(s[7] / c);
+        out[8] = (float)(s[8] / c);
+        out[9] = (float)c;
+    }
+}
+
+extern "C" hipError_t lidf_launch_depth_metrics(const float* pred, const float* gt,
+                                                const unsigned char* seg, int src_h, int src_w,
+                                                int dst_h, int dst_w, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(lidf_depth_metrics_kernel, dim3(1), dim3(1024), 0, st, pred, gt, seg, src_h,
+                       src_w, dst_h, dst_w, out);
+    return hipGetLastError();
+}

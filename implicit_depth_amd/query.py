@@ -320,3 +320,34 @@ def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=
         "valid_v_pid": pid[:Nv].long(), "valid_v_rel_coord": rel[:Nv],
         "occ_vox_bid": occ[:, 0], "occ_vox_global_coord": occ[:, 1:], "voxel_bound": vb[:V],
     }
+
+
+METRIC_NAMES = ("a1", "a2", "a3", "rmse", "rmse_log", "log10", "abs_rel", "mae", "sq_rel")
+
+
+def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
+    """The evaluation statistics of LIDF.compute_loss (models/pipeline.py:577-627, the bs == 1
+    branch) on the device: cv2.resize(..., (256, 144), INTER_NEAREST) of the predicted depth, the
+    ground-truth depth (non-finite -> 0) and the mask, valid = gt > 0 & mask, then a1/a2/a3, rmse,
+    rmse_log, log10, abs_rel, mae, sq_rel. pred_depth / gt_depth [h,w] f32, seg_mask [h,w]
+    bool/uint8 or None. out_size=None keeps the source resolution (the bs != 1 statistics on
+    already-selected pixels). Returns a dict of 0-d device tensors plus "count"."""
+    _lib.require_cuda(pred_depth, gt_depth, names=["pred_depth", "gt_depth"])
+    _f32(pred_depth, "pred_depth"), _f32(gt_depth, "gt_depth")
+    if pred_depth.dim() != 2 or pred_depth.shape != gt_depth.shape:
+        raise RuntimeError("pred_depth and gt_depth must be [h,w] tensors of the same shape")
+    h, w = pred_depth.shape
+    if seg_mask is not None:
+        if seg_mask.shape != pred_depth.shape:
+            raise RuntimeError("seg_mask must have the shape of the depth maps")
+        seg_mask = seg_mask.to(torch.uint8).contiguous()
+        _lib.require_cuda(seg_mask, names=["seg_mask"])
+    dh, dw = (h, w) if out_size is None else out_size
+    out = torch.empty((10,), dtype=torch.float32, device=pred_depth.device)
+    with torch.cuda.device(pred_depth.device):
+        _lib.check(_lib.lib().lidf_depth_metrics_f32(
+            _lib.ptr(pred_depth), _lib.ptr(gt_depth), _lib.ptr(seg_mask) if seg_mask is not None else None,
+            h, w, dh, dw, _lib.ptr(out), _lib.current_stream(pred_depth.device)))
+    res = {k: out[i] for i, k in enumerate(METRIC_NAMES)}
+    res["count"] = out[9]
+    return res

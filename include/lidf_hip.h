@@ -281,6 +281,20 @@ typedef struct LidfRefineArgs {
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
 
+/* ---- Eval depth metrics ----------------------------------------------------------------------
+ * Replaces the bs == 1 evaluation branch of LIDF.compute_loss (models/pipeline.py:577-627): the
+ * predicted depth map, the ground-truth depth map and the segmentation mask ([src_h, src_w],
+ * device; seg_mask uint8 or NULL = all ones) are resized to dst_h x dst_w (144 x 256 in the
+ * reference) with cv2.resize's INTER_NEAREST rule, non-finite ground truth counts as 0, valid =
+ * gt > 0 and mask != 0, and out (device float[10]) receives
+ *   a1, a2, a3 (thresholds 1.05, 1.10, 1.25), rmse, rmse_log, log10 (natural log, as the
+ *   reference computes it), abs_rel, mae, sq_rel, number of valid pixels
+ * — no .cpu() round trip. dst == src gives the plain masked statistics. 0 valid pixels: NaN, as
+ * torch's mean of an empty tensor.                                                              */
+int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const uint8_t* seg_mask,
+                           int32_t src_h, int32_t src_w, int32_t dst_h, int32_t dst_w, float* out,
+                           lidf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

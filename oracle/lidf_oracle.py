@@ -543,3 +543,39 @@ def synthetic_scene(*args, **kw):
         sys.path.insert(0, root)
     from implicit_depth_amd.synthetic import synthetic_scene as _impl
     return _impl(*args, **kw)
+
+
+def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
+    """Eval statistics of LIDF.compute_loss, bs == 1 branch (models/pipeline.py:577-627).
+    cv2 is not installed here, so cv2.resize(img, (256, 144), interpolation=INTER_NEAREST) is
+    restated from OpenCV's resizeNN: source index = min(floor(dst index * (1 / (dst/src))), src-1),
+    factor in double — parity with cv2 itself is unpinned. The statistics follow the reference's
+    torch f32 expressions literally (safe_log10 is the natural log there, :611)."""
+    import math
+    pred = torch.as_tensor(pred_depth, dtype=torch.float32)
+    gt = torch.as_tensor(gt_depth, dtype=torch.float32).clone()
+    h, w = gt.shape
+    dh, dw = (h, w) if out_size is None else out_size
+    ify, ifx = 1.0 / (dh / h), 1.0 / (dw / w)
+    sy = torch.tensor([min(int(math.floor(y * ify)), h - 1) for y in range(dh)])
+    sx = torch.tensor([min(int(math.floor(x * ifx)), w - 1) for x in range(dw)])
+    gt = gt[sy][:, sx]
+    pred = pred[sy][:, sx]
+    gt[torch.isnan(gt)] = 0
+    gt[torch.isinf(gt)] = 0
+    mask = gt > 0
+    if seg_mask is not None:
+        sm = torch.as_tensor(seg_mask).to(torch.uint8)[sy][:, sx]
+        mask = mask & (sm != 0)
+    gt, pred = gt[mask], pred[mask]
+    safe_log = lambda x: torch.log(torch.clamp(x, 1e-6, 1e6))  # noqa: E731
+    thresh = torch.max(gt / pred, pred / gt)
+    return {
+        "a1": (thresh < 1.05).float().mean(), "a2": (thresh < 1.10).float().mean(),
+        "a3": (thresh < 1.25).float().mean(),
+        "rmse": ((gt - pred) ** 2).mean().sqrt(),
+        "rmse_log": ((safe_log(gt) - safe_log(pred)) ** 2).mean().sqrt(),
+        "log10": (safe_log(gt) - safe_log(pred)).abs().mean(),
+        "abs_rel": ((gt - pred).abs() / gt).mean(), "mae": (gt - pred).abs().mean(),
+        "sq_rel": ((gt - pred) ** 2 / gt).mean(), "count": torch.tensor(float(mask.sum())),
+    }

@@ -1,6 +1,7 @@
 """CPU: properties of the two restatements whose third-party sources are absent (roi_align,
 torch_scatter: parity unpinned), and the C box-test oracle against the numpy one."""
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -86,3 +87,21 @@ def test_c_box_oracle_matches_numpy():
     L.pcl_aabb_ref(pts.ctypes.data_as(P), vb.ctypes.data_as(P), rb.ctypes.data_as(P),
                    vbid.ctypes.data_as(P), C.c_int64(R), C.c_int64(V), pm.ctypes.data_as(P))
     assert (pm == orc.pcl_aabb(pts, vb, rb, vbid)).all() and pm.sum() > 0
+
+
+def test_depth_metrics_oracle_known_values():
+    """Hand-checkable cases of the eval statistics (pipeline.py:577-627): a perfect prediction, a
+    uniform +10 % error, and the nearest-neighbour source indices of the 320 -> 256 resize."""
+    gt = torch.full((240, 320), 2.0)
+    m = orc.depth_metrics(gt.clone(), gt, None)
+    assert float(m["a1"]) == 1.0 and float(m["rmse"]) == 0.0 and float(m["count"]) == 144 * 256
+    m = orc.depth_metrics(gt * 1.1, gt, None)
+    assert float(m["a1"]) == 0.0 and float(m["a3"]) == 1.0        # ratio 1.1: above 1.05 (and 1.10 in f32)
+    assert abs(float(m["abs_rel"]) - 0.1) < 1e-6 and abs(float(m["mae"]) - 0.2) < 1e-6
+    assert abs(float(m["rmse_log"]) - math.log(1.1)) < 1e-6
+    # columns: pred = source column index -> resized row 0 must read columns floor(1.25 x)
+    pred = torch.arange(320, dtype=torch.float32).repeat(240, 1) + 1.0
+    gt = pred.clone()
+    gt[:, 5:] = 0.0                                                # only source columns 0..4 valid
+    m = orc.depth_metrics(pred, gt, None)                          # dst x = 0..3 -> src 0,1,2,3 ; x = 4 -> src 5
+    assert float(m["count"]) == 4 * 144
