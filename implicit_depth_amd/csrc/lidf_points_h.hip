@@ -393,7 +393,7 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
     f32x16 a1[2];               // layer-1 tiles, ping-pong: accumulating / being split
     float rpv[2];               // raypart value of this lane's row, same ping-pong
     f32x16 acc2[4], acc3[2];
-    f32x4 bh[2][2], bl[2][2];   // split H1 tile, [parity of T][k-sub-step]
+    f32x4 bh[2], bl[2];         // split H1 tile, [k-sub-step] (single buffer, see below)
     f32x4 gh[4][2], gl[4][2];   // split H2 tiles
     f32x4 pl_cur = zero4, pl_nxt = zero4;  // low pieces of the embedding operand, from LDS
     f32x4 w4[8];
@@ -438,17 +438,14 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
                 pl_nxt = sb[tc.pl + ((d.sub + 1) % NK1) * 64];
                 // split the previous tile behind these matrix instructions (8 pairs over the
                 // NK1 k-steps and the two mixed steps that follow)
-                if (d.T >= 1) {
-                    const int par = (d.T - 1) & 1;
-                    prep_pairs(d.sub, d.sub + 1, a1[par], bh[par], bl[par]);
-                }
+                if (d.T >= 1) prep_pairs(d.sub, d.sub + 1, a1[(d.T - 1) & 1], bh, bl);
             } else {
                 acc = MFMAH(A, pbh[d.sub], acc);
                 pl_cur = pl_nxt;
             }
         } else if (d.kind == K_XA) {
             a1[d.T & 1] = MFMAH(A, xaB, a1[d.T & 1]);
-            if (d.T >= 1) prep_pairs(NK1, NK1 + 1, a1[(d.T - 1) & 1], bh[(d.T - 1) & 1], bl[(d.T - 1) & 1]);
+            if (d.T >= 1) prep_pairs(NK1, NK1 + 1, a1[(d.T - 1) & 1], bh, bl);
         } else if (d.kind == K_XB) {
             // elements 4, 5 of the weights fragment <- (hi, lo) of the raypart row of this half's
             // ray: the ray part of layer 1 is a rank-1 update, two rays per instruction. Tiles that
@@ -457,7 +454,7 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
             f32x4 Ar = A;
             Ar[2] = split1(rpv[d.T & 1]);
             acc = MFMAH(Ar, xbB, acc);
-            if (d.T >= 1) prep_pairs(NK1 + 1, 8, a1[(d.T - 1) & 1], bh[(d.T - 1) & 1], bl[(d.T - 1) & 1]);
+            if (d.T >= 1) prep_pairs(NK1 + 1, 8, a1[(d.T - 1) & 1], bh, bl);
             if (tc.todo) {
                 unsigned todo = tc.todo;
                 while (todo) {
@@ -481,34 +478,38 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
                 }
             }
         } else if (d.kind == K_L2) {
-            const int par = d.T & 1;
             if (!d.lo) {
                 // the tile after next can start loading: its accumulator is free once the split
                 // of tile T (same parity) is done
                 if (d.j == 0 && d.T + 2 < 8) gather(d.T + 2);
-                acc2[d.t] = MFMAH(A, bh[par][d.sub], acc2[d.t]);
-                acc2[d.t] = MFMAH(A, bl[par][d.sub], acc2[d.t]);
-                if (d.T == 6) {
-                    // tile 7 has no layer-1 segment after it to hide behind
-                    prep_pairs(d.j, d.j + 1, a1[1], bh[1], bl[1]);
-                } else if (d.T == 7) {
+                // tile 7 has no layer-1 segment after it to hide its split behind, and a second
+                // operand buffer just for it would push the kernel into spilling
+                if (d.T == 7 && d.j == 0) prep_pairs(0, 8, a1[1], bh, bl);
+                acc2[d.t] = MFMAH(A, bh[d.sub], acc2[d.t]);
+                acc2[d.t] = MFMAH(A, bl[d.sub], acc2[d.t]);
+                if (d.T == 7) {
                     // last segment (tile-major): output tiles complete one by one
                     if (d.j >= 2 && d.j < 6) prep_pairs(2 * (d.j - 2), 2 * (d.j - 2) + 2, acc2[0], gh[0], gl[0]);
                     if (d.j >= 6) prep_pairs(2 * (d.j - 6), 2 * (d.j - 6) + 2, acc2[1], gh[1], gl[1]);
                 }
             } else {
-                acc2[d.t] = MFMAH(A, bh[par][d.sub], acc2[d.t]);
+                acc2[d.t] = MFMAH(A, bh[d.sub], acc2[d.t]);
             }
         } else if (d.kind == K_B3) {
             acc3[d.t] = MFMAH(A, onesB, zero16);
-            if (d.t == 0) {
-                // operands of the tail, fetched here so that their latency hides behind layer 3
-#pragma unroll
-                for (int i = 0; i < 8; ++i) w4[i] = *(const f32x4*)(ax + h * 32 + 4 * i);
-                b4 = ax[64];
-            }
+            if (d.t == 0) b4 = ax[64];
         } else if (d.kind == K_L3) {
             if (!d.lo) {
+                // operands of the tail (layer 4), fetched late and in two halves so that they do not
+                // hold 32 registers through layer 3; their latency still hides behind it
+                if (d.T == 2 && d.j == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w4[i] = *(const f32x4*)(ax + h * 32 + 4 * i);
+                }
+                if (d.T == 3 && d.j == 0) {
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) w4[i] = *(const f32x4*)(ax + h * 32 + 4 * i);
+                }
                 acc3[d.t] = MFMAH(A, gh[d.T][d.sub], acc3[d.t]);
                 acc3[d.t] = MFMAH(A, gl[d.T][d.sub], acc3[d.t]);
                 // pending splits: segment T handles the second half of H2[T+1] (first two pairs)
