@@ -29,6 +29,7 @@
 // ds_read_b128 in flight.
 #include "lidf_device.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -51,9 +52,13 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define PROF_DUMP
 #endif
 
+
 #define CH_QUADS 16
 #define CH_ELEMS (CH_QUADS * 64)  // f32x4 elements per chunk buffer
 #define NBUF 3
+#ifndef RING_D
+#define RING_D 4  // quads of the stream in flight between LDS and the matrix instructions
+#endif
 #define NK1 LIDF_H_NK1            // layer-1 k-steps of 16: 6 of sin/cos (8 octaves) + raw x,y,z
 #define PASS_QUADS LIDF_HPASS_QUADS
 #define LDS_STREAM_ELEMS (NBUF * CH_ELEMS)
@@ -107,6 +112,7 @@ __host__ __device__ constexpr QD pass_desc(int s) {
 }
 static_assert(4 + 8 * (2 * NK1 + 2) + 8 * 16 + 2 + 32 <= PASS_QUADS, "section size");
 static_assert(PASS_QUADS % CH_QUADS == 0, "sections are whole chunks");
+static_assert(PASS_QUADS % RING_D == 0 && CH_QUADS - RING_D > 6, "ring slots are static; ring reads of the next chunk start after the barrier");
 
 __host__ __device__ constexpr int tile_feature(int r, int half) {
     return (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -292,7 +298,7 @@ __device__ __forceinline__ void rev_sincos_h(const RevH& r, float sc, float& s, 
 
 // The stream feed of one wavefront.
 struct Feed {
-    f32x4 ring[4];   // next four quads
+    f32x4 ring[RING_D];  // next RING_D quads
     f32x4 stage[4];  // this wavefront's quarter of the chunk after the next one, in flight
     int cur, nxt;    // element index (f32x4 units) of this lane in the current / next LDS buffer
     int nb;          // index of the next buffer
@@ -324,23 +330,26 @@ __device__ __forceinline__ void feed_issue(Feed& f, const FeedCfg& c) {
 
 // position Q (0..15) of the current chunk: returns the quad, refills the ring four quads ahead,
 // and at mid-chunk publishes the staged chunk to LDS and starts the next global fetch
-__device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb, const int Q) {
-    const f32x4 a = f.ring[Q & 3];
-    if (Q + 4 < CH_QUADS)
-        f.ring[Q & 3] = sb[f.cur + (Q + 4) * 64];
+__device__ __forceinline__ f32x4 feed_take(Feed& f, const FeedCfg& c, f32x4* sb, const int Q,
+                                            const int slot) {
+    // slot = (position in the section) % RING_D; sections are multiples of RING_D quads
+    const f32x4 a = f.ring[slot];
+    if (Q + RING_D < CH_QUADS)
+        f.ring[slot] = sb[f.cur + (Q + RING_D) * 64];
     else
-        f.ring[Q & 3] = sb[f.nxt + (Q + 4 - CH_QUADS) * 64];
-    if (Q == 6) {
+        f.ring[slot] = sb[f.nxt + (Q + RING_D - CH_QUADS) * 64];
+    if (Q == 4) {
         // The buffer written here last held the chunk before the previous one: every wavefront
         // finished reading it before it passed the previous barrier.
 #pragma unroll
         for (int j = 0; j < 4; ++j) sb[f.nb * CH_ELEMS + (4 * c.wave + j) * 64 + c.lane] = f.stage[j];
         feed_issue(f, c);
     }
-    if (Q == 8) {
-        // LDS operations complete in order and at least two (the ring reads of positions 7 and 8)
-        // were issued after the four writes of position 6: once at most two are outstanding the
-        // writes have landed, and the ring need not drain.
+    if (Q == 6) {
+        // LDS operations complete in order and at least two (the ring reads of positions 5 and 6)
+        // were issued after the four writes of position 4: once at most two are outstanding the
+        // writes have landed, and the ring need not drain. The first read of the next buffer
+        // comes at position CH_QUADS - RING_D > 6.
         asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
     }
     if (Q == CH_QUADS - 1) {
@@ -366,6 +375,12 @@ struct TileCtx {
 // One decoder pass on the 32 points of this wavefront:
 //   H1 = lrelu(W1 x + b1 [+ u*val]);  H2 = lrelu(W2 H1 + b2);  H3 = lrelu(W3 H2 + b3);  y = w4.H3 + b4
 // with W1 x = voxpart[voxel] + raypart[ray] + W1[:, enter|leave] PE(position).
+#ifdef LIDF_PROFILE_CHUNKS
+__device__ long long g_chunk_ticks[32];
+#define CHUNK_PROF(q, s_) if ((q) == CH_QUADS - 1) { const long long t_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_chunk_ticks[(s_) / CH_QUADS] += t_ - chunk_t; chunk_t = t_; }
+#else
+#define CHUNK_PROF(q, s_)
+#endif
 __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4* sb,
                                                 const TileCtx& tc, const f32x4 (&pbh)[NK1],
                                                 const f32x4 xaB, const float xyB, const _Float16 zh,
@@ -404,29 +419,24 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
     auto gather = [&](const int T) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#if defined(DBG_VARIANT) && (DBG_VARIANT == 22 || DBG_VARIANT == 23)
-            const f32x4 v = {0.1f, 0.2f, 0.3f, 0.4f};
-#else
             const f32x4 v = *(const f32x4*)(tc.vp + T * 32 + 8 * g);
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) a1[T & 1][4 * g + i] = v[i];
         }
-#if defined(DBG_VARIANT) && (DBG_VARIANT == 21 || DBG_VARIANT == 23)
-        rpv[T & 1] = 0.25f;
-#else
         rpv[T & 1] = tc.rp[T * 32];
-#endif
     };
     gather(0);
     gather(1);
     pl_cur = sb[tc.pl];
+#ifdef LIDF_PROFILE_CHUNKS
+    long long chunk_t = clock64();
+#endif
 
 #pragma unroll
     for (int s = 0; s < PASS_QUADS; ++s) {
         const int Q = s % CH_QUADS;
         const QD d = pass_desc(s);
-        const f32x4 A = feed_take(f, c, sb, Q);
+        const f32x4 A = feed_take(f, c, sb, Q, s % RING_D);
         if (d.kind == K_B2) {
             acc2[d.t] = MFMAH(A, onesB, zero16);
         } else if (d.kind == K_L1) {
@@ -526,8 +536,12 @@ __device__ __forceinline__ float decoder_pass_h(Feed& f, const FeedCfg& c, f32x4
                 acc3[d.t] = MFMAH(A, gh[d.T][d.sub], acc3[d.t]);
             }
         }
+        CHUNK_PROF(Q, s)
         SCHED_FENCE();
     }
+#ifdef LIDF_PROFILE_CHUNKS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_chunk_ticks[31] += 1; }
+#endif
     // layer 4 (64 -> 1) on the VALU, second tile; halves combined with one cross-half shuffle
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -584,7 +598,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
     f.nb = 1;
     f.nxt = CH_ELEMS + lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.ring[i] = sb[f.cur + i * 64];
+    for (int i = 0; i < RING_D; ++i) f.ring[i] = sb[f.cur + i * 64];
 
     auto load_idx = [&](long long tile, GeoH& g) {
         long long pc = tile * 128 + wave * 32 + col;
@@ -747,7 +761,23 @@ extern "C" hipError_t lidf_launch_points_h(const PointsArgs& a, int cus, hipStre
     }
     // two workgroups per CU
     const long long ntile = (a.n + 127) / 128;
-    const int grid = (int)(ntile < 2LL * cus ? ntile : 2LL * cus);
+    int grid = (int)(ntile < 2LL * cus ? ntile : 2LL * cus);
+#ifdef LIDF_PROFILE
+    if (getenv("LIDF_H_SOLO")) grid = cus;
+#endif
+#ifdef LIDF_PROFILE_CHUNKS
+    static long long zero_[32] = {0};
+    hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chunk_ticks), zero_, sizeof(zero_), 0, hipMemcpyHostToDevice, st);
+#endif
     hipLaunchKernelGGL(lidf_points_h_kernel, dim3(grid), dim3(256), LDS_BYTES, st, a);
+#ifdef LIDF_PROFILE_CHUNKS
+    {
+        long long t_[32];
+        hipMemcpyFromSymbol(t_, HIP_SYMBOL(g_chunk_ticks), sizeof(t_), 0, hipMemcpyDeviceToHost);
+        fprintf(stderr, "passes of workgroup 0: %lld ; ticks per chunk (avg per pass):", t_[31]);
+        for (int i = 0; i < PASS_QUADS / CH_QUADS; ++i) fprintf(stderr, " %lld", t_[31] ? t_[i] / t_[31] : 0);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
