@@ -48,6 +48,11 @@ class LidfQueryArgs(C.Structure):
     ]
 
 
+class LidfDecoderGrads(C.Structure):
+    """struct LidfDecoderGrads (include/lidf_hip.h)."""
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc")]
+
+
 class LidfPointNet(C.Structure):
     """struct LidfPointNet (include/lidf_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
@@ -102,6 +107,12 @@ SIGNATURES = {
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
+    "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
+    "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,
+                                                 _P, C.c_size_t, _P]),
+    "lidf_decoder_backward_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P, _P,
+                                            _I64, C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -28,6 +28,13 @@ hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, con
                                      long long, long long, int*, hipStream_t);
 hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
+                             float*, int, float*, hipStream_t);
+hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long long, float*,
+                                hipStream_t);
+hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
+hipError_t lidf_launch_out_act(const float*, long long, int, float*, const float*, float*,
+                               hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -750,5 +757,226 @@ LIDF_API int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_dep
     if ((int64_t)dst_h * dst_w > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
     CHECK_HIP(lidf_launch_depth_metrics(pred_depth, gt_depth, seg_mask, src_h, src_w, dst_h, dst_w,
                                         out, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- decoders, training path (forward with kept activations + backward) ---------------------------
+// One linear layer through lidf_linear_kernel with the training epilogues.
+struct LinEx {
+    const float* w; const float* b; int ldw;   // weight [rows, ldw] (+ bias); see `transposed`
+    int nout, k;                               // outputs and contraction length
+    int transposed;                            // outputs index weight columns, k indexes rows (W^T)
+    const LidfDecoder* ief;                    // layer 1 of an IEF: bias += c, column k+1 = u
+    const float* X; long long ldx; long long n;
+    const float* xoff;
+    int relu; float slope;
+    const float* mask_src; long long ld_mask; float mask_slope;
+    float* out; long long ld_out; int accumulate;
+};
+
+static int nt_for(int nout) { return nout <= 32 ? 1 : nout <= 64 ? 2 : nout <= 128 ? 4 : 8; }
+
+static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) / 8) * 8 * 1024, 256); }
+
+static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st) {
+    if (L.n <= 0) return LIDF_OK;
+    const int nt = nt_for(L.nout);
+    L1Map m = rows_map(L.k, 0, 0, 0, L.b ? 1 : 0);
+    m.KQ1 = (L.k + 2 + 7) / 8;   // room for the bias and the u column
+    m.nt = nt;
+    m.nout = L.nout;
+    m.transposed = L.transposed;
+    m.add_u = L.ief ? 1 : 0;
+    StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
+    NetW nw = {};
+    nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.k; nw.is_ief = 0;
+    if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
+    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    LinearArgs a = {};
+    a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
+    a.D = L.k; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
+    a.relu = L.relu; a.slope = L.slope;
+    a.mask_src = L.mask_src; a.ld_mask = L.ld_mask; a.mask_slope = L.mask_slope;
+    a.out = L.out; a.ld_out = L.ld_out; a.nout = L.nout; a.accumulate = L.accumulate;
+    const long long nt128 = (L.n + 127) / 128;
+    const int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
+    CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
+    return LIDF_OK;
+}
+
+#define ACT_ROW_FLOATS (LIDF_H1 + LIDF_H2 + LIDF_H3 + 1)   // per row and pass: H1 | H2 | H3 | offset in
+
+LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
+    if (n <= 0 || n_pass <= 0) return 0;
+    return (size_t)n * ((size_t)n_pass * ACT_ROW_FLOATS + 1);  // + the pre-activation output
+}
+
+struct TrainWs {
+    size_t stream, dz1, dz2, dz3, goff, enc, denc, total;
+};
+static TrainWs train_ws(int64_t n, int d) {
+    TrainWs w;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    size_t o = 0;
+    const int kmax = d > 256 ? d : 256;
+    w.stream = o; o += linex_stream_bytes(kmax);
+    w.dz1 = o;    o += align_up(N * LIDF_H1 * 4, 256);
+    w.dz2 = o;    o += align_up(N * LIDF_H2 * 4, 256);
+    w.dz3 = o;    o += align_up(N * LIDF_H3 * 4, 256);
+    w.goff = o;   o += align_up(N * 4, 256);
+    w.enc = o;    o += align_up(N * 16 * 4, 256);
+    w.denc = o;   o += align_up(N * 16 * 4, 256);
+    w.total = o;
+    return w;
+}
+LIDF_API size_t lidf_decoder_train_workspace_bytes(int64_t n, int32_t d) { return train_ws(n, d).total; }
+
+static inline const float* act_h1(const float* act, int64_t n, int k) { return act + (size_t)k * n * ACT_ROW_FLOATS; }
+
+LIDF_API int lidf_decoder_forward_train_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                              const LidfDecoder* dec, float* out, float* act,
+                                              void* workspace, size_t workspace_bytes,
+                                              lidf_stream_t stream) {
+    if (n < 0 || d <= 0 || ld_inp < d || !dec) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(dec))) return rc;
+    if (n == 0) return LIDF_OK;
+    if (!inp || !out || !act) return LIDF_ERR_BAD_ARG;
+    const TrainWs w = train_ws(n, d);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sbuf = (float*)((char*)workspace + w.stream);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    const int ld1 = d + (dec->is_ief ? 16 : 0);
+    float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;  // running offset / final pre-activation
+    CHECK_HIP(lidf_launch_fill(pre, n, dec->is_ief ? dec->init_offset : 0.f, st));
+    for (int k = 0; k < npass; ++k) {
+        float* h1 = act + (size_t)k * n * ACT_ROW_FLOATS;
+        float* h2 = h1 + (size_t)n * LIDF_H1;
+        float* h3 = h2 + (size_t)n * LIDF_H2;
+        float* offin = h3 + (size_t)n * LIDF_H3;
+        if (dec->is_ief) CHECK_HIP(hipMemcpyAsync(offin, pre, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        LinEx L = {};
+        L.n = n; L.relu = 1; L.slope = 0.02f;
+        // layer 1: [inp | enc(off)] W1^T + b1 = inp W1x^T + (b1 + c) + u * off
+        L.w = dec->w1; L.b = dec->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = d;
+        L.ief = dec->is_ief ? dec : nullptr; L.X = inp; L.ldx = ld_inp;
+        L.xoff = dec->is_ief ? offin : nullptr; L.out = h1; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.ief = nullptr; L.xoff = nullptr;
+        L.w = dec->w2; L.b = dec->b2; L.ldw = LIDF_H1; L.nout = LIDF_H2; L.k = LIDF_H1;
+        L.X = h1; L.ldx = LIDF_H1; L.out = h2; L.ld_out = LIDF_H2;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.w = dec->w3; L.b = dec->b3; L.ldw = LIDF_H2; L.nout = LIDF_H3; L.k = LIDF_H2;
+        L.X = h2; L.ldx = LIDF_H2; L.out = h3; L.ld_out = LIDF_H3;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        // layer 4 adds straight into the running offset (IMNet: pre starts at 0)
+        L.relu = 0;
+        L.w = dec->w4; L.b = dec->b4; L.ldw = LIDF_H3; L.nout = 1; L.k = LIDF_H3;
+        L.X = h3; L.ldx = LIDF_H3; L.out = pre; L.ld_out = 1; L.accumulate = 1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
+    CHECK_HIP(lidf_launch_out_act(pre, n, dec->use_sigmoid, out, nullptr, nullptr, st));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                         const LidfDecoder* dec, const float* act,
+                                         const float* g_out, float* d_inp, int64_t ld_dinp,
+                                         const LidfDecoderGrads* grads, void* workspace,
+                                         size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || d <= 0 || ld_inp < d || !dec || !grads) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(dec))) return rc;
+    if (!grads->w1 || !grads->b1 || !grads->w2 || !grads->b2 || !grads->w3 || !grads->b3 ||
+        !grads->w4 || !grads->b4 || (dec->is_ief && (!grads->wenc || !grads->benc)))
+        return LIDF_ERR_BAD_ARG;
+    if (d_inp && ld_dinp < d) return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    const int ld1 = d + (dec->is_ief ? 16 : 0);
+    // gradients start at zero (also what an empty batch returns)
+    CHECK_HIP(hipMemsetAsync(grads->w1, 0, (size_t)LIDF_H1 * ld1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b1, 0, LIDF_H1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w2, 0, (size_t)LIDF_H2 * LIDF_H1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b2, 0, LIDF_H2 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w3, 0, (size_t)LIDF_H3 * LIDF_H2 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b3, 0, LIDF_H3 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w4, 0, LIDF_H3 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b4, 0, 4, st));
+    if (dec->is_ief) {
+        CHECK_HIP(hipMemsetAsync(grads->wenc, 0, 16 * 4, st));
+        CHECK_HIP(hipMemsetAsync(grads->benc, 0, 16 * 4, st));
+    }
+    if (n == 0) return LIDF_OK;
+    if (!inp || !act || !g_out) return LIDF_ERR_BAD_ARG;
+    const TrainWs w = train_ws(n, d);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    float* sbuf = (float*)(ws + w.stream);
+    float* dz1 = (float*)(ws + w.dz1);
+    float* dz2 = (float*)(ws + w.dz2);
+    float* dz3 = (float*)(ws + w.dz3);
+    float* goff = (float*)(ws + w.goff);
+    float* enc = (float*)(ws + w.enc);
+    float* denc = (float*)(ws + w.denc);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;
+    // through the output activation: goff = dL/d(off_n)
+    CHECK_HIP(lidf_launch_out_act(pre, n, dec->use_sigmoid, nullptr, g_out, goff, st));
+    for (int k = npass - 1; k >= 0; --k) {
+        const float* h1 = act_h1(act, n, k);
+        const float* h2 = h1 + (size_t)n * LIDF_H1;
+        const float* h3 = h2 + (size_t)n * LIDF_H2;
+        const float* offin = h3 + (size_t)n * LIDF_H3;
+        // y_k = w4 . H3 + b4 ;  dL/dy_k = dL/d(off_{k+1}) = goff
+        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, n, grads->w4, LIDF_H3, grads->b4, st));
+        LinEx L = {};
+        L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
+        // dZ3 = (goff (x) w4) * lrelu'(Z3)
+        L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
+        L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, st));
+        // dZ2 = (dZ3 W3) * lrelu'(Z2)
+        L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
+        L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, st));
+        // dZ1 = (dZ2 W2) * lrelu'(Z1)
+        L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
+        L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, st));
+        L.mask_src = nullptr;
+        if (d_inp) {
+            // d inp (+)= dZ1 W1[:, 0:d], 256 input columns per launch
+            for (int c0 = 0; c0 < d; c0 += 256) {
+                const int cols = d - c0 < 256 ? d - c0 : 256;
+                L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
+                L.out = d_inp + c0; L.ld_out = ld_dinp; L.accumulate = k < npass - 1;
+                if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+            }
+            L.accumulate = 0;
+        }
+        if (dec->is_ief) {
+            // the 16 offset-encoding columns of layer 1: enc_k = off_k wenc^T + benc
+            CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, n, enc, st));
+            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, n, grads->w1 + d, ld1, nullptr, st));
+            // d enc = dZ1 W1[:, d:d+16] ; d wenc = d enc^T off_k ; d benc = sum d enc
+            L.w = dec->w1 + d; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
+            L.out = denc; L.ld_out = 16;
+            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, n, grads->wenc, 1, grads->benc, st));
+            // d off_k = d off_{k+1} + d enc . wenc
+            L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
+            L.out = goff; L.ld_out = 1; L.accumulate = 1;
+            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+            L.accumulate = 0;
+        }
+    }
     return LIDF_OK;
 }

@@ -64,6 +64,8 @@ struct L1Map {
     int add_bias;  // bias k-step carries b1 (+ IEF constant) ; else 0
     int nt;        // output tiles per k-quad in the rows modes (8 for the decoders' layer 1)
     int nout;      // rows of w1 (outputs); tiles beyond it are zero
+    int transposed;  // rows modes: weight element (out, col) is read at w1[col*ld1 + out] (dgrad)
+    int add_u;       // rows modes: operand column D+1 carries the IEF vector u (operand = offset)
     // fused mode
     int L;         // octaves
     int enter_c0;  // w1 column of enter-position embedding
@@ -153,4 +155,12 @@ struct LinearArgs {
     float* pool;           // optional: pool[poolidx[row], f] = max(pool[..], value); needs relu
     const int* poolidx;
     int ld_pool;
+    // training path (lidf_train.hip)
+    float slope;           // with relu: leaky slope (0 = plain ReLU)
+    const float* xoff;     // optional [n]: operand of column D+1 (the IEF offset fed to this pass)
+    const float* mask_src; // optional [n, ld_mask]: value *= (mask_src > 0 ? 1 : mask_slope)
+    long long ld_mask;
+    float mask_slope;
+    int nout;              // > 0: only columns < nout are stored
+    int accumulate;        // out += value instead of out = value
 };

@@ -1,8 +1,10 @@
 // lidf_linear.hip — generic f32 MFMA linear layer with fused epilogues, used by the PointNet2Stage
 // forward (models/pointnet.py:22-38) and by the stage-2 refinement query.
 //
-//   out[row, 0:32*NT] = epilogue( X[row, 0:D] W^T + b )
-//   epilogue: (+ addrows[addidx[row]])  ->  (relu)  ->  (store)  and/or  (atomic max into a pool)
+//   out[row, 0:32*NT] = epilogue( X[row, 0:D] W^T + b  [+ u * xoff[row]] )
+//   epilogue: (+ addrows[addidx[row]])  ->  (relu / leaky relu)  ->  (* slope mask of another tensor)
+//             ->  (store or accumulate)  and/or  (atomic max into a pool)
+// The mask / accumulate / u-column options serve the decoders' training path (lidf_train.hip).
 //
 // Same transposed 32x32x2 f32 MFMA formulation and the same packed weight-stream format as the
 // decoder kernel (lidf_device.h, rows mode with NT output tiles): one wavefront owns 32 rows, lane
@@ -50,7 +52,9 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
-                                          : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+                                          : ((x0 + jj == a.D && a.has_bias)
+                                                 ? 1.f
+                                                 : ((x0 + jj == a.D + 1 && a.xoff) ? a.xoff[pc] : 0.f));
             }
         };
         float bc[4];
@@ -84,6 +88,7 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
         const float* ar =
             (valid && a.addrows) ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
         float* op = (valid && a.out) ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
+        const float* mp = (valid && a.mask_src) ? a.mask_src + (size_t)p * a.ld_mask + 4 * h : nullptr;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -98,9 +103,33 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 }
                 if (a.relu) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], a.slope * v[i]);
                 }
-                if (op) *(f32x4*)(op + t * 32 + 8 * g) = v;
+                const int c0 = t * 32 + 8 * g + 4 * h;  // first of this lane's four columns
+                if (mp && (a.nout <= 0 || c0 < a.nout)) {
+                    // dgrad through a leaky ReLU: the activation's output has the sign of its input
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (a.nout <= 0 || c0 + i < a.nout)
+                            v[i] *= mp[t * 32 + 8 * g + i] > 0.f ? 1.f : a.mask_slope;
+                }
+                if (op) {
+                    if (a.nout <= 0 || c0 + 3 < a.nout) {
+                        if (a.accumulate) {
+                            const f32x4 o = *(const f32x4*)(op + t * 32 + 8 * g);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += o[i];
+                        }
+                        *(f32x4*)(op + t * 32 + 8 * g) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (c0 + i < a.nout) {
+                                float* q = op + t * 32 + 8 * g + i;
+                                *q = a.accumulate ? *q + v[i] : v[i];
+                            }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = v[i];
             }
@@ -170,6 +199,7 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a, int grid, 
         case 1: hipLaunchKernelGGL(lidf_linear_kernel<1>, g, b, 0, st, a); break;
         case 2: hipLaunchKernelGGL(lidf_linear_kernel<2>, g, b, 0, st, a); break;
         case 4: hipLaunchKernelGGL(lidf_linear_kernel<4>, g, b, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(lidf_linear_kernel<8>, g, b, 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -101,13 +101,14 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         (void)s;
         if (x < m.D) {
             const int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
-            return n.w1[(size_t)out * n.ld1 + col];
+            return m.transposed ? n.w1[(size_t)col * n.ld1 + out] : n.w1[(size_t)out * n.ld1 + col];
         }
         if (x == m.D && m.add_bias) {
             float b = n.b1[out];
             if (n.is_ief) b += ief_c(n, out);
             return b;
         }
+        if (x == m.D + 1 && m.add_u && n.is_ief) return ief_u(n, out);
         return 0.f;
     }
     quad -= lay.l1_quads;

@@ -8,9 +8,10 @@ with the reference's `restore()` (utils/training_utils.py:27-63) and the modules
 
 Execution:
   * CUDA f32 input, no autograd needed  -> liblidf_hip.so (hand-written gfx950 kernels);
-  * autograd needed (training)          -> composite torch ops on the SAME device (the HIP
-    backward is not written yet; this is the differentiable definition, not a fallback for a
-    missing library);
+  * autograd needed (training)          -> liblidf_hip.so as well: a forward that keeps the
+    activations (lidf_decoder_forward_train_f32) and a backward (lidf_decoder_backward_f32)
+    behind a torch.autograd.Function; `forward_composite` is the same function written in
+    torch ops, kept as the differentiable definition the tests compare against;
   * CPU input                           -> RuntimeError. There is no CPU product path.
 """
 import ctypes as C
@@ -155,7 +156,70 @@ def decoders_forward(inp_feat, prob_dec=None, offset_dec=None):
     return out_p, out_o
 
 
+_PARAM_ORDER = ("linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
+                "linear_3.weight", "linear_3.bias", "linear_4.weight", "linear_4.bias",
+                "offset_enc.weight", "offset_enc.bias")
+
+
+class _DecoderTrainFn(torch.autograd.Function):
+    """IMNet / IEF on [n, D] rows with a HIP forward that keeps the activations and a HIP backward
+    (what autograd derives for models/implicit_net.py:81-98 / :131-152)."""
+
+    @staticmethod
+    def forward(ctx, mod, inp_feat, *params):
+        x = inp_feat.detach()
+        if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+            x = x.contiguous()
+        n, d = x.shape
+        ld = x.stride(0) if n > 1 else d
+        keep = []
+        dec = _decoder_struct(mod, keep)
+        L = _lib.lib()
+        n_pass = int(mod.n_iter) if isinstance(mod, IEF) else 1
+        f32 = dict(dtype=torch.float32, device=x.device)
+        act = torch.empty((max(L.lidf_decoder_train_act_floats(n, n_pass), 1),), **f32)
+        wsb = L.lidf_decoder_train_workspace_bytes(n, d)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+        out = torch.empty((n, 1), **f32)
+        with torch.cuda.device(x.device):
+            _lib.check(L.lidf_decoder_forward_train_f32(
+                _lib.ptr(x), n, d, ld, C.byref(dec), _lib.ptr(out), _lib.ptr(act), _lib.ptr(ws), wsb,
+                _lib.current_stream(x.device)))
+        ctx.mod, ctx.x, ctx.ld, ctx.act, ctx.ws, ctx.wsb = mod, x, ld, act, ws, wsb
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        mod, x = ctx.mod, ctx.x
+        n, d = x.shape
+        keep = []
+        dec = _decoder_struct(mod, keep)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g = g_out.detach().reshape(-1).contiguous().float()
+        sd = dict(mod.named_parameters())
+        names = [k for k in _PARAM_ORDER if k in sd]
+        gtens = {k: torch.empty_like(sd[k], **f32).contiguous() for k in names}
+        gs = _lib.LidfDecoderGrads()
+        for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _PARAM_ORDER):
+            setattr(gs, field, gtens[k].data_ptr() if k in gtens else None)
+        d_inp = torch.empty((n, d), **f32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_decoder_backward_f32(
+                _lib.ptr(x), n, d, ctx.ld, C.byref(dec), _lib.ptr(ctx.act), _lib.ptr(g),
+                _lib.ptr(d_inp), d, C.byref(gs), _lib.ptr(ctx.ws), ctx.wsb,
+                _lib.current_stream(x.device)))
+        return (None, d_inp) + tuple(gtens[k] for k in names)
+
+
 class _DecoderBase(nn.Module):
+    def _forward_train(self, inp_feat):
+        """Differentiable forward through liblidf_hip (training)."""
+        _check_supported(self)
+        if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != self.inp_dim:
+            raise RuntimeError("inp_feat must be float32 [n, %d]" % self.inp_dim)
+        sd = dict(self.named_parameters())
+        return _DecoderTrainFn.apply(self, inp_feat, *[sd[k] for k in _PARAM_ORDER if k in sd])
+
     def _needs_autograd(self, inp_feat):
         if not torch.is_grad_enabled():
             return False
@@ -192,11 +256,11 @@ class IMNet(_DecoderBase):
         if not inp_feat.is_cuda:
             raise RuntimeError("IMNet.forward: CUDA tensor required (no CPU path)")
         if self._needs_autograd(inp_feat):
-            return self.forward_composite(inp_feat)
+            return self._forward_train(inp_feat)
         return decoders_forward(inp_feat, prob_dec=self)[0]
 
     def forward_composite(self, inp_feat):
-        """Differentiable definition in torch ops (used only when autograd is required)."""
+        """The same function in differentiable torch ops (the definition the tests compare with)."""
         y = self._trunk(inp_feat)
         return torch.sigmoid(y) if self.use_sigmoid else _leaky_clamp(y)
 
@@ -228,11 +292,11 @@ class IEF(_DecoderBase):
         if not inp_feat.is_cuda:
             raise RuntimeError("IEF.forward: CUDA tensor required (no CPU path)")
         if self._needs_autograd(inp_feat):
-            return self.forward_composite(inp_feat)
+            return self._forward_train(inp_feat)
         return decoders_forward(inp_feat, offset_dec=self)[1]
 
     def forward_composite(self, inp_feat):
-        """Differentiable definition in torch ops (used only when autograd is required)."""
+        """The same function in differentiable torch ops (the definition the tests compare with)."""
         off = self.init_offset.to(inp_feat.device).expand(inp_feat.shape[0], -1)
         for _ in range(self.n_iter):
             off = off + self._trunk(torch.cat([inp_feat, self.offset_enc(off)], 1))

@@ -295,6 +295,30 @@ int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const
                            int32_t src_h, int32_t src_w, int32_t dst_h, int32_t dst_w, float* out,
                            lidf_stream_t stream);
 
+/* ---- Decoders, training path (first step) -------------------------------------
+ * What autograd does for models/implicit_net.py IMNet / IEF on [n, d] rows: a forward that keeps
+ * the activations of every layer and pass, and a backward that returns the gradient of the input
+ * rows and of every parameter. Same arithmetic as lidf_decoders_f32, layer by layer.
+ *   act        caller-owned, lidf_decoder_train_act_floats(n, n_pass) floats, written by the
+ *              forward and read by the backward (n_pass = n_iter for an IEF, 1 for an IMNet)
+ *   g_out      [n] dL/d(output)
+ *   d_inp      [n, d] (row stride ld_dinp) or NULL
+ *   grads      device buffers shaped like the parameters (w1 [256, d(+16)], ...); overwritten.
+ * Weight gradients are reduced with float atomics: their summation order is not fixed.        */
+typedef struct LidfDecoderGrads {
+    float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+    float *wenc, *benc; /* IEF only */
+} LidfDecoderGrads;
+size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass);
+size_t lidf_decoder_train_workspace_bytes(int64_t n, int32_t d);
+int lidf_decoder_forward_train_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                   const LidfDecoder* dec, float* out, float* act, void* workspace,
+                                   size_t workspace_bytes, lidf_stream_t stream);
+int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                              const LidfDecoder* dec, const float* act, const float* g_out,
+                              float* d_inp, int64_t ld_dinp, const LidfDecoderGrads* grads,
+                              void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
