@@ -144,6 +144,25 @@ def secondary(args):
                 return decoders_forward(x, prob, off)
         flop_alg, bytes_alg, name = F_ALG, 1548.0, "lidf_points_kernel<ROWS>"
         what = "prob_dec (IMNet) + offset_dec (IEF n_iter=2) on a materialised [P,385] f32 input"
+    elif args.workload == "train":
+        # one training step of both decoders at the decoder boundary: forward that keeps the
+        # activations + backward (input and parameter gradients), liblidf_hip on both sides
+        P = 240 * 320 * args.samples // 8      # 614,400 rows: the activations of 3 passes stay modest
+        x = torch.randn(P, 385, generator=g, device=dev).requires_grad_(True)
+        prob = IMNet(385, 1, 64).to(dev).train()
+        prob.load_state_dict(init_decoder_params("IMNET", 385, 7, 5.0))
+        off = IEF(dev, 385, 1, 64, n_iter=2).to(dev).train()
+        off.load_state_dict(init_decoder_params("IEF", 385, 8, 5.0))
+
+        def step():
+            for m in (prob, off):
+                for p in m.parameters():
+                    p.grad = None
+            x.grad = None
+            (prob(x).sum() + off(x).sum()).backward()
+        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_linear_kernel + lidf_wgrad_kernel"
+        what = ("training step of prob_dec (IMNet) + offset_dec (IEF n_iter=2) on [P,385] rows: "
+                "forward with kept activations + backward (d input, d parameters); FLOP = 3 x forward")
     else:
         x = (torch.rand(P, 3, generator=g, device=dev) - 0.5) * 4.6
         fn, dim = get_embedder(8)
@@ -192,13 +211,13 @@ def main():
                          "accuracy, LidfQueryArgs.precision); the default f32 run also reports the "
                          "f16x3 rate and its deviation from the f32 outputs as \"split_f16\"")
     ap.add_argument("--workload", default="query",
-                    choices=["query", "query+refine", "decoders", "embed"],
+                    choices=["query", "query+refine", "decoders", "embed", "train"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
                          "configs[3] (stage 1 + 2 x get_pred_refine); decoders = IMNet+IEF on a "
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
                          "stand-alone positional encoding (the one HBM-bound kernel of the path)")
     args = ap.parse_args()
-    if args.workload in ("decoders", "embed"):
+    if args.workload in ("decoders", "embed", "train"):
         return secondary(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -8,9 +8,9 @@
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // C[m, j] += sum over rows r of A[r, m] * B[r, j]   (m < M, j < N), db[m] += sum_r A[r, m].
-// One wavefront per (32x32 tile of C, slice of rows): lane (c, h) feeds A[r+h, 32mt+c] and
-// B[r+h, 32nt+c] — 128 contiguous bytes per half-wave and matrix — into v_mfma_f32_32x32x2_f32 with
-// k = the row pair; partial tiles are added with float atomics (summation order is not fixed).
+// One wavefront per (64x64 tile of C, slice of rows): lane (c, h) feeds A[r+h, 64mt+32t+c] and
+// B[r+h, 64nt+32t+c] — 128 contiguous bytes per half-wave and matrix — into v_mfma_f32_32x32x2_f32
+// with k = the row pair; partial tiles are added with float atomics (summation order is not fixed).
 struct WgradArgs {
     const float* A; long long lda; int M;
     const float* B; long long ldb; int N;
@@ -22,41 +22,95 @@ struct WgradArgs {
 };
 
 __global__ void __launch_bounds__(256) lidf_wgrad_kernel(WgradArgs a) {
+    // one wavefront: a 64 x 64 tile of C (2 x 2 matrix tiles), so every loaded value feeds two
+    // instructions
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
-    int id = blockIdx.x;
-    const int mt = id % a.mtiles; id /= a.mtiles;
-    const int nt = id % a.ntiles; id /= a.ntiles;
-    const long long r0 = (long long)id * a.rows_per_split;
+    long long id = (long long)blockIdx.x * 4 + wave;  // every wavefront is an independent unit
+    if (id >= (long long)a.mtiles * a.ntiles * a.splits) return;
+    const int mt = (int)(id % a.mtiles); id /= a.mtiles;
+    const int nt = (int)(id % a.ntiles); id /= a.ntiles;
+    const long long r0 = id * a.rows_per_split;
     long long r1 = r0 + a.rows_per_split;
     if (r1 > a.n) r1 = a.n;
-    const int am = 32 * mt + c, bj = 32 * nt + c;
-    const bool a_ok = am < a.M, b_ok = bj < a.N, b_one = a.db && bj == a.N;
-    f32x16 acc;
+    int am[2], bj[2];
+    bool a_ok[2], b_ok[2], b_one[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // the four wavefronts interleave blocks of 16 rows
-    for (long long r = r0 + wave * 16; r < r1; r += 64) {
-        float av[8], bv[8];
+    for (int t = 0; t < 2; ++t) {
+        am[t] = 64 * mt + 32 * t + c;
+        bj[t] = 64 * nt + 32 * t + c;
+        a_ok[t] = am[t] < a.M;
+        b_ok[t] = bj[t] < a.N;
+        b_one[t] = a.db && bj[t] == a.N;
+    }
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long row = r + 2 * u + h;
-            const bool in = row < r1;
-            av[u] = (in && a_ok) ? a.A[(size_t)row * a.lda + am] : 0.f;
-            bv[u] = in ? (b_ok ? a.B[(size_t)row * a.ldb + bj] : (b_one ? 1.f : 0.f)) : 0.f;
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t >> 1][t & 1][i] = 0.f;
+    }
+    // 8 rows per step; the loads of the next step are in flight while this one multiplies.
+    // Buffer loads over this unit's rows: the row advance is a scalar offset, rows past the end
+    // and columns past the matrix fall outside the descriptor and read as 0 — no per-load
+    // address arithmetic or bounds test on the vector unit.
+    const int nrows = (int)(r1 - r0);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.A + (size_t)r0 * a.lda), 0, (int)((size_t)nrows * a.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.B + (size_t)r0 * a.ldb), 0, (int)((size_t)nrows * a.ldb * 4), 0x00020000);
+    int va[2], vb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        va[t] = a_ok[t] ? (int)((h * a.lda + am[t]) * 4) : 0x7ffffff0;
+        vb[t] = b_ok[t] ? (int)((h * a.ldb + bj[t]) * 4) : 0x7ffffff0;
+    }
+    const int sa = (int)(a.lda * 8), sbb = (int)(a.ldb * 8);  // two rows
+    float av[4][2], bv[4][2], an[4][2], bn[4][2];
+    auto load = [&](int r, float (&x)[4][2], float (&y)[4][2]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                x[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, va[t], (r / 2 + u) * sa, 0));
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vb[t], (r / 2 + u) * sbb, 0));
+                y[u][t] = b_one[t] ? ((r + 2 * u + h < nrows) ? 1.f : 0.f) : v;
+            }
+        }
+    };
+    load(0, av, bv);
+    for (int r = 0; r < nrows; r += 8) {
+        load(r + 8, an, bn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t >> 1][t & 1] = MFMA(av[u][t >> 1], bv[u][t & 1], acc[t >> 1][t & 1]);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = MFMA(av[u], bv[u], acc);
-    }
-    // result register q of lane (c, h): C row 32mt + (q&3) + 8(q>>2) + 4h, column 32nt + c
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int m = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (m >= a.M || acc[q] == 0.f) continue;
-        if (bj < a.N)
-            atomicAdd(a.C + (size_t)m * a.ldc + bj, acc[q]);
-        else if (b_one)
-            atomicAdd(a.db + m, acc[q]);
+            for (int t = 0; t < 2; ++t) {
+                av[u][t] = an[u][t];
+                bv[u][t] = bn[u][t];
+            }
+        }
+    }
+    // result register q of lane (c, h) in tile (tm, tn): C row 64mt + 32tm + (q&3) + 8(q>>2) + 4h,
+    // column 64nt + 32tn + c
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tm = t >> 1, tn = t & 1;
+        const int col = bj[tn];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = 64 * mt + 32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float v = acc[tm][tn][q];
+            if (m >= a.M || v == 0.f) continue;
+            if (col < a.N)
+                atomicAdd(a.C + (size_t)m * a.ldc + col, v);
+            else if (b_one[tn])
+                atomicAdd(a.db + m, v);
+        }
     }
 }
 
@@ -67,11 +121,18 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
     WgradArgs a;
     a.A = A; a.lda = lda; a.M = M; a.B = B; a.ldb = ldb; a.N = N; a.n = n; a.C = C; a.ldc = ldc;
     a.db = db;
-    a.mtiles = (M + 31) / 32;
-    a.ntiles = (N + (db ? 1 : 0) + 31) / 32;
-    a.rows_per_split = 4096;
+    a.mtiles = (M + 63) / 64;
+    a.ntiles = (N + (db ? 1 : 0) + 63) / 64;
+    // enough units to fill the chip (~8 wavefronts per SIMD), as few as possible beyond that: every
+    // unit ends with 4096 atomic adds
+    const long long tiles = (long long)a.mtiles * a.ntiles;
+    long long splits = (8192 + tiles - 1) / tiles;
+    const long long max_splits = (n + 511) / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.rows_per_split = ((n + splits - 1) / splits + 7) / 8 * 8;
     a.splits = (int)((n + a.rows_per_split - 1) / a.rows_per_split);
-    const long long blocks = (long long)a.mtiles * a.ntiles * a.splits;
+    const long long blocks = (tiles * a.splits + 3) / 4;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(lidf_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return hipGetLastError();
