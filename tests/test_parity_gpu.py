@@ -91,8 +91,9 @@ def test_decoders_strided_rows(cuda):
 
 
 def test_autograd_path_matches_hip(cuda):
-    """With autograd enabled the modules run their differentiable torch definition on the same
-    GPU: same values as the HIP path, and gradients reach the parameters and the input."""
+    """With autograd enabled the modules run the library's training path: same values as the
+    inference kernel, and gradients reach the parameters and the input (values of the gradients:
+    tests/test_train_gpu.py)."""
     d = 385
     p = orc.randomize_biases(orc.init_decoder("IEF", d, 5, 5.0), 6)
     m = make_module("IEF", p, d, cuda)
