@@ -9,6 +9,8 @@ Python modules are imported and executed, and only their inputs/outputs are stor
   g2_decoders.npz   IMNet / IEF forward outputs on closed-form weights  (models/implicit_net.py:60-152)
   g3_pipeline.npz   LIDF.get_miss_ray -> compute_ray_aabb -> get_embedding -> get_pred trace on a
                     2 x 16 x 24 synthetic batch                           (models/pipeline.py:203-466)
+  g5_decoder_grads.npz  autograd gradients of the reference IMNet / IEF (input rows and every
+                    parameter) for a closed-form upstream gradient   (models/implicit_net.py:60-152)
   g4_refine.npz     RefineNet.get_pred_refine x 2 on the same batch (stage 2), incl. the refine
                     PointNet2Stage outputs                     (models/pipeline.py:922-1041, pointnet.py)
 
@@ -110,6 +112,53 @@ def g1_embed():
         assert y.shape[1] == dim
         out["embed_L%d" % L] = y.numpy()
     np.savez_compressed(os.path.join(HERE, "g1_embed.npz"), **out)
+
+
+def g5_decoder_grads():
+    """The reference modules' own autograd: what the training path of the product must return."""
+    import models.implicit_net as ref
+    out = {}
+    def min_abs_preact(p, x, kind, n_iter):
+        """Smallest |pre-activation| of the three leaky-ReLU layers over all rows and passes (f64):
+        a fixture with one of them within rounding of 0 would pin a coin flip of the f32 summation
+        order (the derivative jumps there), not the algorithm."""
+        pd = {k: v.double() for k, v in p.items()}
+        xd = x.detach().double()
+        off = torch.full((xd.shape[0], 1), 0.001, dtype=torch.float64)
+        lo = 1e9
+        for _ in range(n_iter):
+            h = torch.cat([xd, off @ pd["offset_enc.weight"].t() + pd["offset_enc.bias"]], 1) if kind == "IEF" else xd
+            for i in (1, 2, 3):
+                z = h @ pd["linear_%d.weight" % i].t() + pd["linear_%d.bias" % i]
+                lo = min(lo, z.abs().min().item())
+                h = torch.nn.functional.leaky_relu(z, 0.02)
+            off = off + h @ pd["linear_4.weight"].t() + pd["linear_4.bias"]
+        return lo
+
+    for kind, d, n_iter, sig in (("IMNET", 385, 1, False), ("IEF", 385, 2, False), ("IEF", 334, 3, True)):
+        seed = 51 + 10 * len(out)
+        while True:
+            p = closed_form_params(kind, d, seed=seed)
+            x = closed_form((96, d), 0.5698402910, 0.1 * d, 1.0)
+            if min_abs_preact(p, x, kind, n_iter) > 2e-5:
+                break
+            seed += 1
+        x.requires_grad_(True)
+        wgt = closed_form((96, 1), 0.7390851332, 0.37, 1.0)
+        if kind == "IEF":
+            m = ref.IEF(torch.device("cpu"), d, 1, 64, n_iter=n_iter, use_sigmoid=sig)
+        else:
+            m = ref.IMNet(d, 1, 64, use_sigmoid=sig)
+        m.load_state_dict(p)
+        y = m(x)
+        (y * wgt).sum().backward()
+        key = "%s_%d_%d_%d" % (kind, d, n_iter, int(sig))
+        out[key + "_seed"] = np.int64(seed)
+        out[key + "_y"] = y.detach().numpy()
+        out[key + "_g_input"] = x.grad.numpy()
+        for k, v in m.named_parameters():
+            out[key + "_g_" + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_decoder_grads.npz"), **out)
 
 
 def g2_decoders():
@@ -232,6 +281,7 @@ def g3_pipeline():
 if __name__ == "__main__":
     g1_embed()
     g2_decoders()
+    g5_decoder_grads()
     g3_pipeline()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

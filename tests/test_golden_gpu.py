@@ -73,3 +73,23 @@ def test_g3_pipeline_hip(cuda, precision):
         assert abs(sm[gid_ref[r]] - sm[g["max_pair_id"][r]]) <= 1e-6  # only float-noise ties may differ
     dref = g["pred_pos"][:, 2].reshape(2, h, w)
     assert np.abs(depth.cpu().numpy() - dref).mean() <= TOL
+
+
+def test_g5_decoder_grads_hip(cuda):
+    """The library's training path (forward with kept activations + backward) against the
+    gradients of the reference's own IMNet / IEF modules."""
+    from test_oracle_golden import g5_cases, g5_inputs
+    g = load("g5_decoder_grads.npz")
+    for key, kind, d, n_iter, sig, seed in g5_cases(g):
+        m = make_module(kind, closed_form_params(kind, d, seed=seed), d, cuda, n_iter=n_iter,
+                        use_sigmoid=sig).train()
+        x, wgt = g5_inputs(d)
+        x = x.to(cuda).requires_grad_(True)
+        y = m(x)
+        (y * wgt.to(cuda)).sum().backward()
+        assert np.abs(y.detach().cpu().numpy() - g[key + "_y"]).max() <= TOL, key
+        ref = g[key + "_g_input"]
+        assert np.abs(x.grad.cpu().numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), key
+        for k, v in m.named_parameters():
+            ref = g[key + "_g_" + k]
+            assert np.abs(v.grad.cpu().numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (key, k)

@@ -142,3 +142,35 @@ def test_g3_occupied_voxels():
         assert (res[k].numpy() == g[k]).all(), k
     for k in ("valid_v_rel_coord", "voxel_bound", "xmin"):
         assert np.abs(res[k].numpy() - g[k]).max() == 0.0, k
+
+
+def g5_cases(g):
+    for key in sorted(k[:-5] for k in g if k.endswith("_seed")):
+        kind, d, n_iter, sig = key.split("_")
+        yield key, kind, int(d), int(n_iter), bool(int(sig)), int(g[key + "_seed"])
+
+
+def g5_inputs(d):
+    x = closed_form((96, d), 0.5698402910, 0.1 * d, 1.0)
+    wgt = closed_form((96, 1), 0.7390851332, 0.37, 1.0)
+    return x, wgt
+
+
+def test_g5_decoder_grads():
+    """Autograd of the oracle's restatement against the reference modules' own gradients."""
+    g = load("g5_decoder_grads.npz")
+    n = 0
+    for key, kind, d, n_iter, sig, seed in g5_cases(g):
+        p = {k: v.clone().requires_grad_(True) for k, v in closed_form_params(kind, d, seed=seed).items()}
+        x, wgt = g5_inputs(d)
+        x.requires_grad_(True)
+        y = orc.decoder_forward(p, x, kind, n_iter, sig)
+        (y * wgt).sum().backward()
+        assert np.abs(y.detach().numpy() - g[key + "_y"]).max() <= 1e-6, key
+        ref = g[key + "_g_input"]
+        assert np.abs(x.grad.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), key
+        for k, v in p.items():
+            ref = g[key + "_g_" + k]
+            assert np.abs(v.grad.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (key, k)
+        n += 1
+    assert n == 3
