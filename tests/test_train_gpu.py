@@ -94,3 +94,25 @@ def test_empty_batch_and_no_input_grad(cuda):
         p.grad = None
     m(x).sum().backward()
     assert m.linear_1.weight.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("kind,n_iter", [("IMNET", 1), ("IEF", 2)])
+def test_backward_against_f64(cuda, kind, n_iter):
+    """Tighter: the same gradients from the composite definition evaluated in float64 on the GPU.
+    f32 rounding level is all that may separate them (seeded inputs without a pre-activation at
+    the leaky-ReLU kink)."""
+    d, n = 385, 300
+    p = orc.randomize_biases(orc.init_decoder(kind, d, 61, 5.0), 62)
+    m = make_module(kind, p, d, cuda, n_iter=n_iter).train()
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(n, d, generator=gen).to(cuda)
+    wgt = torch.randn(n, generator=gen).to(cuda)
+    _, g_hip = _grads(m, x, m, wgt)
+    md = make_module(kind, p, d, cuda, n_iter=n_iter).double().train()
+    if kind == "IEF":
+        md.init_offset = md.init_offset.double()
+    _, g_ref = _grads(md, x.double(), md.forward_composite, wgt.double())
+    for k in g_ref:
+        scale = max(1e-3, g_ref[k].abs().max().item())
+        err = (g_hip[k].double() - g_ref[k]).abs().max().item()
+        assert err <= 2e-5 * scale, (k, err, scale)
