@@ -107,6 +107,9 @@ SIGNATURES = {
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
+    "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),
+    "lidf_ray_features_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
     "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,

@@ -35,6 +35,13 @@ hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long l
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
 hipError_t lidf_launch_out_act(const float*, long long, int, float*, const float*, float*,
                                hipStream_t);
+hipError_t lidf_launch_build_rows(const int*, const int*, const float*, const float*, const float*, int,
+                                  const float*, const float*, int, int, int, long long, float*, int,
+                                  hipStream_t);
+hipError_t lidf_launch_rows_backward(const float*, int, int, const int*, const int*, long long,
+                                     long long, int, float*, float*, int, hipStream_t);
+hipError_t lidf_launch_rayfeat_backward(const float*, int, const int*, const int*, long long, int, int,
+                                        int, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -978,5 +985,56 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
             L.accumulate = 0;
         }
     }
+    return LIDF_OK;
+}
+
+// ---- query, training path: decoder input rows and their gradient ------------------------------------
+LIDF_API int lidf_build_rows_f32(const int32_t* pair_ray, const int32_t* pair_vox,
+                                   const float* pair_t, const float* ray_dir,
+                                   const float* vox_center, int32_t pos_rel, const float* vox_feat,
+                                   const float* rayfeat, int32_t multires, int32_t multires_views,
+                                   int64_t n_pairs, float* rows, lidf_stream_t stream) {
+    if (n_pairs < 0 || multires < 0 || multires > 16 || multires_views < 0 || multires_views > 16)
+        return LIDF_ERR_BAD_ARG;
+    if (n_pairs == 0) return LIDF_OK;
+    if (!pair_ray || !pair_vox || !pair_t || !ray_dir || !vox_feat || !rayfeat || !rows)
+        return LIDF_ERR_BAD_ARG;
+    if (pos_rel && !vox_center) return LIDF_ERR_BAD_ARG;
+    const int E = 3 + 6 * multires, Ed = 3 + 6 * multires_views;
+    CHECK_HIP(lidf_launch_build_rows(pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel,
+                                     vox_feat, rayfeat, 128 + Ed, multires, Ed, n_pairs, rows,
+                                     256 + 2 * E + Ed, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_rows_backward_f32(const float* d_rows, const int32_t* pair_off,
+                                      const int32_t* pair_vox, int64_t n_rays, int64_t n_pairs,
+                                      int64_t n_vox, int32_t multires, int32_t multires_views,
+                                      float* d_vox_feat, float* d_rayfeat, lidf_stream_t stream) {
+    if (n_pairs < 0 || n_rays < 0 || n_vox < 0 || multires < 0 || multires > 16 ||
+        multires_views < 0 || multires_views > 16)
+        return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int E = 3 + 6 * multires, Ed = 3 + 6 * multires_views;
+    if (d_vox_feat && n_vox > 0) CHECK_HIP(hipMemsetAsync(d_vox_feat, 0, (size_t)n_vox * 128 * 4, st));
+    if (n_rays == 0) return LIDF_OK;
+    if (!pair_off || (n_pairs > 0 && (!d_rows || !pair_vox))) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_rows_backward(d_rows, 256 + 2 * E + Ed, 2 * E, pair_off, pair_vox, n_rays,
+                                        n_pairs, Ed, d_vox_feat, d_rayfeat, 128 + Ed, st));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_t* ray_pix,
+                                              const int32_t* ray_bid, int64_t n_rays, int32_t batch,
+                                              int32_t height, int32_t width, int32_t roi_inp_bbox,
+                                              int32_t multires_views, float* d_feat_grid,
+                                              lidf_stream_t stream) {
+    if (n_rays < 0 || batch <= 0 || height <= 0 || width <= 0 || !d_feat_grid) return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_HIP(hipMemsetAsync(d_feat_grid, 0, (size_t)batch * 32 * height * width * 4, st));
+    if (n_rays == 0) return LIDF_OK;
+    if (!d_rayfeat || !ray_pix || !ray_bid) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_rayfeat_backward(d_rayfeat, 128 + 3 + 6 * multires_views, ray_pix, ray_bid,
+                                           n_rays, roi_inp_bbox / 2, height, width, d_feat_grid, st));
     return LIDF_OK;
 }

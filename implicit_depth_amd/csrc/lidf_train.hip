@@ -193,3 +193,162 @@ extern "C" hipError_t lidf_launch_out_act(const float* pre, long long n, int use
                        pre, n, use_sigmoid, out, g, gpre);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training path of the query (LIDF.get_embedding, models/pipeline.py:338-420, with gradients):
+// the decoder input rows are materialised — the reference's own formulation — so that the
+// decoders' training path above applies; their gradient is reduced back to the voxel features and
+// the per-ray features, and the ROI part of the latter through RoIAlign to the feature map.
+// ------------------------------------------------------------------------------------------------
+// row p = [ vox_feat[pair_vox] (128) | rayfeat[pair_ray][0:128] | embed(enter) | embed(leave) |
+//           rayfeat[pair_ray][128:128+Ed] ]; one wavefront per row, lanes stride the columns.
+__global__ void __launch_bounds__(256) lidf_build_rows_kernel(
+    const int* __restrict__ pair_ray, const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
+    const float* __restrict__ ray_dir, const float* __restrict__ vox_center, int pos_rel,
+    const float* __restrict__ vox_feat, const float* __restrict__ rayfeat, int ld_rf, int L, int Ed,
+    long long P, float* __restrict__ rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int r = pair_ray[p], v = pair_vox[p];
+    const float te = pair_t[2 * p], tl = pair_t[2 * p + 1];
+    const float d[3] = {ray_dir[3 * (size_t)r], ray_dir[3 * (size_t)r + 1], ray_dir[3 * (size_t)r + 2]};
+    float c[3] = {0.f, 0.f, 0.f};
+    if (pos_rel) {
+        c[0] = vox_center[3 * (size_t)v];
+        c[1] = vox_center[3 * (size_t)v + 1];
+        c[2] = vox_center[3 * (size_t)v + 2];
+    }
+    const int E = 3 + 6 * L;
+    float* o = rows + (size_t)p * D;
+    for (int j = lane; j < D; j += 64) {
+        float val;
+        if (j < 128) {
+            val = vox_feat[(size_t)v * 128 + j];
+        } else if (j < 256) {
+            val = rayfeat[(size_t)r * ld_rf + (j - 128)];
+        } else if (j < 256 + 2 * E) {
+            const int k = (j - 256) % E;
+            const float t = j - 256 < E ? te : tl;
+            // positional encoding element k of the position d*t (- voxel centre): models/implicit_net.py:30-39
+            const int i = k < 3 ? k : (k - 3) % 3;
+            const float x = __fmul_rn(d[i], t) - c[i];
+            if (k < 3) {
+                val = x;
+            } else {
+                const int oct = (k - 3) / 6;
+                const float a = x * (float)(1 << oct);
+                val = ((k - 3) % 6) < 3 ? sinf(a) : cosf(a);
+            }
+        } else {
+            val = rayfeat[(size_t)r * ld_rf + 128 + (j - 256 - 2 * E)];
+        }
+        o[j] = val;
+    }
+}
+
+// d rayfeat[r] = sum of the row gradients of the ray's (contiguous) pairs; one wavefront per ray
+__global__ void __launch_bounds__(256) lidf_rows_ray_backward_kernel(
+    const float* __restrict__ d_rows, int D, int E2, const int* __restrict__ pair_off, long long R,
+    int Ed, float* __restrict__ d_rayfeat, int ld_rf) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int beg = pair_off[r], end = pair_off[r + 1];
+    for (int j = lane; j < 128 + Ed; j += 64) {
+        const int colr = j < 128 ? 128 + j : 256 + E2 + (j - 128);
+        float acc = 0.f;
+        for (int p = beg; p < end; ++p) acc += d_rows[(size_t)p * D + colr];
+        d_rayfeat[(size_t)r * ld_rf + j] = acc;
+    }
+}
+
+// d vox_feat[v] += row gradient columns 0..127 (pairs of a voxel are scattered over the rays:
+// float atomics, summation order not fixed)
+__global__ void __launch_bounds__(256) lidf_rows_vox_backward_kernel(
+    const float* __restrict__ d_rows, int D, const int* __restrict__ pair_vox, long long P,
+    float* __restrict__ d_vox_feat) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * 128) return;
+    const long long p = i >> 7;
+    const int j = (int)(i & 127);
+    const float g = d_rows[(size_t)p * D + j];
+    if (g != 0.f) atomicAdd(d_vox_feat + (size_t)pair_vox[p] * 128 + j, g);
+}
+
+// RoIAlign backward (torchvision roi_align, output 2x2, aligned): every sample of bin (ph, pw)
+// passes g / count to its four bilinear taps. One thread per (ray, channel, bin).
+__global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
+    const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
+    const int* __restrict__ ray_bid, long long R, int half, int H, int W, float* __restrict__ d_feat) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * 128) return;
+    const long long r = i >> 7;
+    const int cb = (int)(i & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
+    const float g = d_rayfeat[(size_t)r * ld_rf + cb];
+    if (g == 0.f) return;
+    const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
+    const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+    const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+    const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+    const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
+    const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+    const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+    const float gs = g / (float)max(gh * gw, 1);
+    float* img = d_feat + ((size_t)ray_bid[r] * 32 + c) * H * W;
+    for (int iy = 0; iy < gh; ++iy) {
+        float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+            float yy = y;
+            // the taps of bilinear() in lidf_aux.hip
+            if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+            if (yy <= 0.f) yy = 0.f;
+            if (x <= 0.f) x = 0.f;
+            int y_low = (int)yy, x_low = (int)x, y_high, x_high;
+            if (y_low >= H - 1) { y_high = y_low = H - 1; yy = (float)y_low; } else { y_high = y_low + 1; }
+            if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+            const float ly = yy - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+            if (hy * hx != 0.f) atomicAdd(img + y_low * W + x_low, gs * hy * hx);
+            if (hy * lx != 0.f) atomicAdd(img + y_low * W + x_high, gs * hy * lx);
+            if (ly * hx != 0.f) atomicAdd(img + y_high * W + x_low, gs * ly * hx);
+            if (ly * lx != 0.f) atomicAdd(img + y_high * W + x_high, gs * ly * lx);
+        }
+    }
+}
+
+extern "C" hipError_t lidf_launch_build_rows(const int* pair_ray, const int* pair_vox,
+                                             const float* pair_t, const float* ray_dir,
+                                             const float* vox_center, int pos_rel,
+                                             const float* vox_feat, const float* rayfeat, int ld_rf,
+                                             int L, int Ed, long long P, float* rows, int D,
+                                             hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_build_rows_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st,
+                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, vox_feat, rayfeat,
+                       ld_rf, L, Ed, P, rows, D);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_rows_backward(const float* d_rows, int D, int E2,
+                                                const int* pair_off, const int* pair_vox,
+                                                long long R, long long P, int Ed, float* d_vox_feat,
+                                                float* d_rayfeat, int ld_rf, hipStream_t st) {
+    if (d_rayfeat && R > 0)
+        hipLaunchKernelGGL(lidf_rows_ray_backward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0,
+                           st, d_rows, D, E2, pair_off, R, Ed, d_rayfeat, ld_rf);
+    if (d_vox_feat && P > 0)
+        hipLaunchKernelGGL(lidf_rows_vox_backward_kernel, dim3((unsigned)((P * 128 + 255) / 256)),
+                           dim3(256), 0, st, d_rows, D, pair_vox, P, d_vox_feat);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int ld_rf,
+                                                   const int* ray_pix, const int* ray_bid,
+                                                   long long R, int half, int H, int W,
+                                                   float* d_feat, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_rayfeat_backward_kernel, dim3((unsigned)((R * 128 + 255) / 256)),
+                       dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat);
+    return hipGetLastError();
+}

@@ -351,3 +351,107 @@ def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
     res = {k: out[i] for i, k in enumerate(METRIC_NAMES)}
     res["count"] = out[9]
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# Training path of the query (gradients to vox_feat, feat_grid and the decoders' parameters)
+# ------------------------------------------------------------------------------------------------
+class _RayFeaturesFn(torch.autograd.Function):
+    """ray_features with RoIAlign backward to the feature map (lidf_ray_features_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views):
+        fg = feat_grid.detach().contiguous()
+        out = ray_features(fg, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+        ctx.save_for_backward(ray_pix, ray_bid)
+        ctx.shape, ctx.bbox, ctx.lv = tuple(fg.shape), roi_inp_bbox, multires_views
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ray_pix, ray_bid = ctx.saved_tensors
+        B, _, h, w = ctx.shape
+        g = g.detach().contiguous().float()
+        d_feat = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().lidf_ray_features_backward_f32(
+                _lib.ptr(g), _lib.ptr(ray_pix), _lib.ptr(ray_bid), g.shape[0], B, h, w, ctx.bbox,
+                ctx.lv, _lib.ptr(d_feat), _lib.current_stream(g.device)))
+        return d_feat, None, None, None, None, None
+
+
+class _BuildRowsFn(torch.autograd.Function):
+    """Decoder input rows (LIDF.get_embedding's concat, models/pipeline.py:399-420) with the
+    gradient reduced back to vox_feat and the per-ray features (lidf_rows_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir, vox_center,
+                pos_rel, multires, multires_views):
+        vf, rf = vox_feat.detach().contiguous(), rayfeat.detach().contiguous()
+        P = pair_ray.shape[0]
+        D = 256 + 2 * (3 + 6 * multires) + 3 + 6 * multires_views
+        rows = torch.empty((P, D), dtype=torch.float32, device=vf.device)
+        with torch.cuda.device(vf.device):
+            _lib.check(_lib.lib().lidf_build_rows_f32(
+                _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
+                _lib.ptr(vf), _lib.ptr(rf), multires, multires_views, P, _lib.ptr(rows),
+                _lib.current_stream(vf.device)))
+        ctx.save_for_backward(pair_off, pair_vox)
+        ctx.dims = (vf.shape[0], rf.shape[0], P, multires, multires_views)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        pair_off, pair_vox = ctx.saved_tensors
+        V, R, P, L, Lv = ctx.dims
+        g = g.detach().contiguous().float()
+        f32 = dict(dtype=torch.float32, device=g.device)
+        d_vox = torch.empty((V, 128), **f32) if ctx.needs_input_grad[0] else None
+        d_ray = torch.zeros((R, 128 + 3 + 6 * Lv), **f32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().lidf_rows_backward_f32(
+                _lib.ptr(g), _lib.ptr(pair_off), _lib.ptr(pair_vox), R, P, V, L, Lv,
+                _lib.ptr(d_vox), _lib.ptr(d_ray), _lib.current_stream(g.device)))
+        return (d_vox, d_ray) + (None,) * 9
+
+
+def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
+                     vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
+                     offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False):
+    """Differentiable get_embedding + get_pred (models/pipeline.py:338-466) for training
+    (train_lidf.py:393-396): gradients reach feat_grid (through RoIAlign), vox_feat and every
+    decoder parameter, all through liblidf_hip — ROI pooling, the decoder input rows, the decoders'
+    forward that keeps activations and their backward. The cheap per-pair / per-ray tail
+    (pair_pred_pos, softmax over a ray, arg-max, select) is written in torch ops on [P] vectors.
+    Same arguments as lidf_query; the decoders must be in autograd mode (parameters requiring grad).
+    Returns pred_offset, pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
+    max_pair_id [R] (P for an empty ray) and pred_pos [R,3]."""
+    import math
+    _lib.require_cuda(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
+                      vox_feat, names=["ray_dir", "ray_pix", "ray_bid", "pair_off", "pair_ray",
+                                       "pair_vox", "pair_t", "feat_grid", "vox_feat"])
+    R, P = ray_dir.shape[0], pair_ray.shape[0]
+    rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    rows = _BuildRowsFn.apply(vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
+                              vox_center, pos_rel, multires, multires_views)
+    pred_prob = prob_dec(rows)
+    pred_offset = offset_dec(rows)
+    pr = pair_ray.long()
+    d = ray_dir[pr]
+    # pipeline.py:437-439
+    sc = pred_offset * (offset_range[1] - offset_range[0]) + offset_range[0]
+    sc = sc * float(torch.tensor(math.sqrt(3.0), dtype=torch.float32)) * part_size
+    pair_pred_pos = d * pair_t[:, 0:1] + sc * d
+    # scatter_softmax over the pairs of a ray, scatter_max, dummy-row select (pipeline.py:442-454)
+    logit = pred_prob[:, 0]
+    m = torch.full((R,), float("-inf"), device=logit.device).scatter_reduce(0, pr, logit.detach(), "amax")
+    e = torch.exp(logit - m[pr])
+    sm = e / torch.zeros(R, device=logit.device).index_add(0, pr, e)[pr]
+    best = torch.full((R,), float("-inf"), device=logit.device).scatter_reduce(0, pr, sm.detach(), "amax")
+    idx = torch.arange(P, device=logit.device)
+    cand = torch.where(sm.detach() == best[pr], idx, torch.full_like(idx, P))
+    max_pair_id = torch.full((R,), P, dtype=torch.long, device=logit.device).scatter_reduce(0, pr, cand, "amin")
+    dummy = torch.cat((pair_pred_pos, torch.zeros(1, 3, device=logit.device)), 0)
+    return {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
+            "pred_prob_end_softmax": sm, "max_pair_id": max_pair_id, "pred_pos": dummy[max_pair_id]}

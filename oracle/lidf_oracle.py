@@ -332,7 +332,7 @@ def scatter_softmax(src, index, dim_size=None):
 def scatter_max(src, index, dim_size):
     out = torch.zeros(dim_size, dtype=src.dtype)
     arg = torch.full((dim_size,), src.shape[0], dtype=torch.long)
-    s = src.numpy()
+    s = src.detach().numpy()   # values only: the arg-max carries no gradient
     idx = index.numpy()
     best = {}
     for i in range(s.shape[0]):

@@ -1,0 +1,77 @@
+"""Training path of the query: gradients to feat_grid (through RoIAlign), vox_feat and the decoders'
+parameters, against autograd of the CPU oracle's torch restatement of get_embedding + get_pred."""
+import pytest
+import torch
+
+from util import TOL, make_module, orc, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss(out, w):
+    return ((out["pred_prob_end"][:, 0] * w["prob"]).sum() + (out["pred_offset"][:, 0] * w["off"]).sum()
+            + (out["pred_pos"] * w["pos"]).sum())
+
+
+@pytest.mark.parametrize("ragged,pos_rel", [(False, False), (True, True)])
+def test_query_gradients(cuda, ragged, pos_rel):
+    from implicit_depth_amd.query import lidf_query, lidf_query_train
+    scene = orc.synthetic_scene(2, 12, 16, 8, seed=71, ragged=ragged)
+    R, P, D = scene["R"], scene["P"], scene["D"]
+    gen = torch.Generator().manual_seed(72)
+    w = {"prob": torch.randn(P, generator=gen), "off": torch.randn(P, generator=gen),
+         "pos": torch.randn(R, 3, generator=gen)}
+    kw = dict(offset_range=(-0.2, 0.2), part_size=0.25)
+    # ---- oracle autograd (torch CPU)
+    pp = {k: v.clone().requires_grad_(True) for k, v in scene["prob_p"].items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in scene["off_p"].items()}
+    fg = scene["feat_grid"].clone().requires_grad_(True)
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], fg, vf, pp, po,
+                    fast_roi=True, vox_center=scene["vox_center"], pos_rel=pos_rel, **kw)
+    _loss(ref, w).backward()
+    # ---- product
+    s = to_dev(scene, cuda)
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", scene["off_p"], D, cuda).train()
+    fgd = s["feat_grid"].clone().requires_grad_(True)
+    vfd = s["vox_feat"].clone().requires_grad_(True)
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
+    out = lidf_query_train(*args, fgd, vfd, prob, off, vox_center=s["vox_center"], pos_rel=pos_rel, **kw)
+    _loss(out, {k: v.to(cuda) for k, v in w.items()}).backward()
+    # forward values: the oracle, and the inference kernel
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() <= TOL, k
+    with torch.no_grad():
+        inf = lidf_query(*args, s["feat_grid"], s["vox_feat"], prob, off, vox_center=s["vox_center"],
+                         pos_rel=pos_rel, **kw)
+    assert (inf["pred_prob_end"] - out["pred_prob_end"]).abs().max().item() <= 1e-5
+    assert (inf["max_pair_id"] == out["max_pair_id"]).all()
+    # gradients
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(fgd.grad.cpu(), fg.grad, "feat_grid")
+    close(vfd.grad.cpu(), vf.grad, "vox_feat")
+    for k, v in pp.items():
+        close(dict(prob.named_parameters())[k].grad.cpu(), v.grad, "prob." + k)
+    for k, v in po.items():
+        close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
+
+
+def test_ray_features_backward_border(cuda):
+    """RoIAlign backward on its own, boxes clamped at the image border (fractional samples)."""
+    from implicit_depth_amd.query import _RayFeaturesFn
+    scene = orc.synthetic_scene(2, 12, 16, 1, seed=73)
+    s = to_dev(scene, cuda)
+    gen = torch.Generator().manual_seed(74)
+    for bbox in (8, 7, 4):
+        wgt = torch.randn(scene["R"], 128, generator=gen)
+        fg = scene["feat_grid"].clone().requires_grad_(True)
+        boxes = orc.roi_boxes(scene["ray_pix"].long(), scene["ray_bid"].long(), 12, 16, bbox)
+        (orc.roi_align_fast(fg, boxes).reshape(scene["R"], -1) * wgt).sum().backward()
+        fgd = s["feat_grid"].clone().requires_grad_(True)
+        got = _RayFeaturesFn.apply(fgd, s["ray_dir"], s["ray_pix"], s["ray_bid"], bbox, 4)
+        (got[:, :128] * wgt.to(cuda)).sum().backward()
+        assert (fgd.grad.cpu() - fg.grad).abs().max().item() <= 1e-5 * max(1.0, fg.grad.abs().max().item()), bbox
