@@ -144,6 +144,34 @@ def secondary(args):
                 return decoders_forward(x, prob, off)
         flop_alg, bytes_alg, name = F_ALG, 1548.0, "lidf_points_kernel<ROWS>"
         what = "prob_dec (IMNet) + offset_dec (IEF n_iter=2) on a materialised [P,385] f32 input"
+    elif args.workload == "train-query":
+        # one training step of the whole query: forward + backward to feat_grid, vox_feat and the
+        # decoders' parameters (lidf_query_train), on one 240x320 frame with samples/8 candidates
+        from implicit_depth_amd.query import lidf_query_train
+        from implicit_depth_amd.synthetic import synthetic_scene
+        scene = synthetic_scene(1, 240, 320, max(args.samples // 8, 1), seed=1235)
+        P = scene["P"]
+        sd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+        prob = IMNet(scene["D"], 1, 64).to(dev).train()
+        prob.load_state_dict(scene["prob_p"])
+        off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).train()
+        off.load_state_dict(scene["off_p"])
+        fg = sd["feat_grid"].clone().requires_grad_(True)
+        vf = sd["vox_feat"].clone().requires_grad_(True)
+
+        def step():
+            for m in (prob, off):
+                for p in m.parameters():
+                    p.grad = None
+            fg.grad = None
+            vf.grad = None
+            o = lidf_query_train(sd["ray_dir"], sd["ray_pix"], sd["ray_bid"], sd["pair_off"], sd["pair_ray"],
+                                 sd["pair_vox"], sd["pair_t"], fg, vf, prob, off)
+            (o["pred_pos"].sum() + o["pred_prob_end_softmax"].sum() + o["pred_offset"].sum()).backward()
+        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_linear_kernel + lidf_wgrad_kernel"
+        what = ("training step of the query (lidf_query_train): ROI pooling, decoder input rows, both "
+                "decoders forward + backward, gradients to feat_grid / vox_feat / parameters; "
+                "240x320 rays x %d candidates; FLOP = 3 x forward" % max(args.samples // 8, 1))
     elif args.workload == "train":
         # one training step of both decoders at the decoder boundary: forward that keeps the
         # activations + backward (input and parameter gradients), liblidf_hip on both sides
@@ -211,13 +239,13 @@ def main():
                          "accuracy, LidfQueryArgs.precision); the default f32 run also reports the "
                          "f16x3 rate and its deviation from the f32 outputs as \"split_f16\"")
     ap.add_argument("--workload", default="query",
-                    choices=["query", "query+refine", "decoders", "embed", "train"],
+                    choices=["query", "query+refine", "decoders", "embed", "train", "train-query"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
                          "configs[3] (stage 1 + 2 x get_pred_refine); decoders = IMNet+IEF on a "
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
                          "stand-alone positional encoding (the one HBM-bound kernel of the path)")
     args = ap.parse_args()
-    if args.workload in ("decoders", "embed", "train"):
+    if args.workload in ("decoders", "embed", "train", "train-query"):
         return secondary(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
