@@ -53,6 +53,16 @@ class LidfDecoderGrads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc")]
 
 
+class LidfQueryTrainArgs(C.Structure):
+    """struct LidfQueryTrainArgs (include/lidf_hip.h)."""
+    _fields_ = [
+        ("n_pairs", C.c_int64), ("n_rays", C.c_int64), ("n_vox", C.c_int64),
+        ("pair_off", C.c_void_p), ("pair_ray", C.c_void_p), ("pair_vox", C.c_void_p),
+        ("pe", C.c_void_p), ("multires", C.c_int32), ("multires_views", C.c_int32),
+        ("vox_feat", C.c_void_p), ("rayfeat", C.c_void_p), ("dec", C.POINTER(LidfDecoder)),
+    ]
+
+
 class LidfPointNet(C.Structure):
     """struct LidfPointNet (include/lidf_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
@@ -110,6 +120,13 @@ SIGNATURES = {
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),
     "lidf_ray_features_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+    "lidf_pe_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I64, _P, _P]),
+    "lidf_query_decoder_act_floats": (C.c_size_t, [_I64, _I64, _I64, _I]),
+    "lidf_query_decoder_workspace_bytes": (C.c_size_t, [_I64, _I64, _I64]),
+    "lidf_query_decoder_forward_train_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P,
+                                                       C.c_size_t, _P]),
+    "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
+                                                  C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
     "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,

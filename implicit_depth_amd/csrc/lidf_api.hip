@@ -33,6 +33,7 @@ hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long lo
 hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long long, float*,
                                 hipStream_t);
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
+hipError_t lidf_launch_axpy(const float*, long long, float*, hipStream_t);
 hipError_t lidf_launch_out_act(const float*, long long, int, float*, const float*, float*,
                                hipStream_t);
 hipError_t lidf_launch_build_rows(const int*, const int*, const float*, const float*, const float*, int,
@@ -42,6 +43,10 @@ hipError_t lidf_launch_rows_backward(const float*, int, int, const int*, const i
                                      long long, int, float*, float*, int, hipStream_t);
 hipError_t lidf_launch_rayfeat_backward(const float*, int, const int*, const int*, long long, int, int,
                                         int, float*, hipStream_t);
+hipError_t lidf_launch_pe_rows(const int*, const int*, const float*, const float*, const float*, int, int,
+                               long long, float*, hipStream_t);
+hipError_t lidf_launch_seg_sum_ray(const float*, int, const int*, long long, float*, hipStream_t);
+hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -775,6 +780,10 @@ struct LinEx {
     int transposed;                            // outputs index weight columns, k indexes rows (W^T)
     const LidfDecoder* ief;                    // layer 1 of an IEF: bias += c, column k+1 = u
     const float* X; long long ldx; long long n;
+    int c0, k1, c1;                            // operand columns [0,k) -> weight columns c0.., [k,k+k1) -> c1..
+    int dcore;                                 // IEF: weight column of the offset encoding (default k)
+    const float* addrows; const int* addidx;   // gathered 256-wide terms added before the activation
+    const float* addrows2; const int* addidx2;
     const float* xoff;
     int relu; float slope;
     const float* mask_src; long long ld_mask; float mask_slope;
@@ -784,24 +793,28 @@ struct LinEx {
 static int nt_for(int nout) { return nout <= 32 ? 1 : nout <= 64 ? 2 : nout <= 128 ? 4 : 8; }
 
 static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) / 8) * 8 * 1024, 256); }
+// NOTE: the bias / u columns exist in the stream only when the layer has them; a layer with a
+// second operand segment passes k = k + k1 here.
 
 static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st) {
     if (L.n <= 0) return LIDF_OK;
     const int nt = nt_for(L.nout);
-    L1Map m = rows_map(L.k, 0, 0, 0, L.b ? 1 : 0);
-    m.KQ1 = (L.k + 2 + 7) / 8;   // room for the bias and the u column
+    L1Map m = rows_map(L.k, L.c0, L.k1, L.c1, L.b ? 1 : 0);
+    m.KQ1 = (m.D + 2 + 7) / 8;   // room for the bias and the u column
     m.nt = nt;
     m.nout = L.nout;
     m.transposed = L.transposed;
     m.add_u = L.ief ? 1 : 0;
     StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
     NetW nw = {};
-    nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.k; nw.is_ief = 0;
+    nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.dcore ? L.dcore : L.k; nw.is_ief = 0;
     if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
     CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
-    a.D = L.k; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
+    a.D = m.D; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
+    a.addrows = L.addrows; a.addidx = L.addidx; a.ld_add = L.nout;
+    a.addrows2 = L.addrows2; a.addidx2 = L.addidx2; a.ld_add2 = L.nout;
     a.relu = L.relu; a.slope = L.slope;
     a.mask_src = L.mask_src; a.ld_mask = L.ld_mask; a.mask_slope = L.mask_slope;
     a.out = L.out; a.ld_out = L.ld_out; a.nout = L.nout; a.accumulate = L.accumulate;
@@ -1036,5 +1049,252 @@ LIDF_API int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_
     if (!d_rayfeat || !ray_pix || !ray_bid) return LIDF_ERR_BAD_ARG;
     CHECK_HIP(lidf_launch_rayfeat_backward(d_rayfeat, 128 + 3 + 6 * multires_views, ray_pix, ray_bid,
                                            n_rays, roi_inp_bbox / 2, height, width, d_feat_grid, st));
+    return LIDF_OK;
+}
+
+// ---- query decoders, factorised training path -------------------------------------------------------
+LIDF_API int lidf_pe_rows_f32(const int32_t* pair_ray, const int32_t* pair_vox, const float* pair_t,
+                                const float* ray_dir, const float* vox_center, int32_t pos_rel,
+                                int32_t multires, int64_t n_pairs, float* pe, lidf_stream_t stream) {
+    if (n_pairs < 0 || multires < 0 || multires > 16) return LIDF_ERR_BAD_ARG;
+    if (n_pairs == 0) return LIDF_OK;
+    if (!pair_ray || !pair_vox || !pair_t || !ray_dir || !pe || (pos_rel && !vox_center))
+        return LIDF_ERR_BAD_ARG;
+    if (n_pairs * 2 * (3 + 6 * multires) > 0x7fffffffLL * 256) return LIDF_ERR_UNSUPPORTED;
+    CHECK_HIP(lidf_launch_pe_rows(pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, multires,
+                                  n_pairs, pe, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+static inline size_t qact_pass(int64_t P) { return (size_t)P * ACT_ROW_FLOATS; }
+
+LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, int64_t n_vox,
+                                                int32_t n_pass) {
+    if (n_pairs < 0 || n_rays < 0 || n_vox < 0 || n_pass <= 0) return 0;
+    return (size_t)(n_vox + n_rays) * LIDF_H1 + (size_t)n_pass * qact_pass(n_pairs) + (size_t)n_pairs;
+}
+
+struct QTrainWs {
+    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, total;
+};
+static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
+    QTrainWs w;
+    const size_t N = (size_t)(P > 0 ? P : 1);
+    size_t o = 0;
+    w.stream = o; o += linex_stream_bytes(256);
+    w.dz1 = o;    o += align_up(N * LIDF_H1 * 4, 256);
+    w.dz2 = o;    o += align_up(N * LIDF_H2 * 4, 256);
+    w.dz3 = o;    o += align_up(N * LIDF_H3 * 4, 256);
+    w.S = o;      o += align_up(N * LIDF_H1 * 4, 256);
+    w.goff = o;   o += align_up(N * 4, 256);
+    w.enc = o;    o += align_up(N * 16 * 4, 256);
+    w.denc = o;   o += align_up(N * 16 * 4, 256);
+    w.dvox = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
+    w.dray = o;   o += align_up((size_t)(R > 0 ? R : 1) * LIDF_H1 * 4, 256);
+    w.total = o;
+    return w;
+}
+LIDF_API size_t lidf_query_decoder_workspace_bytes(int64_t n_pairs, int64_t n_rays, int64_t n_vox) {
+    return qtrain_ws(n_pairs, n_rays, n_vox).total;
+}
+
+static int check_qtrain(const LidfQueryTrainArgs* q) {
+    if (!q || !q->dec) return LIDF_ERR_BAD_ARG;
+    if (q->n_pairs < 0 || q->n_rays < 0 || q->n_vox < 0) return LIDF_ERR_BAD_ARG;
+    if (q->multires < 0 || q->multires > 16 || q->multires_views < 0 || q->multires_views > 16)
+        return LIDF_ERR_BAD_ARG;
+    if (q->n_pairs > 0 && (!q->pair_off || !q->pair_ray || !q->pair_vox || !q->pe || !q->vox_feat ||
+                           !q->rayfeat || q->n_rays == 0 || q->n_vox == 0))
+        return LIDF_ERR_BAD_ARG;
+    return check_decoder(q->dec);
+}
+
+LIDF_API int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* q, float* out, float* act,
+                                                    void* workspace, size_t workspace_bytes,
+                                                    lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_qtrain(q))) return rc;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    if (P == 0) return LIDF_OK;
+    if (!out || !act) return LIDF_ERR_BAD_ARG;
+    const QTrainWs w = qtrain_ws(P, R, V);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sbuf = (float*)((char*)workspace + w.stream);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const LidfDecoder* dec = q->dec;
+    const int E2 = 2 * (3 + 6 * q->multires), Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    float* voxpart = act;
+    float* raypart = voxpart + (size_t)V * LIDF_H1;
+    float* passes = raypart + (size_t)R * LIDF_H1;
+    float* pre = passes + (size_t)npass * qact_pass(P);
+    LinEx L = {};
+    // voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c) ; raypart[r] = W1[:, rgb | dir] rayfeat[r]
+    L.w = dec->w1; L.b = dec->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
+    L.ief = dec->is_ief ? dec : nullptr;   // bias += c (no offset operand: xoff stays NULL)
+    L.X = q->vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    L = {};
+    L.w = dec->w1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.c0 = 128; L.k1 = Ed; L.c1 = 256 + E2;
+    L.X = q->rayfeat; L.ldx = 128 + Ed; L.n = R; L.out = raypart; L.ld_out = LIDF_H1;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    CHECK_HIP(lidf_launch_fill(pre, P, dec->is_ief ? dec->init_offset : 0.f, st));
+    for (int k = 0; k < npass; ++k) {
+        float* h1 = passes + (size_t)k * qact_pass(P);
+        float* h2 = h1 + (size_t)P * LIDF_H1;
+        float* h3 = h2 + (size_t)P * LIDF_H2;
+        float* offin = h3 + (size_t)P * LIDF_H3;
+        if (dec->is_ief) CHECK_HIP(hipMemcpyAsync(offin, pre, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+        L = {};
+        L.n = P; L.relu = 1; L.slope = 0.02f;
+        // layer 1: W1[:, enter|leave] PE + voxpart[voxel] + raypart[ray] (+ u * off)
+        L.w = dec->w1 + 256; L.ldw = ld1; L.nout = LIDF_H1; L.k = E2; L.dcore = D - 256;
+        L.ief = dec->is_ief ? dec : nullptr; L.X = q->pe; L.ldx = E2;
+        L.xoff = dec->is_ief ? offin : nullptr;
+        L.addrows = voxpart; L.addidx = q->pair_vox; L.addrows2 = raypart; L.addidx2 = q->pair_ray;
+        L.out = h1; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L = {};
+        L.n = P; L.relu = 1; L.slope = 0.02f;
+        L.w = dec->w2; L.b = dec->b2; L.ldw = LIDF_H1; L.nout = LIDF_H2; L.k = LIDF_H1;
+        L.X = h1; L.ldx = LIDF_H1; L.out = h2; L.ld_out = LIDF_H2;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.w = dec->w3; L.b = dec->b3; L.ldw = LIDF_H2; L.nout = LIDF_H3; L.k = LIDF_H2;
+        L.X = h2; L.ldx = LIDF_H2; L.out = h3; L.ld_out = LIDF_H3;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.relu = 0;
+        L.w = dec->w4; L.b = dec->b4; L.ldw = LIDF_H3; L.nout = 1; L.k = LIDF_H3;
+        L.X = h3; L.ldx = LIDF_H3; L.out = pre; L.ld_out = 1; L.accumulate = 1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
+    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, out, nullptr, nullptr, st));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const float* act,
+                                               const float* g_out, float* d_vox_feat,
+                                               float* d_rayfeat, int32_t accumulate_inputs,
+                                               const LidfDecoderGrads* grads, void* workspace,
+                                               size_t workspace_bytes, lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_qtrain(q))) return rc;
+    if (!grads) return LIDF_ERR_BAD_ARG;
+    const LidfDecoder* dec = q->dec;
+    if (!grads->w1 || !grads->b1 || !grads->w2 || !grads->b2 || !grads->w3 || !grads->b3 ||
+        !grads->w4 || !grads->b4 || (dec->is_ief && (!grads->wenc || !grads->benc)))
+        return LIDF_ERR_BAD_ARG;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    hipStream_t st = (hipStream_t)stream;
+    const int E2 = 2 * (3 + 6 * q->multires), Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    CHECK_HIP(hipMemsetAsync(grads->w1, 0, (size_t)LIDF_H1 * ld1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b1, 0, LIDF_H1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w2, 0, (size_t)LIDF_H2 * LIDF_H1 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b2, 0, LIDF_H2 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w3, 0, (size_t)LIDF_H3 * LIDF_H2 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b3, 0, LIDF_H3 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->w4, 0, LIDF_H3 * 4, st));
+    CHECK_HIP(hipMemsetAsync(grads->b4, 0, 4, st));
+    if (dec->is_ief) {
+        CHECK_HIP(hipMemsetAsync(grads->wenc, 0, 16 * 4, st));
+        CHECK_HIP(hipMemsetAsync(grads->benc, 0, 16 * 4, st));
+    }
+    if (!accumulate_inputs) {
+        if (d_vox_feat && V > 0) CHECK_HIP(hipMemsetAsync(d_vox_feat, 0, (size_t)V * 128 * 4, st));
+        if (d_rayfeat && R > 0) CHECK_HIP(hipMemsetAsync(d_rayfeat, 0, (size_t)R * (128 + Ed) * 4, st));
+    }
+    if (P == 0) return LIDF_OK;
+    if (!act || !g_out) return LIDF_ERR_BAD_ARG;
+    const QTrainWs w = qtrain_ws(P, R, V);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    float* sbuf = (float*)(ws + w.stream);
+    float* dz1 = (float*)(ws + w.dz1);
+    float* dz2 = (float*)(ws + w.dz2);
+    float* dz3 = (float*)(ws + w.dz3);
+    float* S = (float*)(ws + w.S);
+    float* goff = (float*)(ws + w.goff);
+    float* enc = (float*)(ws + w.enc);
+    float* denc = (float*)(ws + w.denc);
+    float* dvox = (float*)(ws + w.dvox);
+    float* dray = (float*)(ws + w.dray);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const float* voxpart = act;
+    const float* raypart = voxpart + (size_t)V * LIDF_H1;
+    const float* passes = raypart + (size_t)R * LIDF_H1;
+    const float* pre = passes + (size_t)npass * qact_pass(P);
+    (void)voxpart; (void)raypart;
+    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
+    for (int k = npass - 1; k >= 0; --k) {
+        const float* h1 = passes + (size_t)k * qact_pass(P);
+        const float* h2 = h1 + (size_t)P * LIDF_H1;
+        const float* h3 = h2 + (size_t)P * LIDF_H2;
+        const float* offin = h3 + (size_t)P * LIDF_H3;
+        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, P, grads->w4, LIDF_H3, grads->b4, st));
+        LinEx L = {};
+        L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
+        L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
+        L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, st));
+        L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
+        L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, st));
+        // dZ1 of this pass, and its running sum over the passes: everything of layer 1 except the
+        // offset encoding sees the same operand in every pass
+        L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
+        L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        if (npass == 1) {
+            S = dz1;
+        } else if (k == npass - 1) {
+            CHECK_HIP(hipMemcpyAsync(S, dz1, (size_t)P * LIDF_H1 * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            // S += dZ1 through the linear kernel's accumulate epilogue would need an identity
+            // product; a plain wide add is the wgrad-free way: reuse the fill/out kernels? -> axpy
+            CHECK_HIP(lidf_launch_axpy(dz1, (long long)P * LIDF_H1, S, st));
+        }
+        L.mask_src = nullptr;
+        if (dec->is_ief) {
+            CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, P, enc, st));
+            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, P, grads->w1 + D, ld1, nullptr, st));
+            L.w = dec->w1 + D; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
+            L.out = denc; L.ld_out = 16;
+            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, P, grads->wenc, 1, grads->benc, st));
+            L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
+            L.out = goff; L.ld_out = 1; L.accumulate = 1;
+            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+            L.accumulate = 0;
+        }
+    }
+    // layer 1, the pass-independent operands: S = sum over passes of dZ1
+    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, st));
+    CHECK_HIP(hipMemsetAsync(dvox, 0, (size_t)V * LIDF_H1 * 4, st));
+    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, dvox, st));
+    CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
+    // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
+    CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, st));
+    // ray part: raypart[r] = W1[:, 128:256] roi[r] + W1[:, 256+E2:] embed(dir)[r]
+    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat, 128 + Ed, 128, R, grads->w1 + 128, ld1, nullptr, st));
+    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat + 128, 128 + Ed, Ed, R, grads->w1 + 256 + E2, ld1, nullptr, st));
+    LinEx L = {};
+    L.transposed = 1; L.ldw = ld1; L.k = LIDF_H1; L.ldx = LIDF_H1; L.accumulate = accumulate_inputs ? 1 : 0;
+    if (d_vox_feat) {
+        L.w = dec->w1; L.nout = 128; L.X = dvox; L.n = V; L.out = d_vox_feat; L.ld_out = 128;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
+    if (d_rayfeat) {
+        L.w = dec->w1 + 128; L.nout = 128; L.X = dray; L.n = R; L.out = d_rayfeat; L.ld_out = 128 + Ed;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.w = dec->w1 + 256 + E2; L.nout = Ed; L.out = d_rayfeat + 128;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
     return LIDF_OK;
 }

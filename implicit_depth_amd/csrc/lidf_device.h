@@ -163,4 +163,7 @@ struct LinearArgs {
     float mask_slope;
     int nout;              // > 0: only columns < nout are stored
     int accumulate;        // out += value instead of out = value
+    const float* addrows2; // optional second gathered term: += addrows2[addidx2[row]]
+    const int* addidx2;
+    int ld_add2;
 };

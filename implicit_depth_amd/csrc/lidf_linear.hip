@@ -87,6 +87,8 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
         // ---- epilogue: this lane holds, per tile t and group g, features 32t + 8g + 4h + {0..3}
         const float* ar =
             (valid && a.addrows) ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
+        const float* ar2 =
+            (valid && a.addrows2) ? a.addrows2 + (size_t)a.addidx2[p] * a.ld_add2 + 4 * h : nullptr;
         float* op = (valid && a.out) ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
         const float* mp = (valid && a.mask_src) ? a.mask_src + (size_t)p * a.ld_mask + 4 * h : nullptr;
 #pragma unroll
@@ -98,6 +100,11 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * g + i];
                 if (ar) {
                     const f32x4 r = *(const f32x4*)(ar + t * 32 + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += r[i];
+                }
+                if (ar2) {
+                    const f32x4 r = *(const f32x4*)(ar2 + t * 32 + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += r[i];
                 }

@@ -352,3 +352,119 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
                        dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Factorised training path of the query (the layer-1 rewrite of the inference kernel, DESIGN §2,
+// carried through the backward): layer 1 = W1[:, enter|leave] PE(p) + voxpart[voxel] + raypart[ray]
+// (+ u*off), so only the positional encodings are per-pair rows.
+// ------------------------------------------------------------------------------------------------
+// pe[p] = [ embed(enter) | embed(leave) ]  (2*(3+6L) columns)
+__global__ void __launch_bounds__(256) lidf_pe_rows_kernel(
+    const int* __restrict__ pair_ray, const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
+    const float* __restrict__ ray_dir, const float* __restrict__ vox_center, int pos_rel, int L,
+    long long P, float* __restrict__ pe) {
+    const int E = 3 + 6 * L, W = 2 * E;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * W) return;
+    const long long p = i / W;
+    const int j = (int)(i % W), k = j % E;
+    const int r = pair_ray[p];
+    const float t = pair_t[2 * p + (j >= E ? 1 : 0)];
+    const int c = k < 3 ? k : (k - 3) % 3;
+    float x = __fmul_rn(ray_dir[3 * (size_t)r + c], t);
+    if (pos_rel) x -= vox_center[3 * (size_t)pair_vox[p] + c];
+    float val = x;
+    if (k >= 3) {
+        const float a = x * (float)(1 << ((k - 3) / 6));
+        val = ((k - 3) % 6) < 3 ? sinf(a) : cosf(a);
+    }
+    pe[i] = val;
+}
+
+// out[r, :] = sum over the ray's contiguous pairs of S[p, :]   (one wavefront per ray, no atomics)
+__global__ void __launch_bounds__(256) lidf_seg_sum_ray_kernel(const float* __restrict__ S, int F,
+                                                               const int* __restrict__ pair_off,
+                                                               long long R, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int beg = pair_off[r], end = pair_off[r + 1];
+    for (int j = lane * 4; j < F; j += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int p = beg; p < end; ++p) {
+            const f32x4 v = *(const f32x4*)(S + (size_t)p * F + j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += v[i];
+        }
+        *(f32x4*)(out + (size_t)r * F + j) = acc;
+    }
+}
+
+// out[idx[p], :] += S[p, :]: a wavefront takes 64 consecutive pairs; each lane owns 4 of the F = 256
+// columns and walks the pairs, flushing its running sum with atomics whenever the index changes
+// (ray-major pairs change voxel every few pairs, so few flushes; summation order not fixed).
+__global__ void __launch_bounds__(256) lidf_seg_sum_idx_kernel(const float* __restrict__ S,
+                                                               const int* __restrict__ idx,
+                                                               long long P, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (p0 >= P) return;
+    const long long p1 = p0 + 64 < P ? p0 + 64 : P;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int cur = idx[p0];
+    for (long long p = p0; p < p1; ++p) {
+        const int v = idx[p];
+        if (v != cur) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(out + (size_t)cur * 256 + 4 * lane + i, acc[i]);
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            cur = v;
+        }
+        const f32x4 s = *(const f32x4*)(S + (size_t)p * 256 + 4 * lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(out + (size_t)cur * 256 + 4 * lane + i, acc[i]);
+}
+
+extern "C" hipError_t lidf_launch_pe_rows(const int* pair_ray, const int* pair_vox,
+                                          const float* pair_t, const float* ray_dir,
+                                          const float* vox_center, int pos_rel, int L, long long P,
+                                          float* pe, hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    const long long total = P * 2 * (3 + 6 * L);
+    hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, pe);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_seg_sum_ray(const float* S, int F, const int* pair_off,
+                                              long long R, float* out, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_seg_sum_ray_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, S, F,
+                       pair_off, R, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, long long P,
+                                              float* out, hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_seg_sum_idx_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                       S, idx, P, out);
+    return hipGetLastError();
+}
+
+// y += x
+__global__ void lidf_axpy_kernel(const float* __restrict__ x, long long n4, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = ((const f32x4*)x)[i], b = ((f32x4*)y)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] += a[k];
+    ((f32x4*)y)[i] = b;
+}
+extern "C" hipError_t lidf_launch_axpy(const float* x, long long n, float* y, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x,
+                       n / 4, y);
+    return hipGetLastError();
+}

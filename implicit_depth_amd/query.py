@@ -416,15 +416,91 @@ class _BuildRowsFn(torch.autograd.Function):
         return (d_vox, d_ray) + (None,) * 9
 
 
+class _QueryDecoderFn(torch.autograd.Function):
+    """One decoder of the query in the factorised form (lidf_query_decoder_forward_train_f32 /
+    lidf_query_decoder_backward_f32): inputs vox_feat [V,128] and rayfeat [R,128+Ed], no [P,385]
+    rows; gradients for both and for every parameter."""
+
+    @staticmethod
+    def forward(ctx, mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires,
+                multires_views, *params):
+        from . import decoders as _dec
+        vf, rf = vox_feat.detach().contiguous(), rayfeat.detach().contiguous()
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        keep = []
+        dec = _dec._decoder_struct(mod, keep)
+        a = _lib.LidfQueryTrainArgs()
+        a.n_pairs, a.n_rays, a.n_vox = P, R, V
+        a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+        a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+        a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dec)
+        L = _lib.lib()
+        n_pass = int(mod.n_iter) if isinstance(mod, _dec.IEF) else 1
+        f32 = dict(dtype=torch.float32, device=vf.device)
+        act = torch.empty((max(L.lidf_query_decoder_act_floats(P, R, V, n_pass), 1),), **f32)
+        wsb = L.lidf_query_decoder_workspace_bytes(P, R, V)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=vf.device)
+        out = torch.empty((P, 1), **f32)
+        with torch.cuda.device(vf.device):
+            _lib.check(L.lidf_query_decoder_forward_train_f32(
+                C.byref(a), _lib.ptr(out), _lib.ptr(act), _lib.ptr(ws), wsb,
+                _lib.current_stream(vf.device)))
+        ctx.mod, ctx.t = mod, (vf, rf, pe, pair_off, pair_ray, pair_vox, act, ws)
+        ctx.cfg = (multires, multires_views, wsb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from . import decoders as _dec
+        mod = ctx.mod
+        vf, rf, pe, pair_off, pair_ray, pair_vox, act, ws = ctx.t
+        multires, multires_views, wsb = ctx.cfg
+        keep = []
+        dec = _dec._decoder_struct(mod, keep)
+        a = _lib.LidfQueryTrainArgs()
+        a.n_pairs, a.n_rays, a.n_vox = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+        a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+        a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dec)
+        f32 = dict(dtype=torch.float32, device=vf.device)
+        g = g_out.detach().reshape(-1).contiguous().float()
+        sd = dict(mod.named_parameters())
+        names = [k for k in _dec._PARAM_ORDER if k in sd]
+        gt = {k: torch.empty_like(sd[k], **f32).contiguous() for k in names}
+        gs = _lib.LidfDecoderGrads()
+        for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
+            setattr(gs, field, gt[k].data_ptr() if k in gt else None)
+        d_vox = torch.empty_like(vf) if ctx.needs_input_grad[1] else None
+        d_ray = torch.empty_like(rf) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(vf.device):
+            _lib.check(_lib.lib().lidf_query_decoder_backward_f32(
+                C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 0,
+                C.byref(gs), _lib.ptr(ws), wsb, _lib.current_stream(vf.device)))
+        return (None, d_vox, d_ray) + (None,) * 6 + tuple(gt[k] for k in names)
+
+
+def _query_decoder(mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires, multires_views):
+    from . import decoders as _dec
+    _dec._check_supported(mod)
+    sd = dict(mod.named_parameters())
+    return _QueryDecoderFn.apply(mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires,
+                                 multires_views, *[sd[k] for k in _dec._PARAM_ORDER if k in sd])
+
+
 def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                      vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
-                     offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False):
+                     offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
+                     factorised=True):
     """Differentiable get_embedding + get_pred (models/pipeline.py:338-466) for training
     (train_lidf.py:393-396): gradients reach feat_grid (through RoIAlign), vox_feat and every
     decoder parameter, all through liblidf_hip — ROI pooling, the decoder input rows, the decoders'
     forward that keeps activations and their backward. The cheap per-pair / per-ray tail
     (pair_pred_pos, softmax over a ray, arg-max, select) is written in torch ops on [P] vectors.
     Same arguments as lidf_query; the decoders must be in autograd mode (parameters requiring grad).
+    factorised=True (default) keeps the layer-1 rewrite of the inference kernel — per-voxel and
+    per-ray partial products, only the positional encodings as per-pair rows, the layer-1 gradient
+    reduced per voxel / per ray before it meets a weight; factorised=False materialises the
+    reference's [P,385] decoder input rows (same results, more memory and work).
     Returns pred_offset, pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
     max_pair_id [R] (P for an empty ray) and pred_pos [R,3]."""
     import math
@@ -433,10 +509,22 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
                                        "pair_vox", "pair_t", "feat_grid", "vox_feat"])
     R, P = ray_dir.shape[0], pair_ray.shape[0]
     rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
-    rows = _BuildRowsFn.apply(vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
-                              vox_center, pos_rel, multires, multires_views)
-    pred_prob = prob_dec(rows)
-    pred_offset = offset_dec(rows)
+    if factorised:
+        pe = torch.empty((P, 2 * (3 + 6 * multires)), dtype=torch.float32, device=ray_dir.device)
+        with torch.cuda.device(ray_dir.device):
+            _lib.check(_lib.lib().lidf_pe_rows_f32(
+                _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
+                multires, P, _lib.ptr(pe), _lib.current_stream(ray_dir.device)))
+        pred_prob = _query_decoder(prob_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox,
+                                   multires, multires_views)
+        pred_offset = _query_decoder(offset_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox,
+                                     multires, multires_views)
+    else:
+        rows = _BuildRowsFn.apply(vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
+                                  vox_center, pos_rel, multires, multires_views)
+        pred_prob = prob_dec(rows)
+        pred_offset = offset_dec(rows)
     pr = pair_ray.long()
     d = ray_dir[pr]
     # pipeline.py:437-439

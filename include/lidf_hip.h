@@ -340,6 +340,36 @@ int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_t* ray_pi
                                    int32_t height, int32_t width, int32_t roi_inp_bbox,
                                    int32_t multires_views, float* d_feat_grid, lidf_stream_t stream);
 
+/* ---- Query decoders, factorised training path ------------------------------------------------
+ * The layer-1 rewrite of the inference kernel carried through training: per decoder
+ *   layer 1 = W1[:, enter|leave] pe[p] + voxpart[pair_vox[p]] + raypart[pair_ray[p]] (+ u*off)
+ * with voxpart = W1[:, 0:128] vox_feat + b1 (+c) per voxel and raypart = W1[:, rgb|dir] rayfeat per
+ * ray, so only the positional encodings pe [P, 2(3+6L)] (lidf_pe_rows_f32) are per-pair rows and
+ * the backward reduces the layer-1 gradient to per-voxel and per-ray sums before any product
+ * with a weight: no [P, 385] row or row gradient exists. d_vox_feat [V,128] / d_rayfeat
+ * [R,128+(3+6Lv)] are overwritten, or added to when accumulate_inputs != 0 (second decoder).    */
+typedef struct LidfQueryTrainArgs {
+    int64_t n_pairs, n_rays, n_vox;
+    const int32_t *pair_off, *pair_ray, *pair_vox; /* ray-major CSR pairs, as LidfQueryArgs */
+    const float* pe;        /* [P, 2(3+6*multires)] */
+    int32_t multires, multires_views;
+    const float* vox_feat;  /* [V,128] */
+    const float* rayfeat;   /* [R,128+3+6*multires_views] (lidf_ray_features_f32) */
+    const LidfDecoder* dec;
+} LidfQueryTrainArgs;
+int lidf_pe_rows_f32(const int32_t* pair_ray, const int32_t* pair_vox, const float* pair_t,
+                     const float* ray_dir, const float* vox_center, int32_t pos_rel,
+                     int32_t multires, int64_t n_pairs, float* pe, lidf_stream_t stream);
+size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, int64_t n_vox, int32_t n_pass);
+size_t lidf_query_decoder_workspace_bytes(int64_t n_pairs, int64_t n_rays, int64_t n_vox);
+int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* args, float* out, float* act,
+                                         void* workspace, size_t workspace_bytes,
+                                         lidf_stream_t stream);
+int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float* act,
+                                    const float* g_out, float* d_vox_feat, float* d_rayfeat,
+                                    int32_t accumulate_inputs, const LidfDecoderGrads* grads,
+                                    void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,9 @@ def _loss(out, w):
             + (out["pred_pos"] * w["pos"]).sum())
 
 
+@pytest.mark.parametrize("factorised", [True, False])
 @pytest.mark.parametrize("ragged,pos_rel", [(False, False), (True, True)])
-def test_query_gradients(cuda, ragged, pos_rel):
+def test_query_gradients(cuda, ragged, pos_rel, factorised):
     from implicit_depth_amd.query import lidf_query, lidf_query_train
     scene = orc.synthetic_scene(2, 12, 16, 8, seed=71, ragged=ragged)
     R, P, D = scene["R"], scene["P"], scene["D"]
@@ -38,7 +39,8 @@ def test_query_gradients(cuda, ragged, pos_rel):
     fgd = s["feat_grid"].clone().requires_grad_(True)
     vfd = s["vox_feat"].clone().requires_grad_(True)
     args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
-    out = lidf_query_train(*args, fgd, vfd, prob, off, vox_center=s["vox_center"], pos_rel=pos_rel, **kw)
+    out = lidf_query_train(*args, fgd, vfd, prob, off, vox_center=s["vox_center"], pos_rel=pos_rel,
+                           factorised=factorised, **kw)
     _loss(out, {k: v.to(cuda) for k, v in w.items()}).backward()
     # forward values: the oracle, and the inference kernel
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
