@@ -119,7 +119,7 @@ SIGNATURES = {
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),
-    "lidf_ray_features_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+    "lidf_ray_features_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "lidf_pe_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_query_decoder_act_floats": (C.c_size_t, [_I64, _I64, _I64, _I]),
     "lidf_query_decoder_workspace_bytes": (C.c_size_t, [_I64, _I64, _I64]),

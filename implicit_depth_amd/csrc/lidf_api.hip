@@ -42,11 +42,11 @@ hipError_t lidf_launch_build_rows(const int*, const int*, const float*, const fl
 hipError_t lidf_launch_rows_backward(const float*, int, int, const int*, const int*, long long,
                                      long long, int, float*, float*, int, hipStream_t);
 hipError_t lidf_launch_rayfeat_backward(const float*, int, const int*, const int*, long long, int, int,
-                                        int, float*, hipStream_t);
+                                        int, int, float*, float*, hipStream_t);
 hipError_t lidf_launch_pe_rows(const int*, const int*, const float*, const float*, const float*, int, int,
                                long long, float*, hipStream_t);
 hipError_t lidf_launch_seg_sum_ray(const float*, int, const int*, long long, float*, hipStream_t);
-hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, float*, hipStream_t);
+hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, long long, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -1041,14 +1041,19 @@ LIDF_API int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_
                                               const int32_t* ray_bid, int64_t n_rays, int32_t batch,
                                               int32_t height, int32_t width, int32_t roi_inp_bbox,
                                               int32_t multires_views, float* d_feat_grid,
+                                              void* workspace, size_t workspace_bytes,
                                               lidf_stream_t stream) {
     if (n_rays < 0 || batch <= 0 || height <= 0 || width <= 0 || !d_feat_grid) return LIDF_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     CHECK_HIP(hipMemsetAsync(d_feat_grid, 0, (size_t)batch * 32 * height * width * 4, st));
     if (n_rays == 0) return LIDF_OK;
     if (!d_rayfeat || !ray_pix || !ray_bid) return LIDF_ERR_BAD_ARG;
+    // with room for a [B,128,h,w] scratch image the unclamped boxes take the atomic-free gather path
+    const size_t need = (size_t)batch * 128 * height * width * 4;
+    float* gimg = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
     CHECK_HIP(lidf_launch_rayfeat_backward(d_rayfeat, 128 + 3 + 6 * multires_views, ray_pix, ray_bid,
-                                           n_rays, roi_inp_bbox / 2, height, width, d_feat_grid, st));
+                                           n_rays, roi_inp_bbox / 2, batch, height, width, d_feat_grid,
+                                           gimg, st));
     return LIDF_OK;
 }
 
@@ -1277,7 +1282,7 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
     CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, st));
     CHECK_HIP(hipMemsetAsync(dvox, 0, (size_t)V * LIDF_H1 * 4, st));
-    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, dvox, st));
+    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, st));
     CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
     // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
     CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, st));

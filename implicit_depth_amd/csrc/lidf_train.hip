@@ -278,18 +278,26 @@ __global__ void __launch_bounds__(256) lidf_rows_vox_backward_kernel(
 
 // RoIAlign backward (torchvision roi_align, output 2x2, aligned): every sample of bin (ph, pw)
 // passes g / count to its four bilinear taps. One thread per (ray, channel, bin).
+// `gimg` != NULL: rays whose box is not clamped are left to the gather pair below.
 __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
-    const int* __restrict__ ray_bid, long long R, int half, int H, int W, float* __restrict__ d_feat) {
+    const int* __restrict__ ray_bid, long long R, int half, int H, int W, float* __restrict__ d_feat,
+    float* __restrict__ gimg) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * 128) return;
     const long long r = i >> 7;
     const int cb = (int)(i & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
     const float g = d_rayfeat[(size_t)r * ld_rf + cb];
-    if (g == 0.f) return;
     const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
     const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
     const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+    if (gimg && half > 0 && u2 - u1 == 2 * half && v2 - v1 == 2 * half) {
+        // unclamped box: every sample sits on a pixel centre, bin (ph, pw) spreads g / half^2 over a
+        // half x half pixel block; parked at the ray's pixel, gathered by lidf_rayfeat_gather_kernel
+        gimg[(((size_t)ray_bid[r] * 128 + cb) * H + qy) * W + qx] = g;
+        return;
+    }
+    if (g == 0.f) return;
     const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
     const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
     const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
@@ -343,13 +351,53 @@ extern "C" hipError_t lidf_launch_rows_backward(const float* d_rows, int D, int 
     return hipGetLastError();
 }
 
+// d_feat[b,c,y,x] += 1/half^2 * sum over the 4 bins of the parked gradients of the rays whose bin
+// covers the pixel: bin ph = 0 is covered by rays at rows y+1 .. y+half, ph = 1 by rows
+// y-half+1 .. y (columns alike) — the adjoint of the forward's box-sum shortcut, no atomics.
+__global__ void __launch_bounds__(256) lidf_rayfeat_gather_kernel(const float* __restrict__ gimg,
+                                                                  int B, int H, int W, int half,
+                                                                  float* __restrict__ d_feat) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * 32 * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long bc = i / ((long long)W * H);
+    const long long b = bc / 32;
+    const int c = (int)(bc % 32);
+    float acc = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const int ya = ph ? y - half + 1 : y + 1, yb = ph ? y : y + half;
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+            const int xa = pw ? x - half + 1 : x + 1, xb = pw ? x : x + half;
+            const float* g = gimg + ((size_t)(b * 128 + c * 4 + ph * 2 + pw) * H) * W;
+            for (int yy = max(ya, 0); yy <= min(yb, H - 1); ++yy)
+                for (int xx = max(xa, 0); xx <= min(xb, W - 1); ++xx) acc += g[(size_t)yy * W + xx];
+        }
+    }
+    d_feat[i] += acc / (float)(half * half);
+}
+
+// gimg: optional scratch [B,128,H,W]; with it the unclamped boxes take the gather path
 extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int ld_rf,
                                                    const int* ray_pix, const int* ray_bid,
-                                                   long long R, int half, int H, int W,
-                                                   float* d_feat, hipStream_t st) {
+                                                   long long R, int half, int B, int H, int W,
+                                                   float* d_feat, float* gimg, hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    if (half <= 0) gimg = nullptr;
+    if (gimg) {
+        hipError_t e = hipMemsetAsync(gimg, 0, (size_t)B * 128 * H * W * 4, st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(lidf_rayfeat_backward_kernel, dim3((unsigned)((R * 128 + 255) / 256)),
-                       dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat);
+                       dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat,
+                       gimg);
+    if (gimg) {
+        const long long total = (long long)B * 32 * H * W;
+        hipLaunchKernelGGL(lidf_rayfeat_gather_kernel, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, st, gimg, B, H, W, half, d_feat);
+    }
     return hipGetLastError();
 }
 
@@ -445,11 +493,54 @@ extern "C" hipError_t lidf_launch_seg_sum_ray(const float* S, int F, const int* 
                        pair_off, R, out);
     return hipGetLastError();
 }
-extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, long long P,
+// The same reduction with the table privatised in LDS: a workgroup owns a slice of CW columns of
+// ALL rows of `out` (V x CW floats of LDS) and a block of pairs; LDS float atomics absorb the
+// scatter, one global atomic per table entry flushes it. Used when V x 4 columns fit in 64 KiB.
+template <int CW>
+__global__ void __launch_bounds__(256) lidf_seg_sum_idx_lds_kernel(const float* __restrict__ S,
+                                                                   const int* __restrict__ idx,
+                                                                   long long P, int V,
+                                                                   long long rows_per_wg,
+                                                                   float* __restrict__ out) {
+    extern __shared__ float tab[];  // [V][CW]
+    const int slice = blockIdx.x % (256 / CW);
+    const long long p0 = (long long)(blockIdx.x / (256 / CW)) * rows_per_wg;
+    const long long p1 = p0 + rows_per_wg < P ? p0 + rows_per_wg : P;
+    for (int i = threadIdx.x; i < V * CW; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    // thread -> (row within a group of 256/CW rows, column of the slice): CW consecutive lanes read
+    // one contiguous CW-float piece of a row
+    const int c = threadIdx.x % CW, rr = threadIdx.x / CW;
+    for (long long p = p0 + rr; p < p1; p += 256 / CW)
+        atomicAdd(tab + idx[p] * CW + c, S[(size_t)p * 256 + slice * CW + c]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * CW; i += 256) {
+        const float v = tab[i];
+        if (v != 0.f) atomicAdd(out + (size_t)(i / CW) * 256 + slice * CW + i % CW, v);
+    }
+}
+
+extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, long long P, long long V,
                                               float* out, hipStream_t st) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_seg_sum_idx_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
-                       S, idx, P, out);
+    int cw = 0;
+    for (int w = 32; w >= 4; w >>= 1)
+        if ((long long)V * w * 4 <= 65536) { cw = w; break; }
+    if (cw == 0) {
+        hipLaunchKernelGGL(lidf_seg_sum_idx_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                           st, S, idx, P, out);
+        return hipGetLastError();
+    }
+    const long long rows_per_wg = 8192;
+    const long long blocks = ((P + rows_per_wg - 1) / rows_per_wg) * (256 / cw);
+    const size_t lds = (size_t)V * cw * 4;
+    dim3 g((unsigned)blocks), b(256);
+    switch (cw) {
+        case 32: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<32>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
+        case 16: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<16>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
+        case 8: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<8>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
+        default: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<4>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
+    }
     return hipGetLastError();
 }
 

@@ -373,10 +373,12 @@ class _RayFeaturesFn(torch.autograd.Function):
         B, _, h, w = ctx.shape
         g = g.detach().contiguous().float()
         d_feat = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        wsb = B * 128 * h * w * 4    # scratch image for the atomic-free path of the unclamped boxes
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().lidf_ray_features_backward_f32(
                 _lib.ptr(g), _lib.ptr(ray_pix), _lib.ptr(ray_bid), g.shape[0], B, h, w, ctx.bbox,
-                ctx.lv, _lib.ptr(d_feat), _lib.current_stream(g.device)))
+                ctx.lv, _lib.ptr(d_feat), _lib.ptr(ws), wsb, _lib.current_stream(g.device)))
         return d_feat, None, None, None, None, None
 
 

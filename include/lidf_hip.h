@@ -326,7 +326,9 @@ int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld
  * (rayfeat = lidf_ray_features_f32) and go through the decoders' training path; the gradient of the
  * rows is reduced to d vox_feat [V,128] (float atomics) and d rayfeat [R, 128+(3+6Lv)] (per-ray
  * sums over the contiguous pairs, pair_off = CSR), and the ROI columns of d rayfeat pass through
- * RoIAlign backward to d feat_grid [B,32,h,w] (float atomics). Outputs are overwritten.           */
+ * RoIAlign backward to d feat_grid [B,32,h,w]: rays whose box is clamped at the image border use
+ * float atomics; with an optional workspace of batch*128*height*width floats the others are parked in
+ * a [B,128,h,w] image and gathered per pixel (no atomics). Outputs are overwritten.              */
 int lidf_build_rows_f32(const int32_t* pair_ray, const int32_t* pair_vox, const float* pair_t,
                         const float* ray_dir, const float* vox_center, int32_t pos_rel,
                         const float* vox_feat, const float* rayfeat, int32_t multires,
@@ -338,7 +340,8 @@ int lidf_rows_backward_f32(const float* d_rows, const int32_t* pair_off, const i
 int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_t* ray_pix,
                                    const int32_t* ray_bid, int64_t n_rays, int32_t batch,
                                    int32_t height, int32_t width, int32_t roi_inp_bbox,
-                                   int32_t multires_views, float* d_feat_grid, lidf_stream_t stream);
+                                   int32_t multires_views, float* d_feat_grid, void* workspace,
+                                   size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Query decoders, factorised training path ------------------------------------------------
  * The layer-1 rewrite of the inference kernel carried through training: per decoder
