@@ -77,3 +77,26 @@ def test_ray_features_backward_border(cuda):
         got = _RayFeaturesFn.apply(fgd, s["ray_dir"], s["ray_pix"], s["ray_bid"], bbox, 4)
         (got[:, :128] * wgt.to(cuda)).sum().backward()
         assert (fgd.grad.cpu() - fg.grad).abs().max().item() <= 1e-5 * max(1.0, fg.grad.abs().max().item()), bbox
+
+
+@pytest.mark.parametrize("factorised", [True, False])
+def test_query_train_no_pairs(cuda, factorised):
+    """No ray meets a voxel: empty outputs, zero gradients everywhere, nothing launched on P = 0."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(1, 8, 8, 4, seed=75)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", scene["off_p"], D, cuda).train()
+    R = scene["R"]
+    zero_off = torch.zeros(R + 1, dtype=torch.int32, device=cuda)
+    e_i = torch.zeros(0, dtype=torch.int32, device=cuda)
+    fg = s["feat_grid"].clone().requires_grad_(True)
+    vf = s["vox_feat"].clone().requires_grad_(True)
+    out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], zero_off, e_i, e_i,
+                           torch.zeros(0, 2, device=cuda), fg, vf, prob, off, factorised=factorised)
+    assert out["pred_prob_end"].shape == (0, 1) and out["pred_pos"].shape == (R, 3)
+    assert (out["max_pair_id"] == 0).all() and (out["pred_pos"] == 0).all()
+    (out["pred_pos"].sum() + out["pred_offset"].sum() + out["pred_prob_end"].sum()).backward()
+    assert (fg.grad == 0).all() and (vf.grad == 0).all()
+    assert all(p.grad is not None and (p.grad == 0).all() for p in list(prob.parameters()) + list(off.parameters()))
