@@ -259,7 +259,8 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats
     w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
     w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
     w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
-    w.box = o;        o += align_up((size_t)grid_floats * 4, 256);  // optional box-sum image (last)
+    // optional box-sum image + the list of clamped-box rays (last)
+    w.box = o;        o += grid_floats > 0 ? align_up((size_t)(grid_floats + R + 1) * 4, 256) : 0;
     w.total = o;
     return w;
 }

@@ -123,7 +123,8 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
                                     const float* __restrict__ ray_dir,
                                     const int* __restrict__ ray_pix,
                                     const int* __restrict__ ray_bid, long long R, int half,
-                                    int Lv, float* __restrict__ out, int ld) {
+                                    int Lv, float* __restrict__ out, int ld,
+                                    int* __restrict__ border) {
     __shared__ float tile[64 * 129];
     __shared__ int s_list[64];
     __shared__ int s_nb;
@@ -155,7 +156,19 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
         }
     }
     __syncthreads();
-    const int nb = s_nb;
+    int nb = s_nb;
+    if (border) {
+        // the clamped boxes of the whole launch are collected (border[0] = count, then the ray ids)
+        // and evaluated by lidf_rayfeat_border_kernel over all of them at once: here they would put
+        // a serial tail of up to 64 samples x 4 taps per item behind every workgroup's fast path
+        if (cg == 0) {
+            int base = 0;
+            if (lx == 0 && nb > 0) base = atomicAdd(border, nb);
+            base = __shfl(base, 0);
+            if (lx < nb) border[1 + base + lx] = (int)(r0 + s_list[lx]);
+        }
+        nb = 0;
+    }
     for (int item = tid; item < nb * 128; item += 256) {
         const int row = s_list[item >> 7], cb = item & 127;
         const int c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
@@ -199,8 +212,18 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
         tile[row * 129 + cb] = acc / count;
     }
     __syncthreads();
-    for (int e = tid; e < nrow * 128; e += 256)
-        out[(size_t)(r0 + (e >> 7)) * ld + (e & 127)] = tile[(e >> 7) * 129 + (e & 127)];
+    if (border) {
+        // rows of clamped boxes are written by the border kernel
+        for (int e = tid; e < nrow * 128; e += 256) {
+            const int row = e >> 7;
+            bool slow = false;
+            for (int i = 0; i < s_nb; ++i) slow |= s_list[i] == row;
+            if (!slow) out[(size_t)(r0 + row) * ld + (e & 127)] = tile[row * 129 + (e & 127)];
+        }
+    } else {
+        for (int e = tid; e < nrow * 128; e += 256)
+            out[(size_t)(r0 + (e >> 7)) * ld + (e & 127)] = tile[(e >> 7) * 129 + (e & 127)];
+    }
     if (cg == 0 && live) {
         const float d[3] = {ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]};
         float* e = out + (size_t)r * ld + 128;
@@ -215,19 +238,60 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
     }
 }
 
-// `box` (scratch, B*32*H*W floats) may be NULL: every ray then takes the general path.
+// The collected clamped-box rays: one (ray, channel, bin) item per thread, grid-stride over all
+// of them (the count is read on the device: no host round trip).
+__global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
+    const float* __restrict__ feat, int H, int W, const int* __restrict__ ray_pix,
+    const int* __restrict__ ray_bid, int half, const int* __restrict__ border,
+    float* __restrict__ out, int ld) {
+    const long long nitem = (long long)border[0] * 128;
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < nitem;
+         item += (long long)gridDim.x * 256) {
+        const long long rr = border[1 + (item >> 7)];
+        const int cb = (int)(item & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
+        const int qx = ray_pix[2 * rr], qy = ray_pix[2 * rr + 1];
+        const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+        const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+        const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+        const float rew = (float)u2 - 0.5f, reh = (float)v2 - 0.5f;
+        const float roi_w = rew - rsw, roi_h = reh - rsh;
+        const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+        const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+        const float count = (float)max(gh * gw, 1);
+        const float* img = feat + ((size_t)ray_bid[rr] * 32 + c) * H * W;
+        float acc = 0.f;  // the reference's (iy, ix) order
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                acc += bilinear(img, H, W, y, x);
+            }
+        }
+        out[(size_t)rr * ld + cb] = acc / count;
+    }
+}
+
+// `box` (scratch, B*32*H*W floats, followed by R+1 ints for the clamped-box list) may be NULL:
+// every ray then takes the general path inside the main kernel.
 extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, int H, int W,
                                           const float* ray_dir, const int* ray_pix,
                                           const int* ray_bid, long long R, int half, int Lv,
                                           float* out, int ld, hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    int* border = nullptr;
     if (box && half > 0) {
         const long long total = (long long)B * 32 * H * W;
         hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                            st, feat, B * 32, H, W, half, box);
+        border = (int*)(box + total);
+        hipError_t e = hipMemsetAsync(border, 0, 4, st);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4), 0, st,
-                       feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld);
+                       feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld, border);
+    if (border)
+        hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(1024), dim3(256), 0, st, feat, H, W,
+                           ray_pix, ray_bid, half, border, out, ld);
     return hipGetLastError();
 }
 
