@@ -745,12 +745,15 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
 
 extern "C" hipError_t lidf_launch_points_h(const PointsArgs& a, int cus, hipStream_t st) {
     if (a.n <= 0) return hipSuccess;
-    static bool configured = false;
-    if (!configured) {
+    // > 64 KiB of dynamic LDS needs the opt-in once per device (one process may drive several)
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)lidf_points_h_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[dev] = true;
 #ifdef LIDF_PROFILE
         for (int lds = 32768; lds <= LDS_BYTES + 8192; lds += 4096) {
             int nb = -1;
