@@ -1,0 +1,1 @@
+"""HIP sources of liblidf_hip.so and their build script (build.py)."""
