@@ -113,12 +113,15 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], a.slope * v[i]);
                 }
                 const int c0 = t * 32 + 8 * g + 4 * h;  // first of this lane's four columns
-                if (mp && (a.nout <= 0 || c0 < a.nout)) {
+                if (mp && (a.nout <= 0 || c0 + 3 < a.nout)) {
                     // dgrad through a leaky ReLU: the activation's output has the sign of its input
+                    const f32x4 m = *(const f32x4*)(mp + t * 32 + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= m[i] > 0.f ? 1.f : a.mask_slope;
+                } else if (mp && c0 < a.nout) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (a.nout <= 0 || c0 + i < a.nout)
-                            v[i] *= mp[t * 32 + 8 * g + i] > 0.f ? 1.f : a.mask_slope;
+                        if (c0 + i < a.nout) v[i] *= mp[t * 32 + 8 * g + i] > 0.f ? 1.f : a.mask_slope;
                 }
                 if (op) {
                     if (a.nout <= 0 || c0 + 3 < a.nout) {
