@@ -54,3 +54,25 @@ def test_unsupported_and_bad_precision(cuda):
             lidf_query(*args, multires=10, precision="f16x3")
         with pytest.raises(ValueError):
             lidf_query(*args, multires=10, precision="bf16")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_fewer_octaves(cuda, precision):
+    """multires = 4, multires_views = 2 (D = 256 + 2*27 + 15): the split-f16 kernel is built for 8
+    octaves and must ignore the unused ones."""
+    from implicit_depth_amd.query import lidf_query
+    scene = orc.synthetic_scene(1, 12, 16, 8, seed=45, multires=4, multires_views=2)
+    D = scene["D"]
+    assert D == 256 + 54 + 15
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"],
+                    scene["vox_feat"], scene["prob_p"], scene["off_p"], multires=4, multires_views=2)
+    s = to_dev(scene, cuda)
+    with torch.no_grad():
+        got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                         s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"],
+                         make_module("IMNET", scene["prob_p"], D, cuda),
+                         make_module("IEF", scene["off_p"], D, cuda),
+                         multires=4, multires_views=2, precision=precision)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
