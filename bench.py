@@ -141,8 +141,9 @@ def secondary(args):
 
         def step():
             with torch.no_grad():
-                return decoders_forward(x, prob, off)
-        flop_alg, bytes_alg, name = F_ALG, 1548.0, "lidf_points_kernel<ROWS>"
+                return decoders_forward(x, prob, off, precision=args.precision)
+        flop_alg, bytes_alg, name = F_ALG, 1548.0, ("lidf_rows_h_kernel" if args.precision == "f16x3"
+                                                   else "lidf_points_kernel<ROWS>")
         what = "prob_dec (IMNet) + offset_dec (IEF n_iter=2) on a materialised [P,385] f32 input"
     elif args.workload == "train-query":
         # one training step of the whole query: forward + backward to feat_grid, vox_feat and the
@@ -212,13 +213,19 @@ def secondary(args):
     elapsed = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps  # one dominant kernel per step on torch's stream
     hbm = args.workload == "embed"
+    split_rows = args.workload == "decoders" and args.precision == "f16x3"
+    if split_rows:
+        # executed: 2 nets x 25 layer-1 k-steps x 24 + 3 passes x 254 v_mfma_f32_32x32x16_f16 per 32 rows
+        flop_alg = (2 * 25 * 24 + 3 * 254) * 32768 / 32.0
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_alg * P / (kern_ms * 1e-3) / 1e12)
-    peak = 8000.0 if hbm else PEAK_F32_TFLOPS
+    peak = 8000.0 if hbm else (PEAK_F16_TFLOPS if split_rows else PEAK_F32_TFLOPS)
     print(json.dumps({
         "metric": "Mpoints/sec, %s" % args.workload, "value": round(P * args.steps / elapsed / 1e6, 2),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_F16X3 if (args.workload == "decoders" and args.precision == "f16x3") else "f32",
+        "data": "synthetic",
         "config": {"workload": "secondary: %s, P = %d rows" % (what, P)},
         "roofline": {"bound": "hbm" if hbm else "mfma", "achieved": round(ach, 2), "peak": peak,
                      "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),

@@ -97,6 +97,8 @@ SIGNATURES = {
     "lidf_decoders_workspace_bytes": (_SZ, [_I64, _I]),
     "lidf_decoders_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder),
                                     C.POINTER(LidfDecoder), _P, _P, _P, _SZ, _P]),
+    "lidf_decoders_split_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder),
+                                    C.POINTER(LidfDecoder), _P, _P, _P, _SZ, _P]),
     "lidf_query_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
     "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P]),

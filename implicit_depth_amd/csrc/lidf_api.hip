@@ -10,6 +10,10 @@ hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
 hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
+StreamLayout lidf_make_layout_rows_h(int nets, int D);
+hipError_t lidf_launch_pack_rows_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
+                                   float*, hipStream_t);
+hipError_t lidf_launch_rows_h(const PointsArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_embed(const float*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_rayfeat(const float*, float*, int, int, int, const float*, const int*,
                                const int*, long long, int, int, float*, int, hipStream_t);
@@ -155,13 +159,34 @@ LIDF_API size_t lidf_decoders_workspace_bytes(int64_t n, int d) {
     if (d <= 0) return 0;
     L1Map m = rows_map(d, 0, 0, 0, 1);
     StreamLayout lay = lidf_make_layout(2, LIDF_MODE_ROWS, m);
-    return align_up((size_t)lay.total * 4, 256) + align_up(2 * LIDF_AUX_FLOATS * 4, 256);
+    const size_t hs = (size_t)lidf_make_layout_rows_h(2, d).total * 4;  // split-f16 stream
+    const size_t fs = (size_t)lay.total * 4;
+    return align_up(fs > hs ? fs : hs, 256) + align_up(2 * LIDF_AUX_FLOATS * 4, 256);
 }
+
+static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, const LidfDecoder* prob,
+                         const LidfDecoder* off, float* out_prob, float* out_off, void* workspace,
+                         size_t workspace_bytes, int precision, lidf_stream_t stream);
 
 LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
                                  const LidfDecoder* prob, const LidfDecoder* off, float* out_prob,
                                  float* out_off, void* workspace, size_t workspace_bytes,
                                  lidf_stream_t stream) {
+    return decoders_impl(inp, n, d, ld_inp, prob, off, out_prob, out_off, workspace, workspace_bytes,
+                         LIDF_PRECISION_F32, stream);
+}
+
+LIDF_API int lidf_decoders_split_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
+                                       const LidfDecoder* prob, const LidfDecoder* off,
+                                       float* out_prob, float* out_off, void* workspace,
+                                       size_t workspace_bytes, lidf_stream_t stream) {
+    return decoders_impl(inp, n, d, ld_inp, prob, off, out_prob, out_off, workspace, workspace_bytes,
+                         LIDF_PRECISION_F16X3, stream);
+}
+
+static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, const LidfDecoder* prob,
+                         const LidfDecoder* off, float* out_prob, float* out_off, void* workspace,
+                         size_t workspace_bytes, int precision, lidf_stream_t stream) {
     if (n < 0 || d <= 0 || ld_inp < d) return LIDF_ERR_BAD_ARG;
     if (d > (1 << 20)) return LIDF_ERR_UNSUPPORTED;
     if (!prob && !off) return LIDF_ERR_BAD_ARG;
@@ -178,12 +203,17 @@ LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_in
     const LidfDecoder* ds[2] = {prob ? prob : off, off};
     float* outs[2] = {prob ? out_prob : out_off, out_off};
     L1Map m = rows_map(d, 0, 0, 0, 1);
-    StreamLayout lay = lidf_make_layout(nets, LIDF_MODE_ROWS, m);
+    const bool split = precision == LIDF_PRECISION_F16X3;
+    StreamLayout lay = split ? lidf_make_layout_rows_h(nets, d) : lidf_make_layout(nets, LIDF_MODE_ROWS, m);
     float* stream_buf = (float*)workspace;
-    float* aux = (float*)((char*)workspace + align_up((size_t)lidf_make_layout(2, LIDF_MODE_ROWS, m).total * 4, 256));
+    float* aux = (float*)((char*)workspace + lidf_decoders_workspace_bytes(n, d) -
+                          align_up(2 * LIDF_AUX_FLOATS * 4, 256));
     NetW n0 = to_netw(ds[0], d);
     NetW n1 = nets == 2 ? to_netw(ds[1], d) : n0;
-    CHECK_HIP(lidf_launch_pack(lay, n0, n1, m, stream_buf, aux, st));
+    if (split)
+        CHECK_HIP(lidf_launch_pack_rows_h(lay, n0, n1, m, stream_buf, aux, st));
+    else
+        CHECK_HIP(lidf_launch_pack(lay, n0, n1, m, stream_buf, aux, st));
 
     PointsArgs a = {};
     a.stream = stream_buf;
@@ -200,7 +230,10 @@ LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_in
     if ((rc = cu_count(&cus))) return rc;
     long long ntile = (n + 127) / 128;
     int grid = (int)(ntile < cus ? ntile : cus);
-    CHECK_HIP(lidf_launch_points(LIDF_MODE_ROWS, a, grid, st));
+    if (split)
+        CHECK_HIP(lidf_launch_rows_h(a, grid, st));
+    else
+        CHECK_HIP(lidf_launch_points(LIDF_MODE_ROWS, a, grid, st));
     return LIDF_OK;
 }
 

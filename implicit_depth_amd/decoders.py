@@ -118,9 +118,12 @@ def _check_supported(mod):
                            % (mod.gf_dim, mod.linear_4.out_features))
 
 
-def decoders_forward(inp_feat, prob_dec=None, offset_dec=None):
+def decoders_forward(inp_feat, prob_dec=None, offset_dec=None, precision="f32"):
     """Run one or both decoders on a materialised [n, D] input through liblidf_hip
-    (lidf_decoders_f32). Returns (pred_prob or None, pred_offset or None), each [n,1]."""
+    (lidf_decoders_f32; precision="f16x3": lidf_decoders_split_f32, the split-f16 products of
+    lidf_query). Returns (pred_prob or None, pred_offset or None), each [n,1]."""
+    if precision not in ("f32", "f16x3"):
+        raise ValueError("precision must be 'f32' or 'f16x3'")
     if prob_dec is None and offset_dec is None:
         raise ValueError("need at least one decoder")
     if not inp_feat.is_cuda:
@@ -149,7 +152,8 @@ def decoders_forward(inp_feat, prob_dec=None, offset_dec=None):
     wsb = L.lidf_decoders_workspace_bytes(n, d)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(L.lidf_decoders_f32(
+        fn = L.lidf_decoders_split_f32 if precision == "f16x3" else L.lidf_decoders_f32
+        _lib.check(fn(
             _lib.ptr(x), n, d, ld,
             C.byref(dp) if dp is not None else None, C.byref(do) if do is not None else None,
             _lib.ptr(out_p), _lib.ptr(out_o), _lib.ptr(ws), wsb, _lib.current_stream(x.device)))

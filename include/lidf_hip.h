@@ -77,6 +77,12 @@ int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
                       const LidfDecoder* prob, const LidfDecoder* off,
                       float* out_prob, float* out_off,
                       void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+/* Same call with the matrix products of layers 1-3 evaluated as three f16-piece products per term,
+ * f32 accumulation (LIDF_PRECISION_F16X3 of LidfQueryArgs): |activations| < 65504 required. */
+int lidf_decoders_split_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
+                      const LidfDecoder* prob, const LidfDecoder* off,
+                      float* out_prob, float* out_off,
+                      void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Fused per-point query -------------------------------------------------------------
  * Replaces LIDF.get_embedding (positional encoding + ROIAlign gather + voxel feature gather,

@@ -76,3 +76,35 @@ def test_fewer_octaves(cuda, precision):
                          multires=4, multires_views=2, precision=precision)
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
         assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+
+
+@pytest.mark.parametrize("kind,d,n,sig", [("IMNET", 385, 1000, False), ("IEF", 385, 1000, False),
+                                          ("IEF", 334, 333, True), ("IMNET", 265, 5, False),
+                                          ("IEF", 17, 129, False)])
+def test_decoders_boundary_split(cuda, kind, d, n, sig):
+    """lidf_decoders_split_f32: the decoder boundary on materialised rows with split-f16 products,
+    against the oracle (same tolerance as the f32 kernel) and close to the f32 kernel."""
+    from implicit_depth_amd.decoders import decoders_forward
+    p = orc.randomize_biases(orc.init_decoder(kind, d, 81, 5.0), 82)
+    m = make_module(kind, p, d, cuda, use_sigmoid=sig)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d))
+    ref = orc.decoder_forward(p, x, kind, 2, sig)
+    kw = {"prob_dec": m} if kind == "IMNET" else {"offset_dec": m}
+    got = [o for o in decoders_forward(x.to(cuda), precision="f16x3", **kw) if o is not None][0]
+    f32 = [o for o in decoders_forward(x.to(cuda), precision="f32", **kw) if o is not None][0]
+    assert (got.cpu() - ref).abs().max().item() <= TOL
+    assert (got - f32).abs().max().item() <= 2e-5
+
+
+def test_decoders_boundary_split_pair_strided(cuda):
+    """Both decoders in one call on a strided view of a wider tensor."""
+    from implicit_depth_amd.decoders import decoders_forward
+    d = 385
+    pp = orc.randomize_biases(orc.init_decoder("IMNET", d, 83, 5.0), 84)
+    po = orc.randomize_biases(orc.init_decoder("IEF", d, 85, 5.0), 86)
+    mp, mo = make_module("IMNET", pp, d, cuda), make_module("IEF", po, d, cuda)
+    wide = torch.randn(700, d + 19, generator=torch.Generator().manual_seed(9)).to(cuda)
+    x = wide[:, 7:7 + d]
+    gp, go = decoders_forward(x, mp, mo, precision="f16x3")
+    assert (gp.cpu() - orc.imnet_forward(pp, x.cpu())).abs().max().item() <= TOL
+    assert (go.cpu() - orc.ief_forward(po, x.cpu(), 2)).abs().max().item() <= TOL
