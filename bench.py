@@ -98,7 +98,7 @@ def cpu_baseline(scene, budget_s=15.0):
                       "query() (torch CPU ops, vectorised ROIAlign), %.1f s" % (rows, h, P, t)}
 
 
-def refine_setup(scene, s, dev):
+def refine_setup(scene, s, dev, precision="f32"):
     """Synthetic stage-2 inputs for configs[3]: 10,000 valid points (valid_sample_num), a refine
     PointNet2Stage and IEF(D=334) with seeded weights, the occupied-voxel boxes of the 9^3 grid."""
     from implicit_depth_amd import IEF, PointNet2Stage
@@ -120,7 +120,8 @@ def refine_setup(scene, s, dev):
     def run(out):
         return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], out["pred_pos"],
                            out["max_pair_id"], s["pair_vox"], vb, vbid, rgb, s["feat_grid"], valid_inp,
-                           valid_vox, pnet, offr, forward_times=2, rayfeat=out["rayfeat"])[0]
+                           valid_vox, pnet, offr, forward_times=2, rayfeat=out["rayfeat"],
+                           precision=precision)[0]
     return run
 
 
@@ -287,7 +288,7 @@ def main():
     gathered = torch.empty((world * B, h, w), device=dev) if use_dist else None
     refine = None
     if args.workload == "query+refine":
-        refine = refine_setup(scene, s, dev)
+        refine = refine_setup(scene, s, dev, args.precision)
     ev = HipEvents()
     pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
     state = {"ws": None}

@@ -726,8 +726,10 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
         return rc;
     CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
-    if ((rc = lidf_decoders_f32(inp_embed, R, D, D, nullptr, q->off, nullptr, off, ws + w.dec,
-                                lidf_decoders_workspace_bytes(R, D), stream)))
+    if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
+        return LIDF_ERR_BAD_ARG;
+    if ((rc = decoders_impl(inp_embed, R, D, D, nullptr, q->off, nullptr, off, ws + w.dec,
+                            lidf_decoders_workspace_bytes(R, D), q->precision, stream)))
         return rc;
     CHECK_HIP(lidf_launch_refine_finish(q->pred_pos, off, q->ray_dir, q->offset_range0,
                                         q->offset_range1 - q->offset_range0, R, q->pred_pos_out,

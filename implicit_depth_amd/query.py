@@ -211,7 +211,8 @@ def ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox=8, multires_
 def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                 forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
-                offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None):
+                offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None,
+                precision="f32"):
     """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
     `forward_times` iterations of get_pred_refine through lidf_refine_f32.
 
@@ -268,6 +269,9 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         q.offset_range0, q.offset_range1 = float(offset_range[0]), float(offset_range[1])
         q.pred_pos_out, q.end_voxel_id = out.data_ptr(), end_voxel.data_ptr()
         q.workspace, q.workspace_bytes = ws.data_ptr(), wsb
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        q.precision = PRECISIONS[precision]
         with torch.cuda.device(dev):
             _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out

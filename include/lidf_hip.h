@@ -283,6 +283,7 @@ typedef struct LidfRefineArgs {
     int32_t* end_voxel_id;       /* [R] optional output */
     void* workspace;
     size_t workspace_bytes;
+    int32_t precision;           /* LIDF_PRECISION_F32 (0) / LIDF_PRECISION_F16X3: the refine IEF  */
 } LidfRefineArgs;
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);

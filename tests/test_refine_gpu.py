@@ -28,7 +28,8 @@ def test_pointnet_vs_oracle(cuda, n, v):
         assert (got[empty] - ref[empty]).abs().max().item() <= 2e-5
 
 
-def test_refine_golden_hip(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_refine_golden_hip(cuda, precision):
     from implicit_depth_amd.query import compute_ray_aabb, lidf_query, lidf_refine
     g3, g4 = load("g3_pipeline.npz"), load("g4_refine.npz")
     h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid = g3_inputs(g3)
@@ -49,7 +50,7 @@ def test_refine_golden_hip(cuda):
             pv, vb.to(dev), vbid.to(dev), torch.from_numpy(g4["rgb_img"]).to(dev), feat_grid,
             torch.from_numpy(g4["valid_inp"]).to(dev),
             torch.from_numpy(g4["valid_vox"]).int().to(dev), pnet, offr)
-    kw = dict(offset_range=tuple(float(v) for v in g4["offset_range"]))
+    kw = dict(offset_range=tuple(float(v) for v in g4["offset_range"]), precision=precision)
     with torch.no_grad():
         p1, ev1 = lidf_refine(*args, forward_times=1, **kw)
         p2, ev2 = lidf_refine(*args, forward_times=2, **kw)
@@ -59,7 +60,8 @@ def test_refine_golden_hip(cuda):
     assert (ev1.cpu().long() == outs[0][1]).all()  # end voxel ids: exact
 
 
-def test_refine_synthetic_vs_oracle(cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_refine_synthetic_vs_oracle(cuda, precision):
     """Stage 1 + 2 on a synthetic frame: rays without pairs (dummy voxel 0), relative positions."""
     from implicit_depth_amd.query import lidf_query, lidf_refine
     scene = orc.synthetic_scene(2, 12, 16, 6, seed=21, ragged=True)
@@ -95,6 +97,7 @@ def test_refine_synthetic_vs_oracle(cuda):
                                    s1["pred_pos"], s1["max_pair_id"], s["pair_vox"], vb.to(cuda),
                                    vbid.to(cuda), rgb.to(cuda), s["feat_grid"], valid_inp.to(cuda),
                                    valid_vox.to(cuda), make_pointnet(pnet_p, cuda),
-                                   make_module("IEF", offr_p, Dr, cuda), pos_rel=pos_rel)
+                                   make_module("IEF", offr_p, Dr, cuda), pos_rel=pos_rel,
+                                   precision=precision)
         assert (got.cpu() - pos).abs().max().item() <= TOL, pos_rel
         assert (gev.cpu().long() == ev).all()
