@@ -10,7 +10,7 @@ hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
 hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
-StreamLayout lidf_make_layout_rows_h(int nets, int D);
+StreamLayout lidf_make_layout_rows_h(int nets, int D, int l1only);
 hipError_t lidf_launch_pack_rows_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                                    float*, hipStream_t);
 hipError_t lidf_launch_rows_h(const PointsArgs&, int grid, hipStream_t);
@@ -159,7 +159,7 @@ LIDF_API size_t lidf_decoders_workspace_bytes(int64_t n, int d) {
     if (d <= 0) return 0;
     L1Map m = rows_map(d, 0, 0, 0, 1);
     StreamLayout lay = lidf_make_layout(2, LIDF_MODE_ROWS, m);
-    const size_t hs = (size_t)lidf_make_layout_rows_h(2, d).total * 4;  // split-f16 stream
+    const size_t hs = (size_t)lidf_make_layout_rows_h(2, d, 0).total * 4;  // split-f16 stream
     const size_t fs = (size_t)lay.total * 4;
     return align_up(fs > hs ? fs : hs, 256) + align_up(2 * LIDF_AUX_FLOATS * 4, 256);
 }
@@ -204,7 +204,7 @@ static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, con
     float* outs[2] = {prob ? out_prob : out_off, out_off};
     L1Map m = rows_map(d, 0, 0, 0, 1);
     const bool split = precision == LIDF_PRECISION_F16X3;
-    StreamLayout lay = split ? lidf_make_layout_rows_h(nets, d) : lidf_make_layout(nets, LIDF_MODE_ROWS, m);
+    StreamLayout lay = split ? lidf_make_layout_rows_h(nets, d, 0) : lidf_make_layout(nets, LIDF_MODE_ROWS, m);
     float* stream_buf = (float*)workspace;
     float* aux = (float*)((char*)workspace + lidf_decoders_workspace_bytes(n, d) -
                           align_up(2 * LIDF_AUX_FLOATS * 4, 256));
@@ -288,7 +288,11 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats
     }
     w.aux_pts = o;    o += align_up(2 * LIDF_AUX_FLOATS * 4, 256);
     w.stream_vox = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, 0, 0, 1)).total * 4, 256);
-    w.stream_ray = o; o += align_up((size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, Ed, 0, 0)).total * 4, 256);
+    {
+        const size_t f32 = (size_t)lidf_make_layout(2, LIDF_MODE_L1ONLY, rows_map(128, 0, Ed, 0, 0)).total * 4;
+        const size_t f16 = (size_t)lidf_make_layout_rows_h(2, 128 + Ed, 1).total * 4;
+        w.stream_ray = o; o += align_up(f32 > f16 ? f32 : f16, 256);
+    }
     w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
     w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
     w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
@@ -369,7 +373,7 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
         CHECK_HIP(lidf_launch_pack(lv, np, no, mv, stream_vox, aux_pts, st));
         L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
-        CHECK_HIP(lidf_launch_pack(lr, np, no, mr, stream_ray, aux_pts, st));
+        if (!split) CHECK_HIP(lidf_launch_pack(lr, np, no, mr, stream_ray, aux_pts, st));
 
         // 2. per-voxel partial  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c)
         {
@@ -395,7 +399,16 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0;
             a.out_base = raypart;
             long long nt = (R + 127) / 128;
-            CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
+            if (split) {
+                // the per-ray partial products with the split-f16 rows kernel (layer 1 only)
+                StreamLayout lh = lidf_make_layout_rows_h(2, mr.D, 1);
+                CHECK_HIP(lidf_launch_pack_rows_h(lh, np, no, mr, stream_ray, nullptr, st));
+                a.l1_quads = lh.l1_quads; a.net_quads = lh.net_quads;
+                a.npass[0] = a.npass[1] = 0;
+                CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
+            } else {
+                CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
+            }
         }
         // 4. per-point kernel
         {

@@ -97,8 +97,9 @@ __device__ _Float16 stream_value_r(const StreamLayout& lay, const NetW* nets, co
         const int x = 16 * ks + 8 * half + i, out = 32 * t + o;
         float w = 0.f;
         if (x < m.D) {
-            w = n.w1[(size_t)out * n.ld1 + x];
-        } else if (x == m.D) {
+            const int colw = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
+            w = n.w1[(size_t)out * n.ld1 + colw];
+        } else if (x == m.D && m.add_bias) {
             w = n.b1[out];
             if (n.is_ief)
                 for (int j = 0; j < 16; ++j) w += n.w1[(size_t)out * n.ld1 + n.dcore + j] * n.benc[j];
@@ -135,7 +136,7 @@ __global__ void lidf_pack_r_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map
     NetW nets[2] = {net0, net1};
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (long long)lay.total * 2) stream[e] = stream_value_r(lay, nets, m, e);
-    if (e < lay.nets * LIDF_AUX_FLOATS) {
+    if (aux && e < lay.nets * LIDF_AUX_FLOATS) {
         const int sec = (int)e / LIDF_AUX_FLOATS, i = (int)e % LIDF_AUX_FLOATS;
         const NetW& n = nets[sec];
         float v = 0.f;
@@ -483,6 +484,23 @@ __global__ void __launch_bounds__(256) lidf_rows_h_kernel(PointsArgs a) {
                 }
             }
 
+            if (a.out_base) {
+                // layer-1-only use (the per-ray partial products of the query): [n, nets*256]
+                if (valid) {
+                    float* ob = a.out_base + ((size_t)p * a.nets + net) * 256 + 4 * h;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = base[t][4 * g + i];
+                            *(f32x4*)(ob + t * 32 + 8 * g) = v;
+                        }
+                    }
+                }
+                continue;
+            }
             // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
             float val = a.init[net];
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
@@ -496,12 +514,13 @@ __global__ void __launch_bounds__(256) lidf_rows_h_kernel(PointsArgs a) {
 
 }  // namespace rowsh
 
-extern "C" StreamLayout lidf_make_layout_rows_h(int nets, int D) {
+// l1only: the stream holds the layer-1 sections only (npass must be 0 for every net)
+extern "C" StreamLayout lidf_make_layout_rows_h(int nets, int D, int l1only) {
     StreamLayout s;
     s.nets = nets;
     s.mode = LIDF_MODE_FUSED_H;
     s.l1_quads = 16 * ((D + 1 + 15) / 16);
-    s.net_quads = s.l1_quads + RPASS_QUADS;
+    s.net_quads = s.l1_quads + (l1only ? 0 : RPASS_QUADS);
     s.total = nets * s.net_quads * 256;
     return s;
 }
