@@ -42,7 +42,6 @@ class LidfQueryArgs(C.Structure):
         ("pred_prob_softmax", C.c_void_p), ("max_pair_id", C.c_void_p), ("pred_pos", C.c_void_p),
         ("depth", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("ev_points_begin", C.c_void_p), ("ev_points_end", C.c_void_p),
         ("rayfeat_out", C.c_void_p),
         ("precision", C.c_int32),
     ]
@@ -102,9 +101,13 @@ SIGNATURES = {
                                     C.POINTER(LidfDecoder), _P, _P, _P, _SZ, _P]),
     "lidf_query_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
+    "lidf_query_profile_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P, _P, _P]),
     "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P]),
     "lidf_ray_reduce_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lidf_ray_dirs_f32": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "lidf_miss_ray_workspace_bytes": (_SZ, [_I64]),
+    "lidf_miss_ray_count": (C.c_int, [_P, _I, _I64, _P, _P, _SZ, _P]),
+    "lidf_miss_ray_fill_f32": (C.c_int, [_P, _I, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lidf_ray_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "lidf_ray_aabb_count_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
     "lidf_ray_aabb_fill_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),

@@ -31,6 +31,9 @@ hipError_t lidf_launch_pcl_aabb_dense(const float*, const float*, const int*, co
 hipError_t lidf_launch_pcl_aabb_last(const float*, const float*, const int*, const int*,
                                      long long, long long, int*, hipStream_t);
 hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
+hipError_t lidf_launch_miss_count(const void*, int, long long, int*, int*, int*, int*, hipStream_t);
+hipError_t lidf_launch_miss_fill(const void*, int, long long, const int*, const float*, int, int, int*,
+                                 int*, int*, float*, long long*, long long*, long long*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
                              float*, int, float*, hipStream_t);
@@ -74,7 +77,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 1
+#define LIDF_ABI_VERSION 2
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \
@@ -307,7 +310,8 @@ LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_
     return query_ws(n_rays, n_vox, LIDF_MAX_L_FUSED, 16, grid_floats > 0 ? grid_floats : 0).total;
 }
 
-LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
+static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
+                      lidf_stream_t stream) {
     if (!q) return LIDF_ERR_BAD_ARG;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
@@ -431,12 +435,12 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif
             long long nt = (P + 127) / 128;
-            if (q->ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_begin, st));
+            if (ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)ev_points_begin, st));
             if (split)
                 CHECK_HIP(lidf_launch_points_h(a, cus, st));
             else
                 CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
-            if (q->ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)q->ev_points_end, st));
+            if (ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)ev_points_end, st));
         }
     }
     // 5. per-ray softmax / argmax / select / depth
@@ -449,6 +453,15 @@ LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
     return LIDF_OK;
 }
 
+LIDF_API int lidf_query_f32(const LidfQueryArgs* q, lidf_stream_t stream) {
+    return query_impl(q, nullptr, nullptr, stream);
+}
+
+LIDF_API int lidf_query_profile_f32(const LidfQueryArgs* q, void* ev_points_begin,
+                                      void* ev_points_end, lidf_stream_t stream) {
+    return query_impl(q, ev_points_begin, ev_points_end, stream);
+}
+
 // ---- rays, boxes, scan ---------------------------------------------------------------------------
 LIDF_API int lidf_ray_dirs_f32(const float* intr, int batch, int height, int width,
                                  float* ray_dir, lidf_stream_t stream) {
@@ -456,6 +469,62 @@ LIDF_API int lidf_ray_dirs_f32(const float* intr, int batch, int height, int wid
     if ((long long)batch * height * width == 0) return LIDF_OK;
     if (!intr || !ray_dir) return LIDF_ERR_BAD_ARG;
     CHECK_HIP(lidf_launch_ray_dirs(intr, batch, height, width, ray_dir, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- get_miss_ray (mask -> compacted rays) ------------------------------------------------------
+struct MissWs {
+    size_t block_cnt, block_off, sums, total;
+};
+static MissWs miss_ws(int64_t n) {
+    if (n < 0) n = 0;
+    const size_t nb = (size_t)((n + 1023) / 1024);
+    MissWs w;
+    size_t o = 0;
+    w.block_cnt = o; o += align_up((nb + 1) * 4, 256);
+    w.block_off = o; o += align_up((nb + 2) * 4, 256);
+    w.sums = o;      o += lidf_exclusive_scan_workspace_bytes((int64_t)nb);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_miss_ray_workspace_bytes(int64_t n_pixels) { return miss_ws(n_pixels).total; }
+
+LIDF_API int lidf_miss_ray_count(const void* mask, int mask_dtype, int64_t n_pixels,
+                                   int32_t* n_rays, void* workspace, size_t workspace_bytes,
+                                   lidf_stream_t stream) {
+    if (n_pixels < 0 || !n_rays) return LIDF_ERR_BAD_ARG;
+    if (mask_dtype < LIDF_MASK_F32 || mask_dtype > LIDF_MASK_I64) return LIDF_ERR_BAD_ARG;
+    if (n_pixels > 0x7ffffbffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n_pixels > 0 && !mask) return LIDF_ERR_BAD_ARG;
+    const MissWs w = miss_ws(n_pixels);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    CHECK_HIP(lidf_launch_miss_count(mask, mask_dtype, n_pixels, (int*)(ws + w.block_cnt),
+                                     (int*)(ws + w.block_off), (int*)(ws + w.sums), n_rays,
+                                     (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_miss_ray_fill_f32(const void* mask, int mask_dtype, const float* intr, int batch,
+                                      int height, int width, const void* workspace,
+                                      size_t workspace_bytes, int32_t* ray_bid, int32_t* ray_flat,
+                                      int32_t* ray_pix, float* ray_dir, int64_t* miss_bid,
+                                      int64_t* miss_flat_img_id, int64_t* miss_img_ind,
+                                      lidf_stream_t stream) {
+    if (batch < 0 || height < 0 || width < 0) return LIDF_ERR_BAD_ARG;
+    if (mask_dtype < LIDF_MASK_F32 || mask_dtype > LIDF_MASK_I64) return LIDF_ERR_BAD_ARG;
+    const int64_t n = (int64_t)batch * height * width;
+    if (n > 0x7ffffbffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n == 0) return LIDF_OK;
+    if (!mask || (ray_dir && !intr)) return LIDF_ERR_BAD_ARG;
+    const MissWs w = miss_ws(n);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    const char* ws = (const char*)workspace;
+    CHECK_HIP(lidf_launch_miss_fill(mask, mask_dtype, n, (const int*)(ws + w.block_off), intr,
+                                    height, width, ray_bid, ray_flat, ray_pix, ray_dir,
+                                    (long long*)miss_bid, (long long*)miss_flat_img_id,
+                                    (long long*)miss_img_ind, (hipStream_t)stream));
     return LIDF_OK;
 }
 

@@ -348,7 +348,10 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
         }
     }
     if (lane == 0) {
-        const bool empty = end <= beg;
+        // no candidate, or no softmax value compared greater than -inf (NaN / +-inf logits make
+        // every value NaN): torch_scatter's scatter_max leaves its out-of-range index then, which
+        // selects the dummy row (pipeline.py:452-454) -> id = P, position (0,0,0)
+        const bool empty = end <= beg || bi >= end;
         float x = 0.f, y = 0.f, z = 0.f;
         if (!empty && pos) {
             x = pos[3 * (size_t)bi];
@@ -892,5 +895,122 @@ extern "C" hipError_t lidf_launch_depth_metrics(const float* pred, const float* 
                                                 int dst_h, int dst_w, float* out, hipStream_t st) {
     hipLaunchKernelGGL(lidf_depth_metrics_kernel, dim3(1), dim3(1024), 0, st, pred, gt, seg, src_h,
                        src_w, dst_h, dst_w, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_miss_ray — models/pipeline.py:203-269 (eval flavour): miss_idx = nonzero(mask.view(bs,-1))
+// in row-major (image, pixel) order, then per selected pixel the image index, the flat pixel index,
+// the unit ray direction (same expression as lidf_ray_dirs_kernel, formed here for the selected
+// pixels only: no dense [bs,h*w,3] field) and the integer pixel (x, y).
+//   pass 1: per block of 1024 pixels the number of non-zero mask entries
+//   scan of the block counts (lidf_launch_scan), total -> n_rays
+//   pass 2: the block recomputes its flags, ranks them with a block scan (ascending pixel order
+//           inside a thread's 4 consecutive pixels and across threads) and writes the rays
+// mask element types as torch.nonzero accepts them: f32 (the reference's corrupt_mask / pred_mask
+// are float tensors, datasets/cleargrasp_dataset.py:114), u8/bool, i32, i64. NaN counts as non-zero.
+// ------------------------------------------------------------------------------------------------
+#define MISS_ITEMS 1024
+
+__device__ __forceinline__ bool mask_nonzero(const void* mask, int dtype, long long i) {
+    switch (dtype) {
+        case 0: return ((const float*)mask)[i] != 0.f;
+        case 1: return ((const unsigned char*)mask)[i] != 0;
+        case 2: return ((const int*)mask)[i] != 0;
+        default: return ((const long long*)mask)[i] != 0;
+    }
+}
+
+__global__ void lidf_miss_count_kernel(const void* __restrict__ mask, int dtype, long long n,
+                                       int* __restrict__ block_cnt) {
+    __shared__ int s_tmp[4];
+    const long long b0 = (long long)blockIdx.x * MISS_ITEMS + threadIdx.x * 4;
+    int v = 0;
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < n && mask_nonzero(mask, dtype, b0 + k)) ++v;
+    int total;
+    block_scan_256(v, s_tmp, total);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+
+__global__ void lidf_miss_total_kernel(const int* __restrict__ block_off, long long nb,
+                                       int* __restrict__ n_rays) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) n_rays[0] = block_off[nb];
+}
+
+__global__ void lidf_miss_fill_kernel(const void* __restrict__ mask, int dtype, long long n,
+                                      const int* __restrict__ block_off,
+                                      const float* __restrict__ intr, int H, int W,
+                                      int* __restrict__ ray_bid, int* __restrict__ ray_flat,
+                                      int* __restrict__ ray_pix, float* __restrict__ ray_dir,
+                                      long long* __restrict__ bid64, long long* __restrict__ flat64,
+                                      long long* __restrict__ pix64) {
+    __shared__ int s_tmp[4];
+    const long long b0 = (long long)blockIdx.x * MISS_ITEMS + threadIdx.x * 4;
+    bool f[4];
+    int v = 0;
+    for (int k = 0; k < 4; ++k) {
+        f[k] = b0 + k < n && mask_nonzero(mask, dtype, b0 + k);
+        v += f[k] ? 1 : 0;
+    }
+    int total;
+    int j = block_off[blockIdx.x] + block_scan_256(v, s_tmp, total);
+    const long long hw = (long long)H * W;
+    for (int k = 0; k < 4; ++k) {
+        if (!f[k]) continue;
+        const long long i = b0 + k;
+        const int b = (int)(i / hw);
+        const int rem = (int)(i % hw);
+        const int y = rem / W, x = rem % W;
+        if (ray_bid) ray_bid[j] = b;
+        if (ray_flat) ray_flat[j] = rem;
+        if (ray_pix) {
+            ray_pix[2 * j] = x;
+            ray_pix[2 * j + 1] = y;
+        }
+        if (bid64) bid64[j] = b;
+        if (flat64) flat64[j] = rem;
+        if (pix64) {
+            pix64[2 * j] = x;
+            pix64[2 * j + 1] = y;
+        }
+        if (ray_dir) {  // pipeline.py:215-219, as lidf_ray_dirs_kernel
+            const float fx = intr[4 * b], fy = intr[4 * b + 1], cx = intr[4 * b + 2],
+                        cy = intr[4 * b + 3];
+            const float vx = (float)x - cx;
+            const float vy = ((float)y - cy) * fx / fy;
+            const float vz = fx;
+            const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+            ray_dir[3 * j] = vx / nrm;
+            ray_dir[3 * j + 1] = vy / nrm;
+            ray_dir[3 * j + 2] = vz / nrm;
+        }
+        ++j;
+    }
+}
+
+extern "C" hipError_t lidf_launch_miss_count(const void* mask, int dtype, long long n,
+                                             int* block_cnt, int* block_off, int* sums,
+                                             int* n_rays, hipStream_t st) {
+    const long long nb = (n + MISS_ITEMS - 1) / MISS_ITEMS;
+    if (nb > 0)
+        hipLaunchKernelGGL(lidf_miss_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, mask, dtype,
+                           n, block_cnt);
+    hipError_t e = lidf_launch_scan(block_cnt, nb, block_off, sums, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lidf_miss_total_kernel, dim3(1), dim3(64), 0, st, block_off, nb, n_rays);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_miss_fill(const void* mask, int dtype, long long n,
+                                            const int* block_off, const float* intr, int H, int W,
+                                            int* ray_bid, int* ray_flat, int* ray_pix,
+                                            float* ray_dir, long long* bid64, long long* flat64,
+                                            long long* pix64, hipStream_t st) {
+    const long long nb = (n + MISS_ITEMS - 1) / MISS_ITEMS;
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_miss_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, mask, dtype, n,
+                       block_off, intr, H, W, ray_bid, ray_flat, ray_pix, ray_dir, bid64, flat64,
+                       pix64);
     return hipGetLastError();
 }

@@ -28,6 +28,16 @@ def _i32(t, name):
     return t
 
 
+def _as_i32(t, name):
+    """Index tensors of the reference's data_dict are int64 (torch.nonzero); the kernels take
+    int32. An int64 tensor is narrowed here (one cast) instead of being misread as int32."""
+    if t is None or t.dtype == torch.int32:
+        return t
+    if t.dtype == torch.int64:
+        return t.to(torch.int32)
+    raise RuntimeError("%s must be int32 or int64 (got %s)" % (name, t.dtype))
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
@@ -43,6 +53,61 @@ def ray_dirs(fx, fy, cx, cy, h, w):
     with torch.cuda.device(intr.device):
         _lib.check(_lib.lib().lidf_ray_dirs_f32(_lib.ptr(intr), bs, h, w, _lib.ptr(out),
                                                 _lib.current_stream(intr.device)))
+    return out
+
+
+MASK_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.bool: 1, torch.int32: 2, torch.int64: 3}
+
+
+def get_miss_ray(mask, fx, fy, cx, cy):
+    """LIDF.get_miss_ray (models/pipeline.py:203-269), eval flavour: the pixels where `mask`
+    ([bs,h,w] or [bs,1,h,w]; float, bool/uint8, int32 or int64 — data_dict['pred_mask'] /
+    ['corrupt_mask']) is non-zero, in torch.nonzero's (image, pixel) order, with their ray
+    directions — mark, scan and compact on the device (lidf_miss_ray_count / _fill_f32).
+
+    Returns the reference's data_dict entries miss_bid [R] i64, miss_flat_img_id [R] i64,
+    miss_ray_dir [R,3] f32, miss_img_ind [R,2] i64 (x, y), total_miss_sample_num, plus the int32
+    forms the query kernels take: ray_bid, ray_flat [R], ray_pix [R,2]. R == 0 is the reference's
+    'no miss ray' early exit (pipeline.py:676, :686-687). The train-only random window of
+    pipeline.py:232-254 is a slice [start:start+miss_sample_num] of these outputs per image."""
+    if mask.dim() == 4 and mask.shape[1] == 1:
+        mask = mask[:, 0]
+    if mask.dim() != 3:
+        raise RuntimeError("mask must be [bs,h,w] or [bs,1,h,w]")
+    if mask.dtype not in MASK_DTYPES:
+        raise RuntimeError("mask dtype %s is not supported" % mask.dtype)
+    mask = mask.contiguous()
+    intr = torch.stack((fx.float(), fy.float(), cx.float(), cy.float()), 1).contiguous()
+    _lib.require_cuda(mask, intr, names=["mask", "intrinsics"])
+    bs, h, w = mask.shape
+    if intr.shape[0] != bs:
+        raise RuntimeError("fx/fy/cx/cy must have one entry per image")
+    dev = mask.device
+    L = _lib.lib()
+    n = bs * h * w
+    wsb = L.lidf_miss_ray_workspace_bytes(n)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    mt = MASK_DTYPES[mask.dtype]
+    with torch.cuda.device(dev):
+        st = _lib.current_stream(dev)
+        _lib.check(L.lidf_miss_ray_count(_lib.ptr(mask), mt, n, _lib.ptr(cnt), _lib.ptr(ws), wsb, st))
+        R = int(cnt.item())  # host needs R to size the outputs (as nonzero() does)
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        out = {
+            "ray_bid": torch.empty((R,), **i32), "ray_flat": torch.empty((R,), **i32),
+            "ray_pix": torch.empty((R, 2), **i32),
+            "miss_ray_dir": torch.empty((R, 3), dtype=torch.float32, device=dev),
+            "miss_bid": torch.empty((R,), **i64), "miss_flat_img_id": torch.empty((R,), **i64),
+            "miss_img_ind": torch.empty((R, 2), **i64), "total_miss_sample_num": R,
+        }
+        if R > 0:
+            _lib.check(L.lidf_miss_ray_fill_f32(
+                _lib.ptr(mask), mt, _lib.ptr(intr), bs, h, w, _lib.ptr(ws), wsb,
+                _lib.ptr(out["ray_bid"]), _lib.ptr(out["ray_flat"]), _lib.ptr(out["ray_pix"]),
+                _lib.ptr(out["miss_ray_dir"]), _lib.ptr(out["miss_bid"]),
+                _lib.ptr(out["miss_flat_img_id"]), _lib.ptr(out["miss_img_ind"]), st))
     return out
 
 
@@ -110,16 +175,19 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     Returns a dict with the reference's data_dict keys (models/pipeline.py:460-466):
     pred_offset [P,1], pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
     max_pair_id [R] i64, pred_pos [R,3]; `depth` [B,h,w] is updated in place if given."""
+    # the reference's index tensors (miss_bid, miss_flat_img_id, miss_img_ind) are int64
+    ray_pix, ray_bid, ray_flat = (_as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid"),
+                                  _as_i32(ray_flat, "ray_flat"))
     tensors = [ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                vox_feat, vox_center, ray_flat, depth]
     names = ["ray_dir", "ray_pix", "ray_bid", "pair_off", "pair_ray", "pair_vox", "pair_t",
              "feat_grid", "vox_feat", "vox_center", "ray_flat", "depth"]
     _lib.require_cuda(*tensors, names=names)
     for t, n in ((ray_dir, "ray_dir"), (pair_t, "pair_t"), (feat_grid, "feat_grid"),
-                 (vox_feat, "vox_feat")):
-        _f32(t, n)
-    for t, n in ((ray_pix, "ray_pix"), (ray_bid, "ray_bid"), (pair_off, "pair_off"),
-                 (pair_ray, "pair_ray"), (pair_vox, "pair_vox")):
+                 (vox_feat, "vox_feat"), (vox_center, "vox_center"), (depth, "depth")):
+        if t is not None:
+            _f32(t, n)
+    for t, n in ((pair_off, "pair_off"), (pair_ray, "pair_ray"), (pair_vox, "pair_vox")):
         _i32(t, n)
     if feat_grid.dim() != 4 or feat_grid.shape[1] != 32:
         raise RuntimeError("feat_grid must be [B,32,h,w] (rgb_out=32)")
@@ -137,6 +205,12 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
         raise RuntimeError("pair_off must have R+1 entries")
     if depth is not None and ray_flat is None:
         raise RuntimeError("depth needs ray_flat")
+    if depth is not None and tuple(depth.shape) != (B, h, w):
+        raise RuntimeError("depth must be [B,h,w] = %s (got %s)" % ((B, h, w), tuple(depth.shape)))
+    if vox_center is not None and tuple(vox_center.shape) != (V, 3):
+        raise RuntimeError("vox_center must be [V,3]")
+    if ray_pix.shape != (R, 2) or ray_bid.shape != (R,) or (ray_flat is not None and ray_flat.shape != (R,)):
+        raise RuntimeError("ray_pix / ray_bid / ray_flat must be [R,2] / [R] / [R]")
 
     f32 = dict(dtype=torch.float32, device=dev)
     out = {
@@ -181,10 +255,12 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     q.precision = PRECISIONS[precision]
-    if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end) as integers
-        q.ev_points_begin, q.ev_points_end = profile_events
     with torch.cuda.device(dev):
-        _lib.check(L.lidf_query_f32(C.byref(q), _lib.current_stream(dev)))
+        if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end): benchmarks only
+            _lib.check(L.lidf_query_profile_f32(C.byref(q), profile_events[0], profile_events[1],
+                                                _lib.current_stream(dev)))
+        else:
+            _lib.check(L.lidf_query_f32(C.byref(q), _lib.current_stream(dev)))
     out["workspace"] = workspace
     return out
 

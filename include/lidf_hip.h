@@ -133,10 +133,6 @@ typedef struct LidfQueryArgs {
     /* scratch */
     void* workspace;
     size_t workspace_bytes;
-    /* optional instrumentation: two hipEvent_t recorded on `stream` immediately before and after
-     * the per-point decoder kernel (the dominant launch); NULL = no recording.               */
-    void* ev_points_begin;
-    void* ev_points_end;
     /* optional output: the per-ray [ROI feature | embed(dir)] rows, [R, 128 + 3+6*multires_views]
      * (what lidf_ray_features_f32 computes) so that stage 2 (lidf_refine_f32) can re-use them. */
     float* rayfeat_out;
@@ -152,6 +148,11 @@ typedef struct LidfQueryArgs {
  * ROIAlign of unclamped boxes into 4 gathers per channel; 0 = minimal workspace (general path). */
 size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_t grid_floats);
 int lidf_query_f32(const LidfQueryArgs* args, lidf_stream_t stream);
+/* Instrumented variant for benchmarks: the same call, with two hipEvent_t recorded on `stream`
+ * immediately before and after the per-point decoder kernel (the dominant launch); either may be
+ * NULL. Not part of the reference's interface.                                                */
+int lidf_query_profile_f32(const LidfQueryArgs* args, void* ev_points_begin, void* ev_points_end,
+                           lidf_stream_t stream);
 
 /* Per-ray ROIAlign feature (torchvision.ops.roi_align, output 2x2, aligned=True, called at
  * models/pipeline.py:374-387 and :954-967) + direction embedding, exposed on its own because
@@ -175,6 +176,30 @@ int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_pos,
  * ray_dir[b,y,x] = normalize(x-cx, (y-cy)*fx/fy, fx). intr: [B,4] = (fx,fy,cx,cy) f32.       */
 int lidf_ray_dirs_f32(const float* intr, int batch, int height, int width, float* ray_dir,
                       lidf_stream_t stream);
+
+/* ---- Miss-ray selection -------------------------------------------------------------------
+ * Replaces LIDF.get_miss_ray (models/pipeline.py:203-269), eval flavour (the train-only random
+ * window of :232-254 is the caller's slice of the outputs): miss_idx = nonzero(mask.view(bs,-1))
+ * in (image, pixel) order, then per selected pixel the image index, the flat pixel index y*w+x,
+ * the unit ray direction (pipeline.py:215-219) and the integer pixel (x, y).
+ * mask: [batch*height*width] elements of mask_dtype (the reference passes float masks; NaN is
+ * non-zero, as for torch.nonzero). Two calls, because the caller sizes the outputs:
+ *   lidf_miss_ray_count  -> n_rays (device int32[1]); keeps block offsets in the workspace
+ *   lidf_miss_ray_fill   -> same mask + the SAME workspace; every output may be NULL:
+ *       ray_bid/ray_flat [R] i32, ray_pix [R,2] i32, ray_dir [R,3] f32 (what lidf_query_f32 takes)
+ *       miss_bid/miss_flat_img_id [R] i64, miss_img_ind [R,2] i64 (the reference's data_dict dtypes) */
+#define LIDF_MASK_F32 0
+#define LIDF_MASK_U8 1
+#define LIDF_MASK_I32 2
+#define LIDF_MASK_I64 3
+size_t lidf_miss_ray_workspace_bytes(int64_t n_pixels);
+int lidf_miss_ray_count(const void* mask, int mask_dtype, int64_t n_pixels, int32_t* n_rays,
+                        void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+int lidf_miss_ray_fill_f32(const void* mask, int mask_dtype, const float* intr, int batch, int height,
+                           int width, const void* workspace, size_t workspace_bytes,
+                           int32_t* ray_bid, int32_t* ray_flat, int32_t* ray_pix, float* ray_dir,
+                           int64_t* miss_bid, int64_t* miss_flat_img_id, int64_t* miss_img_ind,
+                           lidf_stream_t stream);
 
 /* ---- Ray / voxel slab test ---------------------------------------------------------------
  * Dense drop-in for extensions/ray_aabb (ray_aabb_cuda_kernel.cu:10-126): mask [V,R] i32 and

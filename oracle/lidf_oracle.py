@@ -120,6 +120,20 @@ def ray_dirs(fx, fy, cx, cy, h, w):
     return d, img_ind_flat
 
 
+def get_miss_ray(mask, fx, fy, cx, cy):
+    """LIDF.get_miss_ray, eval flavour (models/pipeline.py:208-230, :255-269): mask [bs,h,w]
+    (data_dict['pred_mask']); the train-only random window (:232-254) is not restated."""
+    bs, h, w = mask.shape
+    d, img_ind_flat = ray_dirs(fx, fy, cx, cy, h, w)
+    ray_dir_flat = d.reshape(bs, -1, 3)
+    miss_idx = torch.nonzero(mask.reshape(bs, -1), as_tuple=False)
+    miss_bid, miss_flat_img_id = miss_idx[:, 0], miss_idx[:, 1]
+    return {"miss_bid": miss_bid, "miss_flat_img_id": miss_flat_img_id,
+            "miss_ray_dir": ray_dir_flat[miss_bid, miss_flat_img_id],
+            "miss_img_ind": img_ind_flat[miss_bid, miss_flat_img_id],
+            "total_miss_sample_num": miss_idx.shape[0]}
+
+
 # ----------------------------------------------------------------------------------------------
 # a5  ray_aabb — extensions/ray_aabb/ray_aabb_cuda_kernel.cu:24-88 (numpy, same arithmetic)
 # ----------------------------------------------------------------------------------------------

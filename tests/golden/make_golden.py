@@ -11,6 +11,8 @@ Python modules are imported and executed, and only their inputs/outputs are stor
                     2 x 16 x 24 synthetic batch                           (models/pipeline.py:203-466)
   g5_decoder_grads.npz  autograd gradients of the reference IMNet / IEF (input rows and every
                     parameter) for a closed-form upstream gradient   (models/implicit_net.py:60-152)
+  g6_miss_ray.npz   LIDF.get_miss_ray on float masks (holes, an empty image, -0.0, tiny values)
+                                                                       (models/pipeline.py:203-269)
   g4_refine.npz     RefineNet.get_pred_refine x 2 on the same batch (stage 2), incl. the refine
                     PointNet2Stage outputs                     (models/pipeline.py:922-1041, pointnet.py)
 
@@ -278,11 +280,50 @@ def g3_pipeline():
     np.savez_compressed(os.path.join(HERE, "g4_refine.npz"), **g4)
 
 
+def g6_miss_ray():
+    """LIDF.get_miss_ray of the reference on float masks with holes, an empty image and odd values
+    (models/pipeline.py:203-269, eval flavour)."""
+    install_stubs()
+    import models.pipeline as pl
+    from opt import Params
+    cfg = os.path.join(REF, "experiments", "implicit_depth")
+    opt = Params(os.path.join(cfg, "default_config.yaml"))
+    opt.update(os.path.join(cfg, "test_lidf.yaml"))
+    lidf = pl.LIDF(opt, torch.device("cpu")).eval()
+    out = {}
+    cases = {"a": (3, 10, 13), "b": (2, 33, 47), "c": (1, 5, 1030)}
+    for key, (B, h, w) in cases.items():
+        g = torch.Generator().manual_seed(600 + B * h)
+        mask = (torch.rand(B, h, w, generator=g) < 0.37).float()
+        mask = mask * (torch.rand(B, h, w, generator=g) * 4 - 2)      # non-zero values of both signs
+        if B > 1:
+            mask[1] = 0                                                # an image without miss rays
+        mask[0, 0, 0] = -0.0                                           # negative zero is zero
+        mask[0, h - 1, w - 1] = 1e-30
+        fx = torch.rand(B, generator=g) * 10 + 0.9 * w
+        fy = fx * (1 + 0.05 * torch.rand(B, generator=g))
+        cx = torch.rand(B, generator=g) + w / 2 - 0.5
+        cy = torch.rand(B, generator=g) + h / 2 - 0.5
+        dd = {"bs": B, "h": h, "w": w, "fx": fx, "fy": fy, "cx": cx, "cy": cy, "pred_mask": mask}
+        with torch.no_grad():
+            lidf.get_miss_ray(dd, "test")
+        out[key + "_mask"] = mask.numpy()
+        out[key + "_intr"] = torch.stack((fx, fy, cx, cy), 1).numpy()
+        for k in ("miss_bid", "miss_flat_img_id", "miss_ray_dir", "miss_img_ind"):
+            out[key + "_" + k] = dd[k].numpy()
+        print("g6", key, "R =", dd["total_miss_sample_num"])
+    np.savez_compressed(os.path.join(HERE, "g6_miss_ray.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-g6" in sys.argv:
+        g6_miss_ray()
+        sys.exit(0)
     g1_embed()
     g2_decoders()
     g5_decoder_grads()
     g3_pipeline()
+    g6_miss_ray()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

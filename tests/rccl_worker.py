@@ -1,0 +1,48 @@
+"""Worker of tests/test_rccl_gpu.py, launched by torch.distributed.run (one process per GPU,
+backend nccl = RCCL): the depth all-gather of implicit_depth_amd.dist on real device buffers —
+equal shards, ragged shards, and the depth map of a small lidf_query."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from implicit_depth_amd.dist import all_gather_depth, all_gather_depth_ragged, shard_frames
+    from util import orc, run_query
+
+    # equal shards
+    loc = torch.full((2, 6, 8), float(rank + 1), device=dev)
+    full = all_gather_depth(loc)
+    assert full.shape == (2 * world, 6, 8)
+    for r in range(world):
+        assert (full[2 * r:2 * r + 2] == r + 1).all()
+    # ragged shards: 2*world + 1 frames
+    n = 2 * world + 1
+    lo, hi = shard_frames(n, world, rank)
+    loc = torch.arange(lo, hi, device=dev, dtype=torch.float32).view(-1, 1, 1).expand(hi - lo, 3, 4).contiguous()
+    full = all_gather_depth_ragged(loc, n)
+    assert full.shape == (n, 3, 4) and (full[:, 0, 0] == torch.arange(n, device=dev)).all()
+    # the depth map of a query, gathered
+    scene = orc.synthetic_scene(1, 12, 16, 8, seed=50 + rank)
+    got = run_query(scene, dev)
+    full = all_gather_depth(got["depth"])
+    assert (full[rank] == got["depth"][0]).all() and torch.isfinite(full).all()
+    dist.barrier()
+    if rank == 0:
+        print("RCCL_WORKER_OK world=%d" % world, flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

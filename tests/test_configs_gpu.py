@@ -1,0 +1,87 @@
+"""Every BASELINE.json configuration on the GPU, HIP path (through the C ABI) against the oracle.
+
+  configs[0]  64x64 grid, 16 candidates/ray: the whole frame against the oracle (P = 65,536)
+  configs[1]  240x320x64, one frame: tests/test_edge_gpu.py::test_full_size_properties
+  configs[2]  the per-GPU shard of the 32-frame batch over 8 GPUs: 4 frames x 240x320x64
+  configs[3]  stage 1 + stage 2 at 240x320x64: test_config3_refine_full_size below
+  configs[4]  256 candidates/ray (one frame of the shard)
+At the full sizes the oracle cannot run the whole frame in seconds, so the checks are
+size-independent properties (softmax sums to 1 per ray, the arg-max is a maximal logit of its own
+ray, select and depth are pure gathers) plus >= 96 random WHOLE rays per frame against the oracle.
+"""
+import functools
+
+import pytest
+import torch
+
+from util import TOL, oracle_query, orc, run_query, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@functools.lru_cache(maxsize=2)
+def _scene(B, h, w, N, seed, ragged=False):
+    return orc.synthetic_scene(B, h, w, N, seed=seed, ragged=ragged)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_config0_64x64x16_whole_frame(cuda, precision, ragged):
+    scene = _scene(1, 64, 64, 16, 1234, ragged)
+    ref = oracle_query(scene, fast_roi=True)
+    got = run_query(scene, cuda, precision=precision)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+    assert (got["pred_prob_end_softmax"].cpu() - ref["pred_prob_end_softmax"]).abs().max().item() <= 1e-5
+    depth_ref = torch.zeros(64 * 64)
+    depth_ref[scene["ray_flat"].long()] = ref["pred_pos"][:, 2]
+    assert (got["depth"].cpu().reshape(-1) - depth_ref).abs().mean().item() <= TOL  # depth L1 vs ref
+    gid, rid = got["max_pair_id"].cpu(), ref["max_pair_id"]
+    sm = ref["pred_prob_end_softmax"]
+    for r in (gid != rid).nonzero().flatten().tolist():   # only float-noise ties may differ
+        assert gid[r] < scene["P"] and rid[r] < scene["P"] and abs(sm[gid[r]] - sm[rid[r]]) <= 1e-6
+
+
+def check_full_size(scene, got, cuda, rays_per_frame=96):
+    B, N, R, P = scene["B"], scene["N"], scene["R"], scene["P"]
+    assert P == R * N
+    sm = got["pred_prob_end_softmax"]
+    assert torch.isfinite(got["pair_pred_pos"]).all() and torch.isfinite(sm).all()
+    assert (sm.reshape(R, N).sum(1) - 1).abs().max().item() <= 1e-5
+    mid = got["max_pair_id"]
+    ar = torch.arange(R, device=cuda)
+    assert ((mid >= ar * N) & (mid < (ar + 1) * N)).all()                  # inside its own ray
+    logit = got["pred_prob_end"][:, 0].reshape(R, N)
+    assert (logit.gather(1, (mid - ar * N).unsqueeze(1))[:, 0] >= logit.max(1).values - 1e-6).all()
+    assert (got["pred_pos"] == got["pair_pred_pos"][mid]).all()
+    assert (got["depth"].reshape(-1) == got["pred_pos"][:, 2]).all()
+    g = torch.Generator().manual_seed(0)
+    hw = scene["h"] * scene["w"]
+    rows = torch.cat([b * hw + torch.randperm(hw, generator=g)[:rays_per_frame] for b in range(B)]).sort().values
+    n = rows.shape[0]
+    pidx = (rows.unsqueeze(1) * N + torch.arange(N)).reshape(-1)
+    ref = orc.query(scene["ray_dir"][rows], scene["ray_pix"][rows], scene["ray_bid"][rows],
+                    torch.arange(n).repeat_interleave(N), scene["pair_vox"][pidx].long(),
+                    scene["pair_t"][pidx], None, scene["feat_grid"], scene["vox_feat"],
+                    scene["prob_p"], scene["off_p"], fast_roi=True)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert (got[k][pidx.to(cuda)].cpu() - ref[k]).abs().max().item() <= TOL, k
+    assert (got["pred_pos"][rows.to(cuda)].cpu() - ref["pred_pos"]).abs().max().item() <= TOL
+    dsel = got["depth"].reshape(-1)[rows.to(cuda)].cpu()
+    assert (dsel - ref["pred_pos"][:, 2]).abs().mean().item() <= TOL            # depth L1 vs ref
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_config2_shard_4_frames(cuda, precision):
+    """configs[2]: 32 frames over 8 GPUs = 4 frames of 240x320x64 per GPU (P = 19,660,800)."""
+    scene = _scene(4, 240, 320, 64, 1236)
+    got = run_query(scene, cuda, precision=precision)
+    check_full_size(scene, got, cuda)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_config4_256_candidates(cuda, precision):
+    """configs[4]: dense resample, 256 candidates per ray, one 240x320 frame (P = 19,660,800)."""
+    scene = _scene(1, 240, 320, 256, 1238)
+    got = run_query(scene, cuda, precision=precision)
+    check_full_size(scene, got, cuda)

@@ -125,3 +125,53 @@ def test_full_size_properties(cuda, precision):
     for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
         assert (got[k][pidx.to(cuda)].cpu() - ref[k]).abs().max().item() <= TOL, k
     assert (got["pred_pos"][rows.to(cuda)].cpu() - ref["pred_pos"]).abs().max().item() <= TOL
+
+
+def test_ray_reduce_nonfinite_logits(cuda):
+    """NaN / all -inf / +inf logits of a ray: torch_scatter's scatter_max leaves its out-of-range
+    index (no value compares greater), i.e. the dummy row: id = P, position (0,0,0) — and no
+    out-of-bounds read."""
+    import ctypes as C
+    from implicit_depth_amd import _lib
+    off = torch.tensor([0, 3, 6, 9, 9, 12], dtype=torch.int32, device=cuda)
+    inf, nan = float("inf"), float("nan")
+    prob = torch.tensor([0.1, 0.5, 0.2, nan, nan, nan, -inf, -inf, -inf, inf, 1.0, 2.0], device=cuda)
+    pos = torch.arange(36, dtype=torch.float32, device=cuda).reshape(12, 3) + 1
+    R, P = 5, 12
+    sm = torch.empty(P, device=cuda)
+    mid = torch.empty(R, dtype=torch.int64, device=cuda)
+    pp = torch.empty(R, 3, device=cuda)
+    _lib.check(_lib.lib().lidf_ray_reduce_f32(_lib.ptr(prob), _lib.ptr(pos), _lib.ptr(off), R, P, None,
+                                              None, 0, _lib.ptr(sm), _lib.ptr(mid), _lib.ptr(pp), None,
+                                              _lib.current_stream(cuda)))
+    torch.cuda.synchronize()
+    assert mid.tolist() == [1, P, P, P, P]
+    assert (pp[0] == pos[1]).all() and (pp[1:] == 0).all()
+    ref_sm, ref_id = orc.scatter_softmax(prob.cpu(), torch.tensor([0, 0, 0, 1, 1, 1, 2, 2, 2, 4, 4, 4]), 5), None
+    assert torch.allclose(sm[:3].cpu(), ref_sm[:3], atol=1e-6)
+
+
+def test_embed_large_and_nonfinite(cuda):
+    """|x| up to 1e3 (arguments up to 1.3e5 rad at octave 7) against float64 sin/cos of the exact
+    f32 products, and NaN / inf inputs -> NaN like torch.sin / torch.cos."""
+    from implicit_depth_amd import get_embedder
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(4096, 3, generator=g) - 0.5) * 2000.0
+    x[:8] = torch.tensor([[1e3, -1e3, 999.999]]).expand(8, 3)
+    fn, dim = get_embedder(8)
+    got = fn(x.to(cuda)).cpu().double()
+    xd = x.double()
+    ref = [xd]
+    for o in range(8):
+        ref += [torch.sin(xd * 2.0 ** o), torch.cos(xd * 2.0 ** o)]
+    ref = torch.cat(ref, -1)
+    assert (got - ref).abs().max().item() <= 1e-6
+    # and against torch's own f32 sin/cos (the reference's arithmetic): both within a few ulp of exact
+    ref32 = orc.embed(x, 8).double()
+    assert (got - ref32).abs().max().item() <= 2e-6
+    bad = torch.tensor([[float("nan"), float("inf"), -float("inf")], [0.0, 1.0, float("nan")]])
+    gb = fn(bad.to(cuda)).cpu()
+    rb = orc.embed(bad, 8)
+    assert (torch.isnan(gb) == torch.isnan(rb)).all()
+    ok = ~torch.isnan(rb)
+    assert (gb[ok] - rb[ok]).abs().max().item() <= 1e-6

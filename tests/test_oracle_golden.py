@@ -174,3 +174,15 @@ def test_g5_decoder_grads():
             assert np.abs(v.grad.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (key, k)
         n += 1
     assert n == 3
+
+
+def test_g6_miss_ray():
+    """Oracle get_miss_ray vs the reference's LIDF.get_miss_ray on float masks."""
+    g = load("g6_miss_ray.npz")
+    for key in ("a", "b", "c"):
+        mask = torch.from_numpy(g[key + "_mask"])
+        intr = torch.from_numpy(g[key + "_intr"])
+        res = orc.get_miss_ray(mask, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3])
+        for k in ("miss_bid", "miss_flat_img_id", "miss_img_ind"):
+            assert (res[k].numpy() == g[key + "_" + k]).all(), (key, k)
+        assert np.abs(res["miss_ray_dir"].numpy() - g[key + "_miss_ray_dir"]).max() == 0.0
