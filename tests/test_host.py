@@ -35,15 +35,33 @@ def test_library_exports_every_declared_symbol():
     assert L.lidf_decoders_workspace_bytes(10, 385) > 0
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """Every ctypes mirror in _lib.py against the C compiler's view of include/lidf_hip.h: size of
+    the struct and offset of every field (gcc compiles a probe that prints them)."""
     import ctypes as C
+    import subprocess
     from implicit_depth_amd import _lib
-    # LidfDecoder: 10 pointers + 4 x 4-byte fields; LidfQueryArgs: as declared, natural alignment
-    assert C.sizeof(_lib.LidfDecoder) == 10 * 8 + 16
-    assert C.sizeof(_lib.LidfQueryArgs) % 8 == 0
-    # workspace_bytes, two events, rayfeat_out, precision (+ padding to 8)
-    assert _lib.LidfQueryArgs.workspace_bytes.offset + 8 + 24 + 8 == C.sizeof(_lib.LidfQueryArgs)
-    assert _lib.LidfQueryArgs.precision.offset == _lib.LidfQueryArgs.rayfeat_out.offset + 8
+    structs = [n for n in dir(_lib) if n.startswith("Lidf") and isinstance(getattr(_lib, n), type)
+               and issubclass(getattr(_lib, n), C.Structure)]
+    assert {"LidfDecoder", "LidfQueryArgs", "LidfRefineArgs", "LidfPointNet", "LidfDecoderGrads",
+            "LidfQueryTrainArgs"} <= set(structs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lidf_hip.h"', 'int main(void){']
+    for n in structs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (n, n))
+        for f, _ in getattr(_lib, n)._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (n, f, n, f))
+    lines.append("return 0;}")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = dict(ln.split() for ln in out.strip().splitlines())
+    for n in structs:
+        cls = getattr(_lib, n)
+        assert int(seen[n]) == C.sizeof(cls), n
+        for f, _ in cls._fields_:
+            assert int(seen["%s.%s" % (n, f)]) == getattr(cls, f).offset, (n, f)
 
 
 def test_modules_keep_reference_interface():
