@@ -173,5 +173,7 @@ def test_embed_large_and_nonfinite(cuda):
     gb = fn(bad.to(cuda)).cpu()
     rb = orc.embed(bad, 8)
     assert (torch.isnan(gb) == torch.isnan(rb)).all()
-    ok = ~torch.isnan(rb)
+    inf = torch.isinf(rb)                      # the passed-through input columns
+    assert (gb[inf] == rb[inf]).all()
+    ok = torch.isfinite(rb)
     assert (gb[ok] - rb[ok]).abs().max().item() <= 1e-6
