@@ -83,7 +83,7 @@ class LidfRefineArgs(C.Structure):
         ("offset_range0", C.c_float), ("offset_range1", C.c_float),
         ("pred_pos_out", C.c_void_p), ("end_voxel_id", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("pnet_select", C.c_void_p),
     ]
 
 

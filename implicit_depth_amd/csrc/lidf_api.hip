@@ -71,7 +71,8 @@ hipError_t lidf_launch_vox_points(const float*, const int*, const int*, const in
 hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, long long,
                                    const float*, const int*, long long, const int*, const int*,
                                    const float*, long long, const float*, int, int, int, int, int,
-                                   long long, float*, int*, float*, int, int*, hipStream_t);
+                                   long long, float*, int*, float*, int, int*, const unsigned char*,
+                                   hipStream_t);
 hipError_t lidf_launch_refine_gather(const float*, const int*, long long, float*, int, hipStream_t);
 hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, float, float,
                                      long long, float*, hipStream_t);
@@ -803,7 +804,7 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
                                       q->rgb_img, (long long)q->height * q->width, q->rayfeat,
                                       128 + Ed, q->multires_views, q->multires, q->pnet_pos_rel,
                                       q->pos_rel, R, pnet_inp + (size_t)Nv * 6, pnet_vox + Nv,
-                                      inp_embed, D, end_voxel, st));
+                                      inp_embed, D, end_voxel, q->pnet_select, st));
     if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
         return rc;

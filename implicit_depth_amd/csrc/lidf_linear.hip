@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
             SCHED_FENCE();
         }
         // ---- epilogue: this lane holds, per tile t and group g, features 32t + 8g + 4h + {0..3}
-        const float* ar =
-            (valid && a.addrows) ? a.addrows + (size_t)a.addidx[p] * a.ld_add + 4 * h : nullptr;
+        // a negative index = this row takes no part (its gathered term is absent, it is not pooled)
+        const int ai = (valid && a.addrows) ? a.addidx[p] : -1;
+        const float* ar = ai >= 0 ? a.addrows + (size_t)ai * a.ld_add + 4 * h : nullptr;
         const float* ar2 =
             (valid && a.addrows2) ? a.addrows2 + (size_t)a.addidx2[p] * a.ld_add2 + 4 * h : nullptr;
         float* op = (valid && a.out) ? a.out + (size_t)p * a.ld_out + 4 * h : nullptr;
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
             // and only where a plain (possibly stale; entries only grow) read does not already
             // prove them unnecessary. More than 4 distinct voxels: per-lane atomics.
             const int vox = valid ? a.poolidx[p] : -1;
-            unsigned todo = (unsigned)__ballot(valid && h == 0);
+            unsigned todo = (unsigned)__ballot(valid && h == 0 && vox >= 0);
             int rounds = 0;
             while (todo && rounds < 4) {
                 const int lead = __builtin_ctz(todo);

@@ -29,7 +29,8 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
                                         int L, int pnet_rel, int pos_rel, long long R,
                                         float* __restrict__ pnet_inp, int* __restrict__ pnet_vox,
                                         float* __restrict__ inp_embed, int ld_e,
-                                        int* __restrict__ end_voxel) {
+                                        int* __restrict__ end_voxel,
+                                        const unsigned char* __restrict__ pnet_select) {
     __shared__ float s_vb[256 * 6];
     __shared__ int s_bid[256];
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +59,9 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
     const float* vb = vbound + 6 * (size_t)ev;
     const float cx = (vb[0] + vb[3]) / 2.f, cy = (vb[1] + vb[4]) / 2.f, cz = (vb[2] + vb[5]) / 2.f;
     end_voxel[r] = ev;
-    pnet_vox[r] = ev;
+    // use_all_pix == False (pipeline.py:987-996): an unselected ray's point stays out of the
+    // PointNet — voxel index -1 is skipped by the pooling and gather epilogues
+    pnet_vox[r] = (!pnet_select || pnet_select[r]) ? ev : -1;
     float* pi = pnet_inp + 6 * r;
     pi[0] = pnet_rel ? x - cx : x;
     pi[1] = pnet_rel ? y - cy : y;
@@ -91,12 +94,13 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
                                               const float* rayfeat, int ld_rf, int Lv, int L,
                                               int pnet_rel, int pos_rel, long long R,
                                               float* pnet_inp, int* pnet_vox, float* inp_embed,
-                                              int ld_e, int* end_voxel, hipStream_t st) {
+                                              int ld_e, int* end_voxel,
+                                              const unsigned char* pnet_select, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
                        st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid,
                        ray_flat, rgb, hw, rayfeat, ld_rf, Lv, L, pnet_rel, pos_rel, R, pnet_inp,
-                       pnet_vox, inp_embed, ld_e, end_voxel);
+                       pnet_vox, inp_embed, ld_e, end_voxel, pnet_select);
     return hipGetLastError();
 }
 

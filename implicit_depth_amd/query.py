@@ -59,17 +59,9 @@ def ray_dirs(fx, fy, cx, cy, h, w):
 MASK_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.bool: 1, torch.int32: 2, torch.int64: 3}
 
 
-def get_miss_ray(mask, fx, fy, cx, cy):
-    """LIDF.get_miss_ray (models/pipeline.py:203-269), eval flavour: the pixels where `mask`
-    ([bs,h,w] or [bs,1,h,w]; float, bool/uint8, int32 or int64 — data_dict['pred_mask'] /
-    ['corrupt_mask']) is non-zero, in torch.nonzero's (image, pixel) order, with their ray
-    directions — mark, scan and compact on the device (lidf_miss_ray_count / _fill_f32).
-
-    Returns the reference's data_dict entries miss_bid [R] i64, miss_flat_img_id [R] i64,
-    miss_ray_dir [R,3] f32, miss_img_ind [R,2] i64 (x, y), total_miss_sample_num, plus the int32
-    forms the query kernels take: ray_bid, ray_flat [R], ray_pix [R,2]. R == 0 is the reference's
-    'no miss ray' early exit (pipeline.py:676, :686-687). The train-only random window of
-    pipeline.py:232-254 is a slice [start:start+miss_sample_num] of these outputs per image."""
+def _compact_mask(mask, intr):
+    """mark -> scan -> compact of the non-zero pixels of mask [bs,h,w] (lidf_miss_ray_count /
+    lidf_miss_ray_fill_f32); intr [bs,4] or None (no ray directions)."""
     if mask.dim() == 4 and mask.shape[1] == 1:
         mask = mask[:, 0]
     if mask.dim() != 3:
@@ -77,10 +69,9 @@ def get_miss_ray(mask, fx, fy, cx, cy):
     if mask.dtype not in MASK_DTYPES:
         raise RuntimeError("mask dtype %s is not supported" % mask.dtype)
     mask = mask.contiguous()
-    intr = torch.stack((fx.float(), fy.float(), cx.float(), cy.float()), 1).contiguous()
     _lib.require_cuda(mask, intr, names=["mask", "intrinsics"])
     bs, h, w = mask.shape
-    if intr.shape[0] != bs:
+    if intr is not None and intr.shape[0] != bs:
         raise RuntimeError("fx/fy/cx/cy must have one entry per image")
     dev = mask.device
     L = _lib.lib()
@@ -98,17 +89,40 @@ def get_miss_ray(mask, fx, fy, cx, cy):
         out = {
             "ray_bid": torch.empty((R,), **i32), "ray_flat": torch.empty((R,), **i32),
             "ray_pix": torch.empty((R, 2), **i32),
-            "miss_ray_dir": torch.empty((R, 3), dtype=torch.float32, device=dev),
             "miss_bid": torch.empty((R,), **i64), "miss_flat_img_id": torch.empty((R,), **i64),
             "miss_img_ind": torch.empty((R, 2), **i64), "total_miss_sample_num": R,
         }
+        if intr is not None:
+            out["miss_ray_dir"] = torch.empty((R, 3), dtype=torch.float32, device=dev)
         if R > 0:
             _lib.check(L.lidf_miss_ray_fill_f32(
                 _lib.ptr(mask), mt, _lib.ptr(intr), bs, h, w, _lib.ptr(ws), wsb,
                 _lib.ptr(out["ray_bid"]), _lib.ptr(out["ray_flat"]), _lib.ptr(out["ray_pix"]),
-                _lib.ptr(out["miss_ray_dir"]), _lib.ptr(out["miss_bid"]),
+                _lib.ptr(out.get("miss_ray_dir")), _lib.ptr(out["miss_bid"]),
                 _lib.ptr(out["miss_flat_img_id"]), _lib.ptr(out["miss_img_ind"]), st))
     return out
+
+
+def get_miss_ray(mask, fx, fy, cx, cy):
+    """LIDF.get_miss_ray (models/pipeline.py:203-269), eval flavour: the pixels where `mask`
+    ([bs,h,w] or [bs,1,h,w]; float, bool/uint8, int32 or int64 — data_dict['pred_mask'] /
+    ['corrupt_mask']) is non-zero, in torch.nonzero's (image, pixel) order, with their ray
+    directions — mark, scan and compact on the device (lidf_miss_ray_count / _fill_f32).
+
+    Returns the reference's data_dict entries miss_bid [R] i64, miss_flat_img_id [R] i64,
+    miss_ray_dir [R,3] f32, miss_img_ind [R,2] i64 (x, y), total_miss_sample_num, plus the int32
+    forms the query kernels take: ray_bid, ray_flat [R], ray_pix [R,2]. R == 0 is the reference's
+    'no miss ray' early exit (pipeline.py:676, :686-687). The train-only random window of
+    pipeline.py:232-254 is a slice [start:start+miss_sample_num] of these outputs per image."""
+    intr = torch.stack((fx.float(), fy.float(), cx.float(), cy.float()), 1).contiguous()
+    return _compact_mask(mask, intr)
+
+
+def nonzero_pixels(mask):
+    """torch.nonzero(mask.view(bs,-1)) of LIDF.get_valid_points (models/pipeline.py:144-146) with
+    the same device compaction: {'bid', 'flat'} int64 [N]."""
+    out = _compact_mask(mask, None)
+    return {"bid": out["miss_bid"], "flat": out["miss_flat_img_id"]}
 
 
 def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid):
@@ -288,7 +302,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                 forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
                 offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None,
-                precision="f32"):
+                precision="f32", pnet_select=None):
     """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
     `forward_times` iterations of get_pred_refine through lidf_refine_f32.
 
@@ -296,6 +310,9 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     voxel_bid [V] i32; rgb_img [B,3,h,w]; feat_grid [B,32,h,w] (data_dict['full_rgb_feat']);
     valid_inp [Nv,6] = cat(valid_v_rel_coord, valid_v_rgb), valid_vox [Nv] i32 = revidx;
     pnet_model: pointnet.PointNet2Stage (refine), offset_dec: decoders.IEF/IMNet (D = 334).
+    pnet_select: None = refine.use_all_pix True (shipped configs); [R] mask (bool / uint8 / float,
+    non-zero = selected) = the mask_type 'all', use_all_pix False branch (pipeline.py:987-996): pass
+    inp_zero_mask = 1 - valid_mask at the rays' pixels.
     Returns pred_pos_refine [R,3] and the last iteration's end_voxel_id [R] i32."""
     from .pointnet import check_pointnet, pointnet_struct
     ts = [ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
@@ -329,6 +346,11 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     do = _decoder_struct(offset_dec, keep)
     cur = pred_pos.contiguous()
     end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
+    if pnet_select is not None:
+        pnet_select = (pnet_select.reshape(-1) != 0).to(torch.uint8).contiguous()
+        _lib.require_cuda(pnet_select, names=["pnet_select"])
+        if pnet_select.shape[0] != R:
+            raise RuntimeError("pnet_select must have one entry per ray")
     for _ in range(forward_times):
         out = torch.empty((R, 3), dtype=torch.float32, device=dev)
         q = _lib.LidfRefineArgs()
@@ -348,6 +370,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         q.precision = PRECISIONS[precision]
+        q.pnet_select = pnet_select.data_ptr() if pnet_select is not None else None
         with torch.cuda.device(dev):
             _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out

@@ -94,3 +94,46 @@ def synthetic_scene(B, h, w, N, seed, ragged=False, weight_scale=5.0, multires=8
         "prob_p": init_decoder_params("IMNET", D, 7, weight_scale),
         "off_p": init_decoder_params("IEF", D, 8, weight_scale), "intr": intr.contiguous(),
     }
+
+
+def synthetic_batch(B, h, w, seed, hole_frac=1.0):
+    """A geometry-derived ClearGrasp-shaped batch (the keys of the reference's dataset items,
+    datasets/cleargrasp_dataset.py:165-180): a slanted table with boxes and a sphere in front of
+    it, elliptical holes where transparent objects corrupt the depth (corrupt_mask = 1,
+    depth_corrupt = 0), camera-frame points inside the reference's grid bounds
+    (utils/constants.py:15-16). Also returns a smooth 32-channel map standing in for the ResNet
+    output `full_rgb_feat` (the producer is upstream of the path). Ragged by construction: the
+    number of occupied voxels a ray crosses varies from 0 to ~10."""
+    g = torch.Generator().manual_seed(seed)
+    ray_dir, _, intr = pixel_rays(B, h, w)
+    d = ray_dir.reshape(B, h, w, 3)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) / h,
+                            torch.arange(w, dtype=torch.float32) / w, indexing="ij")
+    depth = torch.empty(B, h, w)
+    hole = torch.zeros(B, 1, h, w)
+    for b in range(B):
+        z = 1.55 - 0.55 * ys + 0.10 * xs + 0.02 * b
+        for k in range(4):   # boxes standing on the table
+            x0, y0 = 0.08 + 0.22 * k + 0.03 * b, 0.25 + 0.1 * ((k + b) % 3)
+            m = (xs > x0) & (xs < x0 + 0.14) & (ys > y0) & (ys < y0 + 0.3)
+            z = torch.where(m, z - (0.15 + 0.06 * k), z)
+        cxs, cys, rad = 0.55 + 0.05 * b, 0.62, 0.16   # a sphere
+        rr = ((xs - cxs) ** 2 + ((ys - cys) * h / w) ** 2) / rad ** 2
+        z = torch.where(rr < 1, z - 0.3 * torch.sqrt((1 - rr).clamp(min=0)), z)
+        depth[b] = z
+        for k in range(3):   # transparent objects: elliptical holes in the measured depth
+            ex, ey = 0.2 + 0.3 * k + 0.02 * b, 0.45 + 0.12 * ((k + b) % 2)
+            e = ((xs - ex) / (0.07 * hole_frac)) ** 2 + ((ys - ey) / (0.16 * hole_frac)) ** 2
+            hole[b, 0] = torch.maximum(hole[b, 0], (e < 1).float())
+    xyz = (d / d[..., 2:3] * depth.unsqueeze(-1)).permute(0, 3, 1, 2).contiguous()
+    coarse = torch.randn(B, 3, max(h // 6, 1), max(w // 6, 1), generator=g)
+    rgb = F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+    coarse = torch.randn(B, 32, max(h // 8, 1), max(w // 8, 1), generator=g)
+    feat = F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False).contiguous()
+    batch = {
+        "rgb": rgb, "xyz": xyz, "xyz_corrupt": xyz * (1 - hole),
+        "depth_corrupt": depth.unsqueeze(1) * (1 - hole), "corrupt_mask": hole.clone(),
+        "valid_mask": 1 - hole, "fx": intr[:, 0].clone(), "fy": intr[:, 1].clone(),
+        "cx": intr[:, 2].clone(), "cy": intr[:, 3].clone(), "item_path": ["synthetic_%d" % b for b in range(B)],
+    }
+    return batch, feat

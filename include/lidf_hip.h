@@ -260,7 +260,8 @@ int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n_pts, int b
  * Replaces PointNet2Stage.forward (models/pointnet.py:22-38) incl. its two
  * torch_scatter.scatter(..., reduce='max') poolings, for the shipped dimensions
  * (input_channels 6, gf_dim 32, output_channels 128). Weights: nn.Linear storage [out,in].
- * inp [N,6] f32, vox [N] i32 (vox2point_idx: voxel of every point, < n_vox) -> out [n_vox,128]. */
+ * inp [N,6] f32, vox [N] i32 (vox2point_idx: voxel of every point, < n_vox; a negative entry
+ * leaves that point out of both poolings) -> out [n_vox,128].                                    */
 typedef struct LidfPointNet {
     const float *w_p1, *b_p1; /* point_lin1 [32,6]    */
     const float *w_p2, *b_p2; /* point_lin2 [64,32]   */
@@ -276,7 +277,7 @@ int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vo
 
 /* ---- Stage-2 refinement query -------------------------------------------------------------
  * One iteration of RefineNet.get_pred_refine (models/pipeline.py:922-1030), eval flavour
- * (no perturbation, mask_type 'all' with refine.use_all_pix): end voxel of every ray, PointNet
+ * (no perturbation; refine.use_all_pix True or, with pnet_select, False): end voxel of every ray, PointNet
  * over (valid points + predicted points), [voxel feature | ROI feature | embed(pos) | embed(dir)]
  * -> IEF (D = 256 + 3+6*multires + 3+6*multires_views) -> pred_pos + offset * ray_dir.
  * RefineNet.forward (:1032-1041) calls it refine.forward_times times, feeding pred_pos_out back. */
@@ -309,6 +310,11 @@ typedef struct LidfRefineArgs {
     void* workspace;
     size_t workspace_bytes;
     int32_t precision;           /* LIDF_PRECISION_F32 (0) / LIDF_PRECISION_F16X3: the refine IEF  */
+    /* mask_type 'all' with refine.use_all_pix == False (models/pipeline.py:987-996): [R] bytes, only
+     * rays with a non-zero entry (inp_zero_mask = 1 - valid_mask at the ray's pixel) feed their
+     * predicted point back into the PointNet; every ray is still refined. NULL = all rays
+     * (refine.use_all_pix == True, the shipped configs).                                         */
+    const uint8_t* pnet_select;
 } LidfRefineArgs;
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);

@@ -502,8 +502,10 @@ def pointnet2stage(p, inp, vox, n_vox):
 def refine_step(pred_pos, ray_dir, ray_pix, ray_bid, ray_flat, max_pair_id, pair_vox, voxel_bound,
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_p, off_p, off_kind="IEF",
                 n_iter=2, multires=8, multires_views=4, roi_inp_bbox=8, offset_range=(-0.2, 0.2),
-                pos_rel=False, pnet_pos_rel=True, ray_rgb=None):
-    """One get_pred_refine call. Returns (pred_pos_refine, end_voxel_id, occ_voxel_feat)."""
+                pos_rel=False, pnet_pos_rel=True, ray_rgb=None, pnet_select=None):
+    """One get_pred_refine call. Returns (pred_pos_refine, end_voxel_id, occ_voxel_feat).
+    pnet_select [R] bool: the mask_type 'all' / refine.use_all_pix False branch
+    (models/pipeline.py:987-996) — only the selected rays' predicted points join the PointNet."""
     R, P, V = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0]
     h, w = rgb_img.shape[2], rgb_img.shape[3]
     # end voxel: arg-max pair's voxel (dummy row -> 0), raised to the largest containing voxel
@@ -522,14 +524,69 @@ def refine_step(pred_pos, ray_dir, ray_pix, ray_bid, ray_flat, max_pair_id, pair
     eb = voxel_bound[end_voxel]
     center = (eb[:, :3] + eb[:, 3:]) / 2.0
     pred_inp = torch.cat(((pred_pos - center) if pnet_pos_rel else pred_pos, miss_rgb), 1)
-    pn_inp = torch.cat((valid_inp, pred_inp), 0)
-    pn_vox = torch.cat((valid_vox.long(), end_voxel), 0)
+    if pnet_select is not None:
+        sel = torch.nonzero(pnet_select.reshape(-1), as_tuple=False)[:, 0]
+        pn_inp = torch.cat((valid_inp, pred_inp[sel]), 0)
+        pn_vox = torch.cat((valid_vox.long(), end_voxel[sel]), 0)
+    else:
+        pn_inp = torch.cat((valid_inp, pred_inp), 0)
+        pn_vox = torch.cat((valid_vox.long(), end_voxel), 0)
     occ_voxel_feat = pointnet2stage(pnet_p, pn_inp, pn_vox, V)
     enter = (pred_pos - center) if pos_rel else pred_pos
     inp = torch.cat((occ_voxel_feat[end_voxel], ray_rgb, embed(enter, multires), e_dir), -1)
     off = decoder_forward(off_p, inp, off_kind, n_iter)
     scaled = off * (offset_range[1] - offset_range[0]) + offset_range[0]
     return pred_pos + scaled * ray_dir, end_voxel, occ_voxel_feat
+
+
+def lidf_forward(batch, full_rgb_feat, pnet_p, prob_p, off_p, valid_stride=None, multires=8,
+                 multires_views=4, offset_range=(0.0, 1.0), fast_roi=True):
+    """LIDF.forward, exp_type 'test', mask_type 'all' (models/pipeline.py:652-717) as a chain of the
+    restatements above: prepare_data (:91-133), get_valid_points with every valid pixel (:135-160;
+    optionally every valid_stride-th), get_occ_vox_bound, get_miss_ray, compute_ray_aabb,
+    PointNet2Stage, get_embedding + get_pred, and the depth map of compute_loss (:593-596).
+    Returns (success, dict)."""
+    rgb = batch["rgb"]
+    bs, _, h, w = rgb.shape
+    dd = {"bs": bs, "h": h, "w": w}
+    xyz_corrupt_flat = batch["xyz_corrupt"].permute(0, 2, 3, 1).contiguous().reshape(bs, -1, 3)
+    valid_mask = 1 - (batch["depth_corrupt"] == 0).squeeze(1).float()
+    pred_mask = torch.ones_like(batch["corrupt_mask"].squeeze(1))
+    valid_idx = torch.nonzero(valid_mask.reshape(bs, -1), as_tuple=False)
+    if valid_stride and valid_stride > 1:
+        valid_idx = valid_idx[::valid_stride]
+    vb_, vf_ = valid_idx[:, 0], valid_idx[:, 1]
+    valid_xyz = xyz_corrupt_flat[vb_, vf_]
+    valid_rgb = rgb.permute(0, 2, 3, 1).contiguous().reshape(bs, -1, 3)[vb_, vf_]
+    occ = occupied_voxels(valid_xyz, vb_)
+    dd.update(occ)
+    dd.update({"valid_mask": valid_mask, "valid_xyz": valid_xyz, "valid_rgb": valid_rgb, "valid_bid": vb_})
+    V = occ["voxel_bound"].shape[0]
+    if V == 0:
+        return False, dd
+    mr = get_miss_ray(pred_mask, batch["fx"].float(), batch["fy"].float(), batch["cx"].float(),
+                      batch["cy"].float())
+    dd.update(mr)
+    if mr["total_miss_sample_num"] == 0:
+        return False, dd
+    mask, dist = ray_aabb(mr["miss_ray_dir"].numpy(), occ["voxel_bound"].numpy(),
+                          mr["miss_bid"].numpy(), occ["occ_vox_bid"].numpy())
+    pair_ray, pair_vox, pair_t, pair_off = pairs_from_dense(mask, dist)
+    dd.update({"pair_ray": pair_ray, "pair_vox": pair_vox, "pair_t": pair_t, "pair_off": pair_off})
+    if pair_ray.shape[0] == 0:
+        return False, dd
+    pnet_inp = torch.cat((occ["valid_v_rel_coord"], valid_rgb[occ["valid_v_pid"]]), -1)
+    dd["pnet_inp"] = pnet_inp
+    dd["occ_voxel_feat"] = pointnet2stage(pnet_p, pnet_inp, occ["revidx"], V)
+    out = query(mr["miss_ray_dir"], mr["miss_img_ind"], mr["miss_bid"], pair_ray, pair_vox, pair_t,
+                pair_off, full_rgb_feat, dd["occ_voxel_feat"], prob_p, off_p, multires=multires,
+                multires_views=multires_views, offset_range=offset_range,
+                part_size=occ["part_size"], fast_roi=fast_roi)
+    dd.update(out)
+    pred_xyz = xyz_corrupt_flat.clone()
+    pred_xyz[mr["miss_bid"], mr["miss_flat_img_id"]] = out["pred_pos"]
+    dd["pred_depth"] = pred_xyz[:, :, 2].reshape(bs, h, w)
+    return True, dd
 
 
 def init_pointnet(seed, scale=1.0):

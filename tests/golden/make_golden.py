@@ -13,6 +13,8 @@ Python modules are imported and executed, and only their inputs/outputs are stor
                     parameter) for a closed-form upstream gradient   (models/implicit_net.py:60-152)
   g6_miss_ray.npz   LIDF.get_miss_ray on float masks (holes, an empty image, -0.0, tiny values)
                                                                        (models/pipeline.py:203-269)
+  g7_refine_select.npz  the same two refine iterations with refine.use_all_pix = False
+                                                                       (models/pipeline.py:987-996)
   g4_refine.npz     RefineNet.get_pred_refine x 2 on the same batch (stage 2), incl. the refine
                     PointNet2Stage outputs                     (models/pipeline.py:922-1041, pointnet.py)
 
@@ -278,6 +280,21 @@ def g3_pipeline():
     }
     print("g4: Nv=%d Dr=%d" % (g4["valid_inp"].shape[0], Dr))
     np.savez_compressed(os.path.join(HERE, "g4_refine.npz"), **g4)
+
+    # ---- g7: the same two iterations with refine.use_all_pix = False (pipeline.py:987-996): only
+    # the predicted points of zero-depth input pixels are fed back into the PointNet
+    opt2.refine.use_all_pix = False
+    feats = []
+    hk = refine.pnet_model.register_forward_hook(lambda m, i, o: feats.append(o.detach().clone()))
+    with torch.no_grad():
+        q1 = refine.get_pred_refine(dd, dd["pred_pos"], "test", 0)
+        q2 = refine.get_pred_refine(dd, q1, "test", 1)
+    hk.remove()
+    g7 = {"inp_zero_mask": (1 - dd["valid_mask"]).numpy(), "pred_pos_refine_1": q1.numpy(),
+          "pred_pos_refine_2": q2.numpy(), "occ_voxel_feat_1": feats[0].numpy(),
+          "occ_voxel_feat_2": feats[1].numpy()}
+    print("g7: selected pixels = %d of %d" % (int(g7["inp_zero_mask"].sum()), g7["inp_zero_mask"].size))
+    np.savez_compressed(os.path.join(HERE, "g7_refine_select.npz"), **g7)
 
 
 def g6_miss_ray():

@@ -106,7 +106,7 @@ def test_g3_query_matches_reference_trace():
     assert np.abs(res["ray_rgb"][pr].numpy() - g["intersect_rgb_feat"]).max() == 0.0
 
 
-def g4_oracle(g3, g4):
+def g4_oracle(g3, g4, pnet_select=None):
     """Oracle refine iterations on the reference's stage-1 trace; returns per-iteration outputs."""
     from util import closed_form_pointnet
     h, w, ray_dir, ray_pix, ray_bid, ray_flat, vb, vbid = g3_inputs(g3)
@@ -121,7 +121,8 @@ def g4_oracle(g3, g4):
             pos, ray_dir, ray_pix, ray_bid, ray_flat, res["max_pair_id"], pair_vox, vb, vbid,
             torch.from_numpy(g4["rgb_img"]), torch.from_numpy(g3["full_rgb_feat"]),
             torch.from_numpy(g4["valid_inp"]), torch.from_numpy(g4["valid_vox"]), pnet_p, off_p,
-            offset_range=tuple(float(v) for v in g4["offset_range"]), ray_rgb=res["ray_rgb"])
+            offset_range=tuple(float(v) for v in g4["offset_range"]), ray_rgb=res["ray_rgb"],
+            pnet_select=pnet_select)
         outs.append((pos, ev, feat))
     return outs
 
@@ -132,6 +133,17 @@ def test_g4_refine_matches_reference_trace():
     for i, (pos, ev, feat) in enumerate(outs, 1):
         assert np.abs(feat.numpy() - g4["occ_voxel_feat_%d" % i]).max() <= 2e-6
         assert np.abs(pos.numpy() - g4["pred_pos_refine_%d" % i]).max() <= 2e-6
+
+
+def test_g7_refine_select_matches_reference_trace():
+    """refine.use_all_pix = False (pipeline.py:987-996): only zero-depth pixels feed the PointNet."""
+    g3, g4, g7 = load("g3_pipeline.npz"), load("g4_refine.npz"), load("g7_refine_select.npz")
+    sel = torch.from_numpy(g7["inp_zero_mask"]).reshape(-1) != 0
+    outs = g4_oracle(g3, g4, pnet_select=sel)
+    for i, (pos, ev, feat) in enumerate(outs, 1):
+        assert np.abs(feat.numpy() - g7["occ_voxel_feat_%d" % i]).max() <= 2e-6
+        assert np.abs(pos.numpy() - g7["pred_pos_refine_%d" % i]).max() <= 2e-6
+    assert np.abs(g7["pred_pos_refine_2"] - g4["pred_pos_refine_2"]).max() > 1e-5  # the branch matters
 
 
 def test_g3_occupied_voxels():
