@@ -334,6 +334,79 @@ def secondary(args):
                      "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4)}}), flush=True)
 
 
+def e2e(args):
+    """--workload e2e: the whole evaluation path of one frame, chained on the device
+    (implicit_depth_amd.pipeline): valid points -> occupied voxels -> PointNet2Stage -> miss rays ->
+    compact ray/voxel pairs -> fused query -> 2 x get_pred_refine -> eval metrics, on a ragged
+    geometry-derived frame (synthetic_batch). Host syncs included (sizes of compacted lists, as the
+    reference's nonzero()/unique() have). Secondary record, same schema."""
+    from implicit_depth_amd import IEF, IMNet, PointNet2Stage, pipeline as pl
+    from implicit_depth_amd.synthetic import init_decoder_params, synthetic_batch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B, h, w = args.frames, 240, 320
+    batch, feat = synthetic_batch(B, h, w, seed=77)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    feat = feat.to(dev)
+    torch.manual_seed(3)
+    pnet = PointNet2Stage(6, 128, 32).to(dev).eval()
+    pnet_r = PointNet2Stage(6, 128, 32).to(dev).eval()
+    prob = IMNet(385, 1, 64).to(dev).eval()
+    prob.load_state_dict(init_decoder_params("IMNET", 385, 7, 5.0))
+    off = IEF(dev, 385, 1, 64, n_iter=2).to(dev).eval()
+    off.load_state_dict(init_decoder_params("IEF", 385, 8, 5.0))
+    offr = IEF(dev, 334, 1, 64, n_iter=2).to(dev).eval()
+    offr.load_state_dict(init_decoder_params("IEF", 334, 9, 5.0))
+    # valid_sample_num = 10000 of the shipped configs, as a deterministic stride over the valid pixels
+    n_valid = int((batch["depth_corrupt"] != 0).sum().item())
+    opt = pl.LidfOptions(valid_stride=max(1, n_valid // (10000 * B)))
+    state = {"ws": None}
+
+    def step(marks=None):
+        with torch.no_grad():
+            ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=args.precision,
+                                     workspace=state["ws"], marks=marks)
+            assert ok
+            state["ws"] = dd["workspace"]
+            pl.refine_forward(dd, pnet_r, offr, opt, precision=args.precision)
+            pl._mark(marks, "refine_x2")
+            m = pl.eval_metrics(dd, "pred_depth_refine")
+            pl._mark(marks, "metrics")
+        return dd, m
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    all_marks = []
+    for _ in range(args.steps):
+        mk = []
+        dd, m = step(mk)
+        all_marks.append(mk)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stages = {}
+    for mk in all_marks:
+        for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
+            stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
+    P, R = int(dd["pair_ray"].shape[0]), int(dd["miss_ray_dir"].shape[0])
+    print(json.dumps({
+        "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),
+        "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE_F16X3 if args.precision == "f16x3" else "f32",
+        "data": "synthetic",
+        "config": {"workload": "secondary: whole evaluation path of %d 240x320 frame(s): valid points, "
+                               "occupied voxels, PointNet2Stage, miss rays, compact ray/voxel pairs, fused "
+                               "query, 2 x get_pred_refine, eval metrics; geometry-derived ragged scene" % B,
+                   "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
+                   "voxels": int(dd["voxel_bound"].shape[0]), "valid_points": int(dd["valid_xyz"].shape[0])},
+        "frames_per_s": round(B * args.steps / elapsed, 2),
+        "rays_per_s": round(R * args.steps / elapsed, 1),
+        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,8 +420,12 @@ def main():
                          "f16x3 = three f16-piece products per term with f32 accumulation (f32-level "
                          "accuracy, LidfQueryArgs.precision); the default f32 run also reports the "
                          "f16x3 rate and its deviation from the f32 outputs as \"split_f16\"")
+    ap.add_argument("--pairs", default="dense", choices=["dense", "ragged", "n1", "scene"],
+                    help="candidate list of the query workload: dense = N per ray (the headline shape); "
+                         "ragged = U{0..N} per ray; n1 = one per ray; scene = the pairs "
+                         "compute_ray_aabb finds on a geometry-derived frame (0..8 per ray)")
     ap.add_argument("--workload", default="query",
-                    choices=["query", "query+refine", "decoders", "embed", "train", "train-query"],
+                    choices=["query", "query+refine", "decoders", "embed", "train", "train-query", "e2e"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
                          "configs[3] (stage 1 + 2 x get_pred_refine); decoders = IMNet+IEF on a "
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
@@ -356,6 +433,8 @@ def main():
     args = ap.parse_args()
     if args.workload in ("decoders", "embed", "train", "train-query"):
         return secondary(args)
+    if args.workload == "e2e":
+        return e2e(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -378,9 +457,31 @@ def main():
     from implicit_depth_amd.synthetic import synthetic_scene
 
     h, w, N, B = 240, 320, args.samples, args.frames
-    scene = synthetic_scene(B, h, w, N, seed=1235 + rank)
-    P = scene["P"]
+    if args.pairs == "n1":
+        N = 1
+    scene = synthetic_scene(B, h, w, N, seed=1235 + rank, ragged=args.pairs == "ragged")
     s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    if args.pairs == "scene":
+        # rays, voxels and pairs as the candidate generator produces them on real geometry
+        from implicit_depth_amd import PointNet2Stage, pipeline as pl
+        from implicit_depth_amd.synthetic import synthetic_batch
+        batch, feat = synthetic_batch(B, h, w, seed=77 + rank)
+        torch.manual_seed(3)
+        pn = PointNet2Stage(6, 128, 32).to(dev).eval()
+        pm = IMNet(scene["D"], 1, 64).to(dev).eval()
+        om = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
+        pm.load_state_dict(scene["prob_p"]), om.load_state_dict(scene["off_p"])
+        with torch.no_grad():
+            ok, dd = pl.lidf_forward({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()},
+                                     feat.to(dev), pn, pm, om)
+        assert ok
+        s.update({"ray_dir": dd["miss_ray_dir"], "ray_pix": dd["ray_pix"], "ray_bid": dd["ray_bid"],
+                  "ray_flat": dd["ray_flat"], "pair_off": dd["pair_off"], "pair_ray": dd["pair_ray"],
+                  "pair_vox": dd["pair_vox"], "pair_t": dd["pair_t"], "feat_grid": dd["full_rgb_feat"],
+                  "vox_feat": dd["occ_voxel_feat"]})
+        scene = dict(scene, P=int(dd["pair_ray"].shape[0]), V=int(dd["occ_voxel_feat"].shape[0]))
+    P = scene["P"]
+    dense = args.pairs == "dense"
     prob = IMNet(scene["D"], 1, 64).to(dev).eval()
     prob.load_state_dict(scene["prob_p"])
     off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
@@ -444,13 +545,16 @@ def main():
         gather_ok = bool(t.item())
     split = None
     hip_f32 = None
-    if world == 1 and refine is None:
+    if world == 1 and refine is None and dense:
         hip_f32 = step()   # outputs of the measured configuration, kept for the parity record
         hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos",
                                                    "pred_pos", "max_pair_id")}
         hip_f32["depth"] = depth.clone()
     hip_h = None
     if world == 1 and args.precision == "f32" and refine is None:
+        if hip_f32 is None:
+            hip_f32 = step()
+            hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos")}
         # the same workload through the split-f16 kernel: rate, and deviation from the f32 outputs
         for _ in range(args.warmup):
             step(precision="f16x3")
@@ -524,7 +628,13 @@ def main():
                                   "inside_timed_region": True, "gathered_equals_local": gather_ok}
         if split is not None:
             line["split_f16"] = split
-        if world == 1 and not args.no_cpu_baseline:
+        if not dense:
+            line["config"]["pairs"] = {"kind": args.pairs, "points": P, "rays": scene["R"],
+                                       "pairs_per_ray": round(P / scene["R"], 3)}
+            line["config"]["workload"] = line["config"]["workload"].replace(
+                "configs[1]", "secondary (not the headline shape): %s candidate list" % args.pairs)
+            line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.pairs
+        if world == 1 and not args.no_cpu_baseline and dense:
             cb, ref = cpu_baseline(scene)
             line["cpu_baseline"] = cb
             if hip_f32 is not None:

@@ -171,12 +171,16 @@ extern "C" hipError_t lidf_launch_pack(const StreamLayout& lay, const NetW& n0, 
 // is the whole activation, implicit_net.py:83)
 template <int LO, int HI>
 __device__ __forceinline__ void lrelu_part(f32x16& v) {
+    // two values per v_pk_mul_f32, one v_max_f32 each
 #pragma unroll
-    for (int i = LO; i < HI; ++i) {
-        const float x = v[i], t = x * 0.02f;
-        float r;
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
-        v[i] = r;
+    for (int i = LO; i < HI; i += 2) {
+        f32x2 x = {v[i], v[i + 1]};
+        const f32x2 t = x * 0.02f;
+        float r0, r1;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(x[0]), "v"(t[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x[1]), "v"(t[1]));
+        v[i] = r0;
+        v[i + 1] = r1;
     }
 }
 
@@ -213,11 +217,51 @@ __device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, flo
 // `ring` holds the next 8 quads of the stream on entry (u0, u1, first six layer-2 quads) and the
 // next 8 quads after the pass on exit: the pass's own first quads again when wrap_base ==
 // pass_base (another pass of the same net follows) or the first quads of the next block.
+//
+// Prefetch of the next layer-1 accumulator init: while layer 2 runs, the pass copies the voxpart
+// row that the NEXT net / tile starts from (32 x 16 bytes per lane, address vox_rows + vp_off)
+// into this wavefront's 32 KiB of LDS with global -> LDS DMA (global_load_lds_dwordx4: no register
+// is held, nothing waits); the caller moves it from LDS into `base` once the passes of the net
+// are over. Slot j (tile j/4, register group j%4) of lane l sits at lds_wave + j*1024 + l*16.
+#define LIDF_PF_S0 36  // first DMA step (every H1 tile exists after step 26); one every 2nd step
+#define LIDF_PF_S1 (LIDF_U_QUADS + 4 * LIDF_L2_QUADS + 1)  // first LDS -> base step (layer 3)
+typedef __attribute__((address_space(3))) float lds_float;
+// Issued as inline assembly on purpose: when the compiler sees LDS-DMA and ordinary buffer loads
+// share vmcnt it assumes they may complete out of order and drains the queue (s_waitcnt vmcnt(0))
+// every few steps — the weight ring would stall eight times per pass. Hidden from its counter the
+// DMA only makes the ring waits slightly stricter (the compiler under-counts what is in flight), so
+// it is issued every second step. M0 (LDS base of the transfer) is not used by anything else in
+// this kernel. The instruction offset is added to the global AND the LDS address: global row
+// offset 32 j bytes, LDS slot offset 1024 j bytes -> M0 = wave base + 992 j.
+#define LIDF_DMA_CASE(J)                                                                     \
+    case J:                                                                                  \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"  \
+                     :                                                                       \
+                     : "s"(lds_addr + (J) * 992), "v"(vp_off), "s"(vox_rows), "n"(32 * (J))   \
+                     : "memory");                                                            \
+        break;
+__device__ __forceinline__ void dma_slot(const char* vox_rows, const unsigned vp_off,
+                                         const unsigned lds_addr, const int j) {
+    switch (j) {
+        LIDF_DMA_CASE(0) LIDF_DMA_CASE(1) LIDF_DMA_CASE(2) LIDF_DMA_CASE(3) LIDF_DMA_CASE(4)
+        LIDF_DMA_CASE(5) LIDF_DMA_CASE(6) LIDF_DMA_CASE(7) LIDF_DMA_CASE(8) LIDF_DMA_CASE(9)
+        LIDF_DMA_CASE(10) LIDF_DMA_CASE(11) LIDF_DMA_CASE(12) LIDF_DMA_CASE(13) LIDF_DMA_CASE(14)
+        LIDF_DMA_CASE(15) LIDF_DMA_CASE(16) LIDF_DMA_CASE(17) LIDF_DMA_CASE(18) LIDF_DMA_CASE(19)
+        LIDF_DMA_CASE(20) LIDF_DMA_CASE(21) LIDF_DMA_CASE(22) LIDF_DMA_CASE(23) LIDF_DMA_CASE(24)
+        LIDF_DMA_CASE(25) LIDF_DMA_CASE(26) LIDF_DMA_CASE(27) LIDF_DMA_CASE(28) LIDF_DMA_CASE(29)
+        LIDF_DMA_CASE(30) LIDF_DMA_CASE(31)
+        default: break;
+    }
+}
+template <bool PF>
 __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, const int vq,
                                               f32x4 (&ring)[LIDF_RING], const int pass_base,
-                                              const int wrap_base, const f32x16 (&base)[8],
+                                              const int wrap_base, f32x16 (&base)[8],
                                               const float val, const int h, const float one_b,
-                                              const float* __restrict__ ax
+                                              const float* __restrict__ ax,
+                                              const char* __restrict__ vox_rows,
+                                              const unsigned vp_off, const unsigned lds_addr,
+                                              const lds_float* lds_wave, const int lane
 #ifdef LIDF_PROFILE
                                               , long long& prof_t, long long (&prof_acc)[8]
 #endif
@@ -235,6 +279,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                            0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 H1[8], H2[4], H3[2];
     f32x4 u0, u1, w4[8];
+    f32x4 pend = {0.f, 0.f, 0.f, 0.f};
     float b4 = 0.f;
 #pragma unroll
     for (int s = 0; s < LIDF_PASS_QUADS; ++s) {
@@ -244,6 +289,26 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
             const int rel = nx < LIDF_PASS_QUADS ? nx : nx - LIDF_PASS_QUADS;
             ring[s % LIDF_RING] = LDQ(srs, vq + (rel & 3) * 1024,
                                       (nx < LIDF_PASS_QUADS ? pb : wb) + (rel >> 2) * 4096);
+        }
+        if (PF && s >= LIDF_PF_S0 && s < LIDF_PF_S0 + 64 && ((s - LIDF_PF_S0) & 1) == 0)
+            dma_slot(vox_rows, vp_off, lds_addr, (s - LIDF_PF_S0) / 2);
+        if (PF && s == LIDF_PF_S1) {
+            // the last DMA is more than 30 ring loads old and the queue completes in order: with
+            // at most 12 operations outstanding every transfer has landed (this never stalls)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+        if (PF && s >= LIDF_PF_S1 && s <= LIDF_PF_S1 + 32) {
+            // LDS -> base, one slot per step during layer 3 (the old contents are dead: this is
+            // the last pass that reads them, and it did so in its first 27 steps); the value read
+            // in step s is moved into the accumulator registers in step s+1, so nothing waits on
+            // the LDS latency
+            const int j = s - LIDF_PF_S1;
+            if (j > 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) base[(j - 1) / 4][4 * ((j - 1) % 4) + i] = pend[i];
+            }
+            if (j < 32)
+                pend = *(const __attribute__((address_space(3))) f32x4*)(lds_wave + j * 256 + 4 * lane);
         }
         if (s == 0) {
             u0 = a;
@@ -324,8 +389,20 @@ struct Geo {
     float te, tl, dx, dy, dz;
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
+// ------------------------------------------------------------------------------------------------
+// Fused per-point kernel (LIDF_MODE_FUSED): get_embedding + both decoders + pair_pred_pos.
+// Per 32-point wave-tile and per net:
+//   base  = voxpart[vid]            prefetched by the previous pass (see decoder_pass<PF>)
+//   base += W1[:, enter|leave] PE   51 k-steps x 8 tiles, embedding produced in registers
+//   base += raypart[ray]            rank-1 MFMAs, two distinct rays per instruction; the row loads
+//                                   are issued before the PE steps and consumed after them, up to
+//                                   RB rounds (2*RB rays) per batch
+//   passes (1 for the IMNet, n_iter for the IEF)
+// ------------------------------------------------------------------------------------------------
+#define LIDF_RB 4   // rank-1 rounds whose row loads are in flight together
+
+__global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
+    extern __shared__ float lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
@@ -337,6 +414,9 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
     const int net_bytes = a.net_quads * 1024;
     const int l1_bytes = a.l1_quads * 1024;
     const int Lp = (a.L + 1) / 2;
+    // this wavefront's staging area: 32 slots x 64 lanes x 16 B (wave-uniform address)
+    lds_float* lds_wave = (lds_float*)lds_raw + __builtin_amdgcn_readfirstlane(wave) * 8192;
+    const unsigned lds_addr = (unsigned)(size_t)lds_wave;
 
     // contiguous range of 128-point tiles per workgroup; the 4 waves interleave inside it
     const long long ntile = (a.n + 127) / 128;
@@ -344,6 +424,7 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
     if (tb >= te_) return;
+    if (tb * 128 + wave * 32 >= a.n) return;
 
     // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
     f32x4 ring[LIDF_RING];
@@ -364,14 +445,30 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
         g.dy = a.ray_dir[3 * (size_t)g.ray + 1];
         g.dz = a.ray_dir[3 * (size_t)g.ray + 2];
     };
+    auto vox_row = [&](int vid, int net) {
+        return a.voxpart + ((size_t)vid * a.nets + net) * 256 + 4 * h;
+    };
 
     // two-stage geometry prefetch: `cur` complete, `nxt` has its indices (directions are fetched
     // one tile ahead, indices two tiles ahead)
     Geo cur = {}, nxt = {}, nx2 = {};
-    if constexpr (MODE == LIDF_MODE_FUSED) {
-        load_idx(tb, cur);
-        load_idx(tb + 1, nxt);
-        load_dir(cur);
+    load_idx(tb, cur);
+    load_idx(tb + 1, nxt);
+    load_dir(cur);
+
+    // layer-1 accumulator of the first (tile, net): fetched here, in the open
+    f32x16 base[8];
+    {
+        const float* vp = vox_row(cur.vid, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *(const f32x4*)(vp + t * 32 + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
+            }
+        }
     }
 
     PROF_DECL
@@ -380,29 +477,214 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
         PROF(0)
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < a.n;
-        const long long pc = valid ? p : a.n - 1;
 
-        Rev rx = {}, ry = {}, rz = {};
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if constexpr (MODE == LIDF_MODE_FUSED) {
-            load_dir(nxt);
-            load_idx(tile + 2, nx2);
-            // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the
-            // leave position (pipeline.py:349-360; 'rel' subtracts the voxel centre)
-            const float t = h ? cur.tl : cur.te;
-            px = __fmul_rn(cur.dx, t);
-            py = __fmul_rn(cur.dy, t);
-            pz = __fmul_rn(cur.dz, t);
-            if (a.pos_rel) {
-                px -= a.vox_center[3 * (size_t)cur.vid + 0];
-                py -= a.vox_center[3 * (size_t)cur.vid + 1];
-                pz -= a.vox_center[3 * (size_t)cur.vid + 2];
-            }
-            rx = to_rev(px);
-            ry = to_rev(py);
-            rz = to_rev(pz);
+        load_dir(nxt);
+        load_idx(tile + 2, nx2);
+        // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the
+        // leave position (pipeline.py:349-360; 'rel' subtracts the voxel centre)
+        const float tt = h ? cur.tl : cur.te;
+        float px = __fmul_rn(cur.dx, tt);
+        float py = __fmul_rn(cur.dy, tt);
+        float pz = __fmul_rn(cur.dz, tt);
+        if (a.pos_rel) {
+            px -= a.vox_center[3 * (size_t)cur.vid + 0];
+            py -= a.vox_center[3 * (size_t)cur.vid + 1];
+            pz -= a.vox_center[3 * (size_t)cur.vid + 2];
         }
+        const Rev rx = to_rev(px), ry = to_rev(py), rz = to_rev(pz);
         PROF(1)
+
+        for (int net = 0; net < a.nets; ++net) {
+            const int nsb = net * net_bytes;  // byte offset of this net's block
+            const int next_blk = net + 1 < a.nets ? nsb + net_bytes : 0;
+
+            // ---------------- layer 1 ----------------
+            // raypart[ray] is constant over the points of one ray, so it enters as a rank-1
+            // update: A = raypart row (lanes 0..31: one ray, lanes 32..63: another), B = one-hot
+            // membership of the point. Any pair order works; ray-major pairs need one round per
+            // two distinct rays of the tile. The rows of the first LIDF_RB rounds are requested
+            // now and used after the embedding steps.
+            unsigned todo = (unsigned)__ballot(h == 0);  // points still to be covered
+            float ar[LIDF_RB][8], bsel[LIDF_RB];
+            int nr = 0;
+            auto issue_round = [&](float (&arow)[8], float& bs) {
+                const int p0 = __builtin_ctz(todo);
+                const int r0 = __builtin_amdgcn_readlane(cur.ray, p0);
+                const unsigned m0 = (unsigned)__ballot(cur.ray == r0) & todo;
+                todo &= ~m0;
+                int r1 = r0;
+                unsigned m1 = 0;
+                if (todo) {
+                    const int p1 = __builtin_ctz(todo);
+                    r1 = __builtin_amdgcn_readlane(cur.ray, p1);
+                    m1 = (unsigned)__ballot(cur.ray == r1) & todo;
+                    todo &= ~m1;
+                }
+                bs = (((h ? m1 : m0) >> col) & 1u) ? 1.f : 0.f;
+                const float* rp = a.raypart + ((size_t)(h ? r1 : r0) * a.nets + net) * 256 + col;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) arow[t] = rp[t * 32];
+            };
+#pragma unroll
+            for (int j = 0; j < LIDF_RB; ++j) {
+                if (todo) {
+                    issue_round(ar[j], bsel[j]);
+                    nr = j + 1;
+                }
+            }
+            PROF(2)
+            // octave pairs: 12 k-steps (sin xyz, cos xyz of octaves 2it, 2it+1) x 8 tiles per
+            // iteration; the embedding values are produced right here, in registers
+            float sc0 = 1.f;
+            for (int it = 0; it < Lp; ++it) {
+                const float sc1 = sc0 * 2.f;
+                float sb[12];
+                rev_sincos(rx, sc0, sb[0], sb[3]);
+                rev_sincos(ry, sc0, sb[1], sb[4]);
+                rev_sincos(rz, sc0, sb[2], sb[5]);
+                rev_sincos(rx, sc1, sb[6], sb[9]);
+                rev_sincos(ry, sc1, sb[7], sb[10]);
+                rev_sincos(rz, sc1, sb[8], sb[11]);
+                const int qb = nsb + (it * 24 + LIDF_RING) * 1024;
+#pragma unroll
+                for (int s = 0; s < 24; ++s) {
+                    const int t = s / 3, jq = s % 3;
+                    const f32x4 q = ring[s % LIDF_RING];
+                    ring[s % LIDF_RING] = LDQ(srs, vq + (s & 3) * 1024, qb + (s >> 2) * 4096);
+                    f32x16 c = base[t];
+                    c = MFMA(q[0], sb[4 * jq + 0], c);
+                    c = MFMA(q[1], sb[4 * jq + 1], c);
+                    c = MFMA(q[2], sb[4 * jq + 2], c);
+                    c = MFMA(q[3], sb[4 * jq + 3], c);
+                    base[t] = c;
+                    SCHED_FENCE();
+                }
+                sc0 = sc1 * 2.f;
+            }
+            {
+                // tail: raw x, y, z; the refills run on into the u / layer-2 quads of this block
+                const int qb = nsb + (Lp * 24 + LIDF_RING) * 1024;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const f32x4 q = ring[t];
+                    ring[t] = LDQ(srs, vq, qb + t * 1024);
+                    f32x16 c = base[t];
+                    c = MFMA(q[0], px, c);
+                    c = MFMA(q[1], py, c);
+                    c = MFMA(q[2], pz, c);
+                    base[t] = c;
+                    SCHED_FENCE();
+                }
+            }
+            // the rank-1 rounds (rows requested before the embedding steps); more than
+            // 2*LIDF_RB distinct rays in the tile: further batches, in the open
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < LIDF_RB; ++j) {
+                    if (j < nr) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) base[t] = MFMA(ar[j][t], bsel[j], base[t]);
+                    }
+                }
+                if (!todo) break;
+                nr = 0;
+#pragma unroll
+                for (int j = 0; j < LIDF_RB; ++j) {
+                    if (todo) {
+                        issue_round(ar[j], bsel[j]);
+                        nr = j + 1;
+                    }
+                }
+            }
+            PROF(3)
+
+            // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
+            // the last pass of the net copies the accumulator init of what runs next — the other net
+            // of this tile, or the first net of the next tile — into LDS while its layer 2 runs
+            const bool last_net = net + 1 == a.nets;
+            const unsigned vp_off =
+                (unsigned)(((last_net ? nxt.vid : cur.vid) * a.nets + (last_net ? 0 : net + 1)) * 1024 + 16 * h);
+            float val = a.init[net];
+            const int pass_base = nsb + l1_bytes;
+            const float* ax = a.aux + net * LIDF_AUX_FLOATS;
+            const int npass = a.npass[net];
+            for (int pass = 0; pass + 1 < npass; ++pass)
+                val += decoder_pass<false>(srs, vq, ring, pass_base, pass_base, base, val, h, one_b,
+                                           ax, nullptr, 0u, 0u, nullptr, 0
+#ifdef LIDF_PROFILE
+                                           , prof_t, prof_acc
+#endif
+                                           );
+            val += decoder_pass<true>(srs, vq, ring, pass_base, next_blk, base, val, h, one_b, ax,
+                                      (const char*)a.voxpart, vp_off, lds_addr, lds_wave, lane
+#ifdef LIDF_PROFILE
+                                      , prof_t, prof_acc
+#endif
+                                      );
+            // `base` now holds the accumulator init of the next (net, tile)
+            PROF(5)
+            // ---------------- outputs ----------------
+            if (valid && h == 0) {
+                const float o = out_act(val, a.sigmoid[net]);
+                if (a.out[net]) a.out[net][p] = o;
+                if (a.is_offset[net]) {
+                    // pipeline.py:437-439, same operation order in f32
+                    const float ex = __fmul_rn(cur.dx, cur.te);
+                    const float ey = __fmul_rn(cur.dy, cur.te);
+                    const float ez = __fmul_rn(cur.dz, cur.te);
+                    float sc = __fadd_rn(__fmul_rn(o, a.rscale), a.r0);
+                    sc = __fmul_rn(__fmul_rn(sc, a.sqrt3), a.part_size);
+                    a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(sc, cur.dx));
+                    a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(sc, cur.dy));
+                    a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(sc, cur.dz));
+                }
+            }
+        }
+        PROF(0)
+        cur = nxt;
+        nxt.ray = nx2.ray;
+        nxt.vid = nx2.vid;
+        nxt.te = nx2.te;
+        nxt.tl = nx2.tl;
+    }
+    PROF_DUMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rows modes: the decoders (LIDF_MODE_ROWS) or layer 1 only (LIDF_MODE_L1ONLY: voxpart / raypart
+// producers) on materialised input rows.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const float one_b = h ? 0.f : 1.f;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.stream, 0, a.nets * a.net_quads * 1024, 0x00020000);
+    const int vq = lane * 16;
+    const int net_bytes = a.net_quads * 1024;
+    const int l1_bytes = a.l1_quads * 1024;
+
+    // contiguous range of 128-row tiles per workgroup; the 4 waves interleave inside it
+    const long long ntile = (a.n + 127) / 128;
+    const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
+    const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
+    const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
+    if (tb >= te_) return;
+
+    // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
+    f32x4 ring[LIDF_RING];
+#pragma unroll
+    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+
+    PROF_DECL
+    for (long long tile = tb; tile < te_; ++tile) {
+        if (tile * 128 + wave * 32 >= a.n) break;  // whole wave out of range (wave-uniform)
+        const long long p = tile * 128 + wave * 32 + col;
+        const bool valid = p < a.n;
+        const long long pc = valid ? p : a.n - 1;
 
         for (int net = 0; net < a.nets; ++net) {
             const int nsb = net * net_bytes;  // byte offset of this net's block
@@ -410,152 +692,60 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
             f32x16 base[8];
 
             // ---------------- layer 1 ----------------
-            if constexpr (MODE == LIDF_MODE_FUSED) {
-                // accumulator init = voxpart[vid] (carries the layer-1 bias), gathered per lane
-                // straight into the accumulator layout, + raypart[ray]: constant over the points
-                // of one ray, so it is a rank-1 update  A = raypart row (lanes 0..31: one ray,
-                // lanes 32..63: another), B = one-hot membership of the point.  Two distinct rays
-                // of the wave per MFMA round: ray-major pairs need one round (two when a tile
-                // straddles three rays); any pair order works. The loads of the first round are
-                // issued ahead of the voxpart gather so that the two latencies overlap.
-                unsigned todo = (unsigned)__ballot(h == 0);  // points still to be covered
-                float ar[8], bsel;
-                auto next_round = [&]() {
-                    const int p0 = __builtin_ctz(todo);
-                    const int r0 = __builtin_amdgcn_readlane(cur.ray, p0);
-                    const unsigned m0 = (unsigned)__ballot(cur.ray == r0) & todo;
-                    todo &= ~m0;
-                    int r1 = r0;
-                    unsigned m1 = 0;
-                    if (todo) {
-                        const int p1 = __builtin_ctz(todo);
-                        r1 = __builtin_amdgcn_readlane(cur.ray, p1);
-                        m1 = (unsigned)__ballot(cur.ray == r1) & todo;
-                        todo &= ~m1;
-                    }
-                    bsel = (((h ? m1 : m0) >> col) & 1u) ? 1.f : 0.f;
-                    const float* rp =
-                        a.raypart + ((size_t)(h ? r1 : r0) * a.nets + net) * 256 + col;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) ar[t] = rp[t * 32];
-                };
-                next_round();
-                const float* vp = a.voxpart + ((size_t)cur.vid * a.nets + net) * 256 + 4 * h;
+            for (int t = 0; t < 8; ++t) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int i = 0; i < 16; ++i) base[t][i] = 0.f;
+            }
+            // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
+            const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+            auto load_b = [&](int kq, float (&b)[4]) {
+                const int x0 = 8 * kq + 4 * h;
+                if (x0 + 3 < a.D) {
+                    const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+                    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+                } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = *(const f32x4*)(vp + t * 32 + 8 * g);
+                    for (int jj = 0; jj < 4; ++jj)
+                        b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
+                                              : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+                }
+            };
+            // where the stream continues after this layer-1 section
+            const int after_l1 = MODE == LIDF_MODE_L1ONLY ? next_blk : nsb + l1_bytes;
+            // The operand rows stream from HBM, and VMEM loads return in order: an HBM-latency
+            // load would hold up every weight-ring load queued behind it, once per iteration.
+            // So the operands of up to 25 k-quads (100 VGPRs, free during layer 1) are fetched
+            // in one burst per chunk and the iterations run with only the L2-resident ring in
+            // the queue.
+            constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : 8;  // L1ONLY: keep 2 waves/SIMD
+            for (int k0 = 0; k0 < a.KQ1; k0 += XCH) {
+                float xb[XCH][4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
+                for (int i = 0; i < XCH; ++i) {
+                    if (k0 + i < a.KQ1) {
+                        load_b(k0 + i, xb[i]);
+                    } else {
+                        xb[i][0] = xb[i][1] = xb[i][2] = xb[i][3] = 0.f;
                     }
                 }
-                for (;;) {
+                SCHED_FENCE();
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) base[t] = MFMA(ar[t], bsel, base[t]);
-                    if (!todo) break;
-                    next_round();
-                }
-                PROF(2)
-                // octave pairs: 12 k-steps (sin xyz, cos xyz of octaves 2it, 2it+1) x 8 tiles per
-                // iteration; the embedding values are produced right here, in registers
-                float sc0 = 1.f;
-                for (int it = 0; it < Lp; ++it) {
-                    const float sc1 = sc0 * 2.f;
-                    float sb[12];
-                    rev_sincos(rx, sc0, sb[0], sb[3]);
-                    rev_sincos(ry, sc0, sb[1], sb[4]);
-                    rev_sincos(rz, sc0, sb[2], sb[5]);
-                    rev_sincos(rx, sc1, sb[6], sb[9]);
-                    rev_sincos(ry, sc1, sb[7], sb[10]);
-                    rev_sincos(rz, sc1, sb[8], sb[11]);
-                    const int qb = nsb + (it * 24 + LIDF_RING) * 1024;
-#pragma unroll
-                    for (int s = 0; s < 24; ++s) {
-                        const int t = s / 3, jq = s % 3;
-                        const f32x4 q = ring[s % LIDF_RING];
-                        ring[s % LIDF_RING] = LDQ(srs, vq + (s & 3) * 1024, qb + (s >> 2) * 4096);
-                        f32x16 c = base[t];
-                        c = MFMA(q[0], sb[4 * jq + 0], c);
-                        c = MFMA(q[1], sb[4 * jq + 1], c);
-                        c = MFMA(q[2], sb[4 * jq + 2], c);
-                        c = MFMA(q[3], sb[4 * jq + 3], c);
-                        base[t] = c;
-                        SCHED_FENCE();
-                    }
-                    sc0 = sc1 * 2.f;
-                }
-                {
-                    // tail: raw x, y, z; the refills run on into the u / layer-2 quads of this block
-                    const int qb = nsb + (Lp * 24 + LIDF_RING) * 1024;
+                for (int i = 0; i < XCH; ++i) {
+                    const int kq = k0 + i;
+                    if (kq >= a.KQ1) break;
+                    const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const f32x4 q = ring[t];
                         ring[t] = LDQ(srs, vq, qb + t * 1024);
                         f32x16 c = base[t];
-                        c = MFMA(q[0], px, c);
-                        c = MFMA(q[1], py, c);
-                        c = MFMA(q[2], pz, c);
+                        c = MFMA(q[0], xb[i][0], c);
+                        c = MFMA(q[1], xb[i][1], c);
+                        c = MFMA(q[2], xb[i][2], c);
+                        c = MFMA(q[3], xb[i][3], c);
                         base[t] = c;
                         SCHED_FENCE();
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) base[t][i] = 0.f;
-                }
-                // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
-                const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
-                auto load_b = [&](int kq, float (&b)[4]) {
-                    const int x0 = 8 * kq + 4 * h;
-                    if (x0 + 3 < a.D) {
-                        const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
-                        b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
-                                                  : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
-                    }
-                };
-                // where the stream continues after this layer-1 section
-                const int after_l1 = MODE == LIDF_MODE_L1ONLY ? next_blk : nsb + l1_bytes;
-                // The operand rows stream from HBM, and VMEM loads return in order: an HBM-latency
-                // load would hold up every weight-ring load queued behind it, once per iteration.
-                // So the operands of up to 25 k-quads (100 VGPRs, free during layer 1) are fetched
-                // in one burst per chunk and the iterations run with only the L2-resident ring in
-                // the queue.
-                constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : 8;  // L1ONLY: keep 2 waves/SIMD
-                for (int k0 = 0; k0 < a.KQ1; k0 += XCH) {
-                    float xb[XCH][4];
-#pragma unroll
-                    for (int i = 0; i < XCH; ++i) {
-                        if (k0 + i < a.KQ1) {
-                            load_b(k0 + i, xb[i]);
-                        } else {
-                            xb[i][0] = xb[i][1] = xb[i][2] = xb[i][3] = 0.f;
-                        }
-                    }
-                    SCHED_FENCE();
-#pragma unroll
-                    for (int i = 0; i < XCH; ++i) {
-                        const int kq = k0 + i;
-                        if (kq >= a.KQ1) break;
-                        const int qb = kq + 1 < a.KQ1 ? nsb + (kq + 1) * 8 * 1024 : after_l1;
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const f32x4 q = ring[t];
-                            ring[t] = LDQ(srs, vq, qb + t * 1024);
-                            f32x16 c = base[t];
-                            c = MFMA(q[0], xb[i][0], c);
-                            c = MFMA(q[1], xb[i][1], c);
-                            c = MFMA(q[2], xb[i][2], c);
-                            c = MFMA(q[3], xb[i][3], c);
-                            base[t] = c;
-                            SCHED_FENCE();
-                        }
                     }
                 }
             }
@@ -575,7 +765,6 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                     }
                 }
             } else {
-                PROF(3)
                 // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
                 float val = a.init[net];
                 const int pass_base = nsb + l1_bytes;
@@ -583,40 +772,19 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
                 const int npass = a.npass[net];
                 for (int pass = 0; pass < npass; ++pass) {
                     const int wrap_base = pass + 1 < npass ? pass_base : next_blk;
-                    val += decoder_pass(srs, vq, ring, pass_base, wrap_base, base, val, h, one_b, ax
+                    val += decoder_pass<false>(srs, vq, ring, pass_base, wrap_base, base, val, h,
+                                               one_b, ax, nullptr, 0u, 0u, nullptr, 0
 #ifdef LIDF_PROFILE
-                                        , prof_t, prof_acc
+                                               , prof_t, prof_acc
 #endif
-                                        );
+                                               );
                 }
-                PROF(5)
                 // ---------------- outputs ----------------
                 if (valid && h == 0) {
                     const float o = out_act(val, a.sigmoid[net]);
                     if (a.out[net]) a.out[net][p] = o;
-                    if constexpr (MODE == LIDF_MODE_FUSED) {
-                        if (a.is_offset[net]) {
-                            // pipeline.py:437-439, same operation order in f32
-                            const float ex = __fmul_rn(cur.dx, cur.te);
-                            const float ey = __fmul_rn(cur.dy, cur.te);
-                            const float ez = __fmul_rn(cur.dz, cur.te);
-                            float s = __fadd_rn(__fmul_rn(o, a.rscale), a.r0);
-                            s = __fmul_rn(__fmul_rn(s, a.sqrt3), a.part_size);
-                            a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(s, cur.dx));
-                            a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(s, cur.dy));
-                            a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(s, cur.dz));
-                        }
-                    }
                 }
             }
-        }
-        PROF(0)
-        if constexpr (MODE == LIDF_MODE_FUSED) {
-            cur = nxt;
-            nxt.ray = nx2.ray;
-            nxt.vid = nx2.vid;
-            nxt.te = nx2.te;
-            nxt.tl = nx2.tl;
         }
     }
     PROF_DUMP
@@ -631,7 +799,15 @@ static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
 extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid,
                                          hipStream_t st) {
     if (a.n <= 0) return hipSuccess;
-    if (mode == LIDF_MODE_FUSED) return launch_points<LIDF_MODE_FUSED>(a, grid, st);
+    if (mode == LIDF_MODE_FUSED) {
+        // 4 waves x 32 KiB of LDS: the staging area of the accumulator prefetch
+        static_assert(4 * 8192 * 4 == 131072, "LDS staging size");
+        hipError_t e = hipFuncSetAttribute((const void*)lidf_points_fused_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, a);
+        return hipGetLastError();
+    }
     if (mode == LIDF_MODE_ROWS) return launch_points<LIDF_MODE_ROWS>(a, grid, st);
     if (mode == LIDF_MODE_L1ONLY) return launch_points<LIDF_MODE_L1ONLY>(a, grid, st);
     return hipErrorInvalidValue;

@@ -93,24 +93,36 @@ def get_valid_points(dd, opt, valid_idx=None):
     return dd
 
 
+def _mark(marks, name):
+    """Benchmarks only: record a CUDA event named `name` on the current stream."""
+    if marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+
+
 def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=None, pred_mask=None,
-                 valid_idx=None, precision="f32", workspace=None):
+                 valid_idx=None, precision="f32", workspace=None, marks=None):
     """LIDF.forward for evaluation (models/pipeline.py:652-717): returns (success, data_dict).
     success False = one of the reference's early exits (no occupied voxel / no miss ray / no
     intersecting pair); data_dict then holds what was computed up to that point."""
     opt = opt or LidfOptions()
+    _mark(marks, "start")
     dd = prepare_data(batch, opt, pred_mask)
     get_valid_points(dd, opt, valid_idx)
+    _mark(marks, "valid_points")
     bs, h, w = dd["bs"], dd["h"], dd["w"]
     # occupied voxels (get_occ_vox_bound)
     occ = Q.get_occ_vox_bound(dd["valid_xyz"].contiguous(), dd["valid_bid"].to(torch.int32).contiguous(),
                               bs, opt.xmin, opt.xmax, opt.grid_res)
     dd.update(occ)
     V = occ["voxel_bound"].shape[0]
+    _mark(marks, "occupied_voxels")
     if V == 0:
         return False, dd
     # miss rays
     dd.update(Q.get_miss_ray(dd["pred_mask"], dd["fx"], dd["fy"], dd["cx"], dd["cy"]))
+    _mark(marks, "miss_rays")
     if dd["total_miss_sample_num"] == 0:
         return False, dd
     # ray / voxel pairs (compact, ray-major)
@@ -119,6 +131,7 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
                                                               dd["ray_bid"], vox_bid)
     dd.update({"pair_off": pair_off, "pair_ray": pair_ray, "pair_vox": pair_vox, "pair_t": pair_t,
                "voxel_bid": vox_bid})
+    _mark(marks, "ray_aabb")
     if pair_ray.shape[0] == 0:
         return False, dd
     # voxel embedding: PointNet over the valid points of every occupied voxel
@@ -127,6 +140,7 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
     dd["pnet_inp"] = pnet_inp
     dd["occ_voxel_feat"] = pnet_model(pnet_inp, occ["revidx"], n_vox=V)
     dd["full_rgb_feat"] = full_rgb_feat
+    _mark(marks, "pointnet")
     # get_embedding + get_pred + depth map (pred_xyz = xyz_corrupt with the rays' pixels replaced)
     depth = dd["xyz_corrupt_flat"][:, :, 2].reshape(bs, h, w).clone()
     vox_center = None
@@ -142,6 +156,7 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
                        want_rayfeat=True, precision=precision, workspace=workspace)
     dd.update(out)
     dd["pred_depth"] = depth
+    _mark(marks, "query")
     return True, dd
 
 
