@@ -43,7 +43,7 @@ class LidfQueryArgs(C.Structure):
         ("depth", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("rayfeat_out", C.c_void_p),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("packed", C.c_void_p),
     ]
 
 
@@ -100,6 +100,8 @@ SIGNATURES = {
     "lidf_decoders_split_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder),
                                     C.POINTER(LidfDecoder), _P, _P, _P, _SZ, _P]),
     "lidf_query_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "lidf_query_pack_bytes": (_SZ, []),
+    "lidf_query_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), C.POINTER(LidfDecoder), _I, _I, _I, _P, _SZ, _P]),
     "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
     "lidf_query_profile_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P, _P, _P]),
     "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P]),
@@ -133,6 +135,10 @@ SIGNATURES = {
                                                        C.c_size_t, _P]),
     "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
                                                   C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
+    "lidf_query_tail_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float, C.c_float,
+                                      _P, _P, _P, _P, _P, _P]),
+    "lidf_query_tail_backward_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float,
+                                               C.c_float, _P, _P]),
     "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,

@@ -54,6 +54,12 @@ hipError_t lidf_launch_pe_rows(const int*, const int*, const float*, const float
                                long long, float*, hipStream_t);
 hipError_t lidf_launch_seg_sum_ray(const float*, int, const int*, long long, float*, hipStream_t);
 hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, long long, float*, hipStream_t);
+hipError_t lidf_launch_pair_pos(const float*, const int*, const float*, const float*, long long, float,
+                                float, float, float, float*, hipStream_t);
+hipError_t lidf_launch_ray_select(const float*, const long long*, long long, long long, float*,
+                                  hipStream_t);
+hipError_t lidf_launch_pair_pos_backward(const float*, const float*, const long long*, const int*,
+                                         const float*, long long, float, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -276,7 +282,9 @@ LIDF_API int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_
 
 // ---- fused query ---------------------------------------------------------------------------------
 struct QueryWs {
-    size_t stream_pts, aux_pts, stream_vox, stream_ray, voxpart, raypart, rayfeat, box, total;
+    // the first four slots hold the packed weights (lidf_query_pack_f32 writes exactly this prefix)
+    size_t stream_pts, aux_pts, stream_vox, stream_ray, packed_end, counter, voxpart, raypart, rayfeat,
+        box, total;
 };
 
 static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats = 0) {
@@ -297,6 +305,8 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats
         const size_t f16 = (size_t)lidf_make_layout_rows_h(2, 128 + Ed, 1).total * 4;
         w.stream_ray = o; o += align_up(f32 > f16 ? f32 : f16, 256);
     }
+    w.packed_end = o;
+    w.counter = o;    o += 256;  // tile hand-out counter of the split-f16 kernel
     w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
     w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
     w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
@@ -311,23 +321,78 @@ LIDF_API size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_
     return query_ws(n_rays, n_vox, LIDF_MAX_L_FUSED, 16, grid_floats > 0 ? grid_floats : 0).total;
 }
 
+// The decoders' parameters re-ordered into the streams the query kernels consume: the per-point
+// stream (+ layer-4 operands), the per-voxel and the per-ray layer-1 streams.
+static int pack_query_weights(const LidfDecoder* prob, const LidfDecoder* off, int L, int Lv,
+                              int precision, char* dst, hipStream_t st) {
+    const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
+    const int D = 256 + 2 * E + Ed;
+    const QueryWs w = query_ws(1, 1, L, Lv);
+    float* stream_pts = (float*)(dst + w.stream_pts);
+    float* aux_pts = (float*)(dst + w.aux_pts);
+    float* stream_vox = (float*)(dst + w.stream_vox);
+    float* stream_ray = (float*)(dst + w.stream_ray);
+    NetW np = to_netw(prob, D), no = to_netw(off, D);
+    L1Map mf = {};
+    mf.L = L;
+    mf.enter_c0 = 256;
+    mf.leave_c0 = 256 + E;
+    const bool split = precision == LIDF_PRECISION_F16X3;
+    if (split)
+        CHECK_HIP(lidf_launch_pack_h(lidf_make_layout_h(2, mf), np, no, mf, stream_pts, aux_pts, st));
+    else
+        CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_FUSED, mf), np, no, mf, stream_pts,
+                                   aux_pts, st));
+    L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
+    CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_L1ONLY, mv), np, no, mv, stream_vox,
+                               aux_pts, st));
+    L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
+    if (split)
+        CHECK_HIP(lidf_launch_pack_rows_h(lidf_make_layout_rows_h(2, mr.D, 1), np, no, mr, stream_ray,
+                                          nullptr, st));
+    else
+        CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_L1ONLY, mr), np, no, mr, stream_ray,
+                                   aux_pts, st));
+    return LIDF_OK;
+}
+
+static int check_query_model(const LidfDecoder* prob, const LidfDecoder* off, int L, int Lv,
+                             int precision) {
+    if (L < 0 || L > LIDF_MAX_L_FUSED || Lv < 0 || Lv > 16) return LIDF_ERR_UNSUPPORTED;
+    int rc;
+    if (!prob || !off) return LIDF_ERR_BAD_ARG;
+    if ((rc = check_decoder(prob)) || (rc = check_decoder(off))) return rc;
+    if (prob->is_ief) return LIDF_ERR_UNSUPPORTED;  // prob_dec is an IMNet (pipeline.py:82)
+    if (precision != LIDF_PRECISION_F32 && precision != LIDF_PRECISION_F16X3) return LIDF_ERR_BAD_ARG;
+    // the split-f16 kernel is built for up to 8 octaves (opt.model.multires = 8)
+    if (precision == LIDF_PRECISION_F16X3 && L > 8) return LIDF_ERR_UNSUPPORTED;
+    return LIDF_OK;
+}
+
+LIDF_API size_t lidf_query_pack_bytes(void) {
+    return query_ws(1, 1, LIDF_MAX_L_FUSED, 16).packed_end;
+}
+
+LIDF_API int lidf_query_pack_f32(const LidfDecoder* prob, const LidfDecoder* off, int multires,
+                                   int multires_views, int precision, void* packed,
+                                   size_t packed_bytes, lidf_stream_t stream) {
+    int rc = check_query_model(prob, off, multires, multires_views, precision);
+    if (rc) return rc;
+    if (!packed || packed_bytes < query_ws(1, 1, multires, multires_views).packed_end)
+        return LIDF_ERR_WORKSPACE;
+    return pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
+                              (hipStream_t)stream);
+}
+
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
                       lidf_stream_t stream) {
     if (!q) return LIDF_ERR_BAD_ARG;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
     if (P > 0x7fffffffLL || R > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
-    if (q->multires < 0 || q->multires > LIDF_MAX_L_FUSED || q->multires_views < 0 ||
-        q->multires_views > 16)
-        return LIDF_ERR_UNSUPPORTED;
     int rc;
-    if (!q->prob || !q->off) return LIDF_ERR_BAD_ARG;
-    if ((rc = check_decoder(q->prob)) || (rc = check_decoder(q->off))) return rc;
-    if (q->prob->is_ief) return LIDF_ERR_UNSUPPORTED;  // prob_dec is an IMNet (pipeline.py:82)
-    if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
-        return LIDF_ERR_BAD_ARG;
-    // the split-f16 kernel is built for up to 8 octaves (opt.model.multires = 8)
-    if (q->precision == LIDF_PRECISION_F16X3 && q->multires > 8) return LIDF_ERR_UNSUPPORTED;
+    if ((rc = check_query_model(q->prob, q->off, q->multires, q->multires_views, q->precision)))
+        return rc;
     hipStream_t st = (hipStream_t)stream;
     const int L = q->multires, Lv = q->multires_views;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
@@ -350,35 +415,29 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         if (!use_box) w = query_ws(R, V, L, Lv);
         if (!q->workspace || q->workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
         char* ws = (char*)q->workspace;
-        float* stream_pts = (float*)(ws + w.stream_pts);
-        float* aux_pts = (float*)(ws + w.aux_pts);
-        float* stream_vox = (float*)(ws + w.stream_vox);
-        float* stream_ray = (float*)(ws + w.stream_ray);
+        // 1. weight streams: the caller's packed blob (lidf_query_pack_f32, built once per
+        // parameter version) or packed here, into the head of the workspace, for this call
+        const char* pk = q->packed ? (const char*)q->packed : ws;
+        if (!q->packed &&
+            (rc = pack_query_weights(q->prob, q->off, L, Lv, q->precision, ws, st)))
+            return rc;
+        const float* stream_pts = (const float*)(pk + w.stream_pts);
+        const float* aux_pts = (const float*)(pk + w.aux_pts);
+        const float* stream_vox = (const float*)(pk + w.stream_vox);
+        const float* stream_ray = (const float*)(pk + w.stream_ray);
         float* voxpart = (float*)(ws + w.voxpart);
         float* raypart = (float*)(ws + w.raypart);
         float* rayfeat = q->rayfeat_out ? q->rayfeat_out : (float*)(ws + w.rayfeat);
         int cus;
         if ((rc = cu_count(&cus))) return rc;
-
-        NetW np = to_netw(q->prob, D), no = to_netw(q->off, D);
-
-        // 1. weight streams
         L1Map mf = {};
         mf.L = L;
-        mf.enter_c0 = 256;
-        mf.leave_c0 = 256 + E;
         const bool split = q->precision == LIDF_PRECISION_F16X3;
         StreamLayout lf = split ? lidf_make_layout_h(2, mf) : lidf_make_layout(2, LIDF_MODE_FUSED, mf);
-        if (split)
-            CHECK_HIP(lidf_launch_pack_h(lf, np, no, mf, stream_pts, aux_pts, st));
-        else
-            CHECK_HIP(lidf_launch_pack(lf, np, no, mf, stream_pts, aux_pts, st));
-        L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
+        L1Map mv = rows_map(128, 0, 0, 0, 1);
         StreamLayout lv = lidf_make_layout(2, LIDF_MODE_L1ONLY, mv);
-        CHECK_HIP(lidf_launch_pack(lv, np, no, mv, stream_vox, aux_pts, st));
-        L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
+        L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
-        if (!split) CHECK_HIP(lidf_launch_pack(lr, np, no, mr, stream_ray, aux_pts, st));
 
         // 2. per-voxel partial  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c)
         {
@@ -407,7 +466,6 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             if (split) {
                 // the per-ray partial products with the split-f16 rows kernel (layer 1 only)
                 StreamLayout lh = lidf_make_layout_rows_h(2, mr.D, 1);
-                CHECK_HIP(lidf_launch_pack_rows_h(lh, np, no, mr, stream_ray, nullptr, st));
                 a.l1_quads = lh.l1_quads; a.net_quads = lh.net_quads;
                 a.npass[0] = a.npass[1] = 0;
                 CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
@@ -431,7 +489,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.sqrt3 = (float)1.7320508075688772;  // np.sqrt(3) rounded to f32 (pipeline.py:438)
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
-            a.tile_counter = (int*)aux_pts + 2 * LIDF_AUX_FLOATS;  // inside the aux slot's padding
+            a.tile_counter = (int*)(ws + w.counter);
+            if (split) CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
 #ifdef LIDF_PROFILE
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif
@@ -1420,5 +1479,49 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         L.w = dec->w1 + 256 + E2; L.nout = Ed; L.out = d_rayfeat + 128;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
     }
+    return LIDF_OK;
+}
+
+// ---- per-pair / per-ray tail of get_pred, forward and adjoint -------------------------------------
+LIDF_API int lidf_query_tail_f32(const float* pred_offset, const float* pred_prob,
+                                   const int32_t* pair_off, const int32_t* pair_ray,
+                                   const float* pair_t, const float* ray_dir, int64_t n_rays,
+                                   int64_t n_pairs, float offset_range0, float offset_range1,
+                                   float part_size, const int64_t* max_pair_id_in,
+                                   float* pair_pred_pos, float* softmax, int64_t* max_pair_id,
+                                   float* pred_pos, lidf_stream_t stream) {
+    if (n_rays < 0 || n_pairs < 0) return LIDF_ERR_BAD_ARG;
+    if (n_rays == 0) return LIDF_OK;
+    if (!pair_off || (n_pairs > 0 && (!pred_offset || !pred_prob || !pair_ray || !pair_t || !ray_dir ||
+                                      !pair_pred_pos)))
+        return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_HIP(lidf_launch_pair_pos(pred_offset, pair_ray, pair_t, ray_dir, n_pairs, offset_range0,
+                                   offset_range1 - offset_range0, (float)1.7320508075688772,
+                                   part_size, pair_pred_pos, st));
+    // softmax over the pairs of a ray, arg-max, select (pipeline.py:442-454)
+    CHECK_HIP(lidf_launch_ray_reduce(pred_prob, pair_pred_pos, pair_off, n_rays, n_pairs, nullptr,
+                                     nullptr, 0, softmax, (long long*)max_pair_id,
+                                     max_pair_id_in ? nullptr : pred_pos, nullptr, st));
+    // training with ground-truth labels selects the pair itself (pipeline.py:444-446)
+    if (max_pair_id_in && pred_pos)
+        CHECK_HIP(lidf_launch_ray_select(pair_pred_pos, (const long long*)max_pair_id_in, n_rays,
+                                         n_pairs, pred_pos, st));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_query_tail_backward_f32(const float* g_pair_pred_pos, const float* g_pred_pos,
+                                            const int64_t* max_pair_id, const int32_t* pair_ray,
+                                            const float* ray_dir, int64_t n_rays, int64_t n_pairs,
+                                            float offset_range0, float offset_range1,
+                                            float part_size, float* d_pred_offset,
+                                            lidf_stream_t stream) {
+    if (n_rays < 0 || n_pairs < 0) return LIDF_ERR_BAD_ARG;
+    if (n_pairs == 0) return LIDF_OK;
+    if (!pair_ray || !ray_dir || !d_pred_offset || (g_pred_pos && !max_pair_id)) return LIDF_ERR_BAD_ARG;
+    const float k = (offset_range1 - offset_range0) * (float)1.7320508075688772 * part_size;
+    CHECK_HIP(lidf_launch_pair_pos_backward(g_pair_pred_pos, g_pred_pos, (const long long*)max_pair_id,
+                                            pair_ray, ray_dir, n_pairs, k, d_pred_offset,
+                                            (hipStream_t)stream));
     return LIDF_OK;
 }

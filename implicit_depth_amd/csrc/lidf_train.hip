@@ -294,7 +294,8 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     if (gimg && half > 0 && u2 - u1 == 2 * half && v2 - v1 == 2 * half) {
         // unclamped box: every sample sits on a pixel centre, bin (ph, pw) spreads g / half^2 over a
         // half x half pixel block; parked at the ray's pixel, gathered by lidf_rayfeat_gather_kernel
-        gimg[(((size_t)ray_bid[r] * 128 + cb) * H + qy) * W + qx] = g;
+        // (atomicAdd into the zeroed image: two rays may name the same pixel)
+        if (g != 0.f) atomicAdd(gimg + (((size_t)ray_bid[r] * 128 + cb) * H + qy) * W + qx, g);
         return;
     }
     if (g == 0.f) return;
@@ -557,5 +558,89 @@ extern "C" hipError_t lidf_launch_axpy(const float* x, long long n, float* y, hi
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x,
                        n / 4, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-pair tail of LIDF.get_pred and its adjoint (models/pipeline.py:437-439, :452-454):
+//   s = (off (r1-r0) + r0) sqrt(3) part_size ;  pair_pred_pos = dir t_enter + s dir
+//   pred_pos[r] = pair_pred_pos[max_pair_id[r]]   (dummy row (0,0,0) for a ray without pairs)
+// The per-ray softmax / arg-max is not differentiated (the reference detaches the logits, :442).
+// Backward: d off[p] = k dir[ray(p)] . (g_pair_pred_pos[p] + [p == max_pair_id[ray(p)]] g_pred_pos[ray(p)]),
+// k = (r1-r0) sqrt(3) part_size — one thread per pair, no atomics (a pair knows whether it is its
+// ray's selected one).
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_pair_pos_kernel(const float* __restrict__ off, const int* __restrict__ pair_ray,
+                                     const float* __restrict__ pair_t,
+                                     const float* __restrict__ ray_dir, long long P, float r0,
+                                     float rs, float sqrt3, float part, float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t r = (size_t)pair_ray[p];
+    const float dx = ray_dir[3 * r], dy = ray_dir[3 * r + 1], dz = ray_dir[3 * r + 2];
+    const float te = pair_t[2 * p];
+    float s = __fadd_rn(__fmul_rn(off[p], rs), r0);
+    s = __fmul_rn(__fmul_rn(s, sqrt3), part);
+    out[3 * p + 0] = __fadd_rn(__fmul_rn(dx, te), __fmul_rn(s, dx));
+    out[3 * p + 1] = __fadd_rn(__fmul_rn(dy, te), __fmul_rn(s, dy));
+    out[3 * p + 2] = __fadd_rn(__fmul_rn(dz, te), __fmul_rn(s, dz));
+}
+
+__global__ void lidf_ray_select_kernel(const float* __restrict__ pos, const long long* __restrict__ id,
+                                       long long R, long long P, float* __restrict__ pred_pos) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long m = id[r];
+    const bool ok = m >= 0 && m < P;
+    pred_pos[3 * r + 0] = ok ? pos[3 * m + 0] : 0.f;
+    pred_pos[3 * r + 1] = ok ? pos[3 * m + 1] : 0.f;
+    pred_pos[3 * r + 2] = ok ? pos[3 * m + 2] : 0.f;
+}
+
+__global__ void lidf_pair_pos_backward_kernel(const float* __restrict__ g_pos,
+                                              const float* __restrict__ g_pred,
+                                              const long long* __restrict__ id,
+                                              const int* __restrict__ pair_ray,
+                                              const float* __restrict__ ray_dir, long long P,
+                                              float k, float* __restrict__ d_off) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t r = (size_t)pair_ray[p];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (g_pos) {
+        gx = g_pos[3 * p];
+        gy = g_pos[3 * p + 1];
+        gz = g_pos[3 * p + 2];
+    }
+    if (g_pred && id[r] == p) {
+        gx += g_pred[3 * r];
+        gy += g_pred[3 * r + 1];
+        gz += g_pred[3 * r + 2];
+    }
+    d_off[p] = k * (ray_dir[3 * r] * gx + ray_dir[3 * r + 1] * gy + ray_dir[3 * r + 2] * gz);
+}
+
+extern "C" hipError_t lidf_launch_pair_pos(const float* off, const int* pair_ray, const float* pair_t,
+                                           const float* ray_dir, long long P, float r0, float rs,
+                                           float sqrt3, float part, float* out, hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_pair_pos_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, off,
+                       pair_ray, pair_t, ray_dir, P, r0, rs, sqrt3, part, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_ray_select(const float* pos, const long long* id, long long R,
+                                             long long P, float* pred_pos, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_ray_select_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, pos,
+                       id, R, P, pred_pos);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_pair_pos_backward(const float* g_pos, const float* g_pred,
+                                                    const long long* id, const int* pair_ray,
+                                                    const float* ray_dir, long long P, float k,
+                                                    float* d_off, hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_pair_pos_backward_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                       st, g_pos, g_pred, id, pair_ray, ray_dir, P, k, d_off);
     return hipGetLastError();
 }

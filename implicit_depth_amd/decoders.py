@@ -80,10 +80,23 @@ def _leaky_clamp(y):
     return torch.max(torch.min(y, y * 0.01 + 0.99), y * 0.01)
 
 
-def _decoder_struct(mod, keep):
+def _init_offset_value(mod):
+    """IEF.init_offset (implicit_net.py:104) as a Python float, read from the device once."""
+    v = mod.__dict__.get("_init_offset_f")
+    if v is None:
+        io = mod.init_offset
+        v = float(io.reshape(-1)[0].item()) if torch.is_tensor(io) else float(io)
+        mod.__dict__["_init_offset_f"] = v
+    return v
+
+
+def _decoder_struct(mod, keep, tensors=None):
     """Fill a LidfDecoder from a module's parameters; `keep` collects the contiguous tensors
-    whose storage the struct borrows for the duration of the call."""
-    def p(t):
+    whose storage the struct borrows for the duration of the call. `tensors` (state-dict names ->
+    tensors) overrides the module's live parameters: autograd's backward passes what its forward
+    saved, so that an in-place update between the two is caught by torch's version check."""
+    def p(name):
+        t = tensors[name] if tensors is not None else _get(mod, name)
         t = t.detach()
         if t.dtype != torch.float32:
             raise RuntimeError("lidf_hip: float32 parameters required")
@@ -92,16 +105,15 @@ def _decoder_struct(mod, keep):
         return t.data_ptr()
 
     d = _lib.LidfDecoder()
-    d.w1, d.b1 = p(mod.linear_1.weight), p(mod.linear_1.bias)
-    d.w2, d.b2 = p(mod.linear_2.weight), p(mod.linear_2.bias)
-    d.w3, d.b3 = p(mod.linear_3.weight), p(mod.linear_3.bias)
-    d.w4, d.b4 = p(mod.linear_4.weight), p(mod.linear_4.bias)
+    d.w1, d.b1 = p("linear_1.weight"), p("linear_1.bias")
+    d.w2, d.b2 = p("linear_2.weight"), p("linear_2.bias")
+    d.w3, d.b3 = p("linear_3.weight"), p("linear_3.bias")
+    d.w4, d.b4 = p("linear_4.weight"), p("linear_4.bias")
     is_ief = isinstance(mod, IEF)
     if is_ief:
-        d.wenc, d.benc = p(mod.offset_enc.weight), p(mod.offset_enc.bias)
+        d.wenc, d.benc = p("offset_enc.weight"), p("offset_enc.bias")
         d.n_iter = int(mod.n_iter)
-        d.init_offset = float(mod.init_offset.reshape(-1)[0].item()) if torch.is_tensor(
-            mod.init_offset) else float(mod.init_offset)
+        d.init_offset = _init_offset_value(mod)
     else:
         d.wenc, d.benc = None, None
         d.n_iter = 1
@@ -109,6 +121,11 @@ def _decoder_struct(mod, keep):
     d.is_ief = 1 if is_ief else 0
     d.use_sigmoid = 1 if mod.use_sigmoid else 0
     return d
+
+
+def _get(mod, name):
+    layer, attr = name.split(".")
+    return getattr(getattr(mod, layer), attr)
 
 
 def _check_supported(mod):
@@ -189,30 +206,41 @@ class _DecoderTrainFn(torch.autograd.Function):
             _lib.check(L.lidf_decoder_forward_train_f32(
                 _lib.ptr(x), n, d, ld, C.byref(dec), _lib.ptr(out), _lib.ptr(act), _lib.ptr(ws), wsb,
                 _lib.current_stream(x.device)))
-        ctx.mod, ctx.x, ctx.ld, ctx.act, ctx.ws, ctx.wsb = mod, x, ld, act, ws, wsb
+        # the parameters are saved (not re-read from the module in backward): torch's version
+        # counters then catch an in-place update between forward and backward
+        ctx.mod, ctx.ld, ctx.ws, ctx.wsb = mod, ld, ws, wsb
+        ctx.names = [k for k in _PARAM_ORDER if _has(mod, k)]
+        ctx.save_for_backward(x, act, *params)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        mod, x = ctx.mod, ctx.x
+        mod = ctx.mod
+        x, act = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        saved = dict(zip(ctx.names, ctx.saved_tensors[2:]))
         n, d = x.shape
         keep = []
-        dec = _decoder_struct(mod, keep)
+        dec = _decoder_struct(mod, keep, saved)
         f32 = dict(dtype=torch.float32, device=x.device)
         g = g_out.detach().reshape(-1).contiguous().float()
-        sd = dict(mod.named_parameters())
-        names = [k for k in _PARAM_ORDER if k in sd]
-        gtens = {k: torch.empty_like(sd[k], **f32).contiguous() for k in names}
+        gtens = {k: torch.empty_like(saved[k], **f32).contiguous() for k in ctx.names}
         gs = _lib.LidfDecoderGrads()
         for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _PARAM_ORDER):
             setattr(gs, field, gtens[k].data_ptr() if k in gtens else None)
         d_inp = torch.empty((n, d), **f32) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().lidf_decoder_backward_f32(
-                _lib.ptr(x), n, d, ctx.ld, C.byref(dec), _lib.ptr(ctx.act), _lib.ptr(g),
+                _lib.ptr(x), n, d, ctx.ld, C.byref(dec), _lib.ptr(act), _lib.ptr(g),
                 _lib.ptr(d_inp), d, C.byref(gs), _lib.ptr(ctx.ws), ctx.wsb,
                 _lib.current_stream(x.device)))
-        return (None, d_inp) + tuple(gtens[k] for k in names)
+        # frozen parameters get no gradient tensor
+        return (None, d_inp) + tuple(gtens[k] if ctx.needs_input_grad[2 + i] else None
+                                     for i, k in enumerate(ctx.names))
+
+
+def _has(mod, name):
+    layer, _ = name.split(".")
+    return hasattr(mod, layer)
 
 
 class _DecoderBase(nn.Module):
@@ -221,8 +249,7 @@ class _DecoderBase(nn.Module):
         _check_supported(self)
         if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != self.inp_dim:
             raise RuntimeError("inp_feat must be float32 [n, %d]" % self.inp_dim)
-        sd = dict(self.named_parameters())
-        return _DecoderTrainFn.apply(self, inp_feat, *[sd[k] for k in _PARAM_ORDER if k in sd])
+        return _DecoderTrainFn.apply(self, inp_feat, *[_get(self, k) for k in _PARAM_ORDER if _has(self, k)])
 
     def _needs_autograd(self, inp_feat):
         if not torch.is_grad_enabled():
@@ -276,6 +303,7 @@ class IEF(_DecoderBase):
         super(IEF, self).__init__()
         self.device = device
         self.init_offset = torch.Tensor([0.001]).float().to(self.device)
+        self._init_offset_f = 0.001   # host copy: no device read per call
         self.inp_dim = inp_dim
         self.gf_dim = gf_dim
         self.n_iter = n_iter

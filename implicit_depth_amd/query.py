@@ -173,6 +173,28 @@ def to_reference_order(pair_ray, pair_vox):
 PRECISIONS = {"f32": 0, "f16x3": 1}
 
 
+def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, dp, do, dev):
+    """Packed weight streams of the fused query (lidf_query_pack_f32), cached on prob_dec and
+    rebuilt when any parameter of either decoder was modified (torch's in-place version counter)
+    or replaced (data pointer) — so an eval loop packs once per checkpoint and a training loop once
+    per optimizer step, not once per frame."""
+    params = [p for m in (prob_dec, offset_dec) for p in m.parameters()]
+    key = (id(offset_dec), multires, multires_views, precision, str(dev),
+           tuple((p.data_ptr(), p._version) for p in params))
+    cache = prob_dec.__dict__.get("_lidf_pack_cache")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    L = _lib.lib()
+    nb = L.lidf_query_pack_bytes()
+    blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.lidf_query_pack_f32(C.byref(dp), C.byref(do), multires, multires_views,
+                                         PRECISIONS[precision], _lib.ptr(blob), nb,
+                                         _lib.current_stream(dev)))
+    prob_dec.__dict__["_lidf_pack_cache"] = (key, blob)
+    return blob
+
+
 def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
@@ -269,6 +291,8 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     q.precision = PRECISIONS[precision]
+    packed = _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, dp, do, dev)
+    q.packed = packed.data_ptr()
     with torch.cuda.device(dev):
         if profile_events is not None:  # (hipEvent_t begin, hipEvent_t end): benchmarks only
             _lib.check(L.lidf_query_profile_f32(C.byref(q), profile_events[0], profile_events[1],
@@ -550,18 +574,21 @@ class _QueryDecoderFn(torch.autograd.Function):
             _lib.check(L.lidf_query_decoder_forward_train_f32(
                 C.byref(a), _lib.ptr(out), _lib.ptr(act), _lib.ptr(ws), wsb,
                 _lib.current_stream(vf.device)))
-        ctx.mod, ctx.t = mod, (vf, rf, pe, pair_off, pair_ray, pair_vox, act, ws)
+        ctx.mod, ctx.ws = mod, ws
         ctx.cfg = (multires, multires_views, wsb)
+        ctx.names = [k for k in _dec._PARAM_ORDER if _dec._has(mod, k)]
+        ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, act, *params)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         from . import decoders as _dec
-        mod = ctx.mod
-        vf, rf, pe, pair_off, pair_ray, pair_vox, act, ws = ctx.t
+        mod, ws = ctx.mod, ctx.ws
+        vf, rf, pe, pair_off, pair_ray, pair_vox, act = ctx.saved_tensors[:7]
+        saved = dict(zip(ctx.names, ctx.saved_tensors[7:]))
         multires, multires_views, wsb = ctx.cfg
         keep = []
-        dec = _dec._decoder_struct(mod, keep)
+        dec = _dec._decoder_struct(mod, keep, saved)
         a = _lib.LidfQueryTrainArgs()
         a.n_pairs, a.n_rays, a.n_vox = pair_ray.shape[0], rf.shape[0], vf.shape[0]
         a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
@@ -569,9 +596,8 @@ class _QueryDecoderFn(torch.autograd.Function):
         a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dec)
         f32 = dict(dtype=torch.float32, device=vf.device)
         g = g_out.detach().reshape(-1).contiguous().float()
-        sd = dict(mod.named_parameters())
-        names = [k for k in _dec._PARAM_ORDER if k in sd]
-        gt = {k: torch.empty_like(sd[k], **f32).contiguous() for k in names}
+        names = ctx.names
+        gt = {k: torch.empty_like(saved[k], **f32).contiguous() for k in names}
         gs = _lib.LidfDecoderGrads()
         for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
             setattr(gs, field, gt[k].data_ptr() if k in gt else None)
@@ -581,26 +607,71 @@ class _QueryDecoderFn(torch.autograd.Function):
             _lib.check(_lib.lib().lidf_query_decoder_backward_f32(
                 C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 0,
                 C.byref(gs), _lib.ptr(ws), wsb, _lib.current_stream(vf.device)))
-        return (None, d_vox, d_ray) + (None,) * 6 + tuple(gt[k] for k in names)
+        return (None, d_vox, d_ray) + (None,) * 6 + tuple(
+            gt[k] if ctx.needs_input_grad[9 + i] else None for i, k in enumerate(names))
 
 
 def _query_decoder(mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires, multires_views):
     from . import decoders as _dec
     _dec._check_supported(mod)
-    sd = dict(mod.named_parameters())
     return _QueryDecoderFn.apply(mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires,
-                                 multires_views, *[sd[k] for k in _dec._PARAM_ORDER if k in sd])
+                                 multires_views, *[_dec._get(mod, k) for k in _dec._PARAM_ORDER if _dec._has(mod, k)])
+
+
+class _QueryTailFn(torch.autograd.Function):
+    """pair_pred_pos, per-ray softmax / arg-max / select of LIDF.get_pred (models/pipeline.py:437-454)
+    through lidf_query_tail_f32, adjoint lidf_query_tail_backward_f32. The logits are detached as in
+    the reference (:442): the only gradient is d pred_offset."""
+
+    @staticmethod
+    def forward(ctx, pred_offset, pred_prob, pair_off, pair_ray, pair_t, ray_dir, r0, r1, part, mid_in):
+        dev = ray_dir.device
+        R, P = ray_dir.shape[0], pair_ray.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        off = pred_offset.detach().reshape(-1).contiguous()
+        prob = pred_prob.detach().reshape(-1).contiguous()
+        pos = torch.empty((P, 3), **f32)
+        sm = torch.empty((P,), **f32)
+        mid = torch.empty((R,), dtype=torch.int64, device=dev)
+        pred = torch.empty((R, 3), **f32)
+        if mid_in is not None:
+            mid_in = mid_in.to(torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lidf_query_tail_f32(
+                _lib.ptr(off), _lib.ptr(prob), _lib.ptr(pair_off), _lib.ptr(pair_ray), _lib.ptr(pair_t),
+                _lib.ptr(ray_dir), R, P, r0, r1, part, _lib.ptr(mid_in), _lib.ptr(pos), _lib.ptr(sm),
+                _lib.ptr(mid), _lib.ptr(pred), _lib.current_stream(dev)))
+        sel = mid_in if mid_in is not None else mid
+        ctx.save_for_backward(sel, pair_ray, ray_dir)
+        ctx.cfg = (r0, r1, part, R, P, tuple(pred_offset.shape))
+        ctx.mark_non_differentiable(sm, mid)
+        return pos, sm, sel if mid_in is not None else mid, pred
+
+    @staticmethod
+    def backward(ctx, g_pos, g_sm, g_mid, g_pred):
+        sel, pair_ray, ray_dir = ctx.saved_tensors
+        r0, r1, part, R, P, shape = ctx.cfg
+        d_off = torch.empty((P,), dtype=torch.float32, device=ray_dir.device)
+        g_pos = g_pos.contiguous().float() if g_pos is not None else None
+        g_pred = g_pred.contiguous().float() if g_pred is not None else None
+        with torch.cuda.device(ray_dir.device):
+            _lib.check(_lib.lib().lidf_query_tail_backward_f32(
+                _lib.ptr(g_pos), _lib.ptr(g_pred), _lib.ptr(sel), _lib.ptr(pair_ray), _lib.ptr(ray_dir),
+                R, P, r0, r1, part, _lib.ptr(d_off), _lib.current_stream(ray_dir.device)))
+        return (d_off.reshape(shape),) + (None,) * 9
 
 
 def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                      vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                      offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-                     factorised=True):
+                     factorised=True, max_pair_id=None):
     """Differentiable get_embedding + get_pred (models/pipeline.py:338-466) for training
     (train_lidf.py:393-396): gradients reach feat_grid (through RoIAlign), vox_feat and every
     decoder parameter, all through liblidf_hip — ROI pooling, the decoder input rows, the decoders'
-    forward that keeps activations and their backward. The cheap per-pair / per-ray tail
-    (pair_pred_pos, softmax over a ray, arg-max, select) is written in torch ops on [P] vectors.
+    forward that keeps activations and their backward, and the per-pair / per-ray tail
+    (pair_pred_pos, softmax over a ray of the detached logits, arg-max, select) with its adjoint.
+    max_pair_id [R] int64 overrides the arg-max selection: the reference selects by ground-truth
+    labels while epoch < maxpool_label_epo (pipeline.py:444-446).
     Same arguments as lidf_query; the decoders must be in autograd mode (parameters requiring grad).
     factorised=True (default) keeps the layer-1 rewrite of the inference kernel — per-voxel and
     per-ray partial products, only the positional encodings as per-pair rows, the layer-1 gradient
@@ -630,21 +701,9 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
                                   vox_center, pos_rel, multires, multires_views)
         pred_prob = prob_dec(rows)
         pred_offset = offset_dec(rows)
-    pr = pair_ray.long()
-    d = ray_dir[pr]
-    # pipeline.py:437-439
-    sc = pred_offset * (offset_range[1] - offset_range[0]) + offset_range[0]
-    sc = sc * float(torch.tensor(math.sqrt(3.0), dtype=torch.float32)) * part_size
-    pair_pred_pos = d * pair_t[:, 0:1] + sc * d
-    # scatter_softmax over the pairs of a ray, scatter_max, dummy-row select (pipeline.py:442-454)
-    logit = pred_prob[:, 0]
-    m = torch.full((R,), float("-inf"), device=logit.device).scatter_reduce(0, pr, logit.detach(), "amax")
-    e = torch.exp(logit - m[pr])
-    sm = e / torch.zeros(R, device=logit.device).index_add(0, pr, e)[pr]
-    best = torch.full((R,), float("-inf"), device=logit.device).scatter_reduce(0, pr, sm.detach(), "amax")
-    idx = torch.arange(P, device=logit.device)
-    cand = torch.where(sm.detach() == best[pr], idx, torch.full_like(idx, P))
-    max_pair_id = torch.full((R,), P, dtype=torch.long, device=logit.device).scatter_reduce(0, pr, cand, "amin")
-    dummy = torch.cat((pair_pred_pos, torch.zeros(1, 3, device=logit.device)), 0)
+    pair_pred_pos, sm, mid, pred_pos = _QueryTailFn.apply(
+        pred_offset, pred_prob, pair_off, pair_ray, pair_t, ray_dir, float(offset_range[0]),
+        float(offset_range[1]), float(part_size), max_pair_id)
     return {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
-            "pred_prob_end_softmax": sm, "max_pair_id": max_pair_id, "pred_pos": dummy[max_pair_id]}
+            "pred_prob_end_softmax": sm, "max_pair_id": mid, "pred_pos": pred_pos}
+

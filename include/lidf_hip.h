@@ -142,7 +142,20 @@ typedef struct LidfQueryArgs {
      *       v_mfma_f32_32x32x16_f16 products per term, f32 accumulation: f32-level accuracy
      *       (relative error of a product <= 2^-22) as long as |activations| < 65504        */
     int32_t precision;
+    /* optional: the decoders' weights already packed by lidf_query_pack_f32 for the SAME multires,
+     * multires_views and precision (device memory, read-only here). NULL = pack inside this call
+     * (3 small launches); eval loops pack once per checkpoint, training loops once per optimizer
+     * step. The LidfDecoder pointers are then only consulted for n_iter / init_offset / sigmoid. */
+    const void* packed;
 } LidfQueryArgs;
+
+/* Packed weights of the fused query: the parameters of prob_dec / offset_dec re-ordered into the
+ * streams the kernels consume (the reference re-reads nn.Linear storage every call; here the
+ * re-ordering is hoisted out of the per-frame path). Valid until a parameter changes.           */
+size_t lidf_query_pack_bytes(void);
+int lidf_query_pack_f32(const LidfDecoder* prob, const LidfDecoder* off, int multires,
+                        int multires_views, int precision, void* packed, size_t packed_bytes,
+                        lidf_stream_t stream);
 
 /* grid_floats = batch*32*height*width makes room for the optional 4x4 box-sum image that turns the
  * ROIAlign of unclamped boxes into 4 gathers per channel; 0 = minimal workspace (general path). */
@@ -410,6 +423,24 @@ int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float*
                                     const float* g_out, float* d_vox_feat, float* d_rayfeat,
                                     int32_t accumulate_inputs, const LidfDecoderGrads* grads,
                                     void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
+/* ---- Per-pair / per-ray tail of get_pred with its adjoint --------------------------------------
+ * models/pipeline.py:437-454 for the training path (the inference path has it inside
+ * lidf_query_f32): pair_pred_pos = dir t_enter + ((off (r1-r0) + r0) sqrt(3) part_size) dir, the
+ * per-ray softmax of the (detached, :442) logits, arg-max (or max_pair_id_in: the ground-truth
+ * selection of :444-446) and pred_pos = pair_pred_pos[max_pair_id] with the dummy row. The adjoint
+ * returns d pred_offset [P] from the gradients of pair_pred_pos [P,3] and pred_pos [R,3] (either may
+ * be NULL); nothing flows into the logits.                                                        */
+int lidf_query_tail_f32(const float* pred_offset, const float* pred_prob, const int32_t* pair_off,
+                        const int32_t* pair_ray, const float* pair_t, const float* ray_dir,
+                        int64_t n_rays, int64_t n_pairs, float offset_range0, float offset_range1,
+                        float part_size, const int64_t* max_pair_id_in, float* pair_pred_pos,
+                        float* softmax, int64_t* max_pair_id, float* pred_pos, lidf_stream_t stream);
+int lidf_query_tail_backward_f32(const float* g_pair_pred_pos, const float* g_pred_pos,
+                                 const int64_t* max_pair_id, const int32_t* pair_ray,
+                                 const float* ray_dir, int64_t n_rays, int64_t n_pairs,
+                                 float offset_range0, float offset_range1, float part_size,
+                                 float* d_pred_offset, lidf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -116,3 +116,39 @@ def test_autograd_path_matches_hip(cuda):
     assert pts.grad is not None
     with torch.no_grad():
         assert (fn(pts.detach()) - e.detach()).abs().max().item() <= 1e-6
+
+
+def test_packed_weights_follow_parameter_updates(cuda):
+    """The query caches its packed weight streams per parameter version: an in-place update, a
+    load_state_dict and a replaced .data must all be picked up by the next call."""
+    scene = orc.synthetic_scene(1, 8, 12, 4, seed=91)
+    from implicit_depth_amd.query import lidf_query
+    from util import to_dev
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob, off = make_module("IMNET", scene["prob_p"], D, cuda), make_module("IEF", scene["off_p"], D, cuda)
+
+    def run():
+        with torch.no_grad():
+            return lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                              s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+    a = run()
+    cache0 = prob.__dict__["_lidf_pack_cache"][1]
+    b = run()
+    assert prob.__dict__["_lidf_pack_cache"][1] is cache0                 # reused
+    assert (a["pred_offset"] == b["pred_offset"]).all()
+    with torch.no_grad():
+        off.linear_2.weight.mul_(1.25)                                     # in-place (optimizer step)
+    c = run()
+    p2 = {k: v.clone() for k, v in scene["off_p"].items()}
+    p2["linear_2.weight"] = p2["linear_2.weight"] * 1.25
+    ref = oracle_query(dict(scene, off_p=p2))
+    assert (c["pred_offset"].cpu() - ref["pred_offset"]).abs().max().item() <= TOL
+    assert (c["pred_offset"] - a["pred_offset"]).abs().max().item() > 1e-4
+    prob.load_state_dict({k: v * 0.5 for k, v in scene["prob_p"].items()})  # copy_ in place
+    d = run()
+    ref = oracle_query(dict(scene, off_p=p2, prob_p={k: v * 0.5 for k, v in scene["prob_p"].items()}))
+    assert (d["pred_prob_end"].cpu() - ref["pred_prob_end"]).abs().max().item() <= TOL
+    prob.linear_1.weight.data = prob.linear_1.weight.data * 2.0             # replaced storage
+    e = run()
+    assert (e["pred_prob_end"] - d["pred_prob_end"]).abs().max().item() > 1e-5
