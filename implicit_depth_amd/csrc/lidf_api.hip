@@ -7,6 +7,7 @@ extern "C" {
 hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                             float*, hipStream_t);
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_l1only_pair(const PointsArgs&, int, const PointsArgs&, int, hipStream_t);
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
 hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
@@ -439,23 +440,21 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
 
-        // 2. per-voxel partial  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c)
-        {
-            PointsArgs a = {};
-            a.stream = stream_vox; a.aux = aux_pts;
-            a.nets = 2; a.l1_quads = lv.l1_quads; a.net_quads = lv.net_quads;
-            a.n = V; a.X = q->vox_feat; a.ldx = 128;
-            a.D = mv.D; a.KQ1 = mv.KQ1; a.has_bias = 1;
-            a.out_base = voxpart;
-            long long nt = (V + 127) / 128;
-            CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
-        }
-        // 3. per-ray features and partial  raypart[r] = W1[:, rgb|dir] rayfeat[r]
+        // 2. per-ray features [ROI 2x2 of the feature map | embed(dir)]
         CHECK_HIP(lidf_launch_rayfeat(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
                                       q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
                                       q->ray_bid, R, q->roi_inp_bbox / 2, Lv, rayfeat, 128 + Ed,
                                       st));
+        // 3. layer-1 partial products: per voxel  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c),
+        //    per ray  raypart[r] = W1[:, rgb|dir] rayfeat[r]
         {
+            PointsArgs av = {};
+            av.stream = stream_vox; av.aux = aux_pts;
+            av.nets = 2; av.l1_quads = lv.l1_quads; av.net_quads = lv.net_quads;
+            av.n = V; av.X = q->vox_feat; av.ldx = 128;
+            av.D = mv.D; av.KQ1 = mv.KQ1; av.has_bias = 1;
+            av.out_base = voxpart;
+            const long long ntv = (V + 127) / 128;
             PointsArgs a = {};
             a.stream = stream_ray; a.aux = aux_pts;
             a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
@@ -464,13 +463,17 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.out_base = raypart;
             long long nt = (R + 127) / 128;
             if (split) {
+                CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, av, (int)(ntv < 2 * cus ? ntv : 2 * cus), st));
                 // the per-ray partial products with the split-f16 rows kernel (layer 1 only)
                 StreamLayout lh = lidf_make_layout_rows_h(2, mr.D, 1);
                 a.l1_quads = lh.l1_quads; a.net_quads = lh.net_quads;
                 a.npass[0] = a.npass[1] = 0;
                 CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
             } else {
-                CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, a, (int)(nt < 2 * cus ? nt : 2 * cus), st));
+                // one launch: (ray tiles | voxel tiles) x nets; two workgroups fit a CU
+                const int gx_v = (int)(ntv < 32 ? ntv : 32);
+                const int gx_r = (int)(nt < cus - gx_v ? nt : (cus - gx_v > 1 ? cus - gx_v : 1));
+                CHECK_HIP(lidf_launch_l1only_pair(a, gx_r, av, gx_v, st));
             }
         }
         // 4. per-point kernel

@@ -655,7 +655,8 @@ __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
 // producers) on materialised input rows.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
+__device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int bx, const int gx,
+                                                 const int net_lo, const int net_hi) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
@@ -669,15 +670,15 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
 
     // contiguous range of 128-row tiles per workgroup; the 4 waves interleave inside it
     const long long ntile = (a.n + 127) / 128;
-    const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
-    const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
-    const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
+    const long long per = ntile / gx, rem = ntile % gx;
+    const long long tb = bx * per + (bx < rem ? bx : rem);
+    const long long te_ = tb + per + (bx < rem ? 1 : 0);
     if (tb >= te_) return;
 
     // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
     f32x4 ring[LIDF_RING];
 #pragma unroll
-    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, net_lo * net_bytes + i * 1024);
 
     PROF_DECL
     for (long long tile = tb; tile < te_; ++tile) {
@@ -686,9 +687,9 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
         const bool valid = p < a.n;
         const long long pc = valid ? p : a.n - 1;
 
-        for (int net = 0; net < a.nets; ++net) {
+        for (int net = net_lo; net < net_hi; ++net) {
             const int nsb = net * net_bytes;  // byte offset of this net's block
-            const int next_blk = net + 1 < a.nets ? nsb + net_bytes : 0;
+            const int next_blk = net + 1 < net_hi ? nsb + net_bytes : net_lo * net_bytes;
             f32x16 base[8];
 
             // ---------------- layer 1 ----------------
@@ -791,8 +792,32 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
 }
 
 template <int MODE>
+__global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
+    points_rows_body<MODE>(a, blockIdx.x, gridDim.x, 0, a.nets);
+}
+
+// Layer-1-only launch of the query: the per-ray rows (problem a, workgroups [0, gx_a) of every
+// grid row) and the per-voxel rows (problem b, the remaining workgroups) in ONE launch, each net
+// on its own grid row: twice the work items of a (tile, both nets) split, so the last round of
+// tiles is better filled, and the small per-voxel problem runs beside the per-ray one.
+__global__ void __launch_bounds__(256) lidf_l1only_pair_kernel(PointsArgs a, PointsArgs b, int gx_a) {
+    const int net = blockIdx.y;
+    if ((int)blockIdx.x < gx_a)
+        points_rows_body<LIDF_MODE_L1ONLY>(a, blockIdx.x, gx_a, net, net + 1);
+    else
+        points_rows_body<LIDF_MODE_L1ONLY>(b, blockIdx.x - gx_a, gridDim.x - gx_a, net, net + 1);
+}
+
+template <int MODE>
 static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((lidf_points_kernel<MODE>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, int gx_a, const PointsArgs& b,
+                                              int gx_b, hipStream_t st) {
+    if (a.n <= 0 || b.n <= 0 || a.nets != b.nets) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lidf_l1only_pair_kernel, dim3(gx_a + gx_b, a.nets), dim3(256), 0, st, a, b, gx_a);
     return hipGetLastError();
 }
 
