@@ -196,7 +196,8 @@ def profile_record(kernel_name):
 
 
 # launches per step of the f32 query (for the per-step HBM counter sum)
-PER_STEP_LAUNCHES = {"void lidf_points_kernel<2>": 2, "lidf_pack_kernel": 3}
+PER_STEP_LAUNCHES = {"lidf_pack_kernel": 0, "void lidf_points_kernel<2>": 0,
+                     "rowsh::lidf_rows_h_kernel": 0, "_ZN5rowsh18lidf_pack_r_kernelE12StreamLayout4NetWS1_5L1MapPDF16_Pf": 0}
 
 
 def refine_setup(scene, s, dev, precision="f32"):
@@ -581,7 +582,7 @@ def main():
         h16 = args.precision == "f16x3"
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
-        kname = "lidf_points_h_kernel" if h16 else "lidf_points_kernel<0>"
+        kname = "lidf_points_h_kernel" if h16 else "lidf_points_fused_kernel"
         prof = profile_record(kname)
         ach = f_exec * P / (kern_ms * 1e-3) / 1e12          # MFMA FLOP issued / time
         ach_alg = F_ALG * P / (kern_ms * 1e-3) / 1e12       # reference-formulation FLOP / time

@@ -2,7 +2,7 @@
 under profiles/: per-kernel stats of the --kernel-trace --stats run, and per-kernel HBM byte
 counters of the separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs.
 
-usage: python scripts/prof_summary.py <tag> <kernel_trace.db> [<fetch.db> <write.db>]
+usage: python scripts/prof_summary.py <tag> <kernel_trace.db> [<fetch.db> <write.db> [<mfma_pmc.db>]]
 """
 import json
 import os
@@ -61,12 +61,28 @@ def main():
                 traffic[r[0]] = {"reported": rep, "corrected": cor}
         print(open(os.path.join(out, "%s_hbm_pmc.csv" % tag)).read())
         for k, v in traffic.items():
-            if "lidf_points_kernel<0>" in k:
+            if "lidf_points_fused_kernel" in k:
                 json.dump({"source": "profiles/%s_hbm_pmc.csv" % tag,
                            "lidf_points_kernel_bytes_per_launch": v["corrected"],
                            "reported_uncorrected": v["reported"]},
                           open(os.path.join(out, "hbm_traffic.json"), "w"))
 
 
+def mfma_counters(tag, db):
+    """Per-kernel averages of the MFMA counters of a separate --pmc pass."""
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                            "where kernel_name like '%lidf_points%' group by kernel_name, counter_name"))
+    with open(os.path.join(ROOT, "profiles", "%s_mfma_pmc.csv" % tag), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -- "
+                "python bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
+        f.write("kernel,counter,dispatches,avg_value\n")
+        for r in rows:
+            f.write('"%s",%s,%d,%.6g\n' % (r[0], r[1], r[2], r[3]))
+    print(open(os.path.join(ROOT, "profiles", "%s_mfma_pmc.csv" % tag)).read())
+
+
 if __name__ == "__main__":
     main()
+    if len(sys.argv) >= 6:
+        mfma_counters(sys.argv[1], sys.argv[5])
