@@ -40,5 +40,36 @@ def build(force=False, verbose=False):
     return LIB
 
 
+EXT_SRC = os.path.join(HERE, "lidf_torch_ext.cpp")
+EXT = os.path.join(HERE, "lidf_torch_ext.so")
+
+
+def build_torch_ext(force=False, verbose=False):
+    """The pybind11 torch-extension shim over the C ABI (lidf_torch_ext.cpp): plain g++ against
+    torch's headers, linked to liblidf_hip.so beside it ($ORIGIN rpath)."""
+    build(force=False)
+    deps = [EXT_SRC, LIB, os.path.join(ROOT, "include", "lidf_hip.h")]
+    if not force and os.path.exists(EXT) and all(os.path.getmtime(d) <= os.path.getmtime(EXT) for d in deps):
+        return EXT
+    import sysconfig
+    import torch
+    ti = os.path.dirname(torch.__file__)
+    cmd = [
+        os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared",
+        "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=lidf_torch_ext",
+        "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+        "-I", os.path.join(ti, "include"), "-I", os.path.join(ti, "include", "torch", "csrc", "api", "include"),
+        "-I", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"], "-I", os.path.join(ROOT, "include"),
+        EXT_SRC, "-o", EXT, "-L", HERE, "-l:liblidf_hip.so", "-L", os.path.join(ti, "lib"),
+        "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
+        "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ti, "lib"),
+    ]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return EXT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -64,6 +64,18 @@ def test_struct_layouts_match_header(tmp_path):
             assert int(seen["%s.%s" % (n, f)]) == getattr(cls, f).offset, (n, f)
 
 
+def test_torch_extension_shim_loads():
+    """The pybind11 shim over the C ABI is built in-tree and imports without a GPU."""
+    from implicit_depth_amd import torch_ext
+    m = torch_ext.ext()
+    assert m.abi_version() == 2
+    for fn in ("ray_aabb", "pcl_aabb", "compute_ray_aabb", "forward_decoders", "forward_query"):
+        assert callable(getattr(m, fn))
+    with pytest.raises(RuntimeError):     # CHECK_INPUT of the reference bindings: CUDA tensors only
+        m.pcl_aabb(torch.zeros(1, 3), torch.zeros(1, 6), torch.zeros(1, dtype=torch.int32),
+                   torch.zeros(1, dtype=torch.int32))
+
+
 def test_modules_keep_reference_interface():
     from implicit_depth_amd import IEF, IMNet, get_embedder
     fn, dim = get_embedder(8)
