@@ -68,6 +68,12 @@ class LidfPointNet(C.Structure):
         "w_p1", "b_p1", "w_p2", "b_p2", "w_v1", "b_v1", "w_p3", "b_p3", "w_p4", "b_p4", "w_v2", "b_v2")]
 
 
+class LidfPointNetGrads(C.Structure):
+    """struct LidfPointNetGrads (include/lidf_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "w_p1", "b_p1", "w_p2", "b_p2", "w_v1", "b_v1", "w_p3", "b_p3", "w_p4", "b_p4", "w_v2", "b_v2")]
+
+
 class LidfRefineArgs(C.Structure):
     """struct LidfRefineArgs (include/lidf_hip.h)."""
     _fields_ = [
@@ -135,6 +141,12 @@ SIGNATURES = {
                                                        C.c_size_t, _P]),
     "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
                                                   C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
+    "lidf_embed_backward_f32": (C.c_int, [_P, _P, _I64, _I, _P, _P]),
+    "lidf_pointnet_train_act_floats": (_SZ, [_I64, _I64]),
+    "lidf_pointnet_train_workspace_bytes": (_SZ, [_I64, _I64]),
+    "lidf_pointnet_forward_train_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "lidf_pointnet_backward_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _P,
+                                             C.POINTER(LidfPointNetGrads), _P, _SZ, _P]),
     "lidf_query_tail_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float, C.c_float,
                                       _P, _P, _P, _P, _P, _P]),
     "lidf_query_tail_backward_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float,

@@ -61,6 +61,12 @@ hipError_t lidf_launch_ray_select(const float*, const long long*, long long, lon
                                   hipStream_t);
 hipError_t lidf_launch_pair_pos_backward(const float*, const float*, const long long*, const int*,
                                          const float*, long long, float, float*, hipStream_t);
+hipError_t lidf_launch_relu_mask(const float*, const float*, long long, float*, hipStream_t);
+hipError_t lidf_launch_segmax_arg(const float*, const int*, const float*, long long, int, int*, hipStream_t);
+hipError_t lidf_launch_segmax_backward(const float*, const int*, const int*, const float*, long long, int,
+                                       int, float*, hipStream_t);
+hipError_t lidf_launch_seg_sum_rows(const float*, const int*, long long, int, float*, hipStream_t);
+hipError_t lidf_launch_embed_backward(const float*, const float*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
 struct GridSpec {
@@ -748,58 +754,74 @@ LIDF_API size_t lidf_pointnet_workspace_bytes(int64_t n_pts, int64_t n_vox) {
     return pnet_ws(n_pts, n_vox).total;
 }
 
+static int check_pointnet_w(const LidfPointNet* w) {
+    if (!w || !w->w_p1 || !w->b_p1 || !w->w_p2 || !w->b_p2 || !w->w_v1 || !w->b_v1 || !w->w_p3 ||
+        !w->b_p3 || !w->w_p4 || !w->b_p4 || !w->w_v2 || !w->b_v2)
+        return LIDF_ERR_BAD_ARG;
+    return LIDF_OK;
+}
+
+// every intermediate of PointNet2Stage.forward (models/pointnet.py:22-38); f5 may be NULL when the
+// pooled layer's rows are not needed (inference)
+struct PnetBufs {
+    float *f1, *f2, *pool1, *g1, *gpart, *f4, *f5, *pool2;
+    float* streams[7];
+};
+
+static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n,
+                         int64_t n_vox, float* out, const PnetBufs& b, int cus, hipStream_t st) {
+    int rc;
+    // torch_scatter fills voxels without points with 0; values are post-ReLU so 0 is the identity
+    CHECK_HIP(hipMemsetAsync(b.pool1, 0, (size_t)n_vox * 64 * 4, st));
+    CHECK_HIP(hipMemsetAsync(b.pool2, 0, (size_t)n_vox * 128 * 4, st));
+    // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
+    if ((rc = run_linear({w->w_p1, w->b_p1, 32, 6, 0, 6}, inp, 6, n, nullptr, nullptr, 1, b.f1, 32,
+                         nullptr, nullptr, b.streams[0], cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_p2, w->b_p2, 64, 32, 0, 32}, b.f1, 32, n, nullptr, nullptr, 1, b.f2, 64,
+                         b.pool1, vox, b.streams[1], cus, st)))
+        return rc;
+    // occ_voxel_feat = relu(vox_lin1(pool1))
+    if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
+                         b.g1, 64, nullptr, nullptr, b.streams[2], cus, st)))
+        return rc;
+    // point_lin3(cat(voxel feat, point_feat2)) = W3[:, :64] g1[vox] + W3[:, 64:] f2 + b3
+    if ((rc = run_linear({w->w_p3, nullptr, 128, 128, 0, 64}, b.g1, 64, n_vox, nullptr, nullptr, 0,
+                         b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 64, 64}, b.f2, 64, n, b.gpart, vox, 1, b.f4, 128,
+                         nullptr, nullptr, b.streams[4], cus, st)))
+        return rc;
+    // point_feat5 = relu(point_lin4(.)) pooled per voxel; out = relu(vox_lin2(pool2))
+    if ((rc = run_linear({w->w_p4, w->b_p4, 128, 128, 0, 128}, b.f4, 128, n, nullptr, nullptr, 1,
+                         b.f5, 128, b.pool2, vox, b.streams[5], cus, st)))
+        return rc;
+    if ((rc = run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, b.pool2, 128, n_vox, nullptr, nullptr,
+                         1, out, 128, nullptr, nullptr, b.streams[6], cus, st)))
+        return rc;
+    return LIDF_OK;
+}
+
 LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
                                int64_t n, int64_t n_vox, float* out, void* workspace,
                                size_t workspace_bytes, lidf_stream_t stream) {
     if (!w || n < 0 || n_vox < 0) return LIDF_ERR_BAD_ARG;
     if (n_vox == 0) return LIDF_OK;
     if (!out || (n > 0 && (!inp || !vox))) return LIDF_ERR_BAD_ARG;
-    if (!w->w_p1 || !w->b_p1 || !w->w_p2 || !w->b_p2 || !w->w_v1 || !w->b_v1 || !w->w_p3 ||
-        !w->b_p3 || !w->w_p4 || !w->b_p4 || !w->w_v2 || !w->b_v2)
-        return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
     PnetWs ws = pnet_ws(n, n_vox);
     if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
-    float* f1 = (float*)(base + ws.f1);
-    float* f2 = (float*)(base + ws.f2);
-    float* pool1 = (float*)(base + ws.pool1);
-    float* g1 = (float*)(base + ws.g1);
-    float* gpart = (float*)(base + ws.gpart);
-    float* f4 = (float*)(base + ws.f4);
-    float* pool2 = (float*)(base + ws.pool2);
-    int cus, rc;
+    PnetBufs b = {};
+    b.f1 = (float*)(base + ws.f1); b.f2 = (float*)(base + ws.f2);
+    b.pool1 = (float*)(base + ws.pool1); b.g1 = (float*)(base + ws.g1);
+    b.gpart = (float*)(base + ws.gpart); b.f4 = (float*)(base + ws.f4);
+    b.f5 = nullptr; b.pool2 = (float*)(base + ws.pool2);
+    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)(base + ws.s[i]);
+    int cus;
     if ((rc = cu_count(&cus))) return rc;
-    // torch_scatter fills voxels without points with 0; values are post-ReLU so 0 is the identity
-    CHECK_HIP(hipMemsetAsync(pool1, 0, (size_t)n_vox * 64 * 4, st));
-    CHECK_HIP(hipMemsetAsync(pool2, 0, (size_t)n_vox * 128 * 4, st));
-    auto S = [&](int i) { return (float*)(base + ws.s[i]); };
-    // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
-    if ((rc = run_linear({w->w_p1, w->b_p1, 32, 6, 0, 6}, inp, 6, n, nullptr, nullptr, 1, f1, 32,
-                         nullptr, nullptr, S(0), cus, st)))
-        return rc;
-    if ((rc = run_linear({w->w_p2, w->b_p2, 64, 32, 0, 32}, f1, 32, n, nullptr, nullptr, 1, f2, 64,
-                         pool1, vox, S(1), cus, st)))
-        return rc;
-    // occ_voxel_feat = relu(vox_lin1(pool1))
-    if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, n_vox, nullptr, nullptr, 1,
-                         g1, 64, nullptr, nullptr, S(2), cus, st)))
-        return rc;
-    // point_lin3(cat(voxel feat, point_feat2)) = W3[:, :64] g1[vox] + W3[:, 64:] f2 + b3
-    if ((rc = run_linear({w->w_p3, nullptr, 128, 128, 0, 64}, g1, 64, n_vox, nullptr, nullptr, 0,
-                         gpart, 128, nullptr, nullptr, S(3), cus, st)))
-        return rc;
-    if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 64, 64}, f2, 64, n, gpart, vox, 1, f4, 128,
-                         nullptr, nullptr, S(4), cus, st)))
-        return rc;
-    // point_feat5 = relu(point_lin4(.)) pooled per voxel; out = relu(vox_lin2(pool2))
-    if ((rc = run_linear({w->w_p4, w->b_p4, 128, 128, 0, 128}, f4, 128, n, nullptr, nullptr, 1,
-                         nullptr, 0, pool2, vox, S(5), cus, st)))
-        return rc;
-    if ((rc = run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, pool2, 128, n_vox, nullptr, nullptr,
-                         1, out, 128, nullptr, nullptr, S(6), cus, st)))
-        return rc;
-    return LIDF_OK;
+    return pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, (hipStream_t)stream);
 }
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
@@ -1526,5 +1548,186 @@ LIDF_API int lidf_query_tail_backward_f32(const float* g_pair_pred_pos, const fl
     CHECK_HIP(lidf_launch_pair_pos_backward(g_pair_pred_pos, g_pred_pos, (const long long*)max_pair_id,
                                             pair_ray, ray_dir, n_pairs, k, d_pred_offset,
                                             (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- positional encoding, backward ---------------------------------------------------------------
+LIDF_API int lidf_embed_backward_f32(const float* x, const float* g_out, int64_t n, int multires,
+                                       float* d_x, lidf_stream_t stream) {
+    if (n < 0 || multires < 0 || multires > 16) return LIDF_ERR_BAD_ARG;
+    if (n == 0) return LIDF_OK;
+    if (!x || !g_out || !d_x) return LIDF_ERR_BAD_ARG;
+    CHECK_HIP(lidf_launch_embed_backward(x, g_out, n, multires, d_x, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- PointNet2Stage, training path ----------------------------------------------------------------
+struct PnetAct {   // offsets in floats into the caller's `act`
+    size_t f1, f2, f4, f5, pool1, g1, pool2, out, arg1, arg2, total;
+};
+static PnetAct pnet_act(int64_t n, int64_t v) {
+    PnetAct a;
+    const size_t N = (size_t)(n > 0 ? n : 1), V = (size_t)(v > 0 ? v : 1);
+    size_t o = 0;
+    a.f1 = o; o += N * 32;
+    a.f2 = o; o += N * 64;
+    a.f4 = o; o += N * 128;
+    a.f5 = o; o += N * 128;
+    a.pool1 = o; o += V * 64;
+    a.g1 = o; o += V * 64;
+    a.pool2 = o; o += V * 128;
+    a.out = o; o += V * 128;
+    a.arg1 = o; o += V * 64;    // int32
+    a.arg2 = o; o += V * 128;   // int32
+    a.total = o;
+    return a;
+}
+struct PnetTrainWs {
+    size_t s[7], gpart, stream, dz_out, dp2, dz5, dz4, s4, dg1, df2, dp1, dz1, total;
+};
+static PnetTrainWs pnet_train_ws(int64_t n, int64_t v) {
+    PnetTrainWs w;
+    const size_t N = (size_t)(n > 0 ? n : 1), V = (size_t)(v > 0 ? v : 1);
+    size_t o = 0;
+    const int ks[7] = {6, 32, 64, 64, 64, 128, 128};
+    const int nts[7] = {1, 2, 2, 4, 4, 4, 4};
+    for (int i = 0; i < 7; ++i) { w.s[i] = o; o += lin_stream_bytes(ks[i], nts[i]); }
+    w.gpart = o;  o += align_up(V * 128 * 4, 256);
+    w.stream = o; o += linex_stream_bytes(256);
+    w.dz_out = o; o += align_up(V * 128 * 4, 256);
+    w.dp2 = o;    o += align_up(V * 128 * 4, 256);
+    w.dz5 = o;    o += align_up(N * 128 * 4, 256);
+    w.dz4 = o;    o += align_up(N * 128 * 4, 256);
+    w.s4 = o;     o += align_up(V * 128 * 4, 256);
+    w.dg1 = o;    o += align_up(V * 64 * 4, 256);
+    w.df2 = o;    o += align_up(N * 64 * 4, 256);
+    w.dp1 = o;    o += align_up(V * 64 * 4, 256);
+    w.dz1 = o;    o += align_up(N * 32 * 4, 256);
+    w.total = o;
+    return w;
+}
+
+LIDF_API size_t lidf_pointnet_train_act_floats(int64_t n_pts, int64_t n_vox) {
+    return pnet_act(n_pts, n_vox).total;
+}
+LIDF_API size_t lidf_pointnet_train_workspace_bytes(int64_t n_pts, int64_t n_vox) {
+    return pnet_train_ws(n_pts, n_vox).total;
+}
+
+LIDF_API int lidf_pointnet_forward_train_f32(const LidfPointNet* w, const float* inp,
+                                               const int32_t* vox, int64_t n, int64_t n_vox,
+                                               float* out, float* act, void* workspace,
+                                               size_t workspace_bytes, lidf_stream_t stream) {
+    if (!w || n < 0 || n_vox < 0) return LIDF_ERR_BAD_ARG;
+    if (n_vox == 0) return LIDF_OK;
+    if (!out || !act || (n > 0 && (!inp || !vox))) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
+    const PnetTrainWs ws = pnet_train_ws(n, n_vox);
+    if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
+    const PnetAct a = pnet_act(n, n_vox);
+    char* base = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    PnetBufs b = {};
+    b.f1 = act + a.f1; b.f2 = act + a.f2; b.f4 = act + a.f4; b.f5 = act + a.f5;
+    b.pool1 = act + a.pool1; b.g1 = act + a.g1; b.pool2 = act + a.pool2;
+    b.gpart = (float*)(base + ws.gpart);
+    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)(base + ws.s[i]);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    if ((rc = pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, st))) return rc;
+    CHECK_HIP(hipMemcpyAsync(act + a.out, out, (size_t)n_vox * 128 * 4, hipMemcpyDeviceToDevice, st));
+    // arg of every pooled entry: the lowest row attaining the maximum
+    CHECK_HIP(hipMemsetAsync(act + a.arg1, 0x7f, (size_t)n_vox * 64 * 4, st));
+    CHECK_HIP(hipMemsetAsync(act + a.arg2, 0x7f, (size_t)n_vox * 128 * 4, st));
+    CHECK_HIP(lidf_launch_segmax_arg(b.f2, vox, b.pool1, n, 64, (int*)(act + a.arg1), st));
+    CHECK_HIP(lidf_launch_segmax_arg(b.f5, vox, b.pool2, n, 128, (int*)(act + a.arg2), st));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
+                                          int64_t n, int64_t n_vox, const float* act,
+                                          const float* g_out, float* d_inp,
+                                          const LidfPointNetGrads* g, void* workspace,
+                                          size_t workspace_bytes, lidf_stream_t stream) {
+    if (!w || !g || n < 0 || n_vox < 0) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
+    if (!g->w_p1 || !g->b_p1 || !g->w_p2 || !g->b_p2 || !g->w_v1 || !g->b_v1 || !g->w_p3 || !g->b_p3 ||
+        !g->w_p4 || !g->b_p4 || !g->w_v2 || !g->b_v2)
+        return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const struct { float* p; size_t n; } zero[12] = {
+        {g->w_p1, 32 * 6}, {g->b_p1, 32}, {g->w_p2, 64 * 32}, {g->b_p2, 64}, {g->w_v1, 64 * 64}, {g->b_v1, 64},
+        {g->w_p3, 128 * 128}, {g->b_p3, 128}, {g->w_p4, 128 * 128}, {g->b_p4, 128}, {g->w_v2, 128 * 128},
+        {g->b_v2, 128}};
+    for (int i = 0; i < 12; ++i) CHECK_HIP(hipMemsetAsync(zero[i].p, 0, zero[i].n * 4, st));
+    if (d_inp && n > 0) CHECK_HIP(hipMemsetAsync(d_inp, 0, (size_t)n * 6 * 4, st));
+    if (n_vox == 0) return LIDF_OK;
+    if (!act || !g_out || (n > 0 && (!inp || !vox))) return LIDF_ERR_BAD_ARG;
+    const PnetTrainWs ws = pnet_train_ws(n, n_vox);
+    if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
+    const PnetAct a = pnet_act(n, n_vox);
+    char* base = (char*)workspace;
+    float* sbuf = (float*)(base + ws.stream);
+    float* dz_out = (float*)(base + ws.dz_out);
+    float* dp2 = (float*)(base + ws.dp2);
+    float* dz5 = (float*)(base + ws.dz5);
+    float* dz4 = (float*)(base + ws.dz4);
+    float* s4 = (float*)(base + ws.s4);
+    float* dg1 = (float*)(base + ws.dg1);
+    float* df2 = (float*)(base + ws.df2);
+    float* dp1 = (float*)(base + ws.dp1);
+    float* dz1 = (float*)(base + ws.dz1);
+    const float *f1 = act + a.f1, *f2 = act + a.f2, *f4 = act + a.f4, *f5 = act + a.f5;
+    const float *pool1 = act + a.pool1, *g1 = act + a.g1, *pool2 = act + a.pool2, *outv = act + a.out;
+    const int *arg1 = (const int*)(act + a.arg1), *arg2 = (const int*)(act + a.arg2);
+    (void)f5;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const int64_t V = n_vox;
+    // out = relu(vox_lin2(pool2))
+    CHECK_HIP(lidf_launch_relu_mask(g_out, outv, V * 128, dz_out, st));
+    CHECK_HIP(lidf_launch_wgrad(dz_out, 128, 128, pool2, 128, 128, V, g->w_v2, 128, g->b_v2, st));
+    LinEx L = {};
+    L.transposed = 1; L.mask_slope = 0.f;
+    L.n = V; L.w = w->w_v2; L.ldw = 128; L.nout = 128; L.k = 128; L.X = dz_out; L.ldx = 128;
+    L.out = dp2; L.ld_out = 128;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    if (n == 0) return LIDF_OK;   // no points: the pooled inputs were the zero fill
+    // pool2 = segmax(f5): d f5 goes to the arg rows; f5 = relu(point_lin4(f4))
+    CHECK_HIP(lidf_launch_segmax_backward(dp2, arg2, vox, pool2, n, 128, 0, dz5, st));
+    CHECK_HIP(lidf_launch_wgrad(dz5, 128, 128, f4, 128, 128, n, g->w_p4, 128, g->b_p4, st));
+    L.n = n; L.w = w->w_p4; L.X = dz5; L.mask_src = f4; L.ld_mask = 128; L.out = dz4;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    // f4 = relu(point_lin3(cat(g1[vox], f2))): weight columns 0..63 meet g1[vox], 64..127 meet f2
+    CHECK_HIP(hipMemsetAsync(s4, 0, (size_t)V * 128 * 4, st));
+    CHECK_HIP(lidf_launch_seg_sum_rows(dz4, vox, n, 128, s4, st));
+    CHECK_HIP(lidf_launch_wgrad(s4, 128, 128, g1, 64, 64, V, g->w_p3, 128, nullptr, st));
+    CHECK_HIP(lidf_launch_wgrad(dz4, 128, 128, f2, 64, 64, n, g->w_p3 + 64, 128, g->b_p3, st));
+    L.mask_src = nullptr;
+    L.n = n; L.w = w->w_p3 + 64; L.ldw = 128; L.nout = 64; L.k = 128; L.X = dz4; L.ldx = 128;
+    L.out = df2; L.ld_out = 64;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    // g1 = relu(vox_lin1(pool1))
+    L.n = V; L.w = w->w_p3; L.X = s4; L.mask_src = g1; L.ld_mask = 64; L.out = dg1;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    CHECK_HIP(lidf_launch_wgrad(dg1, 64, 64, pool1, 64, 64, V, g->w_v1, 64, g->b_v1, st));
+    L.mask_src = nullptr;
+    L.w = w->w_v1; L.ldw = 64; L.nout = 64; L.k = 64; L.X = dg1; L.ldx = 64; L.out = dp1; L.ld_out = 64;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    // pool1 = segmax(f2): added to the gradient f2 receives through the concat; f2 = relu(point_lin2(f1))
+    CHECK_HIP(lidf_launch_segmax_backward(dp1, arg1, vox, pool1, n, 64, 1, df2, st));
+    CHECK_HIP(lidf_launch_relu_mask(df2, f2, n * 64, df2, st));
+    CHECK_HIP(lidf_launch_wgrad(df2, 64, 64, f1, 32, 32, n, g->w_p2, 32, g->b_p2, st));
+    L.n = n; L.w = w->w_p2; L.ldw = 32; L.nout = 32; L.k = 64; L.X = df2; L.ldx = 64;
+    L.mask_src = f1; L.ld_mask = 32; L.out = dz1; L.ld_out = 32;
+    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    CHECK_HIP(lidf_launch_wgrad(dz1, 32, 32, inp, 6, 6, n, g->w_p1, 6, g->b_p1, st));
+    if (d_inp) {
+        L.mask_src = nullptr;
+        L.w = w->w_p1; L.ldw = 6; L.nout = 6; L.k = 32; L.X = dz1; L.ldx = 32; L.out = d_inp; L.ld_out = 6;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
     return LIDF_OK;
 }

@@ -644,3 +644,114 @@ extern "C" hipError_t lidf_launch_pair_pos_backward(const float* g_pos, const fl
                        st, g_pos, g_pred, id, pair_ray, ray_dir, P, k, d_off);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// PointNet2Stage training pieces (models/pointnet.py:22-38 under autograd):
+//   relu mask, arg of the per-voxel max (torch_scatter's scatter-max sends the gradient of a pooled
+//   entry to ONE source row: here the lowest row index attaining the maximum), its backward, and
+//   the per-voxel sum of rows (adjoint of the gather g1[vox]).
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_relu_mask_kernel(const float* __restrict__ g, const float* __restrict__ src,
+                                      long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[i] > 0.f ? g[i] : 0.f;
+}
+
+__global__ void lidf_segmax_arg_kernel(const float* __restrict__ f, const int* __restrict__ vox,
+                                       const float* __restrict__ pool, long long N, int F,
+                                       int* __restrict__ arg) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * F) return;
+    const long long n = i / F;
+    const int c = (int)(i % F), v = vox[n];
+    if (v < 0) return;
+    if (f[i] == pool[(size_t)v * F + c]) atomicMin(arg + (size_t)v * F + c, (int)n);
+}
+
+// out[n, c] (+)= dp[vox[n], c] if row n is the arg of (vox[n], c) and the pooled value is positive
+// (a pooled 0 came from the zero fill or from a relu output at its kink: no gradient either way)
+__global__ void lidf_segmax_backward_kernel(const float* __restrict__ dp, const int* __restrict__ arg,
+                                            const int* __restrict__ vox,
+                                            const float* __restrict__ pool, long long N, int F,
+                                            int accumulate, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * F) return;
+    const long long n = i / F;
+    const int c = (int)(i % F), v = vox[n];
+    float g = 0.f;
+    if (v >= 0) {
+        const size_t k = (size_t)v * F + c;
+        if (arg[k] == (int)n && pool[k] > 0.f) g = dp[k];
+    }
+    out[i] = accumulate ? out[i] + g : g;
+}
+
+__global__ void lidf_seg_sum_rows_kernel(const float* __restrict__ S, const int* __restrict__ idx,
+                                         long long N, int F, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * (F / 4)) return;
+    const long long n = i / (F / 4);
+    const int c = (int)(i % (F / 4)) * 4, v = idx[n];
+    if (v < 0) return;
+    const f32x4 s = *(const f32x4*)(S + (size_t)n * F + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (s[k] != 0.f) atomicAdd(out + (size_t)v * F + c + k, s[k]);
+}
+
+extern "C" hipError_t lidf_launch_relu_mask(const float* g, const float* src, long long n, float* out,
+                                            hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, src,
+                       n, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_segmax_arg(const float* f, const int* vox, const float* pool,
+                                             long long N, int F, int* arg, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_segmax_arg_kernel, dim3((unsigned)((N * F + 255) / 256)), dim3(256), 0, st, f,
+                       vox, pool, N, F, arg);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_segmax_backward(const float* dp, const int* arg, const int* vox,
+                                                  const float* pool, long long N, int F,
+                                                  int accumulate, float* out, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_segmax_backward_kernel, dim3((unsigned)((N * F + 255) / 256)), dim3(256), 0,
+                       st, dp, arg, vox, pool, N, F, accumulate, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_seg_sum_rows(const float* S, const int* idx, long long N, int F,
+                                               float* out, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_seg_sum_rows_kernel, dim3((unsigned)((N * (F / 4) + 255) / 256)), dim3(256),
+                       0, st, S, idx, N, F, out);
+    return hipGetLastError();
+}
+
+// Positional-encoding backward (models/implicit_net.py:9-39 under autograd):
+//   d x[i,c] = g[i,c] + sum_o 2^o ( cos(2^o x) g_sin[o,c] - sin(2^o x) g_cos[o,c] )
+__global__ void lidf_embed_backward_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                           long long n, int L, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const long long r = i / 3;
+    const int c = (int)(i % 3);
+    const float v = x[i];
+    const float* gr = g + (size_t)r * (3 + 6 * L);
+    float acc = gr[c];
+    float f = 1.f;
+    for (int o = 0; o < L; ++o) {
+        const float a = v * f;
+        acc += f * (cosf(a) * gr[3 + 6 * o + c] - sinf(a) * gr[3 + 6 * o + 3 + c]);
+        f *= 2.f;
+    }
+    dx[i] = acc;
+}
+extern "C" hipError_t lidf_launch_embed_backward(const float* x, const float* g, long long n, int L,
+                                                 float* dx, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_embed_backward_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0,
+                       st, x, g, n, L, dx);
+    return hipGetLastError();
+}

@@ -26,6 +26,31 @@ from . import _lib
 # --------------------------------------------------------------------------------------------
 # Positional encoding
 # --------------------------------------------------------------------------------------------
+class _EmbedFn(torch.autograd.Function):
+    """embed(x) with the HIP backward lidf_embed_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, x2, multires):
+        x = x2.detach().contiguous()
+        out = torch.empty((x.shape[0], 3 + 6 * multires), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_embed_f32(_lib.ptr(x), x.shape[0], multires, _lib.ptr(out),
+                                                 _lib.current_stream(x.device)))
+        ctx.save_for_backward(x)
+        ctx.multires = multires
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.detach().contiguous().float()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_embed_backward_f32(_lib.ptr(x), _lib.ptr(g), x.shape[0], ctx.multires,
+                                                          _lib.ptr(dx), _lib.current_stream(x.device)))
+        return dx, None
+
+
 class Embedder:
     """Counterpart of the reference Embedder (models/implicit_net.py:9-39) for the one
     configuration get_embedder builds: include_input, log-sampled 2^0..2^(L-1), [sin, cos]."""
@@ -39,14 +64,14 @@ class Embedder:
     def embed(self, inputs):
         if not inputs.is_cuda:
             raise RuntimeError("embed: inputs must be a CUDA tensor (no CPU path)")
-        if torch.is_grad_enabled() and inputs.requires_grad:
-            return self.embed_composite(inputs)
-        x = inputs.detach()
-        if x.dtype != torch.float32:
+        if inputs.dtype != torch.float32:
             raise RuntimeError("embed: float32 required")
-        lead = x.shape[:-1]
-        if x.shape[-1] != 3:
+        if inputs.shape[-1] != 3:
             raise RuntimeError("embed: last dim must be 3")
+        lead = inputs.shape[:-1]
+        if torch.is_grad_enabled() and inputs.requires_grad:
+            return _EmbedFn.apply(inputs.reshape(-1, 3), self.multires).reshape(*lead, self.out_dim)
+        x = inputs.detach()
         x2 = x.reshape(-1, 3).contiguous()
         out = torch.empty((x2.shape[0], self.out_dim), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -55,7 +80,7 @@ class Embedder:
         return out.reshape(*lead, self.out_dim)
 
     def embed_composite(self, inputs):
-        """Differentiable definition in torch ops (same formula, same order)."""
+        """The same function in differentiable torch ops (the definition the tests compare with)."""
         outs = [inputs]
         for o in range(self.multires):
             f = float(2 ** o)

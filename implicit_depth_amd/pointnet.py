@@ -5,8 +5,10 @@ names (`point_lin1..4`, `vox_lin1..2`) as the reference (models/pointnet.py:7-38
 checkpoints' `pnet_model` / `pnet_model_refine` entries load unchanged
 (trainers/train_lidf.py:74-75, train_refine.py:364-366). On CUDA f32 inputs without autograd the
 forward runs liblidf_hip.so's lidf_pointnet_f32 (MFMA linear layers with the two scatter-max
-poolings fused as atomic-max epilogues); with autograd it runs the same maths as torch ops on the
-same device; CPU tensors are refused.
+poolings fused as atomic-max epilogues); with autograd it runs the library's training path
+(lidf_pointnet_forward_train_f32 / lidf_pointnet_backward_f32); `forward_composite` is the same
+function in torch ops, kept as the definition the gradient tests compare with; CPU tensors are
+refused.
 """
 import ctypes as C
 
@@ -48,6 +50,72 @@ def check_pointnet(mod):
                            "output_channels=128 (every shipped config)")
 
 
+_PN_ORDER = ("point_lin1", "point_lin2", "vox_lin1", "point_lin3", "point_lin4", "vox_lin2")
+_PN_FIELDS = ("p1", "p2", "v1", "p3", "p4", "v2")
+
+
+def _pn_struct_from(tensors, keep):
+    """LidfPointNet from a list [w, b] x (point_lin1, point_lin2, vox_lin1, point_lin3, point_lin4,
+    vox_lin2)."""
+    s = _lib.LidfPointNet()
+    for i, f in enumerate(_PN_FIELDS):
+        for j, pre in enumerate(("w_", "b_")):
+            t = tensors[2 * i + j].detach()
+            if t.dtype != torch.float32:
+                raise RuntimeError("lidf_hip: float32 parameters required")
+            t = t.contiguous()
+            keep.append(t)
+            setattr(s, pre + f, t.data_ptr())
+    return s
+
+
+class _PointNetTrainFn(torch.autograd.Function):
+    """PointNet2Stage.forward under autograd (models/pointnet.py:22-38): HIP forward that keeps the
+    activations (lidf_pointnet_forward_train_f32) and HIP backward (lidf_pointnet_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, inp, idx, n_vox, *params):
+        x = inp.detach().contiguous()
+        n = x.shape[0]
+        keep = []
+        s = _pn_struct_from(params, keep)
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        act = torch.empty((max(L.lidf_pointnet_train_act_floats(n, n_vox), 1),), **f32)
+        wsb = L.lidf_pointnet_train_workspace_bytes(n, n_vox)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+        out = torch.empty((n_vox, 128), **f32)
+        with torch.cuda.device(x.device):
+            _lib.check(L.lidf_pointnet_forward_train_f32(C.byref(s), _lib.ptr(x), _lib.ptr(idx), n, n_vox,
+                                                         _lib.ptr(out), _lib.ptr(act), _lib.ptr(ws), wsb,
+                                                         _lib.current_stream(x.device)))
+        ctx.n_vox, ctx.ws, ctx.wsb = n_vox, ws, wsb
+        ctx.save_for_backward(x, idx, act, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, idx, act = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        n, n_vox = x.shape[0], ctx.n_vox
+        keep = []
+        s = _pn_struct_from(params, keep)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g = g_out.detach().contiguous().float()
+        grads = [torch.empty_like(p, **f32).contiguous() for p in params]
+        gs = _lib.LidfPointNetGrads()
+        for i, f in enumerate(_PN_FIELDS):
+            setattr(gs, "w_" + f, grads[2 * i].data_ptr())
+            setattr(gs, "b_" + f, grads[2 * i + 1].data_ptr())
+        d_inp = torch.empty((n, 6), **f32) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_pointnet_backward_f32(
+                C.byref(s), _lib.ptr(x), _lib.ptr(idx), n, n_vox, _lib.ptr(act), _lib.ptr(g),
+                _lib.ptr(d_inp), C.byref(gs), _lib.ptr(ctx.ws), ctx.wsb, _lib.current_stream(x.device)))
+        return (d_inp, None, None) + tuple(gr if ctx.needs_input_grad[3 + i] else None
+                                           for i, gr in enumerate(grads))
+
+
 class PointNet2Stage(nn.Module):
     def __init__(self, input_channels=6, output_channels=256, gf_dim=64):
         super(PointNet2Stage, self).__init__()
@@ -68,12 +136,14 @@ class PointNet2Stage(nn.Module):
             n_vox = int(vox2point_idx.max().item()) + 1 if vox2point_idx.numel() else 0
         needs_grad = torch.is_grad_enabled() and (
             inp_feat.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad:
-            return self.forward_composite(inp_feat, vox2point_idx, n_vox)
         check_pointnet(self)
-        x = inp_feat.detach()
-        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 6:
+        if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != 6:
             raise RuntimeError("inp_feat must be float32 [N,6]")
+        if needs_grad:   # the library's training path: forward that keeps activations + backward
+            params = [t for name in _PN_ORDER for t in (getattr(self, name).weight, getattr(self, name).bias)]
+            return _PointNetTrainFn.apply(inp_feat, vox2point_idx.detach().to(torch.int32).contiguous(),
+                                          int(n_vox), *params)
+        x = inp_feat.detach()
         x = x.contiguous()
         idx = vox2point_idx.detach().to(torch.int32).contiguous()
         n = x.shape[0]
@@ -90,7 +160,7 @@ class PointNet2Stage(nn.Module):
         return out
 
     def forward_composite(self, inp_feat, vox2point_idx, n_vox):
-        """Differentiable definition in torch ops (used only when autograd is required)."""
+        """The same function in differentiable torch ops (the definition the tests compare with)."""
         idx = vox2point_idx.long()
         f2 = F.relu(self.point_lin2(F.relu(self.point_lin1(inp_feat))))
         g1 = F.relu(self.vox_lin1(_segment_max(f2, idx, n_vox)))

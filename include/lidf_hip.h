@@ -424,6 +424,30 @@ int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float*
                                     int32_t accumulate_inputs, const LidfDecoderGrads* grads,
                                     void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
+/* ---- Positional encoding and PointNet2Stage, training path ----------------------------------------
+ * What autograd derives for Embedder.embed (models/implicit_net.py:9-39) and for
+ * PointNet2Stage.forward (models/pointnet.py:22-38, torch_scatter max pooling: the gradient of a
+ * pooled entry goes to one source row — here the lowest row index attaining the maximum).
+ *   lidf_embed_backward_f32: d x [n,3] from g_out [n, 3+6*multires]
+ *   lidf_pointnet_forward_train_f32: the forward, keeping every layer's rows, the pooled tables and
+ *     their arg rows in `act` (lidf_pointnet_train_act_floats floats)
+ *   lidf_pointnet_backward_f32: g_out [n_vox,128] -> d_inp [n,6] (optional) and the gradient of every
+ *     parameter (buffers shaped like the parameters, overwritten; float atomics inside).        */
+typedef struct LidfPointNetGrads {
+    float *w_p1, *b_p1, *w_p2, *b_p2, *w_v1, *b_v1, *w_p3, *b_p3, *w_p4, *b_p4, *w_v2, *b_v2;
+} LidfPointNetGrads;
+int lidf_embed_backward_f32(const float* x, const float* g_out, int64_t n, int multires, float* d_x,
+                            lidf_stream_t stream);
+size_t lidf_pointnet_train_act_floats(int64_t n_pts, int64_t n_vox);
+size_t lidf_pointnet_train_workspace_bytes(int64_t n_pts, int64_t n_vox);
+int lidf_pointnet_forward_train_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
+                                    int64_t n_pts, int64_t n_vox, float* out, float* act,
+                                    void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
+                               int64_t n_pts, int64_t n_vox, const float* act, const float* g_out,
+                               float* d_inp, const LidfPointNetGrads* grads, void* workspace,
+                               size_t workspace_bytes, lidf_stream_t stream);
+
 /* ---- Per-pair / per-ray tail of get_pred with its adjoint --------------------------------------
  * models/pipeline.py:437-454 for the training path (the inference path has it inside
  * lidf_query_f32): pair_pred_pos = dir t_enter + ((off (r1-r0) + r0) sqrt(3) part_size) dir, the

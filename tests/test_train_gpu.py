@@ -116,3 +116,56 @@ def test_backward_against_f64(cuda, kind, n_iter):
         scale = max(1e-3, g_ref[k].abs().max().item())
         err = (g_hip[k].double() - g_ref[k]).abs().max().item()
         assert err <= 2e-5 * scale, (k, err, scale)
+
+
+@pytest.mark.parametrize("n,v,drop", [(3000, 40, False), (257, 9, True), (5, 3, False)])
+def test_pointnet_gradients(cuda, n, v, drop):
+    """PointNet2Stage under autograd: HIP forward-with-activations + HIP backward against torch
+    autograd on the CPU oracle (scatter-max routes the gradient to one arg row per pooled entry)."""
+    from util import make_pointnet
+    g = torch.Generator().manual_seed(n + v)
+    p = orc.init_pointnet(7, 1.5)
+    inp = torch.randn(n, 6, generator=g)
+    vox = torch.randint(0, v, (n,), generator=g)
+    if drop:
+        vox[torch.rand(n, generator=g) < 0.2] = -1          # rows left out of the poolings
+    wgt = torch.randn(v, 128, generator=g)
+    # oracle autograd
+    pr = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    xi = inp.clone().requires_grad_(True)
+    keep = vox >= 0
+    ref = orc.pointnet2stage(pr, xi[keep], vox[keep], v)
+    (ref * wgt).sum().backward()
+    m = make_pointnet(p, cuda).train()
+    xd = inp.to(cuda).requires_grad_(True)
+    out = m(xd, vox.to(cuda), n_vox=v)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 2e-5
+    (out * wgt.to(cuda)).sum().backward()
+
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(xd.grad.cpu(), xi.grad, "inp")
+    for k, t in pr.items():
+        close(dict(m.named_parameters())[k].grad.cpu(), t.grad, k)
+    # and the inference kernel gives the same values
+    with torch.no_grad():
+        assert (m(inp.to(cuda), vox.to(cuda), n_vox=v) - out.detach()).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("multires", [0, 4, 8])
+def test_embed_gradient(cuda, multires):
+    from implicit_depth_amd import get_embedder
+    fn, dim = get_embedder(multires)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(500, 3, generator=g) - 0.5) * 4.0
+    wgt = torch.randn(500, dim, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    outs = [xr] + [f(xr * 2.0 ** o) for o in range(multires) for f in (torch.sin, torch.cos)]
+    (torch.cat(outs, -1) * wgt.double()).sum().backward()
+    xd = x.to(cuda).requires_grad_(True)
+    e = fn(xd)
+    assert e.shape == (500, dim)
+    (e * wgt.to(cuda)).sum().backward()
+    scale = max(1.0, xr.grad.abs().max().item())
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= 2e-5 * scale
