@@ -399,7 +399,9 @@ struct Geo {
 //                                   RB rounds (2*RB rays) per batch
 //   passes (1 for the IMNet, n_iter for the IEF)
 // ------------------------------------------------------------------------------------------------
+#ifndef LIDF_RB
 #define LIDF_RB 4   // rank-1 rounds whose row loads are in flight together
+#endif
 
 __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
     extern __shared__ float lds_raw[];
