@@ -396,7 +396,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
     if (!q) return LIDF_ERR_BAD_ARG;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
-    if (P > 0x7fffffffLL || R > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    // 32-bit lane offsets in the kernels: 12 R bytes of ray directions must fit
+    if (P > 0x7fffffffLL || R > 0x15555555LL) return LIDF_ERR_UNSUPPORTED;
     int rc;
     if ((rc = check_query_model(q->prob, q->off, q->multires, q->multires_views, q->precision)))
         return rc;

@@ -433,19 +433,25 @@ __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
 #pragma unroll
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
 
+    // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
     auto load_idx = [&](long long tile, Geo& g) {
-        long long pc = tile * 128 + wave * 32 + col;
-        pc = pc < a.n ? pc : a.n - 1;
-        g.ray = a.pair_ray[pc];
-        g.vid = a.pair_vox[pc];
-        const f32x2 tt = *(const f32x2*)(a.pair_t + 2 * pc);
+        const long long last = a.n - 1;
+        long long t0 = tile * 128;                  // uniform
+        if (t0 > last) t0 = last & ~127LL;          // a prefetch past the end re-reads the last tile
+        const long long rem = last - t0;
+        const int lo = wave * 32 + col;
+        const unsigned off = (unsigned)(lo < rem ? lo : rem);  // out-of-range points are clamped
+        g.ray = (a.pair_ray + t0)[off];
+        g.vid = (a.pair_vox + t0)[off];
+        const f32x2 tt = *(const f32x2*)((const char*)(a.pair_t + 2 * t0) + 8u * off);
         g.te = tt[0];
         g.tl = tt[1];
     };
     auto load_dir = [&](Geo& g) {
-        g.dx = a.ray_dir[3 * (size_t)g.ray + 0];
-        g.dy = a.ray_dir[3 * (size_t)g.ray + 1];
-        g.dz = a.ray_dir[3 * (size_t)g.ray + 2];
+        const char* rd = (const char*)a.ray_dir + 12u * (unsigned)g.ray;
+        g.dx = *(const float*)(rd + 0);
+        g.dy = *(const float*)(rd + 4);
+        g.dz = *(const float*)(rd + 8);
     };
     auto vox_row = [&](int vid, int net) {
         return a.voxpart + ((size_t)vid * a.nets + net) * 256 + 4 * h;

@@ -62,7 +62,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define NK1 LIDF_H_NK1            // layer-1 k-steps of 16: 6 of sin/cos (8 octaves) + raw x,y,z
 #define PASS_QUADS LIDF_HPASS_QUADS
 #define LDS_STREAM_ELEMS (NBUF * CH_ELEMS)
-#define LDS_BYTES ((LDS_STREAM_ELEMS + 4 * NK1 * 64 + 1) * 16)  // + the tile-grab slot
+// + the tile-grab slot + 7 floats per lane of per-tile geometry parked outside the register file
+// (28 B/lane: with it two workgroups use 163,632 of the CU's 163,840 B)
+#define LDS_STASH_FLOATS 7
+#define LDS_BYTES ((LDS_STREAM_ELEMS + 4 * NK1 * 64 + 1) * 16 + 4 * LDS_STASH_FLOATS * 64 * 4)
 #define LIDF_H_GRAB 2
 
 // ------------------------------------------------------------------------------------------------
@@ -583,6 +586,10 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
     // points are clamped.
     const long long ntile = (a.n + 127) / 128;
     int* const grab_slot = (int*)(sb + LDS_STREAM_ELEMS + 4 * NK1 * 64);
+    // geometry that is only needed again at the end of the tile (the offset net's output, the next
+    // tile's indices) waits in LDS instead of occupying registers through every pass
+    float* const stash = (float*)(sb + LDS_STREAM_ELEMS + 4 * NK1 * 64 + 1) +
+                         wave * (LDS_STASH_FLOATS * 64) + lane;
 
     // prologue: chunk 0 into buffer 0, chunk 1 in flight
     Feed f;
@@ -600,19 +607,25 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
 #pragma unroll
     for (int i = 0; i < RING_D; ++i) f.ring[i] = sb[f.cur + i * 64];
 
+    // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
     auto load_idx = [&](long long tile, GeoH& g) {
-        long long pc = tile * 128 + wave * 32 + col;
-        pc = pc < a.n ? pc : a.n - 1;
-        g.ray = a.pair_ray[pc];
-        g.vid = a.pair_vox[pc];
-        const f32x2 tt = *(const f32x2*)(a.pair_t + 2 * pc);
+        const long long last = a.n - 1;
+        long long t0 = tile * 128;                  // uniform
+        if (t0 > last) t0 = last & ~127LL;          // a prefetch past the end re-reads the last tile
+        const long long rem = last - t0;
+        const int lo = wave * 32 + col;
+        const unsigned off = (unsigned)(lo < rem ? lo : rem);  // out-of-range points are clamped
+        g.ray = (a.pair_ray + t0)[off];
+        g.vid = (a.pair_vox + t0)[off];
+        const f32x2 tt = *(const f32x2*)((const char*)(a.pair_t + 2 * t0) + 8u * off);
         g.te = tt[0];
         g.tl = tt[1];
     };
     auto load_dir = [&](GeoH& g) {
-        g.dx = a.ray_dir[3 * (size_t)g.ray + 0];
-        g.dy = a.ray_dir[3 * (size_t)g.ray + 1];
-        g.dz = a.ray_dir[3 * (size_t)g.ray + 2];
+        const char* rd = (const char*)a.ray_dir + 12u * (unsigned)g.ray;
+        g.dx = *(const float*)(rd + 0);
+        g.dy = *(const float*)(rd + 4);
+        g.dz = *(const float*)(rd + 8);
     };
     GeoH cur = {}, nxt = {}, nx2 = {};
 
@@ -647,6 +660,13 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
             py -= a.vox_center[3 * (size_t)cur.vid + 1];
             pz -= a.vox_center[3 * (size_t)cur.vid + 2];
         }
+        stash[0 * 64] = cur.te;
+        stash[1 * 64] = cur.dx;
+        stash[2 * 64] = cur.dy;
+        stash[3 * 64] = cur.dz;
+        stash[4 * 64] = nxt.te;
+        stash[5 * 64] = nxt.tl;
+        stash[6 * 64] = __int_as_float(nxt.vid);
         // operands of the layer-1 k-steps, shared by all passes of this tile: high pieces in
         // registers, low pieces in this wavefront's LDS rows
         f32x4 pbh[NK1];
@@ -722,18 +742,26 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
                 if (a.out[net]) a.out[net][p] = o;
                 if (a.is_offset[net]) {
                     // pipeline.py:437-439, same operation order in f32
-                    const float ex = __fmul_rn(cur.dx, cur.te);
-                    const float ey = __fmul_rn(cur.dy, cur.te);
-                    const float ez = __fmul_rn(cur.dz, cur.te);
+                    const float te = stash[0 * 64], dx = stash[1 * 64], dy = stash[2 * 64],
+                                dz = stash[3 * 64];
+                    const float ex = __fmul_rn(dx, te);
+                    const float ey = __fmul_rn(dy, te);
+                    const float ez = __fmul_rn(dz, te);
                     float s = __fadd_rn(__fmul_rn(o, a.rscale), a.r0);
                     s = __fmul_rn(__fmul_rn(s, a.sqrt3), a.part_size);
-                    a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(s, cur.dx));
-                    a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(s, cur.dy));
-                    a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(s, cur.dz));
+                    a.pair_pred_pos[3 * p + 0] = __fadd_rn(ex, __fmul_rn(s, dx));
+                    a.pair_pred_pos[3 * p + 1] = __fadd_rn(ey, __fmul_rn(s, dy));
+                    a.pair_pred_pos[3 * p + 2] = __fadd_rn(ez, __fmul_rn(s, dz));
                 }
             }
         }
-        cur = nxt;
+        cur.ray = nxt.ray;
+        cur.dx = nxt.dx;
+        cur.dy = nxt.dy;
+        cur.dz = nxt.dz;
+        cur.te = stash[4 * 64];
+        cur.tl = stash[5 * 64];
+        cur.vid = __float_as_int(stash[6 * 64]);
         nxt.ray = nx2.ray;
         nxt.vid = nx2.vid;
         nxt.te = nx2.te;
