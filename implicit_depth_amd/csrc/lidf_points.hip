@@ -175,7 +175,9 @@ __device__ __forceinline__ void lrelu_part(f32x16& v) {
 #pragma unroll
     for (int i = LO; i < HI; i += 2) {
         f32x2 x = {v[i], v[i + 1]};
-        const f32x2 t = x * 0.02f;
+        f32x2 t;
+        const f32x2 slope = {0.02f, 0.02f};
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(slope));
         float r0, r1;
         asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(x[0]), "v"(t[0]));
         asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x[1]), "v"(t[1]));
