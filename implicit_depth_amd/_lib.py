@@ -110,7 +110,8 @@ SIGNATURES = {
     "lidf_query_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), C.POINTER(LidfDecoder), _I, _I, _I, _P, _SZ, _P]),
     "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
     "lidf_query_profile_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P, _P, _P]),
-    "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P]),
+    "lidf_ray_features_workspace_bytes": (_SZ, [_I, _I, _I, _I64]),
+    "lidf_ray_features_f32": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _I64, _I, _I, _P, _P, _SZ, _P]),
     "lidf_ray_reduce_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lidf_ray_dirs_f32": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "lidf_miss_ray_workspace_bytes": (_SZ, [_I64]),

@@ -37,7 +37,7 @@ hipError_t lidf_launch_miss_fill(const void*, int, long long, const int*, const 
                                  int*, int*, float*, long long*, long long*, long long*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
-                             float*, int, float*, hipStream_t);
+                             float*, int, float*, float*, size_t, hipStream_t);
 hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long long, float*,
                                 hipStream_t);
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
@@ -91,7 +91,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 2
+#define LIDF_ABI_VERSION 3
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \
@@ -255,19 +255,29 @@ static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, con
 }
 
 // ---- per-ray features ---------------------------------------------------------------------------
+LIDF_API size_t lidf_ray_features_workspace_bytes(int batch, int height, int width, int64_t n_rays) {
+    if (batch <= 0 || height <= 0 || width <= 0 || n_rays < 0) return 0;
+    return align_up(((size_t)batch * 32 * height * width + (size_t)n_rays + 1) * 4, 256);
+}
+
 LIDF_API int lidf_ray_features_f32(const float* feat_grid, int batch, int height, int width,
                                      const float* ray_dir, const int32_t* ray_pix,
                                      const int32_t* ray_bid, int64_t n_rays, int roi_inp_bbox,
-                                     int multires_views, float* rayfeat, lidf_stream_t stream) {
+                                     int multires_views, float* rayfeat, void* workspace,
+                                     size_t workspace_bytes, lidf_stream_t stream) {
     if (n_rays < 0 || batch <= 0 || height <= 0 || width <= 0 || roi_inp_bbox < 0 ||
         multires_views < 0 || multires_views > 16)
         return LIDF_ERR_BAD_ARG;
     if (n_rays == 0) return LIDF_OK;
     if (!feat_grid || !ray_dir || !ray_pix || !ray_bid || !rayfeat) return LIDF_ERR_BAD_ARG;
     const int ld = 128 + 3 + 6 * multires_views;
-    CHECK_HIP(lidf_launch_rayfeat(feat_grid, nullptr, batch, height, width, ray_dir, ray_pix,
-                                  ray_bid, n_rays, roi_inp_bbox / 2, multires_views, rayfeat, ld,
-                                  (hipStream_t)stream));
+    // with room for the 4x4 box-sum image (+ the list of clamped-box rays) the unclamped boxes take
+    // 4 gathers per channel; without it every ray takes the general bilinear path
+    const bool use_box = workspace &&
+                         workspace_bytes >= lidf_ray_features_workspace_bytes(batch, height, width, n_rays);
+    CHECK_HIP(lidf_launch_rayfeat(feat_grid, use_box ? (float*)workspace : nullptr, batch, height,
+                                  width, ray_dir, ray_pix, ray_bid, n_rays, roi_inp_bbox / 2,
+                                  multires_views, rayfeat, ld, (hipStream_t)stream));
     return LIDF_OK;
 }
 
@@ -1028,6 +1038,8 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st)
     return LIDF_OK;
 }
 
+// partial blocks of the weight-gradient reduction: 512 row slices x (128 x 256 block + its bias part)
+#define WG_SCRATCH_FLOATS ((size_t)512 * (128 * 256 + 128))
 #define ACT_ROW_FLOATS (LIDF_H1 + LIDF_H2 + LIDF_H3 + 1)   // per row and pass: H1 | H2 | H3 | offset in
 
 LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
@@ -1036,7 +1048,7 @@ LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
 }
 
 struct TrainWs {
-    size_t stream, dz1, dz2, dz3, goff, enc, denc, total;
+    size_t stream, dz1, dz2, dz3, goff, enc, denc, wg, total;
 };
 static TrainWs train_ws(int64_t n, int d) {
     TrainWs w;
@@ -1050,6 +1062,7 @@ static TrainWs train_ws(int64_t n, int d) {
     w.goff = o;   o += align_up(N * 4, 256);
     w.enc = o;    o += align_up(N * 16 * 4, 256);
     w.denc = o;   o += align_up(N * 16 * 4, 256);
+    w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.total = o;
     return w;
 }
@@ -1146,6 +1159,7 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
     float* goff = (float*)(ws + w.goff);
     float* enc = (float*)(ws + w.enc);
     float* denc = (float*)(ws + w.denc);
+    float* wgs = (float*)(ws + w.wg);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     const float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;
@@ -1157,24 +1171,24 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         const float* h3 = h2 + (size_t)n * LIDF_H2;
         const float* offin = h3 + (size_t)n * LIDF_H3;
         // y_k = w4 . H3 + b4 ;  dL/dy_k = dL/d(off_{k+1}) = goff
-        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, n, grads->w4, LIDF_H3, grads->b4, st));
+        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, n, grads->w4, LIDF_H3, grads->b4, wgs, WG_SCRATCH_FLOATS, st));
         LinEx L = {};
         L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
         // dZ3 = (goff (x) w4) * lrelu'(Z3)
         L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
         L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, st));
+        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         // dZ2 = (dZ3 W3) * lrelu'(Z2)
         L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
         L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, st));
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         // dZ1 = (dZ2 W2) * lrelu'(Z1)
         L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
         L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, st));
+        CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
         L.mask_src = nullptr;
         if (d_inp) {
             // d inp (+)= dZ1 W1[:, 0:d], 256 input columns per launch
@@ -1189,12 +1203,12 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         if (dec->is_ief) {
             // the 16 offset-encoding columns of layer 1: enc_k = off_k wenc^T + benc
             CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, n, enc, st));
-            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, n, grads->w1 + d, ld1, nullptr, st));
+            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, n, grads->w1 + d, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
             // d enc = dZ1 W1[:, d:d+16] ; d wenc = d enc^T off_k ; d benc = sum d enc
             L.w = dec->w1 + d; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
             L.out = denc; L.ld_out = 16;
             if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, n, grads->wenc, 1, grads->benc, st));
+            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, n, grads->wenc, 1, grads->benc, wgs, WG_SCRATCH_FLOATS, st));
             // d off_k = d off_{k+1} + d enc . wenc
             L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
             L.out = goff; L.ld_out = 1; L.accumulate = 1;
@@ -1284,7 +1298,7 @@ LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, i
 }
 
 struct QTrainWs {
-    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, total;
+    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, total;
 };
 static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     QTrainWs w;
@@ -1300,6 +1314,7 @@ static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     w.denc = o;   o += align_up(N * 16 * 4, 256);
     w.dvox = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
     w.dray = o;   o += align_up((size_t)(R > 0 ? R : 1) * LIDF_H1 * 4, 256);
+    w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.total = o;
     return w;
 }
@@ -1429,6 +1444,7 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     float* goff = (float*)(ws + w.goff);
     float* enc = (float*)(ws + w.enc);
     float* denc = (float*)(ws + w.denc);
+    float* wgs = (float*)(ws + w.wg);
     float* dvox = (float*)(ws + w.dvox);
     float* dray = (float*)(ws + w.dray);
     int cus;
@@ -1444,17 +1460,17 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         const float* h2 = h1 + (size_t)P * LIDF_H1;
         const float* h3 = h2 + (size_t)P * LIDF_H2;
         const float* offin = h3 + (size_t)P * LIDF_H3;
-        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, P, grads->w4, LIDF_H3, grads->b4, st));
+        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, P, grads->w4, LIDF_H3, grads->b4, wgs, WG_SCRATCH_FLOATS, st));
         LinEx L = {};
         L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
         L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
         L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, st));
+        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
         L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, st));
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         // dZ1 of this pass, and its running sum over the passes: everything of layer 1 except the
         // offset encoding sees the same operand in every pass
         L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
@@ -1472,11 +1488,11 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         L.mask_src = nullptr;
         if (dec->is_ief) {
             CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, P, enc, st));
-            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, P, grads->w1 + D, ld1, nullptr, st));
+            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, P, grads->w1 + D, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
             L.w = dec->w1 + D; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
             L.out = denc; L.ld_out = 16;
             if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, P, grads->wenc, 1, grads->benc, st));
+            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, P, grads->wenc, 1, grads->benc, wgs, WG_SCRATCH_FLOATS, st));
             L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
             L.out = goff; L.ld_out = 1; L.accumulate = 1;
             if ((rc = run_linex(L, sbuf, cus, st))) return rc;
@@ -1484,15 +1500,15 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         }
     }
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
-    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, st));
+    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
     CHECK_HIP(hipMemsetAsync(dvox, 0, (size_t)V * LIDF_H1 * 4, st));
     CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, st));
     CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
     // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
-    CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, st));
+    CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
     // ray part: raypart[r] = W1[:, 128:256] roi[r] + W1[:, 256+E2:] embed(dir)[r]
-    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat, 128 + Ed, 128, R, grads->w1 + 128, ld1, nullptr, st));
-    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat + 128, 128 + Ed, Ed, R, grads->w1 + 256 + E2, ld1, nullptr, st));
+    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat, 128 + Ed, 128, R, grads->w1 + 128, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat + 128, 128 + Ed, Ed, R, grads->w1 + 256 + E2, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
     LinEx L = {};
     L.transposed = 1; L.ldw = ld1; L.k = LIDF_H1; L.ldx = LIDF_H1; L.accumulate = accumulate_inputs ? 1 : 0;
     if (d_vox_feat) {
@@ -1584,7 +1600,7 @@ static PnetAct pnet_act(int64_t n, int64_t v) {
     return a;
 }
 struct PnetTrainWs {
-    size_t s[7], gpart, stream, dz_out, dp2, dz5, dz4, s4, dg1, df2, dp1, dz1, total;
+    size_t s[7], gpart, stream, dz_out, dp2, dz5, dz4, s4, dg1, df2, dp1, dz1, wg, total;
 };
 static PnetTrainWs pnet_train_ws(int64_t n, int64_t v) {
     PnetTrainWs w;
@@ -1604,6 +1620,7 @@ static PnetTrainWs pnet_train_ws(int64_t n, int64_t v) {
     w.df2 = o;    o += align_up(N * 64 * 4, 256);
     w.dp1 = o;    o += align_up(V * 64 * 4, 256);
     w.dz1 = o;    o += align_up(N * 32 * 4, 256);
+    w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.total = o;
     return w;
 }
@@ -1680,6 +1697,7 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
     float* df2 = (float*)(base + ws.df2);
     float* dp1 = (float*)(base + ws.dp1);
     float* dz1 = (float*)(base + ws.dz1);
+    float* wgs = (float*)(base + ws.wg);
     const float *f1 = act + a.f1, *f2 = act + a.f2, *f4 = act + a.f4, *f5 = act + a.f5;
     const float *pool1 = act + a.pool1, *g1 = act + a.g1, *pool2 = act + a.pool2, *outv = act + a.out;
     const int *arg1 = (const int*)(act + a.arg1), *arg2 = (const int*)(act + a.arg2);
@@ -1689,7 +1707,7 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
     const int64_t V = n_vox;
     // out = relu(vox_lin2(pool2))
     CHECK_HIP(lidf_launch_relu_mask(g_out, outv, V * 128, dz_out, st));
-    CHECK_HIP(lidf_launch_wgrad(dz_out, 128, 128, pool2, 128, 128, V, g->w_v2, 128, g->b_v2, st));
+    CHECK_HIP(lidf_launch_wgrad(dz_out, 128, 128, pool2, 128, 128, V, g->w_v2, 128, g->b_v2, wgs, WG_SCRATCH_FLOATS, st));
     LinEx L = {};
     L.transposed = 1; L.mask_slope = 0.f;
     L.n = V; L.w = w->w_v2; L.ldw = 128; L.nout = 128; L.k = 128; L.X = dz_out; L.ldx = 128;
@@ -1698,14 +1716,14 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
     if (n == 0) return LIDF_OK;   // no points: the pooled inputs were the zero fill
     // pool2 = segmax(f5): d f5 goes to the arg rows; f5 = relu(point_lin4(f4))
     CHECK_HIP(lidf_launch_segmax_backward(dp2, arg2, vox, pool2, n, 128, 0, dz5, st));
-    CHECK_HIP(lidf_launch_wgrad(dz5, 128, 128, f4, 128, 128, n, g->w_p4, 128, g->b_p4, st));
+    CHECK_HIP(lidf_launch_wgrad(dz5, 128, 128, f4, 128, 128, n, g->w_p4, 128, g->b_p4, wgs, WG_SCRATCH_FLOATS, st));
     L.n = n; L.w = w->w_p4; L.X = dz5; L.mask_src = f4; L.ld_mask = 128; L.out = dz4;
     if ((rc = run_linex(L, sbuf, cus, st))) return rc;
     // f4 = relu(point_lin3(cat(g1[vox], f2))): weight columns 0..63 meet g1[vox], 64..127 meet f2
     CHECK_HIP(hipMemsetAsync(s4, 0, (size_t)V * 128 * 4, st));
     CHECK_HIP(lidf_launch_seg_sum_rows(dz4, vox, n, 128, s4, st));
-    CHECK_HIP(lidf_launch_wgrad(s4, 128, 128, g1, 64, 64, V, g->w_p3, 128, nullptr, st));
-    CHECK_HIP(lidf_launch_wgrad(dz4, 128, 128, f2, 64, 64, n, g->w_p3 + 64, 128, g->b_p3, st));
+    CHECK_HIP(lidf_launch_wgrad(s4, 128, 128, g1, 64, 64, V, g->w_p3, 128, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    CHECK_HIP(lidf_launch_wgrad(dz4, 128, 128, f2, 64, 64, n, g->w_p3 + 64, 128, g->b_p3, wgs, WG_SCRATCH_FLOATS, st));
     L.mask_src = nullptr;
     L.n = n; L.w = w->w_p3 + 64; L.ldw = 128; L.nout = 64; L.k = 128; L.X = dz4; L.ldx = 128;
     L.out = df2; L.ld_out = 64;
@@ -1713,18 +1731,18 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
     // g1 = relu(vox_lin1(pool1))
     L.n = V; L.w = w->w_p3; L.X = s4; L.mask_src = g1; L.ld_mask = 64; L.out = dg1;
     if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    CHECK_HIP(lidf_launch_wgrad(dg1, 64, 64, pool1, 64, 64, V, g->w_v1, 64, g->b_v1, st));
+    CHECK_HIP(lidf_launch_wgrad(dg1, 64, 64, pool1, 64, 64, V, g->w_v1, 64, g->b_v1, wgs, WG_SCRATCH_FLOATS, st));
     L.mask_src = nullptr;
     L.w = w->w_v1; L.ldw = 64; L.nout = 64; L.k = 64; L.X = dg1; L.ldx = 64; L.out = dp1; L.ld_out = 64;
     if ((rc = run_linex(L, sbuf, cus, st))) return rc;
     // pool1 = segmax(f2): added to the gradient f2 receives through the concat; f2 = relu(point_lin2(f1))
     CHECK_HIP(lidf_launch_segmax_backward(dp1, arg1, vox, pool1, n, 64, 1, df2, st));
     CHECK_HIP(lidf_launch_relu_mask(df2, f2, n * 64, df2, st));
-    CHECK_HIP(lidf_launch_wgrad(df2, 64, 64, f1, 32, 32, n, g->w_p2, 32, g->b_p2, st));
+    CHECK_HIP(lidf_launch_wgrad(df2, 64, 64, f1, 32, 32, n, g->w_p2, 32, g->b_p2, wgs, WG_SCRATCH_FLOATS, st));
     L.n = n; L.w = w->w_p2; L.ldw = 32; L.nout = 32; L.k = 64; L.X = df2; L.ldx = 64;
     L.mask_src = f1; L.ld_mask = 32; L.out = dz1; L.ld_out = 32;
     if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    CHECK_HIP(lidf_launch_wgrad(dz1, 32, 32, inp, 6, 6, n, g->w_p1, 6, g->b_p1, st));
+    CHECK_HIP(lidf_launch_wgrad(dz1, 32, 32, inp, 6, 6, n, g->w_p1, 6, g->b_p1, wgs, WG_SCRATCH_FLOATS, st));
     if (d_inp) {
         L.mask_src = nullptr;
         L.w = w->w_p1; L.ldw = 6; L.nout = 6; L.k = 32; L.X = dz1; L.ldx = 32; L.out = d_inp; L.ld_out = 6;

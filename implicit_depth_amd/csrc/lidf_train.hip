@@ -114,10 +114,206 @@ __global__ void __launch_bounds__(256) lidf_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient for the wide layers: one workgroup = a 128 x 256 block of C over a slice of rows,
+// so A and B stream from HBM once per block instead of once per 64 x 64 tile (the 64-wide tiling
+// re-reads A N/64 times and B M/64 times: 2.5 GB for the 128 x 256 layer at 614,400 rows).
+// Wavefront w owns the C rows {m0 + 4i + w}; every lane loads ONE float4 of A and two of B per row
+// pair — lane (c, h) reads row r+h, columns 4c..4c+3 — and element e of a float4 feeds the matrix
+// instruction of column tile e: the tiles hold the columns {4c + e}, a permutation that the
+// write-back undoes. Rows past the slice / matrix read as 0 through the buffer descriptors;
+// columns past M / N accumulate garbage that is never stored.
+// ------------------------------------------------------------------------------------------------
+struct Wgrad2Args {
+    const float* A; long long lda; int M;
+    const float* B; long long ldb; int N;
+    long long n;
+    float* C; int ldc;
+    float* db;
+    long long rows_per_split;   // multiple of 8
+    float* part;                // optional [splits, mb, nb, 128*256 + 128] partial blocks
+};
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+#define LDX4(rs, voff, soff) \
+    __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
+
+__global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
+    // 8 rows of A (128 columns) and of B (256 columns) per step, staged once per workgroup through
+    // LDS (double-buffered): the four wavefronts read the same B rows and the same A float4
+    __shared__ f32x4w sA[2][8][32];   // [buffer][row][float4 column]
+    __shared__ f32x4w sB[2][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 256;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_split;
+    long long r1 = r0 + a.rows_per_split;
+    if (r1 > a.n) r1 = a.n;
+    const int nrows = r0 < r1 ? (int)(r1 - r0) : 0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.A + (size_t)r0 * a.lda), 0, (int)((size_t)nrows * a.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.B + (size_t)r0 * a.ldb), 0, (int)((size_t)nrows * a.ldb * 4), 0x00020000);
+    // staging role of this thread: row tr (0..7) of the step, float4 column tc (A), tc and tc+32 (B)
+    const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
+    const bool second = n0 + 128 < a.N;
+    const int ga = (int)((tr * a.lda + m0 + 4 * tc) * 4);
+    const int gb0 = (int)((tr * a.ldb + n0 + 4 * tc) * 4);
+    const int gb1 = second ? gb0 + 512 : 0x7ffffff0;
+    const int sa = (int)(a.lda * 32), sbb = (int)(a.ldb * 32);  // eight rows
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    }
+    f32x4w asum = {0.f, 0.f, 0.f, 0.f};
+    const int nstep = (nrows + 7) / 8;
+    f32x4w ga4 = LDX4(ra, ga, 0), gb4 = LDX4(rb, gb0, 0), gc4 = LDX4(rb, gb1, 0);
+    sA[0][tr][tc] = ga4;
+    sB[0][tr][tc] = gb4;
+    sB[0][tr][32 + tc] = gc4;
+    __syncthreads();
+    for (int st = 0; st < nstep; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nstep) {   // next step's rows: global -> registers while this step multiplies
+            ga4 = LDX4(ra, ga, (st + 1) * sa);
+            gb4 = LDX4(rb, gb0, (st + 1) * sbb);
+            gc4 = LDX4(rb, gb1, (st + 1) * sbb);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4w a4 = sA[cur][2 * u + h][c];
+            const f32x4w b0 = sB[cur][2 * u + h][c], b1 = sB[cur][2 * u + h][32 + c];
+            const float aw = wave == 0 ? a4[0] : wave == 1 ? a4[1] : wave == 2 ? a4[2] : a4[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = MFMA(aw, b0[e], acc[e]);
+                acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
+            }
+            asum += a4;
+        }
+        if (st + 1 < nstep) {
+            sA[cur ^ 1][tr][tc] = ga4;
+            sB[cur ^ 1][tr][tc] = gb4;
+            sB[cur ^ 1][tr][32 + tc] = gc4;
+        }
+        __syncthreads();
+    }
+    // register q of lane (c, h) in tile e: C row m0 + 4((q&3) + 8(q>>2) + 4h) + wave,
+    // column n0 + 128(e>>2) + 4c + (e&3)
+    if (a.part) {
+        // deterministic path: this block's partial sums go to its own slab, summed by
+        // lidf_wgrad_reduce_kernel in a fixed order
+        float* slab = a.part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 256 + 128);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ml = 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + wave;
+                slab[ml * 256 + 128 * (e >> 2) + 4 * c + (e & 3)] = acc[e][q];
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = asum[e];
+                v += __shfl_xor(v, 32);
+                if (h == 0) slab[128 * 256 + 4 * c + e] = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = n0 + 128 * (e >> 2) + 4 * c + (e & 3);
+        if (col >= a.N) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + wave;
+            const float v = acc[e][q];
+            if (m < a.M && v != 0.f) atomicAdd(a.C + (size_t)m * a.ldc + col, v);
+        }
+    }
+    // bias gradient: column sums of A (first column block only); lanes c and c+32 hold the two rows
+    if (a.db && blockIdx.z == 0 && wave == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = asum[e];
+            v += __shfl_xor(v, 32);
+            const int m = m0 + 4 * c + e;
+            if (h == 0 && m < a.M && v != 0.f) atomicAdd(a.db + m, v);
+        }
+    }
+}
+
+// C[m, col] += sum over the row slices of the partial blocks, in a fixed order (deterministic):
+// thread (entry group g of 32 float4 entries, slice group k of 8) sums every 8th slice of its
+// float4, the 8 slice groups are combined through LDS in order k = 0..7.
+__global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                int splits, int mb, int nb, int M,
+                                                                int N, float* __restrict__ C, int ldc,
+                                                                float* __restrict__ db) {
+    __shared__ f32x4w red[8][32];
+    const int blk = blockIdx.y;                  // (m block, n block)
+    const int bm = blk / nb, bn = blk % nb;
+    const int e4 = blockIdx.x * 32 + (threadIdx.x & 31);   // float4 entry of the 128 x 256 (+128) slab
+    const int k = threadIdx.x >> 5;
+    constexpr int SLAB = 128 * 256 + 128;
+    f32x4w s = {0.f, 0.f, 0.f, 0.f};
+    if (e4 < SLAB / 4) {
+        const float* p = part + ((size_t)bm * nb + bn) * SLAB + 4 * (size_t)e4;
+        for (int sp = k; sp < splits; sp += 8) s += *(const f32x4w*)(p + (size_t)sp * mb * nb * SLAB);
+    }
+    red[k][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (k != 0 || e4 >= SLAB / 4) return;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += red[j][threadIdx.x & 31];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = 4 * e4 + i;
+        if (e < 128 * 256) {
+            const int m = bm * 128 + e / 256, col = bn * 256 + e % 256;
+            if (m < M && col < N) C[(size_t)m * ldc + col] += s[i];
+        } else if (db && bn == 0) {
+            const int m = bm * 128 + (e - 128 * 256);
+            if (m < M) db[m] += s[i];
+        }
+    }
+}
+
 extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, const float* B,
                                         long long ldb, int N, long long n, float* C, int ldc,
-                                        float* db, hipStream_t st) {
+                                        float* db, float* g_wgrad_scratch,
+                                        size_t g_wgrad_scratch_floats, hipStream_t st) {
     if (n <= 0 || M <= 0) return hipSuccess;
+    // the wide layers: 128 x 256 blocks (float4 loads want lda/ldb*4 within the 32-bit offsets the
+    // buffer instructions take, and a slice of rows below 2 GiB)
+    if (M >= 32 && N >= 64) {
+        Wgrad2Args w;
+        w.A = A; w.lda = lda; w.M = M; w.B = B; w.ldb = ldb; w.N = N; w.n = n; w.C = C; w.ldc = ldc;
+        w.db = db;
+        const int mb = (M + 127) / 128, nb = (N + 255) / 256;
+        // two workgroups per CU; with a scratch area for the partial blocks the slices are as long
+        // as possible (fewer partial sums), without it shorter slices keep the atomics spread
+        long long splits = (g_wgrad_scratch ? 512 : 1024) / (mb * nb);
+        const long long max_splits = (n + 1023) / 1024;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        w.rows_per_split = ((n + splits - 1) / splits + 7) / 8 * 8;
+        const long long sp = (n + w.rows_per_split - 1) / w.rows_per_split;
+        const size_t slice_bytes = (size_t)w.rows_per_split * (size_t)(lda > ldb ? lda : ldb) * 4;
+        const size_t need = (size_t)sp * mb * nb * (128 * 256 + 128);
+        w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats) ? g_wgrad_scratch : nullptr;
+        if (slice_bytes < 0x7fffffffULL) {
+            hipLaunchKernelGGL(lidf_wgrad2_kernel, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+            if (w.part)
+                hipLaunchKernelGGL(lidf_wgrad_reduce_kernel, dim3(((128 * 256 + 128) / 4 + 31) / 32, mb * nb),
+                                   dim3(256), 0, st, w.part, (int)sp, mb, nb, M, N, C, ldc, db);
+            return hipGetLastError();
+        }
+    }
     WgradArgs a;
     a.A = A; a.lda = lda; a.M = M; a.B = B; a.ldb = ldb; a.N = N; a.n = n; a.C = C; a.ldc = ldc;
     a.db = db;

@@ -315,10 +315,14 @@ def ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox=8, multires_
         raise RuntimeError("feat_grid must have 32 channels")
     R = ray_dir.shape[0]
     out = torch.empty((R, 128 + 3 + 6 * multires_views), dtype=torch.float32, device=ray_dir.device)
+    L = _lib.lib()
+    wsb = L.lidf_ray_features_workspace_bytes(B, h, w, R)   # box-sum image: 4 gathers per channel
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=ray_dir.device)
     with torch.cuda.device(ray_dir.device):
-        _lib.check(_lib.lib().lidf_ray_features_f32(
+        _lib.check(L.lidf_ray_features_f32(
             _lib.ptr(feat_grid), B, h, w, _lib.ptr(ray_dir), _lib.ptr(ray_pix), _lib.ptr(ray_bid),
-            R, roi_inp_bbox, multires_views, _lib.ptr(out), _lib.current_stream(ray_dir.device)))
+            R, roi_inp_bbox, multires_views, _lib.ptr(out), _lib.ptr(ws), wsb,
+            _lib.current_stream(ray_dir.device)))
     return out
 
 

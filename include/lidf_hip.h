@@ -170,11 +170,14 @@ int lidf_query_profile_f32(const LidfQueryArgs* args, void* ev_points_begin, voi
 /* Per-ray ROIAlign feature (torchvision.ops.roi_align, output 2x2, aligned=True, called at
  * models/pipeline.py:374-387 and :954-967) + direction embedding, exposed on its own because
  * stage 2 (RefineNet.get_pred_refine) re-uses it. rayfeat: [R, 128 + 3 + 6*multires_views],
- * row = [c*4 + ph*2 + pw for 32 channels | embed(dir)].                                    */
+ * row = [c*4 + ph*2 + pw for 32 channels | embed(dir)]. workspace is optional (NULL / 0): with
+ * lidf_ray_features_workspace_bytes the unclamped boxes are pooled from a 4x4 box-sum image.   */
+size_t lidf_ray_features_workspace_bytes(int batch, int height, int width, int64_t n_rays);
 int lidf_ray_features_f32(const float* feat_grid, int batch, int height, int width,
                           const float* ray_dir, const int32_t* ray_pix, const int32_t* ray_bid,
                           int64_t n_rays, int roi_inp_bbox, int multires_views,
-                          float* rayfeat, lidf_stream_t stream);
+                          float* rayfeat, void* workspace, size_t workspace_bytes,
+                          lidf_stream_t stream);
 
 /* Per-ray softmax / argmax / select on its own (torch_scatter.scatter_softmax + scatter_max at
  * models/pipeline.py:442-454). Ties: lowest pair index. Empty ray: id = P, pos = 0.          */
