@@ -31,6 +31,11 @@ def build(force=False, verbose=False):
         # the decoder pass is one 168-step fully unrolled software pipeline; clang's default
         # 16k-instruction cap on `#pragma unroll` would silently leave it rolled (arrays in scratch)
         "-mllvm", "-pragma-unroll-threshold=8000000",
+        # MFMA results in architectural VGPRs wherever they fit: a layer's outputs are the next
+        # layer's B operands, which must be VGPRs — with accumulators in AGPRs every activation
+        # costs a v_accvgpr_read, a VALU slot that f32 MFMA does not hide on gfx950. The decoder
+        # pass is ordered k-major so that the live set fits (lidf_points.hip); AGPRs stay as spill space
+        "-mllvm", "-amdgpu-mfma-vgpr-form",
         "-I", os.path.join(ROOT, "include"),
         "-I", HERE, "-o", LIB,
     ] + [os.path.join(HERE, s) for s in SOURCES]

@@ -14,7 +14,9 @@
 // Biases ride along as one extra k-step whose B operand is 1.0 in lanes 0..31 and 0 in 32..63.
 //
 // One block per decoder ("net"), consumed strictly front to back by an 8-deep register ring:
-//   [ layer 1 : NL1 quads ][ u : 2 quads ][ layer 2 : 4 tiles x 33 quads ][ layer 3 : 2 x 17 ]
+//   [ layer 1 : NL1 quads ][ u : 2 quads ][ layer 2 : 33 k-quads x 4 tiles ][ layer 3 : 17 x 2 ]
+//   (layers 2 and 3 are k-quad major: every output tile advances together, so an input tile of 16
+//    registers is produced right before its four k-quads and is dead after them)
 //   layer 1, fused mode : for octave pair it, tile t, jq<3 : quad (it*24 + t*3 + jq) = k-steps
 //                         4jq..4jq+3 of the 12 (sin x,y,z, cos x,y,z of octaves 2it, 2it+1);
 //                         then 8 tail quads (x, y, z, pad), one per tile

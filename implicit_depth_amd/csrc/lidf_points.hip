@@ -117,16 +117,16 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         return ief_u(n, 32 * (4 * quad + jj) + c32);
     }
     quad -= LIDF_U_QUADS;
-    if (quad < 4 * LIDF_L2_QUADS) {  // ---- layer 2, output tile major
-        const int t = quad / LIDF_L2_QUADS, s = 4 * (quad % LIDF_L2_QUADS) + jj;
+    if (quad < 4 * LIDF_L2_QUADS) {  // ---- layer 2, k-quad major: quad = 4 kq + output tile
+        const int t = quad % 4, s = 4 * (quad / 4) + jj;
         const int out = 32 * t + c32;
         if (s < LIDF_H1 / 2) return n.w2[(size_t)out * LIDF_H1 + k_to_feature(s, half)];
         if (s == LIDF_H1 / 2 && half == 0) return n.b2[out];
         return 0.f;
     }
     quad -= 4 * LIDF_L2_QUADS;
-    {  // ---- layer 3
-        const int t = quad / LIDF_L3_QUADS, s = 4 * (quad % LIDF_L3_QUADS) + jj;
+    {  // ---- layer 3, k-quad major: quad = 2 kq + output tile
+        const int t = quad % 2, s = 4 * (quad / 2) + jj;
         const int out = 32 * t + c32;
         if (s < LIDF_H2 / 2) return n.w3[(size_t)out * LIDF_H2 + k_to_feature(s, half)];
         if (s == LIDF_H2 / 2 && half == 0) return n.b3[out];
@@ -319,16 +319,14 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
             H1[0] = MFMA(u0[0], ob, base[0]);
             lrelu_part<0, 16>(H1[0]);
         } else if (s < S_L3) {
-            // ---- layer 2: output tile t, k-steps 4kq..4kq+3 (H1 tile kq/4)
-            const int t = (s - S_L2) / LIDF_L2_QUADS, kq = (s - S_L2) % LIDF_L2_QUADS;
-            if (t == 0 && (kq & 3) == 0 && kq / 4 + 1 < 8) {
-                // H1 tile needed four quads from now
-                const int T = kq / 4 + 1;
+            // ---- layer 2, k-quad major: all four output tiles advance together, so a layer-1
+            // tile is produced right before its four k-quads and is dead after them
+            const int kq = (s - S_L2) / 4, t = (s - S_L2) % 4;
+            if (t == 3 && (kq & 3) == 3 && kq / 4 + 1 < 8) {
+                const int T = kq / 4 + 1;   // needed from the next step on
                 H1[T] = MFMA(T < 4 ? u0[T & 3] : u1[T & 3], ob, base[T]);
                 lrelu_part<0, 16>(H1[T]);
             }
-            if (t >= 1 && kq == 0) lrelu_part<0, 8>(H2[t - 1]);
-            if (t >= 1 && kq == 1) lrelu_part<8, 16>(H2[t - 1]);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int k = 4 * kq + jj;
@@ -339,19 +337,16 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 else if (k == LIDF_H1 / 2)
                     H2[t] = MFMA(a[jj], one_b, H2[t]);
             }
+            if (kq == LIDF_L2_QUADS - 1) lrelu_part<0, 16>(H2[t]);   // tile complete (bias quad)
         } else {
-            // ---- layer 3
-            const int t = (s - S_L3) / LIDF_L3_QUADS, kq = (s - S_L3) % LIDF_L3_QUADS;
-            if (s == S_L3) {
+            // ---- layer 3, k-quad major
+            const int kq = (s - S_L3) / 2, t = (s - S_L3) % 2;
+            if (s == S_L3 + 8) {
                 // operands of the tail, fetched here so that their latency hides behind layer 3
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w4[i] = *(const f32x4*)(ax + h * 32 + 4 * i);
                 b4 = ax[64];
             }
-            if (t == 0 && kq == 0) lrelu_part<0, 8>(H2[3]);
-            if (t == 0 && kq == 1) lrelu_part<8, 16>(H2[3]);
-            if (t == 1 && kq == 0) lrelu_part<0, 8>(H3[0]);
-            if (t == 1 && kq == 1) lrelu_part<8, 16>(H3[0]);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int k = 4 * kq + jj;
@@ -362,6 +357,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 else if (k == LIDF_H2 / 2)
                     H3[t] = MFMA(a[jj], one_b, H3[t]);
             }
+            if (kq == LIDF_L3_QUADS - 1 && t == 0) lrelu_part<0, 16>(H3[0]);
         }
         SCHED_FENCE();
 #ifdef LIDF_PROFILE

@@ -14,7 +14,7 @@ if "--build" in sys.argv or not os.path.exists(LIB):
     src = [os.path.join(B.HERE, s) for s in B.SOURCES]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                     "-ffp-contract=off", "-fvisibility=hidden", "-DLIDF_PROFILE", "-mllvm",
-                    "-pragma-unroll-threshold=8000000", "-I", os.path.join(ROOT, "include"), "-I", B.HERE,
+                    "-pragma-unroll-threshold=8000000", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", os.path.join(ROOT, "include"), "-I", B.HERE,
                     "-o", LIB] + src, check=True)
     if "--build" in sys.argv:
         sys.exit(0)
