@@ -188,6 +188,11 @@ def profile_record(kernel_name):
                     tot += float(f[4]) * (PER_STEP_LAUNCHES.get(name.strip('"').split("(")[0], 1))
             if tot:
                 out["hbm_bytes_step_counter"] = tot
+            mp = os.path.join(ROOT, "profiles", "%s_mfma_pmc.csv" % tag)
+            for ln in open(mp) if os.path.exists(mp) else ():
+                if ln.startswith('"') and kernel_name in ln and "SQ_INSTS_VALU_MFMA_MOPS_F32" in ln:
+                    # the counter ticks once per 512 FLOP (8 per v_mfma_f32_32x32x2_f32)
+                    out["mfma_flop_counter"] = float(ln.strip().rsplit(",", 1)[1]) * 512.0
         except Exception:
             pass
         if out:
@@ -624,6 +629,8 @@ def main():
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "profile": prof.get("profile"),
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,
+                         "flop_per_point_counter": (round(prof["mfma_flop_counter"] / (240 * 320 * 64), 1)
+                                                    if prof.get("mfma_flop_counter") and not h16 else None),
                          "achieved_alg": round(ach_alg, 2), "frac_alg": round(ach_alg / peak, 4)},
             "hbm": {"bytes_alg": round(bytes_alg), "bytes_counter": prof.get("hbm_bytes_step_counter"),
                     "gbps_alg": round(bytes_alg / (elapsed / args.steps) / 1e9, 2),
