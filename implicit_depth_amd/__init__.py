@@ -4,7 +4,10 @@ Host-side mirror of the reference interface for this path (names follow the refe
   decoders.get_embedder / IMNet / IEF        <- models/implicit_net.py
   pointnet.PointNet2Stage                    <- models/pointnet.py
   extensions.ray_aabb.forward / pcl_aabb     <- extensions/{ray_aabb,pcl_aabb}
-  query.lidf_query / get_miss_ray / ...      <- models/pipeline.py:203-466, 593-596
+  query.get_miss_ray / compute_ray_aabb / lidf_query / lidf_refine / get_occ_vox_bound /
+        depth_metrics / lidf_query_train     <- models/pipeline.py:162-466, 577-627, 922-1041
+  pipeline.lidf_forward / refine_forward     <- LIDF.forward / RefineNet.forward, eval flavour
+  torch_ext.ext()                            <- the pybind11 operator module (extensions/*/jit.py)
 All compute goes through csrc/liblidf_hip.so (C ABI in include/lidf_hip.h).
 """
 from . import _lib  # noqa: F401
