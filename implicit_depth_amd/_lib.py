@@ -65,7 +65,8 @@ class LidfQueryTrainArgs(C.Structure):
 class LidfPointNet(C.Structure):
     """struct LidfPointNet (include/lidf_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
-        "w_p1", "b_p1", "w_p2", "b_p2", "w_v1", "b_v1", "w_p3", "b_p3", "w_p4", "b_p4", "w_v2", "b_v2")]
+        "w_p1", "b_p1", "w_p2", "b_p2", "w_v1", "b_v1", "w_p3", "b_p3", "w_p4", "b_p4", "w_v2", "b_v2",
+        "packed")]
 
 
 class LidfPointNetGrads(C.Structure):
@@ -128,6 +129,8 @@ SIGNATURES = {
     "lidf_voxelize_f32": (C.c_int, [_P, _P, _I64, _I, C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                     C.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "lidf_pointnet_workspace_bytes": (_SZ, [_I64, _I64]),
+    "lidf_pointnet_pack_bytes": (_SZ, []),
+    "lidf_pointnet_pack_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _SZ, _P]),
     "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),

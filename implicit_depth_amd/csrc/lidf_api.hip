@@ -87,6 +87,8 @@ hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, l
                                    long long, float*, int*, float*, int, int*, const unsigned char*,
                                    hipStream_t);
 hipError_t lidf_launch_refine_gather(const float*, const int*, long long, float*, int, hipStream_t);
+hipError_t lidf_launch_refine_rows(const float*, const int*, const float*, const float*, int, int, int, int,
+                                   long long, float*, int, hipStream_t);
 hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, float, float,
                                      long long, float*, hipStream_t);
 }
@@ -719,8 +721,8 @@ static size_t lin_stream_bytes(int k, int nt) {
 static int run_linear(const LinSpec& L, const float* X, long long ldx, long long n,
                       const float* addrows, const int* addidx, int relu, float* out,
                       long long ld_out, float* pool, const int* poolidx, float* stream_buf,
-                      int cus, hipStream_t st) {
-    if (n <= 0) return LIDF_OK;
+                      int cus, hipStream_t st, bool pack_only = false, bool prepacked = false) {
+    if (n <= 0 && !pack_only) return LIDF_OK;
     const int nt = L.nout / 32;
     L1Map m = rows_map(L.k, L.c0, 0, 0, L.b ? 1 : 0);
     m.nt = nt;
@@ -728,7 +730,8 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.is_ief = 0; nw.dcore = L.ldw;
-    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (!prepacked) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (pack_only) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
     a.D = m.D; a.has_bias = L.b ? 1 : 0;
@@ -779,36 +782,42 @@ struct PnetBufs {
     float* streams[7];
 };
 
+// mode 0: pack the weight streams and run; 1: pack only (lidf_pointnet_pack_f32); 2: run on
+// streams packed earlier
 static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n,
-                         int64_t n_vox, float* out, const PnetBufs& b, int cus, hipStream_t st) {
+                         int64_t n_vox, float* out, const PnetBufs& b, int cus, hipStream_t st,
+                         int mode = 0) {
     int rc;
-    // torch_scatter fills voxels without points with 0; values are post-ReLU so 0 is the identity
-    CHECK_HIP(hipMemsetAsync(b.pool1, 0, (size_t)n_vox * 64 * 4, st));
-    CHECK_HIP(hipMemsetAsync(b.pool2, 0, (size_t)n_vox * 128 * 4, st));
+    const bool po = mode == 1, pp = mode == 2;
+    if (!po) {
+        // torch_scatter fills voxels without points with 0; values are post-ReLU so 0 is the identity
+        CHECK_HIP(hipMemsetAsync(b.pool1, 0, (size_t)n_vox * 64 * 4, st));
+        CHECK_HIP(hipMemsetAsync(b.pool2, 0, (size_t)n_vox * 128 * 4, st));
+    }
     // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
     if ((rc = run_linear({w->w_p1, w->b_p1, 32, 6, 0, 6}, inp, 6, n, nullptr, nullptr, 1, b.f1, 32,
-                         nullptr, nullptr, b.streams[0], cus, st)))
+                         nullptr, nullptr, b.streams[0], cus, st, po, pp)))
         return rc;
     if ((rc = run_linear({w->w_p2, w->b_p2, 64, 32, 0, 32}, b.f1, 32, n, nullptr, nullptr, 1, b.f2, 64,
-                         b.pool1, vox, b.streams[1], cus, st)))
+                         b.pool1, vox, b.streams[1], cus, st, po, pp)))
         return rc;
     // occ_voxel_feat = relu(vox_lin1(pool1))
     if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
-                         b.g1, 64, nullptr, nullptr, b.streams[2], cus, st)))
+                         b.g1, 64, nullptr, nullptr, b.streams[2], cus, st, po, pp)))
         return rc;
     // point_lin3(cat(voxel feat, point_feat2)) = W3[:, :64] g1[vox] + W3[:, 64:] f2 + b3
     if ((rc = run_linear({w->w_p3, nullptr, 128, 128, 0, 64}, b.g1, 64, n_vox, nullptr, nullptr, 0,
-                         b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st)))
+                         b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st, po, pp)))
         return rc;
     if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 64, 64}, b.f2, 64, n, b.gpart, vox, 1, b.f4, 128,
-                         nullptr, nullptr, b.streams[4], cus, st)))
+                         nullptr, nullptr, b.streams[4], cus, st, po, pp)))
         return rc;
     // point_feat5 = relu(point_lin4(.)) pooled per voxel; out = relu(vox_lin2(pool2))
     if ((rc = run_linear({w->w_p4, w->b_p4, 128, 128, 0, 128}, b.f4, 128, n, nullptr, nullptr, 1,
-                         b.f5, 128, b.pool2, vox, b.streams[5], cus, st)))
+                         b.f5, 128, b.pool2, vox, b.streams[5], cus, st, po, pp)))
         return rc;
     if ((rc = run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, b.pool2, 128, n_vox, nullptr, nullptr,
-                         1, out, 128, nullptr, nullptr, b.streams[6], cus, st)))
+                         1, out, 128, nullptr, nullptr, b.streams[6], cus, st, po, pp)))
         return rc;
     return LIDF_OK;
 }
@@ -829,10 +838,26 @@ LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const in
     b.pool1 = (float*)(base + ws.pool1); b.g1 = (float*)(base + ws.g1);
     b.gpart = (float*)(base + ws.gpart); b.f4 = (float*)(base + ws.f4);
     b.f5 = nullptr; b.pool2 = (float*)(base + ws.pool2);
-    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)(base + ws.s[i]);
+    for (int i = 0; i < 7; ++i)
+        b.streams[i] = w->packed ? (float*)((char*)w->packed + ws.s[i]) : (float*)(base + ws.s[i]);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
-    return pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, (hipStream_t)stream);
+    return pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, (hipStream_t)stream, w->packed ? 2 : 0);
+}
+
+LIDF_API size_t lidf_pointnet_pack_bytes(void) { return pnet_ws(1, 1).f1; }   // the 7 stream slots
+
+LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
+                                      lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
+    if (!packed || packed_bytes < lidf_pointnet_pack_bytes()) return LIDF_ERR_WORKSPACE;
+    const PnetWs ws = pnet_ws(1, 1);
+    PnetBufs b = {};
+    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)((char*)packed + ws.s[i]);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    return pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1);
 }
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
@@ -900,6 +925,8 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
                                       128 + Ed, q->multires_views, q->multires, q->pnet_pos_rel,
                                       q->pos_rel, R, pnet_inp + (size_t)Nv * 6, pnet_vox + Nv,
                                       inp_embed, D, end_voxel, q->pnet_select, st));
+    CHECK_HIP(lidf_launch_refine_rows(q->pred_pos, end_voxel, q->voxel_bound, q->rayfeat, 128 + Ed,
+                                      q->multires_views, q->multires, q->pos_rel, R, inp_embed, D, st));
     if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
         return rc;

@@ -70,21 +70,46 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
     pi[3] = px[0];
     pi[4] = px[hw];
     pi[5] = px[2 * hw];
-    float* e = inp_embed + (size_t)r * ld_e;
-    const float* rf = rayfeat + (size_t)r * ld_rf;
-    for (int i = 0; i < 128; ++i) e[128 + i] = rf[i];
-    const float q[3] = {pos_rel ? x - cx : x, pos_rel ? y - cy : y, pos_rel ? z - cz : z};
-    float* pe = e + 256;
-    for (int i = 0; i < 3; ++i) pe[i] = q[i];
-    for (int l = 0; l < L; ++l) {
-        const float f = (float)(1 << l);
-        for (int i = 0; i < 3; ++i) {
-            pe[3 + 6 * l + i] = sinf(q[i] * f);
-            pe[3 + 6 * l + 3 + i] = cosf(q[i] * f);
-        }
-    }
+}
+
+// inp_embed[r, 128:] = [ROI feature | embed(pos) | embed(dir)]  (pipeline.py:947-969, :1019-1026):
+// one thread per (ray, column) so that the rows leave as coalesced segments; columns 0..127 (voxel
+// feature) are filled after the PointNet pass. Same expressions as the per-ray loop it replaces.
+__global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
+                                        const int* __restrict__ end_voxel,
+                                        const float* __restrict__ vbound,
+                                        const float* __restrict__ rayfeat, int ld_rf, int Lv, int L,
+                                        int pos_rel, long long R, float* __restrict__ inp_embed,
+                                        int ld_e) {
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
-    for (int i = 0; i < Ed; ++i) e[256 + E + i] = rf[128 + i];
+    const int ncol = 128 + E + Ed;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * ncol) return;
+    const long long r = i / ncol;
+    const int c = (int)(i % ncol);
+    const float* rf = rayfeat + (size_t)r * ld_rf;
+    float v;
+    if (c < 128) {
+        v = rf[c];
+    } else if (c < 128 + E) {
+        const int k = c - 128;                    // index inside embed(pos)
+        const int a = k < 3 ? k : (k - 3) % 3;    // coordinate
+        float q = pred_pos[3 * r + a];
+        if (pos_rel) {
+            const float* vb = vbound + 6 * (size_t)end_voxel[r];
+            q = q - (vb[a] + vb[3 + a]) / 2.f;
+        }
+        if (k < 3) {
+            v = q;
+        } else {
+            const int l = (k - 3) / 6;
+            const float f = (float)(1 << l);
+            v = ((k - 3) % 6) < 3 ? sinf(q * f) : cosf(q * f);
+        }
+    } else {
+        v = rf[128 + (c - 128 - E)];
+    }
+    inp_embed[(size_t)r * ld_e + 128 + c] = v;
 }
 
 extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long long* max_pair_id,
@@ -101,6 +126,17 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
                        st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid,
                        ray_flat, rgb, hw, rayfeat, ld_rf, Lv, L, pnet_rel, pos_rel, R, pnet_inp,
                        pnet_vox, inp_embed, ld_e, end_voxel, pnet_select);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_refine_rows(const float* pred_pos, const int* end_voxel,
+                                              const float* vbound, const float* rayfeat, int ld_rf,
+                                              int Lv, int L, int pos_rel, long long R,
+                                              float* inp_embed, int ld_e, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    const long long total = R * (128 + 3 + 6 * L + 3 + 6 * Lv);
+    hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e);
     return hipGetLastError();
 }
 

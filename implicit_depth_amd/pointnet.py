@@ -44,6 +44,26 @@ def pointnet_struct(mod, keep):
     return s
 
 
+def packed_pointnet(mod, s, dev):
+    """The module's weight streams packed once per parameter version (lidf_pointnet_pack_f32),
+    cached on the module and rebuilt when a parameter is modified in place or replaced; sets
+    s.packed and returns the blob (keep it alive for the call)."""
+    params = list(mod.parameters())
+    key = (str(dev), tuple((p.data_ptr(), p._version) for p in params))
+    cache = mod.__dict__.get("_lidf_pack_cache")
+    if cache is None or cache[0] != key:
+        L = _lib.lib()
+        nb = L.lidf_pointnet_pack_bytes()
+        blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        s.packed = None
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_pointnet_pack_f32(C.byref(s), _lib.ptr(blob), nb, _lib.current_stream(dev)))
+        cache = (key, blob)
+        mod.__dict__["_lidf_pack_cache"] = cache
+    s.packed = cache[1].data_ptr()
+    return cache[1]
+
+
 def check_pointnet(mod):
     if (mod.input_channels, mod.gf_dim, mod.point_lin4.out_features) != (6, 32, 128):
         raise RuntimeError("lidf_hip PointNet2Stage is built for input_channels=6, gf_dim=32, "
@@ -150,6 +170,7 @@ class PointNet2Stage(nn.Module):
         out = torch.empty((n_vox, 128), dtype=torch.float32, device=x.device)
         keep = []
         s = pointnet_struct(self, keep)
+        keep.append(packed_pointnet(self, s, x.device))
         L = _lib.lib()
         wsb = L.lidf_pointnet_workspace_bytes(n, n_vox)
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)

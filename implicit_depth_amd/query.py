@@ -371,6 +371,8 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
     keep = []
     pn = pointnet_struct(pnet_model, keep)
+    from .pointnet import packed_pointnet
+    keep.append(packed_pointnet(pnet_model, pn, dev))   # weight streams packed once per version
     do = _decoder_struct(offset_dec, keep)
     cur = pred_pos.contiguous()
     end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)

@@ -285,7 +285,13 @@ typedef struct LidfPointNet {
     const float *w_p3, *b_p3; /* point_lin3 [128,128] */
     const float *w_p4, *b_p4; /* point_lin4 [128,128] */
     const float *w_v2, *b_v2; /* vox_lin2   [128,128] */
+    /* optional: the seven weight streams already packed by lidf_pointnet_pack_f32 (device memory);
+     * NULL = pack inside every call (7 small launches). Valid until a parameter changes.       */
+    const void* packed;
 } LidfPointNet;
+size_t lidf_pointnet_pack_bytes(void);
+int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
+                           lidf_stream_t stream);
 size_t lidf_pointnet_workspace_bytes(int64_t n_pts, int64_t n_vox);
 int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_pts,
                       int64_t n_vox, float* out, void* workspace, size_t workspace_bytes,
