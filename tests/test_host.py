@@ -167,3 +167,33 @@ def test_depth_all_gather_gloo_world2(n_frames):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Status codes of the C ABI for malformed calls (checked before any HIP call is made, so this
+    runs without a GPU): negative = lidf_status, lidf_strerror gives the text."""
+    import ctypes as C
+    from implicit_depth_amd import _lib
+    L = _lib.lib()
+    BAD, UNSUP, WS = -1, -2, -3
+    assert L.lidf_query_f32(None, None) == BAD
+    assert L.lidf_refine_f32(None, None) == BAD
+    assert L.lidf_embed_f32(None, -1, 8, None, None) == BAD
+    assert L.lidf_embed_f32(None, 0, 8, None, None) == 0            # empty input: nothing to do
+    assert L.lidf_miss_ray_count(None, 0, -5, None, None, 0, None) == BAD
+    assert L.lidf_miss_ray_count(None, 9, 10, None, None, 0, None) == BAD   # unknown mask dtype
+    assert L.lidf_query_pack_f32(None, None, 8, 4, 0, None, 0, None) == BAD
+    d = _lib.LidfDecoder()                                           # all-NULL weights
+    assert L.lidf_query_pack_f32(C.byref(d), C.byref(d), 8, 4, 0, None, 0, None) == BAD
+    assert L.lidf_pointnet_pack_f32(None, None, 0, None) == BAD
+    q = _lib.LidfQueryArgs()
+    q.n_rays = -1
+    assert L.lidf_query_f32(C.byref(q), None) == BAD
+    q.n_rays, q.multires = 4, 99
+    assert L.lidf_query_f32(C.byref(q), None) in (BAD, UNSUP)
+    assert L.lidf_exclusive_scan_i32(None, 10, None, None, 0, None) == BAD
+    for code, word in ((0, "ok"), (BAD, "bad argument"), (UNSUP, "unsupported"), (WS, "workspace")):
+        assert word in L.lidf_strerror(code).decode()
+    assert L.lidf_query_pack_bytes() > 0 and L.lidf_pointnet_pack_bytes() > 0
+    assert L.lidf_miss_ray_workspace_bytes(76800) > 0
+    assert L.lidf_ray_features_workspace_bytes(1, 240, 320, 76800) >= 32 * 240 * 320 * 4
