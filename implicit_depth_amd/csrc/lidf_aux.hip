@@ -238,17 +238,20 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
     }
 }
 
-// The collected clamped-box rays: one (ray, channel, bin) item per thread, grid-stride over all
-// of them (the count is read on the device: no host round trip).
+// The collected clamped-box rays: one (ray, channel) item per thread with the RAY index fastest —
+// consecutive list entries are mostly neighbouring pixels of a border row, so the taps of a
+// wavefront fall into the same rows of one channel plane (coalesced) — grid-stride over all items
+// (the count is read on the device: no host round trip). Each item evaluates its four bins.
 __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
     const float* __restrict__ feat, int H, int W, const int* __restrict__ ray_pix,
     const int* __restrict__ ray_bid, int half, const int* __restrict__ border,
     float* __restrict__ out, int ld) {
-    const long long nitem = (long long)border[0] * 128;
+    const long long nb = border[0];
+    const long long nitem = nb * 32;
     for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < nitem;
          item += (long long)gridDim.x * 256) {
-        const long long rr = border[1 + (item >> 7)];
-        const int cb = (int)(item & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
+        const long long rr = border[1 + item % nb];
+        const int c = (int)(item / nb);
         const int qx = ray_pix[2 * rr], qy = ray_pix[2 * rr + 1];
         const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
         const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
@@ -259,15 +262,21 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
         const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
         const float count = (float)max(gh * gw, 1);
         const float* img = feat + ((size_t)ray_bid[rr] * 32 + c) * H * W;
-        float acc = 0.f;  // the reference's (iy, ix) order
-        for (int iy = 0; iy < gh; ++iy) {
-            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
-            for (int ix = 0; ix < gw; ++ix) {
-                const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
-                acc += bilinear(img, H, W, y, x);
+        float res[4];
+#pragma unroll
+        for (int bin = 0; bin < 4; ++bin) {
+            const int ph = bin >> 1, pw = bin & 1;
+            float acc = 0.f;  // the reference's (iy, ix) order
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                    acc += bilinear(img, H, W, y, x);
+                }
             }
+            res[bin] = acc / count;
         }
-        out[(size_t)rr * ld + cb] = acc / count;
+        *(f32x4u*)(out + (size_t)rr * ld + 4 * c) = f32x4u{res[0], res[1], res[2], res[3]};  // rows are only dword-aligned
     }
 }
 
