@@ -118,6 +118,33 @@ def get_miss_ray(mask, fx, fy, cx, cy):
     return _compact_mask(mask, intr)
 
 
+def sample_miss_rays(miss, bs, miss_sample_num):
+    """The train-only sub-sampling of LIDF.get_miss_ray (models/pipeline.py:232-254) applied to
+    get_miss_ray's output: per image a contiguous window of miss_sample_num rays at a random start
+    — drawn with np.random.choice(start_range), the reference's own call, so a run seeded like the
+    reference selects the same windows — or every ray of an image that has no more than that.
+    Returns a dict with the same keys, sliced (views / index_select: plumbing, no compute)."""
+    import numpy as np
+    R = miss["total_miss_sample_num"]
+    if miss_sample_num == -1 or bs * miss_sample_num >= R:
+        return miss
+    cnt = torch.bincount(miss["miss_bid"], minlength=bs).cpu().tolist()
+    sel, sid = [], 0
+    for c in cnt:
+        if c > miss_sample_num:
+            start = int(np.random.choice(c - miss_sample_num + 1)) + sid
+            sel.append((start, start + miss_sample_num))
+        else:
+            sel.append((sid, sid + c))
+        sid += c
+    out = {}
+    for k, v in miss.items():
+        if torch.is_tensor(v):
+            out[k] = torch.cat([v[a:b] for a, b in sel], 0).contiguous()
+    out["total_miss_sample_num"] = int(sum(b - a for a, b in sel))
+    return out
+
+
 def nonzero_pixels(mask):
     """torch.nonzero(mask.view(bs,-1)) of LIDF.get_valid_points (models/pipeline.py:144-146) with
     the same device compaction: {'bid', 'flat'} int64 [N]."""

@@ -134,6 +134,26 @@ def get_miss_ray(mask, fx, fy, cx, cy):
             "total_miss_sample_num": miss_idx.shape[0]}
 
 
+def sample_miss_window(miss_idx, bs, miss_sample_num):
+    """The train-only sub-sampling of LIDF.get_miss_ray (models/pipeline.py:232-254): per image a
+    contiguous window of miss_sample_num entries of miss_idx [R,2] at a random start
+    (np.random.choice(start_range), the reference's own RNG call), every entry if the image has no
+    more than that. Returns the selected row indices into miss_idx."""
+    if miss_sample_num == -1 or bs * miss_sample_num >= miss_idx.shape[0]:
+        return torch.arange(miss_idx.shape[0])
+    cnt = torch.bincount(miss_idx[:, 0], minlength=bs)
+    edges = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(cnt, 0)))
+    sel = []
+    for i in range(bs):
+        sid, eid, c = int(edges[i]), int(edges[i + 1]), int(cnt[i])
+        if c > miss_sample_num:
+            start = int(np.random.choice(c - miss_sample_num + 1)) + sid
+            sel.append(torch.arange(start, start + miss_sample_num))
+        else:
+            sel.append(torch.arange(sid, eid))
+    return torch.cat(sel, 0)
+
+
 # ----------------------------------------------------------------------------------------------
 # a5  ray_aabb — extensions/ray_aabb/ray_aabb_cuda_kernel.cu:24-88 (numpy, same arithmetic)
 # ----------------------------------------------------------------------------------------------

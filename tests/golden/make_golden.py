@@ -329,6 +329,26 @@ def g6_miss_ray():
         for k in ("miss_bid", "miss_flat_img_id", "miss_ray_dir", "miss_img_ind"):
             out[key + "_" + k] = dd[k].numpy()
         print("g6", key, "R =", dd["total_miss_sample_num"])
+    # train flavour: corrupt_mask + the random contiguous window (pipeline.py:229-254) with the
+    # reference's own np.random.choice calls, seeded
+    B, h, w = 3, 12, 16
+    g = torch.Generator().manual_seed(611)
+    mask = (torch.rand(B, h, w, generator=g) < 0.5).float()
+    mask[2, 2:, :] = 0                                                # an image with fewer rays than the window
+    fx = torch.full((B,), 14.0)
+    cx, cy = torch.full((B,), 7.5), torch.full((B,), 5.5)
+    lidf.opt.grid.miss_sample_num = 20
+    dd = {"bs": B, "h": h, "w": w, "fx": fx, "fy": fx, "cx": cx, "cy": cy, "corrupt_mask": mask}
+    np.random.seed(12345)
+    with torch.no_grad():
+        lidf.get_miss_ray(dd, "train")
+    out["t_mask"] = mask.numpy()
+    out["t_intr"] = torch.stack((fx, fx, cx, cy), 1).numpy()
+    out["t_seed"] = np.int64(12345)
+    out["t_miss_sample_num"] = np.int64(20)
+    for k in ("miss_bid", "miss_flat_img_id", "miss_ray_dir", "miss_img_ind"):
+        out["t_" + k] = dd[k].numpy()
+    print("g6 train window: R =", dd["total_miss_sample_num"])
     np.savez_compressed(os.path.join(HERE, "g6_miss_ray.npz"), **out)
 
 

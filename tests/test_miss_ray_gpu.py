@@ -78,3 +78,18 @@ def test_empty_mask_and_feeds_query(cuda):
         get_miss_ray(z.cpu(), one, one, one, one)
     with pytest.raises(RuntimeError):
         get_miss_ray(z.half(), one, one, one, one)
+
+
+def test_train_window_matches_reference(cuda):
+    """sample_miss_rays on the device output = the reference's train-time window (same seed, same
+    np.random.choice calls): tests/golden/g6_miss_ray.npz 't_*'."""
+    from implicit_depth_amd.query import get_miss_ray, sample_miss_rays
+    g = np.load(os.path.join(GOLD, "g6_miss_ray.npz"))
+    mask = torch.from_numpy(g["t_mask"]).to(cuda)
+    intr = torch.from_numpy(g["t_intr"]).to(cuda)
+    res = get_miss_ray(mask, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3])
+    np.random.seed(int(g["t_seed"]))
+    sub = sample_miss_rays(res, mask.shape[0], int(g["t_miss_sample_num"]))
+    ref = {k: g["t_" + k] for k in ("miss_bid", "miss_flat_img_id", "miss_ray_dir", "miss_img_ind")}
+    _check(sub, ref, ref["miss_bid"].shape[0])
+    assert sample_miss_rays(res, mask.shape[0], -1) is res          # miss_sample_num == -1: all rays

@@ -198,3 +198,18 @@ def test_g6_miss_ray():
         for k in ("miss_bid", "miss_flat_img_id", "miss_img_ind"):
             assert (res[k].numpy() == g[key + "_" + k]).all(), (key, k)
         assert np.abs(res["miss_ray_dir"].numpy() - g[key + "_miss_ray_dir"]).max() == 0.0
+
+
+def test_g6_miss_ray_train_window():
+    """Train flavour (pipeline.py:229-254): the random contiguous window, drawn with the
+    reference's own np.random.choice calls under the same seed."""
+    g = load("g6_miss_ray.npz")
+    mask = torch.from_numpy(g["t_mask"])
+    intr = torch.from_numpy(g["t_intr"])
+    res = orc.get_miss_ray(mask, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3])
+    idx = torch.stack((res["miss_bid"], res["miss_flat_img_id"]), 1)
+    np.random.seed(int(g["t_seed"]))
+    sel = orc.sample_miss_window(idx, mask.shape[0], int(g["t_miss_sample_num"]))
+    for k in ("miss_bid", "miss_flat_img_id", "miss_img_ind"):
+        assert (res[k][sel].numpy() == g["t_" + k]).all(), k
+    assert np.abs(res["miss_ray_dir"][sel].numpy() - g["t_miss_ray_dir"]).max() == 0.0
