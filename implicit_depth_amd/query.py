@@ -712,11 +712,24 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
     reference's [P,385] decoder input rows (same results, more memory and work).
     Returns pred_offset, pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
     max_pair_id [R] (P for an empty ray) and pred_pos [R,3]."""
-    import math
+    ray_pix, ray_bid = _as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid")   # int64 accepted
     _lib.require_cuda(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
-                      vox_feat, names=["ray_dir", "ray_pix", "ray_bid", "pair_off", "pair_ray",
-                                       "pair_vox", "pair_t", "feat_grid", "vox_feat"])
+                      vox_feat, vox_center,
+                      names=["ray_dir", "ray_pix", "ray_bid", "pair_off", "pair_ray", "pair_vox",
+                             "pair_t", "feat_grid", "vox_feat", "vox_center"])
+    for t, n in ((ray_dir, "ray_dir"), (pair_t, "pair_t"), (feat_grid, "feat_grid"),
+                 (vox_feat, "vox_feat"), (vox_center, "vox_center")):
+        if t is not None:
+            _f32(t, n)
+    for t, n in ((pair_off, "pair_off"), (pair_ray, "pair_ray"), (pair_vox, "pair_vox")):
+        _i32(t, n)
+    if feat_grid.dim() != 4 or feat_grid.shape[1] != 32:
+        raise RuntimeError("feat_grid must be [B,32,h,w] (rgb_out=32)")
+    if vox_feat.dim() != 2 or vox_feat.shape[1] != 128:
+        raise RuntimeError("vox_feat must be [V,128] (pnet_out=128)")
     R, P = ray_dir.shape[0], pair_ray.shape[0]
+    if pair_off.shape[0] != R + 1 or ray_pix.shape != (R, 2) or ray_bid.shape != (R,):
+        raise RuntimeError("pair_off / ray_pix / ray_bid must be [R+1] / [R,2] / [R]")
     rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
     if factorised:
         pe = torch.empty((P, 2 * (3 + 6 * multires)), dtype=torch.float32, device=ray_dir.device)
