@@ -58,8 +58,12 @@ def packed_pointnet(mod, s, dev):
         s.packed = None
         with torch.cuda.device(dev):
             _lib.check(L.lidf_pointnet_pack_f32(C.byref(s), _lib.ptr(blob), nb, _lib.current_stream(dev)))
-        cache = (key, blob)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        cache = (key, blob, ev)
         mod.__dict__["_lidf_pack_cache"] = cache
+    else:
+        torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
     s.packed = cache[1].data_ptr()
     return cache[1]
 

@@ -210,6 +210,7 @@ def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, d
            tuple((p.data_ptr(), p._version) for p in params))
     cache = prob_dec.__dict__.get("_lidf_pack_cache")
     if cache is not None and cache[0] == key:
+        torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
         return cache[1]
     L = _lib.lib()
     nb = L.lidf_query_pack_bytes()
@@ -218,7 +219,9 @@ def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, d
         _lib.check(L.lidf_query_pack_f32(C.byref(dp), C.byref(do), multires, multires_views,
                                          PRECISIONS[precision], _lib.ptr(blob), nb,
                                          _lib.current_stream(dev)))
-    prob_dec.__dict__["_lidf_pack_cache"] = (key, blob)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+    prob_dec.__dict__["_lidf_pack_cache"] = (key, blob, ev)
     return blob
 
 
