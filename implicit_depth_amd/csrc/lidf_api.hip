@@ -7,7 +7,7 @@ extern "C" {
 hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                             float*, hipStream_t);
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
-hipError_t lidf_launch_l1only_pair(const PointsArgs&, int, const PointsArgs&, int, hipStream_t);
+hipError_t lidf_launch_l1only_pair(const PointsArgs&, const PointsArgs&, int cus, hipStream_t);
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
 hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
@@ -489,10 +489,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
                 a.npass[0] = a.npass[1] = 0;
                 CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
             } else {
-                // one launch: (ray tiles | voxel tiles) x nets; two workgroups fit a CU
-                const int gx_v = (int)(ntv < 32 ? ntv : 32);
-                const int gx_r = (int)(nt < cus - gx_v ? nt : (cus - gx_v > 1 ? cus - gx_v : 1));
-                CHECK_HIP(lidf_launch_l1only_pair(a, gx_r, av, gx_v, st));
+                // one launch over the (tile, net, half) items of both tables
+                CHECK_HIP(lidf_launch_l1only_pair(a, av, cus, st));
             }
         }
         // 4. per-point kernel

@@ -802,16 +802,127 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
     points_rows_body<MODE>(a, blockIdx.x, gridDim.x, 0, a.nets);
 }
 
-// Layer-1-only launch of the query: the per-ray rows (problem a, workgroups [0, gx_a) of every
-// grid row) and the per-voxel rows (problem b, the remaining workgroups) in ONE launch, each net
-// on its own grid row: twice the work items of a (tile, both nets) split, so the last round of
-// tiles is better filled, and the small per-voxel problem runs beside the per-ray one.
-__global__ void __launch_bounds__(256) lidf_l1only_pair_kernel(PointsArgs a, PointsArgs b, int gx_a) {
-    const int net = blockIdx.y;
-    if ((int)blockIdx.x < gx_a)
-        points_rows_body<LIDF_MODE_L1ONLY>(a, blockIdx.x, gx_a, net, net + 1);
-    else
-        points_rows_body<LIDF_MODE_L1ONLY>(b, blockIdx.x - gx_a, gridDim.x - gx_a, net, net + 1);
+// ------------------------------------------------------------------------------------------------
+// Layer-1 partial products of the query in work items of (128-row tile, net, half of the 256
+// outputs): four times the items of a (tile, both nets) split, so the last round of a launch that
+// covers only a few rounds (600 ray tiles on 256 CUs) is well filled; 64 accumulator registers per
+// wavefront instead of 128 (more wavefronts per SIMD hide the operand-row latency); the 32 x 32
+// output tiles leave through LDS as 128-byte row segments (direct stores would touch 64 lines per
+// instruction with 16 bytes each: raypart is 157 MB per frame). Stream: the rows-mode layer-1
+// layout with 8 tiles per k-quad (lidf_device.h); half hf reads the quads kq*8 + 4hf + {0..3}.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long tile, const int net,
+                                            const int hf, float* s_stage) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int net_bytes = a.net_quads * 1024;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.stream, 0, a.nets * net_bytes, 0x00020000);
+    const int vq = lane * 16;
+    const int sbase = net * net_bytes + 4 * hf * 1024;
+    float* stage = s_stage + wave * (32 * 33);
+    {
+        if (tile * 128 + wave * 32 >= a.n) return;
+        const long long p = tile * 128 + wave * 32 + col;
+        const long long pc = p < a.n ? p : a.n - 1;
+        const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+        auto load_b = [&](int kq, float (&b)[4]) {
+            const int x0 = 8 * kq + 4 * h;
+            if (x0 + 3 < a.D) {
+                const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+                b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
+                                          : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+            }
+        };
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        }
+        // operand rows four k-quads ahead (they stream from HBM), weight quads one k-quad ahead
+        constexpr int XD = 4;
+        float xr[XD][4];
+#pragma unroll
+        for (int i = 0; i < XD; ++i) {
+            if (i < a.KQ1) load_b(i, xr[i]);
+            else xr[i][0] = xr[i][1] = xr[i][2] = xr[i][3] = 0.f;
+        }
+        f32x4 qc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qc[t] = LDQ(srs, vq, sbase + t * 1024);
+        for (int kq0 = 0; kq0 < a.KQ1; kq0 += XD) {
+#pragma unroll
+            for (int i = 0; i < XD; ++i) {
+                const int kq = kq0 + i;
+                if (kq >= a.KQ1) break;
+                const float bc[4] = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
+                if (kq + XD < a.KQ1) load_b(kq + XD, xr[i]);
+                f32x4 qn[4];
+                const int kn = kq + 1 < a.KQ1 ? kq + 1 : kq;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qn[t] = LDQ(srs, vq, sbase + (kn * 8 + t) * 1024);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x16 c = acc[t];
+                    c = MFMA(qc[t][0], bc[0], c);
+                    c = MFMA(qc[t][1], bc[1], c);
+                    c = MFMA(qc[t][2], bc[2], c);
+                    c = MFMA(qc[t][3], bc[3], c);
+                    acc[t] = c;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qc[t] = qn[t];
+                SCHED_FENCE();
+            }
+        }
+        // register 4g+i of lane (col, h) in tile t = output 32(4hf+t) + 8g + 4h + i of row `col`
+        float* ob = a.out_base + ((size_t)(tile * 128 + wave * 32) * a.nets + net) * 256 + 128 * hf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stage[col * 33 + 8 * g + 4 * h + i] = acc[t][4 * g + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 8 * j + (lane >> 3), f4 = (lane & 7) * 4;
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = stage[row * 33 + f4 + i];
+                if (tile * 128 + wave * 32 + row < a.n)
+                    *(f32x4*)(ob + (size_t)row * a.nets * 256 + 32 * t + f4) = o;
+            }
+        }
+    }
+}
+
+// Flat list of items (problem a then problem b; the 2*nets parts of a tile adjacent, so that the
+// operand rows of a tile are fetched from HBM once and found in L2 by the other parts), cut into
+// equal contiguous runs over the grid.
+__global__ void __launch_bounds__(256) lidf_l1part_pair_kernel(PointsArgs a, PointsArgs b) {
+    __shared__ float s_stage[4 * 32 * 33];
+    const int parts = a.nets * 2;
+    const long long na = (a.n + 127) / 128 * parts, nb = (b.n + 127) / 128 * parts;
+    const long long tot = na + nb, per = tot / gridDim.x, rem = tot % gridDim.x;
+    const long long bx = blockIdx.x;
+    const long long ib = bx * per + (bx < rem ? bx : rem), ie = ib + per + (bx < rem ? 1 : 0);
+    for (long long i = ib; i < ie; ++i) {
+        if (i < na) {
+            const int part = (int)(i % parts);
+            l1part_item(a, i / parts, part >> 1, part & 1, s_stage);
+        } else {
+            const int part = (int)((i - na) % parts);
+            l1part_item(b, (i - na) / parts, part >> 1, part & 1, s_stage);
+        }
+    }
 }
 
 template <int MODE>
@@ -820,10 +931,14 @@ static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
 }
 
-extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, int gx_a, const PointsArgs& b,
-                                              int gx_b, hipStream_t st) {
-    if (a.n <= 0 || b.n <= 0 || a.nets != b.nets) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lidf_l1only_pair_kernel, dim3(gx_a + gx_b, a.nets), dim3(256), 0, st, a, b, gx_a);
+extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, const PointsArgs& b, int cus,
+                                               hipStream_t st) {
+    if (a.nets != b.nets) return hipErrorInvalidValue;
+    const long long items = ((a.n + 127) / 128 + (b.n + 127) / 128) * a.nets * 2;
+    if (items <= 0) return hipSuccess;
+    // two workgroups per CU: 9600 wavefront items of a 240x320 frame leave 10 per SIMD at best
+    const int grid = (int)(items < 2LL * cus ? items : 2LL * cus);
+    hipLaunchKernelGGL(lidf_l1part_pair_kernel, dim3(grid), dim3(256), 0, st, a, b);
     return hipGetLastError();
 }
 
