@@ -42,6 +42,11 @@ hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long l
                                 hipStream_t);
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
 hipError_t lidf_launch_axpy(const float*, long long, float*, hipStream_t);
+hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
+                                   float*, float*, float*, hipStream_t);
+hipError_t lidf_launch_ief_tail(const float*, const float*, const float*, int, const float*,
+                                const float*, long long, int, float*, float*, float*, float*, float*,
+                                float*, hipStream_t);
 hipError_t lidf_launch_out_act(const float*, long long, int, float*, const float*, float*,
                                hipStream_t);
 hipError_t lidf_launch_build_rows(const int*, const int*, const float*, const float*, const float*, int,
@@ -1196,13 +1201,10 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         const float* h3 = h2 + (size_t)n * LIDF_H2;
         const float* offin = h3 + (size_t)n * LIDF_H3;
         // y_k = w4 . H3 + b4 ;  dL/dy_k = dL/d(off_{k+1}) = goff
-        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, n, grads->w4, LIDF_H3, grads->b4, wgs, WG_SCRATCH_FLOATS, st));
+        // dZ3 = (goff (x) w4) * lrelu'(Z3), d w4, d b4: one pass over H3
+        CHECK_HIP(lidf_launch_l4_backward(goff, h3, dec->w4, 0.02f, n, dz3, grads->w4, grads->b4, wgs, st));
         LinEx L = {};
         L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
-        // dZ3 = (goff (x) w4) * lrelu'(Z3)
-        L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
-        L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         // dZ2 = (dZ3 W3) * lrelu'(Z2)
         L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
@@ -1226,19 +1228,11 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
             L.accumulate = 0;
         }
         if (dec->is_ief) {
-            // the 16 offset-encoding columns of layer 1: enc_k = off_k wenc^T + benc
-            CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, n, enc, st));
-            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, n, grads->w1 + d, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-            // d enc = dZ1 W1[:, d:d+16] ; d wenc = d enc^T off_k ; d benc = sum d enc
-            L.w = dec->w1 + d; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
-            L.out = denc; L.ld_out = 16;
-            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, n, grads->wenc, 1, grads->benc, wgs, WG_SCRATCH_FLOATS, st));
-            // d off_k = d off_{k+1} + d enc . wenc
-            L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
-            L.out = goff; L.ld_out = 1; L.accumulate = 1;
-            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            L.accumulate = 0;
+            // the 16 offset-encoding columns of layer 1 (enc_k = off_k wenc^T + benc): d W1[:, d:],
+            // d wenc, d benc and d off_k = d off_{k+1} + d enc . wenc in one pass over dZ1
+            CHECK_HIP(lidf_launch_ief_tail(dz1, offin, dec->w1 + d, ld1, dec->wenc, dec->benc, n, 0,
+                                           nullptr, goff, grads->w1 + d, grads->wenc, grads->benc,
+                                           wgs, st));
         }
     }
     return LIDF_OK;
@@ -1485,12 +1479,9 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         const float* h2 = h1 + (size_t)P * LIDF_H1;
         const float* h3 = h2 + (size_t)P * LIDF_H2;
         const float* offin = h3 + (size_t)P * LIDF_H3;
-        CHECK_HIP(lidf_launch_wgrad(goff, 1, 1, h3, LIDF_H3, LIDF_H3, P, grads->w4, LIDF_H3, grads->b4, wgs, WG_SCRATCH_FLOATS, st));
+        CHECK_HIP(lidf_launch_l4_backward(goff, h3, dec->w4, 0.02f, P, dz3, grads->w4, grads->b4, wgs, st));
         LinEx L = {};
         L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
-        L.w = dec->w4; L.ldw = LIDF_H3; L.nout = LIDF_H3; L.k = 1; L.X = goff; L.ldx = 1;
-        L.mask_src = h3; L.ld_mask = LIDF_H3; L.out = dz3; L.ld_out = LIDF_H3;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
         L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
@@ -1501,28 +1492,12 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
         L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
         if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        if (npass == 1) {
-            S = dz1;
-        } else if (k == npass - 1) {
-            CHECK_HIP(hipMemcpyAsync(S, dz1, (size_t)P * LIDF_H1 * 4, hipMemcpyDeviceToDevice, st));
-        } else {
-            // S += dZ1 through the linear kernel's accumulate epilogue would need an identity
-            // product; a plain wide add is the wgrad-free way: reuse the fill/out kernels? -> axpy
-            CHECK_HIP(lidf_launch_axpy(dz1, (long long)P * LIDF_H1, S, st));
-        }
-        L.mask_src = nullptr;
-        if (dec->is_ief) {
-            CHECK_HIP(lidf_launch_enc_rows(offin, dec->wenc, dec->benc, P, enc, st));
-            CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, enc, 16, 16, P, grads->w1 + D, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-            L.w = dec->w1 + D; L.ldw = ld1; L.nout = 16; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
-            L.out = denc; L.ld_out = 16;
-            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            CHECK_HIP(lidf_launch_wgrad(denc, 16, 16, offin, 1, 1, P, grads->wenc, 1, grads->benc, wgs, WG_SCRATCH_FLOATS, st));
-            L.w = dec->wenc; L.ldw = 1; L.nout = 1; L.k = 16; L.X = denc; L.ldx = 16;
-            L.out = goff; L.ld_out = 1; L.accumulate = 1;
-            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            L.accumulate = 0;
-        }
+        // the offset-encoding columns of layer 1 and the running sum S of dZ1 (everything of
+        // layer 1 except the offset encoding sees the same operand in every pass): one pass over dZ1
+        if (npass == 1) S = dz1;
+        CHECK_HIP(lidf_launch_ief_tail(dz1, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
+                                       dec->benc, P, npass == 1 ? 0 : (k == npass - 1 ? 1 : 2), S, goff,
+                                       grads->w1 + D, grads->wenc, grads->benc, wgs, st));
     }
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
     CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));

@@ -391,6 +391,234 @@ extern "C" hipError_t lidf_launch_out_act(const float* pre, long long n, int use
 }
 
 // ------------------------------------------------------------------------------------------------
+// Narrow ends of the decoder backward as single passes over their wide operand (each was a chain of
+// rank-deficient GEMM launches that re-read it):
+//
+//  * layer 4 (64 -> 1): dZ3 = (goff (x) w4) * lrelu'(H3), d w4 = sum_p goff[p] H3[p,:],
+//    d b4 = sum_p goff[p] — one read of H3.
+//  * the 16 offset-encoding columns of IEF's layer 1 (implicit_net.py:107,139-141). With
+//    enc[p,j] = wenc[j] off[p] + benc[j] every product with `enc` collapses onto two column sums
+//    of dZ1:   A[c] = sum_p dZ1[p,c] off[p],  B[c] = sum_p dZ1[p,c]
+//      d W1[c, D+j] = wenc[j] A[c] + benc[j] B[c]
+//      d wenc[j]    = sum_c W1[c, D+j] A[c] ;  d benc[j] = sum_c W1[c, D+j] B[c]
+//      d off[p]    += dZ1[p,:] . u ,  u[c] = sum_j W1[c, D+j] wenc[j]
+//    — one read of dZ1, and the same pass keeps the running sum S of dZ1 over the passes
+//    (s_mode 1: S = dZ1, 2: S += dZ1) that the query's pass-independent layer-1 operands need.
+//
+// Column sums: per-workgroup partial vectors, summed in a fixed order by lidf_colsum_reduce_kernel
+// (deterministic).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) lidf_l4_backward_kernel(
+    const float* __restrict__ goff, const float* __restrict__ h3, const float* __restrict__ w4,
+    float slope, long long n, long long rows_per_wg, float* __restrict__ dz3,
+    float* __restrict__ part) {
+    __shared__ f32x4w red[4][16];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, c4 = lane & 15;
+    const f32x4w w = *(const f32x4w*)(w4 + 4 * c4);
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+    f32x4w acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    // 16 rows per workgroup step: wavefront `wave` takes rows 4 wave + sub
+    for (long long r = r0 + 4 * wave + sub; r < r1; r += 16) {
+        const float g = goff[r];
+        const f32x4w h = *(const f32x4w*)(h3 + (size_t)r * 64 + 4 * c4);
+        f32x4w d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = __fmul_rn(__fmul_rn(w[i], g), h[i] > 0.f ? 1.f : slope);
+            acc[i] = fmaf(g, h[i], acc[i]);
+        }
+        *(f32x4w*)(dz3 + (size_t)r * 64 + 4 * c4) = d;
+        bsum += g;
+    }
+    // the four row sub-groups of the wavefront, then the four wavefronts, in a fixed order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (sub == 0) red[wave][c4] = acc;
+    if (lane == 0) redb[wave] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        f32x4w s = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s += red[k][threadIdx.x];
+        *(f32x4w*)(part + (size_t)blockIdx.x * 65 + 4 * threadIdx.x) = s;
+    }
+    if (threadIdx.x == 16) part[(size_t)blockIdx.x * 65 + 64] = redb[0] + redb[1] + redb[2] + redb[3];
+}
+
+__global__ void __launch_bounds__(256) lidf_ief_tail_kernel(
+    const float* __restrict__ dz1, const float* __restrict__ off, const float* __restrict__ w1enc,
+    int ld1, const float* __restrict__ wenc, long long n, long long rows_per_wg, int s_mode,
+    float* __restrict__ S, float* __restrict__ goff, float* __restrict__ part) {
+    __shared__ float su[256];
+    __shared__ f32x4w red[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        float u = 0.f;
+        if (w1enc) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u = fmaf(w1enc[(size_t)threadIdx.x * ld1 + j], wenc[j], u);
+        }
+        su[threadIdx.x] = u;
+    }
+    __syncthreads();
+    const f32x4w u4 = *(const f32x4w*)(su + 4 * lane);
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+    f32x4w A = {0.f, 0.f, 0.f, 0.f}, B = {0.f, 0.f, 0.f, 0.f};
+    // one row per wavefront and step (1 KiB), four steps in flight
+    for (long long r = r0 + wave; r < r1; r += 16) {
+        f32x4w v[4], sv[4];
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long rr = r + 4 * j;
+            if (rr < r1) {
+                v[j] = *(const f32x4w*)(dz1 + (size_t)rr * 256 + 4 * lane);
+                o[j] = off ? off[rr] : 0.f;
+                if (s_mode == 2) sv[j] = *(const f32x4w*)(S + (size_t)rr * 256 + 4 * lane);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long rr = r + 4 * j;
+            if (rr >= r1) break;
+            if (s_mode == 1) *(f32x4w*)(S + (size_t)rr * 256 + 4 * lane) = v[j];
+            if (s_mode == 2) *(f32x4w*)(S + (size_t)rr * 256 + 4 * lane) = sv[j] + v[j];
+            if (w1enc) {
+                float d = v[j][0] * u4[0];
+                d = fmaf(v[j][1], u4[1], d);
+                d = fmaf(v[j][2], u4[2], d);
+                d = fmaf(v[j][3], u4[3], d);
+                d = wave_sum(d);
+                if (lane == 0) goff[rr] += d;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[i] = fmaf(v[j][i], o[j], A[i]);
+                    B[i] += v[j][i];
+                }
+            }
+        }
+    }
+    if (!w1enc) return;
+    red[wave][0][lane] = A;
+    red[wave][1][lane] = B;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+        f32x4w s = red[0][which][l];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s += red[k][which][l];
+        *(f32x4w*)(part + (size_t)blockIdx.x * 512 + 256 * which + 4 * l) = s;
+    }
+}
+
+// out[c] = sum over the G partial vectors (stride ncol) in a fixed order: thread (k, c) sums every
+// 4th partial, the four are combined in order.
+__global__ void __launch_bounds__(256) lidf_colsum_reduce_kernel(const float* __restrict__ part, int G,
+                                                                 int ncol, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int k = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s = 0.f;
+    if (c < ncol)
+        for (int g = k; g < G; g += 4) s += part[(size_t)g * ncol + c];
+    red[k][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (k == 0 && c < ncol) out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// d w4 += sums[0:64], d b4 += sums[64]
+__global__ void lidf_l4_finish_kernel(const float* __restrict__ sums, float* __restrict__ dw4,
+                                      float* __restrict__ db4) {
+    const int c = threadIdx.x;
+    if (c < 64) dw4[c] += sums[c];
+    if (c == 64) db4[0] += sums[64];
+}
+
+// sums = [A | B] (256 each): d W1[c, D+j] += wenc[j] A[c] + benc[j] B[c] ; d wenc[j] += W1[:, D+j] . A ;
+// d benc[j] += W1[:, D+j] . B      (one workgroup of 256 threads)
+__global__ void __launch_bounds__(256) lidf_ief_finish_kernel(
+    const float* __restrict__ sums, const float* __restrict__ w1enc, int ld1,
+    const float* __restrict__ wenc, const float* __restrict__ benc, float* __restrict__ dw1enc,
+    float* __restrict__ dwenc, float* __restrict__ dbenc) {
+    __shared__ float sA[256], sB[256];
+    const int c = threadIdx.x;
+    const float A = sums[c], B = sums[256 + c];
+    sA[c] = A;
+    sB[c] = B;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dw1enc[(size_t)c * ld1 + j] += fmaf(wenc[j], A, benc[j] * B);
+    __syncthreads();
+    if (c < 32) {
+        const int j = c & 15;
+        const float* v = c < 16 ? sA : sB;
+        float s = 0.f;
+        for (int i = 0; i < 256; ++i) s = fmaf(w1enc[(size_t)i * ld1 + j], v[i], s);
+        if (c < 16) dwenc[j] += s;
+        else dbenc[j] += s;
+    }
+}
+
+static inline long long narrow_rows_per_wg(long long n, int* G) {
+    long long g = (n + 255) / 256;           // at least 256 rows per workgroup
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    const long long rows = ((n + g - 1) / g + 15) / 16 * 16;
+    *G = (int)((n + rows - 1) / rows);
+    return rows;
+}
+
+// scratch: at least 1024 * 65 + 65 floats
+extern "C" hipError_t lidf_launch_l4_backward(const float* goff, const float* h3, const float* w4,
+                                              float slope, long long n, float* dz3, float* dw4,
+                                              float* db4, float* scratch, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int G;
+    const long long rows = narrow_rows_per_wg(n, &G);
+    float* sums = scratch + (size_t)G * 65;
+    hipLaunchKernelGGL(lidf_l4_backward_kernel, dim3(G), dim3(256), 0, st, goff, h3, w4, slope, n,
+                       rows, dz3, scratch);
+    hipLaunchKernelGGL(lidf_colsum_reduce_kernel, dim3(2), dim3(256), 0, st, scratch, G, 65, sums);
+    hipLaunchKernelGGL(lidf_l4_finish_kernel, dim3(1), dim3(128), 0, st, sums, dw4, db4);
+    return hipGetLastError();
+}
+
+// scratch: at least 1024 * 512 + 512 floats. w1enc = W1 + D (NULL: no offset encoding, only the
+// running sum S is kept); s_mode 0: S untouched.
+extern "C" hipError_t lidf_launch_ief_tail(const float* dz1, const float* off, const float* w1enc,
+                                           int ld1, const float* wenc, const float* benc,
+                                           long long n, int s_mode, float* S, float* goff,
+                                           float* dw1enc, float* dwenc, float* dbenc,
+                                           float* scratch, hipStream_t st) {
+    if (n <= 0 || (!w1enc && s_mode == 0)) return hipSuccess;
+    int G;
+    const long long rows = narrow_rows_per_wg(n, &G);
+    float* sums = scratch + (size_t)G * 512;
+    hipLaunchKernelGGL(lidf_ief_tail_kernel, dim3(G), dim3(256), 0, st, dz1, off, w1enc, ld1, wenc,
+                       n, rows, s_mode, S, goff, scratch);
+    if (w1enc) {
+        hipLaunchKernelGGL(lidf_colsum_reduce_kernel, dim3(8), dim3(256), 0, st, scratch, G, 512, sums);
+        hipLaunchKernelGGL(lidf_ief_finish_kernel, dim3(1), dim3(256), 0, st, sums, w1enc, ld1, wenc,
+                           benc, dw1enc, dwenc, dbenc);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Training path of the query (LIDF.get_embedding, models/pipeline.py:338-420, with gradients):
 // the decoder input rows are materialised — the reference's own formulation — so that the
 // decoders' training path above applies; their gradient is reduced back to the voxel features and
