@@ -59,7 +59,9 @@ hipError_t lidf_launch_rayfeat_backward(const float*, int, const int*, const int
 hipError_t lidf_launch_pe_rows(const int*, const int*, const float*, const float*, const float*, int, int,
                                long long, float*, hipStream_t);
 hipError_t lidf_launch_seg_sum_ray(const float*, int, const int*, long long, float*, hipStream_t);
-hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, long long, float*, hipStream_t);
+hipError_t lidf_launch_seg_sum_idx(const float*, const int*, long long, long long, float*, void*, size_t,
+                                   hipStream_t);
+size_t lidf_seg_sum_idx_ws_bytes(long long, long long);
 hipError_t lidf_launch_pair_pos(const float*, const int*, const float*, const float*, long long, float,
                                 float, float, float, float*, hipStream_t);
 hipError_t lidf_launch_ray_select(const float*, const long long*, long long, long long, float*,
@@ -1317,7 +1319,7 @@ LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, i
 }
 
 struct QTrainWs {
-    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, total;
+    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, seg, seg_bytes, total;
 };
 static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     QTrainWs w;
@@ -1334,6 +1336,8 @@ static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     w.dvox = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
     w.dray = o;   o += align_up((size_t)(R > 0 ? R : 1) * LIDF_H1 * 4, 256);
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
+    w.seg_bytes = lidf_seg_sum_idx_ws_bytes(P, V);
+    w.seg = o;    o += align_up(w.seg_bytes, 256);
     w.total = o;
     return w;
 }
@@ -1501,8 +1505,8 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     }
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
     CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-    CHECK_HIP(hipMemsetAsync(dvox, 0, (size_t)V * LIDF_H1 * 4, st));
-    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, st));
+    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
+                                      w.seg_bytes, st));
     CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
     // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
     CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));

@@ -290,7 +290,7 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
     if (n <= 0 || M <= 0) return hipSuccess;
     // the wide layers: 128 x 256 blocks (float4 loads want lda/ldb*4 within the 32-bit offsets the
     // buffer instructions take, and a slice of rows below 2 GiB)
-    if (M >= 32 && N >= 64) {
+    if (M >= 32 && N >= 16) {
         Wgrad2Args w;
         w.A = A; w.lda = lda; w.M = M; w.B = B; w.ldb = ldb; w.N = N; w.n = n; w.C = C; w.ldc = ldc;
         w.db = db;
@@ -918,54 +918,204 @@ extern "C" hipError_t lidf_launch_seg_sum_ray(const float* S, int F, const int* 
                        pair_off, R, out);
     return hipGetLastError();
 }
-// The same reduction with the table privatised in LDS: a workgroup owns a slice of CW columns of
-// ALL rows of `out` (V x CW floats of LDS) and a block of pairs; LDS float atomics absorb the
-// scatter, one global atomic per table entry flushes it. Used when V x 4 columns fit in 64 KiB.
-template <int CW>
-__global__ void __launch_bounds__(256) lidf_seg_sum_idx_lds_kernel(const float* __restrict__ S,
-                                                                   const int* __restrict__ idx,
-                                                                   long long P, int V,
-                                                                   long long rows_per_wg,
-                                                                   float* __restrict__ out) {
-    extern __shared__ float tab[];  // [V][CW]
-    const int slice = blockIdx.x % (256 / CW);
-    const long long p0 = (long long)(blockIdx.x / (256 / CW)) * rows_per_wg;
-    const long long p1 = p0 + rows_per_wg < P ? p0 + rows_per_wg : P;
-    for (int i = threadIdx.x; i < V * CW; i += 256) tab[i] = 0.f;
+// The deterministic form used when the table has at most 16,384 rows: a stable counting sort of the
+// pairs by their index (per-block histograms -> one exclusive scan over [index][block] -> a
+// single-wavefront placement pass per block that keeps the pair order inside every index), then
+// every index's rows are summed in chunks of SEG_CH gathered rows (a row = 1 KiB contiguous: the
+// column-sliced LDS-atomic form this replaces read 64-byte pieces 1 KiB apart and ran at 0.7 TB/s)
+// and the chunk sums are added up per index in order. out[v,:] is written (zero for an index
+// without pairs), no atomics, no pre-zeroing.
+#define SEG_CH 128
+extern "C" hipError_t lidf_launch_scan(const int*, long long, int*, int*, hipStream_t);
+
+struct SegPlan {
+    long long nblk, per_blk, nscan, max_chunks;
+    size_t hist, scanned, sums, perm, cnt, first, sums2, partial, total;
+};
+static SegPlan seg_plan(long long P, long long V) {
+    SegPlan s;
+    s.nblk = (P + 2047) / 2048;
+    if (s.nblk > 1024) s.nblk = 1024;
+    if (s.nblk < 1) s.nblk = 1;
+    s.per_blk = ((P + s.nblk - 1) / s.nblk + 63) / 64 * 64;
+    if (s.per_blk < 64) s.per_blk = 64;
+    s.nblk = (P + s.per_blk - 1) / s.per_blk;
+    if (s.nblk < 1) s.nblk = 1;
+    s.nscan = V * s.nblk;
+    s.max_chunks = P / SEG_CH + V + 1;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t o = 0;
+    s.hist = o;    o += up((size_t)s.nscan * 4);
+    s.scanned = o; o += up((size_t)(s.nscan + 1) * 4);
+    s.sums = o;    o += up((size_t)(s.nscan / 1024 + 2) * 4);
+    s.perm = o;    o += up((size_t)(P > 0 ? P : 1) * 4);
+    s.cnt = o;     o += up((size_t)(V + 1) * 4);
+    s.first = o;   o += up((size_t)(V + 2) * 4);
+    s.sums2 = o;   o += up((size_t)(V / 1024 + 2) * 4);
+    s.partial = o; o += up((size_t)s.max_chunks * 256 * 4);
+    s.total = o;
+    return s;
+}
+extern "C" size_t lidf_seg_sum_idx_ws_bytes(long long P, long long V) {
+    if (V > 16384 || V <= 0) return 0;
+    return seg_plan(P, V).total;
+}
+
+__global__ void __launch_bounds__(256) lidf_seg_hist_kernel(const int* __restrict__ idx, long long P,
+                                                            int V, long long per_blk, int nblk,
+                                                            int* __restrict__ histT) {
+    extern __shared__ int s_cnt[];
+    for (int i = threadIdx.x; i < V; i += 256) s_cnt[i] = 0;
     __syncthreads();
-    // thread -> (row within a group of 256/CW rows, column of the slice): CW consecutive lanes read
-    // one contiguous CW-float piece of a row
-    const int c = threadIdx.x % CW, rr = threadIdx.x / CW;
-    for (long long p = p0 + rr; p < p1; p += 256 / CW)
-        atomicAdd(tab + idx[p] * CW + c, S[(size_t)p * 256 + slice * CW + c]);
+    const long long p0 = blockIdx.x * per_blk;
+    const long long p1 = p0 + per_blk < P ? p0 + per_blk : P;
+    for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int v = idx[p];
+        if (v >= 0 && v < V) atomicAdd(s_cnt + v, 1);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < V * CW; i += 256) {
-        const float v = tab[i];
-        if (v != 0.f) atomicAdd(out + (size_t)(i / CW) * 256 + slice * CW + i % CW, v);
+    for (int i = threadIdx.x; i < V; i += 256) histT[(size_t)i * nblk + blockIdx.x] = s_cnt[i];
+}
+
+// one wavefront per block of pairs: pairs in order, 64 at a time; lanes with the same index find
+// each other through `nbits` ballots, rank = earlier lanes of the group, the group's first lane
+// advances the index's cursor
+__global__ void __launch_bounds__(64) lidf_seg_place_kernel(const int* __restrict__ idx, long long P,
+                                                            int V, int nbits, long long per_blk,
+                                                            int nblk, const int* __restrict__ scanned,
+                                                            int* __restrict__ perm) {
+    extern __shared__ int s_cur[];
+    for (int i = threadIdx.x; i < V; i += 64) s_cur[i] = scanned[(size_t)i * nblk + blockIdx.x];
+    __syncthreads();
+    const long long p0 = blockIdx.x * per_blk;
+    const long long p1 = p0 + per_blk < P ? p0 + per_blk : P;
+    const int lane = threadIdx.x;
+    for (long long b = p0; b < p1; b += 64) {
+        const long long p = b + lane;
+        int v = p < p1 ? idx[p] : -1;
+        const bool ok = v >= 0 && v < V;
+        if (!ok) v = 0;
+        unsigned long long m = __ballot(ok);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = (v >> bit) & 1;
+            const unsigned long long bb = __ballot(ok && one);
+            m &= one ? bb : ~bb;
+        }
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        int base = 0;
+        if (ok) base = s_cur[v];
+        __syncthreads();
+        if (ok) {
+            perm[base + rank] = (int)p;
+            if (rank == 0) s_cur[v] = base + __popcll(m);
+        }
+        __syncthreads();
     }
 }
 
+__global__ void lidf_seg_chunks_kernel(const int* __restrict__ scanned, int V, int nblk, long long P,
+                                       int* __restrict__ cnt) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const long long beg = scanned[(size_t)v * nblk];
+    const long long end = scanned[(size_t)(v + 1) * nblk];   // v = V-1: the total
+    cnt[v] = (int)((end - beg + SEG_CH - 1) / SEG_CH);
+}
+
+__global__ void __launch_bounds__(256) lidf_seg_chunk_sum_kernel(
+    const float* __restrict__ S, const int* __restrict__ perm, const int* __restrict__ scanned,
+    const int* __restrict__ first, int V, int nblk, float* __restrict__ partial) {
+    __shared__ f32x4 red[4][64];
+    const int c = blockIdx.x;
+    if (c >= first[V]) return;
+    // last index with first[v] <= c (indices without pairs share their successor's value)
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    const int v = lo;
+    const long long beg = (long long)scanned[(size_t)v * nblk] + (long long)(c - first[v]) * SEG_CH;
+    long long end = scanned[(size_t)(v + 1) * nblk];
+    if (end > beg + SEG_CH) end = beg + SEG_CH;
+    const int rl = threadIdx.x >> 6, c4 = threadIdx.x & 63;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = beg + rl; i < end; i += 16) {
+        f32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long ii = i + 4 * j;
+            x[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ii < end) x[j] = *(const f32x4*)(S + (size_t)perm[ii] * 256 + 4 * c4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += x[j];
+    }
+    red[rl][c4] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        f32x4 s = red[0][c4];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s += red[k][c4];
+        *(f32x4*)(partial + (size_t)c * 256 + 4 * c4) = s;
+    }
+}
+
+__global__ void __launch_bounds__(64) lidf_seg_final_kernel(const float* __restrict__ partial,
+                                                            const int* __restrict__ first,
+                                                            float* __restrict__ out) {
+    const int v = blockIdx.x, c4 = threadIdx.x;
+    const int c0 = first[v], c1 = first[v + 1];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+        f32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = *(const f32x4*)(partial + (size_t)(c + j) * 256 + 4 * c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += x[j];
+    }
+    for (; c < c1; ++c) s += *(const f32x4*)(partial + (size_t)c * 256 + 4 * c4);
+    *(f32x4*)(out + (size_t)v * 256 + 4 * c4) = s;
+}
+
+// out[v, :] = sum of S[p, :] over the pairs with idx[p] == v (F = 256). With a workspace of
+// lidf_seg_sum_idx_ws_bytes(P, V) bytes: the deterministic sorted form; without (V > 16,384): `out`
+// is zeroed and the run-walking kernel adds with atomics.
 extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, long long P, long long V,
-                                              float* out, hipStream_t st) {
-    if (P <= 0) return hipSuccess;
-    int cw = 0;
-    for (int w = 32; w >= 4; w >>= 1)
-        if ((long long)V * w * 4 <= 65536) { cw = w; break; }
-    if (cw == 0) {
+                                              float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (V <= 0) return hipSuccess;
+    const size_t need = lidf_seg_sum_idx_ws_bytes(P, V);
+    if (P <= 0 || need == 0 || !ws || ws_bytes < need) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)V * 256 * 4, st);
+        if (e != hipSuccess || P <= 0) return e;
         hipLaunchKernelGGL(lidf_seg_sum_idx_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
                            st, S, idx, P, out);
         return hipGetLastError();
     }
-    const long long rows_per_wg = 8192;
-    const long long blocks = ((P + rows_per_wg - 1) / rows_per_wg) * (256 / cw);
-    const size_t lds = (size_t)V * cw * 4;
-    dim3 g((unsigned)blocks), b(256);
-    switch (cw) {
-        case 32: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<32>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
-        case 16: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<16>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
-        case 8: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<8>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
-        default: hipLaunchKernelGGL(lidf_seg_sum_idx_lds_kernel<4>, g, b, lds, st, S, idx, P, (int)V, rows_per_wg, out); break;
-    }
+    const SegPlan s = seg_plan(P, V);
+    char* w = (char*)ws;
+    int* hist = (int*)(w + s.hist);
+    int* scanned = (int*)(w + s.scanned);
+    int* perm = (int*)(w + s.perm);
+    int* cnt = (int*)(w + s.cnt);
+    int* first = (int*)(w + s.first);
+    float* partial = (float*)(w + s.partial);
+    int nbits = 0;
+    while ((1LL << nbits) < V) ++nbits;
+    hipLaunchKernelGGL(lidf_seg_hist_kernel, dim3((unsigned)s.nblk), dim3(256), (size_t)V * 4, st, idx,
+                       P, (int)V, s.per_blk, (int)s.nblk, hist);
+    hipError_t e = lidf_launch_scan(hist, s.nscan, scanned, (int*)(w + s.sums), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lidf_seg_place_kernel, dim3((unsigned)s.nblk), dim3(64), (size_t)V * 4, st, idx,
+                       P, (int)V, nbits, s.per_blk, (int)s.nblk, scanned, perm);
+    hipLaunchKernelGGL(lidf_seg_chunks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
+                       scanned, (int)V, (int)s.nblk, P, cnt);
+    e = lidf_launch_scan(cnt, V, first, (int*)(w + s.sums2), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lidf_seg_chunk_sum_kernel, dim3((unsigned)s.max_chunks), dim3(256), 0, st, S,
+                       perm, scanned, first, (int)V, (int)s.nblk, partial);
+    hipLaunchKernelGGL(lidf_seg_final_kernel, dim3((unsigned)V), dim3(64), 0, st, partial, first, out);
     return hipGetLastError();
 }
 

@@ -158,3 +158,49 @@ def test_frozen_parameters_and_inplace_update_check(cuda):
         m.linear_3.weight.mul_(1.5)
     with pytest.raises(RuntimeError):
         y.sum().backward()
+
+
+def test_query_gradients_larger_scene_and_run_to_run_identical(cuda):
+    """49k pairs over several sort blocks of the per-voxel reduction (stable counting sort + chunk
+    sums in a fixed order) and several row slices of the weight-gradient kernels: gradients against
+    oracle autograd, and bit-identical between two runs for vox_feat and every parameter."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(1, 48, 64, 16, seed=91, ragged=True)
+    R, P, D = scene["R"], scene["P"], scene["D"]
+    gen = torch.Generator().manual_seed(92)
+    w = {"prob": torch.randn(P, generator=gen), "off": torch.randn(P, generator=gen),
+         "pos": torch.randn(R, 3, generator=gen)}
+    kw = dict(offset_range=(0.0, 1.0), part_size=0.25)
+    pp = {k: v.clone().requires_grad_(True) for k, v in scene["prob_p"].items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in scene["off_p"].items()}
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"], vf,
+                    pp, po, fast_roi=True, **kw)
+    _loss(ref, w).backward()
+    s = to_dev(scene, cuda)
+    wd = {k: v.to(cuda) for k, v in w.items()}
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
+    runs = []
+    for _ in range(2):
+        prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+        off = make_module("IEF", scene["off_p"], D, cuda).train()
+        vfd = s["vox_feat"].clone().requires_grad_(True)
+        out = lidf_query_train(*args, s["feat_grid"], vfd, prob, off, **kw)
+        _loss(out, wd).backward()
+        g = {"vox_feat": vfd.grad.clone()}
+        g.update({"prob." + k: v.grad.clone() for k, v in prob.named_parameters()})
+        g.update({"off." + k: v.grad.clone() for k, v in off.named_parameters()})
+        runs.append(g)
+    differ = [(k, (runs[0][k] - runs[1][k]).abs().max().item()) for k in runs[0]
+              if not torch.equal(runs[0][k], runs[1][k])]
+    assert not differ, differ
+
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(runs[0]["vox_feat"].cpu(), vf.grad, "vox_feat")
+    for k, v in pp.items():
+        close(runs[0]["prob." + k].cpu(), v.grad, "prob." + k)
+    for k, v in po.items():
+        close(runs[0]["off." + k].cpu(), v.grad, "off." + k)
