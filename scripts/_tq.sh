@@ -1,10 +1,9 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python /root/repo/bench.py --workload train-query --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python /root/repo/bench.py --workload ${1:-train-query} --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
 python - <<PY
 import sqlite3,glob
 db=glob.glob("/tmp/pt/**/*.db",recursive=True)[0]
 rows=list(sqlite3.connect(db).execute("select name,start,duration,grid_x from kernels order by start"))
-# last step: take the last third
 n=len(rows)//3
 t0=rows[-n][1]
 for r in rows[-n:]:
