@@ -1079,8 +1079,38 @@ LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
     return (size_t)n * ((size_t)n_pass * ACT_ROW_FLOATS + 1);  // + the pre-activation output
 }
 
+// ---- training forward as ONE launch per decoder: the register-chained rows kernel in the mode that
+// keeps H1 | H2 | H3 | offset-in of every pass (LIDF_MODE_TRAIN, lidf_points.hip) -----------------
+static size_t chain_stream_bytes(int D) {
+    L1Map m = rows_map(D, 0, 0, 0, 1);
+    return align_up((size_t)lidf_make_layout(1, LIDF_MODE_ROWS, m).total * 4, 256) +
+           align_up(LIDF_AUX_FLOATS * 4, 256);
+}
+// X [n, m.D] (row stride ldx) are the layer-1 operand rows named by `m`; voxpart / raypart (or NULL)
+// are added through pair_vox / pair_ray. passes: npass x ACT_ROW_FLOATS x n, pre [n], out [n].
+static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, const float* X,
+                           int64_t ldx, int64_t n, const int32_t* pair_vox, const int32_t* pair_ray,
+                           const float* voxpart, const float* raypart, float* passes, float* pre,
+                           float* out, char* sbuf, int cus, hipStream_t st) {
+    const StreamLayout lay = lidf_make_layout(1, LIDF_MODE_ROWS, m);
+    float* stream_buf = (float*)sbuf;
+    float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
+    const NetW nw = to_netw(dec, dcore);
+    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, aux, st));
+    PointsArgs a = {};
+    a.stream = stream_buf; a.aux = aux; a.nets = 1;
+    a.l1_quads = lay.l1_quads; a.net_quads = lay.net_quads; a.n = n;
+    fill_net_args(a, 0, dec, out, 0);
+    a.X = X; a.ldx = ldx; a.D = m.D; a.KQ1 = m.KQ1; a.has_bias = m.add_bias;
+    a.pair_vox = pair_vox; a.pair_ray = pair_ray; a.voxpart = voxpart; a.raypart = raypart;
+    a.tr_passes = passes; a.tr_pass_floats = (long long)n * ACT_ROW_FLOATS; a.tr_pre = pre;
+    const long long ntile = (n + 127) / 128;
+    CHECK_HIP(lidf_launch_points(LIDF_MODE_TRAIN, a, (int)(ntile < cus ? ntile : cus), st));
+    return LIDF_OK;
+}
+
 struct TrainWs {
-    size_t stream, dz1, dz2, dz3, goff, enc, denc, wg, total;
+    size_t stream, dz1, dz2, dz3, goff, enc, denc, wg, chain, total;
 };
 static TrainWs train_ws(int64_t n, int d) {
     TrainWs w;
@@ -1095,6 +1125,7 @@ static TrainWs train_ws(int64_t n, int d) {
     w.enc = o;    o += align_up(N * 16 * 4, 256);
     w.denc = o;   o += align_up(N * 16 * 4, 256);
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
+    w.chain = o;  o += chain_stream_bytes(d);
     w.total = o;
     return w;
 }
@@ -1119,35 +1150,12 @@ LIDF_API int lidf_decoder_forward_train_f32(const float* inp, int64_t n, int32_t
     if ((rc = cu_count(&cus))) return rc;
     const int npass = dec->is_ief ? dec->n_iter : 1;
     const int ld1 = d + (dec->is_ief ? 16 : 0);
-    float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;  // running offset / final pre-activation
-    CHECK_HIP(lidf_launch_fill(pre, n, dec->is_ief ? dec->init_offset : 0.f, st));
-    for (int k = 0; k < npass; ++k) {
-        float* h1 = act + (size_t)k * n * ACT_ROW_FLOATS;
-        float* h2 = h1 + (size_t)n * LIDF_H1;
-        float* h3 = h2 + (size_t)n * LIDF_H2;
-        float* offin = h3 + (size_t)n * LIDF_H3;
-        if (dec->is_ief) CHECK_HIP(hipMemcpyAsync(offin, pre, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-        LinEx L = {};
-        L.n = n; L.relu = 1; L.slope = 0.02f;
-        // layer 1: [inp | enc(off)] W1^T + b1 = inp W1x^T + (b1 + c) + u * off
-        L.w = dec->w1; L.b = dec->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = d;
-        L.ief = dec->is_ief ? dec : nullptr; L.X = inp; L.ldx = ld_inp;
-        L.xoff = dec->is_ief ? offin : nullptr; L.out = h1; L.ld_out = LIDF_H1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L.ief = nullptr; L.xoff = nullptr;
-        L.w = dec->w2; L.b = dec->b2; L.ldw = LIDF_H1; L.nout = LIDF_H2; L.k = LIDF_H1;
-        L.X = h1; L.ldx = LIDF_H1; L.out = h2; L.ld_out = LIDF_H2;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L.w = dec->w3; L.b = dec->b3; L.ldw = LIDF_H2; L.nout = LIDF_H3; L.k = LIDF_H2;
-        L.X = h2; L.ldx = LIDF_H2; L.out = h3; L.ld_out = LIDF_H3;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        // layer 4 adds straight into the running offset (IMNet: pre starts at 0)
-        L.relu = 0;
-        L.w = dec->w4; L.b = dec->b4; L.ldw = LIDF_H3; L.nout = 1; L.k = LIDF_H3;
-        L.X = h3; L.ldx = LIDF_H3; L.out = pre; L.ld_out = 1; L.accumulate = 1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    }
-    CHECK_HIP(lidf_launch_out_act(pre, n, dec->use_sigmoid, out, nullptr, nullptr, st));
+    float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;  // final pre-activation
+    (void)ld1; (void)sbuf;
+    // [inp | enc(off)] W1^T + b1 = inp W1x^T + (b1 + c) + u * off, then the chain, in registers
+    if ((rc = run_chain_train(dec, d, rows_map(d, 0, 0, 0, 1), inp, ld_inp, n, nullptr, nullptr, nullptr,
+                              nullptr, act, pre, out, (char*)workspace + w.chain, cus, st)))
+        return rc;
     return LIDF_OK;
 }
 
@@ -1319,7 +1327,7 @@ LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, i
 }
 
 struct QTrainWs {
-    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, seg, seg_bytes, total;
+    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, seg, seg_bytes, chain, total;
 };
 static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     QTrainWs w;
@@ -1338,6 +1346,7 @@ static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.seg_bytes = lidf_seg_sum_idx_ws_bytes(P, V);
     w.seg = o;    o += align_up(w.seg_bytes, 256);
+    w.chain = o;  o += chain_stream_bytes(2 * (3 + 6 * 16));
     w.total = o;
     return w;
 }
@@ -1388,36 +1397,11 @@ LIDF_API int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* q, f
     L.w = dec->w1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.c0 = 128; L.k1 = Ed; L.c1 = 256 + E2;
     L.X = q->rayfeat; L.ldx = 128 + Ed; L.n = R; L.out = raypart; L.ld_out = LIDF_H1;
     if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    CHECK_HIP(lidf_launch_fill(pre, P, dec->is_ief ? dec->init_offset : 0.f, st));
-    for (int k = 0; k < npass; ++k) {
-        float* h1 = passes + (size_t)k * qact_pass(P);
-        float* h2 = h1 + (size_t)P * LIDF_H1;
-        float* h3 = h2 + (size_t)P * LIDF_H2;
-        float* offin = h3 + (size_t)P * LIDF_H3;
-        if (dec->is_ief) CHECK_HIP(hipMemcpyAsync(offin, pre, (size_t)P * 4, hipMemcpyDeviceToDevice, st));
-        L = {};
-        L.n = P; L.relu = 1; L.slope = 0.02f;
-        // layer 1: W1[:, enter|leave] PE + voxpart[voxel] + raypart[ray] (+ u * off)
-        L.w = dec->w1 + 256; L.ldw = ld1; L.nout = LIDF_H1; L.k = E2; L.dcore = D - 256;
-        L.ief = dec->is_ief ? dec : nullptr; L.X = q->pe; L.ldx = E2;
-        L.xoff = dec->is_ief ? offin : nullptr;
-        L.addrows = voxpart; L.addidx = q->pair_vox; L.addrows2 = raypart; L.addidx2 = q->pair_ray;
-        L.out = h1; L.ld_out = LIDF_H1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L = {};
-        L.n = P; L.relu = 1; L.slope = 0.02f;
-        L.w = dec->w2; L.b = dec->b2; L.ldw = LIDF_H1; L.nout = LIDF_H2; L.k = LIDF_H1;
-        L.X = h1; L.ldx = LIDF_H1; L.out = h2; L.ld_out = LIDF_H2;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L.w = dec->w3; L.b = dec->b3; L.ldw = LIDF_H2; L.nout = LIDF_H3; L.k = LIDF_H2;
-        L.X = h2; L.ldx = LIDF_H2; L.out = h3; L.ld_out = LIDF_H3;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L.relu = 0;
-        L.w = dec->w4; L.b = dec->b4; L.ldw = LIDF_H3; L.nout = 1; L.k = LIDF_H3;
-        L.X = h3; L.ldx = LIDF_H3; L.out = pre; L.ld_out = 1; L.accumulate = 1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    }
-    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, out, nullptr, nullptr, st));
+    // layer 1 = W1[:, enter|leave] PE + voxpart[voxel] + raypart[ray] (+ u * off), then the chain,
+    // in registers; every pass's H1 | H2 | H3 | offset-in is kept
+    if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, E2, P, q->pair_vox, q->pair_ray,
+                              voxpart, raypart, passes, pre, out, (char*)workspace + w.chain, cus, st)))
+        return rc;
     return LIDF_OK;
 }
 

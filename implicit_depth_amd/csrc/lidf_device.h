@@ -47,7 +47,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 #define LIDF_MAX_L_FUSED 16 // octaves of the in-kernel positional encoding
 
 enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_LINEAR = 3,
-       LIDF_MODE_FUSED_H = 4 };  // split-f16 stream of lidf_points_h.hip
+       LIDF_MODE_FUSED_H = 4,   // split-f16 stream of lidf_points_h.hip
+       LIDF_MODE_TRAIN = 5 };   // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
 
 // One decoder's parameters as the packer sees them.
 struct NetW {
@@ -139,6 +140,13 @@ struct PointsArgs {
     float r0, rscale, sqrt3, part_size;
     float* pair_pred_pos;   // [n,3]
     int* tile_counter;      // split-f16 kernel: dynamic tile hand-out (zeroed by its packer)
+    // LIDF_MODE_TRAIN (one net): X = the per-pair layer-1 operand rows, voxpart[pair_vox] and
+    // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in at
+    // tr_passes + k * tr_pass_floats ([n,256] | [n,128] | [n,64] | [n]), the pre-activation
+    // output goes to tr_pre [n]
+    float* tr_passes;
+    long long tr_pass_floats;
+    float* tr_pre;
 };
 
 // Arguments of the generic linear-layer kernel (lidf_linear.hip): out = epilogue(X W^T + b).

@@ -255,7 +255,24 @@ __device__ __forceinline__ void dma_slot(const char* vox_rows, const unsigned vp
         default: break;
     }
 }
-template <bool PF>
+// ST: the activations of the pass are kept (training forward): tile by tile, as each is complete,
+// to row pointers that already carry the lane's 4h column offset.
+struct TrainRow {
+    float* h1;
+    float* h2;
+    float* h3;
+};
+template <int W>
+__device__ __forceinline__ void store_tile(float* row, const int t, const f32x16& v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[4 * g + i];
+        *(f32x4*)(row + 32 * t + 8 * g) = o;
+    }
+}
+template <bool PF, bool ST = false>
 __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, const int vq,
                                               f32x4 (&ring)[LIDF_RING], const int pass_base,
                                               const int wrap_base, f32x16 (&base)[8],
@@ -263,7 +280,8 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                                               const float* __restrict__ ax,
                                               const char* __restrict__ vox_rows,
                                               const unsigned vp_off, const unsigned lds_addr,
-                                              const lds_float* lds_wave, const int lane
+                                              const lds_float* lds_wave, const int lane,
+                                              const TrainRow tr
 #ifdef LIDF_PROFILE
                                               , long long& prof_t, long long (&prof_acc)[8]
 #endif
@@ -318,6 +336,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
             u1 = a;
             H1[0] = MFMA(u0[0], ob, base[0]);
             lrelu_part<0, 16>(H1[0]);
+            if (ST) store_tile<0>(tr.h1, 0, H1[0]);
         } else if (s < S_L3) {
             // ---- layer 2, k-quad major: all four output tiles advance together, so a layer-1
             // tile is produced right before its four k-quads and is dead after them
@@ -326,6 +345,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 const int T = kq / 4 + 1;   // needed from the next step on
                 H1[T] = MFMA(T < 4 ? u0[T & 3] : u1[T & 3], ob, base[T]);
                 lrelu_part<0, 16>(H1[T]);
+                if (ST) store_tile<0>(tr.h1, T, H1[T]);
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -337,7 +357,10 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 else if (k == LIDF_H1 / 2)
                     H2[t] = MFMA(a[jj], one_b, H2[t]);
             }
-            if (kq == LIDF_L2_QUADS - 1) lrelu_part<0, 16>(H2[t]);   // tile complete (bias quad)
+            if (kq == LIDF_L2_QUADS - 1) {
+                lrelu_part<0, 16>(H2[t]);   // tile complete (bias quad)
+                if (ST) store_tile<0>(tr.h2, t, H2[t]);
+            }
         } else {
             // ---- layer 3, k-quad major
             const int kq = (s - S_L3) / 2, t = (s - S_L3) % 2;
@@ -357,7 +380,10 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 else if (k == LIDF_H2 / 2)
                     H3[t] = MFMA(a[jj], one_b, H3[t]);
             }
-            if (kq == LIDF_L3_QUADS - 1 && t == 0) lrelu_part<0, 16>(H3[0]);
+            if (kq == LIDF_L3_QUADS - 1 && t == 0) {
+                lrelu_part<0, 16>(H3[0]);
+                if (ST) store_tile<0>(tr.h3, 0, H3[0]);
+            }
         }
         SCHED_FENCE();
 #ifdef LIDF_PROFILE
@@ -367,6 +393,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
 #endif
     }
     lrelu_part<0, 16>(H3[1]);
+    if (ST) store_tile<0>(tr.h3, 1, H3[1]);
     // layer 4: 64 -> 1 on the VALU (4 partial sums), halves combined with one cross-half shuffle
     float ys[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -616,13 +643,13 @@ __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
             const int npass = a.npass[net];
             for (int pass = 0; pass + 1 < npass; ++pass)
                 val += decoder_pass<false>(srs, vq, ring, pass_base, pass_base, base, val, h, one_b,
-                                           ax, nullptr, 0u, 0u, nullptr, 0
+                                           ax, nullptr, 0u, 0u, nullptr, 0, TrainRow{}
 #ifdef LIDF_PROFILE
                                            , prof_t, prof_acc
 #endif
                                            );
             val += decoder_pass<true>(srs, vq, ring, pass_base, next_blk, base, val, h, one_b, ax,
-                                      (const char*)a.voxpart, vp_off, lds_addr, lds_wave, lane
+                                      (const char*)a.voxpart, vp_off, lds_addr, lds_wave, lane, TrainRow{}
 #ifdef LIDF_PROFILE
                                       , prof_t, prof_acc
 #endif
@@ -725,7 +752,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
             // So the operands of up to 25 k-quads (100 VGPRs, free during layer 1) are fetched
             // in one burst per chunk and the iterations run with only the L2-resident ring in
             // the queue.
-            constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : 8;  // L1ONLY: keep 2 waves/SIMD
+            constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : MODE == LIDF_MODE_TRAIN ? 13 : 8;  // L1ONLY: keep 2 waves/SIMD
             for (int k0 = 0; k0 < a.KQ1; k0 += XCH) {
                 float xb[XCH][4];
 #pragma unroll
@@ -757,6 +784,33 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                 }
             }
 
+            if (MODE == LIDF_MODE_TRAIN && a.voxpart) {
+                // + voxpart[pair_vox] + raypart[pair_ray]: the rows of tile t+1 load while tile t adds
+                const float* vp = a.voxpart + (size_t)a.pair_vox[pc] * 256 + 4 * h;
+                const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
+                f32x4 gv[2][8];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    gv[0][g] = *(const f32x4*)(vp + 8 * g);
+                    gv[0][4 + g] = *(const f32x4*)(rp + 8 * g);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t + 1 < 8) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            gv[(t + 1) & 1][g] = *(const f32x4*)(vp + 32 * (t + 1) + 8 * g);
+                            gv[(t + 1) & 1][4 + g] = *(const f32x4*)(rp + 32 * (t + 1) + 8 * g);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            base[t][4 * g + i] = (base[t][4 * g + i] + gv[t & 1][g][i]) + gv[t & 1][4 + g][i];
+                    }
+                }
+            }
             if constexpr (MODE == LIDF_MODE_L1ONLY) {
                 if (valid) {
                     float* ob = a.out_base + ((size_t)p * a.nets + net) * 256 + 4 * h;
@@ -779,17 +833,28 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                 const int npass = a.npass[net];
                 for (int pass = 0; pass < npass; ++pass) {
                     const int wrap_base = pass + 1 < npass ? pass_base : next_blk;
-                    val += decoder_pass<false>(srs, vq, ring, pass_base, wrap_base, base, val, h,
-                                               one_b, ax, nullptr, 0u, 0u, nullptr, 0
+                    TrainRow tr = {};
+                    if constexpr (MODE == LIDF_MODE_TRAIN) {
+                        // rows beyond n repeat row n-1 (same operands, same values): no guard needed
+                        float* pk = a.tr_passes + (size_t)pass * a.tr_pass_floats;
+                        tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
+                        tr.h2 = pk + (size_t)a.n * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
+                        tr.h3 = pk + (size_t)a.n * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                        if (valid && h == 0) pk[(size_t)a.n * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = val;
+                    }
+                    val += decoder_pass<false, MODE == LIDF_MODE_TRAIN>(
+                        srs, vq, ring, pass_base, wrap_base, base, val, h, one_b, ax, nullptr, 0u, 0u,
+                        nullptr, 0, tr
 #ifdef LIDF_PROFILE
-                                               , prof_t, prof_acc
+                        , prof_t, prof_acc
 #endif
-                                               );
+                        );
                 }
                 // ---------------- outputs ----------------
                 if (valid && h == 0) {
                     const float o = out_act(val, a.sigmoid[net]);
                     if (a.out[net]) a.out[net][p] = o;
+                    if constexpr (MODE == LIDF_MODE_TRAIN) a.tr_pre[p] = val;
                 }
             }
         }
@@ -956,5 +1021,6 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
     }
     if (mode == LIDF_MODE_ROWS) return launch_points<LIDF_MODE_ROWS>(a, grid, st);
     if (mode == LIDF_MODE_L1ONLY) return launch_points<LIDF_MODE_L1ONLY>(a, grid, st);
+    if (mode == LIDF_MODE_TRAIN) return launch_points<LIDF_MODE_TRAIN>(a, grid, st);
     return hipErrorInvalidValue;
 }
