@@ -138,6 +138,9 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 #define LDX4(rs, voff, soff) \
     __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
 
+// TWO: the block has a second half of 128 columns (N - n0 > 128); without it the four accumulator
+// tiles of that half and their matrix instructions are left out (N = 102 or 128 operands).
+template <bool TWO>
 __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
     // 8 rows of A (128 columns) and of B (256 columns) per step, staged once per workgroup through
     // LDS (double-buffered): the four wavefronts read the same B rows and the same A float4
@@ -156,47 +159,51 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         (void*)(a.B + (size_t)r0 * a.ldb), 0, (int)((size_t)nrows * a.ldb * 4), 0x00020000);
     // staging role of this thread: row tr (0..7) of the step, float4 column tc (A), tc and tc+32 (B)
     const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
-    const bool second = n0 + 128 < a.N;
+    const bool second = TWO && n0 + 128 < a.N;
     const int ga = (int)((tr * a.lda + m0 + 4 * tc) * 4);
     const int gb0 = (int)((tr * a.ldb + n0 + 4 * tc) * 4);
     const int gb1 = second ? gb0 + 512 : 0x7ffffff0;
     const int sa = (int)(a.lda * 32), sbb = (int)(a.ldb * 32);  // eight rows
-    f32x16 acc[8];
+    constexpr int NT = TWO ? 8 : 4;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     }
     f32x4w asum = {0.f, 0.f, 0.f, 0.f};
     const int nstep = (nrows + 7) / 8;
-    f32x4w ga4 = LDX4(ra, ga, 0), gb4 = LDX4(rb, gb0, 0), gc4 = LDX4(rb, gb1, 0);
+    f32x4w ga4 = LDX4(ra, ga, 0), gb4 = LDX4(rb, gb0, 0), gc4 = {0.f, 0.f, 0.f, 0.f};
+    if (TWO) gc4 = LDX4(rb, gb1, 0);
     sA[0][tr][tc] = ga4;
     sB[0][tr][tc] = gb4;
-    sB[0][tr][32 + tc] = gc4;
+    if (TWO) sB[0][tr][32 + tc] = gc4;
     __syncthreads();
     for (int st = 0; st < nstep; ++st) {
         const int cur = st & 1;
         if (st + 1 < nstep) {   // next step's rows: global -> registers while this step multiplies
             ga4 = LDX4(ra, ga, (st + 1) * sa);
             gb4 = LDX4(rb, gb0, (st + 1) * sbb);
-            gc4 = LDX4(rb, gb1, (st + 1) * sbb);
+            if (TWO) gc4 = LDX4(rb, gb1, (st + 1) * sbb);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const f32x4w a4 = sA[cur][2 * u + h][c];
-            const f32x4w b0 = sB[cur][2 * u + h][c], b1 = sB[cur][2 * u + h][32 + c];
+            const f32x4w b0 = sB[cur][2 * u + h][c];
+            f32x4w b1 = b0;
+            if (TWO) b1 = sB[cur][2 * u + h][32 + c];
             const float aw = wave == 0 ? a4[0] : wave == 1 ? a4[1] : wave == 2 ? a4[2] : a4[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[e] = MFMA(aw, b0[e], acc[e]);
-                acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
+                if constexpr (TWO) acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
             }
             asum += a4;
         }
         if (st + 1 < nstep) {
             sA[cur ^ 1][tr][tc] = ga4;
             sB[cur ^ 1][tr][tc] = gb4;
-            sB[cur ^ 1][tr][32 + tc] = gc4;
+            if (TWO) sB[cur ^ 1][tr][32 + tc] = gc4;
         }
         __syncthreads();
     }
@@ -207,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         // lidf_wgrad_reduce_kernel in a fixed order
         float* slab = a.part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 256 + 128);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NT; ++e) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int ml = 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + wave;
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         return;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < NT; ++e) {
         const int col = n0 + 128 * (e >> 2) + 4 * c + (e & 3);
         if (col >= a.N) continue;
 #pragma unroll
@@ -307,7 +314,10 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
         const size_t need = (size_t)sp * mb * nb * (128 * 256 + 128);
         w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats) ? g_wgrad_scratch : nullptr;
         if (slice_bytes < 0x7fffffffULL) {
-            hipLaunchKernelGGL(lidf_wgrad2_kernel, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+            if (N - (nb - 1) * 256 > 128 || nb > 1)
+                hipLaunchKernelGGL(lidf_wgrad2_kernel<true>, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+            else
+                hipLaunchKernelGGL(lidf_wgrad2_kernel<false>, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
             if (w.part)
                 hipLaunchKernelGGL(lidf_wgrad_reduce_kernel, dim3(((128 * 256 + 128) / 4 + 31) / 32, mb * nb),
                                    dim3(256), 0, st, w.part, (int)sp, mb, nb, M, N, C, ldc, db);
