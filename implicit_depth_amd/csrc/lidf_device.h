@@ -177,3 +177,28 @@ struct LinearArgs {
     const int* addidx2;
     int ld_add2;
 };
+
+#ifdef __HIPCC__
+// sin/cos of x*2^o for the positional encoding (implicit_net.py:30-32: freq bands are exact powers
+// of two). x/(2 pi) is formed once as hi + lo (fma residual + low part of 1/(2 pi)); scaling by
+// 2^o and v_fract are exact, so the argument handed to v_sin_f32 / v_cos_f32 (which take
+// revolutions) carries no octave-dependent error: |err| <= 4.2e-7 at every octave, measured
+// against double precision (scripts/hwsin_test.hip). 5 VALU per (coordinate, octave).
+struct Rev {
+    float hi, lo;
+};
+__device__ __forceinline__ Rev to_rev(float x) {
+    const float C_HI = 0.15915493667125702f;   // fl(1/(2 pi))
+    const float C_LO = 6.4206383e-09f;         // 1/(2 pi) - C_HI
+    Rev r;
+    r.hi = x * C_HI;
+    r.lo = fmaf(x, C_HI, -r.hi) + x * C_LO;
+    return r;
+}
+__device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, float& c) {
+    const float t = __builtin_amdgcn_fractf(r.hi * sc) + r.lo * sc;
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
+}
+
+#endif  // __HIPCC__

@@ -735,6 +735,80 @@ __global__ void __launch_bounds__(256) lidf_rows_vox_backward_kernel(
     if (g != 0.f) atomicAdd(d_vox_feat + (size_t)pair_vox[p] * 128 + j, g);
 }
 
+// rays with an unclamped box per pixel (the zeroed [B,H,W] table pix_rays); the rays whose box is
+// clamped at the image border go to `list` (list[0] = their number, zeroed by the launcher)
+__global__ void lidf_rayfeat_count_kernel(const int* __restrict__ ray_pix, const int* __restrict__ ray_bid,
+                                          long long R, int half, int H, int W, int* __restrict__ pix_rays,
+                                          int* __restrict__ list) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
+    const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+    const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+    if (u2 - u1 == 2 * half && v2 - v1 == 2 * half)
+        atomicAdd(pix_rays + ((size_t)ray_bid[r] * H + qy) * W + qx, 1);
+    else
+        list[1 + atomicAdd(list, 1)] = (int)r;
+}
+
+// The rays of `list` (boxes clamped at the border: fractional samples), one thread per (ray, column),
+// densely packed. The bilinear weights of the gh x gw samples of a bin are a product of a row and a
+// column factor, so a pixel's share of the bin is wy(py) wx(px) — one add per touched pixel
+// (<= (gh+1)(gw+1)) instead of four per sample.
+__device__ __forceinline__ void roi_tap(float x, int LIM, int& lo, int& hi, float& l, bool& ok) {
+    ok = !(x < -1.0f || x > (float)LIM);
+    if (x <= 0.f) x = 0.f;
+    lo = (int)x;
+    if (lo >= LIM - 1) { hi = lo = LIM - 1; x = (float)lo; } else { hi = lo + 1; }
+    l = x - (float)lo;
+}
+__device__ __forceinline__ float roi_axis_weight(float start, float bin, int n, int LIM, int px) {
+    float wsum = 0.f;
+    for (int i = 0; i < n; ++i) {
+        int lo, hi; float l; bool ok;
+        roi_tap(start + ((float)i + .5f) * bin / (float)n, LIM, lo, hi, l, ok);
+        if (!ok) continue;
+        if (lo == px) wsum += 1.f - l;
+        if (hi == px) wsum += l;
+    }
+    return wsum;
+}
+__global__ void __launch_bounds__(256) lidf_rayfeat_backward_border_kernel(
+    const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
+    const int* __restrict__ ray_bid, const int* __restrict__ list, int half, int H, int W,
+    float* __restrict__ d_feat) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)list[0] * 128) return;
+    const long long r = list[1 + (i >> 7)];
+    const int cb = (int)(i & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
+    const float g = d_rayfeat[(size_t)r * ld_rf + cb];
+    if (g == 0.f) return;
+    const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
+    const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+    const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+    const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+    const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
+    const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+    const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+    if (gw <= 0 || gh <= 0) return;
+    const float gs = g / (float)(gh * gw);
+    const float xs = rsw + (float)pw * bin_w, ys = rsh + (float)ph * bin_h;
+    int x0, x1, y0, y1, t0; float tl; bool tk;
+    roi_tap(xs + .5f * bin_w / (float)gw, W, x0, t0, tl, tk);
+    roi_tap(xs + ((float)(gw - 1) + .5f) * bin_w / (float)gw, W, t0, x1, tl, tk);
+    roi_tap(ys + .5f * bin_h / (float)gh, H, y0, t0, tl, tk);
+    roi_tap(ys + ((float)(gh - 1) + .5f) * bin_h / (float)gh, H, t0, y1, tl, tk);
+    float* img = d_feat + ((size_t)ray_bid[r] * 32 + c) * H * W;
+    for (int py = y0; py <= y1; ++py) {
+        const float wy = roi_axis_weight(ys, bin_h, gh, H, py);
+        if (wy == 0.f) continue;
+        for (int px = x0; px <= x1; ++px) {
+            const float wx = roi_axis_weight(xs, bin_w, gw, W, px);
+            if (wx != 0.f) atomicAdd(img + (size_t)py * W + px, gs * wy * wx);
+        }
+    }
+}
+
 // RoIAlign backward (torchvision roi_align, output 2x2, aligned): every sample of bin (ph, pw)
 // passes g / count to its four bilinear taps.
 // A workgroup takes 64 rays: their 128 gradient columns are read as rows (coalesced) into LDS, then
@@ -745,7 +819,7 @@ __global__ void __launch_bounds__(256) lidf_rows_vox_backward_kernel(
 __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
     const int* __restrict__ ray_bid, long long R, int half, int H, int W, float* __restrict__ d_feat,
-    float* __restrict__ gimg) {
+    float* __restrict__ gimg, const int* __restrict__ pix_rays, int skip_clamped) {
     __shared__ float tile[64][129];
     const long long r0 = (long long)blockIdx.x * 64;
     for (int i = threadIdx.x; i < 64 * 128; i += 256) {
@@ -760,6 +834,9 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
     const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
     const bool parked = gimg && half > 0 && u2 - u1 == 2 * half && v2 - v1 == 2 * half;
+    // pix_rays (rays parked per pixel, lidf_rayfeat_count_kernel): the only ray of its pixel stores
+    const bool alone = parked && pix_rays && pix_rays[((size_t)bid * H + qy) * W + qx] == 1;
+    if (!parked && skip_clamped) return;   // lidf_rayfeat_backward_border_kernel takes these
     const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
     const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
     const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
@@ -770,9 +847,11 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
         if (parked) {
             // unclamped box: every sample sits on a pixel centre, bin (ph, pw) spreads g / half^2
             // over a half x half pixel block; parked at the ray's pixel, gathered by
-            // lidf_rayfeat_gather_kernel (atomicAdd into the zeroed image: two rays may name the
-            // same pixel)
-            atomicAdd(gimg + (((size_t)bid * 128 + cb) * H + qy) * W + qx, g);
+            // lidf_rayfeat_gather_kernel (into the zeroed image; added atomically where two rays
+            // name the same pixel)
+            float* dst = gimg + (((size_t)bid * 128 + cb) * H + qy) * W + qx;
+            if (alone) *dst = g;
+            else atomicAdd(dst, g);
             continue;
         }
         const int c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
@@ -854,19 +933,37 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_gather_kernel(const float* _
     d_feat[i] += acc / (float)(half * half);
 }
 
-// gimg: optional scratch [B,128,H,W]; with it the unclamped boxes take the gather path
+// gimg: optional scratch [B,128,H,W]; with it the unclamped boxes take the gather path.
+// aux: optional scratch of B*H*W + R + 1 ints behind it: the rays-per-pixel table (pixels named by
+// one ray are stored, not added) and the list of the clamped rays.
 extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int ld_rf,
                                                    const int* ray_pix, const int* ray_bid,
                                                    long long R, int half, int B, int H, int W,
-                                                   float* d_feat, float* gimg, hipStream_t st) {
+                                                   float* d_feat, float* gimg, int* aux,
+                                                   hipStream_t st) {
     if (R <= 0) return hipSuccess;
     if (half <= 0) gimg = nullptr;
+    if (!gimg) aux = nullptr;
+    int* pix_rays = aux;
+    int* list = aux ? aux + (size_t)B * H * W : nullptr;
     if (gimg) {
         hipError_t e = hipMemsetAsync(gimg, 0, (size_t)B * 128 * H * W * 4, st);
         if (e != hipSuccess) return e;
     }
+    if (aux) {
+        hipError_t e = hipMemsetAsync(aux, 0, ((size_t)B * H * W + 1) * 4, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(lidf_rayfeat_count_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                           ray_pix, ray_bid, R, half, H, W, pix_rays, list);
+    }
     hipLaunchKernelGGL(lidf_rayfeat_backward_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0,
-                       st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat, gimg);
+                       st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat, gimg, pix_rays,
+                       aux ? 1 : 0);
+    if (aux) {
+        // at most every ray is clamped: blocks beyond the list's length leave at once
+        hipLaunchKernelGGL(lidf_rayfeat_backward_border_kernel, dim3((unsigned)((R * 128 + 255) / 256)),
+                           dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, list, half, H, W, d_feat);
+    }
     if (gimg) {
         const long long total = (long long)B * 32 * H * W;
         hipLaunchKernelGGL(lidf_rayfeat_gather_kernel, dim3((unsigned)((total + 255) / 256)),
@@ -881,15 +978,18 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
 // (+ u*off), so only the positional encodings are per-pair rows.
 // ------------------------------------------------------------------------------------------------
 // pe[p] = [ embed(enter) | embed(leave) ]  (2*(3+6L) columns)
+// Thread (pair, column): 256 / wpad pairs per workgroup (wpad = the row width rounded up to a power
+// of two: shifts instead of 64-bit divisions); sin/cos as in the inference kernel (revolutions,
+// v_sin_f32 / v_cos_f32, |err| <= 4.2e-7 at every octave — lidf_device.h).
 __global__ void __launch_bounds__(256) lidf_pe_rows_kernel(
     const int* __restrict__ pair_ray, const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
     const float* __restrict__ ray_dir, const float* __restrict__ vox_center, int pos_rel, int L,
-    long long P, float* __restrict__ pe) {
+    long long P, int wshift, float* __restrict__ pe) {
     const int E = 3 + 6 * L, W = 2 * E;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= P * W) return;
-    const long long p = i / W;
-    const int j = (int)(i % W), k = j % E;
+    const long long p = (long long)blockIdx.x * (256 >> wshift) + (threadIdx.x >> wshift);
+    const int j = threadIdx.x & ((1 << wshift) - 1);
+    if (p >= P || j >= W) return;
+    const int k = j >= E ? j - E : j;
     const int r = pair_ray[p];
     const float t = pair_t[2 * p + (j >= E ? 1 : 0)];
     const int c = k < 3 ? k : (k - 3) % 3;
@@ -897,10 +997,11 @@ __global__ void __launch_bounds__(256) lidf_pe_rows_kernel(
     if (pos_rel) x -= vox_center[3 * (size_t)pair_vox[p] + c];
     float val = x;
     if (k >= 3) {
-        const float a = x * (float)(1 << ((k - 3) / 6));
-        val = ((k - 3) % 6) < 3 ? sinf(a) : cosf(a);
+        float sn, cs;
+        rev_sincos(to_rev(x), (float)(1 << ((k - 3) / 6)), sn, cs);
+        val = ((k - 3) % 6) < 3 ? sn : cs;
     }
-    pe[i] = val;
+    pe[(size_t)p * W + j] = val;
 }
 
 // out[r, :] = sum over the ray's contiguous pairs of S[p, :]   (one wavefront per ray, no atomics)
@@ -955,9 +1056,13 @@ extern "C" hipError_t lidf_launch_pe_rows(const int* pair_ray, const int* pair_v
                                           const float* vox_center, int pos_rel, int L, long long P,
                                           float* pe, hipStream_t st) {
     if (P <= 0) return hipSuccess;
-    const long long total = P * 2 * (3 + 6 * L);
-    hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, pe);
+    const int W = 2 * (3 + 6 * L);
+    int wshift = 3;
+    while ((1 << wshift) < W) ++wshift;
+    if (wshift > 8) return hipErrorInvalidValue;
+    const long long per = 256 >> wshift;
+    hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((P + per - 1) / per)), dim3(256), 0, st,
+                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, wshift, pe);
     return hipGetLastError();
 }
 extern "C" hipError_t lidf_launch_seg_sum_ray(const float* S, int F, const int* pair_off,
