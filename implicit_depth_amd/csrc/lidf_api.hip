@@ -42,6 +42,8 @@ hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long l
                                 hipStream_t);
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
 hipError_t lidf_launch_axpy(const float*, long long, float*, hipStream_t);
+hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const float*, const float*,
+                                   long long, float, float*, float*, float*, int, hipStream_t);
 hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
                                    float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_ief_tail(const float*, const float*, const float*, int, const float*,
@@ -1216,15 +1218,9 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         LinEx L = {};
         L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
-        // dZ2 = (dZ3 W3) * lrelu'(Z2)
-        L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
-        L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        // dZ2 = (dZ3 W3) * lrelu'(Z2), dZ1 = (dZ2 W2) * lrelu'(Z1): one register-chained launch
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, n, 0.02f, dz2, dz1, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        // dZ1 = (dZ2 W2) * lrelu'(Z1)
-        L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
-        L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
         CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
         L.mask_src = nullptr;
         if (d_inp) {
@@ -1475,15 +1471,9 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         LinEx L = {};
         L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
-        L.w = dec->w3; L.ldw = LIDF_H2; L.nout = LIDF_H2; L.k = LIDF_H3; L.X = dz3; L.ldx = LIDF_H3;
-        L.mask_src = h2; L.ld_mask = LIDF_H2; L.out = dz2; L.ld_out = LIDF_H2;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        // dZ2, dZ1 of this pass: one register-chained launch
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        // dZ1 of this pass, and its running sum over the passes: everything of layer 1 except the
-        // offset encoding sees the same operand in every pass
-        L.w = dec->w2; L.ldw = LIDF_H1; L.nout = LIDF_H1; L.k = LIDF_H2; L.X = dz2; L.ldx = LIDF_H2;
-        L.mask_src = h1; L.ld_mask = LIDF_H1; L.out = dz1; L.ld_out = LIDF_H1;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
         // the offset-encoding columns of layer 1 and the running sum S of dZ1 (everything of
         // layer 1 except the offset encoding sees the same operand in every pass): one pass over dZ1
         if (npass == 1) S = dz1;
