@@ -1292,10 +1292,10 @@ LIDF_API int lidf_ray_features_backward_f32(const float* d_rayfeat, const int32_
     if (n_rays == 0) return LIDF_OK;
     if (!d_rayfeat || !ray_pix || !ray_bid) return LIDF_ERR_BAD_ARG;
     // with room for a [B,128,h,w] scratch image the unclamped boxes take the atomic-free gather path
-    // (+ B*h*w + n_rays + 1 ints: pixels named by a single ray are stored instead of added
-    // atomically; the rays with a clamped box are listed and take a densely packed launch)
+    // (+ B*h*w ints: pixels named by a single ray are stored instead of added atomically, and the
+    // rays with a clamped box are parked as well and accumulated tile by tile through LDS)
     const size_t need = (size_t)batch * 128 * height * width * 4;
-    const size_t need2 = need + ((size_t)batch * height * width + (size_t)n_rays + 1) * 4;
+    const size_t need2 = need + (size_t)batch * height * width * 4;
     float* gimg = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
     int* pix_rays = (workspace && workspace_bytes >= need2) ? (int*)((char*)workspace + need) : nullptr;
     CHECK_HIP(lidf_launch_rayfeat_backward(d_rayfeat, 128 + 3 + 6 * multires_views, ray_pix, ray_bid,

@@ -735,26 +735,16 @@ __global__ void __launch_bounds__(256) lidf_rows_vox_backward_kernel(
     if (g != 0.f) atomicAdd(d_vox_feat + (size_t)pair_vox[p] * 128 + j, g);
 }
 
-// rays with an unclamped box per pixel (the zeroed [B,H,W] table pix_rays); the rays whose box is
-// clamped at the image border go to `list` (list[0] = their number, zeroed by the launcher)
+// rays per pixel (the zeroed [B,H,W] table pix_rays)
 __global__ void lidf_rayfeat_count_kernel(const int* __restrict__ ray_pix, const int* __restrict__ ray_bid,
-                                          long long R, int half, int H, int W, int* __restrict__ pix_rays,
-                                          int* __restrict__ list) {
+                                          long long R, int H, int W, int* __restrict__ pix_rays) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
-    const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
-    const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
-    if (u2 - u1 == 2 * half && v2 - v1 == 2 * half)
-        atomicAdd(pix_rays + ((size_t)ray_bid[r] * H + qy) * W + qx, 1);
-    else
-        list[1 + atomicAdd(list, 1)] = (int)r;
+    atomicAdd(pix_rays + ((size_t)ray_bid[r] * H + ray_pix[2 * r + 1]) * W + ray_pix[2 * r], 1);
 }
 
-// The rays of `list` (boxes clamped at the border: fractional samples), one thread per (ray, column),
-// densely packed. The bilinear weights of the gh x gw samples of a bin are a product of a row and a
-// column factor, so a pixel's share of the bin is wy(py) wx(px) — one add per touched pixel
-// (<= (gh+1)(gw+1)) instead of four per sample.
+// The bilinear weights of the gh x gw samples of a bin are a product of a row and a column factor,
+// so a pixel's share of the bin is wy(py) wx(px).
 __device__ __forceinline__ void roi_tap(float x, int LIM, int& lo, int& hi, float& l, bool& ok) {
     ok = !(x < -1.0f || x > (float)LIM);
     if (x <= 0.f) x = 0.f;
@@ -773,39 +763,76 @@ __device__ __forceinline__ float roi_axis_weight(float start, float bin, int n, 
     }
     return wsum;
 }
-__global__ void __launch_bounds__(256) lidf_rayfeat_backward_border_kernel(
-    const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
-    const int* __restrict__ ray_bid, const int* __restrict__ list, int half, int H, int W,
-    float* __restrict__ d_feat) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)list[0] * 128) return;
-    const long long r = list[1 + (i >> 7)];
-    const int cb = (int)(i & 127), c = cb >> 2, ph = (cb >> 1) & 1, pw = cb & 1;
-    const float g = d_rayfeat[(size_t)r * ld_rf + cb];
-    if (g == 0.f) return;
-    const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1];
-    const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
-    const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
-    const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
-    const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
-    const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
-    const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
-    if (gw <= 0 || gh <= 0) return;
-    const float gs = g / (float)(gh * gw);
-    const float xs = rsw + (float)pw * bin_w, ys = rsh + (float)ph * bin_h;
-    int x0, x1, y0, y1, t0; float tl; bool tk;
-    roi_tap(xs + .5f * bin_w / (float)gw, W, x0, t0, tl, tk);
-    roi_tap(xs + ((float)(gw - 1) + .5f) * bin_w / (float)gw, W, t0, x1, tl, tk);
-    roi_tap(ys + .5f * bin_h / (float)gh, H, y0, t0, tl, tk);
-    roi_tap(ys + ((float)(gh - 1) + .5f) * bin_h / (float)gh, H, t0, y1, tl, tk);
-    float* img = d_feat + ((size_t)ray_bid[r] * 32 + c) * H * W;
-    for (int py = y0; py <= y1; ++py) {
-        const float wy = roi_axis_weight(ys, bin_h, gh, H, py);
-        if (wy == 0.f) continue;
-        for (int px = x0; px <= x1; ++px) {
-            const float wx = roi_axis_weight(xs, bin_w, gw, W, px);
-            if (wx != 0.f) atomicAdd(img + (size_t)py * W + px, gs * wy * wx);
+
+// The boxes clamped at the image border (fractional samples), from the parked image: a workgroup
+// takes a 16 x 16 tile of source pixels on the ring of clamped boxes and one channel, adds the
+// shares of its pixels' four bins into an LDS patch of (16 + 2 half)^2 pixels (LDS float adds) and
+// flushes the patch with one global add per touched pixel — the boxes of neighbouring border rays
+// overlap almost entirely, a thread per (ray, column) with global adds spent 0.27 ms on 4,416 rays.
+// grid.x = ring tiles (rayfeat_ring_tile), grid.y = B * 32.
+__device__ __forceinline__ void rayfeat_ring_tile(int t, int tx_n, int ty_n, int& tx, int& ty) {
+    // top row, bottom row, then the left and right columns between them
+    if (t < tx_n) { ty = 0; tx = t; return; }
+    t -= tx_n;
+    if (ty_n > 1) {
+        if (t < tx_n) { ty = ty_n - 1; tx = t; return; }
+        t -= tx_n;
+    }
+    const int rows = ty_n - 2;   // (with a single tile column the launcher counts these once)
+    if (t < rows) { ty = 1 + t; tx = 0; return; }
+    t -= rows;
+    ty = 1 + t; tx = tx_n - 1;
+}
+__global__ void __launch_bounds__(256) lidf_rayfeat_backward_ring_kernel(
+    const float* __restrict__ gimg, int half, int H, int W, float* __restrict__ d_feat) {
+    extern __shared__ float patch[];
+    const int PW = 16 + 2 * half;
+    for (int i = threadIdx.x; i < PW * PW; i += 256) patch[i] = 0.f;
+    __syncthreads();
+    const int tx_n = (W + 15) / 16, ty_n = (H + 15) / 16;
+    int tx, ty;
+    rayfeat_ring_tile(blockIdx.x, tx_n, ty_n, tx, ty);
+    const int b = blockIdx.y >> 5, c = blockIdx.y & 31;
+    const int qx = tx * 16 + (threadIdx.x & 15), qy = ty * 16 + (threadIdx.x >> 4);
+    const int ox = tx * 16 - half, oy = ty * 16 - half;   // patch origin
+    const bool clampedbox = qx < W && qy < H && (qx < half || qx > W - 1 - half || qy < half || qy > H - 1 - half);
+    if (clampedbox) {
+        const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+        const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+        const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+        const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
+        const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
+        const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
+        if (gw > 0 && gh > 0) {
+#pragma unroll
+            for (int bin = 0; bin < 4; ++bin) {
+                const int ph = bin >> 1, pw = bin & 1;
+                const float g = gimg[(((size_t)b * 128 + c * 4 + bin) * H + qy) * W + qx];
+                if (g == 0.f) continue;
+                const float gs = g / (float)(gh * gw);
+                const float xs = rsw + (float)pw * bin_w, ys = rsh + (float)ph * bin_h;
+                int x0, x1, y0, y1, t0; float tl; bool tk;
+                roi_tap(xs + .5f * bin_w / (float)gw, W, x0, t0, tl, tk);
+                roi_tap(xs + ((float)(gw - 1) + .5f) * bin_w / (float)gw, W, t0, x1, tl, tk);
+                roi_tap(ys + .5f * bin_h / (float)gh, H, y0, t0, tl, tk);
+                roi_tap(ys + ((float)(gh - 1) + .5f) * bin_h / (float)gh, H, t0, y1, tl, tk);
+                for (int py = y0; py <= y1; ++py) {
+                    const float wy = roi_axis_weight(ys, bin_h, gh, H, py);
+                    if (wy == 0.f) continue;
+                    for (int px = x0; px <= x1; ++px) {
+                        const float wx = roi_axis_weight(xs, bin_w, gw, W, px);
+                        if (wx != 0.f) atomicAdd(patch + (py - oy) * PW + (px - ox), gs * wy * wx);
+                    }
+                }
+            }
         }
+    }
+    __syncthreads();
+    float* img = d_feat + ((size_t)b * 32 + c) * H * W;
+    for (int i = threadIdx.x; i < PW * PW; i += 256) {
+        const float v = patch[i];
+        const int py = oy + i / PW, px = ox + i % PW;
+        if (v != 0.f && py >= 0 && py < H && px >= 0 && px < W) atomicAdd(img + (size_t)py * W + px, v);
     }
 }
 
@@ -819,7 +846,7 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_border_kernel(
 __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     const float* __restrict__ d_rayfeat, int ld_rf, const int* __restrict__ ray_pix,
     const int* __restrict__ ray_bid, long long R, int half, int H, int W, float* __restrict__ d_feat,
-    float* __restrict__ gimg, const int* __restrict__ pix_rays, int skip_clamped) {
+    float* __restrict__ gimg, const int* __restrict__ pix_rays, int park_all) {
     __shared__ float tile[64][129];
     const long long r0 = (long long)blockIdx.x * 64;
     for (int i = threadIdx.x; i < 64 * 128; i += 256) {
@@ -833,10 +860,10 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_kernel(
     const int qx = ray_pix[2 * r], qy = ray_pix[2 * r + 1], bid = ray_bid[r];
     const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
     const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
-    const bool parked = gimg && half > 0 && u2 - u1 == 2 * half && v2 - v1 == 2 * half;
+    // park_all: the clamped boxes are parked too (lidf_rayfeat_backward_ring_kernel takes them)
+    const bool parked = gimg && half > 0 && (park_all || (u2 - u1 == 2 * half && v2 - v1 == 2 * half));
     // pix_rays (rays parked per pixel, lidf_rayfeat_count_kernel): the only ray of its pixel stores
     const bool alone = parked && pix_rays && pix_rays[((size_t)bid * H + qy) * W + qx] == 1;
-    if (!parked && skip_clamped) return;   // lidf_rayfeat_backward_border_kernel takes these
     const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
     const float roi_w = ((float)u2 - 0.5f) - rsw, roi_h = ((float)v2 - 0.5f) - rsh;
     const float bin_w = roi_w / 2.f, bin_h = roi_h / 2.f;
@@ -908,8 +935,10 @@ extern "C" hipError_t lidf_launch_rows_backward(const float* d_rows, int D, int 
 // d_feat[b,c,y,x] += 1/half^2 * sum over the 4 bins of the parked gradients of the rays whose bin
 // covers the pixel: bin ph = 0 is covered by rays at rows y+1 .. y+half, ph = 1 by rows
 // y-half+1 .. y (columns alike) — the adjoint of the forward's box-sum shortcut, no atomics.
+// lo: only source pixels in [lo, W-1-lo] x [lo, H-1-lo] (with the clamped boxes parked too, lo = half
+// leaves them to the ring kernel).
 __global__ void __launch_bounds__(256) lidf_rayfeat_gather_kernel(const float* __restrict__ gimg,
-                                                                  int B, int H, int W, int half,
+                                                                  int B, int H, int W, int half, int lo,
                                                                   float* __restrict__ d_feat) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)B * 32 * H * W;
@@ -926,16 +955,16 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_gather_kernel(const float* _
         for (int pw = 0; pw < 2; ++pw) {
             const int xa = pw ? x - half + 1 : x + 1, xb = pw ? x : x + half;
             const float* g = gimg + ((size_t)(b * 128 + c * 4 + ph * 2 + pw) * H) * W;
-            for (int yy = max(ya, 0); yy <= min(yb, H - 1); ++yy)
-                for (int xx = max(xa, 0); xx <= min(xb, W - 1); ++xx) acc += g[(size_t)yy * W + xx];
+            for (int yy = max(ya, lo); yy <= min(yb, H - 1 - lo); ++yy)
+                for (int xx = max(xa, lo); xx <= min(xb, W - 1 - lo); ++xx) acc += g[(size_t)yy * W + xx];
         }
     }
     d_feat[i] += acc / (float)(half * half);
 }
 
 // gimg: optional scratch [B,128,H,W]; with it the unclamped boxes take the gather path.
-// aux: optional scratch of B*H*W + R + 1 ints behind it: the rays-per-pixel table (pixels named by
-// one ray are stored, not added) and the list of the clamped rays.
+// aux: optional scratch of B*H*W ints behind it (the rays-per-pixel table: pixels named by one ray
+// are stored, not added); with it the clamped boxes are parked as well and go through the ring kernel.
 extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int ld_rf,
                                                    const int* ray_pix, const int* ray_bid,
                                                    long long R, int half, int B, int H, int W,
@@ -943,31 +972,36 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
                                                    hipStream_t st) {
     if (R <= 0) return hipSuccess;
     if (half <= 0) gimg = nullptr;
-    if (!gimg) aux = nullptr;
-    int* pix_rays = aux;
-    int* list = aux ? aux + (size_t)B * H * W : nullptr;
+    // the ring kernel wants tiles of 16 pixels to reach the clamped boxes of one image side only
+    // (also when the last, partial tile row / column is narrower than the ring)
+    const int tx_n = (W + 15) / 16, ty_n = (H + 15) / 16;
+    if (!gimg || half > 16 || W < 2 * half + 1 || H < 2 * half + 1 || W - 16 * (tx_n - 1) < half ||
+        H - 16 * (ty_n - 1) < half)
+        aux = nullptr;
     if (gimg) {
         hipError_t e = hipMemsetAsync(gimg, 0, (size_t)B * 128 * H * W * 4, st);
         if (e != hipSuccess) return e;
     }
     if (aux) {
-        hipError_t e = hipMemsetAsync(aux, 0, ((size_t)B * H * W + 1) * 4, st);
+        hipError_t e = hipMemsetAsync(aux, 0, (size_t)B * H * W * 4, st);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(lidf_rayfeat_count_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
-                           ray_pix, ray_bid, R, half, H, W, pix_rays, list);
+                           ray_pix, ray_bid, R, H, W, aux);
     }
     hipLaunchKernelGGL(lidf_rayfeat_backward_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0,
-                       st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat, gimg, pix_rays,
+                       st, d_rayfeat, ld_rf, ray_pix, ray_bid, R, half, H, W, d_feat, gimg, aux,
                        aux ? 1 : 0);
-    if (aux) {
-        // at most every ray is clamped: blocks beyond the list's length leave at once
-        hipLaunchKernelGGL(lidf_rayfeat_backward_border_kernel, dim3((unsigned)((R * 128 + 255) / 256)),
-                           dim3(256), 0, st, d_rayfeat, ld_rf, ray_pix, ray_bid, list, half, H, W, d_feat);
-    }
     if (gimg) {
         const long long total = (long long)B * 32 * H * W;
         hipLaunchKernelGGL(lidf_rayfeat_gather_kernel, dim3((unsigned)((total + 255) / 256)),
-                           dim3(256), 0, st, gimg, B, H, W, half, d_feat);
+                           dim3(256), 0, st, gimg, B, H, W, half, aux ? half : 0, d_feat);
+    }
+    if (aux) {
+        const int side = ty_n > 2 ? (tx_n > 1 ? 2 : 1) * (ty_n - 2) : 0;
+        const int tiles = (ty_n > 1 ? 2 * tx_n : tx_n) + side;
+        const int PW = 16 + 2 * half;
+        hipLaunchKernelGGL(lidf_rayfeat_backward_ring_kernel, dim3(tiles, B * 32), dim3(256),
+                           (size_t)PW * PW * 4, st, gimg, half, H, W, d_feat);
     }
     return hipGetLastError();
 }
@@ -981,27 +1015,42 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
 // Thread (pair, column): 256 / wpad pairs per workgroup (wpad = the row width rounded up to a power
 // of two: shifts instead of 64-bit divisions); sin/cos as in the inference kernel (revolutions,
 // v_sin_f32 / v_cos_f32, |err| <= 4.2e-7 at every octave — lidf_device.h).
+#define PE_UNROLL 4   // pairs per thread: their dependent index -> direction loads overlap
 __global__ void __launch_bounds__(256) lidf_pe_rows_kernel(
     const int* __restrict__ pair_ray, const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
     const float* __restrict__ ray_dir, const float* __restrict__ vox_center, int pos_rel, int L,
     long long P, int wshift, float* __restrict__ pe) {
     const int E = 3 + 6 * L, W = 2 * E;
-    const long long p = (long long)blockIdx.x * (256 >> wshift) + (threadIdx.x >> wshift);
+    const int per = 256 >> wshift;
+    const long long p0 = (long long)blockIdx.x * (per * PE_UNROLL) + (threadIdx.x >> wshift);
     const int j = threadIdx.x & ((1 << wshift) - 1);
-    if (p >= P || j >= W) return;
+    if (j >= W) return;
     const int k = j >= E ? j - E : j;
-    const int r = pair_ray[p];
-    const float t = pair_t[2 * p + (j >= E ? 1 : 0)];
     const int c = k < 3 ? k : (k - 3) % 3;
-    float x = __fmul_rn(ray_dir[3 * (size_t)r + c], t);
-    if (pos_rel) x -= vox_center[3 * (size_t)pair_vox[p] + c];
-    float val = x;
-    if (k >= 3) {
-        float sn, cs;
-        rev_sincos(to_rev(x), (float)(1 << ((k - 3) / 6)), sn, cs);
-        val = ((k - 3) % 6) < 3 ? sn : cs;
+    const float sc = k >= 3 ? (float)(1 << ((k - 3) / 6)) : 1.f;
+    const bool is_sin = k >= 3 && ((k - 3) % 6) < 3;
+    float x[PE_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PE_UNROLL; ++u) {
+        const long long p = p0 + (long long)u * per;
+        x[u] = 0.f;
+        if (p < P) {
+            x[u] = __fmul_rn(ray_dir[3 * (size_t)pair_ray[p] + c], pair_t[2 * p + (j >= E ? 1 : 0)]);
+            if (pos_rel) x[u] -= vox_center[3 * (size_t)pair_vox[p] + c];
+        }
     }
-    pe[(size_t)p * W + j] = val;
+#pragma unroll
+    for (int u = 0; u < PE_UNROLL; ++u) {
+        const long long p = p0 + (long long)u * per;
+        if (p >= P) break;
+        float val = x[u];
+        if (k >= 3) {
+            float sn, cs;
+            rev_sincos(to_rev(x[u]), sc, sn, cs);
+            val = is_sin ? sn : cs;
+        }
+        pe[(size_t)p * W + j] = val;
+    }
 }
 
 // out[r, :] = sum over the ray's contiguous pairs of S[p, :]   (one wavefront per ray, no atomics)
@@ -1060,7 +1109,7 @@ extern "C" hipError_t lidf_launch_pe_rows(const int* pair_ray, const int* pair_v
     int wshift = 3;
     while ((1 << wshift) < W) ++wshift;
     if (wshift > 8) return hipErrorInvalidValue;
-    const long long per = 256 >> wshift;
+    const long long per = (256 >> wshift) * PE_UNROLL;
     hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((P + per - 1) / per)), dim3(256), 0, st,
                        pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, wshift, pe);
     return hipGetLastError();

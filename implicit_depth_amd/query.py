@@ -536,8 +536,7 @@ class _RayFeaturesFn(torch.autograd.Function):
         B, _, h, w = ctx.shape
         g = g.detach().contiguous().float()
         d_feat = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-        # scratch image of the unclamped boxes + rays-per-pixel table + list of the clamped rays
-        wsb = B * 129 * h * w * 4 + (g.shape[0] + 1) * 4
+        wsb = B * 129 * h * w * 4    # scratch image of the parked gradients + rays-per-pixel table
         ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().lidf_ray_features_backward_f32(
