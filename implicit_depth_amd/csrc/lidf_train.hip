@@ -816,13 +816,18 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_ring_kernel(
                 roi_tap(xs + ((float)(gw - 1) + .5f) * bin_w / (float)gw, W, t0, x1, tl, tk);
                 roi_tap(ys + .5f * bin_h / (float)gh, H, y0, t0, tl, tk);
                 roi_tap(ys + ((float)(gh - 1) + .5f) * bin_h / (float)gh, H, t0, y1, tl, tk);
+                // column factors once per bin (x1 - x0 <= gw <= half <= 16)
+                float wxv[17];
+#pragma unroll
+                for (int i = 0; i < 17; ++i)
+                    wxv[i] = x0 + i <= x1 ? roi_axis_weight(xs, bin_w, gw, W, x0 + i) : 0.f;
                 for (int py = y0; py <= y1; ++py) {
                     const float wy = roi_axis_weight(ys, bin_h, gh, H, py);
                     if (wy == 0.f) continue;
-                    for (int px = x0; px <= x1; ++px) {
-                        const float wx = roi_axis_weight(xs, bin_w, gw, W, px);
-                        if (wx != 0.f) atomicAdd(patch + (py - oy) * PW + (px - ox), gs * wy * wx);
-                    }
+                    float* prow = patch + (py - oy) * PW + (x0 - ox);
+#pragma unroll
+                    for (int i = 0; i < 17; ++i)
+                        if (wxv[i] != 0.f) atomicAdd(prow + i, gs * wy * wxv[i]);
                 }
             }
         }
