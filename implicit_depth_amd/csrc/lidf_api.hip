@@ -1471,14 +1471,16 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         LinEx L = {};
         L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
-        // dZ2, dZ1 of this pass: one register-chained launch
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1, sbuf, cus, st));
-        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        // the offset-encoding columns of layer 1 and the running sum S of dZ1 (everything of
-        // layer 1 except the offset encoding sees the same operand in every pass): one pass over dZ1
+        // dZ2, dZ1 of this pass: one register-chained launch. S = the running sum of dZ1 over the
+        // passes (everything of layer 1 except the offset encoding sees the same operand in every
+        // pass): the first pass processed writes its dZ1 straight into S, the others add theirs in
+        // the same sweep over dZ1 that handles the offset-encoding columns of layer 1
         if (npass == 1) S = dz1;
-        CHECK_HIP(lidf_launch_ief_tail(dz1, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
-                                       dec->benc, P, npass == 1 ? 0 : (k == npass - 1 ? 1 : 2), S, goff,
+        float* dz1k = k == npass - 1 ? S : dz1;
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1k, sbuf, cus, st));
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
+        CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
+                                       dec->benc, P, k == npass - 1 ? 0 : 2, S, goff,
                                        grads->w1 + D, grads->wenc, grads->benc, wgs, st));
     }
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
