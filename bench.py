@@ -322,8 +322,8 @@ def secondary(args):
     kern_ms = e0.elapsed_time(e1) / args.steps  # one dominant kernel per step on torch's stream
     hbm = args.workload == "embed"
     split_rows = args.workload == "decoders" and args.precision == "f16x3"
-    # frac = issued MFMA FLOP / time / peak where the instruction count is known (decoders);
-    # the training steps are priced in model FLOPs (3 x the reference forward) and say so
+    # frac = issued MFMA FLOP / time / peak where the instruction count is known (decoders); the
+    # training steps in the FLOP of the executed formulation; achieved_alg = model FLOPs (F_alg)
     flop_exec, basis = flop_alg, "model FLOPs (F_alg), not a hardware utilisation"
     if split_rows:
         # executed: 2 nets x 25 layer-1 k-steps x 24 + 3 passes x 254 v_mfma_f32_32x32x16_f16 per 32 rows
@@ -331,6 +331,15 @@ def secondary(args):
     elif args.workload == "decoders":
         # rows mode: 2 nets x 49 k-quads x 8 tiles x 4 + 3 passes x 654 v_mfma_f32_32x32x2_f32 per 32 rows
         flop_exec, basis = (2 * 49 * 8 * 4 + 3 * 654) * 4096 / 32.0, "issued MFMA FLOP"
+    elif args.workload in ("train", "train-query"):
+        # 3 x the forward FLOP of the formulation that runs (forward, input gradient, weight
+        # gradient), without tile padding: layers 2-4 per pass 2 (256*128 + 128*64 + 64); layer 1
+        # per net on the per-pair operand (train-query: the 102 position-embedding columns, the
+        # voxel / ray parts are per-voxel / per-ray products; train: all 385 columns, once per net
+        # for the IEF), + the IEF rank-1 term per pass
+        chain, k1 = 2.0 * (256 * 128 + 128 * 64 + 64), (102 if args.workload == "train-query" else 385)
+        fwd = 2 * (2.0 * 256 * k1) + 3 * chain + 2 * (2.0 * 256)
+        flop_exec, basis = 3.0 * fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_exec * P / (kern_ms * 1e-3) / 1e12)
     peak = 8000.0 if hbm else (PEAK_F16_TFLOPS if split_rows else PEAK_F32_TFLOPS)
     print(json.dumps({
