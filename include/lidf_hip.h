@@ -386,9 +386,12 @@ int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld
  * (rayfeat = lidf_ray_features_f32) and go through the decoders' training path; the gradient of the
  * rows is reduced to d vox_feat [V,128] (float atomics) and d rayfeat [R, 128+(3+6Lv)] (per-ray
  * sums over the contiguous pairs, pair_off = CSR), and the ROI columns of d rayfeat pass through
- * RoIAlign backward to d feat_grid [B,32,h,w]: rays whose box is clamped at the image border use
- * float atomics; with an optional workspace of batch*128*height*width floats the others are parked in
- * a [B,128,h,w] image and gathered per pixel (no atomics). Outputs are overwritten.              */
+ * RoIAlign backward to d feat_grid [B,32,h,w]. Without a workspace every ray adds its samples'
+ * shares with float atomics. With batch*128*height*width floats of workspace the rays with an
+ * unclamped box are parked in a [B,128,h,w] image and gathered per pixel (no atomics); with
+ * batch*height*width ints more (a rays-per-pixel table) a pixel named by one ray is stored instead
+ * of added, and the boxes clamped at the border are parked too and accumulated tile by tile through
+ * LDS (one add per touched pixel and tile). Outputs are overwritten.                            */
 int lidf_build_rows_f32(const int32_t* pair_ray, const int32_t* pair_vox, const float* pair_t,
                         const float* ray_dir, const float* vox_center, int32_t pos_rel,
                         const float* vox_feat, const float* rayfeat, int32_t multires,
