@@ -766,7 +766,7 @@ __device__ __forceinline__ float roi_axis_weight(float start, float bin, int n, 
 
 // The boxes clamped at the image border (fractional samples), from the parked image: a workgroup
 // takes a 16 x 16 tile of source pixels on the ring of clamped boxes and one channel, adds the
-// shares of its pixels' four bins into an LDS patch of (16 + 2 half)^2 pixels (LDS float adds) and
+// shares of its pixels' four bins into an LDS patch of (18 + 2 half)^2 pixels (LDS float adds) and
 // flushes the patch with one global add per touched pixel — the boxes of neighbouring border rays
 // overlap almost entirely, a thread per (ray, column) with global adds spent 0.27 ms on 4,416 rays.
 // grid.x = ring tiles (rayfeat_ring_tile), grid.y = B * 32.
@@ -786,7 +786,9 @@ __device__ __forceinline__ void rayfeat_ring_tile(int t, int tx_n, int ty_n, int
 __global__ void __launch_bounds__(256) lidf_rayfeat_backward_ring_kernel(
     const float* __restrict__ gimg, int half, int H, int W, float* __restrict__ d_feat) {
     extern __shared__ float patch[];
-    const int PW = 16 + 2 * half;
+    // (the box of a ray starts half a pixel before column u1: its first samples may fall into
+    // column u1 - 1 — one pixel of margin beyond the boxes on every side)
+    const int PW = 18 + 2 * half;
     for (int i = threadIdx.x; i < PW * PW; i += 256) patch[i] = 0.f;
     __syncthreads();
     const int tx_n = (W + 15) / 16, ty_n = (H + 15) / 16;
@@ -794,7 +796,7 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_backward_ring_kernel(
     rayfeat_ring_tile(blockIdx.x, tx_n, ty_n, tx, ty);
     const int b = blockIdx.y >> 5, c = blockIdx.y & 31;
     const int qx = tx * 16 + (threadIdx.x & 15), qy = ty * 16 + (threadIdx.x >> 4);
-    const int ox = tx * 16 - half, oy = ty * 16 - half;   // patch origin
+    const int ox = tx * 16 - half - 1, oy = ty * 16 - half - 1;   // patch origin
     const bool clampedbox = qx < W && qy < H && (qx < half || qx > W - 1 - half || qy < half || qy > H - 1 - half);
     if (clampedbox) {
         const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
@@ -1004,7 +1006,7 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
     if (aux) {
         const int side = ty_n > 2 ? (tx_n > 1 ? 2 : 1) * (ty_n - 2) : 0;
         const int tiles = (ty_n > 1 ? 2 * tx_n : tx_n) + side;
-        const int PW = 16 + 2 * half;
+        const int PW = 18 + 2 * half;
         hipLaunchKernelGGL(lidf_rayfeat_backward_ring_kernel, dim3(tiles, B * 32), dim3(256),
                            (size_t)PW * PW * 4, st, gimg, half, H, W, d_feat);
     }

@@ -204,3 +204,67 @@ def test_query_gradients_larger_scene_and_run_to_run_identical(cuda):
         close(runs[0]["prob." + k].cpu(), v.grad, "prob." + k)
     for k, v in po.items():
         close(runs[0]["off." + k].cpu(), v.grad, "off." + k)
+
+
+@pytest.mark.parametrize("h,w,bbox", [(17, 23, 8), (18, 35, 8), (40, 50, 4), (33, 48, 16), (9, 9, 8), (8, 8, 8)])
+def test_ray_features_backward_image_shapes(cuda, h, w, bbox):
+    """Every pixel a ray, image sizes that are no multiple of the ring kernel's 16-pixel tiles, a
+    last tile narrower than the ring of clamped boxes ((18, 35): falls back to the atomic path),
+    boxes as wide as the image ((8, 8): every box clamped on both sides)."""
+    from implicit_depth_amd.query import _RayFeaturesFn
+    scene = orc.synthetic_scene(2, h, w, 1, seed=h * 100 + w)
+    s = to_dev(scene, cuda)
+    R = scene["R"]
+    wgt = torch.randn(R, 128, generator=torch.Generator().manual_seed(bbox))
+    fg = scene["feat_grid"].clone().requires_grad_(True)
+    boxes = orc.roi_boxes(scene["ray_pix"].long(), scene["ray_bid"].long(), h, w, bbox)
+    (orc.roi_align_fast(fg, boxes).reshape(R, -1) * wgt).sum().backward()
+    fgd = s["feat_grid"].clone().requires_grad_(True)
+    got = _RayFeaturesFn.apply(fgd, s["ray_dir"], s["ray_pix"], s["ray_bid"], bbox, 4)
+    (got[:, :128] * wgt.to(cuda)).sum().backward()
+    assert (fgd.grad.cpu() - fg.grad).abs().max().item() <= 2e-5 * max(1.0, fg.grad.abs().max().item())
+
+
+def test_query_gradients_other_encoding_widths(cuda):
+    """multires 4 / multires_views 2 (D = 325) and an IMNET offset decoder with sigmoid outputs
+    (offdec_type: IMNET, use_sigmoid, models/pipeline.py:69-71): other layer-1 widths through the
+    chained training forward, the position-embedding rows and the per-ray parts."""
+    from implicit_depth_amd.query import lidf_query_train
+    L, Lv = 4, 2
+    D = 256 + 2 * (3 + 6 * L) + 3 + 6 * Lv
+    scene = orc.synthetic_scene(2, 10, 14, 6, seed=101, ragged=True)
+    R, P = scene["R"], scene["P"]
+    prob_p = orc.randomize_biases(orc.init_decoder("IMNET", D, 102, 5.0), 103)
+    off_p = orc.randomize_biases(orc.init_decoder("IMNET", D, 104, 5.0), 105)
+    gen = torch.Generator().manual_seed(106)
+    w = {"prob": torch.randn(P, generator=gen), "off": torch.randn(P, generator=gen),
+         "pos": torch.randn(R, 3, generator=gen)}
+    kw = dict(multires=L, multires_views=Lv, offset_range=(0.0, 1.0), part_size=0.25)
+    pp = {k: v.clone().requires_grad_(True) for k, v in prob_p.items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in off_p.items()}
+    fg = scene["feat_grid"].clone().requires_grad_(True)
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], fg, vf, pp, po,
+                    off_kind="IMNET", use_sigmoid=True, fast_roi=True, **kw)
+    _loss(ref, w).backward()
+    s = to_dev(scene, cuda)
+    prob = make_module("IMNET", prob_p, D, cuda, use_sigmoid=True).train()
+    off = make_module("IMNET", off_p, D, cuda, use_sigmoid=True).train()
+    fgd = s["feat_grid"].clone().requires_grad_(True)
+    vfd = s["vox_feat"].clone().requires_grad_(True)
+    out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                           s["pair_vox"], s["pair_t"], fgd, vfd, prob, off, **kw)
+    _loss(out, {k: v.to(cuda) for k, v in w.items()}).backward()
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() <= TOL, k
+
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(fgd.grad.cpu(), fg.grad, "feat_grid")
+    close(vfd.grad.cpu(), vf.grad, "vox_feat")
+    for k, v in pp.items():
+        close(dict(prob.named_parameters())[k].grad.cpu(), v.grad, "prob." + k)
+    for k, v in po.items():
+        close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
