@@ -225,15 +225,21 @@ def test_ray_features_backward_image_shapes(cuda, h, w, bbox):
     assert (fgd.grad.cpu() - fg.grad).abs().max().item() <= 2e-5 * max(1.0, fg.grad.abs().max().item())
 
 
-def test_query_gradients_other_encoding_widths(cuda):
-    """multires 4 / multires_views 2 (D = 325) and an IMNET offset decoder with sigmoid outputs
-    (offdec_type: IMNET, use_sigmoid, models/pipeline.py:69-71): other layer-1 widths through the
-    chained training forward, the position-embedding rows and the per-ray parts."""
+@pytest.mark.parametrize("L,Lv,n_vox", [(4, 2, 0), (0, 0, 0), (8, 4, 17000)])
+def test_query_gradients_other_encoding_widths(cuda, L, Lv, n_vox):
+    """multires 4 / multires_views 2 (D = 325), no positional encoding (pos_encode: False, D = 265,
+    models/pipeline.py:44-47) and an IMNET offset decoder with sigmoid outputs (offdec_type: IMNET,
+    use_sigmoid, :69-71): other layer-1 widths through the chained training forward, the
+    position-embedding rows and the per-ray parts. n_vox = 17,000: a voxel table beyond the sorted
+    per-voxel reduction's 16,384 rows (the run-walking atomic form takes over)."""
     from implicit_depth_amd.query import lidf_query_train
-    L, Lv = 4, 2
     D = 256 + 2 * (3 + 6 * L) + 3 + 6 * Lv
     scene = orc.synthetic_scene(2, 10, 14, 6, seed=101, ragged=True)
     R, P = scene["R"], scene["P"]
+    if n_vox:
+        g0 = torch.Generator().manual_seed(107)
+        scene["vox_feat"] = torch.relu(torch.randn(n_vox, 128, generator=g0))
+        scene["pair_vox"] = torch.randint(0, n_vox, (P,), generator=g0, dtype=torch.int32)
     prob_p = orc.randomize_biases(orc.init_decoder("IMNET", D, 102, 5.0), 103)
     off_p = orc.randomize_biases(orc.init_decoder("IMNET", D, 104, 5.0), 105)
     gen = torch.Generator().manual_seed(106)

@@ -28,7 +28,8 @@ def _close(a, b, what):
 
 @pytest.mark.parametrize("kind,d,n,n_iter,sig", [("IMNET", 385, 333, 1, False), ("IEF", 385, 333, 2, False),
                                                   ("IEF", 334, 129, 3, True), ("IMNET", 265, 64, 1, True),
-                                                  ("IEF", 385, 5000, 2, False)])
+                                                  ("IEF", 385, 5000, 2, False), ("IEF", 385, 1, 2, False),
+                                                  ("IMNET", 27, 31, 1, False)])
 def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
     p = orc.randomize_biases(orc.init_decoder(kind, d, 11, 5.0), 12)
     m = make_module(kind, p, d, cuda, n_iter=n_iter, use_sigmoid=sig).train()
