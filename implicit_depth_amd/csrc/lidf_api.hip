@@ -1106,6 +1106,9 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     a.X = X; a.ldx = ldx; a.D = m.D; a.KQ1 = m.KQ1; a.has_bias = m.add_bias;
     a.pair_vox = pair_vox; a.pair_ray = pair_ray; a.voxpart = voxpart; a.raypart = raypart;
     a.tr_passes = passes; a.tr_pass_floats = (long long)n * ACT_ROW_FLOATS; a.tr_pre = pre;
+#ifdef LIDF_PROFILE
+    a.out_base = pre;   // development build: the phase counters land in the first 16 floats
+#endif
     const long long ntile = (n + 127) / 128;
     CHECK_HIP(lidf_launch_points(LIDF_MODE_TRAIN, a, (int)(ntile < cus ? ntile : cus), st));
     return LIDF_OK;

@@ -704,11 +704,32 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
             f32x16 base[8];
 
             // ---------------- layer 1 ----------------
+            // TRAIN with gathered rows: the accumulators start from voxpart[pair_vox] (loaded
+            // straight into them) and the raypart[pair_ray] row is requested now, added after the
+            // matrix instructions of layer 1 — both latencies hide behind them
+            f32x4 rpv[MODE == LIDF_MODE_TRAIN ? 8 : 1][4];
+            const bool gathered = MODE == LIDF_MODE_TRAIN && a.voxpart;
+            if (gathered) {
+                const float* vp = a.voxpart + (size_t)a.pair_vox[pc] * 256 + 4 * h;
+                const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < 8; ++t) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) base[t][i] = 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *(const f32x4*)(vp + 32 * t + 8 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
+                        rpv[MODE == LIDF_MODE_TRAIN ? t : 0][g] = *(const f32x4*)(rp + 32 * t + 8 * g);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) base[t][i] = 0.f;
+                }
             }
+            PROF(0)
             // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
             const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
             auto load_b = [&](int kq, float (&b)[4]) {
@@ -742,6 +763,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                     }
                 }
                 SCHED_FENCE();
+                PROF(1)
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) {
                     const int kq = k0 + i;
@@ -762,30 +784,15 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                 }
             }
 
-            if (MODE == LIDF_MODE_TRAIN && a.voxpart) {
-                // + voxpart[pair_vox] + raypart[pair_ray]: the rows of tile t+1 load while tile t adds
-                const float* vp = a.voxpart + (size_t)a.pair_vox[pc] * 256 + 4 * h;
-                const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
-                f32x4 gv[2][8];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    gv[0][g] = *(const f32x4*)(vp + 8 * g);
-                    gv[0][4 + g] = *(const f32x4*)(rp + 8 * g);
-                }
+            PROF(3)
+            if (gathered) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    if (t + 1 < 8) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            gv[(t + 1) & 1][g] = *(const f32x4*)(vp + 32 * (t + 1) + 8 * g);
-                            gv[(t + 1) & 1][4 + g] = *(const f32x4*)(rp + 32 * (t + 1) + 8 * g);
-                        }
-                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            base[t][4 * g + i] = (base[t][4 * g + i] + gv[t & 1][g][i]) + gv[t & 1][4 + g][i];
+                            base[t][4 * g + i] += rpv[MODE == LIDF_MODE_TRAIN ? t : 0][g][i];
                     }
                 }
             }
@@ -804,6 +811,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                     }
                 }
             } else {
+                PROF(2)
                 // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
                 float val = a.init[net];
                 const int pass_base = nsb + l1_bytes;
@@ -834,6 +842,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                     if (a.out[net]) a.out[net][p] = o;
                     if constexpr (MODE == LIDF_MODE_TRAIN) a.tr_pre[p] = val;
                 }
+                PROF(5)
             }
         }
     }
