@@ -305,7 +305,9 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
         // two workgroups per CU; with a scratch area for the partial blocks the slices are as long
         // as possible (fewer partial sums), without it shorter slices keep the atomics spread
         long long splits = (g_wgrad_scratch ? 512 : 1024) / (mb * nb);
-        const long long max_splits = (n + 1023) / 1024;
+        // (slices of at least 64 rows: a per-ray or per-voxel operand of 76,800 or 729 rows still
+        // fills the chip instead of walking its rows in a few workgroups)
+        const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         w.rows_per_split = ((n + splits - 1) / splits + 7) / 8 * 8;
