@@ -309,17 +309,22 @@ extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, 
 // (models/pipeline.py:442-454) on ray-major CSR pairs: one wavefront per ray, wave-level
 // shuffles for max, sum and arg-max. Ties: lowest pair index. Empty ray: id = P, pos = 0.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
+// G lanes per ray: 64 (a wavefront) for long candidate lists, 8 for short ones (a geometry-derived
+// frame has 3-4 pairs per ray: a wavefront per ray would idle 60 of its lanes).
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    for (int s = G / 2; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    for (int s = G / 2; s >= 1; s >>= 1) v += __shfl_xor(v, s);
     return v;
 }
 
+template <int G>
 __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        const float* __restrict__ pos,
                                        const int* __restrict__ off, long long R, long long P,
@@ -327,19 +332,20 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        const int* __restrict__ ray_flat, long long hw,
                                        float* __restrict__ softmax, long long* __restrict__ maxid,
                                        float* __restrict__ pred_pos, float* __restrict__ depth) {
-    const int lane = threadIdx.x & 63;
-    const long long ray = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ray >= R) return;
-    const int beg = off[ray], end = off[ray + 1];
+    const int lane = threadIdx.x & (G - 1);
+    const long long ray = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    // (a whole group shares `ray`; groups beyond R idle through the shuffles with an empty range)
+    const bool live = ray < R;
+    const int beg = live ? off[ray] : 0, end = live ? off[ray + 1] : 0;
     float m = -INFINITY;
-    for (int i = beg + lane; i < end; i += 64) m = fmaxf(m, prob[i]);
-    m = wave_max(m);
+    for (int i = beg + lane; i < end; i += G) m = fmaxf(m, prob[i]);
+    m = group_max<G>(m);
     float s = 0.f;
-    for (int i = beg + lane; i < end; i += 64) s += expf(prob[i] - m);
-    s = wave_sum(s);
+    for (int i = beg + lane; i < end; i += G) s += expf(prob[i] - m);
+    s = group_sum<G>(s);
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = beg + lane; i < end; i += 64) {
+    for (int i = beg + lane; i < end; i += G) {
         const float v = expf(prob[i] - m) / s;
         if (softmax) softmax[i] = v;
         if (v > bv) {  // ascending i per lane: strict > keeps the first on ties
@@ -348,7 +354,7 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
         }
     }
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
+    for (int sh = G / 2; sh >= 1; sh >>= 1) {
         const float ov = __shfl_xor(bv, sh);
         const int oi = __shfl_xor(bi, sh);
         if (ov > bv || (ov == bv && oi < bi)) {
@@ -356,7 +362,7 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
             bi = oi;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         // no candidate, or no softmax value compared greater than -inf (NaN / +-inf logits make
         // every value NaN): torch_scatter's scatter_max leaves its out-of-range index then, which
         // selects the dummy row (pipeline.py:452-454) -> id = P, position (0,0,0)
@@ -383,9 +389,12 @@ extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos
                                              long long* maxid, float* pred_pos, float* depth,
                                              hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_ray_reduce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st,
-                       prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos,
-                       depth);
+    if (P <= 8 * R)
+        hipLaunchKernelGGL(lidf_ray_reduce_kernel<8>, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, st,
+                           prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos, depth);
+    else
+        hipLaunchKernelGGL(lidf_ray_reduce_kernel<64>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st,
+                           prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos, depth);
     return hipGetLastError();
 }
 

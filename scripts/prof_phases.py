@@ -31,6 +31,21 @@ scene = orc.synthetic_scene(1, 240, 320, 64, seed=1235, ragged=kind == "ragged")
 s = to_dev(scene, dev)
 prob = make_module("IMNET", scene["prob_p"], 385, dev)
 off = make_module("IEF", scene["off_p"], 385, dev)
+if kind == "scene":
+    # rays, voxels and pairs as the candidate generator produces them on a geometry-derived frame
+    from implicit_depth_amd import PointNet2Stage, pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    batch, feat = synthetic_batch(1, 240, 320, seed=77)
+    torch.manual_seed(3)
+    pn = PointNet2Stage(6, 128, 32).to(dev).eval()
+    with torch.no_grad():
+        ok, dd = pl.lidf_forward({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()},
+                                 feat.to(dev), pn, prob, off)
+    s.update({"ray_dir": dd["miss_ray_dir"], "ray_pix": dd["ray_pix"], "ray_bid": dd["ray_bid"],
+              "ray_flat": dd["ray_flat"], "pair_off": dd["pair_off"], "pair_ray": dd["pair_ray"],
+              "pair_vox": dd["pair_vox"], "pair_t": dd["pair_t"], "feat_grid": dd["full_rgb_feat"],
+              "vox_feat": dd["occ_voxel_feat"]})
+    scene = dict(scene, P=int(dd["pair_ray"].shape[0]))
 hev = HipEvents()
 e0, e1 = hev.create(), hev.create()
 with torch.no_grad():
