@@ -42,6 +42,12 @@ hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long l
                                 hipStream_t);
 hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
 hipError_t lidf_launch_axpy(const float*, long long, float*, hipStream_t);
+hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, const float*, const float*,
+                                     const float*, const float*, float*, hipStream_t);
+size_t lidf_pointnet_chain_stream_bytes(void);
+hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int*, const float*, float*,
+                                      float*, long long, long long, int, hipStream_t);
+size_t lidf_pointnet_pool_scratch_bytes(long long);
 hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const float*, const float*,
                                    long long, float, float*, float*, float*, int, hipStream_t);
 hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
@@ -751,7 +757,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
 }
 
 struct PnetWs {
-    size_t s[7], f1, f2, pool1, g1, gpart, f4, pool2, total;
+    size_t s[7], chain, f1, f2, pool1, g1, gpart, f4, pool2, part, part_bytes, total;
 };
 static PnetWs pnet_ws(int64_t n, int64_t v) {
     PnetWs w;
@@ -759,14 +765,18 @@ static PnetWs pnet_ws(int64_t n, int64_t v) {
     const int ks[7] = {6, 32, 64, 64, 64, 128, 128};
     const int nts[7] = {1, 2, 2, 4, 4, 4, 4};
     for (int i = 0; i < 7; ++i) { w.s[i] = o; o += lin_stream_bytes(ks[i], nts[i]); }
+    w.chain = o; o += align_up(lidf_pointnet_chain_stream_bytes(), 256);
     const size_t N = (size_t)(n > 0 ? n : 1), V = (size_t)(v > 0 ? v : 1);
-    w.f1 = o;    o += align_up(N * 32 * 4, 256);
-    w.f2 = o;    o += align_up(N * 64 * 4, 256);
+    // (no per-point intermediates: the inference chains keep them in registers; f1 marks the end of
+    // the stream slots)
+    w.f1 = o; w.f2 = o; w.f4 = o;
+    (void)N;
     w.pool1 = o; o += align_up(V * 64 * 4, 256);
     w.g1 = o;    o += align_up(V * 64 * 4, 256);
     w.gpart = o; o += align_up(V * 128 * 4, 256);
-    w.f4 = o;    o += align_up(N * 128 * 4, 256);
     w.pool2 = o; o += align_up(V * 128 * 4, 256);
+    w.part_bytes = lidf_pointnet_pool_scratch_bytes(v);
+    w.part = o;  o += align_up(w.part_bytes, 256);
     w.total = o;
     return w;
 }
@@ -787,6 +797,8 @@ static int check_pointnet_w(const LidfPointNet* w) {
 struct PnetBufs {
     float *f1, *f2, *pool1, *g1, *gpart, *f4, *f5, *pool2;
     float* streams[7];
+    float* chain;   // stream of the per-point chains (inference)
+    float* part;    // slabs of the LDS pooling path (NULL: global atomic maxima)
 };
 
 // mode 0: pack the weight streams and run; 1: pack only (lidf_pointnet_pack_f32); 2: run on
@@ -801,6 +813,25 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
         CHECK_HIP(hipMemsetAsync(b.pool1, 0, (size_t)n_vox * 64 * 4, st));
         CHECK_HIP(hipMemsetAsync(b.pool2, 0, (size_t)n_vox * 128 * 4, st));
     }
+    if (!b.f5) {
+        // inference: the per-point layers are two register chains (lidf_pointnet.hip), no per-point
+        // intermediate is written; the per-voxel layers stay launches over V rows
+        if (!pp)
+            CHECK_HIP(lidf_launch_pack_pointnet(w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_p3, w->w_p4,
+                                                w->b_p4, b.chain, st));
+        if (!po) CHECK_HIP(lidf_launch_pointnet_chain(1, b.chain, inp, vox, nullptr, b.pool1, b.part, n_vox, n, cus, st));
+        if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
+                             b.g1, 64, nullptr, nullptr, b.streams[2], cus, st, po, pp)))
+            return rc;
+        // gpart[v] = W3[:, :64] g1[v] + b3: what the layer-3 accumulators of a point start from
+        if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, b.g1, 64, n_vox, nullptr, nullptr, 0,
+                             b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st, po, pp)))
+            return rc;
+        if (!po) CHECK_HIP(lidf_launch_pointnet_chain(2, b.chain, inp, vox, b.gpart, b.pool2, b.part, n_vox, n, cus, st));
+        return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, b.pool2, 128, n_vox, nullptr, nullptr, 1,
+                          out, 128, nullptr, nullptr, b.streams[6], cus, st, po, pp);
+    }
+    // with the rows kept (training forward): layer by layer
     // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
     if ((rc = run_linear({w->w_p1, w->b_p1, 32, 6, 0, 6}, inp, 6, n, nullptr, nullptr, 1, b.f1, 32,
                          nullptr, nullptr, b.streams[0], cus, st, po, pp)))
@@ -847,12 +878,14 @@ LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const in
     b.f5 = nullptr; b.pool2 = (float*)(base + ws.pool2);
     for (int i = 0; i < 7; ++i)
         b.streams[i] = w->packed ? (float*)((char*)w->packed + ws.s[i]) : (float*)(base + ws.s[i]);
+    b.chain = w->packed ? (float*)((char*)w->packed + ws.chain) : (float*)(base + ws.chain);
+    b.part = ws.part_bytes ? (float*)(base + ws.part) : nullptr;
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     return pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, (hipStream_t)stream, w->packed ? 2 : 0);
 }
 
-LIDF_API size_t lidf_pointnet_pack_bytes(void) { return pnet_ws(1, 1).f1; }   // the 7 stream slots
+LIDF_API size_t lidf_pointnet_pack_bytes(void) { return pnet_ws(1, 1).f1; }   // the stream slots
 
 LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
                                       lidf_stream_t stream) {
@@ -862,6 +895,7 @@ LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t 
     const PnetWs ws = pnet_ws(1, 1);
     PnetBufs b = {};
     for (int i = 0; i < 7; ++i) b.streams[i] = (float*)((char*)packed + ws.s[i]);
+    b.chain = (float*)((char*)packed + ws.chain);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     return pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1);

@@ -1,0 +1,401 @@
+// lidf_pointnet.hip — the per-point chains of PointNet2Stage (gfx950 / CDNA4), inference.
+//
+// models/pointnet.py:22-38 (called at models/pipeline.py:149-160 and, twice per frame, :1009-1016):
+//   f1 = relu(point_lin1(inp))            6 -> 32
+//   f2 = relu(point_lin2(f1))            32 -> 64      pool1[v] = max over the voxel's points of f2
+//   g1 = relu(vox_lin1(pool1))           per voxel
+//   f4 = relu(point_lin3(cat(g1[vox], f2)))   128 -> 128
+//   f5 = relu(point_lin4(f4))           128 -> 128     pool2[v] = max over the voxel's points of f5
+//   out = relu(vox_lin2(pool2))          per voxel
+// The per-voxel layers are launches over V rows (lidf_linear_kernel). The per-point layers were one
+// launch per layer with every intermediate ([n,32], [n,64], [n,128]) written and read back; here
+// they are two register chains in the accumulator layout of the decoder kernel (lidf_points.hip:
+// a layer's 32 x 32 output tile is the next layer's B operand):
+//   stage 1:  inp -> f1 -> f2 -> pool1
+//   stage 2:  inp -> f1 -> f2 (recomputed: 38 matrix instructions) -> f4 -> f5 -> pool2
+// with W3[:, :64] g1[v] + b3 as a gathered per-voxel row (gpart). No per-point intermediate touches
+// memory; per point 24 B in (+ the voxel index), nothing out but the pooled maxima.
+//
+// Stream (lidf_pack_pointnet_kernel), 1 KiB quads consumed in order through an 8-deep ring:
+//   P1  1 quad            K = 6 inputs + bias (operand columns 4h + {0..3}: 6 = 1.0, 7 = 0)
+//   P2  2 x 5 quads       K = 32 + bias, quad = 2 kq + t
+//   P3  4 x 8 quads       K = 64 (second half of W3's columns), quad = 8 T + kq   [stage 2]
+//   P4  4 x 17 quads      K = 128 + bias, quad = 17 T + kq                         [stage 2]
+//   (+ 1 padding quad)
+// Max-pool (values are post-ReLU, >= 0: their bit patterns order like integers, 0 is the identity):
+//  * voxel table small enough for LDS (V x F floats <= 144 KiB — a frame has 50-150 occupied
+//    voxels): every lane takes the integer maximum of its values into the workgroup's LDS table,
+//    the workgroup writes the table to its slab of a scratch array, lidf_pointnet_poolmax_kernel
+//    takes the maximum over the slabs. No global atomics: with ~2,000 points per voxel they all
+//    land on the same few hundred addresses and were 80 % of the PointNet's time.
+//  * otherwise as in lidf_linear.hip: the wave reduces per distinct voxel of its 32 rows, one lane
+//    issues global integer atomic maxima where a plain read does not already prove them unnecessary.
+#include "lidf_device.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define LDQ(rs, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
+
+#define PN_P1 1
+#define PN_P2 10
+#define PN_P3 32
+#define PN_P4 68
+// per tile a stage walks a multiple of the ring's 8 quads, so that the ring slot of quad 0 is the
+// same for every tile (stage 1 skips over five quads of P3, stage 2 over one padding quad)
+#define PN_S1_QUADS 16
+#define PN_S2_QUADS 112
+static_assert(PN_P1 + PN_P2 <= PN_S1_QUADS && PN_P1 + PN_P2 + PN_P3 + PN_P4 <= PN_S2_QUADS, "stream");
+static_assert(PN_S1_QUADS % LIDF_RING == 0 && PN_S2_QUADS % LIDF_RING == 0, "ring phase");
+
+struct PnetW {
+    const float *w_p1, *b_p1, *w_p2, *b_p2, *w_p3, *w_p4, *b_p4;
+};
+struct PnetChainArgs {
+    const float* stream;   // PN_S2_QUADS KiB
+    const float* inp;      // [n,6]
+    const int* vox;        // [n] (negative: the row is left out)
+    const float* gpart;    // [V,128] = W3[:, :64] g1 + b3 (stage 2)
+    float* pool;           // stage 1: [V,64], stage 2: [V,128]  (global-atomic path; zeroed)
+    float* part;           // LDS path: [gridDim.x, V * F] slabs
+    int V;
+    long long n;
+};
+
+__device__ __forceinline__ int pn_feature(int s, int half) {
+    const int T = s >> 4, r = s & 15;
+    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+__global__ void lidf_pack_pointnet_kernel(PnetW w, float* __restrict__ stream) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= PN_S2_QUADS * 256) return;
+    int quad = e / 256;
+    const int lane = (e % 256) / 4, jj = e & 3;
+    const int half = lane >> 5, c32 = lane & 31;
+    float v = 0.f;
+    if (quad < PN_P1) {
+        const int x = 4 * half + jj;                       // operand column
+        if (x < 6) v = w.w_p1[c32 * 6 + x];
+        else if (x == 6) v = w.b_p1[c32];
+    } else if (quad < PN_P1 + PN_P2) {
+        quad -= PN_P1;
+        const int kq = quad / 2, t = quad % 2, s = 4 * kq + jj, out = 32 * t + c32;
+        if (s < 16) v = w.w_p2[out * 32 + pn_feature(s, half)];
+        else if (s == 16 && half == 0) v = w.b_p2[out];
+    } else if (quad < PN_P1 + PN_P2 + PN_P3) {
+        quad -= PN_P1 + PN_P2;
+        const int T = quad / 8, kq = quad % 8, s = 4 * kq + jj, out = 32 * T + c32;
+        v = w.w_p3[out * 128 + 64 + pn_feature(s, half)];  // columns 64..127 multiply f2
+    } else if (quad < PN_P1 + PN_P2 + PN_P3 + PN_P4) {
+        quad -= PN_P1 + PN_P2 + PN_P3;
+        const int T = quad / 17, kq = quad % 17, s = 4 * kq + jj, out = 32 * T + c32;
+        if (s < 64) v = w.w_p4[out * 128 + pn_feature(s, half)];
+        else if (s == 64 && half == 0) v = w.b_p4[out];
+    }
+    stream[e] = v;
+}
+
+__device__ __forceinline__ void pn_relu(f32x16& v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+}
+
+// max-pool the NT tiles of `acc` (row = lane & 31 of this wavefront) into pool[vox, 32 T0 ...]
+template <int NT>
+__device__ __forceinline__ void pn_pool(const f32x16 (&acc)[NT], const int T0, const int vox,
+                                        const bool valid, float* pool, const int ld, const int h,
+                                        const int col) {
+    unsigned todo = (unsigned)__ballot(valid && h == 0 && vox >= 0);
+    int rounds = 0;
+    while (todo && rounds < 4) {
+        const int lead = __builtin_ctz(todo);
+        const int vv = __builtin_amdgcn_readlane(vox, lead);
+        const unsigned mem = (unsigned)__ballot(vox == vv) & todo;
+        todo &= ~mem;
+        ++rounds;
+        const bool mine = vox == vv;
+        int* pp = (int*)pool + (size_t)vv * ld + 32 * T0 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 m;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = mine ? acc[t][4 * g + i] : 0.f;
+#pragma unroll
+                    for (int sft = 16; sft >= 1; sft >>= 1) x = fmaxf(x, __shfl_xor(x, sft));
+                    m[i] = x;
+                }
+                if (col == lead) {
+                    const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (m[i] > seen[i]) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(m[i]));
+                }
+            }
+        }
+    }
+    if (todo && valid && ((todo >> col) & 1u)) {   // more than four distinct voxels: per lane
+        int* pp = (int*)pool + (size_t)vox * ld + 32 * T0 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (acc[t][4 * g + i] > seen[i])
+                        atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(acc[t][4 * g + i]));
+            }
+        }
+    }
+}
+
+// lane-level integer maxima of one accumulator tile into the LDS table row of the lane's voxel
+__device__ __forceinline__ void pn_pool_lds(const f32x16& acc, const int T, const int vox,
+                                            const bool valid, int* tab, const int F, const int h) {
+    if (!valid || vox < 0) return;
+    int* row = tab + vox * F + 32 * T + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = acc[4 * g + i];
+            if (v > 0.f) atomicMax(row + 8 * g + i, __float_as_int(v));
+        }
+    }
+}
+
+template <int STAGE, bool LDSPOOL>
+__global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainArgs a) {
+    extern __shared__ int pn_tab[];
+    constexpr int F = STAGE == 1 ? 64 : 128;
+    if (LDSPOOL) {
+        for (int i = threadIdx.x; i < a.V * F; i += 256) pn_tab[i] = 0;
+        __syncthreads();
+    }
+    constexpr int NQ = STAGE == 1 ? PN_S1_QUADS : PN_S2_QUADS;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const float one_b = h ? 0.f : 1.f;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, PN_S2_QUADS * 1024, 0x00020000);
+    const int vq = lane * 16;
+    const long long ntile = (a.n + 127) / 128;
+    const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
+    const long long bx = blockIdx.x;
+    const long long tb = bx * per + (bx < rem ? bx : rem);
+    const long long te = tb + per + (bx < rem ? 1 : 0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ring[LIDF_RING];
+#pragma unroll
+    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+
+    for (long long tile = tb; tile < te; ++tile) {
+        if (tile * 128 + wave * 32 >= a.n) break;   // wave-uniform
+        const long long p = tile * 128 + wave * 32 + col;
+        const bool valid = p < a.n;
+        const long long pc = valid ? p : a.n - 1;
+        const int vox = a.vox[pc];
+        // operand columns of this lane: 4h + {0..3} of [x0..x5, 1, 0]
+        float b1[4];
+        {
+            const float* x = a.inp + (size_t)pc * 6;
+            if (h == 0) {
+                b1[0] = x[0]; b1[1] = x[1]; b1[2] = x[2]; b1[3] = x[3];
+            } else {
+                b1[0] = x[4]; b1[1] = x[5]; b1[2] = 1.f; b1[3] = 0.f;
+            }
+        }
+        // stage 2: the gathered per-voxel row the layer-3 accumulators start from
+        f32x16 F4[STAGE == 2 ? 4 : 1];
+        if (STAGE == 2) {
+            const float* gp = a.gpart + (size_t)(vox >= 0 ? vox : 0) * 128 + 4 * h;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *(const f32x4*)(gp + 32 * T + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) F4[STAGE == 2 ? T : 0][4 * g + i] = v[i];
+                }
+            }
+        }
+        SCHED_FENCE();
+
+        f32x16 F1, F2[2], acc;
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+            const f32x4 aq = ring[s % LIDF_RING];
+            {
+                const int nx = s + LIDF_RING;
+                const int rel = nx < NQ ? nx : nx - NQ;   // wraps: the same stream for the next tile
+                ring[s % LIDF_RING] = LDQ(srs, vq + (rel & 3) * 1024, (rel >> 2) * 4096);
+            }
+            if (s < PN_P1) {
+                F1 = MFMA(aq[0], b1[0], zero16);
+                F1 = MFMA(aq[1], b1[1], F1);
+                F1 = MFMA(aq[2], b1[2], F1);
+                F1 = MFMA(aq[3], b1[3], F1);
+                pn_relu(F1);
+            } else if (s < PN_P1 + PN_P2) {
+                const int q = s - PN_P1, kq = q / 2, t = q % 2;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int k = 4 * kq + jj;
+                    if (k < 16) F2[t] = MFMA(aq[jj], F1[k], k == 0 ? zero16 : F2[t]);
+                    else if (k == 16) F2[t] = MFMA(aq[jj], one_b, F2[t]);
+                }
+                if (kq == 4) pn_relu(F2[t]);
+            } else if (STAGE == 2 && s < PN_P1 + PN_P2 + PN_P3) {
+                const int q = s - PN_P1 - PN_P2, T = q / 8, kq = q % 8;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int k = 4 * kq + jj;
+                    F4[STAGE == 2 ? T : 0] = MFMA(aq[jj], F2[k / 16][k % 16], F4[STAGE == 2 ? T : 0]);
+                }
+                if (kq == 7) pn_relu(F4[STAGE == 2 ? T : 0]);
+            } else if (STAGE == 2 && s < PN_P1 + PN_P2 + PN_P3 + PN_P4) {
+                const int q = s - PN_P1 - PN_P2 - PN_P3, T = q / 17, kq = q % 17;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int k = 4 * kq + jj;
+                    if (k < 64) acc = MFMA(aq[jj], F4[STAGE == 2 ? k / 16 : 0][k % 16], k == 0 ? zero16 : acc);
+                    else if (k == 64) acc = MFMA(aq[jj], one_b, acc);
+                }
+                if (kq == 16) {
+                    pn_relu(acc);
+                    if (LDSPOOL) {
+                        pn_pool_lds(acc, T, vox, valid, pn_tab, 128, h);
+                    } else {
+                        const f32x16 one[1] = {acc};
+                        pn_pool<1>(one, T, vox, valid, a.pool, 128, h, col);
+                    }
+                }
+            }
+            SCHED_FENCE();
+        }
+        if (STAGE == 1) {
+            if (LDSPOOL) {
+                pn_pool_lds(F2[0], 0, vox, valid, pn_tab, 64, h);
+                pn_pool_lds(F2[1], 1, vox, valid, pn_tab, 64, h);
+            } else {
+                pn_pool<2>(F2, 0, vox, valid, a.pool, 64, h, col);
+            }
+        }
+    }
+    if (LDSPOOL) {
+        __syncthreads();
+        f32x4* dst = (f32x4*)(a.part + (size_t)blockIdx.x * a.V * F);
+        const f32x4* src = (const f32x4*)pn_tab;
+        for (int i = threadIdx.x; i < a.V * F / 4; i += 256) dst[i] = src[i];
+    }
+}
+
+// pool[e] = max over the G slabs (entries are >= 0): a workgroup owns 64 entries (16 float4), thread
+// (k, c) takes every 16th slab of its float4 with eight loads in flight, the sixteen partial maxima
+// are combined through LDS.
+__global__ void __launch_bounds__(256) lidf_pointnet_poolmax_kernel(const float* __restrict__ part, int G,
+                                                                    long long count,
+                                                                    float* __restrict__ pool) {
+    __shared__ f32x4 red[16][16];
+    const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const long long e = ((long long)blockIdx.x * 16 + c) * 4;
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    if (e < count) {
+        int g = k;
+        for (; g + 112 < G; g += 128) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(part + (size_t)(g + 16 * j) * count + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], v[j][i]);
+            }
+        }
+        for (; g < G; g += 16) {
+            const f32x4 v = *(const f32x4*)(part + (size_t)g * count + e);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+    }
+    red[k][c] = m;
+    __syncthreads();
+    if (k == 0 && e < count) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], red[j][c][i]);
+        }
+        *(f32x4*)(pool + e) = m;
+    }
+}
+
+extern "C" hipError_t lidf_launch_pack_pointnet(const float* w_p1, const float* b_p1,
+                                                const float* w_p2, const float* b_p2,
+                                                const float* w_p3, const float* w_p4,
+                                                const float* b_p4, float* stream, hipStream_t st) {
+    PnetW w = {w_p1, b_p1, w_p2, b_p2, w_p3, w_p4, b_p4};
+    hipLaunchKernelGGL(lidf_pack_pointnet_kernel, dim3(PN_S2_QUADS), dim3(256), 0, st, w, stream);
+    return hipGetLastError();
+}
+
+extern "C" size_t lidf_pointnet_chain_stream_bytes(void) { return (size_t)PN_S2_QUADS * 1024; }
+
+// Slabs of the LDS pooling path: PN_MAX_WGS x V x 128 floats when the table fits, else 0.
+#define PN_MAX_WGS 512
+#define PN_LDS_LIMIT (144 * 1024)
+extern "C" size_t lidf_pointnet_pool_scratch_bytes(long long V) {
+    if (V <= 0 || (size_t)V * 128 * 4 > PN_LDS_LIMIT) return 0;
+    return (size_t)PN_MAX_WGS * V * 128 * 4;
+}
+
+// stage 1: pool = pool1 [V,64]; stage 2: gpart [V,128], pool = pool2 [V,128]. With `part`
+// (lidf_pointnet_pool_scratch_bytes(V) bytes, non-zero) the pooling goes through LDS tables and
+// `pool` is written; without, `pool` must be zeroed and takes global atomic maxima.
+extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream, const float* inp,
+                                                 const int* vox, const float* gpart, float* pool,
+                                                 float* part, long long V, long long n, int cus,
+                                                 hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    PnetChainArgs a;
+    a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n;
+    a.part = part; a.V = (int)V;
+    const int F = stage == 1 ? 64 : 128;
+    const long long ntile = (n + 127) / 128;
+    const size_t lds = (size_t)V * F * 4;
+    if (part && lidf_pointnet_pool_scratch_bytes(V) != 0) {
+        // two workgroups per CU while two tables fit, else one
+        long long g = lds <= 65536 ? 2LL * cus : cus;
+        if (g > PN_MAX_WGS) g = PN_MAX_WGS;
+        if (g > ntile) g = ntile;
+        hipError_t e;
+        if (stage == 1) {
+            e = hipFuncSetAttribute((const void*)lidf_pointnet_chain_kernel<1, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PN_LDS_LIMIT);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), lds, st, a);
+        } else {
+            e = hipFuncSetAttribute((const void*)lidf_pointnet_chain_kernel<2, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PN_LDS_LIMIT);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
+        }
+        const long long count = V * F;
+        hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
+                           st, part, (int)g, count, pool);
+        return hipGetLastError();
+    }
+    const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
+    if (stage == 1)
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, false>), dim3((unsigned)g), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
