@@ -57,8 +57,8 @@ struct PnetChainArgs {
     const int* vox;        // [n] (negative: the row is left out)
     const float* gpart;    // [V,128] = W3[:, :64] g1 + b3 (stage 2)
     float* pool;           // stage 1: [V,64], stage 2: [V,128]  (global-atomic path; zeroed)
-    float* part;           // LDS path: [gridDim.x, V * F] slabs
-    int V;
+    float* part;           // LDS path: [gridDim.x, V * F] slabs; atomic path: [copies, V * F] (zeroed)
+    int V, copies;
     long long n;
 };
 
@@ -116,37 +116,58 @@ __device__ __forceinline__ void pn_pool(const f32x16 (&acc)[NT], const int T0, c
         ++rounds;
         const bool mine = vox == vv;
         int* pp = (int*)pool + (size_t)vv * ld + 32 * T0 + 4 * h;
+        // what the table holds now (plain, possibly stale reads — entries only grow), requested in
+        // one batch before the shuffles so that the round waits for memory once
+        f32x4 seen[NT][4];
+        if (col == lead) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) seen[t][g] = *(const f32x4*)(pp + t * 32 + 8 * g);
+            }
+        }
+        f32x4 m[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 m;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x = mine ? acc[t][4 * g + i] : 0.f;
 #pragma unroll
                     for (int sft = 16; sft >= 1; sft >>= 1) x = fmaxf(x, __shfl_xor(x, sft));
-                    m[i] = x;
+                    m[t][g][i] = x;
                 }
-                if (col == lead) {
-                    const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+            }
+        }
+        if (col == lead) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (m[i] > seen[i]) atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(m[i]));
+                        if (m[t][g][i] > seen[t][g][i])
+                            atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(m[t][g][i]));
                 }
             }
         }
     }
     if (todo && valid && ((todo >> col) & 1u)) {   // more than four distinct voxels: per lane
         int* pp = (int*)pool + (size_t)vox * ld + 32 * T0 + 4 * h;
+        f32x4 seen[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) seen[t][g] = *(const f32x4*)(pp + t * 32 + 8 * g);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (acc[t][4 * g + i] > seen[i])
+                    if (acc[t][4 * g + i] > seen[t][g][i])
                         atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(acc[t][4 * g + i]));
             }
         }
@@ -177,6 +198,10 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         __syncthreads();
     }
     constexpr int NQ = STAGE == 1 ? PN_S1_QUADS : PN_S2_QUADS;
+    // global-atomic path: the workgroup's copy of the table (thousands of wavefronts raising the
+    // same few rows serialise on their addresses; `copies` tables divide that, a reduce follows)
+    float* const gpool = (!LDSPOOL && a.copies > 0)
+                             ? a.part + (size_t)(blockIdx.x % a.copies) * a.V * F : a.pool;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
@@ -229,6 +254,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         SCHED_FENCE();
 
         f32x16 F1, F2[2], acc;
+        f32x16 F5[(STAGE == 2 && !LDSPOOL) ? 4 : 1];   // global-atomic path: pooled once per tile row
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
             const f32x4 aq = ring[s % LIDF_RING];
@@ -270,22 +296,22 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
                 }
                 if (kq == 16) {
                     pn_relu(acc);
-                    if (LDSPOOL) {
-                        pn_pool_lds(acc, T, vox, valid, pn_tab, 128, h);
-                    } else {
-                        const f32x16 one[1] = {acc};
-                        pn_pool<1>(one, T, vox, valid, a.pool, 128, h, col);
-                    }
+                    if (LDSPOOL) pn_pool_lds(acc, T, vox, valid, pn_tab, 128, h);
+                    else F5[(STAGE == 2 && !LDSPOOL) ? T : 0] = acc;
                 }
             }
             SCHED_FENCE();
+        }
+        if (STAGE == 2 && !LDSPOOL) {
+            // (a zero-length array type is avoided: the template instantiates F5[1] elsewhere)
+            pn_pool<(STAGE == 2 && !LDSPOOL) ? 4 : 1>(F5, 0, vox, valid, gpool, 128, h, col);
         }
         if (STAGE == 1) {
             if (LDSPOOL) {
                 pn_pool_lds(F2[0], 0, vox, valid, pn_tab, 64, h);
                 pn_pool_lds(F2[1], 1, vox, valid, pn_tab, 64, h);
             } else {
-                pn_pool<2>(F2, 0, vox, valid, a.pool, 64, h, col);
+                pn_pool<2>(F2, 0, vox, valid, gpool, 64, h, col);
             }
         }
     }
@@ -348,17 +374,25 @@ extern "C" hipError_t lidf_launch_pack_pointnet(const float* w_p1, const float* 
 
 extern "C" size_t lidf_pointnet_chain_stream_bytes(void) { return (size_t)PN_S2_QUADS * 1024; }
 
-// Slabs of the LDS pooling path: PN_MAX_WGS x V x 128 floats when the table fits, else 0.
+// Scratch of the pooling: PN_MAX_WGS slabs of V x 128 floats when the table fits LDS, else up to
+// PN_COPIES copies of the table for the global-atomic path (at most 32 MiB).
 #define PN_MAX_WGS 512
 #define PN_LDS_LIMIT (144 * 1024)
+#define PN_COPIES 16
+static int pn_copies(long long V) {
+    long long c = (32LL << 20) / (V * 512);
+    return (int)(c > PN_COPIES ? PN_COPIES : (c < 1 ? 1 : c));
+}
 extern "C" size_t lidf_pointnet_pool_scratch_bytes(long long V) {
-    if (V <= 0 || (size_t)V * 128 * 4 > PN_LDS_LIMIT) return 0;
+    if (V <= 0) return 0;
+    if ((size_t)V * 128 * 4 > PN_LDS_LIMIT) return (size_t)pn_copies(V) * V * 128 * 4;
     return (size_t)PN_MAX_WGS * V * 128 * 4;
 }
 
 // stage 1: pool = pool1 [V,64]; stage 2: gpart [V,128], pool = pool2 [V,128]. With `part`
-// (lidf_pointnet_pool_scratch_bytes(V) bytes, non-zero) the pooling goes through LDS tables and
-// `pool` is written; without, `pool` must be zeroed and takes global atomic maxima.
+// (lidf_pointnet_pool_scratch_bytes(V) bytes) `pool` is written: through per-workgroup LDS tables
+// when V x 128 floats fit, else through a few zeroed copies of the table that take global atomic
+// maxima; without `part`, `pool` itself must be zeroed and takes the atomic maxima.
 extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream, const float* inp,
                                                  const int* vox, const float* gpart, float* pool,
                                                  float* part, long long V, long long n, int cus,
@@ -366,11 +400,12 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
     if (n <= 0) return hipSuccess;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n;
-    a.part = part; a.V = (int)V;
+    a.part = part; a.V = (int)V; a.copies = 0;
     const int F = stage == 1 ? 64 : 128;
+    const long long count = V * F;
     const long long ntile = (n + 127) / 128;
     const size_t lds = (size_t)V * F * 4;
-    if (part && lidf_pointnet_pool_scratch_bytes(V) != 0) {
+    if (part && (size_t)V * 128 * 4 <= PN_LDS_LIMIT) {
         // two workgroups per CU while two tables fit, else one
         long long g = lds <= 65536 ? 2LL * cus : cus;
         if (g > PN_MAX_WGS) g = PN_MAX_WGS;
@@ -387,15 +422,22 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
         }
-        const long long count = V * F;
         hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
                            st, part, (int)g, count, pool);
         return hipGetLastError();
+    }
+    if (part) {
+        a.copies = pn_copies(V);
+        hipError_t e = hipMemsetAsync(part, 0, (size_t)a.copies * count * 4, st);
+        if (e != hipSuccess) return e;
     }
     const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
     if (stage == 1)
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, false>), dim3((unsigned)g), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g), dim3(256), 0, st, a);
+    if (part)
+        hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
+                           st, part, a.copies, count, pool);
     return hipGetLastError();
 }

@@ -10,7 +10,10 @@ from util import TOL, closed_form_params, closed_form_pointnet, make_module, mak
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,v", [(5000, 60), (131, 7), (1, 1), (40, 300)])
+# (70000, 50): more 128-point tiles than workgroups — a wavefront walks several tiles and the weight
+# ring wraps; (40, 300) and (90000, 400): a voxel table beyond the LDS pooling path (copies of the
+# table + atomic maxima); the others pool through the per-workgroup LDS tables
+@pytest.mark.parametrize("n,v", [(5000, 60), (131, 7), (1, 1), (40, 300), (70000, 50), (90000, 400)])
 def test_pointnet_vs_oracle(cuda, n, v):
     g = torch.Generator().manual_seed(n + v)
     p = orc.init_pointnet(7, 1.5)
