@@ -17,22 +17,17 @@ __device__ __forceinline__ bool inside_box(float x, float y, float z, const floa
 //   pnet_inp  = [pred_pos - centre(end_voxel) | rgb(pixel)]   (:975-986, pnet_pos_type 'rel')
 //   inp_embed[:, 128:] = [ROI feature | embed(pos) | embed(dir)]   (:947-969, :1019-1026);
 //   columns 0..127 (voxel feature) are filled after the PointNet pass.
-__global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
-                                        const long long* __restrict__ max_pair_id,
-                                        const int* __restrict__ pair_vox, long long P,
-                                        const float* __restrict__ vbound,
-                                        const int* __restrict__ vox_bid, long long V,
-                                        const int* __restrict__ ray_bid,
-                                        const int* __restrict__ ray_flat,
-                                        const float* __restrict__ rgb, long long hw,
-                                        const float* __restrict__ rayfeat, int ld_rf, int Lv,
-                                        int L, int pnet_rel, int pos_rel, long long R,
-                                        float* __restrict__ pnet_inp, int* __restrict__ pnet_vox,
-                                        float* __restrict__ inp_embed, int ld_e,
-                                        int* __restrict__ end_voxel,
-                                        const unsigned char* __restrict__ pnet_select) {
-    __shared__ float s_vb[256 * 6];
-    __shared__ int s_bid[256];
+// Pass 1 (grid.y = slices of the voxel list): end_voxel[r] (zeroed) takes the maximum of the
+// arg-max pair's voxel and the containing voxels of this slice. Every ray is tested against every
+// voxel (the reference's pcl_aabb + scatter max); the voxel index is wave-uniform, so the bounds
+// come through the scalar cache as SGPR operands of the compares (eight voxels per batch of
+// scalar loads), and the slices keep every SIMD busy at 76,800 rays x 729 voxels (one long loop per
+// ray: 150 us; now ~35). Same predicate as inside_box (a NaN coordinate fails no comparison).
+__global__ void __launch_bounds__(256) lidf_refine_endvox_kernel(
+    const float* __restrict__ pred_pos, const long long* __restrict__ max_pair_id,
+    const int* __restrict__ pair_vox, long long P, const float* __restrict__ vbound,
+    const int* __restrict__ vox_bid, long long V, long long per_slice,
+    const int* __restrict__ ray_bid, long long R, int* __restrict__ end_voxel) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < R;
     float x = 0.f, y = 0.f, z = 0.f;
@@ -42,23 +37,39 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
         y = pred_pos[3 * r + 1];
         z = pred_pos[3 * r + 2];
         bid = ray_bid[r];
-        const long long m = max_pair_id[r];
-        ev = (m >= 0 && m < P) ? pair_vox[m] : 0;
+        if (blockIdx.y == 0) {
+            const long long m = max_pair_id[r];
+            ev = (m >= 0 && m < P) ? pair_vox[m] : 0;
+        }
     }
-    for (long long v0 = 0; v0 < V; v0 += 256) {
-        const int nv = (int)min((long long)256, V - v0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < nv * 6; k += blockDim.x) s_vb[k] = vbound[6 * v0 + k];
-        for (int k = threadIdx.x; k < nv; k += blockDim.x) s_bid[k] = vox_bid[v0 + k];
-        __syncthreads();
-        if (!live) continue;
-        for (int j = 0; j < nv; ++j)
-            if (s_bid[j] == bid && inside_box(x, y, z, s_vb + 6 * j)) ev = max(ev, (int)(v0 + j));
+    const long long j0 = blockIdx.y * per_slice;
+    const long long j1 = j0 + per_slice < V ? j0 + per_slice : V;
+#pragma unroll 8
+    for (long long j = j0; j < j1; ++j) {
+        const float* vb = vbound + 6 * j;
+        const bool in = (vox_bid[j] == bid) & !(x < vb[0]) & !(x > vb[3]) & !(y < vb[1]) & !(y > vb[4]) &
+                        !(z < vb[2]) & !(z > vb[5]);
+        ev = in ? max(ev, (int)j) : ev;
     }
-    if (!live) return;
+    if (live && ev > 0) atomicMax(end_voxel + r, ev);
+}
+
+// Pass 2, one thread per ray: pnet_vox, pnet_inp from the end voxel.
+__global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
+                                        const float* __restrict__ vbound,
+                                        const int* __restrict__ ray_bid,
+                                        const int* __restrict__ ray_flat,
+                                        const float* __restrict__ rgb, long long hw, int pnet_rel,
+                                        long long R, float* __restrict__ pnet_inp,
+                                        int* __restrict__ pnet_vox,
+                                        const int* __restrict__ end_voxel,
+                                        const unsigned char* __restrict__ pnet_select) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float x = pred_pos[3 * r], y = pred_pos[3 * r + 1], z = pred_pos[3 * r + 2];
+    const int bid = ray_bid[r], ev = end_voxel[r];
     const float* vb = vbound + 6 * (size_t)ev;
     const float cx = (vb[0] + vb[3]) / 2.f, cy = (vb[1] + vb[4]) / 2.f, cz = (vb[2] + vb[5]) / 2.f;
-    end_voxel[r] = ev;
     // use_all_pix == False (pipeline.py:987-996): an unselected ray's point stays out of the
     // PointNet — voxel index -1 is skipped by the pooling and gather epilogues
     pnet_vox[r] = (!pnet_select || pnet_select[r]) ? ev : -1;
@@ -122,10 +133,23 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
                                               int ld_e, int* end_voxel,
                                               const unsigned char* pnet_select, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
-                       st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid,
-                       ray_flat, rgb, hw, rayfeat, ld_rf, Lv, L, pnet_rel, pos_rel, R, pnet_inp,
-                       pnet_vox, inp_embed, ld_e, end_voxel, pnet_select);
+    (void)rayfeat; (void)ld_rf; (void)Lv; (void)L; (void)pos_rel; (void)inp_embed; (void)ld_e;
+    hipError_t e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
+    if (e != hipSuccess) return e;
+    // slices of at least 64 voxels, enough of them for ~8 wavefronts per SIMD
+    const long long waves = (R + 63) / 64;
+    long long slices = (8 * 1024 + waves - 1) / waves;
+    const long long max_slices = (V + 63) / 64;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    const long long per_slice = (V + slices - 1) / slices;
+    slices = V > 0 ? (V + per_slice - 1) / per_slice : 1;
+    hipLaunchKernelGGL(lidf_refine_endvox_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)slices),
+                       dim3(256), 0, st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V,
+                       per_slice, ray_bid, R, end_voxel);
+    hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                       pred_pos, vbound, ray_bid, ray_flat, rgb, hw, pnet_rel, R, pnet_inp, pnet_vox,
+                       end_voxel, pnet_select);
     return hipGetLastError();
 }
 
