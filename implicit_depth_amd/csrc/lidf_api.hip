@@ -903,8 +903,13 @@ LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t 
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
 struct RefineWs {
-    size_t pnet_inp, pnet_vox, inp_embed, end_voxel, vox_feat, off, pnet, dec, total;
+    size_t pnet_inp, pnet_vox, inp_embed, end_voxel, vox_feat, off, pnet, dec, voxpart, fact, total;
 };
+// the IEF of stage 2 with the voxel-feature columns of layer 1 as a per-voxel product (defined below)
+static size_t refine_fact_bytes(int D);
+static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
+                                 const float* inp_embed, const int32_t* end_voxel, int64_t R,
+                                 float* out, float* voxpart, char* scratch, hipStream_t st);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -917,6 +922,8 @@ static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     w.off = o;       o += align_up(r * 4, 256);
     w.pnet = o;      o += align_up(lidf_pointnet_workspace_bytes(R + Nv, V), 256);
     w.dec = o;       o += align_up(lidf_decoders_workspace_bytes(R, D), 256);
+    w.voxpart = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
+    w.fact = o;      o += align_up(refine_fact_bytes(D), 256);
     w.total = o;
     return w;
 }
@@ -971,12 +978,21 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
     if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
         return rc;
-    CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
     if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
         return LIDF_ERR_BAD_ARG;
-    if ((rc = decoders_impl(inp_embed, R, D, D, nullptr, q->off, nullptr, off, ws + w.dec,
-                            lidf_decoders_workspace_bytes(R, D), q->precision, stream)))
-        return rc;
+    if (q->precision == LIDF_PRECISION_F32) {
+        // inp_embed[:, 0:128] = occ_voxel_feat[end_voxel] (pipeline.py:1016) never materialises: its
+        // share of layer 1 is W1[:, 0:128] vox_feat[v] + b1 (+ c), one row per voxel, gathered as
+        // the start of the layer-1 accumulators
+        if ((rc = refine_ief_factorised(q->off, D, vox_feat, V, inp_embed, end_voxel, R, off,
+                                        (float*)(ws + w.voxpart), ws + w.fact, st)))
+            return rc;
+    } else {
+        CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
+        if ((rc = decoders_impl(inp_embed, R, D, D, nullptr, q->off, nullptr, off, ws + w.dec,
+                                lidf_decoders_workspace_bytes(R, D), q->precision, stream)))
+            return rc;
+    }
     CHECK_HIP(lidf_launch_refine_finish(q->pred_pos, off, q->ray_dir, q->offset_range0,
                                         q->offset_range1 - q->offset_range0, R, q->pred_pos_out,
                                         st));
@@ -1127,7 +1143,8 @@ static size_t chain_stream_bytes(int D) {
 static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, const float* X,
                            int64_t ldx, int64_t n, const int32_t* pair_vox, const int32_t* pair_ray,
                            const float* voxpart, const float* raypart, float* passes, float* pre,
-                           float* out, char* sbuf, int cus, hipStream_t st) {
+                           float* out, char* sbuf, int cus, hipStream_t st,
+                           int mode = LIDF_MODE_TRAIN) {
     const StreamLayout lay = lidf_make_layout(1, LIDF_MODE_ROWS, m);
     float* stream_buf = (float*)sbuf;
     float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
@@ -1144,8 +1161,27 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     a.out_base = pre;   // development build: the phase counters land in the first 16 floats
 #endif
     const long long ntile = (n + 127) / 128;
-    CHECK_HIP(lidf_launch_points(LIDF_MODE_TRAIN, a, (int)(ntile < cus ? ntile : cus), st));
+    CHECK_HIP(lidf_launch_points(mode, a, (int)(ntile < cus ? ntile : cus), st));
     return LIDF_OK;
+}
+
+// scratch of refine_ief_factorised: [layer-1 stream of the per-voxel launch | stream + aux of the chain]
+static size_t refine_fact_bytes(int D) { return linex_stream_bytes(128) + chain_stream_bytes(D - 128); }
+
+static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
+                                 const float* inp_embed, const int32_t* end_voxel, int64_t R,
+                                 float* out, float* voxpart, char* scratch, hipStream_t st) {
+    int rc, cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const int ld1 = D + (off->is_ief ? 16 : 0);
+    LinEx L = {};
+    L.w = off->w1; L.b = off->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
+    L.ief = off->is_ief ? off : nullptr;   // bias += c
+    L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
+    if ((rc = run_linex(L, (float*)scratch, cus, st))) return rc;
+    return run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
+                           nullptr, voxpart, nullptr, nullptr, nullptr, out,
+                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER);
 }
 
 struct TrainWs {

@@ -48,7 +48,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 
 enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_LINEAR = 3,
        LIDF_MODE_FUSED_H = 4,   // split-f16 stream of lidf_points_h.hip
-       LIDF_MODE_TRAIN = 5 };   // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
+       LIDF_MODE_TRAIN = 5,     // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
+       LIDF_MODE_ROWS_GATHER = 6 };  // rows mode whose layer-1 accumulators start from gathered rows
 
 // One decoder's parameters as the packer sees them.
 struct NetW {

@@ -707,11 +707,12 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
             // TRAIN with gathered rows: the accumulators start from voxpart[pair_vox] (loaded
             // straight into them) and the raypart[pair_ray] row is requested now, added after the
             // matrix instructions of layer 1 — both latencies hide behind them
+            // (ROWS_GATHER: the voxel-part rows only — stage 2's IEF, whose voxel feature of the
+            // end voxel is a per-voxel product)
             f32x4 rpv[MODE == LIDF_MODE_TRAIN ? 8 : 1][4];
-            const bool gathered = MODE == LIDF_MODE_TRAIN && a.voxpart;
+            const bool gathered = (MODE == LIDF_MODE_TRAIN || MODE == LIDF_MODE_ROWS_GATHER) && a.voxpart;
             if (gathered) {
                 const float* vp = a.voxpart + (size_t)a.pair_vox[pc] * 256 + 4 * h;
-                const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -719,7 +720,14 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                         const f32x4 v = *(const f32x4*)(vp + 32 * t + 8 * g);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
-                        rpv[MODE == LIDF_MODE_TRAIN ? t : 0][g] = *(const f32x4*)(rp + 32 * t + 8 * g);
+                    }
+                }
+                if constexpr (MODE == LIDF_MODE_TRAIN) {
+                    const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rpv[t][g] = *(const f32x4*)(rp + 32 * t + 8 * g);
                     }
                 }
             } else {
@@ -751,7 +759,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
             // So the operands of up to 25 k-quads (100 VGPRs, free during layer 1) are fetched
             // in one burst per chunk and the iterations run with only the L2-resident ring in
             // the queue.
-            constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : MODE == LIDF_MODE_TRAIN ? 13 : 8;  // L1ONLY: keep 2 waves/SIMD
+            constexpr int XCH = MODE == LIDF_MODE_ROWS ? 25 : (MODE == LIDF_MODE_TRAIN || MODE == LIDF_MODE_ROWS_GATHER) ? 13 : 8;  // L1ONLY: keep 2 waves/SIMD
             for (int k0 = 0; k0 < a.KQ1; k0 += XCH) {
                 float xb[XCH][4];
 #pragma unroll
@@ -785,7 +793,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
             }
 
             PROF(3)
-            if (gathered) {
+            if (MODE == LIDF_MODE_TRAIN && gathered) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -1009,5 +1017,6 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
     if (mode == LIDF_MODE_ROWS) return launch_points<LIDF_MODE_ROWS>(a, grid, st);
     if (mode == LIDF_MODE_L1ONLY) return launch_points<LIDF_MODE_L1ONLY>(a, grid, st);
     if (mode == LIDF_MODE_TRAIN) return launch_points<LIDF_MODE_TRAIN>(a, grid, st);
+    if (mode == LIDF_MODE_ROWS_GATHER) return launch_points<LIDF_MODE_ROWS_GATHER>(a, grid, st);
     return hipErrorInvalidValue;
 }
