@@ -203,3 +203,20 @@ __device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, flo
 }
 
 #endif  // __HIPCC__
+
+#ifdef __HIPCC__
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device and kernel: the attribute belongs
+// to the device's copy of the function, the call costs tens of microseconds of host time, and the
+// small launches of the evaluation path are host-bound. `done` is the call site's static table
+// (a repeated set under a race is harmless).
+static inline hipError_t lidf_max_lds_once(bool (&done)[64], const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+#endif  // __HIPCC__

@@ -412,13 +412,13 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
         if (g > ntile) g = ntile;
         hipError_t e;
         if (stage == 1) {
-            e = hipFuncSetAttribute((const void*)lidf_pointnet_chain_kernel<1, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PN_LDS_LIMIT);
+            static bool configured[64];
+            e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<1, true>, PN_LDS_LIMIT);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), lds, st, a);
         } else {
-            e = hipFuncSetAttribute((const void*)lidf_pointnet_chain_kernel<2, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PN_LDS_LIMIT);
+            static bool configured[64];
+            e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<2, true>, PN_LDS_LIMIT);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
         }

@@ -1008,8 +1008,8 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
     if (mode == LIDF_MODE_FUSED) {
         // 4 waves x 32 KiB of LDS: the staging area of the accumulator prefetch
         static_assert(4 * 8192 * 4 == 131072, "LDS staging size");
-        hipError_t e = hipFuncSetAttribute((const void*)lidf_points_fused_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        static bool configured[64];
+        hipError_t e = lidf_max_lds_once(configured, (const void*)lidf_points_fused_kernel, 131072);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, a);
         return hipGetLastError();
