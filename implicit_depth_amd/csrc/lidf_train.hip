@@ -297,7 +297,7 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
     if (n <= 0 || M <= 0) return hipSuccess;
     // the wide layers: 128 x 256 blocks (float4 loads want lda/ldb*4 within the 32-bit offsets the
     // buffer instructions take, and a slice of rows below 2 GiB)
-    if (M >= 32 && N >= 16) {
+    if (M >= 32 && N >= 4) {
         Wgrad2Args w;
         w.A = A; w.lda = lda; w.M = M; w.B = B; w.ldb = ldb; w.N = N; w.n = n; w.C = C; w.ldc = ldc;
         w.db = db;
