@@ -38,10 +38,6 @@ hipError_t lidf_launch_miss_fill(const void*, int, long long, const int*, const 
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
                              float*, int, float*, float*, size_t, hipStream_t);
-hipError_t lidf_launch_enc_rows(const float*, const float*, const float*, long long, float*,
-                                hipStream_t);
-hipError_t lidf_launch_fill(float*, long long, float, hipStream_t);
-hipError_t lidf_launch_axpy(const float*, long long, float*, hipStream_t);
 hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, float*, hipStream_t);
 size_t lidf_pointnet_chain_stream_bytes(void);
@@ -1185,7 +1181,7 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
 }
 
 struct TrainWs {
-    size_t stream, dz1, dz2, dz3, goff, enc, denc, wg, chain, total;
+    size_t stream, dz1, dz2, dz3, goff, wg, chain, total;
 };
 static TrainWs train_ws(int64_t n, int d) {
     TrainWs w;
@@ -1197,8 +1193,6 @@ static TrainWs train_ws(int64_t n, int d) {
     w.dz2 = o;    o += align_up(N * LIDF_H2 * 4, 256);
     w.dz3 = o;    o += align_up(N * LIDF_H3 * 4, 256);
     w.goff = o;   o += align_up(N * 4, 256);
-    w.enc = o;    o += align_up(N * 16 * 4, 256);
-    w.denc = o;   o += align_up(N * 16 * 4, 256);
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.chain = o;  o += chain_stream_bytes(d);
     w.total = o;
@@ -1272,8 +1266,6 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
     float* dz2 = (float*)(ws + w.dz2);
     float* dz3 = (float*)(ws + w.dz3);
     float* goff = (float*)(ws + w.goff);
-    float* enc = (float*)(ws + w.enc);
-    float* denc = (float*)(ws + w.denc);
     float* wgs = (float*)(ws + w.wg);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
@@ -1400,7 +1392,7 @@ LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, i
 }
 
 struct QTrainWs {
-    size_t stream, dz1, dz2, dz3, S, goff, enc, denc, dvox, dray, wg, seg, seg_bytes, chain, total;
+    size_t stream, dz1, dz2, dz3, S, goff, dvox, dray, wg, seg, seg_bytes, chain, total;
 };
 static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     QTrainWs w;
@@ -1412,8 +1404,6 @@ static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     w.dz3 = o;    o += align_up(N * LIDF_H3 * 4, 256);
     w.S = o;      o += align_up(N * LIDF_H1 * 4, 256);
     w.goff = o;   o += align_up(N * 4, 256);
-    w.enc = o;    o += align_up(N * 16 * 4, 256);
-    w.denc = o;   o += align_up(N * 16 * 4, 256);
     w.dvox = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
     w.dray = o;   o += align_up((size_t)(R > 0 ? R : 1) * LIDF_H1 * 4, 256);
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
@@ -1522,8 +1512,6 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     float* dz3 = (float*)(ws + w.dz3);
     float* S = (float*)(ws + w.S);
     float* goff = (float*)(ws + w.goff);
-    float* enc = (float*)(ws + w.enc);
-    float* denc = (float*)(ws + w.denc);
     float* wgs = (float*)(ws + w.wg);
     float* dvox = (float*)(ws + w.dvox);
     float* dray = (float*)(ws + w.dray);

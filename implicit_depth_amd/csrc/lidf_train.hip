@@ -347,20 +347,6 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
 }
 
 // ---- per-row pieces -------------------------------------------------------------------------------
-// enc[r, j] = off[r] * wenc[j] + benc[j]   (IEF.offset_enc, implicit_net.py:107,139)
-__global__ void lidf_enc_rows_kernel(const float* off, const float* wenc, const float* benc,
-                                     long long n, float* enc) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 16) return;
-    const int j = (int)(i & 15);
-    enc[i] = off[i >> 4] * wenc[j] + benc[j];
-}
-
-__global__ void lidf_fill_kernel(float* x, long long n, float v) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = v;
-}
-
 // out = act(pre) (implicit_net.py:93-96 / :148-151); with g != NULL also gpre = g * act'(pre)
 __global__ void lidf_out_act_kernel(const float* pre, long long n, int use_sigmoid, float* out,
                                     const float* g, float* gpre) {
@@ -380,19 +366,6 @@ __global__ void lidf_out_act_kernel(const float* pre, long long n, int use_sigmo
     if (g) gpre[i] = g[i] * d;
 }
 
-extern "C" hipError_t lidf_launch_enc_rows(const float* off, const float* wenc, const float* benc,
-                                           long long n, float* enc, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_enc_rows_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0,
-                       st, off, wenc, benc, n, enc);
-    return hipGetLastError();
-}
-extern "C" hipError_t lidf_launch_fill(float* x, long long n, float v, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n,
-                       v);
-    return hipGetLastError();
-}
 extern "C" hipError_t lidf_launch_out_act(const float* pre, long long n, int use_sigmoid,
                                           float* out, const float* g, float* gpre,
                                           hipStream_t st) {
@@ -1328,22 +1301,6 @@ extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, lo
     hipLaunchKernelGGL(lidf_seg_chunk_sum_kernel, dim3((unsigned)s.max_chunks), dim3(256), 0, st, S,
                        perm, scanned, first, (int)V, (int)s.nblk, partial);
     hipLaunchKernelGGL(lidf_seg_final_kernel, dim3((unsigned)V), dim3(64), 0, st, partial, first, out);
-    return hipGetLastError();
-}
-
-// y += x
-__global__ void lidf_axpy_kernel(const float* __restrict__ x, long long n4, float* __restrict__ y) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 a = ((const f32x4*)x)[i], b = ((f32x4*)y)[i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] += a[k];
-    ((f32x4*)y)[i] = b;
-}
-extern "C" hipError_t lidf_launch_axpy(const float* x, long long n, float* y, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x,
-                       n / 4, y);
     return hipGetLastError();
 }
 
