@@ -31,6 +31,17 @@ def test_pointnet_vs_oracle(cuda, n, v):
         assert (got[empty] - ref[empty]).abs().max().item() <= 2e-5
 
 
+def test_pointnet_without_points(cuda):
+    """No point at all: every voxel keeps the scatter-max's 0 -> out = relu(vox_lin2(relu(...)(0)))
+    rows, the same for every voxel (nothing is launched over the points)."""
+    p = orc.init_pointnet(7, 1.5)
+    ref = orc.pointnet2stage(p, torch.zeros(0, 6), torch.zeros(0, dtype=torch.long), 5)
+    m = make_pointnet(p, cuda)
+    with torch.no_grad():
+        got = m(torch.zeros(0, 6, device=cuda), torch.zeros(0, dtype=torch.long, device=cuda), n_vox=5).cpu()
+    assert got.shape == (5, 128) and (got - ref).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_refine_golden_hip(cuda, precision):
     from implicit_depth_amd.query import compute_ray_aabb, lidf_query, lidf_refine
