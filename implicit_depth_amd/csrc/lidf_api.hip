@@ -45,12 +45,14 @@ hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int
                                       float*, long long, long long, int, hipStream_t);
 size_t lidf_pointnet_pool_scratch_bytes(long long);
 hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const float*, const float*,
-                                   long long, float, float*, float*, float*, int, hipStream_t);
+                                   long long, float, float*, float*, int, float*, int, hipStream_t);
 hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
                                    float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_ief_tail(const float*, const float*, const float*, int, const float*,
                                 const float*, long long, int, float*, float*, float*, float*, float*,
-                                float*, hipStream_t);
+                                float*, float*, hipStream_t);
+hipError_t lidf_launch_ief_first_pass(const float*, float*, float, const float*, int, const float*,
+                                      const float*, float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_out_act(const float*, long long, int, float*, const float*, float*,
                                hipStream_t);
 hipError_t lidf_launch_build_rows(const int*, const int*, const float*, const float*, const float*, int,
@@ -1284,7 +1286,7 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         // dZ2 = (dZ3 W3) * lrelu'(Z2), dZ1 = (dZ2 W2) * lrelu'(Z1): one register-chained launch
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, n, 0.02f, dz2, dz1, sbuf, cus, st));
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, n, 0.02f, dz2, dz1, 0, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
         L.mask_src = nullptr;
@@ -1303,7 +1305,7 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
             // d wenc, d benc and d off_k = d off_{k+1} + d enc . wenc in one pass over dZ1
             CHECK_HIP(lidf_launch_ief_tail(dz1, offin, dec->w1 + d, ld1, dec->wenc, dec->benc, n, 0,
                                            nullptr, goff, grads->w1 + d, grads->wenc, grads->benc,
-                                           wgs, st));
+                                           nullptr, wgs, st));
         }
     }
     return LIDF_OK;
@@ -1392,7 +1394,7 @@ LIDF_API size_t lidf_query_decoder_act_floats(int64_t n_pairs, int64_t n_rays, i
 }
 
 struct QTrainWs {
-    size_t stream, dz1, dz2, dz3, S, goff, dvox, dray, wg, seg, seg_bytes, chain, total;
+    size_t stream, dz1, dz2, dz3, S, goff, dvox, dray, wg, seg, seg_bytes, chain, small, total;
 };
 static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     QTrainWs w;
@@ -1410,6 +1412,7 @@ static QTrainWs qtrain_ws(int64_t P, int64_t R, int64_t V) {
     w.seg_bytes = lidf_seg_sum_idx_ws_bytes(P, V);
     w.seg = o;    o += align_up(w.seg_bytes, 256);
     w.chain = o;  o += chain_stream_bytes(2 * (3 + 6 * 16));
+    w.small = o;  o += 512 * 4;   // B sums of the passes | column sums of the running sum
     w.total = o;
     return w;
 }
@@ -1515,6 +1518,8 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     float* wgs = (float*)(ws + w.wg);
     float* dvox = (float*)(ws + w.dvox);
     float* dray = (float*)(ws + w.dray);
+    float* small = (float*)(ws + w.small);
+    CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     const float* voxpart = act;
@@ -1536,16 +1541,31 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         // passes (everything of layer 1 except the offset encoding sees the same operand in every
         // pass): the first pass processed writes its dZ1 straight into S, the others add theirs in
         // the same sweep over dZ1 that handles the offset-encoding columns of layer 1
+        // The IEF's first pass (k = 0, the last one processed) has the constant initial offset as
+        // its offset-in: its share of the offset-encoding gradients follows from column sums of S
+        // (lidf_ief_finish_kernel), so its dZ1 is added into S by the chained launch itself and never
+        // swept again.
         if (npass == 1) S = dz1;
-        float* dz1k = k == npass - 1 ? S : dz1;
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1k, sbuf, cus, st));
+        const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
+        float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1k,
+                                          first_pass_short ? 1 : 0, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
-                                       dec->benc, P, k == npass - 1 ? 0 : 2, S, goff,
-                                       grads->w1 + D, grads->wenc, grads->benc, wgs, st));
+        if (!first_pass_short)
+            CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
+                                           dec->benc, P, k == npass - 1 ? 0 : 2, S, goff,
+                                           grads->w1 + D, grads->wenc, grads->benc,
+                                           dec->is_ief && npass > 1 ? small : nullptr, wgs, st));
     }
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
-    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    const bool short_first = dec->is_ief && npass > 1;
+    // (column sums of S through the weight-gradient launch's bias path when the first pass needs them)
+    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1,
+                                short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    if (short_first)
+        CHECK_HIP(lidf_launch_ief_first_pass(small + 256, small, dec->init_offset, dec->w1 + D, ld1,
+                                             dec->wenc, dec->benc, grads->w1 + D, grads->wenc,
+                                             grads->benc, st));
     CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
                                       w.seg_bytes, st));
     CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));

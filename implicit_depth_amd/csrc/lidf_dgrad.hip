@@ -86,6 +86,9 @@ __device__ __forceinline__ void dg_finish_tile(f32x16& acc, const f32x4 (&m)[4],
     }
 }
 
+// ACC: dZ1 is added to what dz1 holds instead of stored (the running sum over the IEF's passes,
+// lidf_api.hip: the last pass processed adds its dZ1 straight into the sum).
+template <bool ACC>
 __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -109,8 +112,9 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
     for (long long tile = tb; tile < te; ++tile) {
         if (tile * 128 + wave * 32 >= a.n) break;   // wave-uniform
         const long long p = tile * 128 + wave * 32 + col;
-        // rows beyond n repeat row n-1: same operands, same values stored twice
+        // rows beyond n repeat row n-1: same operands, same values stored twice (ACC: not added)
         const long long pc = p < a.n ? p : a.n - 1;
+        const bool valid = p < a.n;
         const float* z3 = a.dz3 + (size_t)pc * LIDF_H3 + 4 * h;
         const float* h2r = a.h2 + (size_t)pc * LIDF_H2 + 4 * h;
         const float* h1r = a.h1 + (size_t)pc * LIDF_H1 + 4 * h;
@@ -137,6 +141,7 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
 
         f32x16 Z2[4];
         f32x16 acc[2];
+        f32x4 SB[ACC ? 2 : 1][4];   // ACC: the pair's tiles of the running sum, requested at the pair's start
 #pragma unroll
         for (int s = 0; s < DG_QUADS; ++s) {
             const f32x4 aq = ring[s % LIDF_RING];
@@ -171,12 +176,27 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
                     dg_load_tile(h1r, 2 * pair + 2, M[(pair + 1) & 1][0]);
                     dg_load_tile(h1r, 2 * pair + 3, M[(pair + 1) & 1][1]);
                 }
+                if (ACC && kq == 0) dg_load_tile(z1, 2 * pair + t, SB[ACC ? t : 0]);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int k = 4 * kq + jj;
                     acc[t] = MFMA(aq[jj], Z2[k / 16][k % 16], k == 0 ? zero16 : acc[t]);
                 }
-                if (kq == 15) dg_finish_tile(acc[t], M[pair & 1][t], a.slope, z1, 2 * pair + t);
+                if (kq == 15) {
+                    if (ACC) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                o[i] = SB[ACC ? t : 0][g][i] +
+                                       acc[t][4 * g + i] * (M[pair & 1][t][g][i] > 0.f ? 1.f : a.slope);
+                            if (valid) *(f32x4*)(z1 + 32 * (2 * pair + t) + 8 * g) = o;
+                        }
+                    } else {
+                        dg_finish_tile(acc[t], M[pair & 1][t], a.slope, z1, 2 * pair + t);
+                    }
+                }
             }
             SCHED_FENCE();
         }
@@ -185,8 +205,8 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
 
 extern "C" hipError_t lidf_launch_dgrad_chain(const float* w3, const float* w2, const float* dz3,
                                               const float* h2, const float* h1, long long n,
-                                              float slope, float* dz2, float* dz1, float* stream,
-                                              int cus, hipStream_t st) {
+                                              float slope, float* dz2, float* dz1, int accumulate,
+                                              float* stream, int cus, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_pack_dgrad_kernel, dim3(DG_QUADS), dim3(256), 0, st, w3, w2, stream);
     DgradArgs a;
@@ -194,6 +214,9 @@ extern "C" hipError_t lidf_launch_dgrad_chain(const float* w3, const float* w2, 
     a.slope = slope;
     const long long ntile = (n + 127) / 128;
     const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
-    hipLaunchKernelGGL(lidf_dgrad_chain_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+    if (accumulate)
+        hipLaunchKernelGGL(lidf_dgrad_chain_kernel<true>, dim3((unsigned)g), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(lidf_dgrad_chain_kernel<false>, dim3((unsigned)g), dim3(256), 0, st, a);
     return hipGetLastError();
 }

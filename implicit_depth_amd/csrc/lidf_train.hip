@@ -551,13 +551,26 @@ __global__ void lidf_l4_finish_kernel(const float* __restrict__ sums, float* __r
 
 // sums = [A | B] (256 each): d W1[c, D+j] += wenc[j] A[c] + benc[j] B[c] ; d wenc[j] += W1[:, D+j] . A ;
 // d benc[j] += W1[:, D+j] . B      (one workgroup of 256 threads)
+// `bacc` (optional, 256): the B of the passes finished so far. `btot` != NULL = the pass whose
+// offset-in is the constant initial offset `init` for every row (the first pass of the IEF, the
+// last one the backward reaches): its sums follow from the column sums of the running sum of dZ1
+// over ALL passes, B = btot - bacc, A = init B — no sweep over its dZ1 is needed.
 __global__ void __launch_bounds__(256) lidf_ief_finish_kernel(
     const float* __restrict__ sums, const float* __restrict__ w1enc, int ld1,
     const float* __restrict__ wenc, const float* __restrict__ benc, float* __restrict__ dw1enc,
-    float* __restrict__ dwenc, float* __restrict__ dbenc) {
+    float* __restrict__ dwenc, float* __restrict__ dbenc, float* __restrict__ bacc,
+    const float* __restrict__ btot, float init) {
     __shared__ float sA[256], sB[256];
     const int c = threadIdx.x;
-    const float A = sums[c], B = sums[256 + c];
+    float A, B;
+    if (btot) {
+        B = btot[c] - bacc[c];
+        A = init * B;
+    } else {
+        A = sums[c];
+        B = sums[256 + c];
+        if (bacc) bacc[c] += B;
+    }
     sA[c] = A;
     sB[c] = B;
 #pragma unroll
@@ -613,7 +626,7 @@ extern "C" hipError_t lidf_launch_ief_tail(const float* dz1, const float* off, c
                                            int ld1, const float* wenc, const float* benc,
                                            long long n, int s_mode, float* S, float* goff,
                                            float* dw1enc, float* dwenc, float* dbenc,
-                                           float* scratch, hipStream_t st) {
+                                           float* bacc, float* scratch, hipStream_t st) {
     if (n <= 0 || (!w1enc && s_mode == 0)) return hipSuccess;
     int G;
     const long long rows = narrow_rows_per_wg(n, &G);
@@ -623,8 +636,19 @@ extern "C" hipError_t lidf_launch_ief_tail(const float* dz1, const float* off, c
     if (w1enc) {
         hipLaunchKernelGGL(lidf_colsum_reduce_kernel, dim3(32), dim3(256), 0, st, scratch, G, 512, sums);
         hipLaunchKernelGGL(lidf_ief_finish_kernel, dim3(1), dim3(256), 0, st, sums, w1enc, ld1, wenc,
-                           benc, dw1enc, dwenc, dbenc);
+                           benc, dw1enc, dwenc, dbenc, bacc, (const float*)nullptr, 0.f);
     }
+    return hipGetLastError();
+}
+
+// The IEF's first pass without a sweep over its dZ1 (see lidf_ief_finish_kernel): btot = column sums
+// of the running sum of dZ1 over all passes, bacc = the B sums of the other passes.
+extern "C" hipError_t lidf_launch_ief_first_pass(const float* btot, float* bacc, float init,
+                                                 const float* w1enc, int ld1, const float* wenc,
+                                                 const float* benc, float* dw1enc, float* dwenc,
+                                                 float* dbenc, hipStream_t st) {
+    hipLaunchKernelGGL(lidf_ief_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)nullptr, w1enc,
+                       ld1, wenc, benc, dw1enc, dwenc, dbenc, bacc, btot, init);
     return hipGetLastError();
 }
 

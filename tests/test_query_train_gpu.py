@@ -274,3 +274,39 @@ def test_query_gradients_other_encoding_widths(cuda, L, Lv, n_vox):
         close(dict(prob.named_parameters())[k].grad.cpu(), v.grad, "prob." + k)
     for k, v in po.items():
         close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
+
+
+def test_query_gradients_three_passes(cuda):
+    """IEF n_iter = 3 in the factorised query: the last pass writes dZ1 into the running sum, the
+    middle one adds its own in the offset-encoding sweep, the first one is added by the chained
+    input-gradient launch and gets its offset-encoding share from column sums."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(2, 10, 14, 6, seed=111, ragged=True)
+    R, P, D = scene["R"], scene["P"], scene["D"]
+    off_p = orc.randomize_biases(orc.init_decoder("IEF", D, 112, 5.0), 113)
+    gen = torch.Generator().manual_seed(114)
+    w = {"prob": torch.randn(P, generator=gen), "off": torch.randn(P, generator=gen),
+         "pos": torch.randn(R, 3, generator=gen)}
+    pp = {k: v.clone().requires_grad_(True) for k, v in scene["prob_p"].items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in off_p.items()}
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"], vf,
+                    pp, po, n_iter=3, fast_roi=True)
+    _loss(ref, w).backward()
+    s = to_dev(scene, cuda)
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", off_p, D, cuda, n_iter=3).train()
+    vfd = s["vox_feat"].clone().requires_grad_(True)
+    out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                           s["pair_vox"], s["pair_t"], s["feat_grid"], vfd, prob, off)
+    _loss(out, {k: v.to(cuda) for k, v in w.items()}).backward()
+    for k in ("pred_offset", "pred_prob_end", "pred_pos"):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() <= TOL, k
+
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(vfd.grad.cpu(), vf.grad, "vox_feat")
+    for k, v in po.items():
+        close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
