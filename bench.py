@@ -277,7 +277,7 @@ def secondary(args):
             o = lidf_query_train(sd["ray_dir"], sd["ray_pix"], sd["ray_bid"], sd["pair_off"], sd["pair_ray"],
                                  sd["pair_vox"], sd["pair_t"], fg, vf, prob, off)
             (o["pred_pos"].sum() + o["pred_prob_end_softmax"].sum() + o["pred_offset"].sum()).backward()
-        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_kernel<TRAIN> + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
+        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_fused_train_kernel + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
         what = ("training step of the query (lidf_query_train): ROI pooling, decoder input rows, both "
                 "decoders forward + backward, gradients to feat_grid / vox_feat / parameters; "
                 "240x320 rays x %d candidates; FLOP = 3 x forward" % max(args.samples // 8, 1))
@@ -297,7 +297,7 @@ def secondary(args):
                     p.grad = None
             x.grad = None
             (prob(x).sum() + off(x).sum()).backward()
-        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_kernel<TRAIN> + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
+        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_fused_train_kernel + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
         what = ("training step of prob_dec (IMNet) + offset_dec (IEF n_iter=2) on [P,385] rows: "
                 "forward with kept activations + backward (d input, d parameters); FLOP = 3 x forward")
     else:

@@ -143,6 +143,9 @@ SIGNATURES = {
     "lidf_query_decoder_workspace_bytes": (C.c_size_t, [_I64, _I64, _I64]),
     "lidf_query_decoder_forward_train_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P,
                                                        C.c_size_t, _P]),
+    "lidf_query_forward_train_workspace_bytes": (C.c_size_t, [_I64, _I64]),
+    "lidf_query_forward_train_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), C.POINTER(LidfDecoder), _P, _P,
+                                               _P, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
                                                   C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
     "lidf_embed_backward_f32": (C.c_int, [_P, _P, _I64, _I, _P, _P]),

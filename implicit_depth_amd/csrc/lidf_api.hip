@@ -1154,7 +1154,7 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     fill_net_args(a, 0, dec, out, 0);
     a.X = X; a.ldx = ldx; a.D = m.D; a.KQ1 = m.KQ1; a.has_bias = m.add_bias;
     a.pair_vox = pair_vox; a.pair_ray = pair_ray; a.voxpart = voxpart; a.raypart = raypart;
-    a.tr_passes = passes; a.tr_pass_floats = (long long)n * ACT_ROW_FLOATS; a.tr_pre = pre;
+    a.tr_passes[0] = passes; a.tr_pass_floats = (long long)n * ACT_ROW_FLOATS; a.tr_pre[0] = pre;
 #ifdef LIDF_PROFILE
     a.out_base = pre;   // development build: the phase counters land in the first 16 floats
 #endif
@@ -1468,6 +1468,81 @@ LIDF_API int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* q, f
     if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, E2, P, q->pair_vox, q->pair_ray,
                               voxpart, raypart, passes, pre, out, (char*)workspace + w.chain, cus, st)))
         return rc;
+    return LIDF_OK;
+}
+
+LIDF_API size_t lidf_query_forward_train_workspace_bytes(int64_t n_rays, int64_t n_vox) {
+    return lidf_query_workspace_bytes(n_rays, n_vox, 0);
+}
+
+LIDF_API int lidf_query_forward_train_f32(const LidfQueryTrainArgs* q, const LidfDecoder* offset_dec,
+                                            const float* pair_t, const float* ray_dir,
+                                            const float* vox_center, int32_t pos_rel, float* out_prob,
+                                            float* out_off, float* act_prob, float* act_off,
+                                            void* workspace, size_t workspace_bytes,
+                                            lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_qtrain(q))) return rc;
+    if ((rc = check_decoder(offset_dec))) return rc;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    if (P > 0x7fffffffLL || R > 0x15555555LL) return LIDF_ERR_UNSUPPORTED;
+    const int L = q->multires, Lv = q->multires_views;
+    if ((rc = check_query_model(q->dec, offset_dec, L, Lv, LIDF_PRECISION_F32))) return rc;
+    if (P == 0) return LIDF_OK;
+    if (!pair_t || !ray_dir || !out_prob || !out_off || !act_prob || !act_off || (pos_rel && !vox_center))
+        return LIDF_ERR_BAD_ARG;
+    const QueryWs w = query_ws(R, V, L, Lv);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    if ((rc = pack_query_weights(q->dec, offset_dec, L, Lv, LIDF_PRECISION_F32, ws, st))) return rc;
+    const float* aux_pts = (const float*)(ws + w.aux_pts);
+    float* voxpart = (float*)(ws + w.voxpart);
+    float* raypart = (float*)(ws + w.raypart);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
+    L1Map mf = {};
+    mf.L = L;
+    const StreamLayout lf = lidf_make_layout(2, LIDF_MODE_FUSED, mf);
+    const L1Map mv = rows_map(128, 0, 0, 0, 1);
+    const StreamLayout lv = lidf_make_layout(2, LIDF_MODE_L1ONLY, mv);
+    const L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);
+    const StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
+    {   // per-voxel and per-ray parts of layer 1, both nets: [V,512], [R,512]
+        PointsArgs av = {};
+        av.stream = (const float*)(ws + w.stream_vox); av.aux = aux_pts;
+        av.nets = 2; av.l1_quads = lv.l1_quads; av.net_quads = lv.net_quads;
+        av.n = V; av.X = q->vox_feat; av.ldx = 128;
+        av.D = mv.D; av.KQ1 = mv.KQ1; av.has_bias = 1; av.out_base = voxpart;
+        PointsArgs a = {};
+        a.stream = (const float*)(ws + w.stream_ray); a.aux = aux_pts;
+        a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
+        a.n = R; a.X = q->rayfeat; a.ldx = 128 + Ed;
+        a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0; a.out_base = raypart;
+        CHECK_HIP(lidf_launch_l1only_pair(a, av, cus, st));
+    }
+    PointsArgs a = {};
+    a.stream = (const float*)(ws + w.stream_pts); a.aux = aux_pts;
+    a.nets = 2; a.l1_quads = lf.l1_quads; a.net_quads = lf.net_quads;
+    a.n = P;
+    fill_net_args(a, 0, q->dec, out_prob, 0);
+    fill_net_args(a, 1, offset_dec, out_off, 1);
+    a.pair_ray = q->pair_ray; a.pair_vox = q->pair_vox; a.pair_t = pair_t;
+    a.ray_dir = ray_dir; a.voxpart = voxpart; a.raypart = raypart;
+    a.vox_center = vox_center; a.pos_rel = pos_rel; a.L = L;
+    a.pair_pred_pos = nullptr;   // the differentiable tail (lidf_query_tail_f32) forms it
+    const LidfDecoder* decs[2] = {q->dec, offset_dec};
+    float* acts[2] = {act_prob, act_off};
+    for (int i = 0; i < 2; ++i) {
+        const int np = decs[i]->is_ief ? decs[i]->n_iter : 1;
+        // act = [voxpart V x 256 | raypart R x 256 (not filled here, not read by the backward) | passes | pre]
+        a.tr_passes[i] = acts[i] + (size_t)(V + R) * LIDF_H1;
+        a.tr_pre[i] = a.tr_passes[i] + (size_t)np * qact_pass(P);
+    }
+    a.tr_pass_floats = (long long)qact_pass(P);
+    const long long nt = (P + 127) / 128;
+    CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
     return LIDF_OK;
 }
 

@@ -145,9 +145,10 @@ struct PointsArgs {
     // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in at
     // tr_passes + k * tr_pass_floats ([n,256] | [n,128] | [n,64] | [n]), the pre-activation
     // output goes to tr_pre [n]
-    float* tr_passes;
+    // (per net; the fused training forward keeps both nets' activations in one launch)
+    float* tr_passes[2];
     long long tr_pass_floats;
-    float* tr_pre;
+    float* tr_pre[2];
 };
 
 // Arguments of the generic linear-layer kernel (lidf_linear.hip): out = epilogue(X W^T + b).

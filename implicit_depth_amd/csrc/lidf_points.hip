@@ -406,7 +406,10 @@ struct Geo {
 #define LIDF_RB 4   // rank-1 rounds whose row loads are in flight together
 #endif
 
-__global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
+// ST: every pass's H1 | H2 | H3 | offset-in and the pre-activation output are kept (training forward
+// of both decoders in one launch, a.tr_passes / a.tr_pre per net).
+template <bool ST>
+__device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     extern __shared__ float lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -619,26 +622,41 @@ __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
             const int pass_base = nsb + l1_bytes;
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
             const int npass = a.npass[net];
+            // (ST: rows beyond n repeat point n-1 — load_idx clamps — so their stores repeat its values)
+            const long long pc = valid ? p : a.n - 1;
+            auto train_row = [&](int pass, float v) {
+                TrainRow tr = {};
+                if (ST) {
+                    float* pk = a.tr_passes[net] + (size_t)pass * a.tr_pass_floats;
+                    tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
+                    tr.h2 = pk + (size_t)a.n * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
+                    tr.h3 = pk + (size_t)a.n * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                    if (valid && h == 0) pk[(size_t)a.n * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = v;
+                }
+                return tr;
+            };
             for (int pass = 0; pass + 1 < npass; ++pass)
-                val += decoder_pass<false>(srs, vq, ring, pass_base, pass_base, base, val, h, one_b,
-                                           ax, nullptr, 0u, 0u, nullptr, 0, TrainRow{}
+                val += decoder_pass<false, ST>(srs, vq, ring, pass_base, pass_base, base, val, h, one_b,
+                                               ax, nullptr, 0u, 0u, nullptr, 0, train_row(pass, val)
 #ifdef LIDF_PROFILE
-                                           , prof_t, prof_acc
+                                               , prof_t, prof_acc
 #endif
-                                           );
-            val += decoder_pass<true>(srs, vq, ring, pass_base, next_blk, base, val, h, one_b, ax,
-                                      (const char*)a.voxpart, vp_off, lds_addr, lds_wave, lane, TrainRow{}
+                                               );
+            val += decoder_pass<true, ST>(srs, vq, ring, pass_base, next_blk, base, val, h, one_b, ax,
+                                          (const char*)a.voxpart, vp_off, lds_addr, lds_wave, lane,
+                                          train_row(npass - 1, val)
 #ifdef LIDF_PROFILE
-                                      , prof_t, prof_acc
+                                          , prof_t, prof_acc
 #endif
-                                      );
+                                          );
             // `base` now holds the accumulator init of the next (net, tile)
             PROF(5)
             // ---------------- outputs ----------------
             if (valid && h == 0) {
                 const float o = out_act(val, a.sigmoid[net]);
                 if (a.out[net]) a.out[net][p] = o;
-                if (a.is_offset[net]) {
+                if (ST) a.tr_pre[net][p] = val;
+                if (a.is_offset[net] && a.pair_pred_pos) {
                     // pipeline.py:437-439, same operation order in f32
                     const float ex = __fmul_rn(cur.dx, cur.te);
                     const float ey = __fmul_rn(cur.dy, cur.te);
@@ -660,6 +678,9 @@ __global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) {
     }
     PROF_DUMP
 }
+
+__global__ void __launch_bounds__(256) lidf_points_fused_kernel(PointsArgs a) { points_fused_body<false>(a); }
+__global__ void __launch_bounds__(256) lidf_points_fused_train_kernel(PointsArgs a) { points_fused_body<true>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // Rows modes: the decoders (LIDF_MODE_ROWS) or layer 1 only (LIDF_MODE_L1ONLY: voxpart / raypart
@@ -830,7 +851,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                     TrainRow tr = {};
                     if constexpr (MODE == LIDF_MODE_TRAIN) {
                         // rows beyond n repeat row n-1 (same operands, same values): no guard needed
-                        float* pk = a.tr_passes + (size_t)pass * a.tr_pass_floats;
+                        float* pk = a.tr_passes[net] + (size_t)pass * a.tr_pass_floats;
                         tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
                         tr.h2 = pk + (size_t)a.n * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
                         tr.h3 = pk + (size_t)a.n * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
@@ -848,7 +869,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                 if (valid && h == 0) {
                     const float o = out_act(val, a.sigmoid[net]);
                     if (a.out[net]) a.out[net][p] = o;
-                    if constexpr (MODE == LIDF_MODE_TRAIN) a.tr_pre[p] = val;
+                    if constexpr (MODE == LIDF_MODE_TRAIN) a.tr_pre[net][p] = val;
                 }
                 PROF(5)
             }
@@ -1011,7 +1032,14 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
         static bool configured[64];
         hipError_t e = lidf_max_lds_once(configured, (const void*)lidf_points_fused_kernel, 131072);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, a);
+        if (a.tr_passes[0] || a.tr_passes[1]) {
+            static bool configured_t[64];
+            e = lidf_max_lds_once(configured_t, (const void*)lidf_points_fused_train_kernel, 131072);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(lidf_points_fused_train_kernel, dim3(grid), dim3(256), 131072, st, a);
+        } else {
+            hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, a);
+        }
         return hipGetLastError();
     }
     if (mode == LIDF_MODE_ROWS) return launch_points<LIDF_MODE_ROWS>(a, grid, st);

@@ -647,6 +647,95 @@ class _QueryDecoderFn(torch.autograd.Function):
             gt[k] if ctx.needs_input_grad[9 + i] else None for i, k in enumerate(names))
 
 
+class _QueryDecodersFn(torch.autograd.Function):
+    """Both decoders of the query in the factorised form: forward = ONE launch of the per-point
+    kernel with the activations kept (lidf_query_forward_train_f32; the positional encodings are
+    formed in registers), backward = lidf_query_decoder_backward_f32 per decoder, the second one
+    adding into the first one's d vox_feat / d rayfeat."""
+
+    @staticmethod
+    def forward(ctx, prob_mod, off_mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t,
+                ray_dir, vox_center, pos_rel, multires, multires_views, n_prob, *params):
+        from . import decoders as _dec
+        vf, rf = vox_feat.detach().contiguous(), rayfeat.detach().contiguous()
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        keep = []
+        dp, do = _dec._decoder_struct(prob_mod, keep), _dec._decoder_struct(off_mod, keep)
+        a = _lib.LidfQueryTrainArgs()
+        a.n_pairs, a.n_rays, a.n_vox = P, R, V
+        a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+        a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+        a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dp)
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=vf.device)
+        passes = [int(m.n_iter) if isinstance(m, _dec.IEF) else 1 for m in (prob_mod, off_mod)]
+        acts = [torch.empty((max(L.lidf_query_decoder_act_floats(P, R, V, n), 1),), **f32) for n in passes]
+        wsb = L.lidf_query_forward_train_workspace_bytes(R, V)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=vf.device)
+        outs = [torch.empty((P, 1), **f32) for _ in range(2)]
+        with torch.cuda.device(vf.device):
+            _lib.check(L.lidf_query_forward_train_f32(
+                C.byref(a), C.byref(do), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
+                _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(acts[0]), _lib.ptr(acts[1]), _lib.ptr(ws), wsb,
+                _lib.current_stream(vf.device)))
+        ctx.mods = (prob_mod, off_mod)
+        ctx.cfg = (multires, multires_views, n_prob)
+        ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
+        ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, acts[0], acts[1], *params)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, g_prob, g_off):
+        from . import decoders as _dec
+        vf, rf, pe, pair_off, pair_ray, pair_vox, act_p, act_o = ctx.saved_tensors[:8]
+        params = ctx.saved_tensors[8:]
+        multires, multires_views, n_prob = ctx.cfg
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        f32 = dict(dtype=torch.float32, device=vf.device)
+        L = _lib.lib()
+        wsb = L.lidf_query_decoder_workspace_bytes(P, R, V)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=vf.device)
+        d_vox = torch.empty_like(vf) if ctx.needs_input_grad[2] else None
+        d_ray = torch.empty_like(rf) if ctx.needs_input_grad[3] else None
+        grads_out = []
+        for i, (mod, act, g_out, names, ps) in enumerate((
+                (ctx.mods[0], act_p, g_prob, ctx.names[0], params[:n_prob]),
+                (ctx.mods[1], act_o, g_off, ctx.names[1], params[n_prob:]))):
+            saved = dict(zip(names, ps))
+            keep = []
+            dec = _dec._decoder_struct(mod, keep, saved)
+            a = _lib.LidfQueryTrainArgs()
+            a.n_pairs, a.n_rays, a.n_vox = P, R, V
+            a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+            a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+            a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dec)
+            g = (g_out if g_out is not None else torch.zeros((P, 1), **f32)).detach().reshape(-1).contiguous().float()
+            gt = {k: torch.empty_like(saved[k], **f32).contiguous() for k in names}
+            gs = _lib.LidfDecoderGrads()
+            for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
+                setattr(gs, field, gt[k].data_ptr() if k in gt else None)
+            with torch.cuda.device(vf.device):
+                _lib.check(L.lidf_query_decoder_backward_f32(
+                    C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 1 if i else 0,
+                    C.byref(gs), _lib.ptr(ws), wsb, _lib.current_stream(vf.device)))
+            grads_out += [gt[k] for k in names]
+        base = 15
+        return (None, None, d_vox, d_ray) + (None,) * 11 + tuple(
+            g if ctx.needs_input_grad[base + i] else None for i, g in enumerate(grads_out))
+
+
+def _query_decoders(prob_mod, off_mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t,
+                    ray_dir, vox_center, pos_rel, multires, multires_views):
+    from . import decoders as _dec
+    _dec._check_supported(prob_mod), _dec._check_supported(off_mod)
+    pp = [_dec._get(prob_mod, k) for k in _dec._PARAM_ORDER if _dec._has(prob_mod, k)]
+    po = [_dec._get(off_mod, k) for k in _dec._PARAM_ORDER if _dec._has(off_mod, k)]
+    return _QueryDecodersFn.apply(prob_mod, off_mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox,
+                                  pair_t, ray_dir, vox_center, pos_rel, multires, multires_views, len(pp),
+                                  *pp, *po)
+
+
 def _query_decoder(mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, multires, multires_views):
     from . import decoders as _dec
     _dec._check_supported(mod)
@@ -741,10 +830,9 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
                 _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
                 _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
                 multires, P, _lib.ptr(pe), _lib.current_stream(ray_dir.device)))
-        pred_prob = _query_decoder(prob_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox,
-                                   multires, multires_views)
-        pred_offset = _query_decoder(offset_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox,
-                                     multires, multires_views)
+        pred_prob, pred_offset = _query_decoders(prob_dec, offset_dec, vox_feat, rayfeat, pe, pair_off,
+                                                 pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel,
+                                                 multires, multires_views)
     else:
         rows = _BuildRowsFn.apply(vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
                                   vox_center, pos_rel, multires, multires_views)

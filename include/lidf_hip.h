@@ -431,6 +431,18 @@ size_t lidf_query_decoder_workspace_bytes(int64_t n_pairs, int64_t n_rays, int64
 int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* args, float* out, float* act,
                                          void* workspace, size_t workspace_bytes,
                                          lidf_stream_t stream);
+/* Both decoders' training forward in ONE launch of the per-point kernel of lidf_query_f32 with the
+ * activations kept (the positional encodings are formed in registers, `pe` of `args` is not read;
+ * args->dec = prob_dec). pair_t [P,2], ray_dir [R,3], vox_center [V,3] / pos_rel as LidfQueryArgs.
+ * act_prob / act_off: lidf_query_decoder_act_floats(..., n_pass of that decoder) floats each, in the
+ * layout lidf_query_decoder_backward_f32 reads. Same results as two
+ * lidf_query_decoder_forward_train_f32 calls up to f32 re-association.                           */
+size_t lidf_query_forward_train_workspace_bytes(int64_t n_rays, int64_t n_vox);
+int lidf_query_forward_train_f32(const LidfQueryTrainArgs* args, const LidfDecoder* offset_dec,
+                                 const float* pair_t, const float* ray_dir, const float* vox_center,
+                                 int32_t pos_rel, float* out_prob, float* out_off, float* act_prob,
+                                 float* act_off, void* workspace, size_t workspace_bytes,
+                                 lidf_stream_t stream);
 int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float* act,
                                     const float* g_out, float* d_vox_feat, float* d_rayfeat,
                                     int32_t accumulate_inputs, const LidfDecoderGrads* grads,
