@@ -297,7 +297,7 @@ def secondary(args):
                     p.grad = None
             x.grad = None
             (prob(x).sum() + off(x).sum()).backward()
-        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_fused_train_kernel + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
+        flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_kernel<TRAIN> + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
         what = ("training step of prob_dec (IMNet) + offset_dec (IEF n_iter=2) on [P,385] rows: "
                 "forward with kept activations + backward (d input, d parameters); FLOP = 3 x forward")
     else:
