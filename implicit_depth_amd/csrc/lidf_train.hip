@@ -268,7 +268,15 @@ __global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __r
     const int k = threadIdx.x >> 5;
     constexpr int SLAB = 128 * 256 + 128;
     f32x4w s = {0.f, 0.f, 0.f, 0.f};
-    if (e4 < SLAB / 4) {
+    // entries beyond the matrix (rows >= M, columns >= N of a partial block: a 64 x 128 or 256 x 102
+    // operand fills a quarter or half of its slab; the single-half kernel never writes columns
+    // 128..255) are neither read nor written
+    bool used = e4 < SLAB / 4;
+    if (used && 4 * e4 < 128 * 256) {
+        const int m = bm * 128 + (4 * e4) / 256, col = bn * 256 + (4 * e4) % 256;
+        used = m < M && col < N;
+    }
+    if (used) {
         const float* p = part + ((size_t)bm * nb + bn) * SLAB + 4 * (size_t)e4;
         for (int sp = k; sp < splits; sp += 8) s += *(const f32x4w*)(p + (size_t)sp * mb * nb * SLAB);
     }
