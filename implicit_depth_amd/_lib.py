@@ -168,6 +168,12 @@ SIGNATURES = {
 
 _lib = None
 
+# Packed weight streams per module (query.py / pointnet.py): kept beside the modules, not on them
+# — an entry holds a device blob and a torch.cuda.Event, which must not travel with
+# copy.deepcopy(module) or pickling of the module — and dropped with the module.
+import weakref  # noqa: E402
+PACK_CACHE = weakref.WeakKeyDictionary()
+
 
 def lib():
     """Load liblidf_hip.so (built by implicit_depth_amd/csrc/build.py). Raises if absent."""

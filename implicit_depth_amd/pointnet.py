@@ -46,11 +46,11 @@ def pointnet_struct(mod, keep):
 
 def packed_pointnet(mod, s, dev):
     """The module's weight streams packed once per parameter version (lidf_pointnet_pack_f32),
-    cached on the module and rebuilt when a parameter is modified in place or replaced; sets
+    cached per module (_lib.PACK_CACHE) and rebuilt when a parameter is modified in place or replaced; sets
     s.packed and returns the blob (keep it alive for the call)."""
     params = list(mod.parameters())
     key = (str(dev), tuple((p.data_ptr(), p._version) for p in params))
-    cache = mod.__dict__.get("_lidf_pack_cache")
+    cache = _lib.PACK_CACHE.get(mod)
     if cache is None or cache[0] != key:
         L = _lib.lib()
         nb = L.lidf_pointnet_pack_bytes()
@@ -61,7 +61,7 @@ def packed_pointnet(mod, s, dev):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
         cache = (key, blob, ev)
-        mod.__dict__["_lidf_pack_cache"] = cache
+        _lib.PACK_CACHE[mod] = cache
     else:
         torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
     s.packed = cache[1].data_ptr()
@@ -163,6 +163,8 @@ class PointNet2Stage(nn.Module):
         check_pointnet(self)
         if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != 6:
             raise RuntimeError("inp_feat must be float32 [N,6]")
+        if tuple(vox2point_idx.shape) != (inp_feat.shape[0],) or vox2point_idx.device != inp_feat.device:
+            raise RuntimeError("vox2point_idx must be [N] on the device of inp_feat")
         if needs_grad:   # the library's training path: forward that keeps activations + backward
             params = [t for name in _PN_ORDER for t in (getattr(self, name).weight, getattr(self, name).bias)]
             return _PointNetTrainFn.apply(inp_feat, vox2point_idx.detach().to(torch.int32).contiguous(),

@@ -201,14 +201,14 @@ PRECISIONS = {"f32": 0, "f16x3": 1}
 
 
 def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, dp, do, dev):
-    """Packed weight streams of the fused query (lidf_query_pack_f32), cached on prob_dec and
+    """Packed weight streams of the fused query (lidf_query_pack_f32), cached per prob_dec (_lib.PACK_CACHE) and
     rebuilt when any parameter of either decoder was modified (torch's in-place version counter)
     or replaced (data pointer) — so an eval loop packs once per checkpoint and a training loop once
     per optimizer step, not once per frame."""
     params = [p for m in (prob_dec, offset_dec) for p in m.parameters()]
     key = (id(offset_dec), multires, multires_views, precision, str(dev),
            tuple((p.data_ptr(), p._version) for p in params))
-    cache = prob_dec.__dict__.get("_lidf_pack_cache")
+    cache = _lib.PACK_CACHE.get(prob_dec)
     if cache is not None and cache[0] == key:
         torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
         return cache[1]
@@ -221,7 +221,7 @@ def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, d
                                          _lib.current_stream(dev)))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-    prob_dec.__dict__["_lidf_pack_cache"] = (key, blob, ev)
+    _lib.PACK_CACHE[prob_dec] = (key, blob, ev)
     return blob
 
 
@@ -277,6 +277,10 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
         raise RuntimeError("vox_center must be [V,3]")
     if ray_pix.shape != (R, 2) or ray_bid.shape != (R,) or (ray_flat is not None and ray_flat.shape != (R,)):
         raise RuntimeError("ray_pix / ray_bid / ray_flat must be [R,2] / [R] / [R]")
+    if tuple(ray_dir.shape) != (R, 3):
+        raise RuntimeError("ray_dir must be [R,3]")
+    if tuple(pair_vox.shape) != (P,) or tuple(pair_t.shape) != (P, 2) or pair_ray.dim() != 1:
+        raise RuntimeError("pair_ray / pair_vox / pair_t must be [P] / [P] / [P,2]")
 
     f32 = dict(dtype=torch.float32, device=dev)
     out = {
@@ -394,8 +398,23 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     dev = ray_dir.device
     R, P, V, Nv = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0], valid_inp.shape[0]
     B, _, h, w = rgb_img.shape
+    if (tuple(ray_dir.shape) != (R, 3) or tuple(pred_pos.shape) != (R, 3) or tuple(max_pair_id.shape) != (R,)
+            or tuple(ray_bid.shape) != (R,) or tuple(ray_flat.shape) != (R,)):
+        raise RuntimeError("ray_dir / pred_pos must be [R,3]; ray_bid / ray_flat / max_pair_id [R]")
+    if tuple(voxel_bound.shape) != (V, 6) or tuple(voxel_bid.shape) != (V,):
+        raise RuntimeError("voxel_bound / voxel_bid must be [V,6] / [V]")
+    if tuple(valid_inp.shape) != (Nv, 6) or tuple(valid_vox.shape) != (Nv,):
+        raise RuntimeError("valid_inp / valid_vox must be [Nv,6] / [Nv]")
+    if rgb_img.dim() != 4 or rgb_img.shape[1] != 3:
+        raise RuntimeError("rgb_img must be [B,3,h,w]")
     if rayfeat is None:
-        rayfeat = ray_features(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+        rayfeat = ray_features(feat_grid, ray_dir, _as_i32(ray_pix, "ray_pix"), ray_bid, roi_inp_bbox,
+                               multires_views)
+    else:   # the rows lidf_query(want_rayfeat=True) kept
+        _lib.require_cuda(rayfeat, names=["rayfeat"])
+        _f32(rayfeat, "rayfeat")
+        if tuple(rayfeat.shape) != (R, 128 + Ed):
+            raise RuntimeError("rayfeat must be [R,%d]" % (128 + Ed))
     L = _lib.lib()
     wsb = L.lidf_refine_workspace_bytes(R, Nv, V)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)

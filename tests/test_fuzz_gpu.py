@@ -1,0 +1,89 @@
+"""GPU: seeded random sweeps of the fused query against the oracle. Every case draws its own image
+shape, batch size, candidates per ray, ray subset (the mask -> nonzero compaction of
+models/pipeline.py:221-269 keeps an arbitrary ascending subset of the pixels), candidate counts
+(0..N per ray, with runs of empty rays and rays of a single pair, so 32-point tiles hold anything
+from one ray to 32 of them), voxel ids and segment lengths. Both kernels (f32 and f16x3) must stay
+within the 1e-4 contract and agree with the oracle on every arg-max whose margin is not a rounding
+tie."""
+import pytest
+import torch
+
+from util import TOL, oracle_query, orc, run_query
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    B, h, w, N = ri(1, 3), ri(5, 40), ri(5, 48), ri(1, 40)
+    base = orc.synthetic_scene(B, h, w, N, seed=seed)
+    R0 = base["R"]
+    # ray subset: ascending (bid, pixel) order as nonzero() leaves it
+    frac = float(torch.rand(1, generator=g))
+    keep = torch.rand(R0, generator=g) < (0.15 + 0.85 * frac)
+    if seed % 4 == 0:
+        keep[:] = True
+    if not keep.any():
+        keep[ri(0, R0 - 1)] = True
+    rid = torch.nonzero(keep).squeeze(1)
+    R = int(rid.numel())
+    # candidate counts: mixture of empty rays, single pairs, short and full lists
+    kind = torch.randint(0, 4, (R,), generator=g)
+    cnt = torch.where(kind == 0, torch.zeros(R, dtype=torch.long),
+          torch.where(kind == 1, torch.ones(R, dtype=torch.long),
+          torch.where(kind == 2, torch.randint(0, min(N, 4) + 1, (R,), generator=g),
+                      torch.randint(0, N + 1, (R,), generator=g))))
+    if seed % 5 == 1:   # long runs of empty rays at both ends
+        cnt[: R // 3] = 0
+        cnt[R - R // 4:] = 0
+    P = int(cnt.sum())
+    pair_off = torch.zeros(R + 1, dtype=torch.int32)
+    pair_off[1:] = torch.cumsum(cnt, 0).int()
+    pair_ray = torch.repeat_interleave(torch.arange(R), cnt).int()
+    bid = base["ray_bid"][rid].long()
+    V = base["V"]
+    per = V // B
+    # voxels of the ray's own frame, drawn at random (repeats inside a ray allowed)
+    pair_vox = (bid[pair_ray.long()] * per + torch.randint(0, per, (P,), generator=g)).int()
+    t0 = 0.2 + 1.8 * torch.rand(P, generator=g)
+    pair_t = torch.stack((t0, t0 + 0.02 + 0.4 * torch.rand(P, generator=g)), 1).contiguous()
+    scene = dict(base)
+    scene.update({"R": R, "P": P, "ray_dir": base["ray_dir"][rid].contiguous(),
+                  "ray_pix": base["ray_pix"][rid].contiguous(), "ray_bid": base["ray_bid"][rid].contiguous(),
+                  "ray_flat": base["ray_flat"][rid].contiguous(), "pair_off": pair_off,
+                  "pair_ray": pair_ray, "pair_vox": pair_vox, "pair_t": pair_t})
+    return scene
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_query(cuda, seed):
+    scene = random_case(seed)
+    ref = oracle_query(scene)
+    for precision in ("f32", "f16x3"):
+        got = run_query(scene, cuda, precision=precision)
+        torch.cuda.synchronize()
+        for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_pos"):
+            assert got[k].shape == ref[k].shape, (precision, k)
+            if ref[k].numel():
+                err = (got[k].cpu() - ref[k]).abs().max().item()
+                assert err <= TOL, (seed, precision, k, err)
+        sm = got["pred_prob_end_softmax"].cpu()
+        if scene["P"]:
+            assert (sm - ref["pred_prob_end_softmax"]).abs().max().item() <= TOL
+            # per-ray softmax sums to 1 on every non-empty ray
+            sums = torch.zeros(scene["R"]).index_add_(0, scene["pair_ray"].long(), sm)
+            nonempty = (scene["pair_off"][1:] - scene["pair_off"][:-1]) > 0
+            assert (sums[nonempty] - 1).abs().max().item() <= 1e-5
+        mid, rid = got["max_pair_id"].cpu(), ref["max_pair_id"]
+        diff = mid != rid
+        if diff.any():   # only rounding ties may pick another pair
+            a = ref["pred_prob_end_softmax"][mid[diff].clamp(max=max(scene["P"] - 1, 0))]
+            b = ref["pred_prob_end_softmax"][rid[diff].clamp(max=max(scene["P"] - 1, 0))]
+            assert (a - b).abs().max().item() <= 1e-6, (seed, precision)
+        # empty rays: dummy-row index P, zero position, zero depth
+        empty = (scene["pair_off"][1:] - scene["pair_off"][:-1]) == 0
+        assert (mid[empty] == scene["P"]).all()
+        assert (got["pred_pos"].cpu()[empty] == 0).all()
+        flat = scene["ray_bid"].long() * (scene["h"] * scene["w"]) + scene["ray_flat"].long()
+        assert torch.equal(got["depth"].cpu().view(-1)[flat], got["pred_pos"].cpu()[:, 2])

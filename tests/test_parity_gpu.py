@@ -122,6 +122,8 @@ def test_packed_weights_follow_parameter_updates(cuda):
     """The query caches its packed weight streams per parameter version: an in-place update, a
     load_state_dict and a replaced .data must all be picked up by the next call."""
     scene = orc.synthetic_scene(1, 8, 12, 4, seed=91)
+    import copy
+    from implicit_depth_amd import _lib
     from implicit_depth_amd.query import lidf_query
     from util import to_dev
     s = to_dev(scene, cuda)
@@ -133,9 +135,11 @@ def test_packed_weights_follow_parameter_updates(cuda):
             return lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                               s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
     a = run()
-    cache0 = prob.__dict__["_lidf_pack_cache"][1]
+    cache0 = _lib.PACK_CACHE[prob][1]
     b = run()
-    assert prob.__dict__["_lidf_pack_cache"][1] is cache0                 # reused
+    assert _lib.PACK_CACHE[prob][1] is cache0                 # reused
+    twin = copy.deepcopy(prob)     # the cache (device blob + event) lives beside the module, not on it
+    assert twin not in _lib.PACK_CACHE and "_lidf_pack_cache" not in twin.__dict__
     assert (a["pred_offset"] == b["pred_offset"]).all()
     with torch.no_grad():
         off.linear_2.weight.mul_(1.25)                                     # in-place (optimizer step)
