@@ -121,6 +121,10 @@ SIGNATURES = {
     "lidf_ray_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "lidf_ray_aabb_count_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
     "lidf_ray_aabb_fill_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "lidf_ray_aabb_grid_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "lidf_ray_aabb_grid_build_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _SZ, _P]),
+    "lidf_ray_aabb_grid_count_f32": (C.c_int, [_P, _P, _I64, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "lidf_ray_aabb_grid_fill_f32": (C.c_int, [_P, _P, _I64, _I, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
     "lidf_exclusive_scan_workspace_bytes": (_SZ, [_I64]),
     "lidf_exclusive_scan_i32": (C.c_int, [_P, _I64, _P, _P, _SZ, _P]),
     "lidf_pcl_aabb_dense_f32": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),

@@ -24,6 +24,11 @@ hipError_t lidf_launch_ray_reduce(const float*, const float*, const int*, long l
 hipError_t lidf_launch_ray_dirs(const float*, int, int, int, float*, hipStream_t);
 hipError_t lidf_launch_ray_aabb_dense(const float*, const float*, const int*, const int*,
                                       long long, long long, int*, float*, hipStream_t);
+hipError_t lidf_launch_ray_aabb_grid_build(const float*, const int*, const int*, long long, int, int, int,
+                                           int, int*, unsigned*, float*, hipStream_t);
+hipError_t lidf_launch_ray_aabb_grid(bool, const float*, const int*, long long, int, int, int, int,
+                                     const int*, const unsigned*, const float*, int*, const int*, int*,
+                                     int*, float*, hipStream_t);
 hipError_t lidf_launch_ray_aabb_compact(bool, const float*, const float*, const int*, const int*,
                                         long long, long long, int*, const int*, int*, int*, float*,
                                         hipStream_t);
@@ -106,7 +111,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 3
+#define LIDF_ABI_VERSION 4
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \
@@ -672,6 +677,80 @@ LIDF_API int lidf_ray_aabb_fill_f32(const float* ray_dir, const float* voxel_bou
                                            n_vox, nullptr, pair_off, pair_ray, pair_vox, pair_t,
                                            (hipStream_t)stream));
     return LIDF_OK;
+}
+
+// ---- the compact list on a regular voxel grid (lidf_aux.hip: per-axis interval tables + cell table)
+struct GridWs {
+    size_t cell, col, tab, total;
+};
+static bool grid_dims_ok(int batch, int rx, int ry, int rz) {
+    return batch >= 0 && rx > 0 && ry > 0 && rz > 0 && rx <= 1024 && ry <= 1024 && rz <= 1024 &&
+           (long long)batch * rx * ry * rz <= 0x7fffffffLL;
+}
+static GridWs grid_ws(int batch, int rx, int ry, int rz) {
+    GridWs w;
+    size_t o = 0;
+    w.cell = o; o += align_up((size_t)(batch > 0 ? batch : 1) * rx * ry * rz * 4, 256);
+    w.col = o;  o += align_up((size_t)(batch > 0 ? batch : 1) * rx * ry * ((rz + 31) / 32) * 4, 256);
+    w.tab = o;  o += align_up((size_t)(batch > 0 ? batch : 1) * (rx + ry + rz) * 8, 256);
+    w.total = o;
+    return w;
+}
+LIDF_API size_t lidf_ray_aabb_grid_workspace_bytes(int32_t batch, int32_t rx, int32_t ry, int32_t rz) {
+    if (!grid_dims_ok(batch, rx, ry, rz)) return 0;
+    return grid_ws(batch, rx, ry, rz).total;
+}
+
+LIDF_API int lidf_ray_aabb_grid_build_f32(const float* voxel_bound, const int32_t* voxel_bid,
+                                            const int32_t* voxel_coord, int64_t n_vox, int32_t batch,
+                                            int32_t rx, int32_t ry, int32_t rz, void* grid,
+                                            size_t grid_bytes, lidf_stream_t stream) {
+    if (n_vox < 0 || !grid_dims_ok(batch, rx, ry, rz)) return LIDF_ERR_BAD_ARG;
+    if (n_vox > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n_vox > 0 && (!voxel_bound || !voxel_bid || !voxel_coord)) return LIDF_ERR_BAD_ARG;
+    const GridWs w = grid_ws(batch, rx, ry, rz);
+    if (!grid || grid_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    if (batch == 0) return LIDF_OK;
+    CHECK_HIP(lidf_launch_ray_aabb_grid_build(voxel_bound, voxel_bid, voxel_coord, n_vox, batch, rx, ry,
+                                              rz, (int*)((char*)grid + w.cell),
+                                              (unsigned*)((char*)grid + w.col),
+                                              (float*)((char*)grid + w.tab), (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+static int grid_rays(bool fill, const float* ray_dir, const int32_t* ray_bid, int64_t n_rays,
+                     int32_t batch, int32_t rx, int32_t ry, int32_t rz, const void* grid,
+                     size_t grid_bytes, int32_t* count, const int32_t* pair_off, int32_t* pair_ray,
+                     int32_t* pair_vox, float* pair_t, lidf_stream_t stream) {
+    if (n_rays < 0 || !grid_dims_ok(batch, rx, ry, rz)) return LIDF_ERR_BAD_ARG;
+    if (n_rays > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n_rays == 0) return LIDF_OK;
+    if (!ray_dir || !ray_bid || (fill ? !pair_off : !count)) return LIDF_ERR_BAD_ARG;
+    const GridWs w = grid_ws(batch, rx, ry, rz);
+    if (!grid || grid_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    CHECK_HIP(lidf_launch_ray_aabb_grid(fill, ray_dir, ray_bid, n_rays, batch, rx, ry, rz,
+                                        (const int*)((const char*)grid + w.cell),
+                                        (const unsigned*)((const char*)grid + w.col),
+                                        (const float*)((const char*)grid + w.tab), count, pair_off,
+                                        pair_ray, pair_vox, pair_t, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_ray_aabb_grid_count_f32(const float* ray_dir, const int32_t* ray_bid, int64_t n_rays,
+                                            int32_t batch, int32_t rx, int32_t ry, int32_t rz,
+                                            const void* grid, size_t grid_bytes, int32_t* count,
+                                            lidf_stream_t stream) {
+    return grid_rays(false, ray_dir, ray_bid, n_rays, batch, rx, ry, rz, grid, grid_bytes, count,
+                     nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+LIDF_API int lidf_ray_aabb_grid_fill_f32(const float* ray_dir, const int32_t* ray_bid, int64_t n_rays,
+                                           int32_t batch, int32_t rx, int32_t ry, int32_t rz,
+                                           const void* grid, size_t grid_bytes, const int32_t* pair_off,
+                                           int32_t* pair_ray, int32_t* pair_vox, float* pair_t,
+                                           lidf_stream_t stream) {
+    return grid_rays(true, ray_dir, ray_bid, n_rays, batch, rx, ry, rz, grid, grid_bytes, nullptr,
+                     pair_off, pair_ray, pair_vox, pair_t, stream);
 }
 
 LIDF_API size_t lidf_exclusive_scan_workspace_bytes(int64_t n) {

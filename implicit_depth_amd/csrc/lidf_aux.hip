@@ -562,6 +562,173 @@ extern "C" hipError_t lidf_launch_ray_aabb_compact(bool fill, const float* ray_d
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same compact list when the voxels are cells of a regular grid (LIDF.get_occ_vox_bound,
+// models/pipeline.py:162-201: bound_min = xmin + coord * part_size, so a bound depends on the cell
+// index of its own axis only). The slab test is an intersection of three per-axis t intervals,
+//   hit(i,j,k)  <=>  Tx[i] ^ Ty[j] ^ Tz[k] non-empty      (evaluated x^y first, then ^z),
+// so a ray does not have to visit every voxel: columns (i,j) whose x and y intervals miss are
+// skipped whole, and a cell is looked up in a dense cell -> voxel table only when its three
+// intervals meet. The intervals are formed from the voxels' OWN bounds (gathered into per-frame
+// per-axis tables) with the arithmetic of slab_test, in the same order: t_enter / t_leave and the
+// hit decision are bit-identical to the voxel-by-voxel kernel. Cells are visited in (i,j,k) order
+// = ascending voxel index for a voxel list sorted by (frame, x, y, z) (torch.unique's order).
+// A bit mask of the occupied z cells per (i,j) column lets the walk touch occupied cells only:
+// <= rx*ry column checks + one z check per occupied cell of a passing column, instead of V slab
+// tests of 6 products each.
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_grid_init_kernel(int* __restrict__ cell, long long ncell,
+                                      unsigned* __restrict__ colmask, long long ncol,
+                                      float* __restrict__ tab, long long ntab) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncell) cell[i] = -1;
+    if (i < ncol) colmask[i] = 0u;
+    // an axis index no voxel has: the empty interval (+inf, -inf) fails every overlap check
+    if (i < ntab) *(f32x2*)(tab + 2 * i) = f32x2{__builtin_inff(), -__builtin_inff()};
+}
+
+__global__ void lidf_grid_build_kernel(const float* __restrict__ vbound,
+                                       const int* __restrict__ vox_bid,
+                                       const int* __restrict__ coord, long long V, int B, int rx,
+                                       int ry, int rz, int* __restrict__ cell,
+                                       unsigned* __restrict__ colmask, float* __restrict__ tab) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int b = vox_bid[v], i = coord[3 * v], j = coord[3 * v + 1], k = coord[3 * v + 2];
+    if (b < 0 || b >= B || i < 0 || i >= rx || j < 0 || j >= ry || k < 0 || k >= rz) return;
+    cell[(((size_t)b * rx + i) * ry + j) * rz + k] = (int)v;
+    // occupied z cells of the (i, j) column, 32 per word
+    atomicOr(colmask + (((size_t)b * rx + i) * ry + j) * ((rz + 31) / 32) + (k >> 5), 1u << (k & 31));
+    float* t = tab + (size_t)b * (rx + ry + rz) * 2;
+    // every voxel of one axis index carries the same pair of bounds: the stores agree
+    *(f32x2*)(t + 2 * i) = f32x2{vbound[6 * v + 0], vbound[6 * v + 3]};
+    *(f32x2*)(t + 2 * (rx + j)) = f32x2{vbound[6 * v + 1], vbound[6 * v + 4]};
+    *(f32x2*)(t + 2 * (rx + ry + k)) = f32x2{vbound[6 * v + 2], vbound[6 * v + 5]};
+}
+
+// One thread per ray. A workgroup whose rays all belong to one frame (rays are frame-major, so all
+// but the few workgroups on a frame boundary) first copies that frame's tables into LDS — cell
+// table, column masks, per-axis bounds: 3.4 KB for the reference's 9^3 grid — and every lookup of
+// the walk is an LDS read; other workgroups (and grids beyond the LDS budget) read global memory.
+#define GRID_LDS_CELLS 8192
+#define GRID_LDS_COLS 2048
+#define GRID_LDS_AXES 192
+template <bool FILL>
+__global__ void __launch_bounds__(256) lidf_ray_aabb_grid_kernel(
+    const float* __restrict__ ray_dir, const int* __restrict__ ray_bid, long long R, int B, int rx,
+    int ry, int rz, const int* __restrict__ cell, const unsigned* __restrict__ colmask,
+    const float* __restrict__ tab, int* __restrict__ count, const int* __restrict__ pair_off,
+    int* __restrict__ pair_ray, int* __restrict__ pair_vox, float* __restrict__ pair_t) {
+    __shared__ int s_cell[GRID_LDS_CELLS];
+    __shared__ unsigned s_col[GRID_LDS_COLS];
+    __shared__ float s_tab[2 * GRID_LDS_AXES];
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < R;
+    const int b = live ? ray_bid[r] : -1;
+    const int mw = (rz + 31) / 32;
+    const int ncell = rx * ry * rz, ncol = rx * ry * mw, nax = rx + ry + rz;
+    // frame of the workgroup's first ray; staged if every live ray has it and the tables fit
+    const int b0 = ray_bid[(long long)blockIdx.x * blockDim.x];
+    const bool fits = ncell <= GRID_LDS_CELLS && ncol <= GRID_LDS_COLS && nax <= GRID_LDS_AXES &&
+                      b0 >= 0 && b0 < B;
+    const bool staged = __syncthreads_and(!live || b == b0) && fits;
+    const int* cb;
+    const unsigned* mb;
+    const float* tx;
+    if (staged) {
+        const int* gc = cell + (size_t)b0 * ncell;
+        const unsigned* gm = colmask + (size_t)b0 * ncol;
+        const float* gt = tab + (size_t)b0 * nax * 2;
+        for (int i = threadIdx.x; i < ncell; i += blockDim.x) s_cell[i] = gc[i];
+        for (int i = threadIdx.x; i < ncol; i += blockDim.x) s_col[i] = gm[i];
+        for (int i = threadIdx.x; i < 2 * nax; i += blockDim.x) s_tab[i] = gt[i];
+        __syncthreads();
+        cb = s_cell, mb = s_col, tx = s_tab;
+    } else if (b >= 0 && b < B) {
+        cb = cell + (size_t)b * ncell, mb = colmask + (size_t)b * ncol, tx = tab + (size_t)b * nax * 2;
+    } else {
+        cb = nullptr, mb = nullptr, tx = nullptr;
+    }
+    if (!live) return;
+    int n = 0;
+    if (tx) {
+        const RayInv inv = ray_inv(ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]);
+        const float* ty = tx + 2 * rx;
+        const float* tz = ty + 2 * ry;
+        const size_t base = FILL ? (size_t)pair_off[r] : 0;
+        for (int i = 0; i < rx; ++i) {
+            const float x0 = tx[2 * i], x1 = tx[2 * i + 1];
+            const float a0 = (inv.ix >= 0 ? x0 : x1) * inv.ix;   // tmin of x
+            const float a1 = (inv.ix >= 0 ? x1 : x0) * inv.ix;   // tmax of x
+            for (int j = 0; j < ry; ++j) {
+                const unsigned* mrow = mb + ((size_t)i * ry + j) * mw;
+                const float y0 = ty[2 * j], y1 = ty[2 * j + 1];
+                const float tymin = (inv.iy >= 0 ? y0 : y1) * inv.iy;
+                const float tymax = (inv.iy >= 0 ? y1 : y0) * inv.iy;
+                if ((a0 > tymax) || (a1 < tymin)) continue;
+                const float m = fmaxf(a0, tymin), M = fminf(a1, tymax);
+                const int* cj = cb + ((size_t)i * ry + j) * rz;
+                for (int w = 0; w < mw; ++w) {
+                    unsigned bits = mrow[w];              // occupied cells of the column, ascending k
+                    while (bits) {
+                        const int k = 32 * w + __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        const float z0 = tz[2 * k], z1 = tz[2 * k + 1];
+                        const float tzmin = (inv.iz >= 0 ? z0 : z1) * inv.iz;
+                        const float tzmax = (inv.iz >= 0 ? z1 : z0) * inv.iz;
+                        if ((m > tzmax) || (M < tzmin)) continue;
+                        if (FILL) {
+                            const size_t p = base + n;
+                            pair_ray[p] = (int)r;
+                            pair_vox[p] = cj[k];
+                            *(f32x2*)(pair_t + 2 * p) = f32x2{fmaxf(m, tzmin), fminf(M, tzmax)};
+                        }
+                        ++n;
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) count[r] = n;
+}
+
+// cell: [B*rx*ry*rz] ints, colmask: [B*rx*ry*ceil(rz/32)] words, tab: [B*(rx+ry+rz)*2] floats
+// (all three inside the caller's workspace)
+extern "C" hipError_t lidf_launch_ray_aabb_grid_build(const float* vbound, const int* vox_bid,
+                                                      const int* coord, long long V, int B, int rx,
+                                                      int ry, int rz, int* cell, unsigned* colmask,
+                                                      float* tab, hipStream_t st) {
+    const long long ncell = (long long)B * rx * ry * rz, ntab = (long long)B * (rx + ry + rz);
+    const long long ncol = (long long)B * rx * ry * ((rz + 31) / 32);
+    const long long n = ncell > ntab ? ncell : ntab;   // ncol <= ncell
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_grid_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       cell, ncell, colmask, ncol, tab, ntab);
+    if (V > 0)
+        hipLaunchKernelGGL(lidf_grid_build_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0,
+                           st, vbound, vox_bid, coord, V, B, rx, ry, rz, cell, colmask, tab);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_ray_aabb_grid(bool fill, const float* ray_dir, const int* ray_bid,
+                                                long long R, int B, int rx, int ry, int rz,
+                                                const int* cell, const unsigned* colmask,
+                                                const float* tab, int* count, const int* pair_off,
+                                                int* pair_ray, int* pair_vox, float* pair_t,
+                                                hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    dim3 grid((unsigned)((R + 255) / 256)), block(256);
+    if (fill)
+        hipLaunchKernelGGL(lidf_ray_aabb_grid_kernel<true>, grid, block, 0, st, ray_dir, ray_bid, R,
+                           B, rx, ry, rz, cell, colmask, tab, count, pair_off, pair_ray, pair_vox,
+                           pair_t);
+    else
+        hipLaunchKernelGGL(lidf_ray_aabb_grid_kernel<false>, grid, block, 0, st, ray_dir, ray_bid,
+                           R, B, rx, ry, rz, cell, colmask, tab, count, pair_off, pair_ray, pair_vox,
+                           pair_t);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Point / voxel inside test — extensions/pcl_aabb/pcl_aabb_cuda_kernel.cu:23-44 (inclusive bounds).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool inside_test(float x, float y, float z, const float* vb) {

@@ -152,28 +152,59 @@ def nonzero_pixels(mask):
     return {"bid": out["miss_bid"], "flat": out["miss_flat_img_id"]}
 
 
-def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid):
+def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid, voxel_coord=None, grid_dims=None,
+                     batch=None):
     """Compact ray-major ray/voxel intersection list (replaces the dense ray_aabb.forward +
     torch.nonzero of models/pipeline.py:277-285).
 
     Returns (pair_off [R+1] i32, pair_ray [P] i32, pair_vox [P] i32, pair_t [P,2] f32); inside a
     ray the voxels ascend, which is the reference's order restricted to that ray.  P == 0 is the
-    reference's "no intersection pair" early exit (pipeline.py:287-289)."""
+    reference's "no intersection pair" early exit (pipeline.py:287-289).
+
+    voxel_coord [V,3] (occ_vox_global_coord), grid_dims (rx,ry,rz) and batch — all three as
+    get_occ_vox_bound returns them — select the regular-grid walk (lidf_ray_aabb_grid_*): a ray
+    visits only the cells whose per-axis intervals meet instead of every voxel; the result is
+    bit-identical."""
     _lib.require_cuda(ray_dir, voxel_bound, ray_bid, voxel_bid,
                       names=["ray_dir", "voxel_bound", "ray_bid", "voxel_bid"])
     _f32(ray_dir, "ray_dir"), _f32(voxel_bound, "voxel_bound")
     _i32(ray_bid, "ray_bid"), _i32(voxel_bid, "voxel_bid")
     R, V = ray_dir.shape[0], voxel_bound.shape[0]
+    if tuple(ray_dir.shape) != (R, 3) or tuple(voxel_bound.shape) != (V, 6):
+        raise RuntimeError("ray_dir / voxel_bound must be [R,3] / [V,6]")
+    if tuple(ray_bid.shape) != (R,) or tuple(voxel_bid.shape) != (V,):
+        raise RuntimeError("ray_bid / voxel_bid must be [R] / [V]")
     dev = ray_dir.device
     L = _lib.lib()
+    use_grid = voxel_coord is not None
+    if use_grid:
+        if grid_dims is None or batch is None:
+            raise RuntimeError("voxel_coord needs grid_dims=(rx,ry,rz) and batch")
+        voxel_coord = _as_i32(voxel_coord, "voxel_coord").contiguous()
+        _lib.require_cuda(voxel_coord, names=["voxel_coord"])
+        if tuple(voxel_coord.shape) != (V, 3):
+            raise RuntimeError("voxel_coord must be [V,3]")
+        rx, ry, rz = (int(v) for v in grid_dims)
+        gwb = L.lidf_ray_aabb_grid_workspace_bytes(int(batch), rx, ry, rz)
+        if gwb == 0:
+            raise RuntimeError("unsupported grid dimensions %s x batch %s" % (grid_dims, batch))
+        gws = torch.empty((gwb,), dtype=torch.uint8, device=dev)
     count = torch.empty((max(R, 1),), dtype=torch.int32, device=dev)
     pair_off = torch.zeros((R + 1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         st = _lib.current_stream(dev)
         if R > 0:
-            _lib.check(L.lidf_ray_aabb_count_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
-                                                 _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
-                                                 _lib.ptr(count), st))
+            if use_grid:
+                _lib.check(L.lidf_ray_aabb_grid_build_f32(
+                    _lib.ptr(voxel_bound), _lib.ptr(voxel_bid), _lib.ptr(voxel_coord), V, int(batch),
+                    rx, ry, rz, _lib.ptr(gws), gwb, st))
+                _lib.check(L.lidf_ray_aabb_grid_count_f32(
+                    _lib.ptr(ray_dir), _lib.ptr(ray_bid), R, int(batch), rx, ry, rz, _lib.ptr(gws), gwb,
+                    _lib.ptr(count), st))
+            else:
+                _lib.check(L.lidf_ray_aabb_count_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
+                                                     _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
+                                                     _lib.ptr(count), st))
             wsb = L.lidf_exclusive_scan_workspace_bytes(R)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
             _lib.check(L.lidf_exclusive_scan_i32(_lib.ptr(count), R, _lib.ptr(pair_off),
@@ -183,10 +214,15 @@ def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid):
         pair_vox = torch.empty((P,), dtype=torch.int32, device=dev)
         pair_t = torch.empty((P, 2), dtype=torch.float32, device=dev)
         if P > 0:
-            _lib.check(L.lidf_ray_aabb_fill_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
-                                                _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
-                                                _lib.ptr(pair_off), _lib.ptr(pair_ray),
-                                                _lib.ptr(pair_vox), _lib.ptr(pair_t), st))
+            if use_grid:
+                _lib.check(L.lidf_ray_aabb_grid_fill_f32(
+                    _lib.ptr(ray_dir), _lib.ptr(ray_bid), R, int(batch), rx, ry, rz, _lib.ptr(gws), gwb,
+                    _lib.ptr(pair_off), _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), st))
+            else:
+                _lib.check(L.lidf_ray_aabb_fill_f32(_lib.ptr(ray_dir), _lib.ptr(voxel_bound),
+                                                    _lib.ptr(ray_bid), _lib.ptr(voxel_bid), R, V,
+                                                    _lib.ptr(pair_off), _lib.ptr(pair_ray),
+                                                    _lib.ptr(pair_vox), _lib.ptr(pair_t), st))
     return pair_off, pair_ray, pair_vox, pair_t
 
 
@@ -496,11 +532,14 @@ def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=
                                        _lib.ptr(pid), _lib.ptr(rev), _lib.ptr(rel), _lib.ptr(counts),
                                        _lib.ptr(ws), wsb, _lib.current_stream(dev)))
     V, Nv = [int(v) for v in counts.tolist()]  # host needs the sizes, as torch.unique does
+    coord32 = occ[:V, 1:].contiguous()   # int32 form for compute_ray_aabb's grid walk
     occ = occ[:V].long()
     return {
         "part_size": part_size, "xmin": lo.to(dev), "revidx": rev[:Nv].long(),
         "valid_v_pid": pid[:Nv].long(), "valid_v_rel_coord": rel[:Nv],
         "occ_vox_bid": occ[:, 0], "occ_vox_global_coord": occ[:, 1:], "voxel_bound": vb[:V],
+        # extra entries for compute_ray_aabb's grid walk: cells per axis of the widened grid, int32 coords
+        "grid_dims": tuple(r), "voxel_coord": coord32,
     }
 
 

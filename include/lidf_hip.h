@@ -237,6 +237,31 @@ int lidf_ray_aabb_fill_f32(const float* ray_dir, const float* voxel_bound,
                            int64_t n_rays, int64_t n_vox, const int32_t* pair_off,
                            int32_t* pair_ray, int32_t* pair_vox, float* pair_t,
                            lidf_stream_t stream);
+/* The same compact list for voxels that are cells of a regular grid — what
+ * LIDF.get_occ_vox_bound builds (models/pipeline.py:162-201: bound_min = xmin + coord*part_size,
+ * coord = occ_vox_global_coord), replacing the dense V x R test of pipeline.py:277-285 by a walk
+ * over the cells a ray can meet. voxel_coord [V,3] i32 = the cell index of every voxel
+ * (0 <= coord < (rx,ry,rz); voxels outside are ignored), voxel_bid < batch; all voxels that share
+ * a frame and an axis index must carry the same bounds on that axis (true by construction).
+ * `build` fills `grid` (lidf_ray_aabb_grid_workspace_bytes) with a cell -> voxel table and the
+ * per-axis bound tables; `count` / `fill` are the two passes of the compact form above. Hits,
+ * t_enter and t_leave are bit-identical to lidf_ray_aabb_count/fill_f32 (the same products of the
+ * voxels' own bounds, compared in the same order); within a ray the pairs ascend in (x,y,z) cell
+ * order = ascending voxel index for a list sorted like torch.unique sorts it.                 */
+size_t lidf_ray_aabb_grid_workspace_bytes(int32_t batch, int32_t rx, int32_t ry, int32_t rz);
+int lidf_ray_aabb_grid_build_f32(const float* voxel_bound, const int32_t* voxel_bid,
+                                 const int32_t* voxel_coord, int64_t n_vox, int32_t batch,
+                                 int32_t rx, int32_t ry, int32_t rz, void* grid, size_t grid_bytes,
+                                 lidf_stream_t stream);
+int lidf_ray_aabb_grid_count_f32(const float* ray_dir, const int32_t* ray_bid, int64_t n_rays,
+                                 int32_t batch, int32_t rx, int32_t ry, int32_t rz,
+                                 const void* grid, size_t grid_bytes, int32_t* count,
+                                 lidf_stream_t stream);
+int lidf_ray_aabb_grid_fill_f32(const float* ray_dir, const int32_t* ray_bid, int64_t n_rays,
+                                int32_t batch, int32_t rx, int32_t ry, int32_t rz,
+                                const void* grid, size_t grid_bytes, const int32_t* pair_off,
+                                int32_t* pair_ray, int32_t* pair_vox, float* pair_t,
+                                lidf_stream_t stream);
 /* out[0]=0, out[i+1]=out[i]+in[i]; out has n+1 entries. Single-launch (n up to 2^31-1).      */
 size_t lidf_exclusive_scan_workspace_bytes(int64_t n);
 int lidf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out,

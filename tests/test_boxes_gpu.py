@@ -54,6 +54,78 @@ def test_ray_aabb_empty(cuda):
     assert pr.numel() >= 0 and int(off[-1]) == pr.numel()
 
 
+def grid_scene(R, B, res, fill, seed):
+    """Occupied cells of the reference's widened grid (models/pipeline.py:167-173 with
+    utils/point_utils.py:40-76: bound_min = xmin + coord * part_size in f32), sorted by
+    (frame, x, y, z) like torch.unique sorts them; rays through, beside and along the grid."""
+    g = torch.Generator().manual_seed(seed)
+    ps = torch.tensor(2.0 / 8, dtype=torch.float32)
+    xmin = torch.tensor([-1.0, -1.0, 0.0]) - 0.5 * ps
+    key = torch.nonzero(torch.rand(B * res ** 3, generator=g) < fill).squeeze(1)
+    bid = key // res ** 3
+    coord = torch.stack(((key // res ** 2) % res, (key // res) % res, key % res), 1)
+    lo = xmin + coord.float() * ps
+    vb = torch.cat((lo, lo + ps), 1).contiguous()
+    d = torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    if R >= 8:
+        d[0], d[1], d[2] = torch.tensor([0.0, 0, 1]), torch.tensor([1.0, 0, 0]), torch.tensor([0.0, -1, 0])
+        d[3] = torch.tensor([0.0, 0.6, 0.8])           # in a cell-boundary plane x = const? (x = 0)
+        d[4] = torch.tensor([-0.125, -0.125, 0.125]) / 0.2165063509   # through cell corners
+        d[5] = torch.tensor([0.6, 0.0, -0.8])          # pointing away from the grid (no t >= 0 test)
+        d[6] = -d[7]                                    # a line and its reverse hit the same voxels
+    rb = torch.randint(0, B, (R,), generator=g).int()
+    return d.contiguous(), vb, rb, bid.int().contiguous(), coord.int().contiguous()
+
+
+@pytest.mark.parametrize("R,B,fill", [(3000, 1, 0.15), (2000, 3, 0.6), (900, 2, 1.0), (700, 2, 0.01)])
+def test_ray_aabb_grid_walk(cuda, R, B, fill):
+    """lidf_ray_aabb_grid_*: bit-identical to the voxel-by-voxel compact path and to the oracle."""
+    from implicit_depth_amd.query import compute_ray_aabb
+    res = 9
+    d, vb, rb, vbid, coord = grid_scene(R, B, res, fill, seed=R + B)
+    t = [a.to(cuda) for a in (d, vb, rb, vbid)]
+    ref = compute_ray_aabb(*t)
+    got = compute_ray_aabb(*t, voxel_coord=coord.to(cuda), grid_dims=(res, res, res), batch=B)
+    for a, b in zip(got, ref):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    # int64 coordinates (data_dict['occ_vox_global_coord']) are narrowed
+    got = compute_ray_aabb(*t, voxel_coord=coord.long().to(cuda), grid_dims=(res, res, res), batch=B)
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    if vb.shape[0] <= 600:
+        m_ref, t_ref = orc.ray_aabb(d.numpy(), vb.numpy(), rb.numpy(), vbid.numpy())
+        pr_ref, pv_ref, pt_ref, off_ref = orc.pairs_from_dense(m_ref, t_ref)
+        assert (got[0].cpu().long() == off_ref).all() and (got[2].cpu().long() == pv_ref).all()
+        assert (got[3].cpu() == pt_ref).all()
+
+
+def test_ray_aabb_grid_walk_edges(cuda):
+    from implicit_depth_amd.query import compute_ray_aabb
+    d, vb, rb, vbid, coord = grid_scene(64, 2, 9, 0.3, seed=5)
+    t = [a.to(cuda) for a in (d, vb, rb, vbid)]
+    c = coord.to(cuda)
+    kw = dict(grid_dims=(9, 9, 9), batch=2)
+    off, pr, pv, pt = compute_ray_aabb(t[0][:0], t[1], t[2][:0], t[3], voxel_coord=c, **kw)   # no rays
+    assert off.tolist() == [0] and pr.numel() == 0
+    off, pr, pv, pt = compute_ray_aabb(t[0], t[1][:0], t[2], t[3][:0], voxel_coord=c[:0], **kw)  # no voxels
+    assert off.shape[0] == 65 and int(off[-1]) == 0 and pt.shape == (0, 2)
+    # a non-cubic grid and rays of a frame that has no voxel at all
+    g = torch.Generator().manual_seed(9)
+    key = torch.nonzero(torch.rand(5 * 7 * 11, generator=g) < 0.4).squeeze(1)
+    coord = torch.stack((key // 77, (key // 11) % 7, key % 11), 1)
+    lo = torch.tensor([-0.6, -0.9, 0.1]) + coord.float() * torch.tensor(0.2)
+    vb = torch.cat((lo, lo + torch.tensor(0.2)), 1).contiguous().to(cuda)
+    vbid = torch.ones(key.numel(), dtype=torch.int32, device=cuda)           # every voxel in frame 1
+    rb = (torch.arange(64) % 3).int().to(cuda)                               # frames 0, 1, 2
+    ref = compute_ray_aabb(t[0], vb, rb, vbid)
+    got = compute_ray_aabb(t[0], vb, rb, vbid, voxel_coord=coord.int().to(cuda), grid_dims=(5, 7, 11), batch=3)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert int(ref[0][-1]) > 0
+    with pytest.raises(RuntimeError):
+        compute_ray_aabb(t[0], vb, rb, vbid, voxel_coord=coord.int().to(cuda))   # dims missing
+
+
 @pytest.mark.parametrize("N,V", [(900, 70), (3, 300)])
 def test_pcl_aabb(cuda, N, V):
     from implicit_depth_amd.extensions import pcl_aabb

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
         assert n in _lib.SIGNATURES, "ctypes signature missing for " + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert L.lidf_version() == 3
+    assert L.lidf_version() == 4
     assert b"workspace" in L.lidf_strerror(-3)
     assert L.lidf_query_workspace_bytes(76800, 729, 0) > 76800 * 512 * 4
     assert (L.lidf_query_workspace_bytes(76800, 729, 32 * 240 * 320)
