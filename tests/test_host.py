@@ -68,7 +68,7 @@ def test_torch_extension_shim_loads():
     """The pybind11 shim over the C ABI is built in-tree and imports without a GPU."""
     from implicit_depth_amd import torch_ext
     m = torch_ext.ext()
-    assert m.abi_version() == 3
+    assert m.abi_version() == 4
     for fn in ("ray_aabb", "pcl_aabb", "compute_ray_aabb", "forward_decoders", "forward_query"):
         assert callable(getattr(m, fn))
     with pytest.raises(RuntimeError):     # CHECK_INPUT of the reference bindings: CUDA tensors only
