@@ -7,6 +7,7 @@
 // torch's allocator, fetches the CURRENT HIP stream and calls the C ABI; a non-zero status becomes
 // TORCH_CHECK(false, lidf_strerror(rc)) like the reference's CHECK_* macros. No compute, no state.
 // Built by implicit_depth_amd/csrc/build.py (g++, links liblidf_hip.so next to it).
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -27,6 +28,20 @@ using torch::Tensor;
 #define CHECK_I32(x) TORCH_CHECK((x).scalar_type() == torch::kInt32, #x " must be int32")
 
 void check_rc(int rc) { TORCH_CHECK(rc == LIDF_OK, lidf_strerror(rc)); }
+
+// every tensor of a call on the device of the first one (the shim launches on that device's current
+// stream, with that device current)
+void same_device(std::initializer_list<const Tensor*> ts) {
+    const Tensor* first = nullptr;
+    for (const Tensor* t : ts) {
+        if (!t || !t->defined()) continue;
+        if (!first) first = t;
+        TORCH_CHECK(t->device() == first->device(), "all tensors must be on the same device");
+    }
+}
+void same_device(const Tensor& ref, const std::vector<Tensor>& ts) {
+    for (const auto& t : ts) TORCH_CHECK(t.device() == ref.device(), "all tensors must be on the same device");
+}
 
 lidf_stream_t current_stream(const Tensor& t) {
     return (lidf_stream_t)c10::hip::getCurrentHIPStream(t.device().index()).stream();
@@ -70,6 +85,8 @@ LidfDecoder decoder_of(const std::vector<Tensor>& w, int64_t n_iter, double init
 std::vector<Tensor> ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor ray_bid, Tensor voxel_bid) {
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
+    same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
+    const c10::hip::HIPGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, R}, ray_bid.options());       // ray_aabb_cuda_kernel.cu:105-106
     auto dist = torch::zeros({V, R, 2}, ray_dir.options());
@@ -84,6 +101,8 @@ std::vector<Tensor> ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor ray_bid,
 Tensor pcl_aabb(Tensor pcl, Tensor voxel_bound, Tensor pcl_bid, Tensor voxel_bid) {
     CHECK_IN(pcl); CHECK_IN(voxel_bound); CHECK_IN(pcl_bid); CHECK_IN(voxel_bid);
     CHECK_F32(pcl); CHECK_F32(voxel_bound); CHECK_I32(pcl_bid); CHECK_I32(voxel_bid);
+    same_device({&pcl, &voxel_bound, &pcl_bid, &voxel_bid});
+    const c10::hip::HIPGuard guard(pcl.device());
     const int64_t N = pcl.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, N}, pcl_bid.options());
     check_rc(lidf_pcl_aabb_dense_f32(pcl.data_ptr<float>(), voxel_bound.data_ptr<float>(),
@@ -97,6 +116,8 @@ std::vector<Tensor> compute_ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor 
                                      Tensor voxel_bid) {
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
+    same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
+    const c10::hip::HIPGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto st = current_stream(ray_dir);
     auto iopt = ray_bid.options();
@@ -129,6 +150,8 @@ std::vector<Tensor> forward_decoders(Tensor inp, std::vector<Tensor> prob_w, std
     CHECK_DEV(inp); CHECK_F32(inp);
     TORCH_CHECK(inp.dim() == 2 && inp.stride(1) == 1, "inp_feat must be [n, D] with unit column stride");
     TORCH_CHECK(!prob_w.empty() || !off_w.empty(), "need at least one decoder");
+    same_device(inp, prob_w); same_device(inp, off_w);
+    const c10::hip::HIPGuard guard(inp.device());
     const int64_t n = inp.size(0), d = inp.size(1), ld = n > 1 ? inp.stride(0) : d;
     LidfDecoder dp = {}, dof = {};
     if (!prob_w.empty()) dp = decoder_of(prob_w, 1, 0.0, use_sigmoid);
@@ -163,11 +186,21 @@ std::vector<Tensor> forward_query(Tensor ray_dir, Tensor ray_pix, Tensor ray_bid
     CHECK_I32(pair_off); CHECK_I32(pair_ray); CHECK_I32(pair_vox);
     Tensor pix = as_i32(ray_pix, "ray_pix").contiguous(), bid = as_i32(ray_bid, "ray_bid").contiguous();
     CHECK_DEV(pix); CHECK_DEV(bid);
+    same_device({&ray_dir, &pix, &bid, &pair_off, &pair_ray, &pair_vox, &pair_t, &feat_grid, &vox_feat,
+                 ray_flat.has_value() ? &*ray_flat : nullptr, vox_center.has_value() ? &*vox_center : nullptr,
+                 depth.has_value() ? &*depth : nullptr});
+    same_device(ray_dir, prob_w); same_device(ray_dir, off_w);
+    const c10::hip::HIPGuard guard(ray_dir.device());
+    TORCH_CHECK(ray_dir.dim() == 2 && ray_dir.size(1) == 3, "ray_dir must be [R,3]");
     TORCH_CHECK(feat_grid.dim() == 4 && feat_grid.size(1) == 32, "feat_grid must be [B,32,h,w]");
     TORCH_CHECK(vox_feat.dim() == 2 && vox_feat.size(1) == 128, "vox_feat must be [V,128]");
     const int64_t R = ray_dir.size(0), P = pair_ray.size(0), V = vox_feat.size(0);
     const int64_t B = feat_grid.size(0), h = feat_grid.size(2), w = feat_grid.size(3);
     TORCH_CHECK(pair_off.size(0) == R + 1, "pair_off must have R+1 entries");
+    TORCH_CHECK(pix.dim() == 2 && pix.size(0) == R && pix.size(1) == 2 && bid.dim() == 1 && bid.size(0) == R,
+                "ray_pix / ray_bid must be [R,2] / [R]");
+    TORCH_CHECK(pair_vox.dim() == 1 && pair_vox.size(0) == P && pair_t.dim() == 2 && pair_t.size(0) == P &&
+                    pair_t.size(1) == 2, "pair_vox / pair_t must be [P] / [P,2]");
     LidfDecoder dp = decoder_of(prob_w, 1, 0.0, use_sigmoid);
     LidfDecoder dof = decoder_of(off_w, off_n_iter, off_init, use_sigmoid);
     auto fopt = ray_dir.options();
@@ -184,6 +217,7 @@ std::vector<Tensor> forward_query(Tensor ray_dir, Tensor ray_pix, Tensor ray_bid
     if (ray_flat.has_value()) {
         flat = as_i32(*ray_flat, "ray_flat").contiguous();
         CHECK_DEV(flat);
+        TORCH_CHECK(flat.dim() == 1 && flat.size(0) == R, "ray_flat must be [R]");
         q.ray_flat = flat.data_ptr<int32_t>();
     }
     q.n_pairs = P; q.pair_off = pair_off.data_ptr<int32_t>();
