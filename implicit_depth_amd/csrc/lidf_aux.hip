@@ -113,11 +113,51 @@ __global__ void lidf_boxsum_kernel(const float* __restrict__ feat, int BC, int H
     box[i] = acc;
 }
 
+// The same sums for k <= 8 through LDS: a workgroup owns 64 x 16 outputs of one channel plane,
+// stages the (64+k-1) x (16+k-1) source patch, forms the k-wide row sums once per source pixel and
+// adds k of them per output — (2k + 1) LDS reads per output instead of k*k cached global loads.
+// Same additions in the same order as lidf_boxsum_kernel (row sums from 0, then rows from 0):
+// bit-identical.
+#define BOX_TX 64
+#define BOX_TY 16
+__global__ void __launch_bounds__(256) lidf_boxsum_lds_kernel(const float* __restrict__ feat, int H,
+                                                              int W, int k,
+                                                              float* __restrict__ box) {
+    __shared__ float s_in[(BOX_TY + 7) * (BOX_TX + 7)];
+    __shared__ float s_rs[(BOX_TY + 7) * BOX_TX];
+    const int x0 = blockIdx.x * BOX_TX, y0 = blockIdx.y * BOX_TY;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int pw = BOX_TX + k - 1, ph = BOX_TY + k - 1;
+    for (int i = threadIdx.x; i < ph * pw; i += 256) {
+        const int yy = i / pw, xx = i - yy * pw;
+        const int gy = y0 + yy, gx = x0 + xx;
+        s_in[i] = (gy < H && gx < W) ? feat[plane + (size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ph * BOX_TX; i += 256) {
+        const int yy = i >> 6, xx = i & 63;
+        float row = 0.f;
+        for (int dx = 0; dx < k; ++dx) row += s_in[yy * pw + xx + dx];
+        s_rs[i] = row;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BOX_TY * BOX_TX; i += 256) {
+        const int yy = i >> 6, xx = i & 63;
+        const int gy = y0 + yy, gx = x0 + xx;
+        if (gy >= H || gx >= W) continue;
+        float acc = 0.f;
+        if (gx + k <= W && gy + k <= H)
+            for (int dy = 0; dy < k; ++dy) acc += s_rs[(yy + dy) * BOX_TX + xx];
+        box[plane + (size_t)gy * W + gx] = acc;
+    }
+}
+
 // Per-ray [ROI 2x2 x 32 channels | embed(dir)]. Workgroup = 64 rays x 4 channel groups.
 // Phase 1: rays whose 2k x 2k box is unclamped read 4 box sums per channel. Phase 2: the
 // workgroup's remaining (border / no box image) rays are compacted and their (ray, channel, bin)
 // items spread over all 256 threads, so a few clamped boxes do not serialise whole wavefronts.
-// The 64 x 128 block is staged in LDS (row stride 129) and leaves as coalesced row segments.
+// The 64 x (128 + Ed) block — ROI bins and embed(dir), whose octaves the four wavefronts share — is
+// staged in LDS and leaves as whole contiguous rows.
 __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
                                     const float* __restrict__ box, int B, int H, int W,
                                     const float* __restrict__ ray_dir,
@@ -125,9 +165,13 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
                                     const int* __restrict__ ray_bid, long long R, int half,
                                     int Lv, float* __restrict__ out, int ld,
                                     int* __restrict__ border) {
-    __shared__ float tile[64 * 129];
-    __shared__ int s_list[64];
-    __shared__ int s_nb;
+    // [64 rays][128 + Ed] (row stride TS; 155 for Lv = 4: odd, conflict-free), then the list of
+    // rays that take the general path and its length
+    extern __shared__ float rf_lds[];
+    const int TS = 128 + 3 + 6 * Lv + ((3 + 6 * Lv) & 1 ? 0 : 1);
+    float* tile = rf_lds;
+    int* s_list = (int*)(rf_lds + 64 * TS);
+    int& s_nb = s_list[64];
     const long long r0 = (long long)blockIdx.x * 64;
     const int lx = threadIdx.x, cg = threadIdx.y;
     const int tid = cg * 64 + lx;
@@ -146,7 +190,7 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
     if (live && fast) {
         // unclamped box: bin (ph,pw) = mean of the half x half pixel block at (y1+ph*half, x1+pw*half)
         const float count = (float)(half * half);
-        float* o = tile + lx * 129;
+        float* o = tile + lx * TS;
         for (int c = cg * 8; c < cg * 8 + 8; ++c) {
             const float* bi = box + ((size_t)b * 32 + c) * H * W + (size_t)y1 * W + x1;
             o[c * 4 + 0] = bi[0] / count;
@@ -209,26 +253,15 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
                 }
             }
         }
-        tile[row * 129 + cb] = acc / count;
+        tile[row * TS + cb] = acc / count;
     }
-    __syncthreads();
-    if (border) {
-        // rows of clamped boxes are written by the border kernel
-        for (int e = tid; e < nrow * 128; e += 256) {
-            const int row = e >> 7;
-            bool slow = false;
-            for (int i = 0; i < s_nb; ++i) slow |= s_list[i] == row;
-            if (!slow) out[(size_t)(r0 + row) * ld + (e & 127)] = tile[row * 129 + (e & 127)];
-        }
-    } else {
-        for (int e = tid; e < nrow * 128; e += 256)
-            out[(size_t)(r0 + (e >> 7)) * ld + (e & 127)] = tile[(e >> 7) * 129 + (e & 127)];
-    }
-    if (cg == 0 && live) {
+    // embed(dir) into the row's tail: wavefront cg takes the octaves cg, cg + 4, ...
+    if (live) {
         const float d[3] = {ray_dir[3 * r], ray_dir[3 * r + 1], ray_dir[3 * r + 2]};
-        float* e = out + (size_t)r * ld + 128;
-        for (int i = 0; i < 3; ++i) e[i] = d[i];
-        for (int l = 0; l < Lv; ++l) {
+        float* e = tile + lx * TS + 128;
+        if (cg == 0)
+            for (int i = 0; i < 3; ++i) e[i] = d[i];
+        for (int l = cg; l < Lv; l += 4) {
             const float f = (float)(1 << l);
             for (int i = 0; i < 3; ++i) {
                 e[3 + 6 * l + i] = sinf(d[i] * f);
@@ -236,22 +269,34 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
             }
         }
     }
+    __syncthreads();
+    // rows leave as contiguous segments (a wavefront per row); the ROI part of a clamped box's row
+    // is written by the border kernel
+    const int ncol = 128 + 3 + 6 * Lv;
+    for (int row = cg; row < nrow; row += 4) {
+        bool slow = false;
+        if (border)
+            for (int i = 0; i < s_nb; ++i) slow |= s_list[i] == row;
+        float* orow = out + (size_t)(r0 + row) * ld;
+        for (int c = slow ? 128 + lx : lx; c < ncol; c += 64) orow[c] = tile[row * TS + c];
+    }
 }
 
-// The collected clamped-box rays: one (ray, channel) item per thread with the RAY index fastest —
+// The collected clamped-box rays: one (ray, channel, bin) item per thread with the RAY index fastest —
 // consecutive list entries are mostly neighbouring pixels of a border row, so the taps of a
 // wavefront fall into the same rows of one channel plane (coalesced) — grid-stride over all items
-// (the count is read on the device: no host round trip). Each item evaluates its four bins.
+// (the count is read on the device: no host round trip).
 __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
     const float* __restrict__ feat, int H, int W, const int* __restrict__ ray_pix,
     const int* __restrict__ ray_bid, int half, const int* __restrict__ border,
     float* __restrict__ out, int ld) {
     const long long nb = border[0];
-    const long long nitem = nb * 32;
+    const long long nitem = nb * 128;   // (bin, channel, ray): ray fastest, then channel, then bin
     for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < nitem;
          item += (long long)gridDim.x * 256) {
         const long long rr = border[1 + item % nb];
-        const int c = (int)(item / nb);
+        const int cbin = (int)(item / nb);
+        const int c = cbin & 31, bin = cbin >> 5;
         const int qx = ray_pix[2 * rr], qy = ray_pix[2 * rr + 1];
         const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
         const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
@@ -262,21 +307,16 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
         const int gw = (int)ceilf(roi_w / 2.f), gh = (int)ceilf(roi_h / 2.f);
         const float count = (float)max(gh * gw, 1);
         const float* img = feat + ((size_t)ray_bid[rr] * 32 + c) * H * W;
-        float res[4];
-#pragma unroll
-        for (int bin = 0; bin < 4; ++bin) {
-            const int ph = bin >> 1, pw = bin & 1;
-            float acc = 0.f;  // the reference's (iy, ix) order
-            for (int iy = 0; iy < gh; ++iy) {
-                const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
-                for (int ix = 0; ix < gw; ++ix) {
-                    const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
-                    acc += bilinear(img, H, W, y, x);
-                }
+        const int ph = bin >> 1, pw = bin & 1;
+        float acc = 0.f;  // the reference's (iy, ix) order
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                acc += bilinear(img, H, W, y, x);
             }
-            res[bin] = acc / count;
         }
-        *(f32x4u*)(out + (size_t)rr * ld + 4 * c) = f32x4u{res[0], res[1], res[2], res[3]};  // rows are only dword-aligned
+        out[(size_t)rr * ld + 4 * c + bin] = acc / count;
     }
 }
 
@@ -290,16 +330,24 @@ extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, 
     int* border = nullptr;
     if (box && half > 0) {
         const long long total = (long long)B * 32 * H * W;
-        hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           st, feat, B * 32, H, W, half, box);
+        if (half <= 8 && (long long)B * 32 <= 65535)
+            hipLaunchKernelGGL(lidf_boxsum_lds_kernel,
+                               dim3((unsigned)((W + BOX_TX - 1) / BOX_TX), (unsigned)((H + BOX_TY - 1) / BOX_TY),
+                                    (unsigned)(B * 32)),
+                               dim3(256), 0, st, feat, H, W, half, box);
+        else
+            hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                               st, feat, B * 32, H, W, half, box);
         border = (int*)(box + total);
         hipError_t e = hipMemsetAsync(border, 0, 4, st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4), 0, st,
-                       feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, half, Lv, out, ld, border);
+    const int ts = 128 + 3 + 6 * Lv + ((3 + 6 * Lv) & 1 ? 0 : 1);
+    hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4),
+                       (size_t)(64 * ts + 65) * 4, st, feat, box, B, H, W, ray_dir, ray_pix, ray_bid,
+                       R, half, Lv, out, ld, border);
     if (border)
-        hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(1024), dim3(256), 0, st, feat, H, W,
+        hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(2048), dim3(256), 0, st, feat, H, W,
                            ray_pix, ray_bid, half, border, out, ld);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@
 // torch's allocator, fetches the CURRENT HIP stream and calls the C ABI; a non-zero status becomes
 // TORCH_CHECK(false, lidf_strerror(rc)) like the reference's CHECK_* macros. No compute, no state.
 // Built by implicit_depth_amd/csrc/build.py (g++, links liblidf_hip.so next to it).
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -86,7 +86,7 @@ std::vector<Tensor> ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor ray_bid,
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
     same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
-    const c10::hip::HIPGuard guard(ray_dir.device());
+    const c10::DeviceGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, R}, ray_bid.options());       // ray_aabb_cuda_kernel.cu:105-106
     auto dist = torch::zeros({V, R, 2}, ray_dir.options());
@@ -102,7 +102,7 @@ Tensor pcl_aabb(Tensor pcl, Tensor voxel_bound, Tensor pcl_bid, Tensor voxel_bid
     CHECK_IN(pcl); CHECK_IN(voxel_bound); CHECK_IN(pcl_bid); CHECK_IN(voxel_bid);
     CHECK_F32(pcl); CHECK_F32(voxel_bound); CHECK_I32(pcl_bid); CHECK_I32(voxel_bid);
     same_device({&pcl, &voxel_bound, &pcl_bid, &voxel_bid});
-    const c10::hip::HIPGuard guard(pcl.device());
+    const c10::DeviceGuard guard(pcl.device());
     const int64_t N = pcl.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, N}, pcl_bid.options());
     check_rc(lidf_pcl_aabb_dense_f32(pcl.data_ptr<float>(), voxel_bound.data_ptr<float>(),
@@ -117,7 +117,7 @@ std::vector<Tensor> compute_ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor 
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
     same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
-    const c10::hip::HIPGuard guard(ray_dir.device());
+    const c10::DeviceGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto st = current_stream(ray_dir);
     auto iopt = ray_bid.options();
@@ -151,7 +151,7 @@ std::vector<Tensor> forward_decoders(Tensor inp, std::vector<Tensor> prob_w, std
     TORCH_CHECK(inp.dim() == 2 && inp.stride(1) == 1, "inp_feat must be [n, D] with unit column stride");
     TORCH_CHECK(!prob_w.empty() || !off_w.empty(), "need at least one decoder");
     same_device(inp, prob_w); same_device(inp, off_w);
-    const c10::hip::HIPGuard guard(inp.device());
+    const c10::DeviceGuard guard(inp.device());
     const int64_t n = inp.size(0), d = inp.size(1), ld = n > 1 ? inp.stride(0) : d;
     LidfDecoder dp = {}, dof = {};
     if (!prob_w.empty()) dp = decoder_of(prob_w, 1, 0.0, use_sigmoid);
@@ -190,7 +190,7 @@ std::vector<Tensor> forward_query(Tensor ray_dir, Tensor ray_pix, Tensor ray_bid
                  ray_flat.has_value() ? &*ray_flat : nullptr, vox_center.has_value() ? &*vox_center : nullptr,
                  depth.has_value() ? &*depth : nullptr});
     same_device(ray_dir, prob_w); same_device(ray_dir, off_w);
-    const c10::hip::HIPGuard guard(ray_dir.device());
+    const c10::DeviceGuard guard(ray_dir.device());
     TORCH_CHECK(ray_dir.dim() == 2 && ray_dir.size(1) == 3, "ray_dir must be [R,3]");
     TORCH_CHECK(feat_grid.dim() == 4 && feat_grid.size(1) == 32, "feat_grid must be [B,32,h,w]");
     TORCH_CHECK(vox_feat.dim() == 2 && vox_feat.size(1) == 128, "vox_feat must be [V,128]");

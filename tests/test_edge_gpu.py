@@ -96,6 +96,40 @@ def test_ray_features_border_pixels(cuda):
         assert (got[:, 128:] - orc.embed(scene["ray_dir"], 4)).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("bbox,h,w", [(8, 37, 83), (8, 240, 320), (6, 20, 70), (16, 33, 65), (2, 9, 9)])
+def test_ray_features_interior_bins_bit_exact(cuda, bbox, h, w):
+    """Unclamped boxes: a bin is a half x half block mean, summed row-wise from 0 and then over the
+    rows from 0 — the order of the box-sum kernels (plain and LDS-tiled). Bit-exact against those
+    f32 additions replayed on the CPU, for image shapes that are not multiples of the 64 x 16 tile."""
+    from implicit_depth_amd.query import ray_features
+    g = torch.Generator().manual_seed(bbox + h)
+    B = 2
+    feat = torch.randn(B, 32, h, w, generator=g)
+    feat[0, 0, :2] = 0.0
+    feat[0, 1, :, :3] = -0.0          # signed zeros survive the same additions
+    half = bbox // 2
+    ys, xs = torch.meshgrid(torch.arange(half, h - half), torch.arange(half, w - half), indexing="ij")
+    pix = torch.stack((xs.reshape(-1), ys.reshape(-1)), 1).int()
+    R1 = pix.shape[0]
+    pix = pix.repeat(B, 1).contiguous()
+    bid = torch.arange(B).repeat_interleave(R1).int()
+    d = torch.nn.functional.normalize(torch.randn(pix.shape[0], 3, generator=g), dim=1)
+    got = ray_features(feat.to(cuda), d.to(cuda), pix.to(cuda), bid.to(cuda), bbox, 4).cpu()[:, :128]
+    # box sums in the kernels' order
+    rows = torch.zeros(B, 32, h, w - half + 1)
+    for dx in range(half):
+        rows = rows + feat[:, :, :, dx:dx + w - half + 1]
+    box = torch.zeros(B, 32, h - half + 1, w - half + 1)
+    for dy in range(half):
+        box = box + rows[:, :, dy:dy + h - half + 1]
+    ref = torch.empty(B, R1, 32, 2, 2)
+    x1, y1 = (xs - half).reshape(-1), (ys - half).reshape(-1)
+    for ph in range(2):
+        for pw in range(2):
+            ref[:, :, :, ph, pw] = box[:, :, y1 + ph * half, x1 + pw * half].permute(0, 2, 1) / float(half * half)
+    assert torch.equal(got.view(B, R1, 128).view(torch.int32), ref.reshape(B, R1, 128).view(torch.int32))
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_full_size_properties(cuda, precision):
     """BASELINE configs[1] size (240x320x64): properties that need no full-size oracle run."""
