@@ -372,7 +372,9 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int G>
+// U rays per group, handled side by side: the loads of all U rays are requested before any is used
+// (the kernel is a chain of four dependent memory round trips per ray and nothing else).
+template <int G, int U>
 __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        const float* __restrict__ pos,
                                        const int* __restrict__ off, long long R, long long P,
@@ -381,68 +383,132 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        float* __restrict__ softmax, long long* __restrict__ maxid,
                                        float* __restrict__ pred_pos, float* __restrict__ depth) {
     const int lane = threadIdx.x & (G - 1);
-    const long long ray = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    // (a whole group shares `ray`; groups beyond R idle through the shuffles with an empty range)
-    const bool live = ray < R;
-    const int beg = live ? off[ray] : 0, end = live ? off[ray + 1] : 0;
-    float m = -INFINITY;
-    for (int i = beg + lane; i < end; i += G) m = fmaxf(m, prob[i]);
-    m = group_max<G>(m);
-    float s = 0.f;
-    for (int i = beg + lane; i < end; i += G) s += expf(prob[i] - m);
-    s = group_sum<G>(s);
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = beg + lane; i < end; i += G) {
-        const float v = expf(prob[i] - m) / s;
-        if (softmax) softmax[i] = v;
-        if (v > bv) {  // ascending i per lane: strict > keeps the first on ties
-            bv = v;
-            bi = i;
+    const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    // (a whole group shares its rays; groups beyond R idle through the shuffles with empty ranges)
+    long long ray[U];
+    bool live[U];
+    int beg[U], end[U];
+    bool fast = true;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ray[u] = grp * U + u;
+        live[u] = ray[u] < R;
+        beg[u] = live[u] ? off[ray[u]] : 0;
+        end[u] = live[u] ? off[ray[u] + 1] : 0;
+        fast &= end[u] - beg[u] <= G;
+    }
+    float bv[U];
+    int bi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        bv[u] = -INFINITY;
+        bi[u] = 0x7fffffff;
+    }
+    if (fast) {
+        // at most one candidate per lane (every ray of the dense headline list at G = 64, nearly
+        // every ray of a geometry-derived frame at G = 8): the logit is read once and its
+        // exponential formed once — the same values the general loops below produce
+        float p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = beg[u] + lane < end[u] ? prob[beg[u] + lane] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = beg[u] + lane;
+            const bool has = i < end[u];
+            const float m = group_max<G>(fmaxf(-INFINITY, p[u]));   // (a NaN logit drops out, as in the loop)
+            const float e = has ? expf(p[u] - m) : 0.f;
+            const float s = group_sum<G>(e);
+            if (has) {
+                const float v = e / s;
+                if (softmax) softmax[i] = v;
+                if (v > bv[u]) {
+                    bv[u] = v;
+                    bi[u] = i;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float m = -INFINITY;
+            for (int i = beg[u] + lane; i < end[u]; i += G) m = fmaxf(m, prob[i]);
+            m = group_max<G>(m);
+            float s = 0.f;
+            for (int i = beg[u] + lane; i < end[u]; i += G) s += expf(prob[i] - m);
+            s = group_sum<G>(s);
+            for (int i = beg[u] + lane; i < end[u]; i += G) {
+                const float v = expf(prob[i] - m) / s;
+                if (softmax) softmax[i] = v;
+                if (v > bv[u]) {  // ascending i per lane: strict > keeps the first on ties
+                    bv[u] = v;
+                    bi[u] = i;
+                }
+            }
         }
     }
 #pragma unroll
-    for (int sh = G / 2; sh >= 1; sh >>= 1) {
-        const float ov = __shfl_xor(bv, sh);
-        const int oi = __shfl_xor(bi, sh);
-        if (ov > bv || (ov == bv && oi < bi)) {
-            bv = ov;
-            bi = oi;
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int sh = G / 2; sh >= 1; sh >>= 1) {
+            const float ov = __shfl_xor(bv[u], sh);
+            const int oi = __shfl_xor(bi[u], sh);
+            if (ov > bv[u] || (ov == bv[u] && oi < bi[u])) {
+                bv[u] = ov;
+                bi[u] = oi;
+            }
         }
     }
-    if (lane == 0 && live) {
-        // no candidate, or no softmax value compared greater than -inf (NaN / +-inf logits make
-        // every value NaN): torch_scatter's scatter_max leaves its out-of-range index then, which
-        // selects the dummy row (pipeline.py:452-454) -> id = P, position (0,0,0)
-        const bool empty = end <= beg || bi >= end;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (!empty && pos) {
-            x = pos[3 * (size_t)bi];
-            y = pos[3 * (size_t)bi + 1];
-            z = pos[3 * (size_t)bi + 2];
+    // every lane of the group holds the U results; lane u writes ray u (one pass of loads and
+    // stores for the group instead of U passes on lane 0)
+    if (lane < U) {
+        long long my_ray = ray[0], my_dst = 0;
+        int my_bi = bi[0], my_beg = beg[0], my_end = end[0];
+        bool my_live = live[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            if (lane == u) {
+                my_ray = ray[u], my_bi = bi[u], my_beg = beg[u], my_end = end[u], my_live = live[u];
+            }
         }
-        if (maxid) maxid[ray] = empty ? P : (long long)bi;
-        if (pred_pos) {
-            pred_pos[3 * ray] = x;
-            pred_pos[3 * ray + 1] = y;
-            pred_pos[3 * ray + 2] = z;
+        if (my_live) {
+            if (depth) my_dst = (long long)ray_bid[my_ray] * hw + ray_flat[my_ray];
+            // no candidate, or no softmax value compared greater than -inf (NaN / +-inf logits
+            // make every value NaN): torch_scatter's scatter_max leaves its out-of-range index
+            // then, which selects the dummy row (pipeline.py:452-454) -> id = P, position (0,0,0)
+            const bool empty = my_end <= my_beg || my_bi >= my_end;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (!empty && pos) {
+                x = pos[3 * (size_t)my_bi];
+                y = pos[3 * (size_t)my_bi + 1];
+                z = pos[3 * (size_t)my_bi + 2];
+            }
+            if (maxid) maxid[my_ray] = empty ? P : (long long)my_bi;
+            if (pred_pos) {
+                pred_pos[3 * my_ray] = x;
+                pred_pos[3 * my_ray + 1] = y;
+                pred_pos[3 * my_ray + 2] = z;
+            }
+            if (depth) depth[my_dst] = z;
         }
-        if (depth) depth[(size_t)ray_bid[ray] * hw + ray_flat[ray]] = z;
     }
 }
 
+#define REDUCE_U 4
 extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos, const int* off,
                                              long long R, long long P, const int* ray_bid,
                                              const int* ray_flat, long long hw, float* softmax,
                                              long long* maxid, float* pred_pos, float* depth,
                                              hipStream_t st) {
     if (R <= 0) return hipSuccess;
+    const long long groups = (R + REDUCE_U - 1) / REDUCE_U;
     if (P <= 8 * R)
-        hipLaunchKernelGGL(lidf_ray_reduce_kernel<8>, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, st,
-                           prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos, depth);
+        hipLaunchKernelGGL((lidf_ray_reduce_kernel<8, REDUCE_U>), dim3((unsigned)((groups + 31) / 32)),
+                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
+                           pred_pos, depth);
     else
-        hipLaunchKernelGGL(lidf_ray_reduce_kernel<64>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st,
-                           prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid, pred_pos, depth);
+        hipLaunchKernelGGL((lidf_ray_reduce_kernel<64, REDUCE_U>), dim3((unsigned)((groups + 3) / 4)),
+                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
+                           pred_pos, depth);
     return hipGetLastError();
 }
 
