@@ -29,11 +29,14 @@
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Development-only phase timers (-DLIDF_PROFILE): wave 0 of block 0 accumulates s_memtime deltas
-// per phase into a.out_base[0..7] (as integers). The shipped library is built without it.
+// per phase into a.out_base[0..7] (as integers); every wavefront leaves its start / end wall clock
+// and its shader-clock total at a.out_base[16 + 4 (4 block + wave) ..]. The shipped library is built
+// without it.
 #ifdef LIDF_PROFILE
-#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long prof_c0 = prof_t, prof_w0 = wall_clock64();
 #define PROF(i) { long long t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
-#define PROF_DUMP if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; }
+#define PROF_DUMP if (blockIdx.x == 0 && threadIdx.x == 0 && a.out_base) { for (int i_ = 0; i_ < 8; ++i_) ((long long*)a.out_base)[i_] = prof_acc[i_]; } \
+    if ((threadIdx.x & 63) == 0 && a.out_base) { long long* o_ = (long long*)a.out_base + 16 + 4 * (blockIdx.x * 4 + (threadIdx.x >> 6)); o_[0] = prof_w0; o_[1] = wall_clock64(); o_[2] = clock64() - prof_c0; }
 #else
 #define PROF_DECL
 #define PROF(i)

@@ -35,7 +35,7 @@ if kind == "scene":
     # rays, voxels and pairs as the candidate generator produces them on a geometry-derived frame
     from implicit_depth_amd import PointNet2Stage, pipeline as pl
     from implicit_depth_amd.synthetic import synthetic_batch
-    batch, feat = synthetic_batch(1, 240, 320, seed=77)
+    batch, feat = synthetic_batch(int(os.environ.get("FRAMES", "1")), 240, 320, seed=77)
     torch.manual_seed(3)
     pn = PointNet2Stage(6, 128, 32).to(dev).eval()
     with torch.no_grad():
@@ -64,3 +64,15 @@ for n, v in zip(names, t):
     print("%-34s %12d cycles %5.1f%%  per wave-tile %9.0f" % (n, v, 100.0 * v / max(tot, 1), v / per))
 print("total %d cycles, per wave-tile %.0f (MFMA floor 2778 x 64 = 177792)" % (tot, tot / per))
 print("points kernel %.3f ms" % hev.elapsed_ms(e0, e1))
+# per-wavefront start / end (100 MHz wall clock) and shader-clock totals
+nw = min(256, ntile) * 4
+w = o["rayfeat"].view(-1)[32:32 + 8 * nw].view(torch.int64).cpu().view(nw, 4)
+t0 = w[:, 0].min()
+end = (w[:, 1] - t0).double() / 100.0   # us
+start = (w[:, 0] - t0).double() / 100.0
+cyc = w[:, 2].double()
+import numpy as np
+print("wavefront end times us: min %.1f  median %.1f  p90 %.1f  max %.1f; start max %.1f" % (
+    end.min(), end.median(), np.percentile(end.numpy(), 90), end.max(), start.max()))
+print("shader cycles per wavefront: min %.0f median %.0f max %.0f; effective clock of the slowest %.2f GHz" % (
+    cyc.min(), cyc.median(), cyc.max(), cyc[end.argmax()] / ((end.max() - start[end.argmax()]) * 1e3)))
