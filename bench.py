@@ -36,6 +36,29 @@ PEAK_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (susta
 DTYPE_F16X3 = "f16x3 (f32 operands split into two f16 pieces, 3 products per term, f32 accumulate)"
 
 
+# The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a version banner
+# when its communicator comes up on some boxes), so file descriptor 1 is pointed at stderr for the
+# whole run and the record goes out through a duplicate of the original stdout.
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(record):
+    line = (json.dumps(record) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 class HipEvents:
     """Minimal hipEvent wrapper over libamdhip64 (torch.cuda.Event hides its handle until it has
     been recorded; the library needs raw hipEvent_t values to record on the launch stream)."""
@@ -342,7 +365,7 @@ def secondary(args):
         flop_exec, basis = 3.0 * fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_exec * P / (kern_ms * 1e-3) / 1e12)
     peak = 8000.0 if hbm else (PEAK_F16_TFLOPS if split_rows else PEAK_F32_TFLOPS)
-    print(json.dumps({
+    emit({
         "metric": "Mpoints/sec, %s" % args.workload, "value": round(P * args.steps / elapsed / 1e6, 2),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -354,8 +377,7 @@ def secondary(args):
                      "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),
                      "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4),
                      "basis": "algorithmic bytes" if hbm else basis,
-                     "achieved_alg": None if hbm else round(flop_alg * P / (kern_ms * 1e-3) / 1e12, 2)}}),
-          flush=True)
+                     "achieved_alg": None if hbm else round(flop_alg * P / (kern_ms * 1e-3) / 1e12, 2)}})
 
 
 def e2e(args):
@@ -414,7 +436,7 @@ def e2e(args):
         for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
     P, R = int(dd["pair_ray"].shape[0]), int(dd["miss_ray_dir"].shape[0])
-    print(json.dumps({
+    emit({
         "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -428,7 +450,7 @@ def e2e(args):
         "frames_per_s": round(B * args.steps / elapsed, 2),
         "rays_per_s": round(R * args.steps / elapsed, 1),
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-        "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}}), flush=True)
+        "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
 
 
 def main():
@@ -455,6 +477,7 @@ def main():
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
                          "stand-alone positional encoding (the one HBM-bound kernel of the path)")
     args = ap.parse_args()
+    claim_stdout()
     if args.workload in ("decoders", "embed", "train", "train-query"):
         return secondary(args)
     if args.workload == "e2e":
@@ -668,7 +691,7 @@ def main():
                 if hip_h is not None:
                     ph = parity_record(hip_h, ref, scene, hip_h["depth"])
                     line["split_f16"]["parity"] = {k: ph[k] for k in ("depth_l1", "max_abs", "ok")}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()

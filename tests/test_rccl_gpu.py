@@ -30,7 +30,9 @@ def test_bench_distributed_path_one_rank(cuda):
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"], 29612)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]   # ONE JSON line on stdout, whatever RCCL prints
+    line = lines[0]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["collective"]["gathered_equals_local"] is True
