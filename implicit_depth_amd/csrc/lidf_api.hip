@@ -527,8 +527,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.sqrt3 = (float)1.7320508075688772;  // np.sqrt(3) rounded to f32 (pipeline.py:438)
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
-            a.tile_counter = (int*)(ws + w.counter);
-            if (split) CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
+            a.tile_counter = (int*)(ws + w.counter);   // dynamic tile hand-out of both kernels
+            CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
 #ifdef LIDF_PROFILE
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif

@@ -408,6 +408,9 @@ struct Geo {
 #ifndef LIDF_RB
 #define LIDF_RB 4   // rank-1 rounds whose row loads are in flight together
 #endif
+#ifndef LIDF_CHUNK
+#define LIDF_CHUNK 4   // consecutive wave-tiles per dynamic hand-out
+#endif
 
 // ST: every pass's H1 | H2 | H3 | offset-in and the pre-activation output are kept (training forward
 // of both decoders in one launch, a.tr_passes / a.tr_pre per net).
@@ -429,13 +432,46 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     lds_float* lds_wave = (lds_float*)lds_raw + __builtin_amdgcn_readfirstlane(wave) * 8192;
     const unsigned lds_addr = (unsigned)(size_t)lds_wave;
 
-    // contiguous range of 128-point tiles per workgroup; the 4 waves interleave inside it
+    // Wave-tiles (32 points) are the unit of work; a wavefront walks a sequence of them.
+    //  * a.tile_counter == nullptr: the static split — a contiguous range of 128-point tiles per
+    //    workgroup, the 4 waves interleaved inside it (wave-tile 4 tile + wave);
+    //  * else: dynamic hand-out in chunks of up to LIDF_CHUNK consecutive wave-tiles per wavefront. The
+    //    first chunk of wavefront g is chunk g; further chunks come from an atomic counter (zeroed
+    //    by the launch before), requested one chunk ahead so that the round trip is never waited
+    //    for. Compute units do not run at one clock (2.36-2.40 GHz on the headline launch) and tiles
+    //    of ragged lists do not cost the same (1 to 16 rank-1 rounds per net): the faster take more.
+    const long long nwt = (a.n + 31) / 32;
+    // (short lists keep the static split: with a handful of tiles per wavefront one tile is the
+    // grain either way and the first requests would be waited for)
+    const bool dyn = a.tile_counter != nullptr && nwt >= 32LL * gridDim.x * 4;
     const long long ntile = (a.n + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
-    if (tb >= te_) return;
-    if (tb * 128 + wave * 32 >= a.n) return;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const long long nwaves = (long long)gridDim.x * 4;
+    // chunk length: LIDF_CHUNK when a wavefront has many tiles ahead of it, else 2 (a chunk is also
+    // the grain of the tail)
+    const int chunk = nwt / nwaves >= 16 * LIDF_CHUNK ? LIDF_CHUNK : 2;
+    long long w_cur = dyn ? ((long long)blockIdx.x * 4 + uwave) * chunk : tb * 4 + uwave;
+    if (!dyn && tb >= te_) return;
+    if (w_cur >= nwt) return;
+    int pend_raw = 0;   // lane 0: the counter value of the chunk requested ahead
+    int left = chunk;   // wave-tiles left in the chunk the sequence is in (counting its head)
+    auto request_chunk = [&]() {
+        if (lane == 0) pend_raw = atomicAdd(a.tile_counter, 1);
+    };
+    // successor of wave-tile w in this wavefront's sequence (>= nwt: the sequence has ended)
+    auto next_wt = [&](long long w) -> long long {
+        if (!dyn) return w + 4 < te_ * 4 ? w + 4 : nwt;
+        if (--left > 0) return w + 1;
+        left = chunk;
+        const long long s = (nwaves + __builtin_amdgcn_readfirstlane(pend_raw)) * chunk;
+        request_chunk();
+        return s;
+    };
+    if (dyn) request_chunk();
+    long long w_nxt = next_wt(w_cur), w_nx2 = 0;
 
     // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
     f32x4 ring[LIDF_RING];
@@ -443,12 +479,12 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
 
     // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
-    auto load_idx = [&](long long tile, Geo& g) {
+    auto load_idx = [&](long long wt, Geo& g) {
         const long long last = a.n - 1;
-        long long t0 = tile * 128;                  // uniform
-        if (t0 > last) t0 = last & ~127LL;          // a prefetch past the end re-reads the last tile
+        long long t0 = wt * 32;                     // uniform
+        if (t0 > last) t0 = last & ~31LL;           // a prefetch past the end re-reads the last tile
         const long long rem = last - t0;
-        const int lo = wave * 32 + col;
+        const int lo = col;
         const unsigned off = (unsigned)(lo < rem ? lo : rem);  // out-of-range points are clamped
         g.ray = (a.pair_ray + t0)[off];
         g.vid = (a.pair_vox + t0)[off];
@@ -469,8 +505,8 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     // two-stage geometry prefetch: `cur` complete, `nxt` has its indices (directions are fetched
     // one tile ahead, indices two tiles ahead)
     Geo cur = {}, nxt = {}, nx2 = {};
-    load_idx(tb, cur);
-    load_idx(tb + 1, nxt);
+    load_idx(w_cur, cur);
+    load_idx(w_nxt, nxt);
     load_dir(cur);
 
     // layer-1 accumulator of the first (tile, net): fetched here, in the open
@@ -489,14 +525,14 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     }
 
     PROF_DECL
-    for (long long tile = tb; tile < te_; ++tile) {
-        if (tile * 128 + wave * 32 >= a.n) break;  // whole wave out of range (wave-uniform)
+    for (; w_cur < nwt; w_cur = w_nxt, w_nxt = w_nx2) {
         PROF(0)
-        const long long p = tile * 128 + wave * 32 + col;
+        const long long p = w_cur * 32 + col;
         const bool valid = p < a.n;
 
         load_dir(nxt);
-        load_idx(tile + 2, nx2);
+        w_nx2 = next_wt(w_nxt);
+        load_idx(w_nx2, nx2);
         // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the
         // leave position (pipeline.py:349-360; 'rel' subtracts the voxel centre)
         const float tt = h ? cur.tl : cur.te;

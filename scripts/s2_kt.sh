@@ -11,3 +11,8 @@ for r in cur.execute("select name,count(*),avg(duration),min(duration) from kern
 PY
 cat $O/kt_$TAG.txt; python -c "
 import json; d=json.load(open('$O/bench_$TAG.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
+python - <<PY
+import sqlite3
+cur=sqlite3.connect('/tmp/p_kt/r_results.db').cursor()
+for r in cur.execute("select name,max(vgpr_count),max(accum_vgpr_count),max(sgpr_count),max(scratch_size) from kernels where name like '%points_fused%' group by name"): print(r)
+PY
