@@ -409,7 +409,7 @@ struct Geo {
 #define LIDF_RB 4   // rank-1 rounds whose row loads are in flight together
 #endif
 #ifndef LIDF_CHUNK
-#define LIDF_CHUNK 4   // consecutive wave-tiles per dynamic hand-out
+#define LIDF_CHUNK 2   // consecutive wave-tiles per dynamic hand-out (4: 12.40 ms, 2: 12.36, 1: 12.37)
 #endif
 
 // ST: every pass's H1 | H2 | H3 | offset-in and the pre-activation output are kept (training forward
@@ -435,7 +435,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     // Wave-tiles (32 points) are the unit of work; a wavefront walks a sequence of them.
     //  * a.tile_counter == nullptr: the static split — a contiguous range of 128-point tiles per
     //    workgroup, the 4 waves interleaved inside it (wave-tile 4 tile + wave);
-    //  * else: dynamic hand-out in chunks of up to LIDF_CHUNK consecutive wave-tiles per wavefront. The
+    //  * else: dynamic hand-out in chunks of LIDF_CHUNK consecutive wave-tiles per wavefront. The
     //    first chunk of wavefront g is chunk g; further chunks come from an atomic counter (zeroed
     //    by the launch before), requested one chunk ahead so that the round trip is never waited
     //    for. Compute units do not run at one clock (2.36-2.40 GHz on the headline launch) and tiles
@@ -450,9 +450,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const long long nwaves = (long long)gridDim.x * 4;
-    // chunk length: LIDF_CHUNK when a wavefront has many tiles ahead of it, else 2 (a chunk is also
-    // the grain of the tail)
-    const int chunk = nwt / nwaves >= 16 * LIDF_CHUNK ? LIDF_CHUNK : 2;
+    const int chunk = LIDF_CHUNK;   // (a chunk is also the grain of the tail)
     long long w_cur = dyn ? ((long long)blockIdx.x * 4 + uwave) * chunk : tb * 4 + uwave;
     if (!dyn && tb >= te_) return;
     if (w_cur >= nwt) return;
