@@ -90,7 +90,7 @@ class LidfRefineArgs(C.Structure):
         ("offset_range0", C.c_float), ("offset_range1", C.c_float),
         ("pred_pos_out", C.c_void_p), ("end_voxel_id", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("precision", C.c_int32), ("pnet_select", C.c_void_p),
+        ("precision", C.c_int32), ("pnet_select", C.c_void_p), ("packed", C.c_void_p),
     ]
 
 
@@ -138,6 +138,8 @@ SIGNATURES = {
     "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
+    "lidf_refine_pack_bytes": (_SZ, [_I, _I]),
+    "lidf_refine_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), _I, _I, _P, _SZ, _P]),
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),
@@ -177,6 +179,7 @@ _lib = None
 # copy.deepcopy(module) or pickling of the module — and dropped with the module.
 import weakref  # noqa: E402
 PACK_CACHE = weakref.WeakKeyDictionary()
+PACK_CACHE_REFINE = weakref.WeakKeyDictionary()   # stage-2 IEF (lidf_refine_pack_f32), keyed by the module
 
 
 def lib():

@@ -986,7 +986,8 @@ struct RefineWs {
 static size_t refine_fact_bytes(int D);
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
-                                 float* out, float* voxpart, char* scratch, hipStream_t st);
+                                 float* out, float* voxpart, char* scratch, hipStream_t st,
+                                 int pack_mode);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -1061,8 +1062,11 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
         // inp_embed[:, 0:128] = occ_voxel_feat[end_voxel] (pipeline.py:1016) never materialises: its
         // share of layer 1 is W1[:, 0:128] vox_feat[v] + b1 (+ c), one row per voxel, gathered as
         // the start of the layer-1 accumulators
+        // weight streams: the caller's blob (lidf_refine_pack_f32, once per parameter version) or
+        // packed here for this call
         if ((rc = refine_ief_factorised(q->off, D, vox_feat, V, inp_embed, end_voxel, R, off,
-                                        (float*)(ws + w.voxpart), ws + w.fact, st)))
+                                        (float*)(ws + w.voxpart),
+                                        q->packed ? (char*)q->packed : ws + w.fact, st, q->packed ? 2 : 0)))
             return rc;
     } else {
         CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
@@ -1171,8 +1175,8 @@ static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) /
 // NOTE: the bias / u columns exist in the stream only when the layer has them; a layer with a
 // second operand segment passes k = k + k1 here.
 
-static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st) {
-    if (L.n <= 0) return LIDF_OK;
+static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st, int pack_mode = 0) {
+    if (L.n <= 0 && pack_mode != 1) return LIDF_OK;
     const int nt = nt_for(L.nout);
     L1Map m = rows_map(L.k, L.c0, L.k1, L.c1, L.b ? 1 : 0);
     m.KQ1 = (m.D + 2 + 7) / 8;   // room for the bias and the u column
@@ -1184,7 +1188,8 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st)
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.dcore ? L.dcore : L.k; nw.is_ief = 0;
     if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
-    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (pack_mode == 1) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
     a.D = m.D; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
@@ -1221,12 +1226,13 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
                            int64_t ldx, int64_t n, const int32_t* pair_vox, const int32_t* pair_ray,
                            const float* voxpart, const float* raypart, float* passes, float* pre,
                            float* out, char* sbuf, int cus, hipStream_t st,
-                           int mode = LIDF_MODE_TRAIN) {
+                           int mode = LIDF_MODE_TRAIN, int pack_mode = 0) {
     const StreamLayout lay = lidf_make_layout(1, LIDF_MODE_ROWS, m);
     float* stream_buf = (float*)sbuf;
     float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
     const NetW nw = to_netw(dec, dcore);
-    CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, aux, st));
+    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, aux, st));
+    if (pack_mode == 1) return LIDF_OK;
     PointsArgs a = {};
     a.stream = stream_buf; a.aux = aux; a.nets = 1;
     a.l1_quads = lay.l1_quads; a.net_quads = lay.net_quads; a.n = n;
@@ -1247,7 +1253,8 @@ static size_t refine_fact_bytes(int D) { return linex_stream_bytes(128) + chain_
 
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
-                                 float* out, float* voxpart, char* scratch, hipStream_t st) {
+                                 float* out, float* voxpart, char* scratch, hipStream_t st,
+                                 int pack_mode) {
     int rc, cus;
     if ((rc = cu_count(&cus))) return rc;
     const int ld1 = D + (off->is_ief ? 16 : 0);
@@ -1255,10 +1262,28 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
     L.w = off->w1; L.b = off->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
     L.ief = off->is_ief ? off : nullptr;   // bias += c
     L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
-    if ((rc = run_linex(L, (float*)scratch, cus, st))) return rc;
+    if ((rc = run_linex(L, (float*)scratch, cus, st, pack_mode))) return rc;
     return run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
                            nullptr, voxpart, nullptr, nullptr, nullptr, out,
-                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER);
+                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode);
+}
+
+LIDF_API size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views) {
+    if (multires < 0 || multires > 16 || multires_views < 0 || multires_views > 16) return 0;
+    return align_up(refine_fact_bytes(256 + 3 + 6 * multires + 3 + 6 * multires_views), 256);
+}
+
+LIDF_API int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int32_t multires_views,
+                                    void* packed, size_t packed_bytes, lidf_stream_t stream) {
+    if (!off) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(off))) return rc;
+    const size_t need = lidf_refine_pack_bytes(multires, multires_views);
+    if (!need) return LIDF_ERR_UNSUPPORTED;
+    if (!packed || packed_bytes < need) return LIDF_ERR_WORKSPACE;
+    const int D = 256 + 3 + 6 * multires + 3 + 6 * multires_views;
+    return refine_ief_factorised(off, D, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
+                                 (char*)packed, (hipStream_t)stream, 1);
 }
 
 struct TrainWs {

@@ -459,6 +459,24 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     from .pointnet import packed_pointnet
     keep.append(packed_pointnet(pnet_model, pn, dev))   # weight streams packed once per version
     do = _decoder_struct(offset_dec, keep)
+    packed = None
+    if precision == "f32":   # the IEF's weight streams, packed once per parameter version
+        params = list(offset_dec.parameters())
+        key = (multires, multires_views, str(dev), tuple((p.data_ptr(), p._version) for p in params))
+        cache = _lib.PACK_CACHE_REFINE.get(offset_dec)
+        if cache is None or cache[0] != key:
+            nb = L.lidf_refine_pack_bytes(multires, multires_views)
+            blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.lidf_refine_pack_f32(C.byref(do), multires, multires_views, _lib.ptr(blob), nb,
+                                                  _lib.current_stream(dev)))
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+            cache = (key, blob, ev)
+            _lib.PACK_CACHE_REFINE[offset_dec] = cache
+        else:
+            torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
+        packed = cache[1]
     cur = pred_pos.contiguous()
     end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
     if pnet_select is not None:
@@ -486,6 +504,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         q.precision = PRECISIONS[precision]
         q.pnet_select = pnet_select.data_ptr() if pnet_select is not None else None
+        q.packed = packed.data_ptr() if packed is not None else None
         with torch.cuda.device(dev):
             _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out

@@ -362,8 +362,14 @@ typedef struct LidfRefineArgs {
      * predicted point back into the PointNet; every ray is still refined. NULL = all rays
      * (refine.use_all_pix == True, the shipped configs).                                         */
     const uint8_t* pnet_select;
+    /* f32 precision: the IEF's packed weight streams (lidf_refine_pack_f32, built once per
+     * parameter version) or NULL = packed inside the call, into the workspace.                  */
+    const void* packed;
 } LidfRefineArgs;
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
+size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views);
+int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int32_t multires_views,
+                         void* packed, size_t packed_bytes, lidf_stream_t stream);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
 
 /* ---- Eval depth metrics ----------------------------------------------------------------------

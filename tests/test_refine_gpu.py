@@ -161,3 +161,51 @@ def test_refine_synthetic_vs_oracle(cuda, precision):
                                    precision=precision)
         assert (got.cpu() - pos).abs().max().item() <= TOL, pos_rel
         assert (gev.cpu().long() == ev).all()
+
+
+def test_refine_packed_weights_follow_parameter_updates(cuda):
+    """lidf_refine keeps the IEF's packed weight streams per parameter version
+    (lidf_refine_pack_f32): a second call reuses them, an in-place update is picked up."""
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.query import lidf_query, lidf_refine
+    scene = orc.synthetic_scene(1, 12, 16, 6, seed=23, ragged=True)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob, off = make_module("IMNET", scene["prob_p"], D, cuda), make_module("IEF", scene["off_p"], D, cuda)
+    with torch.no_grad():
+        s1 = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                        s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+    g = torch.Generator().manual_seed(4)
+    vb = torch.cat((scene["vox_center"] - 0.125, scene["vox_center"] + 0.125), 1)
+    vbid = torch.zeros(729, dtype=torch.int32)
+    rgb = torch.randn(1, 3, 12, 16, generator=g)
+    valid_inp = torch.randn(300, 6, generator=g) * 0.2
+    valid_vox = torch.randint(0, scene["V"], (300,), generator=g).int()
+    pnet_p = orc.init_pointnet(5, 1.5)
+    offr_p = orc.randomize_biases(orc.init_decoder("IEF", 334, 77, 5.0), 78)
+    pnet, offr = make_pointnet(pnet_p, cuda), make_module("IEF", offr_p, 334, cuda)
+
+    def run(mod):
+        with torch.no_grad():
+            return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], s1["pred_pos"],
+                               s1["max_pair_id"], s["pair_vox"], vb.to(cuda), vbid.to(cuda), rgb.to(cuda),
+                               s["feat_grid"], valid_inp.to(cuda), valid_vox.to(cuda), pnet, mod)[0]
+    a = run(offr)
+    blob = _lib.PACK_CACHE_REFINE[offr][1]
+    b = run(offr)
+    assert _lib.PACK_CACHE_REFINE[offr][1] is blob and torch.equal(a, b)
+    with torch.no_grad():
+        offr.linear_1.weight.mul_(1.5)          # in place, as an optimizer step
+        offr.linear_3.bias.add_(0.05)
+    c = run(offr)
+    p2 = {k: v.clone() for k, v in offr_p.items()}
+    p2["linear_1.weight"] = p2["linear_1.weight"] * 1.5
+    p2["linear_3.bias"] = p2["linear_3.bias"] + 0.05
+    d = run(make_module("IEF", p2, 334, cuda))   # a fresh module with the updated parameters
+    assert torch.equal(c, d) and (c - a).abs().max().item() > 1e-5
+    pos = s1["pred_pos"].cpu()
+    for _ in range(2):
+        pos, _, _ = orc.refine_step(pos, scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["ray_flat"],
+                                    s1["max_pair_id"].cpu(), scene["pair_vox"], vb, vbid, rgb, scene["feat_grid"],
+                                    valid_inp, valid_vox, pnet_p, p2)
+    assert (c.cpu() - pos).abs().max().item() <= TOL
