@@ -85,3 +85,44 @@ def test_config4_256_candidates(cuda, precision):
     scene = _scene(1, 240, 320, 256, 1238)
     got = run_query(scene, cuda, precision=precision)
     check_full_size(scene, got, cuda)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_full_size_ragged(cuda, precision):
+    """240x320 rays with U{0..64} candidates each (P ~ 2.46 M, not a multiple of the 32-point
+    wave-tile): the list is long enough for the dynamic tile hand-out of the per-point kernel, has
+    empty rays and tiles that hold up to 32 rays. Size-independent properties plus 160 random WHOLE
+    rays against the oracle."""
+    scene = _scene(1, 240, 320, 64, 1240, True)
+    R, P = scene["R"], scene["P"]
+    assert P % 32 != 0 and P > 32 * 1024 * 32
+    got = run_query(scene, cuda, precision=precision)
+    off = scene["pair_off"].long()
+    cnt = off[1:] - off[:-1]
+    sm = got["pred_prob_end_softmax"]
+    assert torch.isfinite(got["pair_pred_pos"]).all() and torch.isfinite(sm).all()
+    ray = scene["pair_ray"].long().to(cuda)
+    sums = torch.zeros(R, device=cuda).index_add_(0, ray, sm)
+    assert (sums[(cnt > 0).to(cuda)] - 1).abs().max().item() <= 1e-5
+    mid = got["max_pair_id"]
+    empty = (cnt == 0).to(cuda)
+    assert (mid[empty] == P).all() and (got["pred_pos"][empty] == 0).all()
+    ne = ~empty
+    assert (ray[mid[ne]] == torch.arange(R, device=cuda)[ne]).all()        # inside its own ray
+    assert (got["pred_pos"][ne] == got["pair_pred_pos"][mid[ne]]).all()
+    assert (got["depth"].reshape(-1) == got["pred_pos"][:, 2]).all()
+    g = torch.Generator().manual_seed(1)
+    rows = torch.randperm(R, generator=g)[:160].sort().values
+    rows = torch.cat((rows, torch.tensor([R - 1]))).unique()                # the ray of the partial last tile too
+    c = cnt[rows]
+    pidx = torch.cat([torch.arange(off[r], off[r + 1]) for r in rows.tolist()])
+    local_off = torch.zeros(rows.numel() + 1, dtype=torch.int32)
+    local_off[1:] = torch.cumsum(c, 0).int()
+    ref = orc.query(scene["ray_dir"][rows], scene["ray_pix"][rows], scene["ray_bid"][rows],
+                    torch.arange(rows.numel()).repeat_interleave(c), scene["pair_vox"][pidx].long(),
+                    scene["pair_t"][pidx], local_off, scene["feat_grid"], scene["vox_feat"],
+                    scene["prob_p"], scene["off_p"], fast_roi=True)
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert (got[k][pidx.to(cuda)].cpu() - ref[k]).abs().max().item() <= TOL, k
+    assert (got["pred_pos"][rows.to(cuda)].cpu() - ref["pred_pos"]).abs().max().item() <= TOL
+    assert (sm[pidx.to(cuda)].cpu() - ref["pred_prob_end_softmax"]).abs().max().item() <= 1e-5
