@@ -129,6 +129,16 @@ static int cu_count(int* out) {
     return LIDF_OK;
 }
 
+extern "C" hipError_t lidf_launch_zero_segments(float* const*, const long long*, int, hipStream_t);
+// the gradient buffers of one decoder start at zero: one launch over the ten arrays
+static hipError_t zero_decoder_grads(const LidfDecoderGrads* g, int ld1, int is_ief, hipStream_t st) {
+    float* const p[10] = {g->w1, g->b1, g->w2, g->b2, g->w3, g->b3, g->w4, g->b4,
+                          is_ief ? g->wenc : nullptr, is_ief ? g->benc : nullptr};
+    const long long c[10] = {(long long)LIDF_H1 * ld1, LIDF_H1, (long long)LIDF_H2 * LIDF_H1, LIDF_H2,
+                             (long long)LIDF_H3 * LIDF_H2, LIDF_H3, LIDF_H3, 1, 16, 16};
+    return lidf_launch_zero_segments(p, c, 10, st);
+}
+
 static int check_decoder(const LidfDecoder* d) {
     if (!d) return LIDF_OK;
     if (!d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->w3 || !d->b3 || !d->w4 || !d->b4)
@@ -1350,18 +1360,7 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
     const int npass = dec->is_ief ? dec->n_iter : 1;
     const int ld1 = d + (dec->is_ief ? 16 : 0);
     // gradients start at zero (also what an empty batch returns)
-    CHECK_HIP(hipMemsetAsync(grads->w1, 0, (size_t)LIDF_H1 * ld1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b1, 0, LIDF_H1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w2, 0, (size_t)LIDF_H2 * LIDF_H1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b2, 0, LIDF_H2 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w3, 0, (size_t)LIDF_H3 * LIDF_H2 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b3, 0, LIDF_H3 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w4, 0, LIDF_H3 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b4, 0, 4, st));
-    if (dec->is_ief) {
-        CHECK_HIP(hipMemsetAsync(grads->wenc, 0, 16 * 4, st));
-        CHECK_HIP(hipMemsetAsync(grads->benc, 0, 16 * 4, st));
-    }
+    CHECK_HIP(zero_decoder_grads(grads, ld1, dec->is_ief, st));
     if (n == 0) return LIDF_OK;
     if (!inp || !act || !g_out) return LIDF_ERR_BAD_ARG;
     const TrainWs w = train_ws(n, d);
@@ -1667,18 +1666,7 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     const int E2 = 2 * (3 + 6 * q->multires), Ed = 3 + 6 * q->multires_views;
     const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
     const int npass = dec->is_ief ? dec->n_iter : 1;
-    CHECK_HIP(hipMemsetAsync(grads->w1, 0, (size_t)LIDF_H1 * ld1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b1, 0, LIDF_H1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w2, 0, (size_t)LIDF_H2 * LIDF_H1 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b2, 0, LIDF_H2 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w3, 0, (size_t)LIDF_H3 * LIDF_H2 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b3, 0, LIDF_H3 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->w4, 0, LIDF_H3 * 4, st));
-    CHECK_HIP(hipMemsetAsync(grads->b4, 0, 4, st));
-    if (dec->is_ief) {
-        CHECK_HIP(hipMemsetAsync(grads->wenc, 0, 16 * 4, st));
-        CHECK_HIP(hipMemsetAsync(grads->benc, 0, 16 * 4, st));
-    }
+    CHECK_HIP(zero_decoder_grads(grads, ld1, dec->is_ief, st));
     if (!accumulate_inputs) {
         if (d_vox_feat && V > 0) CHECK_HIP(hipMemsetAsync(d_vox_feat, 0, (size_t)V * 128 * 4, st));
         if (d_rayfeat && R > 0) CHECK_HIP(hipMemsetAsync(d_rayfeat, 0, (size_t)R * (128 + Ed) * 4, st));

@@ -353,6 +353,44 @@ extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Zero up to ZERO_SEGS float arrays in one launch (the gradient buffers of a decoder: ten
+// hipMemsetAsync calls, each a fill kernel of its own, before).
+// ------------------------------------------------------------------------------------------------
+#define ZERO_SEGS 12
+struct ZeroSegs {
+    float* p[ZERO_SEGS];
+    long long end[ZERO_SEGS];   // running element counts: segment i covers [end[i-1], end[i])
+    int n;
+};
+__global__ void lidf_zero_segments_kernel(ZeroSegs z) {
+    const long long total = z.n ? z.end[z.n - 1] : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int sgm = 0;
+#pragma unroll
+        for (int k = 0; k < ZERO_SEGS - 1; ++k) sgm += (k < z.n - 1 && i >= z.end[k]) ? 1 : 0;
+        z.p[sgm][i - (sgm ? z.end[sgm - 1] : 0)] = 0.f;
+    }
+}
+extern "C" hipError_t lidf_launch_zero_segments(float* const* ptrs, const long long* counts, int n,
+                                                hipStream_t st) {
+    ZeroSegs z = {};
+    long long run = 0;
+    for (int i = 0; i < n && z.n < ZERO_SEGS; ++i) {
+        if (!ptrs[i] || counts[i] <= 0) continue;
+        run += counts[i];
+        z.p[z.n] = ptrs[i];
+        z.end[z.n] = run;
+        ++z.n;
+    }
+    if (!z.n) return hipSuccess;
+    const long long blocks = (run + 255) / 256;
+    hipLaunchKernelGGL(lidf_zero_segments_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)),
+                       dim3(256), 0, st, z);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-ray softmax / argmax / select — scatter_softmax + scatter_max + dummy-row gather
 // (models/pipeline.py:442-454) on ray-major CSR pairs: one wavefront per ray, wave-level
 // shuffles for max, sum and arg-max. Ties: lowest pair index. Empty ray: id = P, pos = 0.
