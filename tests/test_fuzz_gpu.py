@@ -5,6 +5,8 @@ models/pipeline.py:221-269 keeps an arbitrary ascending subset of the pixels), c
 from one ray to 32 of them), voxel ids and segment lengths. Both kernels (f32 and f16x3) must stay
 within the 1e-4 contract and agree with the oracle on every arg-max whose margin is not a rounding
 tie."""
+import os
+
 import pytest
 import torch
 
@@ -56,7 +58,11 @@ def random_case(seed):
     return scene
 
 
-@pytest.mark.parametrize("seed", range(12))
+# LIDF_FUZZ_SEEDS=a:b widens the sweep for a soak run (default: 12 seeds, a few seconds)
+_LO, _HI = (int(v) for v in os.environ.get("LIDF_FUZZ_SEEDS", "0:12").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_query(cuda, seed):
     scene = random_case(seed)
     ref = oracle_query(scene)
