@@ -45,9 +45,13 @@ _REAL_STDOUT = None
 def claim_stdout():
     global _REAL_STDOUT
     if _REAL_STDOUT is None:
-        sys.stdout.flush()
-        _REAL_STDOUT = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            _REAL_STDOUT = saved
+        except OSError:   # no usable stderr: leave stdout as it is
+            _REAL_STDOUT = None
 
 
 def emit(record):
