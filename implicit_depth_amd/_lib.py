@@ -109,6 +109,11 @@ SIGNATURES = {
     "lidf_query_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_query_pack_bytes": (_SZ, []),
     "lidf_query_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), C.POINTER(LidfDecoder), _I, _I, _I, _P, _SZ, _P]),
+    "lidf_pack_guard_bytes": (_SZ, []),
+    "lidf_query_pack_guarded_f32": (C.c_int, [C.POINTER(LidfDecoder), C.POINTER(LidfDecoder), _I, _I, _I, _P,
+                                              _SZ, _P, _P]),
+    "lidf_pointnet_pack_guarded_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _SZ, _P, _P]),
+    "lidf_refine_pack_guarded_f32": (C.c_int, [C.POINTER(LidfDecoder), _I, _I, _P, _SZ, _P, _P]),
     "lidf_query_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P]),
     "lidf_query_profile_f32": (C.c_int, [C.POINTER(LidfQueryArgs), _P, _P, _P]),
     "lidf_ray_features_workspace_bytes": (_SZ, [_I, _I, _I, _I64]),
@@ -180,6 +185,51 @@ _lib = None
 import weakref  # noqa: E402
 PACK_CACHE = weakref.WeakKeyDictionary()
 PACK_CACHE_REFINE = weakref.WeakKeyDictionary()   # stage-2 IEF (lidf_refine_pack_f32), keyed by the module
+FROZEN = weakref.WeakSet()                        # modules whose packed streams the caller froze
+
+
+class PackedEntry:
+    """One packed blob with its device-side guard (lidf_*_pack_guarded_f32) and the stream that used
+    it last. `key` holds only host-side configuration (never a parameter version: torch's version
+    counter misses `p.data` writes — the guard compares the parameters' CONTENTS on the device)."""
+    __slots__ = ("key", "blob", "guard", "stream", "frozen_ready")
+
+    def __init__(self, key, blob, guard):
+        self.key, self.blob, self.guard, self.stream, self.frozen_ready = key, blob, guard, None, False
+
+
+def packed_entry(cache, owner, key, nbytes, device):
+    """The entry of `owner` in `cache` for `key` (created with a zero-filled guard when absent or
+    when the configuration changed), ordered after its previous use when that was on another stream."""
+    import torch
+    e = cache.get(owner)
+    if e is None or e.key != key:
+        blob = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        guard = torch.zeros((lib().lidf_pack_guard_bytes(),), dtype=torch.uint8, device=device)
+        e = PackedEntry(key, blob, guard)
+        cache[owner] = e
+    cur = torch.cuda.current_stream(device)
+    if e.stream is not None and e.stream != cur:
+        cur.wait_stream(e.stream)       # the blob / guard were last touched on another stream
+    e.stream = cur
+    return e
+
+
+def freeze_packed(*modules):
+    """Opt out of the per-call fingerprint check for these modules: their packed weight streams are
+    built on the next call and then trusted until invalidate_packed() — for inference loops that
+    never touch the parameters and want the last microseconds (the check costs one small launch
+    plus the early-exit pack launches per call)."""
+    for m in modules:
+        FROZEN.add(m)
+
+
+def invalidate_packed(*modules):
+    """Drop the packed weight streams of these modules (and un-freeze them): the next call re-packs."""
+    for m in modules:
+        FROZEN.discard(m)
+        PACK_CACHE.pop(m, None)
+        PACK_CACHE_REFINE.pop(m, None)
 
 
 def lib():

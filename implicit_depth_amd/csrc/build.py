@@ -21,24 +21,63 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+_PERF_FLAGS = [
+    # MFMA results in architectural VGPRs wherever they fit: a layer's outputs are the next
+    # layer's B operands, which must be VGPRs — with accumulators in AGPRs every activation
+    # costs a v_accvgpr_read, a VALU slot that f32 MFMA does not hide on gfx950. The decoder
+    # pass is ordered k-major so that the live set fits (lidf_points.hip); AGPRs stay as spill space
+    ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+]
+
+
+def _probe_flags(hipcc, objdir):
+    """Performance-only LLVM options: kept when this compiler knows them (an older LLVM answers
+    'Unknown command line argument' and would otherwise block the whole build)."""
+    src = os.path.join(objdir, "probe.hip")
+    with open(src, "w") as f:
+        f.write("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[0] = 1.f; }\n")
+    keep = []
+    base = [hipcc, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(objdir, "probe.o")]
+    subprocess.run(base, check=True)    # the compiler itself must work
+    for fl in _PERF_FLAGS:
+        r = subprocess.run(base + fl, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if r.returncode == 0:
+            keep += fl
+        else:
+            print("build.py: compiler does not accept %s; building without it (slower kernels)" % " ".join(fl),
+                  file=sys.stderr)
+    return keep
+
+
 def build(force=False, verbose=False):
+    """Compile every source to its own object (in parallel, only the stale ones) and link."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [
-        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-ffp-contract=off", "-fvisibility=hidden",
         # the decoder pass is one 168-step fully unrolled software pipeline; clang's default
         # 16k-instruction cap on `#pragma unroll` would silently leave it rolled (arrays in scratch)
         "-mllvm", "-pragma-unroll-threshold=8000000",
-        # MFMA results in architectural VGPRs wherever they fit: a layer's outputs are the next
-        # layer's B operands, which must be VGPRs — with accumulators in AGPRs every activation
-        # costs a v_accvgpr_read, a VALU slot that f32 MFMA does not hide on gfx950. The decoder
-        # pass is ordered k-major so that the live set fits (lidf_points.hip); AGPRs stay as spill space
-        "-mllvm", "-amdgpu-mfma-vgpr-form",
-        "-I", os.path.join(ROOT, "include"),
-        "-I", HERE, "-o", LIB,
-    ] + [os.path.join(HERE, s) for s in SOURCES]
+    ] + _probe_flags(hipcc, objdir) + ["-I", os.path.join(ROOT, "include"), "-I", HERE]
+    hdr_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(HERE, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp, op = os.path.join(HERE, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
+            cmd = [hipcc] + flags + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,5 +1,7 @@
 // lidf_api.hip — the extern "C" surface declared in include/lidf_hip.h: argument checks,
 // workspace carving, kernel sequencing. No allocation, no synchronisation, no global state.
+#include <string.h>
+
 #include "lidf_device.h"
 #include "lidf_hip.h"
 
@@ -44,7 +46,10 @@ hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
 hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
                              float*, int, float*, float*, size_t, hipStream_t);
 hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, const float*, const float*,
-                                     const float*, const float*, float*, hipStream_t);
+                                     const float*, const float*, float*, const LidfPackGuardState*,
+                                     hipStream_t);
+hipError_t lidf_launch_fingerprint(const float* const*, const long long*, int, unsigned long long,
+                                   LidfPackGuardState*, hipStream_t);
 size_t lidf_pointnet_chain_stream_bytes(void);
 hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int*, const float*, float*,
                                       float*, long long, long long, int, hipStream_t);
@@ -111,7 +116,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 4
+#define LIDF_ABI_VERSION 5
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \
@@ -119,6 +124,24 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Guarded packing (lidf_*_pack_guarded_f32): the guard of the API call in progress on this thread;
+// every pack launch below it carries the pointer and returns at once when the fingerprint of the
+// parameters did not change. Set and cleared inside one API call (no state survives the call).
+static thread_local const LidfPackGuardState* tl_guard = nullptr;
+struct GuardScope {
+    explicit GuardScope(const LidfPackGuardState* g) { tl_guard = g; }
+    ~GuardScope() { tl_guard = nullptr; }
+};
+static inline StreamLayout guarded(StreamLayout lay) {
+    lay.guard = tl_guard;
+    return lay;
+}
+static inline unsigned long long salt_mix(unsigned long long h, unsigned long long v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 27);
+}
 
 static int cu_count(int* out) {
     int dev = 0;
@@ -386,19 +409,19 @@ static int pack_query_weights(const LidfDecoder* prob, const LidfDecoder* off, i
     mf.leave_c0 = 256 + E;
     const bool split = precision == LIDF_PRECISION_F16X3;
     if (split)
-        CHECK_HIP(lidf_launch_pack_h(lidf_make_layout_h(2, mf), np, no, mf, stream_pts, aux_pts, st));
+        CHECK_HIP(lidf_launch_pack_h(guarded(lidf_make_layout_h(2, mf)), np, no, mf, stream_pts, aux_pts, st));
     else
-        CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_FUSED, mf), np, no, mf, stream_pts,
+        CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_FUSED, mf)), np, no, mf, stream_pts,
                                    aux_pts, st));
     L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
-    CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_L1ONLY, mv), np, no, mv, stream_vox,
+    CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_L1ONLY, mv)), np, no, mv, stream_vox,
                                aux_pts, st));
     L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
     if (split)
-        CHECK_HIP(lidf_launch_pack_rows_h(lidf_make_layout_rows_h(2, mr.D, 1), np, no, mr, stream_ray,
+        CHECK_HIP(lidf_launch_pack_rows_h(guarded(lidf_make_layout_rows_h(2, mr.D, 1)), np, no, mr, stream_ray,
                                           nullptr, st));
     else
-        CHECK_HIP(lidf_launch_pack(lidf_make_layout(2, LIDF_MODE_L1ONLY, mr), np, no, mr, stream_ray,
+        CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_L1ONLY, mr)), np, no, mr, stream_ray,
                                    aux_pts, st));
     return LIDF_OK;
 }
@@ -427,6 +450,48 @@ LIDF_API int lidf_query_pack_f32(const LidfDecoder* prob, const LidfDecoder* off
     if (rc) return rc;
     if (!packed || packed_bytes < query_ws(1, 1, multires, multires_views).packed_end)
         return LIDF_ERR_WORKSPACE;
+    return pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
+                              (hipStream_t)stream);
+}
+
+LIDF_API size_t lidf_pack_guard_bytes(void) { return align_up(sizeof(LidfPackGuardState), 64); }
+
+// the parameter buffers of one decoder as fingerprint segments (d_in = columns of linear_1)
+static int decoder_segs(const LidfDecoder* d, int d_in, const float** ptrs, long long* n, int k) {
+    const float* p[10] = {d->w1, d->b1, d->w2, d->b2, d->w3, d->b3, d->w4, d->b4, d->wenc, d->benc};
+    const long long c[10] = {(long long)LIDF_H1 * d_in, LIDF_H1, (long long)LIDF_H2 * LIDF_H1, LIDF_H2,
+                             (long long)LIDF_H3 * LIDF_H2, LIDF_H3, LIDF_H3, 1, 16, 16};
+    for (int i = 0; i < (d->is_ief ? 10 : 8); ++i) { ptrs[k] = p[i]; n[k] = c[i]; ++k; }
+    return k;
+}
+static unsigned long long decoder_salt(unsigned long long h, const LidfDecoder* d) {
+    unsigned init_bits;
+    memcpy(&init_bits, &d->init_offset, 4);
+    h = salt_mix(h, (unsigned long long)d->is_ief | ((unsigned long long)d->n_iter << 8) |
+                        ((unsigned long long)d->use_sigmoid << 40));
+    return salt_mix(h, init_bits);
+}
+
+LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDecoder* off, int multires,
+                                           int multires_views, int precision, void* packed,
+                                           size_t packed_bytes, void* guard, lidf_stream_t stream) {
+    int rc = check_query_model(prob, off, multires, multires_views, precision);
+    if (rc) return rc;
+    if (!guard) return LIDF_ERR_BAD_ARG;
+    if (!packed || packed_bytes < query_ws(1, 1, multires, multires_views).packed_end)
+        return LIDF_ERR_WORKSPACE;
+    const int D = 256 + 2 * (3 + 6 * multires) + 3 + 6 * multires_views;
+    const float* ptrs[LIDF_FP_MAX_SEGS];
+    long long cnt[LIDF_FP_MAX_SEGS];
+    int k = decoder_segs(prob, D + (prob->is_ief ? 16 : 0), ptrs, cnt, 0);
+    k = decoder_segs(off, D + (off->is_ief ? 16 : 0), ptrs, cnt, k);
+    unsigned long long salt = salt_mix(0x51ED270B1ull, ((unsigned long long)multires << 32) |
+                                                           ((unsigned long long)multires_views << 8) |
+                                                           (unsigned long long)precision);
+    salt = decoder_salt(decoder_salt(salt, prob), off);
+    CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, k, salt, (LidfPackGuardState*)guard,
+                                      (hipStream_t)stream));
+    GuardScope scope((const LidfPackGuardState*)guard);
     return pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
                               (hipStream_t)stream);
 }
@@ -830,7 +895,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.is_ief = 0; nw.dcore = L.ldw;
-    if (!prepacked) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (!prepacked) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, nullptr, st));
     if (pack_only) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
@@ -905,7 +970,7 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
         // intermediate is written; the per-voxel layers stay launches over V rows
         if (!pp)
             CHECK_HIP(lidf_launch_pack_pointnet(w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_p3, w->w_p4,
-                                                w->b_p4, b.chain, st));
+                                                w->b_p4, b.chain, tl_guard, st));
         if (!po) CHECK_HIP(lidf_launch_pointnet_chain(1, b.chain, inp, vox, nullptr, b.pool1, b.part, n_vox, n, cus, st));
         if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
                              b.g1, 64, nullptr, nullptr, b.streams[2], cus, st, po, pp)))
@@ -986,6 +1051,22 @@ LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t 
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     return pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1);
+}
+
+LIDF_API int lidf_pointnet_pack_guarded_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
+                                              void* guard, lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
+    if (!guard) return LIDF_ERR_BAD_ARG;
+    if (!packed || packed_bytes < lidf_pointnet_pack_bytes()) return LIDF_ERR_WORKSPACE;
+    const float* ptrs[12] = {w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_v1, w->b_v1,
+                             w->w_p3, w->b_p3, w->w_p4, w->b_p4, w->w_v2, w->b_v2};
+    const long long cnt[12] = {32 * 6, 32, 64 * 32, 64, 64 * 64, 64, 128 * 128, 128, 128 * 128, 128,
+                               128 * 128, 128};
+    CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, 12, 0x9071E7ull, (LidfPackGuardState*)guard,
+                                      (hipStream_t)stream));
+    GuardScope scope((const LidfPackGuardState*)guard);
+    return lidf_pointnet_pack_f32(w, packed, packed_bytes, stream);
 }
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
@@ -1198,7 +1279,7 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.dcore ? L.dcore : L.k; nw.is_ief = 0;
     if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
-    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, nullptr, st));
+    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, nullptr, st));
     if (pack_mode == 1) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
@@ -1241,7 +1322,7 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     float* stream_buf = (float*)sbuf;
     float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
     const NetW nw = to_netw(dec, dcore);
-    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(lay, nw, nw, m, stream_buf, aux, st));
+    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, aux, st));
     if (pack_mode == 1) return LIDF_OK;
     PointsArgs a = {};
     a.stream = stream_buf; a.aux = aux; a.nets = 1;
@@ -1294,6 +1375,28 @@ LIDF_API int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int3
     const int D = 256 + 3 + 6 * multires + 3 + 6 * multires_views;
     return refine_ief_factorised(off, D, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
                                  (char*)packed, (hipStream_t)stream, 1);
+}
+
+LIDF_API int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multires,
+                                            int32_t multires_views, void* packed, size_t packed_bytes,
+                                            void* guard, lidf_stream_t stream) {
+    if (!off || !guard) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(off))) return rc;
+    const size_t need = lidf_refine_pack_bytes(multires, multires_views);
+    if (!need) return LIDF_ERR_UNSUPPORTED;
+    if (!packed || packed_bytes < need) return LIDF_ERR_WORKSPACE;
+    const int D = 256 + 3 + 6 * multires + 3 + 6 * multires_views;
+    const float* ptrs[LIDF_FP_MAX_SEGS];
+    long long cnt[LIDF_FP_MAX_SEGS];
+    const int k = decoder_segs(off, D + (off->is_ief ? 16 : 0), ptrs, cnt, 0);
+    unsigned long long salt = salt_mix(0x2EF19Eull, ((unsigned long long)multires << 32) |
+                                                        (unsigned long long)multires_views);
+    salt = decoder_salt(salt, off);
+    CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, k, salt, (LidfPackGuardState*)guard,
+                                      (hipStream_t)stream));
+    GuardScope scope((const LidfPackGuardState*)guard);
+    return lidf_refine_pack_f32(off, multires, multires_views, packed, packed_bytes, stream);
 }
 
 struct TrainWs {

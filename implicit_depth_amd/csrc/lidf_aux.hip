@@ -1351,3 +1351,86 @@ extern "C" hipError_t lidf_launch_miss_fill(const void* mask, int dtype, long lo
                        pix64);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Guarded packing: fingerprint of the raw parameter buffers, compared on the device
+// ------------------------------------------------------------------------------------------------
+// A module's packed weight streams are valid as long as the CONTENTS of its nn.Parameter storage do
+// not change. The host cannot see that (torch's version counter misses `p.data.mul_()`; SURVEY §8b
+// "Ownership"), so every guarded call hashes the buffers on the device: word i of the concatenated
+// buffers contributes splitmix64(i << 32 | word) to a 64-bit sum (order-independent, so blocks add
+// their partial sums with one atomic each). The block that finishes last compares the sum (+ a salt
+// of the host-side scalars that are baked into the streams) with the fingerprint the streams were
+// built from, leaves the verdict in guard->dirty for the pack kernels that follow on the stream and
+// re-arms the accumulator. ~1.1 MB of parameters: one launch of a few microseconds, no host sync.
+struct FpSegs {
+    const unsigned* p[LIDF_FP_MAX_SEGS];
+    unsigned n[LIDF_FP_MAX_SEGS];      // words
+    unsigned base[LIDF_FP_MAX_SEGS];   // index of the segment's first word in the concatenation
+};
+
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+#define FP_BLOCKS_PER_SEG 32
+
+__global__ void lidf_fingerprint_kernel(FpSegs s, unsigned long long salt, LidfPackGuardState* g) {
+    const int seg = blockIdx.y;
+    const unsigned n = s.n[seg], base = s.base[seg];
+    const unsigned* __restrict__ p = s.p[seg];
+    unsigned long long acc = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {   // four independent loads in flight
+        const unsigned w0 = p[i], w1 = p[i + stride], w2 = p[i + 2 * stride], w3 = p[i + 3 * stride];
+        acc += fp_mix(((unsigned long long)(base + i) << 32) | w0);
+        acc += fp_mix(((unsigned long long)(base + i + stride) << 32) | w1);
+        acc += fp_mix(((unsigned long long)(base + i + 2 * stride) << 32) | w2);
+        acc += fp_mix(((unsigned long long)(base + i + 3 * stride) << 32) | w3);
+    }
+    for (; i < n; i += stride) acc += fp_mix(((unsigned long long)(base + i) << 32) | p[i]);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)acc, o), hi = __shfl_xor((unsigned)(acc >> 32), o);
+        acc += ((unsigned long long)hi << 32) | lo;
+    }
+    __shared__ unsigned long long part[4];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        last = atomicAdd(&g->ticket, 1u) == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long h = atomicAdd(&g->acc, 0ull) + salt;
+        g->dirty = (!g->valid || g->hash != h) ? 1 : 0;
+        g->hash = h;
+        g->valid = 1;
+        g->acc = 0;
+        g->ticket = 0;
+    }
+}
+
+extern "C" hipError_t lidf_launch_fingerprint(const float* const* ptrs, const long long* floats,
+                                              int nseg, unsigned long long salt,
+                                              LidfPackGuardState* guard, hipStream_t st) {
+    if (nseg <= 0 || nseg > LIDF_FP_MAX_SEGS) return hipErrorInvalidValue;
+    FpSegs s = {};
+    unsigned base = 0;
+    for (int i = 0; i < nseg; ++i) {
+        s.p[i] = (const unsigned*)ptrs[i];
+        s.n[i] = (unsigned)floats[i];
+        s.base[i] = base;
+        base += s.n[i];
+    }
+    hipLaunchKernelGGL(lidf_fingerprint_kernel, dim3(FP_BLOCKS_PER_SEG, nseg), dim3(256), 0, st, s,
+                       salt, guard);
+    return hipGetLastError();
+}

@@ -82,6 +82,22 @@ struct StreamLayout {
     int l1_quads;   // per net
     int net_quads;  // per-net block size in quads (layer 1 only for L1ONLY)
     int total;      // floats
+    // guarded packing (lidf_*_pack_guarded_f32): when set, the pack kernel returns at once unless
+    // guard->dirty != 0 — the parameters' fingerprint did not change since the stream was built
+    const struct LidfPackGuardState* guard;
+};
+
+#define LIDF_FP_MAX_SEGS 24   // parameter buffers per fingerprint launch (two decoders: 18)
+
+// Device-side state of a guarded pack (lidf_pack_guard_bytes() bytes, zero-filled by the caller once):
+// the fingerprint the packed streams were built from and the verdict of the latest comparison.
+struct LidfPackGuardState {
+    unsigned long long hash;   // fingerprint of the parameters the streams were packed from
+    unsigned long long acc;    // running sum of the fingerprint launch in flight (0 between launches)
+    unsigned int ticket;       // blocks of that launch that have finished
+    int dirty;                 // verdict of the latest launch: 1 = re-pack
+    int valid;                 // hash holds a fingerprint
+    int pad;
 };
 
 static inline int lidf_l1_quads(int mode, const L1Map& m) {
@@ -96,6 +112,7 @@ static inline StreamLayout lidf_make_layout(int nets, int mode, const L1Map& m) 
     s.l1_quads = lidf_l1_quads(mode, m);
     s.net_quads = s.l1_quads + (mode == LIDF_MODE_L1ONLY || mode == LIDF_MODE_LINEAR ? 0 : LIDF_PASS_QUADS);
     s.total = nets * s.net_quads * 256;
+    s.guard = nullptr;
     return s;
 }
 
@@ -107,6 +124,7 @@ static inline StreamLayout lidf_make_layout_h(int nets, const L1Map& m) {
     s.l1_quads = 0;  // layer 1 is interleaved with layer 2 inside the section
     s.net_quads = LIDF_HPASS_QUADS;
     s.total = nets * s.net_quads * 256;
+    s.guard = nullptr;
     return s;
 }
 

@@ -67,7 +67,9 @@ __device__ __forceinline__ int pn_feature(int s, int half) {
     return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half;
 }
 
-__global__ void lidf_pack_pointnet_kernel(PnetW w, float* __restrict__ stream) {
+__global__ void lidf_pack_pointnet_kernel(PnetW w, float* __restrict__ stream,
+                                          const LidfPackGuardState* guard) {
+    if (guard && guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= PN_S2_QUADS * 256) return;
     int quad = e / 256;
@@ -366,9 +368,11 @@ __global__ void __launch_bounds__(256) lidf_pointnet_poolmax_kernel(const float*
 extern "C" hipError_t lidf_launch_pack_pointnet(const float* w_p1, const float* b_p1,
                                                 const float* w_p2, const float* b_p2,
                                                 const float* w_p3, const float* w_p4,
-                                                const float* b_p4, float* stream, hipStream_t st) {
+                                                const float* b_p4, float* stream,
+                                                const LidfPackGuardState* guard, hipStream_t st) {
     PnetW w = {w_p1, b_p1, w_p2, b_p2, w_p3, w_p4, b_p4};
-    hipLaunchKernelGGL(lidf_pack_pointnet_kernel, dim3(PN_S2_QUADS), dim3(256), 0, st, w, stream);
+    hipLaunchKernelGGL(lidf_pack_pointnet_kernel, dim3(PN_S2_QUADS), dim3(256), 0, st, w, stream,
+                       guard);
     return hipGetLastError();
 }
 

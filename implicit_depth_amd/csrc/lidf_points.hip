@@ -139,6 +139,7 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
 
 __global__ void lidf_pack_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m, float* stream,
                                  float* aux) {
+    if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     NetW nets[2] = {net0, net1};
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < lay.total) stream[e] = stream_value(lay, nets, m, e);

@@ -189,6 +189,7 @@ __device__ _Float16 stream_value_h(const StreamLayout& lay, const NetW* nets, co
 
 __global__ void lidf_pack_h_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m,
                                    _Float16* stream, float* aux) {
+    if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     NetW nets[2] = {net0, net1};
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (long long)lay.total * 2) stream[e] = stream_value_h(lay, nets, m, e);

@@ -133,6 +133,7 @@ __device__ _Float16 stream_value_r(const StreamLayout& lay, const NetW* nets, co
 
 __global__ void lidf_pack_r_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m,
                                    _Float16* stream, float* aux) {
+    if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     NetW nets[2] = {net0, net1};
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (long long)lay.total * 2) stream[e] = stream_value_r(lay, nets, m, e);
@@ -522,6 +523,7 @@ extern "C" StreamLayout lidf_make_layout_rows_h(int nets, int D, int l1only) {
     s.l1_quads = 16 * ((D + 1 + 15) / 16);
     s.net_quads = s.l1_quads + (l1only ? 0 : RPASS_QUADS);
     s.total = nets * s.net_quads * 256;
+    s.guard = nullptr;
     return s;
 }
 

@@ -29,6 +29,18 @@ using torch::Tensor;
 
 void check_rc(int rc) { TORCH_CHECK(rc == LIDF_OK, lidf_strerror(rc)); }
 
+// [n, 3] points / directions against [V, 6] boxes with one image index per row of each: the kernels
+// index these shapes unchecked, so a wrong inner dimension or a short index tensor would read out of
+// bounds on the device
+void check_box_shapes(const Tensor& pts, const Tensor& voxel_bound, const Tensor& pts_bid,
+                      const Tensor& voxel_bid, const char* what) {
+    TORCH_CHECK(pts.dim() == 2 && pts.size(1) == 3, what, " must be [n,3]");
+    TORCH_CHECK(voxel_bound.dim() == 2 && voxel_bound.size(1) == 6, "voxel_bound must be [V,6]");
+    TORCH_CHECK(pts_bid.dim() == 1 && pts_bid.size(0) == pts.size(0), "one image index per row of ", what);
+    TORCH_CHECK(voxel_bid.dim() == 1 && voxel_bid.size(0) == voxel_bound.size(0),
+                "voxel_bid must be [V]");
+}
+
 // every tensor of a call on the device of the first one (the shim launches on that device's current
 // stream, with that device current)
 void same_device(std::initializer_list<const Tensor*> ts) {
@@ -86,6 +98,7 @@ std::vector<Tensor> ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor ray_bid,
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
     same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
+    check_box_shapes(ray_dir, voxel_bound, ray_bid, voxel_bid, "ray_dir");
     const c10::DeviceGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, R}, ray_bid.options());       // ray_aabb_cuda_kernel.cu:105-106
@@ -102,6 +115,7 @@ Tensor pcl_aabb(Tensor pcl, Tensor voxel_bound, Tensor pcl_bid, Tensor voxel_bid
     CHECK_IN(pcl); CHECK_IN(voxel_bound); CHECK_IN(pcl_bid); CHECK_IN(voxel_bid);
     CHECK_F32(pcl); CHECK_F32(voxel_bound); CHECK_I32(pcl_bid); CHECK_I32(voxel_bid);
     same_device({&pcl, &voxel_bound, &pcl_bid, &voxel_bid});
+    check_box_shapes(pcl, voxel_bound, pcl_bid, voxel_bid, "pcl");
     const c10::DeviceGuard guard(pcl.device());
     const int64_t N = pcl.size(0), V = voxel_bound.size(0);
     auto mask = torch::zeros({V, N}, pcl_bid.options());
@@ -117,6 +131,7 @@ std::vector<Tensor> compute_ray_aabb(Tensor ray_dir, Tensor voxel_bound, Tensor 
     CHECK_IN(ray_dir); CHECK_IN(voxel_bound); CHECK_IN(ray_bid); CHECK_IN(voxel_bid);
     CHECK_F32(ray_dir); CHECK_F32(voxel_bound); CHECK_I32(ray_bid); CHECK_I32(voxel_bid);
     same_device({&ray_dir, &voxel_bound, &ray_bid, &voxel_bid});
+    check_box_shapes(ray_dir, voxel_bound, ray_bid, voxel_bid, "ray_dir");
     const c10::DeviceGuard guard(ray_dir.device());
     const int64_t R = ray_dir.size(0), V = voxel_bound.size(0);
     auto st = current_stream(ray_dir);
@@ -199,6 +214,7 @@ std::vector<Tensor> forward_query(Tensor ray_dir, Tensor ray_pix, Tensor ray_bid
     TORCH_CHECK(pair_off.size(0) == R + 1, "pair_off must have R+1 entries");
     TORCH_CHECK(pix.dim() == 2 && pix.size(0) == R && pix.size(1) == 2 && bid.dim() == 1 && bid.size(0) == R,
                 "ray_pix / ray_bid must be [R,2] / [R]");
+    TORCH_CHECK(pair_ray.dim() == 1 && pair_off.dim() == 1, "pair_ray / pair_off must be 1-d");
     TORCH_CHECK(pair_vox.dim() == 1 && pair_vox.size(0) == P && pair_t.dim() == 2 && pair_t.size(0) == P &&
                     pair_t.size(1) == 2, "pair_vox / pair_t must be [P] / [P,2]");
     LidfDecoder dp = decoder_of(prob_w, 1, 0.0, use_sigmoid);

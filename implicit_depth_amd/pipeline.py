@@ -107,6 +107,9 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
     success False = one of the reference's early exits (no occupied voxel / no miss ray / no
     intersecting pair); data_dict then holds what was computed up to that point."""
     opt = opt or LidfOptions()
+    Q._refuse_autograd("pipeline.lidf_forward", "query.lidf_query_train (stage-1 training step)",
+                       (("full_rgb_feat", full_rgb_feat),),
+                       (("pnet_model", pnet_model), ("prob_dec", prob_dec), ("offset_dec", offset_dec)))
     _mark(marks, "start")
     dd = prepare_data(batch, opt, pred_mask)
     get_valid_points(dd, opt, valid_idx)
@@ -168,6 +171,9 @@ def refine_forward(dd, pnet_model_refine, offset_dec_refine, opt=None, precision
     """RefineNet.forward for evaluation (models/pipeline.py:1032-1041) on lidf_forward's data_dict:
     opt.refine_forward_times x get_pred_refine; adds pred_pos_refine and pred_depth_refine."""
     opt = opt or LidfOptions()
+    Q._refuse_autograd("pipeline.refine_forward", "the modules on their own (the fused stage-2 call has "
+                       "no backward)", (("pred_pos", dd.get("pred_pos")),),
+                       (("pnet_model_refine", pnet_model_refine), ("offset_dec_refine", offset_dec_refine)))
     bs, h, w = dd["bs"], dd["h"], dd["w"]
     occ_rev = dd["revidx"].to(torch.int32).contiguous()
     sel = None

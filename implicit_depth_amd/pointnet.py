@@ -45,27 +45,21 @@ def pointnet_struct(mod, keep):
 
 
 def packed_pointnet(mod, s, dev):
-    """The module's weight streams packed once per parameter version (lidf_pointnet_pack_f32),
-    cached per module (_lib.PACK_CACHE) and rebuilt when a parameter is modified in place or replaced; sets
-    s.packed and returns the blob (keep it alive for the call)."""
-    params = list(mod.parameters())
-    key = (str(dev), tuple((p.data_ptr(), p._version) for p in params))
-    cache = _lib.PACK_CACHE.get(mod)
-    if cache is None or cache[0] != key:
-        L = _lib.lib()
-        nb = L.lidf_pointnet_pack_bytes()
-        blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    """The module's weight streams, kept per module (_lib.PACK_CACHE) and re-validated on the device
+    by every call (lidf_pointnet_pack_guarded_f32: fingerprint of the parameter buffers, pack
+    kernels only when it changed — see query._packed_weights); sets s.packed and returns the blob
+    (keep it alive for the call)."""
+    L = _lib.lib()
+    e = _lib.packed_entry(_lib.PACK_CACHE, mod, (str(dev),), L.lidf_pointnet_pack_bytes(), dev)
+    frozen = mod in _lib.FROZEN
+    if not (frozen and e.frozen_ready):
         s.packed = None
         with torch.cuda.device(dev):
-            _lib.check(L.lidf_pointnet_pack_f32(C.byref(s), _lib.ptr(blob), nb, _lib.current_stream(dev)))
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-        cache = (key, blob, ev)
-        _lib.PACK_CACHE[mod] = cache
-    else:
-        torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
-    s.packed = cache[1].data_ptr()
-    return cache[1]
+            _lib.check(L.lidf_pointnet_pack_guarded_f32(C.byref(s), _lib.ptr(e.blob), e.blob.numel(),
+                                                        _lib.ptr(e.guard), _lib.current_stream(dev)))
+        e.frozen_ready = frozen
+    s.packed = e.blob.data_ptr()
+    return e.blob
 
 
 def check_pointnet(mod):

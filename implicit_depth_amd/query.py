@@ -44,6 +44,22 @@ def _f32(t, name):
     return t
 
 
+def _refuse_autograd(fn, alt, tensors, modules):
+    """The inference entry points detach everything they touch. Called with autograd recording and an
+    input or parameter that requires grad, they would hand back outputs the loss cannot reach — and
+    training would silently stall. Refuse loudly instead."""
+    if not torch.is_grad_enabled():
+        return
+    hot = [n for n, t in tensors if t is not None and t.requires_grad]
+    hot += ["%s.%s" % (mn, pn) for mn, m in modules if m is not None
+            for pn, p in m.named_parameters() if p.requires_grad]
+    if hot:
+        raise RuntimeError(
+            "%s is the inference path (outputs are detached) but autograd is recording and %s "
+            "require%s grad: wrap the call in torch.no_grad() for evaluation, or use %s for training"
+            % (fn, ", ".join(hot[:3]) + (" ..." if len(hot) > 3 else ""), "s" if len(hot) == 1 else "", alt))
+
+
 def ray_dirs(fx, fy, cx, cy, h, w):
     """Unit ray direction of every pixel: [bs, h*w, 3] (models/pipeline.py:215-220)."""
     intr = torch.stack((fx.float(), fy.float(), cx.float(), cy.float()), 1).contiguous()
@@ -237,28 +253,24 @@ PRECISIONS = {"f32": 0, "f16x3": 1}
 
 
 def _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, dp, do, dev):
-    """Packed weight streams of the fused query (lidf_query_pack_f32), cached per prob_dec (_lib.PACK_CACHE) and
-    rebuilt when any parameter of either decoder was modified (torch's in-place version counter)
-    or replaced (data pointer) — so an eval loop packs once per checkpoint and a training loop once
-    per optimizer step, not once per frame."""
-    params = [p for m in (prob_dec, offset_dec) for p in m.parameters()]
-    key = (id(offset_dec), multires, multires_views, precision, str(dev),
-           tuple((p.data_ptr(), p._version) for p in params))
-    cache = _lib.PACK_CACHE.get(prob_dec)
-    if cache is not None and cache[0] == key:
-        torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
-        return cache[1]
+    """Packed weight streams of the fused query, kept per prob_dec (_lib.PACK_CACHE) and re-validated
+    on the device by every call (lidf_query_pack_guarded_f32): a fingerprint of the raw parameter
+    buffers of both decoders is compared with the one the streams were built from and the pack
+    kernels run only when it differs. The host never decides from torch's version counters — those
+    miss `p.data.mul_()` / `p.data.copy_()` (EMA, clipping, old-style optimizers). No host sync.
+    _lib.freeze_packed(prob_dec) skips the check (pack once, trust until invalidate_packed)."""
     L = _lib.lib()
-    nb = L.lidf_query_pack_bytes()
-    blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    key = (multires, multires_views, precision, str(dev))   # both decoders are covered by the fingerprint
+    e = _lib.packed_entry(_lib.PACK_CACHE, prob_dec, key, L.lidf_query_pack_bytes(), dev)
+    frozen = prob_dec in _lib.FROZEN
+    if frozen and e.frozen_ready:
+        return e.blob
     with torch.cuda.device(dev):
-        _lib.check(L.lidf_query_pack_f32(C.byref(dp), C.byref(do), multires, multires_views,
-                                         PRECISIONS[precision], _lib.ptr(blob), nb,
-                                         _lib.current_stream(dev)))
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-    _lib.PACK_CACHE[prob_dec] = (key, blob, ev)
-    return blob
+        _lib.check(L.lidf_query_pack_guarded_f32(
+            C.byref(dp), C.byref(do), multires, multires_views, PRECISIONS[precision], _lib.ptr(e.blob),
+            e.blob.numel(), _lib.ptr(e.guard), _lib.current_stream(dev)))
+    e.frozen_ready = frozen
+    return e.blob
 
 
 def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
@@ -277,6 +289,9 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     Returns a dict with the reference's data_dict keys (models/pipeline.py:460-466):
     pred_offset [P,1], pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
     max_pair_id [R] i64, pred_pos [R,3]; `depth` [B,h,w] is updated in place if given."""
+    _refuse_autograd("lidf_query", "lidf_query_train",
+                     (("feat_grid", feat_grid), ("vox_feat", vox_feat)),
+                     (("prob_dec", prob_dec), ("offset_dec", offset_dec)))
     # the reference's index tensors (miss_bid, miss_flat_img_id, miss_img_ind) are int64
     ray_pix, ray_bid, ray_flat = (_as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid"),
                                   _as_i32(ray_flat, "ray_flat"))
@@ -413,6 +428,10 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     inp_zero_mask = 1 - valid_mask at the rays' pixels.
     Returns pred_pos_refine [R,3] and the last iteration's end_voxel_id [R] i32."""
     from .pointnet import check_pointnet, pointnet_struct
+    _refuse_autograd("lidf_refine", "the modules on their own (PointNet2Stage, IEF and get_embedder are "
+                     "differentiable; the fused stage-2 call has no backward)",
+                     (("pred_pos", pred_pos), ("feat_grid", feat_grid), ("valid_inp", valid_inp),
+                      ("rayfeat", rayfeat)), (("pnet_model", pnet_model), ("offset_dec", offset_dec)))
     ts = [ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
           voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox]
     names = ["ray_dir", "ray_pix", "ray_bid", "ray_flat", "pred_pos", "max_pair_id", "pair_vox",
@@ -460,23 +479,18 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     keep.append(packed_pointnet(pnet_model, pn, dev))   # weight streams packed once per version
     do = _decoder_struct(offset_dec, keep)
     packed = None
-    if precision == "f32":   # the IEF's weight streams, packed once per parameter version
-        params = list(offset_dec.parameters())
-        key = (multires, multires_views, str(dev), tuple((p.data_ptr(), p._version) for p in params))
-        cache = _lib.PACK_CACHE_REFINE.get(offset_dec)
-        if cache is None or cache[0] != key:
-            nb = L.lidf_refine_pack_bytes(multires, multires_views)
-            blob = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    if precision == "f32":   # the IEF's weight streams: kept per module, re-validated on the device
+        key = (multires, multires_views, str(dev))
+        e = _lib.packed_entry(_lib.PACK_CACHE_REFINE, offset_dec, key,
+                              L.lidf_refine_pack_bytes(multires, multires_views), dev)
+        frozen = offset_dec in _lib.FROZEN
+        if not (frozen and e.frozen_ready):
             with torch.cuda.device(dev):
-                _lib.check(L.lidf_refine_pack_f32(C.byref(do), multires, multires_views, _lib.ptr(blob), nb,
-                                                  _lib.current_stream(dev)))
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-            cache = (key, blob, ev)
-            _lib.PACK_CACHE_REFINE[offset_dec] = cache
-        else:
-            torch.cuda.current_stream(dev).wait_event(cache[2])   # packed on another stream, perhaps
-        packed = cache[1]
+                _lib.check(L.lidf_refine_pack_guarded_f32(
+                    C.byref(do), multires, multires_views, _lib.ptr(e.blob), e.blob.numel(),
+                    _lib.ptr(e.guard), _lib.current_stream(dev)))
+            e.frozen_ready = frozen
+        packed = e.blob
     cur = pred_pos.contiguous()
     end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
     if pnet_select is not None:

@@ -157,6 +157,21 @@ int lidf_query_pack_f32(const LidfDecoder* prob, const LidfDecoder* off, int mul
                         int multires_views, int precision, void* packed, size_t packed_bytes,
                         lidf_stream_t stream);
 
+/* Guarded packing — the safe default for callers that keep `packed` across calls. nn.Parameter storage
+ * can be rewritten without any host-visible trace (`p.data.mul_()` does not bump torch's version
+ * counter; SURVEY §8b "Ownership": no cache keyed on a pointer without a content check), so the check
+ * is made on the device: one launch forms a 64-bit fingerprint of every parameter buffer (plus the
+ * scalar fields of the structs), the last block compares it with the fingerprint `packed` was built
+ * from, and the pack kernels that follow on the stream return at once when nothing changed. No host
+ * synchronisation, a few microseconds per call. `guard`: lidf_pack_guard_bytes() bytes of device
+ * memory, zero-filled ONCE when `packed` is allocated and then owned by these calls (one guard per
+ * packed blob; calls that share a guard must be ordered on the device).
+ * Same for lidf_pointnet_pack_guarded_f32 / lidf_refine_pack_guarded_f32 below.                   */
+size_t lidf_pack_guard_bytes(void);
+int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDecoder* off, int multires,
+                                int multires_views, int precision, void* packed, size_t packed_bytes,
+                                void* guard, lidf_stream_t stream);
+
 /* grid_floats = batch*32*height*width makes room for the optional 4x4 box-sum image that turns the
  * ROIAlign of unclamped boxes into 4 gathers per channel; 0 = minimal workspace (general path). */
 size_t lidf_query_workspace_bytes(int64_t n_rays, int64_t n_vox, int64_t grid_floats);
@@ -317,6 +332,8 @@ typedef struct LidfPointNet {
 size_t lidf_pointnet_pack_bytes(void);
 int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
                            lidf_stream_t stream);
+int lidf_pointnet_pack_guarded_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
+                                   void* guard, lidf_stream_t stream);
 size_t lidf_pointnet_workspace_bytes(int64_t n_pts, int64_t n_vox);
 int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_pts,
                       int64_t n_vox, float* out, void* workspace, size_t workspace_bytes,
@@ -370,6 +387,8 @@ size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vo
 size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views);
 int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int32_t multires_views,
                          void* packed, size_t packed_bytes, lidf_stream_t stream);
+int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multires, int32_t multires_views,
+                                 void* packed, size_t packed_bytes, void* guard, lidf_stream_t stream);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
 
 /* ---- Eval depth metrics ----------------------------------------------------------------------

@@ -4,7 +4,7 @@
   configs[1]  240x320x64, one frame: tests/test_edge_gpu.py::test_full_size_properties
   configs[2]  the per-GPU shard of the 32-frame batch over 8 GPUs: 4 frames x 240x320x64
   configs[3]  stage 1 + stage 2 at 240x320x64: test_config3_refine_full_size below
-  configs[4]  256 candidates/ray (one frame of the shard)
+  configs[4]  256 candidates/ray: one frame, and the per-GPU shard of the 32-frame batch (4 frames)
 At the full sizes the oracle cannot run the whole frame in seconds, so the checks are
 size-independent properties (softmax sums to 1 per ray, the arg-max is a maximal logit of its own
 ray, select and depth are pure gathers) plus >= 96 random WHOLE rays per frame against the oracle.
@@ -14,12 +14,12 @@ import functools
 import pytest
 import torch
 
-from util import TOL, oracle_query, orc, run_query, to_dev
+from util import TOL, make_module, make_pointnet, oracle_query, orc, run_query, to_dev
 
 pytestmark = pytest.mark.gpu
 
 
-@functools.lru_cache(maxsize=2)
+@functools.lru_cache(maxsize=1)
 def _scene(B, h, w, N, seed, ragged=False):
     return orc.synthetic_scene(B, h, w, N, seed=seed, ragged=ragged)
 
@@ -126,3 +126,72 @@ def test_full_size_ragged(cuda, precision):
         assert (got[k][pidx.to(cuda)].cpu() - ref[k]).abs().max().item() <= TOL, k
     assert (got["pred_pos"][rows.to(cuda)].cpu() - ref["pred_pos"]).abs().max().item() <= TOL
     assert (sm[pidx.to(cuda)].cpu() - ref["pred_prob_end_softmax"]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_config4_shard_4_frames_256_candidates(cuda, precision):
+    """configs[4] at its per-GPU shape: 32 frames over 8 GPUs = 4 frames of 240x320 with 256
+    candidates per ray (P = 78,643,200 points per GPU)."""
+    scene = _scene(4, 240, 320, 256, 1239)
+    got = run_query(scene, cuda, precision=precision)
+    check_full_size(scene, got, cuda, rays_per_frame=32)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_config3_refine_full_size(cuda, precision):
+    """configs[3] at its stated shape: dense stage 1 (240x320 rays x 64 candidates, V = 729) with the
+    per-ray feature rows kept, then 2 x get_pred_refine (RefineNet.forward, models/pipeline.py:
+    922-1041) with 10,000 valid points: PointNet2Stage over 86,800 points, IEF D = 334 on every ray.
+    Stage 1 is checked by check_full_size; each refine iteration is compared over the WHOLE frame with
+    orc.refine_step fed the state the HIP path was fed (end voxel ids exact, positions <= 1e-4),
+    and the chained 2-iteration call must reproduce the two single iterations bit for bit."""
+    from implicit_depth_amd.query import lidf_query, lidf_refine
+    from implicit_depth_amd.synthetic import init_decoder_params
+    scene = _scene(1, 240, 320, 64, 1237)
+    B, h, w, V, R = scene["B"], scene["h"], scene["w"], scene["V"], scene["R"]
+    assert (B, h, w, V, scene["N"]) == (1, 240, 320, 729, 64)
+    s = to_dev(scene, cuda)
+    prob = make_module("IMNET", scene["prob_p"], scene["D"], cuda)
+    off = make_module("IEF", scene["off_p"], scene["D"], cuda)
+    depth = torch.zeros((B, h, w), device=cuda)
+    with torch.no_grad():
+        s1 = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                        s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
+                        ray_flat=s["ray_flat"], depth=depth, want_rayfeat=True, precision=precision)
+    s1["depth"] = depth
+    check_full_size(scene, s1, cuda)
+    # stage-2 inputs as bench.py's refine_setup draws them (valid_sample_num = 10,000)
+    g = torch.Generator().manual_seed(4321)
+    vb = torch.cat((scene["vox_center"] - 0.125, scene["vox_center"] + 0.125), 1)
+    vbid = torch.zeros(V, dtype=torch.int32)
+    rgb = torch.randn(B, 3, h, w, generator=g)
+    valid_inp = torch.randn(10000, 6, generator=g) * 0.2
+    valid_vox = torch.randint(0, V, (10000,), generator=g).int()
+    pnet_p = orc.init_pointnet(5, 1.5)
+    offr_p = init_decoder_params("IEF", 334, 9, 5.0)
+    pnet, offr = make_pointnet(pnet_p, cuda), make_module("IEF", offr_p, 334, cuda)
+    # the per-ray ROI rows: the HIP rows against the restatement first, then shared by both sides
+    boxes = orc.roi_boxes(scene["ray_pix"].long(), scene["ray_bid"].long(), h, w, 8)
+    ray_rgb = orc.roi_align_fast(scene["feat_grid"], boxes).reshape(R, -1)
+    assert (s1["rayfeat"][:, :128].cpu() - ray_rgb).abs().max().item() <= 2e-5
+    mid = s1["max_pair_id"].cpu()
+
+    def hip(pos, times):
+        with torch.no_grad():
+            return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], pos,
+                               s1["max_pair_id"], s["pair_vox"], vb.to(cuda), vbid.to(cuda), rgb.to(cuda),
+                               s["feat_grid"], valid_inp.to(cuda), valid_vox.to(cuda), pnet, offr,
+                               forward_times=times, rayfeat=s1["rayfeat"], precision=precision)
+    cur = s1["pred_pos"]
+    for it in range(2):
+        got, gev = hip(cur, 1)
+        ref, ev, _ = orc.refine_step(cur.cpu(), scene["ray_dir"], scene["ray_pix"], scene["ray_bid"],
+                                     scene["ray_flat"], mid, scene["pair_vox"], vb, vbid, rgb,
+                                     scene["feat_grid"], valid_inp, valid_vox, pnet_p, offr_p,
+                                     ray_rgb=ray_rgb)
+        assert (gev.cpu().long() == ev).all(), it                           # end voxel ids: exact
+        assert (got.cpu() - ref).abs().max().item() <= TOL, it
+        assert (got - cur).abs().max().item() > 1e-3                        # the iteration moved the points
+        cur = got
+    both, bev = hip(s1["pred_pos"], 2)
+    assert torch.equal(both, cur) and torch.equal(bev, gev)

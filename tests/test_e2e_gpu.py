@@ -103,6 +103,9 @@ def test_early_exits(cuda):
     # no occupied voxel: every point outside the grid
     far = dict(b)
     far["xyz_corrupt"] = b["xyz_corrupt"] + 50.0
+    with pytest.raises(RuntimeError, match="inference path"):   # autograd recording: refused loudly
+        pl.lidf_forward(far, feat.to(cuda), pnet, prob, off)
+    torch.set_grad_enabled(False)
     ok, dd = pl.lidf_forward(far, feat.to(cuda), pnet, prob, off)
     assert not ok and dd["voxel_bound"].shape[0] == 0
     # no miss ray: mask_type 'pred' with an empty predicted mask
@@ -121,4 +124,5 @@ def test_early_exits(cuda):
     pm = torch.zeros(1, 24, 32, device=cuda)
     pm[0, 12, 16] = 1
     ok, dd = pl.lidf_forward(lone, feat.to(cuda), pnet, prob, off, opt, pred_mask=pm)
+    torch.set_grad_enabled(True)
     assert not ok and dd["voxel_bound"].shape[0] == 1 and dd["pair_ray"].shape[0] == 0

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
         assert n in _lib.SIGNATURES, "ctypes signature missing for " + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert L.lidf_version() == 4
+    assert L.lidf_version() == 5
     assert b"workspace" in L.lidf_strerror(-3)
     assert L.lidf_query_workspace_bytes(76800, 729, 0) > 76800 * 512 * 4
     assert (L.lidf_query_workspace_bytes(76800, 729, 32 * 240 * 320)
@@ -68,10 +68,10 @@ def test_torch_extension_shim_loads():
     """The pybind11 shim over the C ABI is built in-tree and imports without a GPU."""
     from implicit_depth_amd import torch_ext
     m = torch_ext.ext()
-    assert m.abi_version() == 4
+    assert m.abi_version() == 5
     for fn in ("ray_aabb", "pcl_aabb", "compute_ray_aabb", "forward_decoders", "forward_query"):
         assert callable(getattr(m, fn))
-    with pytest.raises(RuntimeError):     # CHECK_INPUT of the reference bindings: CUDA tensors only
+    with pytest.raises(RuntimeError, match="CUDA"):   # CHECK_INPUT of the reference bindings: CUDA tensors only
         m.pcl_aabb(torch.zeros(1, 3), torch.zeros(1, 6), torch.zeros(1, dtype=torch.int32),
                    torch.zeros(1, dtype=torch.int32))
 
@@ -110,6 +110,33 @@ def test_cpu_tensors_are_refused():
     with pytest.raises(RuntimeError):
         pcl_aabb.forward(torch.zeros(4, 3), torch.zeros(2, 6), torch.zeros(4, dtype=torch.int32),
                          torch.zeros(2, dtype=torch.int32))
+
+
+def test_inference_entry_points_refuse_autograd():
+    """lidf_query / lidf_refine / the pipeline functions detach their outputs: with autograd recording
+    and anything that requires grad they raise instead of silently returning graph-less tensors
+    (the check precedes every device check, so it runs without a GPU)."""
+    from implicit_depth_amd import IEF, IMNet, PointNet2Stage, pipeline as pl
+    from implicit_depth_amd.query import lidf_query, lidf_refine
+    prob, off = IMNet(385, 1), IEF(torch.device("cpu"), 385, 1, n_iter=2)
+    z = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="inference path.*prob_dec.linear_1.weight.*lidf_query_train"):
+        lidf_query(z, z, z, z, z, z, z, z, z, prob, off)
+    for m in (prob, off):
+        m.requires_grad_(False)
+    fg = torch.zeros(1, 32, 4, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="feat_grid requires grad"):
+        lidf_query(z, z, z, z, z, z, z, fg, z, prob, off)
+    zi = torch.zeros(1, dtype=torch.int32)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="CUDA"):   # past the check: the usual refusal
+        lidf_query(torch.zeros(1, 3), zi, zi, zi, zi, zi, z, fg, z, prob, off)
+    offr, pn = IEF(torch.device("cpu"), 334, 1, n_iter=2), PointNet2Stage(6, 128, 32)
+    with pytest.raises(RuntimeError, match="inference path.*pnet_model"):
+        lidf_refine(z, z, z, z, z, z, z, z, z, z, z, z, z, pn, offr)
+    with pytest.raises(RuntimeError, match="inference path"):
+        pl.lidf_forward({}, z, pn, IMNet(385, 1), off)
+    with pytest.raises(RuntimeError, match="inference path"):
+        pl.refine_forward({}, pn, offr)
 
 
 def test_shard_frames():
@@ -186,6 +213,10 @@ def test_c_abi_argument_errors_without_gpu():
     d = _lib.LidfDecoder()                                           # all-NULL weights
     assert L.lidf_query_pack_f32(C.byref(d), C.byref(d), 8, 4, 0, None, 0, None) == BAD
     assert L.lidf_pointnet_pack_f32(None, None, 0, None) == BAD
+    assert L.lidf_pack_guard_bytes() >= 32
+    assert L.lidf_query_pack_guarded_f32(None, None, 8, 4, 0, None, 0, None, None) == BAD
+    assert L.lidf_pointnet_pack_guarded_f32(None, None, 0, None, None) == BAD
+    assert L.lidf_refine_pack_guarded_f32(None, 8, 4, None, 0, None, None) == BAD
     q = _lib.LidfQueryArgs()
     q.n_rays = -1
     assert L.lidf_query_f32(C.byref(q), None) == BAD

@@ -118,9 +118,20 @@ def test_autograd_path_matches_hip(cuda):
         assert (fn(pts.detach()) - e.detach()).abs().max().item() <= 1e-6
 
 
+def _guard_state(entry):
+    """(hash, dirty, valid) of a PackedEntry's device guard (struct LidfPackGuardState)."""
+    import struct
+    raw = bytes(entry.guard.cpu().numpy().tobytes())
+    h, acc, ticket, dirty, valid = struct.unpack_from("<QQIii", raw)
+    assert acc == 0 and ticket == 0          # re-armed by the block that finished last
+    return h, dirty, valid
+
+
 def test_packed_weights_follow_parameter_updates(cuda):
-    """The query caches its packed weight streams per parameter version: an in-place update, a
-    load_state_dict and a replaced .data must all be picked up by the next call."""
+    """The query keeps its packed weight streams per module and re-validates them on the device
+    (fingerprint of the raw parameter buffers): an in-place update, a load_state_dict, a replaced
+    .data AND writes through `p.data` — which torch's version counter does not see —
+    must all be picked up by the next call; an unchanged module must not be re-packed."""
     scene = orc.synthetic_scene(1, 8, 12, 4, seed=91)
     import copy
     from implicit_depth_amd import _lib
@@ -134,25 +145,71 @@ def test_packed_weights_follow_parameter_updates(cuda):
         with torch.no_grad():
             return lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                               s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+
+    def ref_off(pp, po):
+        return oracle_query(dict(scene, prob_p=pp, off_p=po))
     a = run()
-    cache0 = _lib.PACK_CACHE[prob][1]
+    entry = _lib.PACK_CACHE[prob]
+    h0, dirty, valid = _guard_state(entry)
+    assert dirty == 1 and valid == 1                          # first call packed
     b = run()
-    assert _lib.PACK_CACHE[prob][1] is cache0                 # reused
-    twin = copy.deepcopy(prob)     # the cache (device blob + event) lives beside the module, not on it
+    assert _lib.PACK_CACHE[prob] is entry and _guard_state(entry) == (h0, 0, 1)   # reused, not re-packed
+    twin = copy.deepcopy(prob)     # the cache (device blobs) lives beside the module, not on it
     assert twin not in _lib.PACK_CACHE and "_lidf_pack_cache" not in twin.__dict__
     assert (a["pred_offset"] == b["pred_offset"]).all()
+    pp = {k: v.clone() for k, v in scene["prob_p"].items()}
+    po = {k: v.clone() for k, v in scene["off_p"].items()}
     with torch.no_grad():
         off.linear_2.weight.mul_(1.25)                                     # in-place (optimizer step)
+    po["linear_2.weight"] *= 1.25
     c = run()
-    p2 = {k: v.clone() for k, v in scene["off_p"].items()}
-    p2["linear_2.weight"] = p2["linear_2.weight"] * 1.25
-    ref = oracle_query(dict(scene, off_p=p2))
-    assert (c["pred_offset"].cpu() - ref["pred_offset"]).abs().max().item() <= TOL
+    assert _guard_state(entry)[1] == 1
+    assert (c["pred_offset"].cpu() - ref_off(pp, po)["pred_offset"]).abs().max().item() <= TOL
     assert (c["pred_offset"] - a["pred_offset"]).abs().max().item() > 1e-4
-    prob.load_state_dict({k: v * 0.5 for k, v in scene["prob_p"].items()})  # copy_ in place
+    # writes through .data: p._version does not move (the hazard of a version-keyed cache)
+    v0 = off.linear_1.weight._version
+    off.linear_1.weight.data.mul_(0.8)
+    off.offset_enc.bias.data.add_(0.03)
+    prob.linear_3.bias.data.copy_(torch.full_like(prob.linear_3.bias, 0.02))
+    assert off.linear_1.weight._version == v0
+    po["linear_1.weight"] *= 0.8
+    po["offset_enc.bias"] += 0.03
+    pp["linear_3.bias"] = torch.full_like(pp["linear_3.bias"], 0.02)
     d = run()
-    ref = oracle_query(dict(scene, off_p=p2, prob_p={k: v * 0.5 for k, v in scene["prob_p"].items()}))
-    assert (d["pred_prob_end"].cpu() - ref["pred_prob_end"]).abs().max().item() <= TOL
-    prob.linear_1.weight.data = prob.linear_1.weight.data * 2.0             # replaced storage
+    assert _guard_state(entry)[1] == 1
+    r = ref_off(pp, po)
+    assert (d["pred_offset"].cpu() - r["pred_offset"]).abs().max().item() <= TOL
+    assert (d["pred_prob_end"].cpu() - r["pred_prob_end"]).abs().max().item() <= TOL
+    assert (d["pred_offset"] - c["pred_offset"]).abs().max().item() > 1e-4
+    prob.load_state_dict({k: v * 0.5 for k, v in pp.items()})              # copy_ in place
+    pp = {k: v * 0.5 for k, v in pp.items()}
     e = run()
-    assert (e["pred_prob_end"] - d["pred_prob_end"]).abs().max().item() > 1e-5
+    assert (e["pred_prob_end"].cpu() - ref_off(pp, po)["pred_prob_end"]).abs().max().item() <= TOL
+    prob.linear_1.weight.data = prob.linear_1.weight.data * 2.0             # replaced storage
+    f = run()
+    assert (f["pred_prob_end"] - e["pred_prob_end"]).abs().max().item() > 1e-5
+    # the IEF's constant initial offset is part of the streams' key (it is baked into the voxel rows)
+    off.__dict__["_init_offset_f"] = 0.004
+    g = run()
+    assert _guard_state(entry)[1] == 1 and (g["pred_offset"] - f["pred_offset"]).abs().max().item() > 1e-6
+    off.__dict__["_init_offset_f"] = 0.001
+    # another offset decoder with the same prob_dec: the fingerprint covers both modules
+    off2 = make_module("IEF", {k: v * 1.1 for k, v in scene["off_p"].items()}, D, cuda)
+    off_keep, off = off, off2
+    h = run()
+    assert _guard_state(entry)[1] == 1
+    off = off_keep
+    i = run()
+    assert torch.equal(i["pred_offset"], run()["pred_offset"]) and (h["pred_offset"] - i["pred_offset"]).abs().max() > 1e-5
+    # frozen: packed once more, then trusted — no fingerprint launch, updates are NOT seen until
+    # invalidate_packed (the documented contract of the opt-out)
+    _lib.freeze_packed(prob)
+    j = run()
+    hj = _guard_state(_lib.PACK_CACHE[prob])[0]
+    off.linear_2.bias.data.add_(0.5)
+    k = run()
+    assert torch.equal(j["pred_offset"], k["pred_offset"]) and _guard_state(_lib.PACK_CACHE[prob])[0] == hj
+    _lib.invalidate_packed(prob)
+    assert prob not in _lib.PACK_CACHE and prob not in _lib.FROZEN
+    m = run()
+    assert (m["pred_offset"] - k["pred_offset"]).abs().max().item() > 1e-4

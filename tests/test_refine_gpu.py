@@ -164,8 +164,9 @@ def test_refine_synthetic_vs_oracle(cuda, precision):
 
 
 def test_refine_packed_weights_follow_parameter_updates(cuda):
-    """lidf_refine keeps the IEF's packed weight streams per parameter version
-    (lidf_refine_pack_f32): a second call reuses them, an in-place update is picked up."""
+    """lidf_refine keeps the IEF's and the PointNet's packed weight streams per module and
+    re-validates them on the device (lidf_refine_pack_guarded_f32 / lidf_pointnet_pack_guarded_f32):
+    a second call reuses them, in-place updates and writes through `.data` are picked up."""
     from implicit_depth_amd import _lib
     from implicit_depth_amd.query import lidf_query, lidf_refine
     scene = orc.synthetic_scene(1, 12, 16, 6, seed=23, ragged=True)
@@ -186,26 +187,46 @@ def test_refine_packed_weights_follow_parameter_updates(cuda):
     pnet, offr = make_pointnet(pnet_p, cuda), make_module("IEF", offr_p, 334, cuda)
 
     def run(mod):
-        with torch.no_grad():
+        with torch.no_grad():   # `pnet` is looked up at call time (the test swaps it below)
             return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], s1["pred_pos"],
                                s1["max_pair_id"], s["pair_vox"], vb.to(cuda), vbid.to(cuda), rgb.to(cuda),
                                s["feat_grid"], valid_inp.to(cuda), valid_vox.to(cuda), pnet, mod)[0]
+    from test_parity_gpu import _guard_state
     a = run(offr)
-    blob = _lib.PACK_CACHE_REFINE[offr][1]
+    entry, pentry = _lib.PACK_CACHE_REFINE[offr], _lib.PACK_CACHE[pnet]
+    assert _guard_state(entry)[1:] == (1, 1) and _guard_state(pentry)[2] == 1
     b = run(offr)
-    assert _lib.PACK_CACHE_REFINE[offr][1] is blob and torch.equal(a, b)
+    assert _lib.PACK_CACHE_REFINE[offr] is entry and torch.equal(a, b)
+    assert _guard_state(entry)[1] == 0 and _guard_state(pentry)[1] == 0     # nothing re-packed
     with torch.no_grad():
         offr.linear_1.weight.mul_(1.5)          # in place, as an optimizer step
-        offr.linear_3.bias.add_(0.05)
+    offr.linear_3.bias.data.add_(0.05)          # through .data: no version bump
+    pnet.point_lin3.weight.data.mul_(0.9)
+    pnet.vox_lin1.bias.data.copy_(pnet.vox_lin1.bias.data + 0.01)
     c = run(offr)
+    assert _guard_state(entry)[1] == 1 and _guard_state(pentry)[1] == 1
     p2 = {k: v.clone() for k, v in offr_p.items()}
     p2["linear_1.weight"] = p2["linear_1.weight"] * 1.5
     p2["linear_3.bias"] = p2["linear_3.bias"] + 0.05
-    d = run(make_module("IEF", p2, 334, cuda))   # a fresh module with the updated parameters
+    pn2 = {k: v.clone() for k, v in pnet_p.items()}
+    pn2["point_lin3.weight"] = pn2["point_lin3.weight"] * 0.9
+    pn2["vox_lin1.bias"] = pn2["vox_lin1.bias"] + 0.01
+    pnet_old, pnet = pnet, make_pointnet(pn2, cuda)
+    d = run(make_module("IEF", p2, 334, cuda))   # fresh modules with the updated parameters
     assert torch.equal(c, d) and (c - a).abs().max().item() > 1e-5
     pos = s1["pred_pos"].cpu()
     for _ in range(2):
         pos, _, _ = orc.refine_step(pos, scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["ray_flat"],
                                     s1["max_pair_id"].cpu(), scene["pair_vox"], vb, vbid, rgb, scene["feat_grid"],
-                                    valid_inp, valid_vox, pnet_p, p2)
+                                    valid_inp, valid_vox, pn2, p2)
     assert (c.cpu() - pos).abs().max().item() <= TOL
+    # the stand-alone PointNet2Stage.forward goes through the same guarded cache
+    x, idx = valid_inp.to(cuda), valid_vox.to(cuda)
+    with torch.no_grad():
+        f0 = pnet_old(x, idx, n_vox=scene["V"])
+        pnet_old.point_lin1.weight.data.mul_(1.2)
+        f1 = pnet_old(x, idx, n_vox=scene["V"])
+    pn3 = {k: v.clone() for k, v in pn2.items()}
+    pn3["point_lin1.weight"] = pn3["point_lin1.weight"] * 1.2
+    ref = orc.pointnet2stage(pn3, valid_inp, valid_vox.long(), scene["V"])
+    assert (f1.cpu() - ref).abs().max().item() <= 2e-5 and (f1 - f0).abs().max().item() > 1e-5
