@@ -457,6 +457,18 @@ def e2e(args):
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
 
 
+def config_name(args, refine):
+    """Which BASELINE.json configuration the per-GPU workload is (named in config.workload)."""
+    if refine:
+        return "configs[3]"
+    if args.pairs != "dense":
+        return "configs[1]"     # replaced by the 'secondary' wording below
+    shape = (args.frames, args.samples)
+    return {(1, 64): "configs[1]", (4, 64): "configs[2] per-GPU shard (32 frames over 8 GPUs)",
+            (4, 256): "configs[4] per-GPU shard (32 frames x 256 candidates over 8 GPUs)",
+            (1, 256): "configs[4], one frame of the shard"}.get(shape, "secondary shape")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,6 +486,17 @@ def main():
                     help="candidate list of the query workload: dense = N per ray (the headline shape); "
                          "ragged = U{0..N} per ray; n1 = one per ray; scene = the pairs "
                          "compute_ray_aabb finds on a geometry-derived frame (0..8 per ray)")
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[k] at its per-GPU shape: 1 = one 240x320 frame x 64 "
+                         "candidates (the headline, default); 2 = the per-GPU shard of the 32-frame batch "
+                         "over 8 GPUs (4 frames x 64); 3 = stage 1 + 2 x get_pred_refine; 4 = the dense "
+                         "resample stress shard (4 frames x 256 candidates). Sets --frames/--samples/"
+                         "--workload; weak scaling: every rank runs this shard")
+    ap.add_argument("--shard", default="frames", choices=["frames", "rays"],
+                    help="multi-GPU partition: frames = every rank owns whole frames (weak scaling, the "
+                         "default and what configs[2]/[4] describe); rays = ONE frame, image rows split "
+                         "over the ranks (strong scaling, SURVEY 8e for fewer frames than GPUs), depth rows "
+                         "all-gathered")
     ap.add_argument("--workload", default="query",
                     choices=["query", "query+refine", "decoders", "embed", "train", "train-query", "e2e"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
@@ -481,6 +504,21 @@ def main():
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
                          "stand-alone positional encoding (the one HBM-bound kernel of the path)")
     args = ap.parse_args()
+    if args.config is not None:
+        preset = {1: (1, 64, "query"), 2: (4, 64, "query"), 3: (1, 64, "query+refine"), 4: (4, 256, "query")}
+        args.frames, args.samples, args.workload = preset[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called as `python bench.py --gpus N`: become the launcher the driver would have used (one
+        # process per GPU, RCCL rendezvous on the loopback address)
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     claim_stdout()
     if args.workload in ("decoders", "embed", "train", "train-query"):
         return secondary(args)
@@ -490,9 +528,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
-                         "--gpus %d ..." % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even N=1 goes through RCCL
@@ -503,14 +540,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from implicit_depth_amd import IEF, IMNet
-    from implicit_depth_amd.dist import all_gather_depth
+    from implicit_depth_amd.dist import all_gather_depth, all_gather_depth_rows
     from implicit_depth_amd.query import lidf_query
     from implicit_depth_amd.synthetic import synthetic_scene
 
     h, w, N, B = 240, 320, args.samples, args.frames
     if args.pairs == "n1":
         N = 1
-    scene = synthetic_scene(B, h, w, N, seed=1235 + rank, ragged=args.pairs == "ragged")
+    by_rays = args.shard == "rays"
+    if by_rays and (B != 1 or args.pairs == "scene" or args.workload != "query"):
+        raise SystemExit("--shard rays splits the rows of ONE frame of the query workload")
+    scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.pairs == "ragged")
+    rows = (0, h)
+    if by_rays:   # image rows [lo, hi) of the one frame; maps, voxel features and weights replicated
+        from implicit_depth_amd.dist import shard_rays, slice_rays
+        rows = shard_rays(h, world, rank)
+        scene = slice_rays(scene, rows[0] * w, rows[1] * w)
     s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
     if args.pairs == "scene":
         # rays, voxels and pairs as the candidate generator produces them on real geometry
@@ -538,7 +583,7 @@ def main():
     off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
     off.load_state_dict(scene["off_p"])
     depth = torch.zeros((B, h, w), device=dev)
-    gathered = torch.empty((world * B, h, w), device=dev) if use_dist else None
+    gathered = torch.empty((world * B, h, w), device=dev) if use_dist and not by_rays else None
     refine = None
     if args.workload == "query+refine":
         refine = refine_setup(scene, s, dev, args.precision)
@@ -558,7 +603,9 @@ def main():
                 depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
                     out["pred_pos_refine"][:, 2]
         state["ws"] = out["workspace"]
-        if use_dist:
+        if use_dist and by_rays:
+            state["full"] = all_gather_depth_rows(depth[0, rows[0]:rows[1]], h)
+        elif use_dist:
             all_gather_depth(depth, gathered)
         return out
 
@@ -580,17 +627,32 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_ms, ranks_seen, points_all = [elapsed / args.steps * 1e3], 1, scene["P"]
     if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.empty((world,), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, t)               # every rank's own clock
+        rank_ms = [round(float(v) / args.steps * 1e3, 4) for v in every.tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones((1,), device=dev, dtype=torch.int64)
+        dist.all_reduce(one)                                # ranks that actually joined the RCCL group
+        ranks_seen = int(one.item())
+        pts = torch.tensor([scene["P"]], device=dev, dtype=torch.int64)
+        dist.all_reduce(pts)                                # points of the whole job (shards may differ)
+        points_all = int(pts.item())
 
     kern_ms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
     gather_ok = None
     if use_dist:   # the collective's result: every rank's slot holds that rank's depth maps
         import torch.distributed as dist
-        mine = bool((gathered[rank * B:(rank + 1) * B] == depth).all()) and bool(torch.isfinite(gathered).all())
+        if by_rays:
+            full = state["full"]
+            mine = bool((full[rows[0]:rows[1]] == depth[0, rows[0]:rows[1]]).all()) and \
+                bool(torch.isfinite(full).all()) and tuple(full.shape) == (h, w)
+        else:
+            mine = bool((gathered[rank * B:(rank + 1) * B] == depth).all()) and bool(torch.isfinite(gathered).all())
         t = torch.tensor([1 if mine else 0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gather_ok = bool(t.item())
@@ -628,7 +690,7 @@ def main():
                  "max_abs_diff_vs_f32": {k: float((hip_h[k] - hip_f32[k]).abs().max())
                                          for k in ("pred_offset", "pred_prob_end", "pair_pred_pos")}}
     if rank == 0:
-        value = world * P * args.steps / elapsed / 1e6
+        value = points_all * args.steps / elapsed / 1e6
         h16 = args.precision == "f16x3"
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
@@ -643,17 +705,18 @@ def main():
             "metric": "Mpoints/sec implicit-MLP query, 240x320x%d samples; depth L1 vs ref" % N,
             "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if by_rays else "weak", "vs_baseline": None,
             "dtype": DTYPE_F16X3 if h16 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %d x 240x320 frame(s) per GPU, %d candidates/ray, LIDF "
                                    "stage-1 fused query (ROI + PE + prob_dec IMNet + offset_dec IEF n_iter=2 "
                                    "+ per-ray softmax/argmax + depth)%s%s" %
-                                   ("configs[3]" if refine is not None else "configs[1]", B, N,
+                                   (config_name(args, refine is not None), B, N,
                                     " + stage 2 (2 x get_pred_refine: PointNet2Stage over 10,000 valid + "
                                     "76,800 predicted points, IEF D=334)" if refine is not None else "",
                                     "; RCCL all-gather of depth maps" if use_dist else ""),
                        "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
-                       "parallelism": "frames sharded over %d GPU(s)" % world},
+                       "parallelism": ("image rows of one frame sharded over %d GPU(s), depth rows all-gathered"
+                                       if by_rays else "frames sharded over %d GPU(s)") % world},
             # frac = MFMA FLOP the kernel ISSUES (counted from its instruction stream, >99 % useful
             # MACs) / its HIP-event time / dense peak: a hardware utilisation. The reference
             # formulation needs 2.4x more FLOP per point (no layer-1 factorisation, no IEF hoist):
@@ -677,8 +740,12 @@ def main():
                     "note": "whole step; the path is MFMA-bound (>= 3,000 FLOP per HBM byte)"},
         }
         if gather_ok is not None:
-            line["collective"] = {"op": "all_gather_into_tensor (RCCL) of [%d,%d,%d] f32 depth maps per rank" % (B, h, w),
-                                  "inside_timed_region": True, "gathered_equals_local": gather_ok}
+            line["collective"] = {"op": ("all_gather_into_tensor (RCCL) of the depth rows of one [%d,%d] map" % (h, w)
+                                         if by_rays else
+                                         "all_gather_into_tensor (RCCL) of [%d,%d,%d] f32 depth maps per rank" % (B, h, w)),
+                                  "inside_timed_region": True, "gathered_equals_local": gather_ok,
+                                  "ranks_seen": ranks_seen, "ms_per_step_by_rank": rank_ms,
+                                  "points_all_ranks": points_all}
         if split is not None:
             line["split_f16"] = split
         if not dense:

@@ -49,3 +49,54 @@ def all_gather_depth_ragged(local_depth, n_frames, group=None):
     full = all_gather_depth(pad, group=group)
     parts = [full[r * bmax: r * bmax + (sizes[r][1] - sizes[r][0])] for r in range(world)]
     return torch.cat(parts, 0)
+
+
+def shard_rays(height, world_size, rank):
+    """Row range [lo, hi) of ONE image owned by `rank` when there are fewer frames than ranks
+    ("for B < 8 shard rows of rays of one image instead"): whole image rows, contiguous
+    and balanced like shard_frames, so a rank's rays are pixels [lo*w, hi*w) — a contiguous slice of
+    the all-pixel ray list (and of its ray-major candidate list). The feature map, the voxel features
+    and the weights are replicated (9.8 MB + 0.4 MB + 1.1 MB)."""
+    return shard_frames(height, world_size, rank)
+
+
+def slice_rays(rays, lo, hi):
+    """The rays [lo, hi) of a ray-major query input set with their candidate list re-based: `rays` is
+    a dict with ray_dir / ray_pix / ray_bid / ray_flat [R,...] and the CSR pairs pair_off [R+1],
+    pair_ray / pair_vox [P], pair_t [P,2] (host or device tensors; plumbing only: views and two
+    subtractions). pair_ray of the slice counts from 0, as lidf_query expects."""
+    off = rays["pair_off"]
+    p0, p1 = int(off[lo]), int(off[hi])
+    out = dict(rays)
+    for k in ("ray_dir", "ray_pix", "ray_bid", "ray_flat"):
+        if rays.get(k) is not None:
+            out[k] = rays[k][lo:hi].contiguous()
+    out["pair_off"] = (off[lo:hi + 1] - off[lo]).contiguous()
+    out["pair_ray"] = (rays["pair_ray"][p0:p1] - lo).contiguous()
+    out["pair_vox"] = rays["pair_vox"][p0:p1].contiguous()
+    out["pair_t"] = rays["pair_t"][p0:p1].contiguous()
+    out["R"], out["P"] = hi - lo, p1 - p0
+    return out
+
+
+def all_gather_depth_rows(local_rows, height, group=None):
+    """All-gather of the row shards of one depth map: rank r holds rows shard_rays(height, world, r)
+    of a [height, w] map ([rows_r, w] f32); returns the whole [height, w] map on every rank. Shards
+    differ by at most one row, so every rank pads to the largest shard and one
+    all_gather_into_tensor moves the map (307 KB at 240x320: latency-bound on xGMI)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    spans = [shard_rays(height, world, r) for r in range(world)]
+    rmax = max(hi - lo for lo, hi in spans)
+    lo, hi = spans[rank]
+    if tuple(local_rows.shape[:1]) != (hi - lo,):
+        raise ValueError("rank %d owns rows [%d,%d) but holds %d" % (rank, lo, hi, local_rows.shape[0]))
+    w = local_rows.shape[1]
+    pad = torch.zeros((rmax, w), dtype=local_rows.dtype, device=local_rows.device)
+    pad[: hi - lo] = local_rows
+    full = torch.empty((world * rmax, w), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    if all(b - a == rmax for a, b in spans):
+        return full
+    return torch.cat([full[r * rmax: r * rmax + (spans[r][1] - spans[r][0])] for r in range(world)], 0)

@@ -180,7 +180,9 @@ def compute_ray_aabb(ray_dir, voxel_bound, ray_bid, voxel_bid, voxel_coord=None,
     voxel_coord [V,3] (occ_vox_global_coord), grid_dims (rx,ry,rz) and batch — all three as
     get_occ_vox_bound returns them — select the regular-grid walk (lidf_ray_aabb_grid_*): a ray
     visits only the cells whose per-axis intervals meet instead of every voxel; the result is
-    bit-identical."""
+    bit-identical. The walk assumes what get_occ_vox_bound produces: every (frame, cell) at most once
+    and the list sorted by (frame, x, y, z) — with duplicated or unsorted voxels leave voxel_coord
+    out (the voxel-by-voxel kernels make no such assumption)."""
     _lib.require_cuda(ray_dir, voxel_bound, ray_bid, voxel_bid,
                       names=["ray_dir", "voxel_bound", "ray_bid", "voxel_bid"])
     _f32(ray_dir, "ray_dir"), _f32(voxel_bound, "voxel_bound")

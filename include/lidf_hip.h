@@ -262,7 +262,11 @@ int lidf_ray_aabb_fill_f32(const float* ray_dir, const float* voxel_bound,
  * per-axis bound tables; `count` / `fill` are the two passes of the compact form above. Hits,
  * t_enter and t_leave are bit-identical to lidf_ray_aabb_count/fill_f32 (the same products of the
  * voxels' own bounds, compared in the same order); within a ray the pairs ascend in (x,y,z) cell
- * order = ascending voxel index for a list sorted like torch.unique sorts it.                 */
+ * order = ascending voxel index for a list sorted like torch.unique sorts it.
+ * PRECONDITIONS (not checked; lidf_voxelize_f32 / get_occ_vox_bound guarantee them): (frame, cell)
+ * is unique over the voxel list — the cell table keeps ONE voxel per cell, a duplicate would be
+ * dropped silently — and the list is sorted by (frame, x, y, z), otherwise pair_vox does not ascend
+ * within a ray. For an arbitrary voxel list use lidf_ray_aabb_count/fill_f32.                     */
 size_t lidf_ray_aabb_grid_workspace_bytes(int32_t batch, int32_t rx, int32_t ry, int32_t rz);
 int lidf_ray_aabb_grid_build_f32(const float* voxel_bound, const int32_t* voxel_bid,
                                  const int32_t* voxel_coord, int64_t n_vox, int32_t batch,

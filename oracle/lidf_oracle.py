@@ -636,20 +636,28 @@ def synthetic_scene(*args, **kw):
     return _impl(*args, **kw)
 
 
+def resize_nearest_index(src, dst):
+    """Source index of every destination index under cv2.resize(..., interpolation=INTER_NEAREST),
+    restated from OpenCV's resizeNN: min(floor(dst index * (1 / (dst/src))), src - 1), factor in
+    double. cv2 is not installed here and its source is not in the reference tree: parity with cv2
+    itself is UNPINNED (tests/golden/make_golden.py's cv2 stub is this function)."""
+    import math
+    inv = 1.0 / (dst / src)
+    return [min(int(math.floor(i * inv)), src - 1) for i in range(dst)]
+
+
 def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
     """Eval statistics of LIDF.compute_loss, bs == 1 branch (models/pipeline.py:577-627).
-    cv2 is not installed here, so cv2.resize(img, (256, 144), interpolation=INTER_NEAREST) is
-    restated from OpenCV's resizeNN: source index = min(floor(dst index * (1 / (dst/src))), src-1),
-    factor in double — parity with cv2 itself is unpinned. The statistics follow the reference's
-    torch f32 expressions literally (safe_log10 is the natural log there, :611)."""
-    import math
+    cv2.resize(img, (256, 144), interpolation=INTER_NEAREST) is resize_nearest_index above (unpinned
+    against cv2); the statistics follow the reference's torch f32 expressions literally (safe_log10
+    is the natural log there, :611) and are pinned by tests/golden/g8_metrics.npz — the reference's
+    own compute_loss run on a one-frame batch."""
     pred = torch.as_tensor(pred_depth, dtype=torch.float32)
     gt = torch.as_tensor(gt_depth, dtype=torch.float32).clone()
     h, w = gt.shape
     dh, dw = (h, w) if out_size is None else out_size
-    ify, ifx = 1.0 / (dh / h), 1.0 / (dw / w)
-    sy = torch.tensor([min(int(math.floor(y * ify)), h - 1) for y in range(dh)])
-    sx = torch.tensor([min(int(math.floor(x * ifx)), w - 1) for x in range(dw)])
+    sy = torch.tensor(resize_nearest_index(h, dh))
+    sx = torch.tensor(resize_nearest_index(w, dw))
     gt = gt[sy][:, sx]
     pred = pred[sy][:, sx]
     gt[torch.isnan(gt)] = 0

@@ -15,6 +15,10 @@ Python modules are imported and executed, and only their inputs/outputs are stor
                                                                        (models/pipeline.py:203-269)
   g7_refine_select.npz  the same two refine iterations with refine.use_all_pix = False
                                                                        (models/pipeline.py:987-996)
+  g8_metrics.npz    the nine evaluation statistics of LIDF.compute_loss's bs == 1 branch (a1 .. sq_rel)
+                    from the reference's own LIDF.forward(batch, 'test', 0) on a one-frame batch with
+                    NaN / inf ground-truth pixels (cv2.resize stubbed: nearest-neighbour restatement)
+                                                                       (models/pipeline.py:577-618)
   g4_refine.npz     RefineNet.get_pred_refine x 2 on the same batch (stage 2), incl. the refine
                     PointNet2Stage outputs                     (models/pipeline.py:922-1041, pointnet.py)
 
@@ -91,7 +95,15 @@ def install_stubs():
             return torch.from_numpy(orc.pcl_aabb(pos.numpy(), voxel_bound.numpy(), pcl_bid.numpy(),
                                                  voxel_bid.numpy()))
 
-    _stub("cv2")
+    def cv2_resize(img, dsize, interpolation=None):
+        # cv2.resize(img, (W, H), interpolation=cv2.INTER_NEAREST) — cv2 is not installed: the
+        # oracle's restatement of OpenCV's nearest-neighbour index rule (UNPINNED against cv2)
+        assert interpolation == "nearest"
+        sy = orc.resize_nearest_index(img.shape[0], dsize[1])
+        sx = orc.resize_nearest_index(img.shape[1], dsize[0])
+        return np.ascontiguousarray(img[sy][:, sx])
+
+    _stub("cv2", resize=cv2_resize, INTER_NEAREST="nearest")
     tv = _stub("torchvision")
     tv.ops = _stub("torchvision.ops", roi_align=roi_align)
     tv.transforms = _stub("torchvision.transforms")
@@ -297,6 +309,61 @@ def g3_pipeline():
     np.savez_compressed(os.path.join(HERE, "g7_refine_select.npz"), **g7)
 
 
+def g8_metrics():
+    """The reference's LIDF.forward(batch, 'test', 0) on ONE frame (bs == 1 selects the resized
+    ClearGrasp statistics, models/pipeline.py:577-618): the depth maps that enter the statistics and
+    the nine numbers compute_loss returns. Ground truth carries a NaN and an inf inside the hole."""
+    install_stubs()
+    import models.pipeline as pl
+    from opt import Params
+    cfg = os.path.join(REF, "experiments", "implicit_depth")
+    opt = Params(os.path.join(cfg, "default_config.yaml"))
+    opt.update(os.path.join(cfg, "test_lidf.yaml"))
+    opt.grid.valid_sample_num = -1
+    torch.manual_seed(4321)
+    dev = torch.device("cpu")
+    lidf = pl.LIDF(opt, dev).eval()
+    D = lidf.prob_dec.inp_dim
+    lidf.prob_dec.load_state_dict(closed_form_params("IMNET", D, seed=81))
+    lidf.offset_dec.load_state_dict(closed_form_params("IEF", D, seed=82))
+    B, h, w = 1, 45, 60
+    fx, fy = torch.tensor([54.0], dtype=torch.float64), torch.tensor([54.0], dtype=torch.float64)
+    cx, cy = torch.tensor([29.5], dtype=torch.float64), torch.tensor([22.0], dtype=torch.float64)
+    d, _ = orc.ray_dirs(fx.float(), fy.float(), cx.float(), cy.float(), h, w)
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    depth = (0.8 + 0.004 * xs + 0.006 * ys).unsqueeze(0)
+    xyz = (d / d[..., 2:3] * depth.unsqueeze(-1)).permute(0, 3, 1, 2).contiguous()
+    hole = torch.zeros(B, 1, h, w)
+    hole[0, :, 10:34, 14:47] = 1
+    hole[0, :, 2:6, 50:58] = 1
+    xyz_gt = xyz.clone()
+    xyz_gt[0, 2, 12, 20] = float("nan")      # non-finite ground truth counts as 0 (pipeline.py:582-583)
+    xyz_gt[0, 2, 30, 40] = float("inf")
+    xyz_gt[0, 2, 3, 52] = 0.0                # and a true zero
+    batch = {
+        "rgb": closed_form((B, 3, h, w), 0.3819660113, 0.2, 1.5),
+        "xyz": xyz_gt, "xyz_corrupt": xyz * (1 - hole), "depth_corrupt": depth.unsqueeze(1) * (1 - hole),
+        "corrupt_mask": hole.clone(), "valid_mask": 1 - hole,
+        "fx": fx, "fy": fy, "cx": cx, "cy": cy, "item_path": ["a"],
+    }
+    with torch.no_grad():
+        ok, dd, loss = lidf(batch, "test", 0)
+    assert ok
+    pred_xyz = dd["xyz_corrupt_flat"].clone()
+    pred_xyz[dd["miss_bid"], dd["miss_flat_img_id"]] = dd["pred_pos"]
+    out = {
+        "pred_depth": pred_xyz.reshape(B, h, w, 3)[0, :, :, 2].numpy(),
+        "gt_depth": dd["xyz_flat"].reshape(B, h, w, 3)[0, :, :, 2].numpy(),
+        "seg_mask": dd["corrupt_mask"][0].numpy().astype(np.uint8),
+        "out_size": np.array([144, 256]),
+    }
+    for k in ("a1", "a2", "a3", "rmse", "rmse_log", "log10", "abs_rel", "mae", "sq_rel"):
+        out[k] = np.float32(loss[k].item())
+    print("g8:", {k: float(out[k]) for k in ("a1", "a2", "a3", "rmse", "mae")},
+          "rays", dd["total_miss_sample_num"])
+    np.savez_compressed(os.path.join(HERE, "g8_metrics.npz"), **out)
+
+
 def g6_miss_ray():
     """LIDF.get_miss_ray of the reference on float masks with holes, an empty image and odd values
     (models/pipeline.py:203-269, eval flavour)."""
@@ -356,11 +423,15 @@ if __name__ == "__main__":
     if "--only-g6" in sys.argv:
         g6_miss_ray()
         sys.exit(0)
+    if "--only-g8" in sys.argv:
+        g8_metrics()
+        sys.exit(0)
     g1_embed()
     g2_decoders()
     g5_decoder_grads()
     g3_pipeline()
     g6_miss_ray()
+    g8_metrics()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -18,7 +18,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from implicit_depth_amd.dist import all_gather_depth, all_gather_depth_ragged, shard_frames
+    from implicit_depth_amd.dist import (all_gather_depth, all_gather_depth_ragged, all_gather_depth_rows,
+                                         shard_frames, shard_rays, slice_rays)
     from util import orc, run_query
 
     # equal shards
@@ -38,6 +39,15 @@ def main():
     got = run_query(scene, dev)
     full = all_gather_depth(got["depth"])
     assert (full[rank] == got["depth"][0]).all() and torch.isfinite(full).all()
+    # ONE frame, image rows sharded over the ranks (fewer frames than GPUs): every rank
+    # queries its rows of the same ragged scene; the gathered rows equal the unsharded query's map
+    h, w = 13, 16
+    whole = orc.synthetic_scene(1, h, w, 8, seed=77, ragged=True)
+    lo, hi = shard_rays(h, world, rank)
+    part = run_query(dict(slice_rays(whole, lo * w, hi * w), B=1, h=h, w=w), dev)
+    rows = all_gather_depth_rows(part["depth"][0, lo:hi], h)
+    ref = run_query(whole, dev)
+    assert rows.shape == (h, w) and torch.equal(rows, ref["depth"][0])
     dist.barrier()
     if rank == 0:
         print("RCCL_WORKER_OK world=%d" % world, flush=True)

@@ -182,6 +182,61 @@ def _gloo_worker(rank, world, port, n_frames, q):
         dist.destroy_process_group()
 
 
+def _gloo_rows_worker(rank, world, port, h, q):
+    """Row shards of ONE depth map (dist.shard_rays / slice_rays / all_gather_depth_rows): every rank
+    cuts its rays out of the same ragged scene, 'queries' them (depth = a function of the ray's own
+    candidates, standing in for lidf_query) and the gathered map must equal the unsharded one."""
+    import torch.distributed as dist
+    from implicit_depth_amd.dist import all_gather_depth_rows, shard_rays, slice_rays
+    from implicit_depth_amd.synthetic import synthetic_scene
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        w = 12
+        scene = synthetic_scene(1, h, w, 5, seed=11, ragged=True)      # identical on every rank
+
+        def fake_query(s):   # per ray: sum of t_leave over its own candidates + its flat pixel index
+            d = torch.zeros(s["R"]).index_add_(0, s["pair_ray"].long(), s["pair_t"][:, 1])
+            return d + s["ray_flat"].float()
+        lo, hi = shard_rays(h, world, rank)
+        mine = slice_rays(scene, lo * w, hi * w)
+        ok = int(mine["pair_off"][-1]) == mine["P"] and (mine["pair_ray"] >= 0).all() and \
+            (mine["pair_ray"] < mine["R"]).all()
+        full = all_gather_depth_rows(fake_query(mine).reshape(hi - lo, w), h)
+        ok = ok and full.shape == (h, w) and torch.equal(full, fake_query(scene).reshape(h, w))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h", [8, 9])
+def test_ray_row_shards_gloo_world2(h):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_rows_worker, args=(r, 2, port, h, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_slice_rays_covers_the_list():
+    from implicit_depth_amd.dist import shard_rays, slice_rays
+    from implicit_depth_amd.synthetic import synthetic_scene
+    scene = synthetic_scene(1, 10, 7, 6, seed=3, ragged=True)
+    for world in (1, 3, 8):
+        parts = [slice_rays(scene, *[v * 7 for v in shard_rays(10, world, r)]) for r in range(world)]
+        assert sum(p["P"] for p in parts) == scene["P"] and sum(p["R"] for p in parts) == scene["R"]
+        assert torch.equal(torch.cat([p["pair_vox"] for p in parts]), scene["pair_vox"])
+        base = 0
+        for p in parts:
+            assert torch.equal(p["pair_ray"] + base, scene["pair_ray"][int(scene["pair_off"][base]):
+                                                                      int(scene["pair_off"][base + p["R"]])])
+            base += p["R"]
+
+
 @pytest.mark.parametrize("n_frames", [4, 5])
 def test_depth_all_gather_gloo_world2(n_frames):
     ctx = mp.get_context("spawn")

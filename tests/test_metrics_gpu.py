@@ -53,3 +53,15 @@ def test_metrics_argument_errors(cuda):
         depth_metrics(a, a)                                    # CPU tensors
     with pytest.raises(RuntimeError):
         depth_metrics(a.to(cuda), torch.ones(4, 5, device=cuda))
+
+
+def test_metrics_match_reference_compute_loss(cuda):
+    """lidf_depth_metrics_f32 against the reference's own compute_loss statistics
+    (tests/golden/g8_metrics.npz, models/pipeline.py:577-618)."""
+    from implicit_depth_amd.query import depth_metrics
+    from test_oracle_golden import G8_KEYS, load
+    g8 = load("g8_metrics.npz")
+    got = depth_metrics(torch.from_numpy(g8["pred_depth"]).to(cuda), torch.from_numpy(g8["gt_depth"]).to(cuda),
+                        torch.from_numpy(g8["seg_mask"]).to(cuda), tuple(int(v) for v in g8["out_size"]))
+    for k in G8_KEYS:
+        assert abs(float(got[k]) - float(g8[k])) <= 2e-6 * max(1.0, abs(float(g8[k]))), k

@@ -213,3 +213,19 @@ def test_g6_miss_ray_train_window():
     for k in ("miss_bid", "miss_flat_img_id", "miss_img_ind"):
         assert (res[k][sel].numpy() == g["t_" + k]).all(), k
     assert np.abs(res["miss_ray_dir"][sel].numpy() - g["t_miss_ray_dir"]).max() == 0.0
+
+
+G8_KEYS = ("a1", "a2", "a3", "rmse", "rmse_log", "log10", "abs_rel", "mae", "sq_rel")
+
+
+def test_g8_depth_metrics_match_reference_compute_loss():
+    """The nine evaluation statistics against the reference's own LIDF.compute_loss, bs == 1 branch
+    (models/pipeline.py:577-618), run on a one-frame batch whose ground truth holds NaN / inf / 0
+    pixels. (cv2.resize itself stays unpinned: the generator's cv2 stub is the oracle's index rule.)"""
+    g8 = load("g8_metrics.npz")
+    m = orc.depth_metrics(torch.from_numpy(g8["pred_depth"]), torch.from_numpy(g8["gt_depth"]),
+                          torch.from_numpy(g8["seg_mask"]), tuple(int(v) for v in g8["out_size"]))
+    assert 0.0 < float(g8["a1"]) < float(g8["a2"]) < float(g8["a3"]) < 1.0   # a non-trivial frame
+    assert not np.isfinite(g8["gt_depth"]).all()
+    for k in G8_KEYS:
+        assert abs(float(m[k]) - float(g8[k])) <= 1e-6 * max(1.0, abs(float(g8[k]))), k

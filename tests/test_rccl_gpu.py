@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_args, port, timeout=600):
+def _torchrun(script_args, port, timeout=600, nproc=1):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -37,3 +37,41 @@ def test_bench_distributed_path_one_rank(cuda):
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["collective"]["gathered_equals_local"] is True
     assert "RCCL" in rec["config"]["workload"]
+
+
+def test_bench_ray_row_shards_one_rank(cuda):
+    """--shard rays (one frame, image rows split over the ranks, depth rows all-gathered) through
+    RCCL with a single rank; --config 2 names the configs[2] shard."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--shard", "rays"], 29613)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert rec["scaling"] == "strong" and rec["collective"]["gathered_equals_local"] is True
+    assert rec["collective"]["ranks_seen"] == 1 and len(rec["collective"]["ms_per_step_by_rank"]) == 1
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                   "--no-cpu-baseline", "--config", "2"], 29614)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert "configs[2]" in rec["config"]["workload"] and rec["config"]["points_per_gpu"] == 4 * 240 * 320 * 64
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif("_gpus() < 2")
+def test_two_ranks_nccl(cuda):
+    """Only where two GPUs are visible (not on the 1-GPU test box): the worker with world = 2, and
+    bench.py launching itself (`python bench.py --gpus 2` without a launcher) for both partitions."""
+    r = _torchrun([os.path.join(ROOT, "tests", "rccl_worker.py")], 29615, nproc=2)
+    assert r.returncode == 0 and "RCCL_WORKER_OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in ([], ["--shard", "rays"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                            "--warmup", "1", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+        assert rec["n_gpus"] == 2 and rec["collective"]["ranks_seen"] == 2
+        assert rec["collective"]["gathered_equals_local"] is True
