@@ -94,6 +94,40 @@ class LidfRefineArgs(C.Structure):
     ]
 
 
+class LidfFrameArgs(C.Structure):
+    """struct LidfFrameArgs (include/lidf_hip.h)."""
+    _fields_ = [
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("rgb", C.c_void_p), ("xyz_corrupt", C.c_void_p), ("valid_mask", C.c_void_p),
+        ("miss_mask", C.c_void_p), ("intr", C.c_void_p), ("feat_grid", C.c_void_p),
+        ("xmin", C.c_float * 3), ("res", C.c_int32 * 3), ("part_size", C.c_float),
+        ("valid_stride", C.c_int32),
+        ("pnet", C.POINTER(LidfPointNet)), ("prob", C.POINTER(LidfDecoder)), ("off", C.POINTER(LidfDecoder)),
+        ("packed_query", C.c_void_p),
+        ("multires", C.c_int32), ("multires_views", C.c_int32), ("roi_inp_bbox", C.c_int32),
+        ("pos_rel", C.c_int32), ("offset_range0", C.c_float), ("offset_range1", C.c_float),
+        ("refine_times", C.c_int32), ("pnet_refine", C.POINTER(LidfPointNet)),
+        ("off_refine", C.POINTER(LidfDecoder)), ("packed_refine", C.c_void_p),
+        ("refine_pos_rel", C.c_int32), ("refine_pnet_pos_rel", C.c_int32),
+        ("refine_use_all_pix", C.c_int32),
+        ("refine_offset_range0", C.c_float), ("refine_offset_range1", C.c_float),
+        ("max_pairs", C.c_int64), ("lds_voxels", C.c_int32),
+        ("counts", C.c_void_p),
+        ("valid_bid", C.c_void_p), ("valid_flat", C.c_void_p), ("valid_xyz", C.c_void_p),
+        ("valid_rgb", C.c_void_p), ("occ_bid_coord", C.c_void_p), ("voxel_bound", C.c_void_p),
+        ("valid_v_pid", C.c_void_p), ("revidx", C.c_void_p), ("valid_v_rel_coord", C.c_void_p),
+        ("pnet_inp", C.c_void_p), ("occ_voxel_feat", C.c_void_p),
+        ("ray_bid", C.c_void_p), ("ray_flat", C.c_void_p), ("ray_pix", C.c_void_p),
+        ("ray_dir", C.c_void_p), ("pair_off", C.c_void_p), ("pair_ray", C.c_void_p),
+        ("pair_vox", C.c_void_p), ("pair_t", C.c_void_p),
+        ("pred_offset", C.c_void_p), ("pred_prob", C.c_void_p), ("pred_prob_softmax", C.c_void_p),
+        ("pair_pred_pos", C.c_void_p), ("max_pair_id", C.c_void_p), ("pred_pos", C.c_void_p),
+        ("rayfeat", C.c_void_p), ("pred_depth", C.c_void_p), ("pred_pos_refine", C.c_void_p),
+        ("end_voxel_id", C.c_void_p), ("pred_depth_refine", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 _P, _I64, _I, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
 
 # name -> (restype, argtypes); every symbol include/lidf_hip.h declares
@@ -145,6 +179,9 @@ SIGNATURES = {
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
     "lidf_refine_pack_bytes": (_SZ, [_I, _I]),
     "lidf_refine_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), _I, _I, _P, _SZ, _P]),
+    "lidf_frame_workspace_bytes": (_SZ, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _I64,
+                                         C.c_int32, C.c_int32]),
+    "lidf_frame_f32": (C.c_int, [C.POINTER(LidfFrameArgs), _P]),
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),

@@ -48,6 +48,41 @@ hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long lo
 hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, const float*, const float*,
                                      const float*, const float*, float*, const LidfPackGuardState*,
                                      hipStream_t);
+hipError_t lidf_launch_rayfeat_dev(const float*, float*, int, int, int, const float*, const int*,
+                                   const int*, long long, const int*, int, int, float*, int, hipStream_t);
+hipError_t lidf_launch_ray_reduce_dev(const float*, const float*, const int*, long long, long long,
+                                      const int*, const int*, const int*, const int*, long long, float*,
+                                      long long*, float*, float*, hipStream_t);
+hipError_t lidf_launch_scan_dev(const int*, long long, const int*, int*, int*, int*, hipStream_t);
+hipError_t lidf_launch_ray_aabb_compact_dev(bool, const float*, const float*, const int*, const int*,
+                                            long long, long long, const int*, const int*, int*,
+                                            const int*, int*, int*, float*, long long, hipStream_t);
+hipError_t lidf_launch_pointnet_chain_dev(int, const float*, const float*, const int*, const float*,
+                                          float*, float*, long long, int, long long, const int*,
+                                          const int*, int, hipStream_t);
+size_t lidf_pointnet_pool_scratch_bytes_dev(long long);
+hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int*, long long, const float*,
+                                       const int*, long long, const int*, const int*, const float*,
+                                       long long, int, long long, float*, int*, int*,
+                                       const unsigned char*, const int*, const int*, hipStream_t);
+hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int, int, int,
+                                       int, long long, const int*, float*, int, hipStream_t);
+hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float, long long,
+                                         const int*, float*, const int*, const int*, long long, float*,
+                                         hipStream_t);
+hipError_t lidf_launch_frame_head(const float*, const float*, const float*, const float*, const float*, int,
+                                  int, int, int, const GridSpec&, int*, int*, int*, int*, int*, float*,
+                                  float*, int*, int*, int*, int*, int*, int*, float*, float*, float*,
+                                  hipStream_t);
+size_t lidf_frame_head_blocks(long long);
+hipError_t lidf_launch_frame_points(const float*, const float*, const int*, const int*, const int*,
+                                    const GridSpec&, long long, const int*, int*, int*, float*, float*,
+                                    float*, hipStream_t);
+hipError_t lidf_launch_frame_pairs(int*, int*, long long, long long, hipStream_t);
+hipError_t lidf_launch_vox_cells_bid(const int*, const int*, long long, const GridSpec&, int*, float*, int*,
+                                     hipStream_t);
+hipError_t lidf_launch_frame_select(const float*, const int*, const int*, long long, long long, const int*,
+                                    unsigned char*, hipStream_t);
 hipError_t lidf_launch_fingerprint(const float* const*, const long long*, int, unsigned long long,
                                    LidfPackGuardState*, hipStream_t);
 size_t lidf_pointnet_chain_stream_bytes(void);
@@ -92,12 +127,6 @@ hipError_t lidf_launch_seg_sum_rows(const float*, const int*, long long, int, fl
 hipError_t lidf_launch_embed_backward(const float*, const float*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
                                      int, float*, hipStream_t);
-struct GridSpec {
-    float xmin[3];
-    float crop;
-    int r[3];
-    int B;
-};
 hipError_t lidf_launch_vox_mark(const float*, const int*, long long, const GridSpec&, int*, int*,
                                 int*, hipStream_t);
 hipError_t lidf_launch_vox_cells(const int*, const int*, long long, const GridSpec&, int*, float*,
@@ -496,9 +525,13 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
                               (hipStream_t)stream);
 }
 
+// dims (optional): device int32 {R, P, V} — the sync-free frame path. n_rays / n_pairs / n_vox of `q`
+// are then the capacities the launches (and the workspace) are sized for, and every kernel reads its
+// count on the device.
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
-                      lidf_stream_t stream) {
+                      lidf_stream_t stream, const int* dims = nullptr) {
     if (!q) return LIDF_ERR_BAD_ARG;
+    if (dims && (q->precision != LIDF_PRECISION_F32 || !q->packed)) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
     // 32-bit lane offsets in the kernels: 12 R bytes of ray directions must fit
@@ -553,10 +586,10 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
 
         // 2. per-ray features [ROI 2x2 of the feature map | embed(dir)]
-        CHECK_HIP(lidf_launch_rayfeat(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
-                                      q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
-                                      q->ray_bid, R, q->roi_inp_bbox / 2, Lv, rayfeat, 128 + Ed,
-                                      st));
+        CHECK_HIP(lidf_launch_rayfeat_dev(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
+                                          q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
+                                          q->ray_bid, R, dims, q->roi_inp_bbox / 2, Lv, rayfeat,
+                                          128 + Ed, st));
         // 3. layer-1 partial products: per voxel  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c),
         //    per ray  raypart[r] = W1[:, rgb|dir] rayfeat[r]
         {
@@ -564,6 +597,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             av.stream = stream_vox; av.aux = aux_pts;
             av.nets = 2; av.l1_quads = lv.l1_quads; av.net_quads = lv.net_quads;
             av.n = V; av.X = q->vox_feat; av.ldx = 128;
+            av.n_dev = dims ? dims + 2 : nullptr;
             av.D = mv.D; av.KQ1 = mv.KQ1; av.has_bias = 1;
             av.out_base = voxpart;
             const long long ntv = (V + 127) / 128;
@@ -571,6 +605,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.stream = stream_ray; a.aux = aux_pts;
             a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
             a.n = R; a.X = rayfeat; a.ldx = 128 + Ed;
+            a.n_dev = dims;
             a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0;
             a.out_base = raypart;
             long long nt = (R + 127) / 128;
@@ -592,6 +627,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.stream = stream_pts; a.aux = aux_pts;
             a.nets = 2; a.l1_quads = lf.l1_quads; a.net_quads = lf.net_quads;
             a.n = P;
+            a.n_dev = dims ? dims + 1 : nullptr;
             fill_net_args(a, 0, q->prob, q->pred_prob, 0);
             fill_net_args(a, 1, q->off, q->pred_offset, 1);
             a.pair_ray = q->pair_ray; a.pair_vox = q->pair_vox; a.pair_t = q->pair_t;
@@ -618,10 +654,10 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
     }
     // 5. per-ray softmax / argmax / select / depth
     if (q->pred_prob_softmax || q->max_pair_id || q->pred_pos || q->depth) {
-        CHECK_HIP(lidf_launch_ray_reduce(q->pred_prob, q->pair_pred_pos, q->pair_off, R, P,
-                                         q->ray_bid, q->ray_flat,
-                                         (long long)q->height * q->width, q->pred_prob_softmax,
-                                         (long long*)q->max_pair_id, q->pred_pos, q->depth, st));
+        CHECK_HIP(lidf_launch_ray_reduce_dev(q->pred_prob, q->pair_pred_pos, q->pair_off, R, P, dims,
+                                             dims ? dims + 1 : nullptr, q->ray_bid, q->ray_flat,
+                                             (long long)q->height * q->width, q->pred_prob_softmax,
+                                             (long long*)q->max_pair_id, q->pred_pos, q->depth, st));
     }
     return LIDF_OK;
 }
@@ -886,7 +922,8 @@ static size_t lin_stream_bytes(int k, int nt) {
 static int run_linear(const LinSpec& L, const float* X, long long ldx, long long n,
                       const float* addrows, const int* addidx, int relu, float* out,
                       long long ld_out, float* pool, const int* poolidx, float* stream_buf,
-                      int cus, hipStream_t st, bool pack_only = false, bool prepacked = false) {
+                      int cus, hipStream_t st, bool pack_only = false, bool prepacked = false,
+                      const int* n_dev = nullptr) {
     if (n <= 0 && !pack_only) return LIDF_OK;
     const int nt = L.nout / 32;
     L1Map m = rows_map(L.k, L.c0, 0, 0, L.b ? 1 : 0);
@@ -899,6 +936,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     if (pack_only) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
+    a.n_dev = n_dev;
     a.D = m.D; a.has_bias = L.b ? 1 : 0;
     a.addrows = addrows; a.addidx = addidx; a.ld_add = L.nout; a.relu = relu;
     a.out = out; a.ld_out = ld_out; a.pool = pool; a.poolidx = poolidx; a.ld_pool = L.nout;
@@ -1078,7 +1116,7 @@ static size_t refine_fact_bytes(int D);
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
-                                 int pack_mode);
+                                 int pack_mode, const int* R_dev = nullptr, const int* V_dev = nullptr);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -1171,6 +1209,253 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
     return LIDF_OK;
 }
 
+// ---- the evaluation path of a batch of frames without a host round trip (lidf_frame_f32) --------
+// PointNet2Stage with device-side counts: pointnet_impl's inference branch, every launch sized for
+// the capacities (n_cap points, V_cap voxels) and reading *n_dev / *V_dev on the device.
+struct PnetFrameWs {
+    size_t pool1, g1, gpart, pool2, part, total;
+};
+static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds) {
+    PnetFrameWs w;
+    size_t o = 0;
+    const size_t V = (size_t)(v_cap > 0 ? v_cap : 1);
+    w.pool1 = o; o += align_up(V * 64 * 4, 256);
+    w.g1 = o;    o += align_up(V * 64 * 4, 256);
+    w.gpart = o; o += align_up(V * 128 * 4, 256);
+    w.pool2 = o; o += align_up(V * 128 * 4, 256);
+    w.part = o;  o += align_up(lidf_pointnet_pool_scratch_bytes_dev(v_lds), 256);
+    w.total = o;
+    return w;
+}
+static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_cap,
+                          const int* n_dev, int64_t V_cap, int v_lds, const int* V_dev, float* out,
+                          char* ws, int cus, hipStream_t st) {
+    int rc;
+    if ((rc = check_pointnet_w(w))) return rc;
+    if (!w->packed) return LIDF_ERR_BAD_ARG;
+    const PnetFrameWs f = pnet_frame_ws(V_cap, v_lds);
+    const PnetWs pw = pnet_ws(1, 1);   // offsets of the packed streams
+    float* streams[7];
+    for (int i = 0; i < 7; ++i) streams[i] = (float*)((char*)w->packed + pw.s[i]);
+    const float* chain = (const float*)((const char*)w->packed + pw.chain);
+    float* pool1 = (float*)(ws + f.pool1);
+    float* g1 = (float*)(ws + f.g1);
+    float* gpart = (float*)(ws + f.gpart);
+    float* pool2 = (float*)(ws + f.pool2);
+    float* part = (float*)(ws + f.part);
+    CHECK_HIP(hipMemsetAsync(pool1, 0, (size_t)V_cap * 64 * 4, st));
+    CHECK_HIP(hipMemsetAsync(pool2, 0, (size_t)V_cap * 128 * 4, st));
+    CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, part, V_cap, v_lds, n_cap,
+                                             n_dev, V_dev, cus, st));
+    if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, V_cap, nullptr, nullptr, 1, g1, 64,
+                         nullptr, nullptr, streams[2], cus, st, false, true, V_dev)))
+        return rc;
+    if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, g1, 64, V_cap, nullptr, nullptr, 0, gpart,
+                         128, nullptr, nullptr, streams[3], cus, st, false, true, V_dev)))
+        return rc;
+    CHECK_HIP(lidf_launch_pointnet_chain_dev(2, chain, inp, vox, gpart, pool2, part, V_cap, v_lds, n_cap,
+                                             n_dev, V_dev, cus, st));
+    return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, pool2, 128, V_cap, nullptr, nullptr, 1, out,
+                      128, nullptr, nullptr, streams[6], cus, st, false, true, V_dev);
+}
+
+struct FrameWs {
+    size_t blk_valid, blk_miss, cell_flag, cell_rank, vox_bid, pt_key, pt_valid, pt_rank, ray_count, scan, pnet,
+        query, inp_embed, off, vox_feat_r, voxpart_r, pos_a, pos_b, pnet_abs, sel, total;
+};
+static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pairs, int v_lds,
+                        int refine_times) {
+    (void)max_pairs;
+    FrameWs f;
+    size_t o = 0;
+    const size_t N = (size_t)B * h * w, C = (size_t)B * res[0] * res[1] * res[2];
+    const size_t nb = lidf_frame_head_blocks((long long)N);
+    f.blk_valid = o; o += align_up((nb + 1) * 4, 256);
+    f.blk_miss = o;  o += align_up((nb + 1) * 4, 256);
+    f.cell_flag = o; o += align_up(C * 4, 256);
+    f.cell_rank = o; o += align_up((C + 1) * 4, 256);
+    f.vox_bid = o;   o += align_up(C * 4, 256);
+    f.pt_key = o;    o += align_up(N * 4, 256);
+    f.pt_valid = o;  o += align_up(N * 4, 256);
+    f.pt_rank = o;   o += align_up((N + 1) * 4, 256);
+    f.ray_count = o; o += align_up(N * 4, 256);
+    f.scan = o;      o += align_up(lidf_exclusive_scan_workspace_bytes((int64_t)(N > C ? N : C)), 256);
+    f.pnet = o;      o += align_up(pnet_frame_ws((int64_t)C, v_lds).total, 256);
+    f.query = o;     o += align_up(lidf_query_workspace_bytes((int64_t)N, (int64_t)C, (int64_t)B * 32 * h * w), 256);
+    const int Dmax = 256 + 2 * (3 + 6 * 16);
+    const bool rf = refine_times > 0;
+    f.inp_embed = o;  o += rf ? align_up(N * Dmax * 4, 256) : 0;
+    f.off = o;        o += rf ? align_up(N * 4, 256) : 0;
+    f.vox_feat_r = o; o += rf ? align_up(C * 128 * 4, 256) : 0;
+    f.voxpart_r = o;  o += rf ? align_up(C * LIDF_H1 * 4, 256) : 0;
+    f.pos_a = o;      o += rf ? align_up(N * 12, 256) : 0;
+    f.pos_b = o;      o += rf ? align_up(N * 12, 256) : 0;
+    f.pnet_abs = o;   o += rf ? align_up(2 * N * 24, 256) : 0;
+    f.sel = o;        o += rf ? align_up(N, 256) : 0;
+    f.total = o;
+    return f;
+}
+
+static int frame_lds_voxels(int32_t v, size_t C) {
+    int l = v > 0 ? v : 128;
+    if (l > 288) l = 288;
+    if ((size_t)l > C) l = (int)C;
+    return l < 1 ? 1 : l;
+}
+
+LIDF_API size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, const int32_t* res,
+                                           int64_t max_pairs, int32_t lds_voxels, int32_t refine_times) {
+    if (batch <= 0 || height <= 0 || width <= 0 || !res || res[0] <= 0 || res[1] <= 0 || res[2] <= 0) return 0;
+    const size_t C = (size_t)batch * res[0] * res[1] * res[2];
+    return frame_ws(batch, height, width, res, max_pairs, frame_lds_voxels(lds_voxels, C), refine_times).total;
+}
+
+LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
+    if (!a) return LIDF_ERR_BAD_ARG;
+    const int B = a->batch, h = a->height, w = a->width;
+    if (B <= 0 || h <= 0 || w <= 0 || a->valid_stride < 1 || a->max_pairs <= 0 || !(a->part_size > 0.f))
+        return LIDF_ERR_BAD_ARG;
+    if (a->res[0] <= 0 || a->res[1] <= 0 || a->res[2] <= 0 || a->refine_times < 0) return LIDF_ERR_BAD_ARG;
+    const int64_t N = (int64_t)B * h * w, C = (int64_t)B * a->res[0] * a->res[1] * a->res[2];
+    if (N > 0x15555555LL || C > 0x7fffffffLL || a->max_pairs > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (!a->rgb || !a->xyz_corrupt || !a->valid_mask || !a->intr || !a->feat_grid || !a->pnet || !a->prob ||
+        !a->off || !a->packed_query || !a->counts)
+        return LIDF_ERR_BAD_ARG;
+    if (!a->valid_bid || !a->valid_flat || !a->valid_xyz || !a->valid_rgb || !a->occ_bid_coord ||
+        !a->voxel_bound || !a->valid_v_pid || !a->revidx || !a->valid_v_rel_coord || !a->pnet_inp ||
+        !a->occ_voxel_feat || !a->ray_bid || !a->ray_flat || !a->ray_pix || !a->ray_dir || !a->pair_off ||
+        !a->pair_ray || !a->pair_vox || !a->pair_t || !a->pred_offset || !a->pred_prob ||
+        !a->pair_pred_pos || !a->max_pair_id || !a->pred_pos || !a->rayfeat || !a->pred_depth)
+        return LIDF_ERR_BAD_ARG;
+    const bool rf = a->refine_times > 0;
+    if (rf && (!a->pnet_refine || !a->off_refine || !a->packed_refine || !a->pred_pos_refine ||
+               !a->end_voxel_id || !a->pred_depth_refine))
+        return LIDF_ERR_BAD_ARG;
+    int rc, cus;
+    if ((rc = check_query_model(a->prob, a->off, a->multires, a->multires_views, LIDF_PRECISION_F32))) return rc;
+    if (rf && (rc = check_decoder(a->off_refine))) return rc;
+    if ((rc = cu_count(&cus))) return rc;
+    const int v_lds = frame_lds_voxels(a->lds_voxels, (size_t)C);
+    const FrameWs f = frame_ws(B, h, w, a->res, a->max_pairs, v_lds, a->refine_times);
+    if (!a->workspace || a->workspace_bytes < f.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    int* counts = a->counts;
+    int* cell_flag = (int*)(ws + f.cell_flag);
+    int* cell_rank = (int*)(ws + f.cell_rank);
+    int* pt_key = (int*)(ws + f.pt_key);
+    int* pt_valid = (int*)(ws + f.pt_valid);
+    int* pt_rank = (int*)(ws + f.pt_rank);
+    int* ray_count = (int*)(ws + f.ray_count);
+    int* scan = (int*)(ws + f.scan);
+    GridSpec g;
+    for (int k = 0; k < 3; ++k) { g.xmin[k] = a->xmin[k]; g.r[k] = a->res[k]; }
+    g.crop = a->part_size;
+    g.B = B;
+    const long long hw = (long long)h * w;
+
+    // 1. valid points, rays, depth map, voxel marks: three launches over the pixels
+    CHECK_HIP(hipMemsetAsync(cell_flag, 0, (size_t)C * 4, st));
+    CHECK_HIP(lidf_launch_frame_head(a->valid_mask, a->miss_mask, a->xyz_corrupt, a->rgb, a->intr, B, h, w,
+                                     a->valid_stride, g, (int*)(ws + f.blk_valid), (int*)(ws + f.blk_miss),
+                                     counts, a->valid_bid, a->valid_flat, a->valid_xyz, a->valid_rgb,
+                                     cell_flag, pt_key, pt_valid, a->ray_bid, a->ray_flat, a->ray_pix,
+                                     a->ray_dir, a->pred_depth, rf ? a->pred_depth_refine : nullptr, st));
+    // 2. occupied voxels: cell scan (V), point scan (NV), cells -> voxels, points -> PointNet rows
+    CHECK_HIP(lidf_launch_scan_dev(cell_flag, C, nullptr, cell_rank, scan, counts + LIDF_FC_VOX, st));
+    CHECK_HIP(lidf_launch_scan_dev(pt_valid, N, counts + LIDF_FC_VALID_SEL, pt_rank, scan,
+                                   counts + LIDF_FC_VALID_IN, st));
+    int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
+    CHECK_HIP(lidf_launch_vox_cells_bid(cell_flag, cell_rank, C, g, a->occ_bid_coord, a->voxel_bound, vox_bid,
+                                        st));
+    float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
+    CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
+                                       a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
+                                       pnet_abs, st));
+    // 3. ray / voxel pairs: count -> scan -> (cut at max_pairs, P) -> fill
+    CHECK_HIP(lidf_launch_ray_aabb_compact_dev(false, a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, C,
+                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, ray_count,
+                                               nullptr, nullptr, nullptr, nullptr, 0, st));
+    CHECK_HIP(lidf_launch_scan_dev(ray_count, N, counts + LIDF_FC_RAYS, a->pair_off, scan, nullptr, st));
+    CHECK_HIP(lidf_launch_frame_pairs(a->pair_off, counts, N, a->max_pairs, st));
+    CHECK_HIP(lidf_launch_ray_aabb_compact_dev(true, a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, C,
+                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, ray_count,
+                                               a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
+                                               a->max_pairs, st));
+    // 4. voxel embedding: PointNet over the in-grid valid points
+    if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
+                             counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st)))
+        return rc;
+    // 5. get_embedding + get_pred + depth
+    float* vox_center = nullptr;
+    if (a->pos_rel) return LIDF_ERR_UNSUPPORTED;   // intersect_pos_type 'rel': not on this path (shipped: 'abs')
+    {
+        LidfQueryArgs q = {};
+        q.n_rays = N; q.ray_dir = a->ray_dir; q.ray_pix = a->ray_pix; q.ray_bid = a->ray_bid;
+        q.ray_flat = a->ray_flat;
+        q.n_pairs = a->max_pairs; q.pair_off = a->pair_off; q.pair_ray = a->pair_ray;
+        q.pair_vox = a->pair_vox; q.pair_t = a->pair_t;
+        q.batch = B; q.height = h; q.width = w; q.feat_grid = a->feat_grid;
+        q.n_vox = C; q.vox_feat = a->occ_voxel_feat; q.vox_center = vox_center;
+        q.prob = a->prob; q.off = a->off;
+        q.multires = a->multires; q.multires_views = a->multires_views; q.roi_inp_bbox = a->roi_inp_bbox;
+        q.pos_rel = 0;
+        q.offset_range0 = a->offset_range0; q.offset_range1 = a->offset_range1; q.part_size = a->part_size;
+        q.pred_offset = a->pred_offset; q.pred_prob = a->pred_prob; q.pair_pred_pos = a->pair_pred_pos;
+        q.pred_prob_softmax = a->pred_prob_softmax; q.max_pair_id = a->max_pair_id; q.pred_pos = a->pred_pos;
+        q.depth = a->pred_depth;
+        q.workspace = ws + f.query;
+        q.workspace_bytes = lidf_query_workspace_bytes(N, C, (int64_t)B * 32 * h * w);
+        q.rayfeat_out = a->rayfeat;
+        q.precision = LIDF_PRECISION_F32;
+        q.packed = a->packed_query;
+        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts))) return rc;
+    }
+    if (!rf) return LIDF_OK;
+
+    // 6. stage 2: refine_times x get_pred_refine on the device-resident state
+    const int E = 3 + 6 * a->multires, Ed = 3 + 6 * a->multires_views;
+    const int D = 256 + E + Ed;
+    float* inp_embed = (float*)(ws + f.inp_embed);
+    float* offv = (float*)(ws + f.off);
+    float* vox_feat_r = (float*)(ws + f.vox_feat_r);
+    float* voxpart_r = (float*)(ws + f.voxpart_r);
+    unsigned char* sel = nullptr;
+    if (!a->refine_use_all_pix) {
+        sel = (unsigned char*)(ws + f.sel);
+        CHECK_HIP(lidf_launch_frame_select(a->valid_mask, a->ray_bid, a->ray_flat, hw, N, counts, sel, st));
+    }
+    // the stage-2 PointNet reads [valid points | predicted points]: the predicted rows are written
+    // behind the NV valid rows of the same buffer (no copy of the valid rows)
+    float* pn_inp = a->refine_pnet_pos_rel ? a->pnet_inp : pnet_abs;
+    const float* cur = a->pred_pos;
+    for (int it = 0; it < a->refine_times; ++it) {
+        float* out = it == a->refine_times - 1 ? a->pred_pos_refine
+                                               : (float*)(ws + ((it & 1) ? f.pos_b : f.pos_a));
+        CHECK_HIP(lidf_launch_refine_prep_dev(cur, (const long long*)a->max_pair_id, a->pair_vox, a->max_pairs,
+                                              a->voxel_bound, vox_bid, C, a->ray_bid, a->ray_flat, a->rgb, hw,
+                                              a->refine_pnet_pos_rel, N, pn_inp, a->revidx, a->end_voxel_id,
+                                              sel, counts, counts + LIDF_FC_VALID_IN, st));
+        CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
+                                              a->multires_views, a->multires, a->refine_pos_rel, N, counts,
+                                              inp_embed, D, st));
+        if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
+                                 v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st)))
+            return rc;
+        if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N, offv,
+                                        voxpart_r, (char*)a->packed_refine, st, 2, counts + LIDF_FC_RAYS,
+                                        counts + LIDF_FC_VOX)))
+            return rc;
+        const bool last = it == a->refine_times - 1;
+        CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, a->refine_offset_range0,
+                                                a->refine_offset_range1 - a->refine_offset_range0, N, counts,
+                                                out, a->ray_bid, a->ray_flat, hw,
+                                                last ? a->pred_depth_refine : nullptr, st));
+        cur = out;
+    }
+    return LIDF_OK;
+}
+
 // ---- occupied-voxel build ----------------------------------------------------------------------
 struct VoxWs {
     size_t cell_flag, cell_rank, pt_key, pt_valid, pt_rank, scan, total;
@@ -1250,6 +1535,7 @@ struct LinEx {
     int transposed;                            // outputs index weight columns, k indexes rows (W^T)
     const LidfDecoder* ief;                    // layer 1 of an IEF: bias += c, column k+1 = u
     const float* X; long long ldx; long long n;
+    const int* n_dev;                          // optional device-side row count (n = capacity)
     int c0, k1, c1;                            // operand columns [0,k) -> weight columns c0.., [k,k+k1) -> c1..
     int dcore;                                 // IEF: weight column of the offset encoding (default k)
     const float* addrows; const int* addidx;   // gathered 256-wide terms added before the activation
@@ -1283,6 +1569,7 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
     if (pack_mode == 1) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
+    a.n_dev = L.n_dev;
     a.D = m.D; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
     a.addrows = L.addrows; a.addidx = L.addidx; a.ld_add = L.nout;
     a.addrows2 = L.addrows2; a.addidx2 = L.addidx2; a.ld_add2 = L.nout;
@@ -1317,7 +1604,7 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
                            int64_t ldx, int64_t n, const int32_t* pair_vox, const int32_t* pair_ray,
                            const float* voxpart, const float* raypart, float* passes, float* pre,
                            float* out, char* sbuf, int cus, hipStream_t st,
-                           int mode = LIDF_MODE_TRAIN, int pack_mode = 0) {
+                           int mode = LIDF_MODE_TRAIN, int pack_mode = 0, const int* n_dev = nullptr) {
     const StreamLayout lay = lidf_make_layout(1, LIDF_MODE_ROWS, m);
     float* stream_buf = (float*)sbuf;
     float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
@@ -1327,6 +1614,7 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     PointsArgs a = {};
     a.stream = stream_buf; a.aux = aux; a.nets = 1;
     a.l1_quads = lay.l1_quads; a.net_quads = lay.net_quads; a.n = n;
+    a.n_dev = n_dev;
     fill_net_args(a, 0, dec, out, 0);
     a.X = X; a.ldx = ldx; a.D = m.D; a.KQ1 = m.KQ1; a.has_bias = m.add_bias;
     a.pair_vox = pair_vox; a.pair_ray = pair_ray; a.voxpart = voxpart; a.raypart = raypart;
@@ -1345,7 +1633,7 @@ static size_t refine_fact_bytes(int D) { return linex_stream_bytes(128) + chain_
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
-                                 int pack_mode) {
+                                 int pack_mode, const int* R_dev, const int* V_dev) {
     int rc, cus;
     if ((rc = cu_count(&cus))) return rc;
     const int ld1 = D + (off->is_ief ? 16 : 0);
@@ -1353,10 +1641,12 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
     L.w = off->w1; L.b = off->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
     L.ief = off->is_ief ? off : nullptr;   // bias += c
     L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
+    L.n_dev = V_dev;
     if ((rc = run_linex(L, (float*)scratch, cus, st, pack_mode))) return rc;
     return run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
                            nullptr, voxpart, nullptr, nullptr, nullptr, out,
-                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode);
+                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode,
+                           R_dev);
 }
 
 LIDF_API size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views) {

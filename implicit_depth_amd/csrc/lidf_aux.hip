@@ -164,7 +164,9 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
                                     const int* __restrict__ ray_pix,
                                     const int* __restrict__ ray_bid, long long R, int half,
                                     int Lv, float* __restrict__ out, int ld,
-                                    int* __restrict__ border) {
+                                    int* __restrict__ border, const int* __restrict__ R_dev) {
+    if (R_dev) R = *R_dev;   // device-side ray count (the sync-free frame path; R = launch capacity)
+    if ((long long)blockIdx.x * 64 >= R) return;
     // [64 rays][128 + Ed] (row stride TS; 155 for Lv = 4: odd, conflict-free), then the list of
     // rays that take the general path and its length
     extern __shared__ float rf_lds[];
@@ -322,10 +324,22 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
 
 // `box` (scratch, B*32*H*W floats, followed by R+1 ints for the clamped-box list) may be NULL:
 // every ray then takes the general path inside the main kernel.
+extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int B, int H, int W,
+                                              const float* ray_dir, const int* ray_pix,
+                                              const int* ray_bid, long long R, const int* R_dev,
+                                              int half, int Lv, float* out, int ld, hipStream_t st);
 extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, int H, int W,
                                           const float* ray_dir, const int* ray_pix,
                                           const int* ray_bid, long long R, int half, int Lv,
                                           float* out, int ld, hipStream_t st) {
+    return lidf_launch_rayfeat_dev(feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, nullptr, half, Lv,
+                                   out, ld, st);
+}
+// R_dev (optional): the ray count on the device, R then bounds the launch
+extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int B, int H, int W,
+                                              const float* ray_dir, const int* ray_pix,
+                                              const int* ray_bid, long long R, const int* R_dev,
+                                              int half, int Lv, float* out, int ld, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     int* border = nullptr;
     if (box && half > 0) {
@@ -345,7 +359,7 @@ extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, 
     const int ts = 128 + 3 + 6 * Lv + ((3 + 6 * Lv) & 1 ? 0 : 1);
     hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4),
                        (size_t)(64 * ts + 65) * 4, st, feat, box, B, H, W, ray_dir, ray_pix, ray_bid,
-                       R, half, Lv, out, ld, border);
+                       R, half, Lv, out, ld, border, R_dev);
     if (border)
         hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(2048), dim3(256), 0, st, feat, H, W,
                            ray_pix, ray_bid, half, border, out, ld);
@@ -419,7 +433,10 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        const int* __restrict__ ray_bid,
                                        const int* __restrict__ ray_flat, long long hw,
                                        float* __restrict__ softmax, long long* __restrict__ maxid,
-                                       float* __restrict__ pred_pos, float* __restrict__ depth) {
+                                       float* __restrict__ pred_pos, float* __restrict__ depth,
+                                       const int* __restrict__ R_dev, const int* __restrict__ P_dev) {
+    if (R_dev) R = *R_dev;   // device-side counts (the sync-free frame path)
+    if (P_dev) P = *P_dev;
     const int lane = threadIdx.x & (G - 1);
     const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
     // (a whole group shares its rays; groups beyond R idle through the shuffles with empty ranges)
@@ -532,22 +549,32 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
 }
 
 #define REDUCE_U 4
+extern "C" hipError_t lidf_launch_ray_reduce_dev(const float* prob, const float* pos, const int* off,
+                                                 long long R, long long P, const int* R_dev,
+                                                 const int* P_dev, const int* ray_bid,
+                                                 const int* ray_flat, long long hw, float* softmax,
+                                                 long long* maxid, float* pred_pos, float* depth,
+                                                 hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    const long long groups = (R + REDUCE_U - 1) / REDUCE_U;
+    // (with device-side counts the list is a geometry-derived one: a handful of pairs per ray)
+    if (P <= 8 * R || P_dev)
+        hipLaunchKernelGGL((lidf_ray_reduce_kernel<8, REDUCE_U>), dim3((unsigned)((groups + 31) / 32)),
+                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
+                           pred_pos, depth, R_dev, P_dev);
+    else
+        hipLaunchKernelGGL((lidf_ray_reduce_kernel<64, REDUCE_U>), dim3((unsigned)((groups + 3) / 4)),
+                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
+                           pred_pos, depth, R_dev, P_dev);
+    return hipGetLastError();
+}
 extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos, const int* off,
                                              long long R, long long P, const int* ray_bid,
                                              const int* ray_flat, long long hw, float* softmax,
                                              long long* maxid, float* pred_pos, float* depth,
                                              hipStream_t st) {
-    if (R <= 0) return hipSuccess;
-    const long long groups = (R + REDUCE_U - 1) / REDUCE_U;
-    if (P <= 8 * R)
-        hipLaunchKernelGGL((lidf_ray_reduce_kernel<8, REDUCE_U>), dim3((unsigned)((groups + 31) / 32)),
-                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
-                           pred_pos, depth);
-    else
-        hipLaunchKernelGGL((lidf_ray_reduce_kernel<64, REDUCE_U>), dim3((unsigned)((groups + 3) / 4)),
-                           dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
-                           pred_pos, depth);
-    return hipGetLastError();
+    return lidf_launch_ray_reduce_dev(prob, pos, off, R, P, nullptr, nullptr, ray_bid, ray_flat, hw, softmax,
+                                      maxid, pred_pos, depth, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,10 +684,15 @@ __global__ void lidf_ray_aabb_compact_kernel(const float* __restrict__ ray_dir,
                                              const int* __restrict__ pair_off,
                                              int* __restrict__ pair_ray,
                                              int* __restrict__ pair_vox,
-                                             float* __restrict__ pair_t) {
+                                             float* __restrict__ pair_t,
+                                             const int* __restrict__ R_dev,
+                                             const int* __restrict__ V_dev, long long pair_cap) {
     __shared__ float s_vb[256 * 6];
     __shared__ int s_bid[256];
+    if (R_dev) R = *R_dev;   // device-side counts (the sync-free frame path; R, V = launch capacity)
+    if (V_dev) V = *V_dev;
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((long long)blockIdx.x * blockDim.x >= R) return;   // (workgroup-uniform)
     const bool live = r < R;
     float dx = 0.f, dy = 0.f, dz = 1.f;
     int bid = -1;
@@ -684,7 +716,7 @@ __global__ void lidf_ray_aabb_compact_kernel(const float* __restrict__ ray_dir,
             if (s_bid[j] != bid) continue;
             float t0, t1;
             if (!slab_test(inv, s_vb + 6 * j, t0, t1)) continue;
-            if (FILL) {
+            if (FILL && (pair_cap <= 0 || base + n < pair_cap)) {   // (a list cut at its capacity)
                 const size_t p = (size_t)base + n;
                 pair_ray[p] = (int)r;
                 pair_vox[p] = (int)(v0 + j);
@@ -705,11 +737,33 @@ extern "C" hipError_t lidf_launch_ray_aabb_compact(bool fill, const float* ray_d
     dim3 grid((unsigned)((R + 255) / 256)), block(256);
     if (fill)
         hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<true>, grid, block, 0, st, ray_dir, vbound,
-                           ray_bid, vox_bid, R, V, count, pair_off, pair_ray, pair_vox, pair_t);
+                           ray_bid, vox_bid, R, V, count, pair_off, pair_ray, pair_vox, pair_t,
+                           (const int*)nullptr, (const int*)nullptr, 0LL);
     else
         hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<false>, grid, block, 0, st, ray_dir,
                            vbound, ray_bid, vox_bid, R, V, count, pair_off, pair_ray, pair_vox,
-                           pair_t);
+                           pair_t, (const int*)nullptr, (const int*)nullptr, 0LL);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lidf_launch_ray_aabb_compact_dev(bool fill, const float* ray_dir,
+                                                       const float* vbound, const int* ray_bid,
+                                                       const int* vox_bid, long long R_cap,
+                                                       long long V_cap, const int* R_dev,
+                                                       const int* V_dev, int* count,
+                                                       const int* pair_off, int* pair_ray,
+                                                       int* pair_vox, float* pair_t, long long pair_cap,
+                                                       hipStream_t st) {
+    if (R_cap <= 0) return hipSuccess;
+    dim3 grid((unsigned)((R_cap + 255) / 256)), block(256);
+    if (fill)
+        hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<true>, grid, block, 0, st, ray_dir, vbound,
+                           ray_bid, vox_bid, R_cap, V_cap, count, pair_off, pair_ray, pair_vox, pair_t,
+                           R_dev, V_dev, pair_cap);
+    else
+        hipLaunchKernelGGL(lidf_ray_aabb_compact_kernel<false>, grid, block, 0, st, ray_dir, vbound,
+                           ray_bid, vox_bid, R_cap, V_cap, count, pair_off, pair_ray, pair_vox, pair_t,
+                           R_dev, V_dev, 0LL);
     return hipGetLastError();
 }
 
@@ -960,27 +1014,10 @@ extern "C" hipError_t lidf_launch_pcl_aabb_last(const float* pos, const float* v
 // ------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 1024  // per block: 256 threads x 4
 
-__device__ __forceinline__ int block_scan_256(int v, int* s_tmp, int& total) {
-    // inclusive scan of one value per thread over 256 threads; returns exclusive prefix
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const int o = __shfl_up(inc, s);
-        if (lane >= s) inc += o;
-    }
-    if (lane == 63) s_tmp[wave] = inc;
-    __syncthreads();
-    int wpre = 0;
-    for (int w = 0; w < wave; ++w) wpre += s_tmp[w];
-    total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-    __syncthreads();
-    return wpre + inc - v;
-}
-
 __global__ void lidf_scan_sums_kernel(const int* __restrict__ in, long long n,
-                                      int* __restrict__ sums) {
+                                      int* __restrict__ sums, const int* __restrict__ n_dev) {
     __shared__ int s_tmp[4];
+    if (n_dev) n = *n_dev;   // device-side length: entries beyond it count as 0 (n = launch capacity)
     const long long b0 = (long long)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
     int v = 0;
     for (int k = 0; k < 4; ++k)
@@ -1005,8 +1042,10 @@ __global__ void lidf_scan_top_kernel(int* __restrict__ sums, long long nb) {
 }
 
 __global__ void lidf_scan_final_kernel(const int* __restrict__ in, long long n,
-                                       const int* __restrict__ sums, int* __restrict__ out) {
+                                       const int* __restrict__ sums, int* __restrict__ out,
+                                       const int* __restrict__ n_dev, int* __restrict__ total_out) {
     __shared__ int s_tmp[4];
+    if (n_dev) n = *n_dev;
     const long long b0 = (long long)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
     int x[4], v = 0;
     for (int k = 0; k < 4; ++k) {
@@ -1018,22 +1057,41 @@ __global__ void lidf_scan_final_kernel(const int* __restrict__ in, long long n,
     if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
     for (int k = 0; k < 4; ++k) {
         run += x[k];
-        if (b0 + k < n) out[b0 + k + 1] = run;
+        if (b0 + k < n) {
+            out[b0 + k + 1] = run;
+            if (total_out && b0 + k == n - 1) *total_out = run;   // the grand total, where the caller wants it
+        }
     }
+    if (total_out && n <= 0 && blockIdx.x == 0 && threadIdx.x == 0) *total_out = 0;
 }
 
 extern "C" hipError_t lidf_launch_scan(const int* in, long long n, int* out, int* sums,
                                        hipStream_t st) {
     if (n <= 0) {
         hipLaunchKernelGGL(lidf_scan_final_kernel, dim3(1), dim3(256), 0, st, in, (long long)0,
-                           sums, out);
+                           sums, out, (const int*)nullptr, (int*)nullptr);
         return hipGetLastError();
     }
     const long long nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    hipLaunchKernelGGL(lidf_scan_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums);
+    hipLaunchKernelGGL(lidf_scan_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums,
+                       (const int*)nullptr);
     hipLaunchKernelGGL(lidf_scan_top_kernel, dim3(1), dim3(256), 0, st, sums, nb);
     hipLaunchKernelGGL(lidf_scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums,
-                       out);
+                       out, (const int*)nullptr, (int*)nullptr);
+    return hipGetLastError();
+}
+
+// The same scan over the first *n_dev entries of a buffer of capacity n_cap (the sync-free frame
+// path): the launch is sized for n_cap, entries beyond *n_dev are neither read nor written, and the
+// grand total out[*n_dev] is also stored to *total_out when given.
+extern "C" hipError_t lidf_launch_scan_dev(const int* in, long long n_cap, const int* n_dev, int* out,
+                                           int* sums, int* total_out, hipStream_t st) {
+    if (n_cap <= 0) n_cap = 1;
+    const long long nb = (n_cap + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(lidf_scan_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n_cap, sums, n_dev);
+    hipLaunchKernelGGL(lidf_scan_top_kernel, dim3(1), dim3(256), 0, st, sums, nb);
+    hipLaunchKernelGGL(lidf_scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, in, n_cap, sums,
+                       out, n_dev, total_out);
     return hipGetLastError();
 }
 
@@ -1048,12 +1106,6 @@ extern "C" hipError_t lidf_launch_scan(const int* in, long long n, int* out, int
 //   pass C (points): valid_v_pid, revidx, valid_v_rel_coord
 // f32 arithmetic follows the reference op by op: v - xmin ; / crop ; floor ; coord*crop + crop/2.
 // ------------------------------------------------------------------------------------------------
-struct GridSpec {
-    float xmin[3];
-    float crop;
-    int r[3];
-    int B;
-};
 
 __global__ void lidf_vox_mark_kernel(const float* __restrict__ xyz, const int* __restrict__ bid,
                                      long long N, GridSpec g, int* __restrict__ cell_flag,
@@ -1082,7 +1134,8 @@ __global__ void lidf_vox_mark_kernel(const float* __restrict__ xyz, const int* _
 
 __global__ void lidf_vox_cells_kernel(const int* __restrict__ cell_flag,
                                       const int* __restrict__ cell_rank, long long ncell, GridSpec g,
-                                      int* __restrict__ occ, float* __restrict__ vbound) {
+                                      int* __restrict__ occ, float* __restrict__ vbound,
+                                      int* __restrict__ vox_bid) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncell || !cell_flag[k]) return;
     const int v = cell_rank[k];
@@ -1091,6 +1144,7 @@ __global__ void lidf_vox_cells_kernel(const int* __restrict__ cell_flag,
     const int cy = rem % g.r[1]; rem /= g.r[1];
     const int cx = rem % g.r[0]; rem /= g.r[0];
     occ[4 * v + 0] = rem;
+    if (vox_bid) vox_bid[v] = rem;   // the image index on its own ([V] i32: what the box tests take)
     occ[4 * v + 1] = cx;
     occ[4 * v + 2] = cy;
     occ[4 * v + 3] = cz;
@@ -1137,13 +1191,18 @@ extern "C" hipError_t lidf_launch_vox_mark(const float* xyz, const int* bid, lon
                        xyz, bid, N, g, cell_flag, pt_key, pt_valid);
     return hipGetLastError();
 }
+extern "C" hipError_t lidf_launch_vox_cells_bid(const int* cell_flag, const int* cell_rank,
+                                                long long ncell, const GridSpec& g, int* occ,
+                                                float* vbound, int* vox_bid, hipStream_t st) {
+    if (ncell <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_vox_cells_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0,
+                       st, cell_flag, cell_rank, ncell, g, occ, vbound, vox_bid);
+    return hipGetLastError();
+}
 extern "C" hipError_t lidf_launch_vox_cells(const int* cell_flag, const int* cell_rank,
                                             long long ncell, const GridSpec& g, int* occ,
                                             float* vbound, hipStream_t st) {
-    if (ncell <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_vox_cells_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0,
-                       st, cell_flag, cell_rank, ncell, g, occ, vbound);
-    return hipGetLastError();
+    return lidf_launch_vox_cells_bid(cell_flag, cell_rank, ncell, g, occ, vbound, nullptr, st);
 }
 extern "C" hipError_t lidf_launch_vox_points(const float* xyz, const int* pt_key,
                                              const int* pt_rank, const int* cell_rank, long long N,

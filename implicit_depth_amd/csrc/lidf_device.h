@@ -135,6 +135,8 @@ struct PointsArgs {
     int nets;           // per-net blocks in the stream
     int l1_quads, net_quads;
     long long n;        // points (fused) or rows
+    const int* n_dev;   // optional device-side count overriding n (then n is the capacity the launch is
+                        // sized for): the sync-free frame path, where sizes never reach the host
     // per net: passes (n_iter for IEF, 1 for IMNet), initial value (0.001 IEF / 0 IMNet),
     // output activation, output pointer ([n] or NULL), whether it is the offset net
     int npass[2];
@@ -175,6 +177,7 @@ struct LinearArgs {
     int kq1;
     const float* X;        // [n, D] rows, row stride ldx
     long long ldx, n;
+    const int* n_dev;      // optional device-side row count overriding n (n = capacity of the launch)
     int D, has_bias;
     const float* addrows;  // optional: += addrows[addidx[row], 0:32*nt]
     const int* addidx;
@@ -219,6 +222,36 @@ __device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, flo
     const float t = __builtin_amdgcn_fractf(r.hi * sc) + r.lo * sc;
     s = __builtin_amdgcn_sinf(t);
     c = __builtin_amdgcn_cosf(t);
+}
+
+#endif  // __HIPCC__
+
+// Regular voxel grid of LIDF.get_occ_vox_bound (models/pipeline.py:162-201): lower corner (already
+// widened by half a voxel), voxel size, cells per axis, frames.
+struct GridSpec {
+    float xmin[3];
+    float crop;
+    int r[3];
+    int B;
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int block_scan_256(int v, int* s_tmp, int& total) {
+    // inclusive scan of one value per thread over 256 threads; returns exclusive prefix
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(inc, s);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int wpre = 0;
+    for (int w = 0; w < wave; ++w) wpre += s_tmp[w];
+    total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    __syncthreads();
+    return wpre + inc - v;
 }
 
 #endif  // __HIPCC__

@@ -29,12 +29,13 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     const __amdgpu_buffer_rsrc_t srs =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, a.kq1 * NT * 1024, 0x00020000);
     const int vq = lane * 16;
-    const long long ntile = (a.n + 127) / 128;
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;   // device-side row count (frame path)
+    const long long ntile = (AN + 127) / 128;
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        if (tile * 128 + wave * 32 >= a.n) continue;
+        if (tile * 128 + wave * 32 >= AN) continue;
         const long long p = tile * 128 + wave * 32 + col;
-        const bool valid = p < a.n;
-        const long long pc = valid ? p : a.n - 1;
+        const bool valid = p < AN;
+        const long long pc = valid ? p : AN - 1;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

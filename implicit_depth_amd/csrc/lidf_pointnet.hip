@@ -60,6 +60,12 @@ struct PnetChainArgs {
     float* part;           // LDS path: [gridDim.x, V * F] slabs; atomic path: [copies, V * F] (zeroed)
     int V, copies;
     long long n;
+    // sync-free frame path: device-side counts. n_dev overrides n (n = capacity of the launch).
+    // V_dev selects the variant on the device: the LDS-table launch (table of a.V rows, a.V = the
+    // caller's bound) runs iff *V_dev <= a.V, the global-atomic launch iff *V_dev > v_lds.
+    const int* n_dev;
+    const int* V_dev;
+    int v_lds;
 };
 
 __device__ __forceinline__ int pn_feature(int s, int half) {
@@ -195,6 +201,8 @@ template <int STAGE, bool LDSPOOL>
 __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainArgs a) {
     extern __shared__ int pn_tab[];
     constexpr int F = STAGE == 1 ? 64 : 128;
+    if (a.V_dev && ((*a.V_dev <= a.v_lds) != LDSPOOL)) return;   // the other variant owns this call
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;
     if (LDSPOOL) {
         for (int i = threadIdx.x; i < a.V * F; i += 256) pn_tab[i] = 0;
         __syncthreads();
@@ -212,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
     const __amdgpu_buffer_rsrc_t srs =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, PN_S2_QUADS * 1024, 0x00020000);
     const int vq = lane * 16;
-    const long long ntile = (a.n + 127) / 128;
+    const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long bx = blockIdx.x;
     const long long tb = bx * per + (bx < rem ? bx : rem);
@@ -224,10 +232,10 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
 
     for (long long tile = tb; tile < te; ++tile) {
-        if (tile * 128 + wave * 32 >= a.n) break;   // wave-uniform
+        if (tile * 128 + wave * 32 >= AN) break;   // wave-uniform
         const long long p = tile * 128 + wave * 32 + col;
-        const bool valid = p < a.n;
-        const long long pc = valid ? p : a.n - 1;
+        const bool valid = p < AN;
+        const long long pc = valid ? p : AN - 1;
         const int vox = a.vox[pc];
         // operand columns of this lane: 4h + {0..3} of [x0..x5, 1, 0]
         float b1[4];
@@ -330,8 +338,11 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
 // are combined through LDS.
 __global__ void __launch_bounds__(256) lidf_pointnet_poolmax_kernel(const float* __restrict__ part, int G,
                                                                     long long count,
-                                                                    float* __restrict__ pool) {
+                                                                    float* __restrict__ pool,
+                                                                    const int* __restrict__ V_dev,
+                                                                    int v_lds) {
     __shared__ f32x4 red[16][16];
+    if (V_dev && *V_dev > v_lds) return;   // frame path: the global-atomic variant wrote `pool` itself
     const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
     const long long e = ((long long)blockIdx.x * 16 + c) * 4;
     f32x4 m = {0.f, 0.f, 0.f, 0.f};
@@ -405,6 +416,7 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n;
     a.part = part; a.V = (int)V; a.copies = 0;
+    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0;
     const int F = stage == 1 ? 64 : 128;
     const long long count = V * F;
     const long long ntile = (n + 127) / 128;
@@ -427,7 +439,7 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
             hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
         }
         hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
-                           st, part, (int)g, count, pool);
+                           st, part, (int)g, count, pool, (const int*)nullptr, 0);
         return hipGetLastError();
     }
     if (part) {
@@ -442,6 +454,54 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g), dim3(256), 0, st, a);
     if (part)
         hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
-                           st, part, a.copies, count, pool);
+                           st, part, a.copies, count, pool, (const int*)nullptr, 0);
+    return hipGetLastError();
+}
+
+// The same stage with device-side counts (the sync-free frame path): n_cap / V_cap bound the launch,
+// *n_dev / *V_dev are the sizes. Two launches, one of which returns at once: per-workgroup LDS tables
+// of v_lds rows (the caller's bound for typical frames, <= 288) when *V_dev <= v_lds, else global
+// atomic maxima straight into `pool` (zeroed by the caller, [V_cap, F]). `part`: PN_MAX_WGS slabs of
+// v_lds x F floats. `pool` rows >= *V_dev stay zero.
+extern "C" size_t lidf_pointnet_pool_scratch_bytes_dev(long long v_lds) {
+    return (size_t)PN_MAX_WGS * (v_lds > 0 ? v_lds : 1) * 128 * 4;
+}
+extern "C" hipError_t lidf_launch_pointnet_chain_dev(int stage, const float* stream, const float* inp,
+                                                     const int* vox, const float* gpart, float* pool,
+                                                     float* part, long long V_cap, int v_lds,
+                                                     long long n_cap, const int* n_dev,
+                                                     const int* V_dev, int cus, hipStream_t st) {
+    if (n_cap <= 0) return hipSuccess;
+    if (v_lds <= 0 || (size_t)v_lds * 128 * 4 > PN_LDS_LIMIT || !part || !V_dev) return hipErrorInvalidValue;
+    PnetChainArgs a;
+    a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
+    a.part = part; a.V = v_lds; a.copies = 0; a.n_dev = n_dev; a.V_dev = V_dev; a.v_lds = v_lds;
+    const int F = stage == 1 ? 64 : 128;
+    const long long ntile = (n_cap + 127) / 128;
+    const size_t lds = (size_t)v_lds * F * 4;
+    long long g = lds <= 65536 ? 2LL * cus : cus;
+    if (g > PN_MAX_WGS) g = PN_MAX_WGS;
+    if (g > ntile) g = ntile;
+    hipError_t e;
+    if (stage == 1) {
+        static bool configured[64];
+        e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<1, true>, PN_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), lds, st, a);
+    } else {
+        static bool configured[64];
+        e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<2, true>, PN_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
+    }
+    hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)(((long long)v_lds * F + 63) / 64)),
+                       dim3(256), 0, st, part, (int)g, (long long)v_lds * F, pool, V_dev, v_lds);
+    // the fallback: more occupied voxels than the LDS tables hold
+    a.V = (int)V_cap; a.part = nullptr;
+    const long long g2 = ntile < 2LL * cus ? ntile : 2LL * cus;
+    if (stage == 1)
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
     return hipGetLastError();
 }

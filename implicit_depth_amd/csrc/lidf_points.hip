@@ -417,6 +417,8 @@ struct Geo {
 // of both decoders in one launch, a.tr_passes / a.tr_pre per net).
 template <bool ST>
 __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
+    // row / point count: a device-side count (a.n_dev: the sync-free frame path) overrides the host value
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;
     extern __shared__ float lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -441,11 +443,11 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     //    by the launch before), requested one chunk ahead so that the round trip is never waited
     //    for. Compute units do not run at one clock (2.36-2.40 GHz on the headline launch) and tiles
     //    of ragged lists do not cost the same (1 to 16 rank-1 rounds per net): the faster take more.
-    const long long nwt = (a.n + 31) / 32;
+    const long long nwt = (AN + 31) / 32;
     // (short lists keep the static split: with a handful of tiles per wavefront one tile is the
     // grain either way and the first requests would be waited for)
     const bool dyn = a.tile_counter != nullptr && nwt >= 32LL * gridDim.x * 4;
-    const long long ntile = (a.n + 127) / 128;
+    const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
@@ -479,7 +481,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
 
     // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
     auto load_idx = [&](long long wt, Geo& g) {
-        const long long last = a.n - 1;
+        const long long last = AN - 1;
         long long t0 = wt * 32;                     // uniform
         if (t0 > last) t0 = last & ~31LL;           // a prefetch past the end re-reads the last tile
         const long long rem = last - t0;
@@ -527,7 +529,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     for (; w_cur < nwt; w_cur = w_nxt, w_nxt = w_nx2) {
         PROF(0)
         const long long p = w_cur * 32 + col;
-        const bool valid = p < a.n;
+        const bool valid = p < AN;
 
         load_dir(nxt);
         w_nx2 = next_wt(w_nxt);
@@ -661,15 +663,15 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;
             const int npass = a.npass[net];
             // (ST: rows beyond n repeat point n-1 — load_idx clamps — so their stores repeat its values)
-            const long long pc = valid ? p : a.n - 1;
+            const long long pc = valid ? p : AN - 1;
             auto train_row = [&](int pass, float v) {
                 TrainRow tr = {};
                 if (ST) {
                     float* pk = a.tr_passes[net] + (size_t)pass * a.tr_pass_floats;
                     tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
-                    tr.h2 = pk + (size_t)a.n * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
-                    tr.h3 = pk + (size_t)a.n * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
-                    if (valid && h == 0) pk[(size_t)a.n * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = v;
+                    tr.h2 = pk + (size_t)AN * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
+                    tr.h3 = pk + (size_t)AN * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                    if (valid && h == 0) pk[(size_t)AN * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = v;
                 }
                 return tr;
             };
@@ -727,6 +729,8 @@ __global__ void __launch_bounds__(256) lidf_points_fused_train_kernel(PointsArgs
 template <int MODE>
 __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int bx, const int gx,
                                                  const int net_lo, const int net_hi) {
+    // row / point count: a device-side count (a.n_dev: the sync-free frame path) overrides the host value
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
@@ -739,7 +743,7 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
     const int l1_bytes = a.l1_quads * 1024;
 
     // contiguous range of 128-row tiles per workgroup; the 4 waves interleave inside it
-    const long long ntile = (a.n + 127) / 128;
+    const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gx, rem = ntile % gx;
     const long long tb = bx * per + (bx < rem ? bx : rem);
     const long long te_ = tb + per + (bx < rem ? 1 : 0);
@@ -752,10 +756,10 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
 
     PROF_DECL
     for (long long tile = tb; tile < te_; ++tile) {
-        if (tile * 128 + wave * 32 >= a.n) break;  // whole wave out of range (wave-uniform)
+        if (tile * 128 + wave * 32 >= AN) break;  // whole wave out of range (wave-uniform)
         const long long p = tile * 128 + wave * 32 + col;
-        const bool valid = p < a.n;
-        const long long pc = valid ? p : a.n - 1;
+        const bool valid = p < AN;
+        const long long pc = valid ? p : AN - 1;
 
         for (int net = net_lo; net < net_hi; ++net) {
             const int nsb = net * net_bytes;  // byte offset of this net's block
@@ -891,9 +895,9 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                         // rows beyond n repeat row n-1 (same operands, same values): no guard needed
                         float* pk = a.tr_passes[net] + (size_t)pass * a.tr_pass_floats;
                         tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
-                        tr.h2 = pk + (size_t)a.n * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
-                        tr.h3 = pk + (size_t)a.n * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
-                        if (valid && h == 0) pk[(size_t)a.n * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = val;
+                        tr.h2 = pk + (size_t)AN * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
+                        tr.h3 = pk + (size_t)AN * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                        if (valid && h == 0) pk[(size_t)AN * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = val;
                     }
                     val += decoder_pass<false, MODE == LIDF_MODE_TRAIN>(
                         srs, vq, ring, pass_base, wrap_base, base, val, h, one_b, ax, nullptr, 0u, 0u,
@@ -930,8 +934,8 @@ __global__ void __launch_bounds__(256) lidf_points_kernel(PointsArgs a) {
 // instruction with 16 bytes each: raypart is 157 MB per frame). Stream: the rows-mode layer-1
 // layout with 8 tiles per k-quad (lidf_device.h); half hf reads the quads kq*8 + 4hf + {0..3}.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long tile, const int net,
-                                            const int hf, float* s_stage) {
+__device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long AN, const long long tile,
+                                            const int net, const int hf, float* s_stage) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
@@ -943,9 +947,9 @@ __device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long
     const int sbase = net * net_bytes + 4 * hf * 1024;
     float* stage = s_stage + wave * (32 * 33);
     {
-        if (tile * 128 + wave * 32 >= a.n) return;
+        if (tile * 128 + wave * 32 >= AN) return;
         const long long p = tile * 128 + wave * 32 + col;
-        const long long pc = p < a.n ? p : a.n - 1;
+        const long long pc = p < AN ? p : AN - 1;
         const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
         auto load_b = [&](int kq, float (&b)[4]) {
             const int x0 = 8 * kq + 4 * h;
@@ -1016,7 +1020,7 @@ __device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = stage[row * 33 + f4 + i];
-                if (tile * 128 + wave * 32 + row < a.n)
+                if (tile * 128 + wave * 32 + row < AN)
                     *(f32x4*)(ob + (size_t)row * a.nets * 256 + 32 * t + f4) = o;
             }
         }
@@ -1029,17 +1033,18 @@ __device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long
 __global__ void __launch_bounds__(256) lidf_l1part_pair_kernel(PointsArgs a, PointsArgs b) {
     __shared__ float s_stage[4 * 32 * 33];
     const int parts = a.nets * 2;
-    const long long na = (a.n + 127) / 128 * parts, nb = (b.n + 127) / 128 * parts;
+    const long long an = a.n_dev ? (long long)*a.n_dev : a.n, bn = b.n_dev ? (long long)*b.n_dev : b.n;
+    const long long na = (an + 127) / 128 * parts, nb = (bn + 127) / 128 * parts;
     const long long tot = na + nb, per = tot / gridDim.x, rem = tot % gridDim.x;
     const long long bx = blockIdx.x;
     const long long ib = bx * per + (bx < rem ? bx : rem), ie = ib + per + (bx < rem ? 1 : 0);
     for (long long i = ib; i < ie; ++i) {
         if (i < na) {
             const int part = (int)(i % parts);
-            l1part_item(a, i / parts, part >> 1, part & 1, s_stage);
+            l1part_item(a, an, i / parts, part >> 1, part & 1, s_stage);
         } else {
             const int part = (int)((i - na) % parts);
-            l1part_item(b, (i - na) / parts, part >> 1, part & 1, s_stage);
+            l1part_item(b, bn, (i - na) / parts, part >> 1, part & 1, s_stage);
         }
     }
 }

@@ -10,6 +10,18 @@ __device__ __forceinline__ bool inside_box(float x, float y, float z, const floa
     return true;
 }
 
+extern "C" hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int*, long long,
+                                                  const float*, const int*, long long, const int*,
+                                                  const int*, const float*, long long, int, long long,
+                                                  float*, int*, int*, const unsigned char*, const int*,
+                                                  const int*, hipStream_t);
+extern "C" hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int,
+                                                  int, int, int, long long, const int*, float*, int,
+                                                  hipStream_t);
+extern "C" hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float,
+                                                    long long, const int*, float*, const int*, const int*,
+                                                    long long, float*, hipStream_t);
+
 // One thread per ray:
 //   end_voxel = max( voxel of the arg-max pair (0 for a ray without pairs: the dummy row,
 //                    pipeline.py:941-943), largest occupied voxel of the same image containing
@@ -27,7 +39,14 @@ __global__ void __launch_bounds__(256) lidf_refine_endvox_kernel(
     const float* __restrict__ pred_pos, const long long* __restrict__ max_pair_id,
     const int* __restrict__ pair_vox, long long P, const float* __restrict__ vbound,
     const int* __restrict__ vox_bid, long long V, long long per_slice,
-    const int* __restrict__ ray_bid, long long R, int* __restrict__ end_voxel) {
+    const int* __restrict__ ray_bid, long long R, int* __restrict__ end_voxel,
+    const int* __restrict__ dims) {
+    if (dims) {   // device-side counts {R, P, V} (the sync-free frame path): R, P, V above = capacities
+        R = dims[0];
+        P = dims[1];
+        V = dims[2];
+        per_slice = (V + gridDim.y - 1) / gridDim.y;
+    }
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < R;
     float x = 0.f, y = 0.f, z = 0.f;
@@ -63,7 +82,14 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
                                         long long R, float* __restrict__ pnet_inp,
                                         int* __restrict__ pnet_vox,
                                         const int* __restrict__ end_voxel,
-                                        const unsigned char* __restrict__ pnet_select) {
+                                        const unsigned char* __restrict__ pnet_select,
+                                        const int* __restrict__ R_dev,
+                                        const int* __restrict__ row0_dev) {
+    if (R_dev) R = *R_dev;
+    if (row0_dev) {   // frame path: the predicted points follow the *row0_dev valid points
+        pnet_inp += 6 * (size_t)*row0_dev;
+        pnet_vox += *row0_dev;
+    }
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const float x = pred_pos[3 * r], y = pred_pos[3 * r + 1], z = pred_pos[3 * r + 2];
@@ -91,7 +117,8 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
                                         const float* __restrict__ vbound,
                                         const float* __restrict__ rayfeat, int ld_rf, int Lv, int L,
                                         int pos_rel, long long R, float* __restrict__ inp_embed,
-                                        int ld_e) {
+                                        int ld_e, const int* __restrict__ R_dev) {
+    if (R_dev) R = *R_dev;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
     const int ncol = 128 + E + Ed;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,8 +159,23 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
                                               float* pnet_inp, int* pnet_vox, float* inp_embed,
                                               int ld_e, int* end_voxel,
                                               const unsigned char* pnet_select, hipStream_t st) {
-    if (R <= 0) return hipSuccess;
+    return lidf_launch_refine_prep_dev(pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid, ray_flat,
+                                       rgb, hw, pnet_rel, R, pnet_inp, pnet_vox, end_voxel, pnet_select,
+                                       nullptr, nullptr, st);
     (void)rayfeat; (void)ld_rf; (void)Lv; (void)L; (void)pos_rel; (void)inp_embed; (void)ld_e;
+}
+
+// dims (optional): device int32 {R, P, V} overriding the host counts (which then bound the launches);
+// row0_dev (optional): device row offset of pnet_inp / pnet_vox (the number of valid points)
+extern "C" hipError_t lidf_launch_refine_prep_dev(const float* pred_pos, const long long* max_pair_id,
+                                                  const int* pair_vox, long long P, const float* vbound,
+                                                  const int* vox_bid, long long V, const int* ray_bid,
+                                                  const int* ray_flat, const float* rgb, long long hw,
+                                                  int pnet_rel, long long R, float* pnet_inp,
+                                                  int* pnet_vox, int* end_voxel,
+                                                  const unsigned char* pnet_select, const int* dims,
+                                                  const int* row0_dev, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
     if (e != hipSuccess) return e;
     // slices of at least 64 voxels, enough of them for ~8 wavefronts per SIMD
@@ -146,10 +188,10 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
     slices = V > 0 ? (V + per_slice - 1) / per_slice : 1;
     hipLaunchKernelGGL(lidf_refine_endvox_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)slices),
                        dim3(256), 0, st, pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V,
-                       per_slice, ray_bid, R, end_voxel);
+                       per_slice, ray_bid, R, end_voxel, dims);
     hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
                        pred_pos, vbound, ray_bid, ray_flat, rgb, hw, pnet_rel, R, pnet_inp, pnet_vox,
-                       end_voxel, pnet_select);
+                       end_voxel, pnet_select, dims, row0_dev);
     return hipGetLastError();
 }
 
@@ -157,10 +199,18 @@ extern "C" hipError_t lidf_launch_refine_rows(const float* pred_pos, const int* 
                                               const float* vbound, const float* rayfeat, int ld_rf,
                                               int Lv, int L, int pos_rel, long long R,
                                               float* inp_embed, int ld_e, hipStream_t st) {
+    return lidf_launch_refine_rows_dev(pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, nullptr,
+                                       inp_embed, ld_e, st);
+}
+extern "C" hipError_t lidf_launch_refine_rows_dev(const float* pred_pos, const int* end_voxel,
+                                                  const float* vbound, const float* rayfeat, int ld_rf,
+                                                  int Lv, int L, int pos_rel, long long R,
+                                                  const int* R_dev, float* inp_embed, int ld_e,
+                                                  hipStream_t st) {
     if (R <= 0) return hipSuccess;
     const long long total = R * (128 + 3 + 6 * L + 3 + 6 * Lv);
     hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e);
+                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev);
     return hipGetLastError();
 }
 
@@ -184,9 +234,16 @@ __global__ void lidf_refine_gather_kernel(const float* __restrict__ vox_feat,
 __global__ void lidf_refine_finish_kernel(const float* __restrict__ pred_pos,
                                           const float* __restrict__ off,
                                           const float* __restrict__ ray_dir, float r0, float rs,
-                                          long long R, float* __restrict__ out) {
+                                          long long R, float* __restrict__ out,
+                                          const int* __restrict__ R_dev,
+                                          const int* __restrict__ ray_bid,
+                                          const int* __restrict__ ray_flat, long long hw,
+                                          float* __restrict__ depth) {
+    if (R_dev) R = *R_dev;
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    // optional: the refined depth map (pred_xyz[miss_bid, miss_flat_img_id] = pred_pos_refine, z)
+    if (depth) depth[(size_t)ray_bid[r] * hw + ray_flat[r]] = pred_pos[3 * r + 2] + (off[r] * rs + r0) * ray_dir[3 * r + 2];
     const float s = off[r] * rs + r0;
     out[3 * r] = pred_pos[3 * r] + s * ray_dir[3 * r];
     out[3 * r + 1] = pred_pos[3 * r + 1] + s * ray_dir[3 * r + 1];
@@ -205,8 +262,18 @@ extern "C" hipError_t lidf_launch_refine_gather(const float* vox_feat, const int
 extern "C" hipError_t lidf_launch_refine_finish(const float* pred_pos, const float* off,
                                                 const float* ray_dir, float r0, float rs,
                                                 long long R, float* out, hipStream_t st) {
+    return lidf_launch_refine_finish_dev(pred_pos, off, ray_dir, r0, rs, R, nullptr, out, nullptr, nullptr, 0,
+                                         nullptr, st);
+}
+// R_dev (optional): device-side ray count; depth (optional, with ray_bid / ray_flat / hw): the refined
+// depth map written alongside
+extern "C" hipError_t lidf_launch_refine_finish_dev(const float* pred_pos, const float* off,
+                                                    const float* ray_dir, float r0, float rs,
+                                                    long long R, const int* R_dev, float* out,
+                                                    const int* ray_bid, const int* ray_flat,
+                                                    long long hw, float* depth, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_refine_finish_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0,
-                       st, pred_pos, off, ray_dir, r0, rs, R, out);
+                       st, pred_pos, off, ray_dir, r0, rs, R, out, R_dev, ray_bid, ray_flat, hw, depth);
     return hipGetLastError();
 }

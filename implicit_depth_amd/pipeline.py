@@ -205,3 +205,256 @@ def eval_metrics(dd, key="pred_depth", frame=0):
     h, w = dd["h"], dd["w"]
     gt = dd["xyz_flat"][frame, :, 2].reshape(h, w).contiguous()
     return Q.depth_metrics(dd[key][frame].contiguous(), gt, dd["corrupt_mask"][frame])
+
+
+# ------------------------------------------------------------------------------------------------
+# The same evaluation path as ONE library call per batch, without a host round trip
+# ------------------------------------------------------------------------------------------------
+_FC = {"R": 0, "P": 1, "V": 2, "NV": 3, "NV0": 4, "NVS": 5, "NPN": 6, "OVERFLOW": 7}
+
+
+class FrameRunner:
+    """LIDF.forward (+ RefineNet.forward) for evaluation through lidf_frame_f32: every compacted list
+    (valid points, occupied voxels, rays, ray/voxel pairs) lives in a buffer sized for the worst case
+    and its length stays on the device, so a frame is enqueued without a single .item() / nonzero()
+    size read (the reference — and lidf_forward above — stall the stream four times per frame), and
+    the launch sequence depends on (batch, h, w, max_pairs) only: `capture()` records it into a HIP
+    graph that `run()` replays.
+
+        runner = FrameRunner(bs, h, w, device, pnet, prob_dec, offset_dec, opt,
+                             pnet_refine=..., offset_dec_refine=...)
+        runner.run(batch, full_rgb_feat)      # enqueue only (optionally: runner.capture(...) once)
+        dd = runner.result()                  # ONE sync: reads the counts, returns the data_dict
+
+    result() gives the reference's data_dict keys as views of the capacity buffers (int32 index
+    tensors; `reference_dtypes=True` adds the int64 forms). mask_type 'all' / 'pred', every valid
+    pixel or every opt.valid_stride-th; intersect_pos_type 'abs' (the shipped configs); f32.
+    max_pairs bounds the pair list (default 32 per pixel: a ray crosses at most 25 cells of the 9^3
+    grid); a frame with more pairs raises in result()."""
+
+    def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
+                 offset_dec_refine=None, max_pairs=None, lds_voxels=128):
+        import ctypes as C
+        import math
+        from .decoders import _check_supported
+        from .pointnet import check_pointnet
+        self.C = C
+        self.opt = opt = opt or LidfOptions()
+        if opt.intersect_pos_type != "abs":
+            raise RuntimeError("FrameRunner: intersect_pos_type 'abs' only (use lidf_forward for 'rel')")
+        if opt.mask_type not in ("all", "pred"):
+            raise NotImplementedError("mask_type %s" % opt.mask_type)
+        self.bs, self.h, self.w, self.dev = bs, h, w, torch.device(device)
+        self.mods = (pnet_model, prob_dec, offset_dec, pnet_model_refine, offset_dec_refine)
+        _check_supported(prob_dec), _check_supported(offset_dec), check_pointnet(pnet_model)
+        self.refine = pnet_model_refine is not None
+        if self.refine:
+            _check_supported(offset_dec_refine), check_pointnet(pnet_model_refine)
+        # the widened grid of LIDF.get_occ_vox_bound (models/pipeline.py:167-173), in the reference's f32
+        t32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+        lo, hi = t32(opt.xmin), t32(opt.xmax)
+        self.part_size = float(torch.min(hi - lo).item()) / opt.grid_res
+        lo, hi = lo - 0.5 * self.part_size, hi + 0.5 * self.part_size
+        self.xmin = [float(v) for v in lo.tolist()]
+        self.res = [int(v) for v in torch.ceil((hi - lo) / self.part_size).tolist()]
+        N, Cc = bs * h * w, bs * self.res[0] * self.res[1] * self.res[2]
+        self.N, self.Cc = N, Cc
+        self.max_pairs = int(max_pairs) if max_pairs else 32 * N
+        self.lds_voxels = int(lds_voxels)
+        Ed = 3 + 6 * opt.multires_views
+        dev = self.dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        P = self.max_pairs
+        self.buf = {
+            "counts": torch.zeros((8,), **i32),
+            "valid_bid": torch.empty((N,), **i32), "valid_flat": torch.empty((N,), **i32),
+            "valid_xyz": torch.empty((N, 3), **f32), "valid_rgb": torch.empty((N, 3), **f32),
+            "occ_bid_coord": torch.empty((Cc, 4), **i32), "voxel_bound": torch.empty((Cc, 6), **f32),
+            "valid_v_pid": torch.empty((2 * N,), **i32), "revidx": torch.empty((2 * N,), **i32),
+            "valid_v_rel_coord": torch.empty((N, 3), **f32), "pnet_inp": torch.empty((2 * N, 6), **f32),
+            "occ_voxel_feat": torch.empty((Cc, 128), **f32),
+            "ray_bid": torch.empty((N,), **i32), "ray_flat": torch.empty((N,), **i32),
+            "ray_pix": torch.empty((N, 2), **i32), "ray_dir": torch.empty((N, 3), **f32),
+            "pair_off": torch.zeros((N + 1,), **i32), "pair_ray": torch.empty((P,), **i32),
+            "pair_vox": torch.empty((P,), **i32), "pair_t": torch.empty((P, 2), **f32),
+            "pred_offset": torch.empty((P,), **f32), "pred_prob": torch.empty((P,), **f32),
+            "pred_prob_softmax": torch.empty((P,), **f32), "pair_pred_pos": torch.empty((P, 3), **f32),
+            "max_pair_id": torch.empty((N,), dtype=torch.int64, device=dev),
+            "pred_pos": torch.empty((N, 3), **f32), "rayfeat": torch.empty((N, 128 + Ed), **f32),
+            "pred_depth": torch.empty((bs, h, w), **f32),
+        }
+        if self.refine:
+            self.buf.update({"pred_pos_refine": torch.empty((N, 3), **f32),
+                             "end_voxel_id": torch.empty((N,), **i32),
+                             "pred_depth_refine": torch.empty((bs, h, w), **f32)})
+        L = _lib.lib()
+        self.times = opt.refine_forward_times if self.refine else 0
+        res = (C.c_int32 * 3)(*self.res)
+        wsb = L.lidf_frame_workspace_bytes(bs, h, w, res, self.max_pairs, self.lds_voxels, self.times)
+        self.ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        # static inputs (a captured graph replays fixed addresses): load() copies a batch into them
+        self.inp = {
+            "rgb": torch.empty((bs, 3, h, w), **f32), "xyz_corrupt": torch.empty((bs, 3, h, w), **f32),
+            "valid_mask": torch.empty((bs, h, w), **f32), "intr": torch.empty((bs, 4), **f32),
+            "feat_grid": torch.empty((bs, 32, h, w), **f32),
+            "miss_mask": torch.empty((bs, h, w), **f32) if opt.mask_type == "pred" else None,
+        }
+        self.graph = None
+        self._keep = None
+        math.isfinite(self.part_size)
+
+    # -- inputs -----------------------------------------------------------------------------------
+    def load(self, batch, full_rgb_feat, pred_mask=None):
+        """Copy a batch (the reference's dataset item keys) into the runner's static input buffers:
+        device-to-device copies on the current stream, no sync. mask_type 'all': valid <=> the
+        measured depth is non-zero (prepare_data, pipeline.py:119-121), so depth_corrupt itself is the
+        valid mask; 'pred': valid_mask = 1 - pred_mask, rays where pred_mask is non-zero."""
+        i = self.inp
+        i["rgb"].copy_(batch["rgb"], non_blocking=True)
+        i["xyz_corrupt"].copy_(batch["xyz_corrupt"], non_blocking=True)
+        i["feat_grid"].copy_(full_rgb_feat, non_blocking=True)
+        for k, name in enumerate(("fx", "fy", "cx", "cy")):
+            i["intr"][:, k].copy_(batch[name], non_blocking=True)
+        if self.opt.mask_type == "all":
+            i["valid_mask"].copy_(batch["depth_corrupt"].reshape(self.bs, self.h, self.w), non_blocking=True)
+        else:
+            pm = pred_mask.reshape(self.bs, self.h, self.w)
+            i["miss_mask"].copy_(pm, non_blocking=True)
+            torch.sub(1.0, i["miss_mask"], out=i["valid_mask"])
+
+    # -- the launch sequence ------------------------------------------------------------------------
+    def enqueue(self):
+        """lidf_frame_f32 on the static inputs: guarded weight packs (fingerprints compared on the
+        device) + the frame; nothing here reads a size or waits for the device."""
+        from .decoders import _decoder_struct
+        from .pointnet import packed_pointnet, pointnet_struct
+        from .query import _packed_weights
+        C = self.C
+        pnet, prob, off, pnet_r, off_r = self.mods
+        opt, b, i = self.opt, self.buf, self.inp
+        keep = []
+        dp, do = _decoder_struct(prob, keep), _decoder_struct(off, keep)
+        pn = pointnet_struct(pnet, keep)
+        keep.append(packed_pointnet(pnet, pn, self.dev))
+        packed_q = _packed_weights(prob, off, opt.multires, opt.multires_views, "f32", dp, do, self.dev)
+        a = _lib.LidfFrameArgs()
+        a.batch, a.height, a.width = self.bs, self.h, self.w
+        for k in ("rgb", "xyz_corrupt", "valid_mask", "intr", "feat_grid"):
+            setattr(a, k, i[k].data_ptr())
+        a.miss_mask = i["miss_mask"].data_ptr() if i["miss_mask"] is not None else None
+        a.xmin = (C.c_float * 3)(*self.xmin)
+        a.res = (C.c_int32 * 3)(*self.res)
+        a.part_size = self.part_size
+        a.valid_stride = int(opt.valid_stride) if opt.valid_stride and opt.valid_stride > 1 else 1
+        a.pnet, a.prob, a.off = C.pointer(pn), C.pointer(dp), C.pointer(do)
+        a.packed_query = packed_q.data_ptr()
+        a.multires, a.multires_views, a.roi_inp_bbox, a.pos_rel = opt.multires, opt.multires_views, opt.roi_inp_bbox, 0
+        a.offset_range0, a.offset_range1 = float(opt.offset_range[0]), float(opt.offset_range[1])
+        a.refine_times = self.times
+        if self.refine:
+            from .query import PRECISIONS  # noqa: F401
+            dr = _decoder_struct(off_r, keep)
+            pr = pointnet_struct(pnet_r, keep)
+            keep.append(packed_pointnet(pnet_r, pr, self.dev))
+            L = _lib.lib()
+            e = _lib.packed_entry(_lib.PACK_CACHE_REFINE, off_r, (opt.multires, opt.multires_views, str(self.dev)),
+                                  L.lidf_refine_pack_bytes(opt.multires, opt.multires_views), self.dev)
+            if not (off_r in _lib.FROZEN and e.frozen_ready):
+                with torch.cuda.device(self.dev):
+                    _lib.check(L.lidf_refine_pack_guarded_f32(
+                        C.byref(dr), opt.multires, opt.multires_views, _lib.ptr(e.blob), e.blob.numel(),
+                        _lib.ptr(e.guard), _lib.current_stream(self.dev)))
+                e.frozen_ready = off_r in _lib.FROZEN
+            a.pnet_refine, a.off_refine, a.packed_refine = C.pointer(pr), C.pointer(dr), e.blob.data_ptr()
+            a.refine_pos_rel = int(opt.refine_intersect_pos_type == "rel")
+            a.refine_pnet_pos_rel = int(opt.refine_pnet_pos_type == "rel")
+            a.refine_use_all_pix = int(bool(opt.refine_use_all_pix) or opt.mask_type != "all")
+            a.refine_offset_range0 = float(opt.refine_offset_range[0])
+            a.refine_offset_range1 = float(opt.refine_offset_range[1])
+        a.max_pairs, a.lds_voxels = self.max_pairs, self.lds_voxels
+        for k, t in b.items():
+            setattr(a, k, t.data_ptr())
+        a.workspace, a.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        with torch.cuda.device(self.dev):
+            _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))
+        self._keep = keep
+
+    def capture(self):
+        """Record enqueue() into a HIP graph (torch.cuda.CUDAGraph) after one eager warm-up call; run()
+        then replays it. The graph holds the parameters' CURRENT storage pointers: in-place updates are
+        picked up by the fingerprint check inside the graph, a replaced `.data` needs a new capture."""
+        self.enqueue()                       # warm-up: kernel attributes, packed blobs, allocator
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.enqueue()
+        self.graph = g
+        return self
+
+    def run(self, batch=None, full_rgb_feat=None, pred_mask=None):
+        """load() (when a batch is given) + the frame (graph replay if captured). No sync."""
+        Q._refuse_autograd("pipeline.FrameRunner.run", "query.lidf_query_train (stage-1 training step)",
+                           (("full_rgb_feat", full_rgb_feat),),
+                           tuple(zip(("pnet_model", "prob_dec", "offset_dec", "pnet_model_refine",
+                                      "offset_dec_refine"), self.mods)))
+        if batch is not None:
+            self.load(batch, full_rgb_feat, pred_mask)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.enqueue()
+        return self
+
+    # -- outputs ------------------------------------------------------------------------------------
+    def counts(self):
+        """The list lengths (ONE device -> host copy; the only sync of a frame)."""
+        c = self.buf["counts"].tolist()
+        return {k: c[i] for k, i in _FC.items()}
+
+    def result(self, reference_dtypes=False):
+        """(success, data_dict) as lidf_forward / refine_forward return them: views of the capacity
+        buffers cut to the frame's counts. success False = one of the reference's early exits (no
+        occupied voxel / no ray / no pair: the launches ran on empty lists)."""
+        c = self.counts()
+        if c["OVERFLOW"]:
+            raise RuntimeError("FrameRunner: the frame has more than max_pairs = %d ray/voxel pairs; "
+                               "construct the runner with a larger max_pairs" % self.max_pairs)
+        b, R, P, V, NV, NVS = self.buf, c["R"], c["P"], c["V"], c["NV"], c["NVS"]
+        dd = {
+            "bs": self.bs, "h": self.h, "w": self.w, "part_size": self.part_size,
+            "xmin": torch.tensor(self.xmin, device=self.dev), "grid_dims": tuple(self.res),
+            "valid_bid": b["valid_bid"][:NVS], "valid_flat_img_id": b["valid_flat"][:NVS],
+            "valid_xyz": b["valid_xyz"][:NVS], "valid_rgb": b["valid_rgb"][:NVS],
+            "occ_vox_bid": b["occ_bid_coord"][:V, 0], "occ_vox_global_coord": b["occ_bid_coord"][:V, 1:],
+            "voxel_bound": b["voxel_bound"][:V], "valid_v_pid": b["valid_v_pid"][:NV],
+            "revidx": b["revidx"][:NV], "valid_v_rel_coord": b["valid_v_rel_coord"][:NV],
+            "pnet_inp": b["pnet_inp"][:NV], "occ_voxel_feat": b["occ_voxel_feat"][:V],
+            "ray_bid": b["ray_bid"][:R], "ray_flat": b["ray_flat"][:R], "ray_pix": b["ray_pix"][:R],
+            "miss_ray_dir": b["ray_dir"][:R], "total_miss_sample_num": R,
+            "pair_off": b["pair_off"][:R + 1], "pair_ray": b["pair_ray"][:P], "pair_vox": b["pair_vox"][:P],
+            "pair_t": b["pair_t"][:P], "pred_offset": b["pred_offset"][:P].unsqueeze(1),
+            "pred_prob_end": b["pred_prob"][:P].unsqueeze(1), "pair_pred_pos": b["pair_pred_pos"][:P],
+            "pred_prob_end_softmax": b["pred_prob_softmax"][:P], "max_pair_id": b["max_pair_id"][:R],
+            "pred_pos": b["pred_pos"][:R], "rayfeat": b["rayfeat"][:R], "pred_depth": b["pred_depth"],
+            "full_rgb_feat": self.inp["feat_grid"], "rgb_img": self.inp["rgb"], "counts": c,
+        }
+        if reference_dtypes:   # the reference's int64 index tensors (torch.nonzero / torch.unique)
+            dd["miss_bid"], dd["miss_flat_img_id"] = dd["ray_bid"].long(), dd["ray_flat"].long()
+            dd["miss_img_ind"] = dd["ray_pix"].long()
+            for k in ("valid_bid", "valid_flat_img_id", "occ_vox_bid", "occ_vox_global_coord", "valid_v_pid",
+                      "revidx"):
+                dd[k] = dd[k].long()
+        ok = V > 0 and R > 0 and P > 0
+        if self.refine and ok:
+            dd["pred_pos_refine"] = b["pred_pos_refine"][:R]
+            dd["end_voxel_id"] = b["end_voxel_id"][:R]
+            dd["pred_depth_refine"] = b["pred_depth_refine"]
+        return ok, dd
+
+    def metrics(self, batch, key=None, frame=0):
+        """The nine ClearGrasp statistics (models/pipeline.py:577-627) of frame `frame` on the device:
+        xyz[frame, 2] of the NCHW batch is the ground-truth depth map as it lies (no copy)."""
+        key = key or ("pred_depth_refine" if self.refine else "pred_depth")
+        seg = batch["corrupt_mask"].reshape(self.bs, self.h, self.w)[frame]
+        return Q.depth_metrics(self.buf[key][frame], batch["xyz"][frame, 2], seg)

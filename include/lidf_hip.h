@@ -395,6 +395,99 @@ int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multires, int32
                                  void* packed, size_t packed_bytes, void* guard, lidf_stream_t stream);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
 
+/* ---- The evaluation path of a batch of frames in ONE call, without a host round trip --------------
+ * LIDF.forward, exp_type 'test' (models/pipeline.py:652-717: prepare_data :91-133, get_valid_points
+ * :135-160, get_occ_vox_bound :162-201, get_miss_ray :203-269, compute_ray_aabb :271-296, the
+ * PointNet2Stage voxel embedding :399-408, get_embedding + get_pred :338-466, the depth map :593-596)
+ * followed, when refine_times > 0, by RefineNet.forward (:1032-1041: refine_times x get_pred_refine).
+ *
+ * The reference sizes every compacted list on the host (torch.nonzero / torch.unique / .item()):
+ * four device -> host round trips per frame, during which the GPU idles. Here every list lives in a
+ * caller-provided buffer sized for the worst case and its length stays on the device: `counts`
+ * receives the lengths, every launch is sized for the capacity and reads its count on the device.
+ * The call only enqueues work with launch parameters that depend on (batch, height, width,
+ * max_pairs, lds_voxels) alone — it can be captured in a hipGraph and replayed for every frame.
+ *
+ * Capacities: rays / valid points <= batch*height*width; voxels <= batch*res0*res1*res2; pairs <=
+ * max_pairs (a ray crosses at most res0+res1+res2-2 cells of the grid; when a frame has more pairs
+ * than max_pairs the list is cut, counts[7] bit 0 is set and the cut rays' results are invalid).
+ * Output arrays must hold the capacities; entries beyond the counts are unspecified.
+ * f32 precision only; the packed weight streams are mandatory (lidf_*_pack_guarded_f32).          */
+#define LIDF_FRAME_COUNTS 8
+#define LIDF_FC_RAYS 0        /* R:   queried pixels (miss rays)                               */
+#define LIDF_FC_PAIRS 1       /* P:   (ray, occupied voxel) pairs                              */
+#define LIDF_FC_VOX 2         /* V:   occupied voxels                                          */
+#define LIDF_FC_VALID_IN 3    /* NV:  valid points inside the grid (rows of pnet_inp)          */
+#define LIDF_FC_VALID_PIX 4   /* NV0: valid pixels                                             */
+#define LIDF_FC_VALID_SEL 5   /* NVS: valid points kept by valid_stride                        */
+#define LIDF_FC_PNET_REFINE 6 /* NV + R: points of the stage-2 PointNet                        */
+#define LIDF_FC_OVERFLOW 7    /* bit 0: pairs cut at max_pairs                                 */
+typedef struct LidfFrameArgs {
+    int32_t batch, height, width;
+    /* the batch (datasets/cleargrasp_dataset.py:165-180 keys), device, f32 */
+    const float* rgb;          /* [B,3,h,w]                                                       */
+    const float* xyz_corrupt;  /* [B,3,h,w]                                                       */
+    const float* valid_mask;   /* [B,h,w] non-zero = the pixel's measured point is used (mask_type
+                                  'all': depth_corrupt itself — valid <=> depth_corrupt != 0)     */
+    const float* miss_mask;    /* [B,h,w] non-zero = query this pixel (pred_mask); NULL = every pixel */
+    const float* intr;         /* [B,4] fx, fy, cx, cy                                            */
+    const float* feat_grid;    /* [B,32,h,w] full_rgb_feat                                        */
+    /* voxel grid (LIDF.get_occ_vox_bound): lower corner already widened by half a voxel          */
+    float xmin[3];
+    int32_t res[3];
+    float part_size;
+    int32_t valid_stride;      /* >= 1: every valid_stride-th valid pixel feeds the voxels        */
+    /* stage 1 */
+    const LidfPointNet* pnet;  /* ->packed mandatory                                              */
+    const LidfDecoder* prob;
+    const LidfDecoder* off;
+    const void* packed_query;  /* lidf_query_pack(_guarded)_f32 blob, f32 precision               */
+    int32_t multires, multires_views, roi_inp_bbox, pos_rel;
+    float offset_range0, offset_range1;
+    /* stage 2 (refine_times == 0: skipped) */
+    int32_t refine_times;
+    const LidfPointNet* pnet_refine;   /* ->packed mandatory                                      */
+    const LidfDecoder* off_refine;
+    const void* packed_refine;         /* lidf_refine_pack(_guarded)_f32 blob                     */
+    int32_t refine_pos_rel, refine_pnet_pos_rel, refine_use_all_pix;
+    float refine_offset_range0, refine_offset_range1;
+    /* capacities */
+    int64_t max_pairs;
+    int32_t lds_voxels;        /* bound of the PointNet's fast pooling path (<= 288; frames with more
+                                  occupied voxels take global atomic maxima); 0 = 128            */
+    /* outputs (device; capacity in brackets: N = batch*height*width, C = batch*res0*res1*res2)   */
+    int32_t* counts;           /* [LIDF_FRAME_COUNTS]                                             */
+    int32_t *valid_bid, *valid_flat;       /* [N]   image / flat pixel of the selected valid points */
+    float *valid_xyz, *valid_rgb;          /* [N,3]                                               */
+    int32_t* occ_bid_coord;                /* [C,4] (bid, x, y, z) of the occupied voxels          */
+    float* voxel_bound;                    /* [C,6]                                               */
+    int32_t *valid_v_pid, *revidx;         /* [N + N] in-grid points: index into the selected points,
+                                              voxel; revidx has room for the N predicted points of
+                                              stage 2 behind the valid ones                        */
+    float* valid_v_rel_coord;              /* [N,3]                                               */
+    float* pnet_inp;                       /* [N + N, 6] cat(rel coord, rgb) (+ stage-2 rows)      */
+    float* occ_voxel_feat;                 /* [C,128]                                             */
+    int32_t *ray_bid, *ray_flat, *ray_pix; /* [N], [N], [N,2]                                      */
+    float* ray_dir;                        /* [N,3]                                               */
+    int32_t* pair_off;                     /* [N+1]                                               */
+    int32_t *pair_ray, *pair_vox;          /* [max_pairs]                                         */
+    float* pair_t;                         /* [max_pairs,2]                                       */
+    float *pred_offset, *pred_prob, *pred_prob_softmax; /* [max_pairs]                            */
+    float* pair_pred_pos;                  /* [max_pairs,3]                                       */
+    int64_t* max_pair_id;                  /* [N]                                                 */
+    float* pred_pos;                       /* [N,3]                                               */
+    float* rayfeat;                        /* [N, 128 + 3 + 6*multires_views]                     */
+    float* pred_depth;                     /* [B,h,w] xyz_corrupt z with the rays' pixels replaced */
+    float* pred_pos_refine;                /* [N,3]   (refine_times > 0)                          */
+    int32_t* end_voxel_id;                 /* [N]                                                 */
+    float* pred_depth_refine;              /* [B,h,w]                                             */
+    void* workspace;
+    size_t workspace_bytes;
+} LidfFrameArgs;
+size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, const int32_t* res,
+                                  int64_t max_pairs, int32_t lds_voxels, int32_t refine_times);
+int lidf_frame_f32(const LidfFrameArgs* args, lidf_stream_t stream);
+
 /* ---- Eval depth metrics ----------------------------------------------------------------------
  * Replaces the bs == 1 evaluation branch of LIDF.compute_loss (models/pipeline.py:577-627): the
  * predicted depth map, the ground-truth depth map and the segmentation mask ([src_h, src_w],

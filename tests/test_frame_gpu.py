@@ -1,0 +1,166 @@
+"""The evaluation path of a batch of frames as ONE library call without a host round trip
+(lidf_frame_f32 / pipeline.FrameRunner, device-side list lengths, capacity-sized buffers, HIP graph
+replay) against the stepwise path (pipeline.lidf_forward + refine_forward, which reads every size on
+the host and is itself checked against the oracle chain in test_e2e_gpu.py) and against the oracle."""
+import pytest
+import torch
+
+from util import TOL, make_module, make_pointnet, orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _models(cuda):
+    from implicit_depth_amd.synthetic import init_decoder_params
+    pnet = make_pointnet(orc.init_pointnet(3, 1.5), cuda)
+    pnet_r = make_pointnet(orc.init_pointnet(4, 1.5), cuda)
+    prob = make_module("IMNET", init_decoder_params("IMNET", 385, 7, 5.0), 385, cuda)
+    off = make_module("IEF", init_decoder_params("IEF", 385, 8, 5.0), 385, cuda)
+    offr = make_module("IEF", init_decoder_params("IEF", 334, 9, 5.0), 334, cuda)
+    return pnet, prob, off, pnet_r, offr
+
+
+SAME = ("voxel_bound", "valid_v_rel_coord", "miss_ray_dir", "pair_t", "pnet_inp", "occ_voxel_feat",
+        "pred_offset", "pred_prob_end", "pair_pred_pos", "pred_prob_end_softmax", "pred_pos", "rayfeat",
+        "pred_depth", "pred_pos_refine", "pred_depth_refine")
+SAME_INT = ("occ_vox_bid", "revidx", "valid_v_pid", "ray_bid", "ray_flat", "ray_pix", "pair_off", "pair_ray",
+            "pair_vox", "max_pair_id", "end_voxel_id")
+
+
+def _stepwise(batch, feat, models, opt):
+    from implicit_depth_amd import pipeline as pl
+    pnet, prob, off, pnet_r, offr = models
+    with torch.no_grad():
+        ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt)
+        if ok:
+            pl.refine_forward(dd, pnet_r, offr, opt)
+    return ok, dd
+
+
+def _compare(dd, ref):
+    for k in SAME:
+        assert torch.equal(dd[k], ref[k]), k                 # the same kernels on the same lists: bit-equal
+    for k in SAME_INT:
+        assert torch.equal(dd[k].long(), ref[k].long()), k
+
+
+@pytest.mark.parametrize("shape,stride,use_all_pix,graph", [((1, 240, 320), 6, True, True),
+                                                            ((1, 240, 320), None, True, False),
+                                                            ((2, 48, 64), None, False, True),
+                                                            ((4, 60, 80), 3, True, False)])
+def test_frame_equals_stepwise_path(cuda, shape, stride, use_all_pix, graph):
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = shape
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=stride, refine_use_all_pix=use_all_pix)
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+    batch, feat = synthetic_batch(B, h, w, seed=77)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    with torch.no_grad():
+        runner.load(batch, feat)
+        if graph:
+            runner.capture()
+        runner.run()
+    ok, dd = runner.result()
+    ok_ref, ref = _stepwise(batch, feat, models, opt)
+    assert ok and ok_ref
+    c = dd["counts"]
+    assert (c["R"], c["P"], c["V"]) == (ref["miss_ray_dir"].shape[0], ref["pair_ray"].shape[0],
+                                        ref["voxel_bound"].shape[0])
+    assert c["NV"] == ref["revidx"].shape[0] and c["NPN"] == c["NV"] + c["R"] and c["OVERFLOW"] == 0
+    _compare(dd, ref)
+    # a second, different batch through the same runner (and the same graph): nothing stale
+    batch2, feat2 = synthetic_batch(B, h, w, seed=78, hole_frac=1.3)
+    batch2, feat2 = _dev(batch2, cuda), feat2.to(cuda)
+    with torch.no_grad():
+        runner.run(batch2, feat2)
+    ok2, dd2 = runner.result()
+    ok_ref2, ref2 = _stepwise(batch2, feat2, models, opt)
+    assert ok2 and ok_ref2 and dd2["counts"]["P"] != c["P"]
+    _compare(dd2, ref2)
+    m = runner.metrics(batch2)
+    m_ref = pl.eval_metrics(ref2, "pred_depth_refine")
+    for k in m_ref:
+        assert float(m[k]) == float(m_ref[k]) or (m[k] != m[k] and m_ref[k] != m_ref[k]), k
+
+
+def test_frame_vs_oracle_and_reference_dtypes(cuda):
+    """The frame path straight against the oracle chain on a small frame (geometry exact, predictions
+    within 1e-4), with the reference's int64 index tensors."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import init_decoder_params, synthetic_batch
+    B, h, w = 2, 48, 64
+    batch, feat = synthetic_batch(B, h, w, seed=77)
+    pnet_p = orc.init_pointnet(3, 1.5)
+    prob_p, off_p = init_decoder_params("IMNET", 385, 7, 5.0), init_decoder_params("IEF", 385, 8, 5.0)
+    ok_ref, ref = orc.lidf_forward(batch, feat, pnet_p, prob_p, off_p)
+    assert ok_ref
+    pnet = make_pointnet(pnet_p, cuda)
+    prob, off = make_module("IMNET", prob_p, 385, cuda), make_module("IEF", off_p, 385, cuda)
+    runner = pl.FrameRunner(B, h, w, cuda, pnet, prob, off)
+    with torch.no_grad():
+        runner.run(_dev(batch, cuda), feat.to(cuda))
+    ok, dd = runner.result(reference_dtypes=True)
+    assert ok and dd["miss_bid"].dtype == torch.int64 and "pred_pos_refine" not in dd
+    assert (dd["voxel_bound"].cpu() == ref["voxel_bound"]).all()
+    assert (dd["revidx"].cpu() == ref["revidx"]).all() and (dd["valid_v_pid"].cpu() == ref["valid_v_pid"]).all()
+    assert (dd["valid_v_rel_coord"].cpu() == ref["valid_v_rel_coord"]).all()
+    assert (dd["miss_flat_img_id"].cpu() == ref["miss_flat_img_id"]).all()
+    assert (dd["pair_ray"].cpu().long() == ref["pair_ray"]).all()
+    assert (dd["pair_vox"].cpu().long() == ref["pair_vox"]).all()
+    assert (dd["occ_voxel_feat"].cpu() - ref["occ_voxel_feat"]).abs().max().item() <= 2e-5
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert (dd[k].cpu() - ref[k]).abs().max().item() <= TOL, k
+    same = dd["max_pair_id"].cpu() == ref["max_pair_id"]
+    assert (~same).sum().item() <= 2
+    assert (dd["pred_depth"].cpu() - ref["pred_depth"]).abs().reshape(-1)[same].mean().item() <= TOL
+
+
+def test_frame_pred_mask_early_exits_and_overflow(cuda):
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 24, 32
+    models = _models(cuda)
+    batch, feat = synthetic_batch(B, h, w, seed=5)
+    b, feat = _dev(batch, cuda), feat.to(cuda)
+    # mask_type 'pred': rays only where the predicted mask is set, valid points elsewhere
+    opt = pl.LidfOptions(mask_type="pred")
+    pm = (torch.rand(B, h, w, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(cuda)
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+    with torch.no_grad():
+        runner.run(b, feat, pm)
+        ok, dd = runner.result()
+        ok_ref, ref = pl.lidf_forward(b, feat, models[0], models[1], models[2], opt, pred_mask=pm)
+        pl.refine_forward(ref, models[3], models[4], opt)
+    assert ok and ok_ref and dd["counts"]["R"] == int(pm.sum().item())
+    _compare(dd, ref)
+    with torch.no_grad():
+        # no miss ray (pipeline.py:686-687)
+        runner.run(b, feat, torch.zeros(B, h, w, device=cuda))
+        ok, dd = runner.result()
+        assert not ok and dd["counts"]["R"] == 0 and dd["counts"]["P"] == 0
+        # no occupied voxel (:671-672): every point outside the grid
+        far = dict(b)
+        far["xyz_corrupt"] = b["xyz_corrupt"] + 50.0
+        runner.run(far, feat, pm)
+        ok, dd = runner.result()
+        assert not ok and dd["counts"]["V"] == 0 and dd["counts"]["P"] == 0 and dd["counts"]["NV"] == 0
+        # and a good frame again through the same buffers
+        runner.run(b, feat, pm)
+        ok, dd = runner.result()
+        assert ok
+        _compare(dd, ref)
+    # a pair list longer than its capacity is cut and flagged, never written out of bounds
+    small = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], pl.LidfOptions(), max_pairs=100)
+    with torch.no_grad():
+        small.run(b, feat)
+    assert small.counts()["OVERFLOW"] == 1 and small.counts()["P"] == 100
+    with pytest.raises(RuntimeError, match="max_pairs"):
+        small.result()
+    with pytest.raises(RuntimeError, match="inference path"):
+        small.run(b, feat)                                  # autograd recording: refused
