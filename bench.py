@@ -385,11 +385,15 @@ def secondary(args):
 
 
 def e2e(args):
-    """--workload e2e: the whole evaluation path of one frame, chained on the device
-    (implicit_depth_amd.pipeline): valid points -> occupied voxels -> PointNet2Stage -> miss rays ->
-    compact ray/voxel pairs -> fused query -> 2 x get_pred_refine -> eval metrics, on a ragged
-    geometry-derived frame (synthetic_batch). Host syncs included (sizes of compacted lists, as the
-    reference's nonzero()/unique() have). Secondary record, same schema."""
+    """--workload e2e: the whole evaluation path of a batch of frames on a ragged geometry-derived
+    scene (synthetic_batch): valid points -> occupied voxels -> PointNet2Stage -> miss rays -> compact
+    ray/voxel pairs -> fused query -> 2 x get_pred_refine -> eval metrics. Secondary record, same schema.
+      --e2e-mode frame (default)  pipeline.FrameRunner: ONE library call per batch (lidf_frame_f32),
+                                  list lengths stay on the device, no host round trip inside the step
+      --e2e-mode graph            the same call captured in a HIP graph and replayed
+      --e2e-mode stepwise         pipeline.lidf_forward + refine_forward: one call per reference method,
+                                  every list sized on the host (four syncs per frame, as the reference's
+                                  nonzero()/unique() have)"""
     from implicit_depth_amd import IEF, IMNet, PointNet2Stage, pipeline as pl
     from implicit_depth_amd.synthetic import init_decoder_params, synthetic_batch
     dev = torch.device("cuda", 0)
@@ -411,18 +415,37 @@ def e2e(args):
     n_valid = int((batch["depth_corrupt"] != 0).sum().item())
     opt = pl.LidfOptions(valid_stride=max(1, n_valid // (10000 * B)))
     state = {"ws": None}
-
-    def step(marks=None):
+    mode = args.e2e_mode
+    if mode != "stepwise" and args.precision != "f32":
+        raise SystemExit("--e2e-mode %s is f32 only (use --e2e-mode stepwise for f16x3)" % mode)
+    stages = {}
+    if mode == "stepwise":
+        def step(marks=None):
+            with torch.no_grad():
+                ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=args.precision,
+                                         workspace=state["ws"], marks=marks)
+                assert ok
+                state["ws"] = dd["workspace"]
+                pl.refine_forward(dd, pnet_r, offr, opt, precision=args.precision)
+                pl._mark(marks, "refine_x2")
+                m = pl.eval_metrics(dd, "pred_depth_refine")
+                pl._mark(marks, "metrics")
+            return dd, m
+    else:
+        runner = pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr)
         with torch.no_grad():
-            ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=args.precision,
-                                     workspace=state["ws"], marks=marks)
-            assert ok
-            state["ws"] = dd["workspace"]
-            pl.refine_forward(dd, pnet_r, offr, opt, precision=args.precision)
-            pl._mark(marks, "refine_x2")
-            m = pl.eval_metrics(dd, "pred_depth_refine")
-            pl._mark(marks, "metrics")
-        return dd, m
+            runner.load(batch, feat)
+            if mode == "graph":
+                runner.capture()
+
+        def step(marks=None):
+            with torch.no_grad():
+                pl._mark(marks, "start")
+                runner.run(batch, feat)          # input copies + the frame (+ graph replay)
+                pl._mark(marks, "frame")
+                m = runner.metrics(batch)
+                pl._mark(marks, "metrics")
+            return None, m
 
     for _ in range(args.warmup):
         step()
@@ -435,11 +458,18 @@ def e2e(args):
         all_marks.append(mk)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    stages = {}
     for mk in all_marks:
         for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
-    P, R = int(dd["pair_ray"].shape[0]), int(dd["miss_ray_dir"].shape[0])
+    if mode == "stepwise":
+        P, R = int(dd["pair_ray"].shape[0]), int(dd["miss_ray_dir"].shape[0])
+        V, NV = int(dd["voxel_bound"].shape[0]), int(dd["valid_xyz"].shape[0])
+        syncs = "4 host size reads per frame"
+    else:
+        c = runner.counts()                      # the one size read, after the timed region
+        assert not c["OVERFLOW"]
+        P, R, V, NV = c["P"], c["R"], c["V"], c["NVS"]
+        syncs = "none inside the step (list lengths stay on the device)"
     emit({
         "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -449,8 +479,10 @@ def e2e(args):
         "config": {"workload": "secondary: whole evaluation path of %d 240x320 frame(s): valid points, "
                                "occupied voxels, PointNet2Stage, miss rays, compact ray/voxel pairs, fused "
                                "query, 2 x get_pred_refine, eval metrics; geometry-derived ragged scene" % B,
+                   "mode": mode, "host_syncs": syncs,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
-                   "voxels": int(dd["voxel_bound"].shape[0]), "valid_points": int(dd["valid_xyz"].shape[0])},
+                   "voxels": V, "valid_points": NV},
+        "ms_per_frame": round(elapsed / args.steps * 1e3 / B, 4),
         "frames_per_s": round(B * args.steps / elapsed, 2),
         "rays_per_s": round(R * args.steps / elapsed, 1),
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
@@ -497,6 +529,9 @@ def main():
                          "default and what configs[2]/[4] describe); rays = ONE frame, image rows split "
                          "over the ranks (strong scaling, SURVEY 8e for fewer frames than GPUs), depth rows "
                          "all-gathered")
+    ap.add_argument("--e2e-mode", default="frame", choices=["frame", "graph", "stepwise"],
+                    help="--workload e2e: frame = one sync-free library call per batch (default), graph = "
+                         "that call replayed from a HIP graph, stepwise = one call per reference method")
     ap.add_argument("--workload", default="query",
                     choices=["query", "query+refine", "decoders", "embed", "train", "train-query", "e2e"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "

@@ -154,6 +154,16 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+extern "C" hipError_t lidf_launch_zero_segments(float* const* ptrs, const long long* counts, int n,
+                                                hipStream_t st);
+// Zero up to two buffers of 4-byte words with ONE kernel launch (the frame path: a kernel node of a
+// captured graph instead of memset nodes, and one launch where hipMemsetAsync would be one per buffer).
+static hipError_t zero_words(void* a, size_t words_a, void* b, size_t words_b, hipStream_t st) {
+    float* ptrs[2] = {(float*)a, (float*)b};
+    const long long cnt[2] = {(long long)words_a, (long long)words_b};
+    return lidf_launch_zero_segments(ptrs, cnt, 2, st);
+}
+
 // Guarded packing (lidf_*_pack_guarded_f32): the guard of the API call in progress on this thread;
 // every pack launch below it carries the pointer and returns at once when the fingerprint of the
 // parameters did not change. Set and cleared inside one API call (no state survives the call).
@@ -639,7 +649,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
             a.tile_counter = (int*)(ws + w.counter);   // dynamic tile hand-out of both kernels
-            CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
+            if (dims) CHECK_HIP(zero_words(a.tile_counter, 1, nullptr, 0, st));   // (a kernel node in a captured graph)
+            else CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
 #ifdef LIDF_PROFILE
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif
@@ -1243,8 +1254,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
     float* gpart = (float*)(ws + f.gpart);
     float* pool2 = (float*)(ws + f.pool2);
     float* part = (float*)(ws + f.part);
-    CHECK_HIP(hipMemsetAsync(pool1, 0, (size_t)V_cap * 64 * 4, st));
-    CHECK_HIP(hipMemsetAsync(pool2, 0, (size_t)V_cap * 128 * 4, st));
+    CHECK_HIP(zero_words(pool1, (size_t)V_cap * 64, pool2, (size_t)V_cap * 128, st));
     CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, part, V_cap, v_lds, n_cap,
                                              n_dev, V_dev, cus, st));
     if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, V_cap, nullptr, nullptr, 1, g1, 64,
@@ -1355,7 +1365,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     const long long hw = (long long)h * w;
 
     // 1. valid points, rays, depth map, voxel marks: three launches over the pixels
-    CHECK_HIP(hipMemsetAsync(cell_flag, 0, (size_t)C * 4, st));
+    CHECK_HIP(zero_words(cell_flag, (size_t)C, nullptr, 0, st));
     CHECK_HIP(lidf_launch_frame_head(a->valid_mask, a->miss_mask, a->xyz_corrupt, a->rgb, a->intr, B, h, w,
                                      a->valid_stride, g, (int*)(ws + f.blk_valid), (int*)(ws + f.blk_miss),
                                      counts, a->valid_bid, a->valid_flat, a->valid_xyz, a->valid_rgb,

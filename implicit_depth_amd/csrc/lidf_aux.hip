@@ -328,6 +328,8 @@ extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int
                                               const float* ray_dir, const int* ray_pix,
                                               const int* ray_bid, long long R, const int* R_dev,
                                               int half, int Lv, float* out, int ld, hipStream_t st);
+extern "C" hipError_t lidf_launch_zero_segments(float* const* ptrs, const long long* counts, int n,
+                                                hipStream_t st);
 extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, int H, int W,
                                           const float* ray_dir, const int* ray_pix,
                                           const int* ray_bid, long long R, int half, int Lv,
@@ -353,7 +355,14 @@ extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int
             hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                st, feat, B * 32, H, W, half, box);
         border = (int*)(box + total);
-        hipError_t e = hipMemsetAsync(border, 0, 4, st);
+        hipError_t e;
+        if (R_dev) {   // the frame path: a kernel node in a captured graph
+            float* zp[1] = {(float*)border};
+            const long long zc[1] = {1};
+            e = lidf_launch_zero_segments(zp, zc, 1, st);
+        } else {
+            e = hipMemsetAsync(border, 0, 4, st);
+        }
         if (e != hipSuccess) return e;
     }
     const int ts = 128 + 3 + 6 * Lv + ((3 + 6 * Lv) & 1 ? 0 : 1);

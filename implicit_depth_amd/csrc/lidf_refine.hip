@@ -21,6 +21,8 @@ extern "C" hipError_t lidf_launch_refine_rows_dev(const float*, const int*, cons
 extern "C" hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float,
                                                     long long, const int*, float*, const int*, const int*,
                                                     long long, float*, hipStream_t);
+extern "C" hipError_t lidf_launch_zero_segments(float* const* ptrs, const long long* counts, int n,
+                                                hipStream_t st);
 
 // One thread per ray:
 //   end_voxel = max( voxel of the arg-max pair (0 for a ray without pairs: the dummy row,
@@ -176,7 +178,14 @@ extern "C" hipError_t lidf_launch_refine_prep_dev(const float* pred_pos, const l
                                                   const unsigned char* pnet_select, const int* dims,
                                                   const int* row0_dev, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
+    hipError_t e;
+    if (dims) {   // the frame path: a kernel node in a captured graph
+        float* zp[1] = {(float*)end_voxel};
+        const long long zc[1] = {R};
+        e = lidf_launch_zero_segments(zp, zc, 1, st);
+    } else {
+        e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
+    }
     if (e != hipSuccess) return e;
     // slices of at least 64 voxels, enough of them for ~8 wavefronts per SIMD
     const long long waves = (R + 63) / 64;
