@@ -66,7 +66,7 @@ hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int
                                        long long, int, long long, float*, int*, int*,
                                        const unsigned char*, const int*, const int*, hipStream_t);
 hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int, int, int,
-                                       int, long long, const int*, float*, int, hipStream_t);
+                                       int, long long, const int*, float*, int, int, hipStream_t);
 hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float, long long,
                                          const int*, float*, const int*, const int*, long long, float*,
                                          hipStream_t);
@@ -176,6 +176,33 @@ static inline StreamLayout guarded(StreamLayout lay) {
     lay.guard = tl_guard;
     return lay;
 }
+// Pack-only API calls collect the streams of a module and pack them with one launch per
+// LIDF_PACK_JOBS streams (lidf_pack_multi_kernel) instead of one launch per stream.
+extern "C" hipError_t lidf_launch_pack_multi(const PackJobs&, hipStream_t);
+extern "C" hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
+                                       float*, hipStream_t);
+static thread_local PackJobs* tl_jobs = nullptr;
+static hipError_t flush_jobs(PackJobs& j, hipStream_t st) {
+    const hipError_t e = lidf_launch_pack_multi(j, st);
+    j.n = 0;
+    return e;
+}
+static hipError_t pack_stream(const StreamLayout& lay, const NetW& n0, const NetW& n1, const L1Map& m,
+                              float* stream, float* aux, hipStream_t st) {
+    if (!tl_jobs) return lidf_launch_pack(guarded(lay), n0, n1, m, stream, aux, st);
+    if (tl_jobs->n == LIDF_PACK_JOBS) {
+        const hipError_t e = flush_jobs(*tl_jobs, st);
+        if (e != hipSuccess) return e;
+    }
+    PackJob& k = tl_jobs->job[tl_jobs->n++];
+    k.lay = guarded(lay); k.n0 = n0; k.n1 = n1; k.m = m; k.stream = stream; k.aux = aux;
+    return hipSuccess;
+}
+struct JobScope {   // collects until destroyed; the owner flushes explicitly (flush_jobs) before leaving
+    PackJobs jobs;
+    JobScope() { jobs.n = 0; tl_jobs = &jobs; }
+    ~JobScope() { tl_jobs = nullptr; }
+};
 static inline unsigned long long salt_mix(unsigned long long h, unsigned long long v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
     h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -450,18 +477,15 @@ static int pack_query_weights(const LidfDecoder* prob, const LidfDecoder* off, i
     if (split)
         CHECK_HIP(lidf_launch_pack_h(guarded(lidf_make_layout_h(2, mf)), np, no, mf, stream_pts, aux_pts, st));
     else
-        CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_FUSED, mf)), np, no, mf, stream_pts,
-                                   aux_pts, st));
+        CHECK_HIP(pack_stream(lidf_make_layout(2, LIDF_MODE_FUSED, mf), np, no, mf, stream_pts, aux_pts, st));
     L1Map mv = rows_map(128, 0, 0, 0, 1);  // voxel part carries b1 (+ IEF constant)
-    CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_L1ONLY, mv)), np, no, mv, stream_vox,
-                               aux_pts, st));
+    CHECK_HIP(pack_stream(lidf_make_layout(2, LIDF_MODE_L1ONLY, mv), np, no, mv, stream_vox, aux_pts, st));
     L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);  // rgb ROI columns + direction embedding
     if (split)
         CHECK_HIP(lidf_launch_pack_rows_h(guarded(lidf_make_layout_rows_h(2, mr.D, 1)), np, no, mr, stream_ray,
                                           nullptr, st));
     else
-        CHECK_HIP(lidf_launch_pack(guarded(lidf_make_layout(2, LIDF_MODE_L1ONLY, mr)), np, no, mr, stream_ray,
-                                   aux_pts, st));
+        CHECK_HIP(pack_stream(lidf_make_layout(2, LIDF_MODE_L1ONLY, mr), np, no, mr, stream_ray, aux_pts, st));
     return LIDF_OK;
 }
 
@@ -489,8 +513,12 @@ LIDF_API int lidf_query_pack_f32(const LidfDecoder* prob, const LidfDecoder* off
     if (rc) return rc;
     if (!packed || packed_bytes < query_ws(1, 1, multires, multires_views).packed_end)
         return LIDF_ERR_WORKSPACE;
-    return pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
-                              (hipStream_t)stream);
+    JobScope js;
+    if ((rc = pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
+                                 (hipStream_t)stream)))
+        return rc;
+    CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
+    return LIDF_OK;
 }
 
 LIDF_API size_t lidf_pack_guard_bytes(void) { return align_up(sizeof(LidfPackGuardState), 64); }
@@ -531,8 +559,12 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
     CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, k, salt, (LidfPackGuardState*)guard,
                                       (hipStream_t)stream));
     GuardScope scope((const LidfPackGuardState*)guard);
-    return pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
-                              (hipStream_t)stream);
+    JobScope js;
+    if ((rc = pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
+                                 (hipStream_t)stream)))
+        return rc;
+    CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
+    return LIDF_OK;
 }
 
 // dims (optional): device int32 {R, P, V} — the sync-free frame path. n_rays / n_pairs / n_vox of `q`
@@ -649,8 +681,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.part_size = q->part_size;
             a.pair_pred_pos = q->pair_pred_pos;
             a.tile_counter = (int*)(ws + w.counter);   // dynamic tile hand-out of both kernels
-            if (dims) CHECK_HIP(zero_words(a.tile_counter, 1, nullptr, 0, st));   // (a kernel node in a captured graph)
-            else CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
+            // (the frame path zeroes the counter with its other scratch, in one launch up front)
+            if (!dims) CHECK_HIP(hipMemsetAsync(a.tile_counter, 0, 4, st));
 #ifdef LIDF_PROFILE
             a.out_base = rayfeat;  // development only: phase timers land in the rayfeat scratch
 #endif
@@ -943,7 +975,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.is_ief = 0; nw.dcore = L.ldw;
-    if (!prepacked) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, nullptr, st));
+    if (!prepacked) CHECK_HIP(pack_stream(lay, nw, nw, m, stream_buf, nullptr, st));
     if (pack_only) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = X; a.ldx = ldx; a.n = n;
@@ -1099,7 +1131,10 @@ LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t 
     b.chain = (float*)((char*)packed + ws.chain);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
-    return pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1);
+    JobScope js;
+    if ((rc = pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1))) return rc;
+    CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
+    return LIDF_OK;
 }
 
 LIDF_API int lidf_pointnet_pack_guarded_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
@@ -1238,6 +1273,7 @@ static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds) {
     w.total = o;
     return w;
 }
+// (pool1 / pool2 of `ws` must be zero on entry: frame_zero_pools, merged with the caller's other scratch)
 static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_cap,
                           const int* n_dev, int64_t V_cap, int v_lds, const int* V_dev, float* out,
                           char* ws, int cus, hipStream_t st) {
@@ -1254,7 +1290,6 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
     float* gpart = (float*)(ws + f.gpart);
     float* pool2 = (float*)(ws + f.pool2);
     float* part = (float*)(ws + f.part);
-    CHECK_HIP(zero_words(pool1, (size_t)V_cap * 64, pool2, (size_t)V_cap * 128, st));
     CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, part, V_cap, v_lds, n_cap,
                                              n_dev, V_dev, cus, st));
     if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, V_cap, nullptr, nullptr, 1, g1, 64,
@@ -1364,8 +1399,20 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     g.B = B;
     const long long hw = (long long)h * w;
 
+    // 0. every zero-initialised scratch of stage 1 in ONE launch: voxel marks, the max-pool tables of the
+    //    PointNet, the clamped-box list length and the tile counter of the query
+    const PnetFrameWs pf = pnet_frame_ws(C, v_lds);
+    const int64_t grid_floats = (int64_t)B * 32 * h * w;
+    const QueryWs qw = query_ws(N, C, a->multires, a->multires_views, grid_floats);
+    float* pool1 = (float*)(ws + f.pnet + pf.pool1);
+    float* pool2 = (float*)(ws + f.pnet + pf.pool2);
+    {
+        float* zp[5] = {(float*)cell_flag, pool1, pool2, (float*)(ws + f.query + qw.counter),
+                        (float*)(ws + f.query + qw.box) + grid_floats};
+        const long long zc[5] = {(long long)C, (long long)C * 64, (long long)C * 128, 1, 1};
+        CHECK_HIP(lidf_launch_zero_segments(zp, zc, 5, st));
+    }
     // 1. valid points, rays, depth map, voxel marks: three launches over the pixels
-    CHECK_HIP(zero_words(cell_flag, (size_t)C, nullptr, 0, st));
     CHECK_HIP(lidf_launch_frame_head(a->valid_mask, a->miss_mask, a->xyz_corrupt, a->rgb, a->intr, B, h, w,
                                      a->valid_stride, g, (int*)(ws + f.blk_valid), (int*)(ws + f.blk_miss),
                                      counts, a->valid_bid, a->valid_flat, a->valid_xyz, a->valid_rgb,
@@ -1442,13 +1489,19 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     for (int it = 0; it < a->refine_times; ++it) {
         float* out = it == a->refine_times - 1 ? a->pred_pos_refine
                                                : (float*)(ws + ((it & 1) ? f.pos_b : f.pos_a));
+        {   // this iteration's zero-initialised scratch in one launch: end voxels + the max-pool tables
+            float* zp[3] = {(float*)a->end_voxel_id, pool1, pool2};
+            const long long zc[3] = {(long long)N, (long long)C * 64, (long long)C * 128};
+            CHECK_HIP(lidf_launch_zero_segments(zp, zc, 3, st));
+        }
         CHECK_HIP(lidf_launch_refine_prep_dev(cur, (const long long*)a->max_pair_id, a->pair_vox, a->max_pairs,
                                               a->voxel_bound, vox_bid, C, a->ray_bid, a->ray_flat, a->rgb, hw,
                                               a->refine_pnet_pos_rel, N, pn_inp, a->revidx, a->end_voxel_id,
                                               sel, counts, counts + LIDF_FC_VALID_IN, st));
+        // (the ROI and direction columns of a ray's row do not change between the iterations)
         CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
-                                              inp_embed, D, st));
+                                              inp_embed, D, it == 0 ? 0 : 1, st));
         if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
                                  v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st)))
             return rc;
@@ -1575,7 +1628,7 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.dcore ? L.dcore : L.k; nw.is_ief = 0;
     if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
-    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, nullptr, st));
+    if (pack_mode != 2) CHECK_HIP(pack_stream(lay, nw, nw, m, stream_buf, nullptr, st));
     if (pack_mode == 1) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
@@ -1619,7 +1672,7 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     float* stream_buf = (float*)sbuf;
     float* aux = (float*)(sbuf + align_up((size_t)lay.total * 4, 256));
     const NetW nw = to_netw(dec, dcore);
-    if (pack_mode != 2) CHECK_HIP(lidf_launch_pack(guarded(lay), nw, nw, m, stream_buf, aux, st));
+    if (pack_mode != 2) CHECK_HIP(pack_stream(lay, nw, nw, m, stream_buf, aux, st));
     if (pack_mode == 1) return LIDF_OK;
     PointsArgs a = {};
     a.stream = stream_buf; a.aux = aux; a.nets = 1;
@@ -1673,8 +1726,12 @@ LIDF_API int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int3
     if (!need) return LIDF_ERR_UNSUPPORTED;
     if (!packed || packed_bytes < need) return LIDF_ERR_WORKSPACE;
     const int D = 256 + 3 + 6 * multires + 3 + 6 * multires_views;
-    return refine_ief_factorised(off, D, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
-                                 (char*)packed, (hipStream_t)stream, 1);
+    JobScope js;
+    if ((rc = refine_ief_factorised(off, D, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
+                                    (char*)packed, (hipStream_t)stream, 1)))
+        return rc;
+    CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
+    return LIDF_OK;
 }
 
 LIDF_API int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multires,

@@ -355,15 +355,11 @@ extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int
             hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                st, feat, B * 32, H, W, half, box);
         border = (int*)(box + total);
-        hipError_t e;
-        if (R_dev) {   // the frame path: a kernel node in a captured graph
-            float* zp[1] = {(float*)border};
-            const long long zc[1] = {1};
-            e = lidf_launch_zero_segments(zp, zc, 1, st);
-        } else {
-            e = hipMemsetAsync(border, 0, 4, st);
+        // (the frame path — R_dev — zeroes the list length with its other scratch, in one launch up front)
+        if (!R_dev) {
+            hipError_t e = hipMemsetAsync(border, 0, 4, st);
+            if (e != hipSuccess) return e;
         }
-        if (e != hipSuccess) return e;
     }
     const int ts = 128 + 3 + 6 * Lv + ((3 + 6 * Lv) & 1 ? 0 : 1);
     hipLaunchKernelGGL(lidf_rayfeat_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64, 4),
@@ -1435,6 +1431,8 @@ struct FpSegs {
     const unsigned* p[LIDF_FP_MAX_SEGS];
     unsigned n[LIDF_FP_MAX_SEGS];      // words
     unsigned base[LIDF_FP_MAX_SEGS];   // index of the segment's first word in the concatenation
+    unsigned blk0[LIDF_FP_MAX_SEGS + 1];  // first workgroup of the segment (FP_WORDS words per workgroup)
+    int nseg;
 };
 
 __device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {
@@ -1444,23 +1442,30 @@ __device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
-#define FP_BLOCKS_PER_SEG 32
+#define FP_WORDS 4096   // per workgroup: 256 threads x 16 words, four loads in flight per thread
 
-__global__ void lidf_fingerprint_kernel(FpSegs s, unsigned long long salt, LidfPackGuardState* g) {
-    const int seg = blockIdx.y;
+__global__ void __launch_bounds__(256) lidf_fingerprint_kernel(FpSegs s, unsigned long long salt,
+                                                               LidfPackGuardState* g) {
+    int seg = 0;
+    for (int k = 1; k < LIDF_FP_MAX_SEGS; ++k) seg += (k < s.nseg && blockIdx.x >= s.blk0[k]) ? 1 : 0;
     const unsigned n = s.n[seg], base = s.base[seg];
     const unsigned* __restrict__ p = s.p[seg];
+    const unsigned w0 = (blockIdx.x - s.blk0[seg]) * FP_WORDS;
     unsigned long long acc = 0;
-    const unsigned stride = gridDim.x * blockDim.x;
-    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {   // four independent loads in flight
-        const unsigned w0 = p[i], w1 = p[i + stride], w2 = p[i + 2 * stride], w3 = p[i + 3 * stride];
-        acc += fp_mix(((unsigned long long)(base + i) << 32) | w0);
-        acc += fp_mix(((unsigned long long)(base + i + stride) << 32) | w1);
-        acc += fp_mix(((unsigned long long)(base + i + 2 * stride) << 32) | w2);
-        acc += fp_mix(((unsigned long long)(base + i + 3 * stride) << 32) | w3);
+#pragma unroll
+    for (int r = 0; r < FP_WORDS / 1024; ++r) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = w0 + (4 * r + j) * 256 + threadIdx.x;
+            w[j] = i < n ? p[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = w0 + (4 * r + j) * 256 + threadIdx.x;
+            if (i < n) acc += fp_mix(((unsigned long long)(base + i) << 32) | w[j]);
+        }
     }
-    for (; i < n; i += stride) acc += fp_mix(((unsigned long long)(base + i) << 32) | p[i]);
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned lo = __shfl_xor((unsigned)acc, o), hi = __shfl_xor((unsigned)(acc >> 32), o);
         acc += ((unsigned long long)hi << 32) | lo;
@@ -1472,7 +1477,7 @@ __global__ void lidf_fingerprint_kernel(FpSegs s, unsigned long long salt, LidfP
     if (threadIdx.x == 0) {
         atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
         __threadfence();
-        last = atomicAdd(&g->ticket, 1u) == gridDim.x * gridDim.y - 1;
+        last = atomicAdd(&g->ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
@@ -1491,14 +1496,18 @@ extern "C" hipError_t lidf_launch_fingerprint(const float* const* ptrs, const lo
                                               LidfPackGuardState* guard, hipStream_t st) {
     if (nseg <= 0 || nseg > LIDF_FP_MAX_SEGS) return hipErrorInvalidValue;
     FpSegs s = {};
-    unsigned base = 0;
+    unsigned base = 0, blk = 0;
     for (int i = 0; i < nseg; ++i) {
         s.p[i] = (const unsigned*)ptrs[i];
         s.n[i] = (unsigned)floats[i];
         s.base[i] = base;
+        s.blk0[i] = blk;
         base += s.n[i];
+        blk += (s.n[i] + FP_WORDS - 1) / FP_WORDS;
     }
-    hipLaunchKernelGGL(lidf_fingerprint_kernel, dim3(FP_BLOCKS_PER_SEG, nseg), dim3(256), 0, st, s,
-                       salt, guard);
+    s.blk0[nseg] = blk;
+    s.nseg = nseg;
+    if (blk == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lidf_fingerprint_kernel, dim3(blk), dim3(256), 0, st, s, salt, guard);
     return hipGetLastError();
 }

@@ -100,6 +100,20 @@ struct LidfPackGuardState {
     int pad;
 };
 
+// One stream to pack (lidf_pack_multi_kernel packs up to LIDF_PACK_JOBS of them per launch).
+#define LIDF_PACK_JOBS 4
+struct PackJob {
+    StreamLayout lay;
+    NetW n0, n1;
+    L1Map m;
+    float* stream;
+    float* aux;
+};
+struct PackJobs {
+    PackJob job[LIDF_PACK_JOBS];
+    int n;
+};
+
 static inline int lidf_l1_quads(int mode, const L1Map& m) {
     if (mode == LIDF_MODE_FUSED) return 24 * ((m.L + 1) / 2) + 8;
     return m.KQ1 * m.nt;
@@ -178,6 +192,7 @@ struct LinearArgs {
     const float* X;        // [n, D] rows, row stride ldx
     long long ldx, n;
     const int* n_dev;      // optional device-side row count overriding n (n = capacity of the launch)
+    int nt_total;          // set by the launcher: > 0 = launch split over the output tiles (grid.y)
     int D, has_bias;
     const float* addrows;  // optional: += addrows[addidx[row], 0:32*nt]
     const int* addidx;

@@ -26,8 +26,13 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     const int wave = threadIdx.x >> 6;
     const int h = lane >> 5;
     const int col = lane & 31;
+    // a.nt_total > 0: the launch is split over the output tiles (grid.y = tile; NT = 1): a layer over a
+    // handful of rows (the per-voxel layers of the PointNet: 74 rows x 256 outputs) is one wavefront's
+    // chain of NT x 4 matrix instructions per k-quad otherwise — 8 workgroups side by side instead
+    const int NTS = a.nt_total > 0 ? a.nt_total : NT;      // tiles per k-quad in the stream
+    const int T0 = a.nt_total > 0 ? (int)blockIdx.y : 0;   // first output tile of this workgroup
     const __amdgpu_buffer_rsrc_t srs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, a.kq1 * NT * 1024, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, a.kq1 * NTS * 1024, 0x00020000);
     const int vq = lane * 16;
     const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;   // device-side row count (frame path)
     const long long ntile = (AN + 127) / 128;
@@ -62,14 +67,14 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
         f32x4 qc[NT];
         load_b(0, bc);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) qc[t] = LDQ(srs, vq, t * 1024);
+        for (int t = 0; t < NT; ++t) qc[t] = LDQ(srs, vq, (T0 + t) * 1024);
         for (int kq = 0; kq < a.kq1; ++kq) {
             float bn[4] = {0.f, 0.f, 0.f, 0.f};
             f32x4 qn[NT];
             if (kq + 1 < a.kq1) load_b(kq + 1, bn);
             const int kn = kq + 1 < a.kq1 ? kq + 1 : kq;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) qn[t] = LDQ(srs, vq, (kn * NT + t) * 1024);
+            for (int t = 0; t < NT; ++t) qn[t] = LDQ(srs, vq, (kn * NTS + T0 + t) * 1024);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 c = acc[t];
@@ -101,12 +106,12 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * g + i];
                 if (ar) {
-                    const f32x4 r = *(const f32x4*)(ar + t * 32 + 8 * g);
+                    const f32x4 r = *(const f32x4*)(ar + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += r[i];
                 }
                 if (ar2) {
-                    const f32x4 r = *(const f32x4*)(ar2 + t * 32 + 8 * g);
+                    const f32x4 r = *(const f32x4*)(ar2 + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += r[i];
                 }
@@ -114,30 +119,30 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], a.slope * v[i]);
                 }
-                const int c0 = t * 32 + 8 * g + 4 * h;  // first of this lane's four columns
+                const int c0 = (T0 + t) * 32 + 8 * g + 4 * h;  // first of this lane's four columns
                 if (mp && (a.nout <= 0 || c0 + 3 < a.nout)) {
                     // dgrad through a leaky ReLU: the activation's output has the sign of its input
-                    const f32x4 m = *(const f32x4*)(mp + t * 32 + 8 * g);
+                    const f32x4 m = *(const f32x4*)(mp + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] *= m[i] > 0.f ? 1.f : a.mask_slope;
                 } else if (mp && c0 < a.nout) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (c0 + i < a.nout) v[i] *= mp[t * 32 + 8 * g + i] > 0.f ? 1.f : a.mask_slope;
+                        if (c0 + i < a.nout) v[i] *= mp[(T0 + t) * 32 + 8 * g + i] > 0.f ? 1.f : a.mask_slope;
                 }
                 if (op) {
                     if (a.nout <= 0 || c0 + 3 < a.nout) {
                         if (a.accumulate) {
-                            const f32x4 o = *(const f32x4*)(op + t * 32 + 8 * g);
+                            const f32x4 o = *(const f32x4*)(op + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] += o[i];
                         }
-                        *(f32x4*)(op + t * 32 + 8 * g) = v;
+                        *(f32x4*)(op + (T0 + t) * 32 + 8 * g) = v;
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (c0 + i < a.nout) {
-                                float* q = op + t * 32 + 8 * g + i;
+                                float* q = op + (T0 + t) * 32 + 8 * g + i;
                                 *q = a.accumulate ? *q + v[i] : v[i];
                             }
                     }
@@ -177,11 +182,11 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                             m[i] = x;
                         }
                         if (col == lead) {
-                            const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+                            const f32x4 seen = *(const f32x4*)(pp + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 if (m[i] > seen[i])
-                                    atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(m[i]));
+                                    atomicMax(pp + (T0 + t) * 32 + 8 * g + i, __float_as_int(m[i]));
                         }
                     }
                 }
@@ -192,11 +197,11 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 for (int t = 0; t < NT; ++t) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 seen = *(const f32x4*)(pp + t * 32 + 8 * g);
+                        const f32x4 seen = *(const f32x4*)(pp + (T0 + t) * 32 + 8 * g);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (acc[t][4 * g + i] > seen[i])
-                                atomicMax(pp + t * 32 + 8 * g + i, __float_as_int(acc[t][4 * g + i]));
+                                atomicMax(pp + (T0 + t) * 32 + 8 * g + i, __float_as_int(acc[t][4 * g + i]));
                     }
                 }
             }
@@ -204,8 +209,16 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     }
 }
 
-extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a, int grid, hipStream_t st) {
-    if (a.n <= 0) return hipSuccess;
+extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int grid, hipStream_t st) {
+    if (a_in.n <= 0) return hipSuccess;
+    LinearArgs a = a_in;
+    a.nt_total = 0;
+    const long long ntile = (a.n + 127) / 128;
+    if (nt > 1 && ntile <= 16) {   // few rows: one workgroup per (row tile, output tile)
+        a.nt_total = nt;
+        hipLaunchKernelGGL(lidf_linear_kernel<1>, dim3((unsigned)ntile, (unsigned)nt), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     dim3 g(grid), b(256);
     switch (nt) {
         case 1: hipLaunchKernelGGL(lidf_linear_kernel<1>, g, b, 0, st, a); break;

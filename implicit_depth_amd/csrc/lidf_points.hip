@@ -137,8 +137,8 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
     }
 }
 
-__global__ void lidf_pack_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m, float* stream,
-                                 float* aux) {
+__device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& net0, const NetW& net1,
+                                          const L1Map& m, float* stream, float* aux) {
     if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     NetW nets[2] = {net0, net1};
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,6 +155,32 @@ __global__ void lidf_pack_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m
         }
         aux[e] = v;
     }
+}
+
+__global__ void lidf_pack_kernel(StreamLayout lay, NetW net0, NetW net1, L1Map m, float* stream,
+                                 float* aux) {
+    pack_body(lay, net0, net1, m, stream, aux);
+}
+
+// Several streams of one module packed by ONE launch (grid.y = job): the three streams of the fused
+// query, the per-voxel layers of a PointNet, the two streams of the stage-2 IEF — with guarded packing
+// these launches return at once on almost every call, so their number is what they cost.
+__global__ void lidf_pack_multi_kernel(PackJobs j) {
+    const PackJob& k = j.job[blockIdx.y];
+    pack_body(k.lay, k.n0, k.n1, k.m, k.stream, k.aux);
+}
+
+extern "C" hipError_t lidf_launch_pack_multi(const PackJobs& j, hipStream_t st) {
+    if (j.n <= 0) return hipSuccess;
+    int blocks = 1;
+    for (int i = 0; i < j.n; ++i) {
+        const StreamLayout& lay = j.job[i].lay;
+        const int total = lay.total > lay.nets * LIDF_AUX_FLOATS ? lay.total : lay.nets * LIDF_AUX_FLOATS;
+        const int b = (total + 255) / 256;
+        blocks = b > blocks ? b : blocks;
+    }
+    hipLaunchKernelGGL(lidf_pack_multi_kernel, dim3(blocks, j.n), dim3(256), 0, st, j);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t lidf_launch_pack(const StreamLayout& lay, const NetW& n0, const NetW& n1,

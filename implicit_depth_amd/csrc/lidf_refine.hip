@@ -16,7 +16,7 @@ extern "C" hipError_t lidf_launch_refine_prep_dev(const float*, const long long*
                                                   float*, int*, int*, const unsigned char*, const int*,
                                                   const int*, hipStream_t);
 extern "C" hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int,
-                                                  int, int, int, long long, const int*, float*, int,
+                                                  int, int, int, long long, const int*, float*, int, int,
                                                   hipStream_t);
 extern "C" hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float,
                                                     long long, const int*, float*, const int*, const int*,
@@ -119,14 +119,15 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
                                         const float* __restrict__ vbound,
                                         const float* __restrict__ rayfeat, int ld_rf, int Lv, int L,
                                         int pos_rel, long long R, float* __restrict__ inp_embed,
-                                        int ld_e, const int* __restrict__ R_dev) {
+                                        int ld_e, const int* __restrict__ R_dev, int pos_only) {
     if (R_dev) R = *R_dev;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
-    const int ncol = 128 + E + Ed;
+    // pos_only: a later iteration on the same rays — only embed(pos) changed (columns 128 .. 128+E)
+    const int c_lo = pos_only ? 128 : 0, ncol = pos_only ? E : 128 + E + Ed;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * ncol) return;
     const long long r = i / ncol;
-    const int c = (int)(i % ncol);
+    const int c = c_lo + (int)(i % ncol);
     const float* rf = rayfeat + (size_t)r * ld_rf;
     float v;
     if (c < 128) {
@@ -178,15 +179,11 @@ extern "C" hipError_t lidf_launch_refine_prep_dev(const float* pred_pos, const l
                                                   const unsigned char* pnet_select, const int* dims,
                                                   const int* row0_dev, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipError_t e;
-    if (dims) {   // the frame path: a kernel node in a captured graph
-        float* zp[1] = {(float*)end_voxel};
-        const long long zc[1] = {R};
-        e = lidf_launch_zero_segments(zp, zc, 1, st);
-    } else {
-        e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
+    // (the frame path — dims — zeroes end_voxel with its other scratch of the iteration, in one launch)
+    if (!dims) {
+        hipError_t e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);
+        if (e != hipSuccess) return e;
     }
-    if (e != hipSuccess) return e;
     // slices of at least 64 voxels, enough of them for ~8 wavefronts per SIMD
     const long long waves = (R + 63) / 64;
     long long slices = (8 * 1024 + waves - 1) / waves;
@@ -209,17 +206,18 @@ extern "C" hipError_t lidf_launch_refine_rows(const float* pred_pos, const int* 
                                               int Lv, int L, int pos_rel, long long R,
                                               float* inp_embed, int ld_e, hipStream_t st) {
     return lidf_launch_refine_rows_dev(pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, nullptr,
-                                       inp_embed, ld_e, st);
+                                       inp_embed, ld_e, 0, st);
 }
 extern "C" hipError_t lidf_launch_refine_rows_dev(const float* pred_pos, const int* end_voxel,
                                                   const float* vbound, const float* rayfeat, int ld_rf,
                                                   int Lv, int L, int pos_rel, long long R,
                                                   const int* R_dev, float* inp_embed, int ld_e,
-                                                  hipStream_t st) {
+                                                  int pos_only, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    const long long total = R * (128 + 3 + 6 * L + 3 + 6 * Lv);
+    const long long total = R * (pos_only ? 3 + 6 * L : 128 + 3 + 6 * L + 3 + 6 * Lv);
     hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev);
+                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev,
+                       pos_only);
     return hipGetLastError();
 }
 

@@ -302,26 +302,50 @@ class FrameRunner:
         }
         self.graph = None
         self._keep = None
+        self.src = dict(self.inp)
         math.isfinite(self.part_size)
 
     # -- inputs -----------------------------------------------------------------------------------
-    def load(self, batch, full_rgb_feat, pred_mask=None):
-        """Copy a batch (the reference's dataset item keys) into the runner's static input buffers:
-        device-to-device copies on the current stream, no sync. mask_type 'all': valid <=> the
-        measured depth is non-zero (prepare_data, pipeline.py:119-121), so depth_corrupt itself is the
-        valid mask; 'pred': valid_mask = 1 - pred_mask, rays where pred_mask is non-zero."""
+    def load(self, batch, full_rgb_feat, pred_mask=None, copy=None):
+        """Hand a batch (the reference's dataset item keys) to the runner. mask_type 'all': valid <=>
+        the measured depth is non-zero (prepare_data, pipeline.py:119-121), so depth_corrupt itself is
+        the valid mask; 'pred': valid_mask = 1 - pred_mask, rays where pred_mask is non-zero.
+        copy=True (the default once a graph is captured: a graph replays fixed addresses) copies the
+        tensors into the runner's static input buffers — device-to-device, no sync; copy=False passes
+        the caller's own contiguous float32 tensors to the library as they lie (kept alive by the
+        runner until the next load)."""
+        copy = (self.graph is not None) if copy is None else copy
+        bs, h, w = self.bs, self.h, self.w
         i = self.inp
-        i["rgb"].copy_(batch["rgb"], non_blocking=True)
-        i["xyz_corrupt"].copy_(batch["xyz_corrupt"], non_blocking=True)
-        i["feat_grid"].copy_(full_rgb_feat, non_blocking=True)
-        for k, name in enumerate(("fx", "fy", "cx", "cy")):
-            i["intr"][:, k].copy_(batch[name], non_blocking=True)
-        if self.opt.mask_type == "all":
-            i["valid_mask"].copy_(batch["depth_corrupt"].reshape(self.bs, self.h, self.w), non_blocking=True)
+        intr = [batch[k].reshape(bs) for k in ("fx", "fy", "cx", "cy")]
+        if all(t.dtype == torch.float32 for t in intr):
+            torch.stack(intr, 1, out=i["intr"])
         else:
-            pm = pred_mask.reshape(self.bs, self.h, self.w)
-            i["miss_mask"].copy_(pm, non_blocking=True)
-            torch.sub(1.0, i["miss_mask"], out=i["valid_mask"])
+            i["intr"].copy_(torch.stack(intr, 1), non_blocking=True)
+        if self.opt.mask_type == "all":
+            valid, miss = batch["depth_corrupt"].reshape(bs, h, w), None
+        else:
+            miss = pred_mask.reshape(bs, h, w)
+            valid = None
+        srcs = {"rgb": batch["rgb"], "xyz_corrupt": batch["xyz_corrupt"], "feat_grid": full_rgb_feat,
+                "valid_mask": valid, "miss_mask": miss}
+        direct = not copy and all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                                                and t.device == self.dev) for t in srcs.values())
+        if direct:
+            self.src = dict(srcs, intr=i["intr"])
+        else:
+            if self.graph is None and not copy:
+                copy = True   # (not plain contiguous float32 device tensors: go through the static buffers)
+            for k in ("rgb", "xyz_corrupt", "feat_grid"):
+                i[k].copy_(srcs[k], non_blocking=True)
+            if valid is not None:
+                i["valid_mask"].copy_(valid, non_blocking=True)
+            if miss is not None:
+                i["miss_mask"].copy_(miss, non_blocking=True)
+            self.src = dict(i)
+        if miss is not None:   # valid_mask = 1 - pred_mask (prepare_data, pipeline.py:116-117)
+            torch.sub(1.0, self.src["miss_mask"], out=i["valid_mask"])
+            self.src["valid_mask"] = i["valid_mask"]
 
     # -- the launch sequence ------------------------------------------------------------------------
     def enqueue(self):
@@ -332,7 +356,7 @@ class FrameRunner:
         from .query import _packed_weights
         C = self.C
         pnet, prob, off, pnet_r, off_r = self.mods
-        opt, b, i = self.opt, self.buf, self.inp
+        opt, b, i = self.opt, self.buf, self.src
         keep = []
         dp, do = _decoder_struct(prob, keep), _decoder_struct(off, keep)
         pn = pointnet_struct(pnet, keep)
@@ -384,6 +408,10 @@ class FrameRunner:
         """Record enqueue() into a HIP graph (torch.cuda.CUDAGraph) after one eager warm-up call; run()
         then replays it. The graph holds the parameters' CURRENT storage pointers: in-place updates are
         picked up by the fingerprint check inside the graph, a replaced `.data` needs a new capture."""
+        for k, t in self.src.items():        # a batch handed over in place moves into the static buffers:
+            if t is not None and self.inp.get(k) is not None and t is not self.inp[k]:
+                self.inp[k].copy_(t)         # the graph reads those
+        self.src = dict(self.inp)
         self.enqueue()                       # warm-up: kernel attributes, packed blobs, allocator
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
@@ -437,7 +465,7 @@ class FrameRunner:
             "pred_prob_end": b["pred_prob"][:P].unsqueeze(1), "pair_pred_pos": b["pair_pred_pos"][:P],
             "pred_prob_end_softmax": b["pred_prob_softmax"][:P], "max_pair_id": b["max_pair_id"][:R],
             "pred_pos": b["pred_pos"][:R], "rayfeat": b["rayfeat"][:R], "pred_depth": b["pred_depth"],
-            "full_rgb_feat": self.inp["feat_grid"], "rgb_img": self.inp["rgb"], "counts": c,
+            "full_rgb_feat": self.src["feat_grid"], "rgb_img": self.src["rgb"], "counts": c,
         }
         if reference_dtypes:   # the reference's int64 index tensors (torch.nonzero / torch.unique)
             dd["miss_bid"], dd["miss_flat_img_id"] = dd["ray_bid"].long(), dd["ray_flat"].long()
