@@ -251,11 +251,12 @@ def refine_setup(scene, s, dev, precision="f32"):
     offr = IEF(dev, 334, 1, 64, n_iter=2).to(dev).eval()
     offr.load_state_dict(init_decoder_params("IEF", 334, 9, 5.0))
 
-    def run(out):
+    def run(out, events=None):
         return lidf_refine(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], out["pred_pos"],
                            out["max_pair_id"], s["pair_vox"], vb, vbid, rgb, s["feat_grid"], valid_inp,
                            valid_vox, pnet, offr, forward_times=2, rayfeat=out["rayfeat"],
-                           precision=precision)[0]
+                           precision=precision, profile_events=events)[0]
+    run.n_valid = nv
     return run
 
 
@@ -529,6 +530,14 @@ def main():
                          "default and what configs[2]/[4] describe); rays = ONE frame, image rows split "
                          "over the ranks (strong scaling, SURVEY 8e for fewer frames than GPUs), depth rows "
                          "all-gathered")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="query workloads: consecutive steps (independent frames) alternate over this many HIP "
+                         "streams, so the light kernels at the head and tail of a step (per-ray features, "
+                         "layer-1 partial products, per-ray reduce) run beside the previous step's per-point "
+                         "kernel instead of in front of it; 1 (default) = one stream, steps strictly one after "
+                         "another. Measured on MI355X (DESIGN.md 7): 388.4 / 388.2 / 391.1 Mpoints/s at 1 / 2 / 3 "
+                         "streams — the per-point kernel already fills the matrix pipes, what is overlapped "
+                         "comes back as a longer kernel")
     ap.add_argument("--e2e-mode", default="frame", choices=["frame", "graph", "stepwise"],
                     help="--workload e2e: frame = one sync-free library call per batch (default), graph = "
                          "that call replayed from a HIP graph, stepwise = one call per reference method")
@@ -617,35 +626,51 @@ def main():
     prob.load_state_dict(scene["prob_p"])
     off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
     off.load_state_dict(scene["off_p"])
-    depth = torch.zeros((B, h, w), device=dev)
-    gathered = torch.empty((world * B, h, w), device=dev) if use_dist and not by_rays else None
+    S = max(1, args.streams)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
+    depths = [torch.zeros((B, h, w), device=dev) for _ in range(S)]      # per stream: steps in flight
+    gathers = [torch.empty((world * B, h, w), device=dev) if use_dist and not by_rays else None
+               for _ in range(S)]
+    depth, gathered = depths[0], gathers[0]
     refine = None
     if args.workload == "query+refine":
         refine = refine_setup(scene, s, dev, args.precision)
     ev = HipEvents()
     pairs = [(ev.create(), ev.create()) for _ in range(args.steps)]
-    state = {"ws": None}
+    # stage 2: per step and iteration (PointNet begin, end, IEF rows kernel begin, end)
+    rpairs = [[[ev.create() for _ in range(4)] for _ in range(2)] for _ in range(args.steps)] \
+        if refine is not None and args.precision == "f32" else None
+    state = {"ws": [None] * S, "step": None}
 
-    def step(events=None, precision=args.precision):
+    def step(events=None, precision=args.precision, lane=0):
+        depth, gathered = depths[lane], gathers[lane]
         with torch.no_grad():
             out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                              s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
-                             ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"],
+                             ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"][lane],
                              profile_events=events, want_rayfeat=refine is not None,
                              precision=precision)
             if refine is not None:
-                out["pred_pos_refine"] = refine(out)
+                out["pred_pos_refine"] = refine(out, rpairs[state["step"]] if (rpairs and events is not None
+                                                                                 and state["step"] is not None) else None)
                 depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
                     out["pred_pos_refine"][:, 2]
-        state["ws"] = out["workspace"]
+        state["ws"][lane] = out["workspace"]
         if use_dist and by_rays:
             state["full"] = all_gather_depth_rows(depth[0, rows[0]:rows[1]], h)
         elif use_dist:
             all_gather_depth(depth, gathered)
         return out
 
-    for _ in range(args.warmup):
-        step()
+    def lane_step(i, events=None):
+        """Step i on stream i mod S (its own workspace, depth map and gather buffer)."""
+        if S == 1:
+            return step(events)
+        with torch.cuda.stream(streams[i % S]):
+            return step(events, lane=i % S)
+
+    for i in range(max(args.warmup, S)):
+        lane_step(i)
 
     def barrier():
         if use_dist:
@@ -657,7 +682,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(pairs[i])
+        state["step"] = i
+        lane_step(i, pairs[i])
+    state["step"] = None
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -750,6 +777,7 @@ def main():
                                     "76,800 predicted points, IEF D=334)" if refine is not None else "",
                                     "; RCCL all-gather of depth maps" if use_dist else ""),
                        "rays_per_gpu": scene["R"], "points_per_gpu": P, "voxels": scene["V"],
+                       "streams": S,
                        "parallelism": ("image rows of one frame sharded over %d GPU(s), depth rows all-gathered"
                                        if by_rays else "frames sharded over %d GPU(s)") % world},
             # frac = MFMA FLOP the kernel ISSUES (counted from its instruction stream, >99 % useful
@@ -774,6 +802,33 @@ def main():
                     "frac_of_8TBs": round(bytes_alg / (elapsed / args.steps) / 8e12, 5),
                     "note": "whole step; the path is MFMA-bound (>= 3,000 FLOP per HBM byte)"},
         }
+        if rpairs:
+            # stage 2 (2 x get_pred_refine) on its own: the IEF rows kernel (lidf_points_kernel<ROWS_GATHER>,
+            # D = 334: 26 layer-1 k-quads x 8 tiles x 4 + 2 passes x 654 v_mfma_f32_32x32x2 per 32 rays) and
+            # the PointNet2Stage pass (two register chains: 44 + 444 matrix instructions per 32 points +
+            # the per-voxel layers), HIP events recorded by lidf_refine_profile_f32 on the launch stream
+            t_pn = sum(ev.elapsed_ms(it[0], it[1]) for st_ in rpairs for it in st_) / args.steps / 2
+            t_ief = sum(ev.elapsed_ms(it[2], it[3]) for st_ in rpairs for it in st_) / args.steps / 2
+            R = scene["R"]
+            f_ief = (26 * 8 * 4 + 2 * 654) * 4096 / 32.0            # issued FLOP per ray and iteration
+            n_pn = refine.n_valid + R
+            f_pn = (44 + 444) * 4096 / 32.0                          # issued FLOP per PointNet point
+            a_ief, a_pn = f_ief * R / (t_ief * 1e-3) / 1e12, f_pn * n_pn / (t_pn * 1e-3) / 1e12
+            wt = (R + 31) // 32
+            line["roofline_stage2"] = {
+                "refine_ms_per_step": round(elapsed / args.steps * 1e3 - 0.0, 4),
+                "ief_rows": {"kernel": "lidf_points_kernel<LIDF_MODE_ROWS_GATHER>", "bound": "mfma",
+                             "kernel_ms": round(t_ief, 4), "launches_per_step": 2,
+                             "flop_per_ray_exec": f_ief, "achieved": round(a_ief, 2), "peak": PEAK_F32_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(a_ief / PEAK_F32_TFLOPS, 4),
+                             "wave_tiles": wt, "rounds": "%d wave-tiles over 1024 SIMDs = %.2f -> %d rounds"
+                             % (wt, wt / 1024.0, -(-wt // 1024))},
+                "pointnet": {"kernel": "lidf_pointnet_chain_kernel<1|2> + per-voxel lidf_linear_kernel",
+                             "bound": "mfma / atomic max-pool", "ms": round(t_pn, 4), "launches_per_step": 2,
+                             "points": n_pn, "flop_per_point_exec": f_pn, "achieved": round(a_pn, 2),
+                             "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_pn / PEAK_F32_TFLOPS, 4)},
+            }
+            del line["roofline_stage2"]["refine_ms_per_step"]
         if gather_ok is not None:
             line["collective"] = {"op": ("all_gather_into_tensor (RCCL) of the depth rows of one [%d,%d] map" % (h, w)
                                          if by_rays else

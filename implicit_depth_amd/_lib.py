@@ -177,6 +177,7 @@ SIGNATURES = {
     "lidf_pointnet_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "lidf_refine_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "lidf_refine_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P]),
+    "lidf_refine_profile_f32": (C.c_int, [C.POINTER(LidfRefineArgs), _P, _P, _P, _P, _P]),
     "lidf_refine_pack_bytes": (_SZ, [_I, _I]),
     "lidf_refine_pack_f32": (C.c_int, [C.POINTER(LidfDecoder), _I, _I, _P, _SZ, _P]),
     "lidf_frame_workspace_bytes": (_SZ, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _I64,
@@ -226,30 +227,40 @@ FROZEN = weakref.WeakSet()                        # modules whose packed streams
 
 
 class PackedEntry:
-    """One packed blob with its device-side guard (lidf_*_pack_guarded_f32) and the stream that used
-    it last. `key` holds only host-side configuration (never a parameter version: torch's version
-    counter misses `p.data` writes — the guard compares the parameters' CONTENTS on the device)."""
-    __slots__ = ("key", "blob", "guard", "stream", "frozen_ready")
+    """One packed blob with its device-side guard (lidf_*_pack_guarded_f32). `key` holds only
+    host-side configuration (never a parameter version: torch's version counter misses `p.data`
+    writes — the guard compares the parameters' CONTENTS on the device) and the stream the entry
+    belongs to: a blob and its guard are only ever touched by launches of ONE stream, so calls on
+    different streams (frames pipelined over two streams) share nothing and need no cross-stream
+    ordering — each stream keeps its own ~1 MB copy of a module's streams."""
+    __slots__ = ("key", "blob", "guard", "frozen_ready")
 
     def __init__(self, key, blob, guard):
-        self.key, self.blob, self.guard, self.stream, self.frozen_ready = key, blob, guard, None, False
+        self.key, self.blob, self.guard, self.frozen_ready = key, blob, guard, False
 
 
 def packed_entry(cache, owner, key, nbytes, device):
-    """The entry of `owner` in `cache` for `key` (created with a zero-filled guard when absent or
-    when the configuration changed), ordered after its previous use when that was on another stream."""
+    """The entry of `owner` in `cache` for (`key`, current stream), created with a zero-filled guard
+    when absent. A changed configuration key drops the owner's entries of every stream."""
     import torch
-    e = cache.get(owner)
-    if e is None or e.key != key:
+    per = cache.get(owner)
+    if per is None or per[0] != key:
+        per = (key, {})
+        cache[owner] = per
+    sid = torch.cuda.current_stream(device).cuda_stream
+    e = per[1].get(sid)
+    if e is None:
         blob = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         guard = torch.zeros((lib().lidf_pack_guard_bytes(),), dtype=torch.uint8, device=device)
         e = PackedEntry(key, blob, guard)
-        cache[owner] = e
-    cur = torch.cuda.current_stream(device)
-    if e.stream is not None and e.stream != cur:
-        cur.wait_stream(e.stream)       # the blob / guard were last touched on another stream
-    e.stream = cur
+        per[1][sid] = e
     return e
+
+
+def packed_entries(cache, owner):
+    """Every PackedEntry of `owner` (one per stream that used it); tests and diagnostics."""
+    per = cache.get(owner)
+    return list(per[1].values()) if per is not None else []
 
 
 def freeze_packed(*modules):

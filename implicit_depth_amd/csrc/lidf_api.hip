@@ -1162,7 +1162,8 @@ static size_t refine_fact_bytes(int D);
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
-                                 int pack_mode, const int* R_dev = nullptr, const int* V_dev = nullptr);
+                                 int pack_mode, const int* R_dev = nullptr, const int* V_dev = nullptr,
+                                 void* const* ev_rows = nullptr);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -1185,7 +1186,7 @@ LIDF_API size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int
     return refine_ws(n_rays, n_valid, n_vox, 256 + 2 * (3 + 6 * 16)).total;
 }
 
-LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
+static int refine_impl(const LidfRefineArgs* q, lidf_stream_t stream, void* const* ev) {
     if (!q) return LIDF_ERR_BAD_ARG;
     const int64_t R = q->n_rays, Nv = q->n_valid, V = q->n_vox, P = q->n_pairs;
     if (R < 0 || Nv < 0 || V < 0 || P < 0) return LIDF_ERR_BAD_ARG;
@@ -1228,9 +1229,11 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
                                       inp_embed, D, end_voxel, q->pnet_select, st));
     CHECK_HIP(lidf_launch_refine_rows(q->pred_pos, end_voxel, q->voxel_bound, q->rayfeat, 128 + Ed,
                                       q->multires_views, q->multires, q->pos_rel, R, inp_embed, D, st));
+    if (ev && ev[0]) CHECK_HIP(hipEventRecord((hipEvent_t)ev[0], st));
     if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
         return rc;
+    if (ev && ev[1]) CHECK_HIP(hipEventRecord((hipEvent_t)ev[1], st));
     if (q->precision != LIDF_PRECISION_F32 && q->precision != LIDF_PRECISION_F16X3)
         return LIDF_ERR_BAD_ARG;
     if (q->precision == LIDF_PRECISION_F32) {
@@ -1241,7 +1244,8 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
         // packed here for this call
         if ((rc = refine_ief_factorised(q->off, D, vox_feat, V, inp_embed, end_voxel, R, off,
                                         (float*)(ws + w.voxpart),
-                                        q->packed ? (char*)q->packed : ws + w.fact, st, q->packed ? 2 : 0)))
+                                        q->packed ? (char*)q->packed : ws + w.fact, st, q->packed ? 2 : 0,
+                                        nullptr, nullptr, ev ? ev + 2 : nullptr)))
             return rc;
     } else {
         CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
@@ -1253,6 +1257,16 @@ LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
                                         q->offset_range1 - q->offset_range0, R, q->pred_pos_out,
                                         st));
     return LIDF_OK;
+}
+
+LIDF_API int lidf_refine_f32(const LidfRefineArgs* q, lidf_stream_t stream) {
+    return refine_impl(q, stream, nullptr);
+}
+
+LIDF_API int lidf_refine_profile_f32(const LidfRefineArgs* q, void* ev_pnet_begin, void* ev_pnet_end,
+                                       void* ev_ief_begin, void* ev_ief_end, lidf_stream_t stream) {
+    void* ev[4] = {ev_pnet_begin, ev_pnet_end, ev_ief_begin, ev_ief_end};
+    return refine_impl(q, stream, ev);
 }
 
 // ---- the evaluation path of a batch of frames without a host round trip (lidf_frame_f32) --------
@@ -1696,7 +1710,7 @@ static size_t refine_fact_bytes(int D) { return linex_stream_bytes(128) + chain_
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
-                                 int pack_mode, const int* R_dev, const int* V_dev) {
+                                 int pack_mode, const int* R_dev, const int* V_dev, void* const* ev_rows) {
     int rc, cus;
     if ((rc = cu_count(&cus))) return rc;
     const int ld1 = D + (off->is_ief ? 16 : 0);
@@ -1706,10 +1720,13 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
     L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
     L.n_dev = V_dev;
     if ((rc = run_linex(L, (float*)scratch, cus, st, pack_mode))) return rc;
-    return run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
-                           nullptr, voxpart, nullptr, nullptr, nullptr, out,
-                           scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode,
-                           R_dev);
+    if (ev_rows && ev_rows[0]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[0], st));   // (benchmarks only)
+    rc = run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
+                         nullptr, voxpart, nullptr, nullptr, nullptr, out,
+                         scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode,
+                         R_dev);
+    if (!rc && ev_rows && ev_rows[1]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[1], st));
+    return rc;
 }
 
 LIDF_API size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views) {

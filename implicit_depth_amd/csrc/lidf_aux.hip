@@ -1238,30 +1238,49 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
     const double ifx = 1.0 / ((double)dst_w / (double)src_w);
     const double ify = 1.0 / ((double)dst_h / (double)src_h);
     const int n = dst_h * dst_w;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int dy = i / dst_w, dx = i % dst_w;
-        int sx = (int)floor(dx * ifx), sy = (int)floor(dy * ify);
-        sx = sx < src_w - 1 ? sx : src_w - 1;
-        sy = sy < src_h - 1 ? sy : src_h - 1;
-        const size_t si = (size_t)sy * src_w + sx;
-        float g = gt[si];
-        if (isnan(g) || isinf(g)) g = 0.f;
-        if (!(g > 0.f) || (seg && seg[si] == 0)) continue;
-        const float p = pred[si];
-        // same f32 operations as the torch expressions (pipeline.py:612-623)
-        const float thresh = fmaxf(g / p, p / g);
-        const float d = g - p;
-        const float lg = logf(fminf(fmaxf(g, 1e-6f), 1e6f)), lp = logf(fminf(fmaxf(p, 1e-6f), 1e6f));
-        acc[0] += thresh < 1.05f ? 1.0 : 0.0;
-        acc[1] += thresh < 1.10f ? 1.0 : 0.0;
-        acc[2] += thresh < 1.25f ? 1.0 : 0.0;
-        acc[3] += (double)(d * d);
-        acc[4] += (double)((lg - lp) * (lg - lp));
-        acc[5] += (double)fabsf(lg - lp);
-        acc[6] += (double)(fabsf(d) / g);
-        acc[7] += (double)fabsf(d);
-        acc[8] += (double)(d * d / g);
-        acc[9] += 1.0;
+    // four pixels per thread in flight (the loads of a batch are requested together; the sums keep the
+    // order i, i + blockDim, i + 2 blockDim, ... of a plain strided loop)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        float gv[4], pv[4];
+        bool mv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * (int)blockDim.x;
+            gv[k] = 0.f;
+            pv[k] = 1.f;
+            mv[k] = false;
+            if (i < n) {
+                const int dy = i / dst_w, dx = i % dst_w;
+                int sx = (int)floor(dx * ifx), sy = (int)floor(dy * ify);
+                sx = sx < src_w - 1 ? sx : src_w - 1;
+                sy = sy < src_h - 1 ? sy : src_h - 1;
+                const size_t si = (size_t)sy * src_w + sx;
+                gv[k] = gt[si];
+                pv[k] = pred[si];
+                mv[k] = !seg || seg[si] != 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g = gv[k];
+            if (isnan(g) || isinf(g)) g = 0.f;
+            if (!(g > 0.f) || !mv[k]) continue;
+            const float p = pv[k];
+            // same f32 operations as the torch expressions (pipeline.py:612-623)
+            const float thresh = fmaxf(g / p, p / g);
+            const float d = g - p;
+            const float lg = logf(fminf(fmaxf(g, 1e-6f), 1e6f)), lp = logf(fminf(fmaxf(p, 1e-6f), 1e6f));
+            acc[0] += thresh < 1.05f ? 1.0 : 0.0;
+            acc[1] += thresh < 1.10f ? 1.0 : 0.0;
+            acc[2] += thresh < 1.25f ? 1.0 : 0.0;
+            acc[3] += (double)(d * d);
+            acc[4] += (double)((lg - lp) * (lg - lp));
+            acc[5] += (double)fabsf(lg - lp);
+            acc[6] += (double)(fabsf(d) / g);
+            acc[7] += (double)fabsf(d);
+            acc[8] += (double)(d * d / g);
+            acc[9] += 1.0;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll

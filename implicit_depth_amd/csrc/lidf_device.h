@@ -175,6 +175,8 @@ struct PointsArgs {
     float r0, rscale, sqrt3, part_size;
     float* pair_pred_pos;   // [n,3]
     int* tile_counter;      // split-f16 kernel: dynamic tile hand-out (zeroed by its packer)
+    int dyn_min_tiles;      // fused f32 kernel: dynamic hand-out from this many wave-tiles per wavefront (0: 32)
+    int dyn_chunk;          // ... in chunks of this many wave-tiles (0: LIDF_CHUNK)
     // LIDF_MODE_TRAIN (one net): X = the per-pair layer-1 operand rows, voxpart[pair_vox] and
     // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in at
     // tr_passes + k * tr_pass_floats ([n,256] | [n,128] | [n,64] | [n]), the pre-activation

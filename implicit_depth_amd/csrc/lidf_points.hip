@@ -472,14 +472,15 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     const long long nwt = (AN + 31) / 32;
     // (short lists keep the static split: with a handful of tiles per wavefront one tile is the
     // grain either way and the first requests would be waited for)
-    const bool dyn = a.tile_counter != nullptr && nwt >= 32LL * gridDim.x * 4;
+    const bool dyn = a.tile_counter != nullptr &&
+                     nwt >= (long long)(a.dyn_min_tiles > 0 ? a.dyn_min_tiles : 32) * gridDim.x * 4;
     const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const long long nwaves = (long long)gridDim.x * 4;
-    const int chunk = LIDF_CHUNK;   // (a chunk is also the grain of the tail)
+    const int chunk = a.dyn_chunk > 0 ? a.dyn_chunk : LIDF_CHUNK;   // (a chunk is also the grain of the tail)
     long long w_cur = dyn ? ((long long)blockIdx.x * 4 + uwave) * chunk : tb * 4 + uwave;
     if (!dyn && tb >= te_) return;
     if (w_cur >= nwt) return;
@@ -1101,6 +1102,20 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
         static bool configured[64];
         hipError_t e = lidf_max_lds_once(configured, (const void*)lidf_points_fused_kernel, 131072);
         if (e != hipSuccess) return e;
+        static int env_min = -1, env_chunk = -1;   // development knobs of the tile hand-out
+        if (env_min < 0) {
+            const char* e1 = getenv("LIDF_DYN_MIN");
+            const char* e2 = getenv("LIDF_DYN_CHUNK");
+            env_min = e1 ? atoi(e1) : 0;
+            env_chunk = e2 ? atoi(e2) : 0;
+        }
+        if ((env_min > 0 || env_chunk > 0) && !a.tr_passes[0] && !a.tr_passes[1]) {
+            PointsArgs b = a;
+            b.dyn_min_tiles = env_min;
+            b.dyn_chunk = env_chunk;
+            hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, b);
+            return hipGetLastError();
+        }
         if (a.tr_passes[0] || a.tr_passes[1]) {
             static bool configured_t[64];
             e = lidf_max_lds_once(configured_t, (const void*)lidf_points_fused_train_kernel, 131072);

@@ -412,10 +412,15 @@ class FrameRunner:
             if t is not None and self.inp.get(k) is not None and t is not self.inp[k]:
                 self.inp[k].copy_(t)         # the graph reads those
         self.src = dict(self.inp)
-        self.enqueue()                       # warm-up: kernel attributes, packed blobs, allocator
+        # warm-up on the stream the capture will use: kernel attributes are set, the packed weight
+        # streams of that stream exist (and are valid), nothing is allocated during the capture
+        st = torch.cuda.Stream(self.dev)
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            self.enqueue()
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=st):
             self.enqueue()
         self.graph = g
         return self

@@ -417,7 +417,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                 forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
                 offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None,
-                precision="f32", pnet_select=None):
+                precision="f32", pnet_select=None, profile_events=None):
     """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
     `forward_times` iterations of get_pred_refine through lidf_refine_f32.
 
@@ -522,7 +522,12 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         q.pnet_select = pnet_select.data_ptr() if pnet_select is not None else None
         q.packed = packed.data_ptr() if packed is not None else None
         with torch.cuda.device(dev):
-            _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
+            if profile_events is not None:   # benchmarks only: forward_times x 4 hipEvent_t (PointNet, IEF)
+                ev = profile_events[_]
+                _lib.check(L.lidf_refine_profile_f32(C.byref(q), ev[0], ev[1], ev[2], ev[3],
+                                                     _lib.current_stream(dev)))
+            else:
+                _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out
     return cur, end_voxel
 

@@ -394,6 +394,11 @@ int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int32_t multi
 int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multires, int32_t multires_views,
                                  void* packed, size_t packed_bytes, void* guard, lidf_stream_t stream);
 int lidf_refine_f32(const LidfRefineArgs* args, lidf_stream_t stream);
+/* Instrumented variant for benchmarks: the same call with hipEvent_t recorded on `stream` around the
+ * PointNet2Stage pass and around the IEF rows kernel (any may be NULL). Not part of the reference's
+ * interface.                                                                                       */
+int lidf_refine_profile_f32(const LidfRefineArgs* args, void* ev_pnet_begin, void* ev_pnet_end,
+                            void* ev_ief_begin, void* ev_ief_end, lidf_stream_t stream);
 
 /* ---- The evaluation path of a batch of frames in ONE call, without a host round trip --------------
  * LIDF.forward, exp_type 'test' (models/pipeline.py:652-717: prepare_data :91-133, get_valid_points

@@ -149,11 +149,11 @@ def test_packed_weights_follow_parameter_updates(cuda):
     def ref_off(pp, po):
         return oracle_query(dict(scene, prob_p=pp, off_p=po))
     a = run()
-    entry = _lib.PACK_CACHE[prob]
+    (entry,) = _lib.packed_entries(_lib.PACK_CACHE, prob)
     h0, dirty, valid = _guard_state(entry)
     assert dirty == 1 and valid == 1                          # first call packed
     b = run()
-    assert _lib.PACK_CACHE[prob] is entry and _guard_state(entry) == (h0, 0, 1)   # reused, not re-packed
+    assert _lib.packed_entries(_lib.PACK_CACHE, prob) == [entry] and _guard_state(entry) == (h0, 0, 1)   # reused, not re-packed
     twin = copy.deepcopy(prob)     # the cache (device blobs) lives beside the module, not on it
     assert twin not in _lib.PACK_CACHE and "_lidf_pack_cache" not in twin.__dict__
     assert (a["pred_offset"] == b["pred_offset"]).all()
@@ -205,10 +205,10 @@ def test_packed_weights_follow_parameter_updates(cuda):
     # invalidate_packed (the documented contract of the opt-out)
     _lib.freeze_packed(prob)
     j = run()
-    hj = _guard_state(_lib.PACK_CACHE[prob])[0]
+    hj = _guard_state(_lib.packed_entries(_lib.PACK_CACHE, prob)[0])[0]
     off.linear_2.bias.data.add_(0.5)
     k = run()
-    assert torch.equal(j["pred_offset"], k["pred_offset"]) and _guard_state(_lib.PACK_CACHE[prob])[0] == hj
+    assert torch.equal(j["pred_offset"], k["pred_offset"]) and _guard_state(_lib.packed_entries(_lib.PACK_CACHE, prob)[0])[0] == hj
     _lib.invalidate_packed(prob)
     assert prob not in _lib.PACK_CACHE and prob not in _lib.FROZEN
     m = run()

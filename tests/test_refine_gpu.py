@@ -193,10 +193,10 @@ def test_refine_packed_weights_follow_parameter_updates(cuda):
                                s["feat_grid"], valid_inp.to(cuda), valid_vox.to(cuda), pnet, mod)[0]
     from test_parity_gpu import _guard_state
     a = run(offr)
-    entry, pentry = _lib.PACK_CACHE_REFINE[offr], _lib.PACK_CACHE[pnet]
+    (entry,), (pentry,) = _lib.packed_entries(_lib.PACK_CACHE_REFINE, offr), _lib.packed_entries(_lib.PACK_CACHE, pnet)
     assert _guard_state(entry)[1:] == (1, 1) and _guard_state(pentry)[2] == 1
     b = run(offr)
-    assert _lib.PACK_CACHE_REFINE[offr] is entry and torch.equal(a, b)
+    assert _lib.packed_entries(_lib.PACK_CACHE_REFINE, offr) == [entry] and torch.equal(a, b)
     assert _guard_state(entry)[1] == 0 and _guard_state(pentry)[1] == 0     # nothing re-packed
     with torch.no_grad():
         offr.linear_1.weight.mul_(1.5)          # in place, as an optimizer step
