@@ -942,3 +942,88 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
     return {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
             "pred_prob_end_softmax": sm, "max_pair_id": mid, "pred_pos": pred_pos}
 
+
+
+# ------------------------------------------------------------------------------------------------
+# Training path of stage 2 (train_refine.py:393-399: loss.backward() through RefineNet.forward)
+# ------------------------------------------------------------------------------------------------
+def refine_perturb_noise(perturb_prob=0.8):
+    """The train-only perturbation of RefineNet.get_pred_refine (models/pipeline.py:925-937), drawn
+    with the reference's own np.random.random() calls in the reference's order (so a run seeded like
+    the reference perturbs identically): returns the scalar `noise` (pred_pos += noise * ray_dir in
+    the first iteration) or None when the draw says 'no perturbation'."""
+    import numpy as np
+    if not (np.random.random() < perturb_prob):
+        return None
+    prob = np.random.random()
+    if prob < 0.5:
+        return np.random.random() * (0 + 0.05) - 0.05
+    if prob < 0.8:
+        return np.random.random() * (0.05 - 0)
+    if prob < 0.9:
+        return np.random.random() * (-0.05 + 0.1) - 0.1
+    return np.random.random() * (0.1 - 0.05) + 0.05
+
+
+def lidf_refine_train(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
+                      voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
+                      forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
+                      offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, perturb_noise=None):
+    """Differentiable RefineNet.forward (models/pipeline.py:922-1041, exp_type 'train'): the same
+    arguments as lidf_refine; gradients reach every parameter of pnet_model (PointNet2Stage) and
+    offset_dec (IEF / IMNet) — through the second and later iterations also via the refined position
+    (PointNet input, embed(pos) and the additive term, as in the reference's autograd graph) — and
+    feat_grid when it requires grad (RoIAlign backward). Stage 1 is frozen in train_refine.py:73, so
+    pred_pos / max_pair_id arrive detached.
+
+    Every differentiable stage runs liblidf_hip's training kernels (PointNet2Stage forward/backward
+    with arg-routed max-pool, the embedder's backward, the decoder's forward that keeps activations +
+    its backward, RoIAlign backward); the end-voxel lookup is the inference kernel (no gradient flows
+    through an index). torch joins them (cat / row gather and their adjoints).
+    perturb_noise: the scalar of refine_perturb_noise() — or None — applied in the first iteration
+    (pipeline.py:937).  Returns pred_pos_refine [R,3] (with grad) and the last end_voxel_id [R] i32."""
+    from .decoders import get_embedder
+    from .extensions import pcl_aabb
+    ray_pix, ray_bid = _as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid")
+    ray_flat, voxel_bid = _as_i32(ray_flat, "ray_flat"), _as_i32(voxel_bid, "voxel_bid")
+    pair_vox, valid_vox = _as_i32(pair_vox, "pair_vox"), _as_i32(valid_vox, "valid_vox")
+    _lib.require_cuda(ray_dir, pred_pos, max_pair_id, voxel_bound, rgb_img, feat_grid, valid_inp,
+                      names=["ray_dir", "pred_pos", "max_pair_id", "voxel_bound", "rgb_img", "feat_grid",
+                             "valid_inp"])
+    R, P, V = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0]
+    B, _, h, w = rgb_img.shape
+    E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
+    if offset_dec.inp_dim != 256 + E + Ed:
+        raise RuntimeError("refine offset_dec inp_dim must be %d" % (256 + E + Ed))
+    embed_pos, _ = get_embedder(multires) if multires > 0 else (torch.nn.Identity(), 3)
+    # per-ray [ROI | embed(dir)] rows: constants of the iterations (RoIAlign backward when feat_grid trains)
+    if torch.is_grad_enabled() and feat_grid.requires_grad:
+        rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    else:
+        rayfeat = ray_features(feat_grid.detach(), ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    roi, dir_embed = rayfeat[:, :128], rayfeat[:, 128:]
+    miss_rgb = rgb_img.permute(0, 2, 3, 1).reshape(-1, 3).index_select(
+        0, ray_bid.long() * (h * w) + ray_flat.long())
+    # voxel of the arg-max pair; the dummy row (a ray without pairs) selects voxel 0 (pipeline.py:941-943)
+    pv = torch.cat((pair_vox.long(), torch.zeros(1, dtype=torch.long, device=pair_vox.device)))
+    arg_vox = pv[max_pair_id.clamp(max=P)]
+    r0, r1 = float(offset_range[0]), float(offset_range[1])
+    cur = pred_pos
+    if perturb_noise is not None:
+        cur = cur + float(perturb_noise) * ray_dir
+    end_voxel = None
+    for _ in range(forward_times):
+        with torch.no_grad():   # index selection: pcl_aabb + scatter max (pipeline.py:939-944)
+            last = pcl_aabb.last_voxel(cur.detach().contiguous(), voxel_bound, ray_bid, voxel_bid).long()
+            end_voxel = torch.maximum(arg_vox, last)
+            vb = voxel_bound.index_select(0, end_voxel)
+            center = (vb[:, :3] + vb[:, 3:]) / 2.0
+        pred_inp = torch.cat(((cur - center) if pnet_pos_rel else cur, miss_rgb), 1)
+        pn_inp = torch.cat((valid_inp, pred_inp), 0)
+        pn_vox = torch.cat((valid_vox, end_voxel.to(torch.int32)), 0)
+        occ_voxel_feat = pnet_model(pn_inp, pn_vox, n_vox=V)
+        enter = (cur - center) if pos_rel else cur
+        inp_embed = torch.cat((occ_voxel_feat.index_select(0, end_voxel), roi, embed_pos(enter), dir_embed), -1)
+        off = offset_dec(inp_embed)
+        cur = cur + (off * (r1 - r0) + r0) * ray_dir
+    return cur, end_voxel.to(torch.int32)

@@ -531,8 +531,8 @@ def refine_step(pred_pos, ray_dir, ray_pix, ray_bid, ray_flat, max_pair_id, pair
     # end voxel: arg-max pair's voxel (dummy row -> 0), raised to the largest containing voxel
     pv = torch.cat((pair_vox.long(), torch.zeros(1, dtype=torch.long)))
     end_voxel = pv[max_pair_id.clamp(max=P)].clone()
-    m = torch.from_numpy(pcl_aabb(pred_pos.numpy(), voxel_bound.numpy(), ray_bid.numpy(),
-                                  voxel_bid.numpy())).long()
+    m = torch.from_numpy(pcl_aabb(pred_pos.detach().numpy(), voxel_bound.numpy(), ray_bid.numpy(),
+                                  voxel_bid.numpy())).long()   # (an index: no gradient, as in autograd)
     idx = torch.nonzero(m, as_tuple=False)
     end_voxel.scatter_reduce_(0, idx[:, 1], idx[:, 0], reduce="amax", include_self=True)
     e_dir = embed(ray_dir, multires_views)

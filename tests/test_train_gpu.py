@@ -171,3 +171,70 @@ def test_embed_gradient(cuda, multires):
     (e * wgt.to(cuda)).sum().backward()
     scale = max(1.0, xr.grad.abs().max().item())
     assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= 2e-5 * scale
+
+
+def test_refine_train_gradients_vs_oracle(cuda):
+    """Stage-2 training step (RefineNet.forward with exp_type 'train', train_refine.py:393-399):
+    lidf_refine_train's outputs and the gradients of every PointNet2Stage / IEF parameter against
+    torch autograd through the oracle's refine_step chain on the CPU, with the train-only perturbation
+    (pipeline.py:925-937) drawn by the reference's own np.random calls; the inference call
+    (lidf_refine) must give the same forward values."""
+    import numpy as np
+    from implicit_depth_amd.query import lidf_query, lidf_refine, lidf_refine_train, refine_perturb_noise
+    from util import make_module, make_pointnet, to_dev
+    scene = orc.synthetic_scene(2, 10, 14, 5, seed=31, ragged=True)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    prob, off = make_module("IMNET", scene["prob_p"], D, cuda), make_module("IEF", scene["off_p"], D, cuda)
+    with torch.no_grad():
+        s1 = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
+                        s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+    g = torch.Generator().manual_seed(9)
+    V = scene["V"]
+    vb = torch.cat((scene["vox_center"] - 0.125, scene["vox_center"] + 0.125), 1)
+    vbid = torch.arange(2).repeat_interleave(729).int()
+    rgb = torch.randn(2, 3, 10, 14, generator=g)
+    valid_inp = torch.randn(400, 6, generator=g) * 0.2
+    valid_vox = torch.randint(0, V, (400,), generator=g).int()
+    pnet_p = orc.init_pointnet(5, 1.5)
+    offr_p = orc.randomize_biases(orc.init_decoder("IEF", 334, 77, 5.0), 78)
+    np.random.seed(4)
+    noise = refine_perturb_noise(perturb_prob=1.0)
+    assert noise is not None and abs(noise) <= 0.1
+    np.random.seed(4)            # the reference's draws, in its order (pipeline.py:926-936)
+    assert np.random.random() < 1.0
+    pr = np.random.random()
+    ref_noise = (np.random.random() * 0.05 - 0.05 if pr < 0.5 else np.random.random() * 0.05 if pr < 0.8
+                 else np.random.random() * 0.05 - 0.1 if pr < 0.9 else np.random.random() * 0.05 + 0.05)
+    assert noise == ref_noise
+    # --- oracle: autograd through two refine_step iterations on the CPU
+    pn_ref = {k: v.clone().requires_grad_(True) for k, v in pnet_p.items()}
+    of_ref = {k: v.clone().requires_grad_(True) for k, v in offr_p.items()}
+    pos = s1["pred_pos"].cpu() + noise * scene["ray_dir"]
+    for _ in range(2):
+        pos, ev, _ = orc.refine_step(pos, scene["ray_dir"], scene["ray_pix"], scene["ray_bid"],
+                                     scene["ray_flat"], s1["max_pair_id"].cpu(), scene["pair_vox"], vb, vbid,
+                                     rgb, scene["feat_grid"], valid_inp, valid_vox, pn_ref, of_ref)
+    wgt = torch.randn(pos.shape, generator=g)
+    (pos * wgt).sum().backward()
+    # --- product: the training path
+    pnet, offr = make_pointnet(pnet_p, cuda).train(), make_module("IEF", offr_p, 334, cuda).train()
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["ray_flat"], s1["pred_pos"], s1["max_pair_id"],
+            s["pair_vox"], vb.to(cuda), vbid.to(cuda), rgb.to(cuda), s["feat_grid"], valid_inp.to(cuda),
+            valid_vox.to(cuda), pnet, offr)
+    got, gev = lidf_refine_train(*args, perturb_noise=noise)
+    assert got.requires_grad and (gev.cpu().long() == ev).all()
+    assert (got.detach().cpu() - pos.detach()).abs().max().item() <= TOL
+    (got * wgt.to(cuda)).sum().backward()
+    for mod, ref in ((pnet, pn_ref), (offr, of_ref)):
+        for k, p in mod.named_parameters():
+            gr = ref[k].grad
+            assert p.grad is not None, k
+            err = (p.grad.cpu() - gr).abs().max().item()
+            assert err <= 5e-4 * max(gr.abs().max().item(), 1e-3), (k, err, gr.abs().max().item())
+    # the inference call on the perturbed start gives the same forward values
+    with torch.no_grad():
+        inf, _ = lidf_refine(*args[:4], (s1["pred_pos"] + noise * s["ray_dir"]).contiguous(), *args[5:])
+    assert (inf - got.detach()).abs().max().item() <= 2e-5
+    with pytest.raises(RuntimeError, match="inference path"):
+        lidf_refine(*args)       # autograd recording + trainable modules: refused, not silently detached
