@@ -192,7 +192,7 @@ def profile_record(kernel_name):
     scripts/prof_summary.py from the same bench command): average duration of the kernel-trace
     run and the PMC HBM bytes per launch / per step. Absent files -> empty record."""
     out = {}
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         ks = os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag)
         if not os.path.exists(ks):
             continue
@@ -788,6 +788,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": prof.get("hbm_bytes_counter"),
                          "kernel": kname, "kernel_ms": round(kern_ms, 4),
+                         # (static: the average of the committed rocprofv3 summary of an earlier run of this
+                         # command, for comparison with the live kernel_ms above — not a value of this run)
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "profile": prof.get("profile"),
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,

@@ -31,6 +31,16 @@ def counter(db, name):
 
 def main():
     tag, kt = sys.argv[1], sys.argv[2]
+    if len(sys.argv) == 4 and not sys.argv[3].endswith(".db"):   # <tag> <kt.db> "<command line>": stats only
+        rows, tot = kernel_stats(kt)
+        with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- %s\n" % sys.argv[3])
+            f.write("name,calls,total_ns,avg_ns,min_ns,max_ns,pct,vgpr,agpr,sgpr,lds_bytes,scratch_bytes,grid_x,wg_x\n")
+            for r in rows:
+                f.write('"%s",%d,%d,%.1f,%d,%d,%.3f,%s,%s,%s,%s,%s,%s,%s\n' % (
+                    r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10],
+                    r[11], r[12]))
+        return
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     rows, tot = kernel_stats(kt)
@@ -84,5 +94,5 @@ def mfma_counters(tag, db):
 
 if __name__ == "__main__":
     main()
-    if len(sys.argv) >= 6:
+    if len(sys.argv) >= 6 and sys.argv[3].endswith(".db"):
         mfma_counters(sys.argv[1], sys.argv[5])
