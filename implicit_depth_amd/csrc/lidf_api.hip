@@ -59,7 +59,14 @@ hipError_t lidf_launch_ray_aabb_compact_dev(bool, const float*, const float*, co
                                             const int*, int*, int*, float*, long long, hipStream_t);
 hipError_t lidf_launch_pointnet_chain_dev(int, const float*, const float*, const int*, const float*,
                                           float*, float*, long long, int, long long, const int*,
-                                          const int*, int, hipStream_t);
+                                          const int*, const int*, const int*, int, hipStream_t);
+int lidf_pointnet_lds_max_voxels(void);
+size_t lidf_pointnet_sort_bytes(long long, long long);
+hipError_t lidf_launch_sort_idx(const int*, long long, const int*, long long, void*, const int**,
+                                const int**, hipStream_t);
+hipError_t lidf_launch_pointnet_chain_sorted(int, const float*, const float*, const int*, const float*,
+                                             float*, long long, long long, const int*, const int*, int,
+                                             hipStream_t);
 size_t lidf_pointnet_pool_scratch_bytes_dev(long long);
 hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int*, long long, const float*,
                                        const int*, long long, const int*, const int*, const float*,
@@ -990,7 +997,7 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
 }
 
 struct PnetWs {
-    size_t s[7], chain, f1, f2, pool1, g1, gpart, f4, pool2, part, part_bytes, total;
+    size_t s[7], chain, f1, f2, pool1, g1, gpart, f4, pool2, part, part_bytes, sort, total;
 };
 static PnetWs pnet_ws(int64_t n, int64_t v) {
     PnetWs w;
@@ -1010,6 +1017,8 @@ static PnetWs pnet_ws(int64_t n, int64_t v) {
     w.pool2 = o; o += align_up(V * 128 * 4, 256);
     w.part_bytes = lidf_pointnet_pool_scratch_bytes(v);
     w.part = o;  o += align_up(w.part_bytes, 256);
+    // tables beyond the LDS pooling: the points are walked grouped by voxel (counting-sort scratch)
+    w.sort = o;  o += v > lidf_pointnet_lds_max_voxels() ? align_up(lidf_pointnet_sort_bytes(n, v), 256) : 0;
     w.total = o;
     return w;
 }
@@ -1032,6 +1041,7 @@ struct PnetBufs {
     float* streams[7];
     float* chain;   // stream of the per-point chains (inference)
     float* part;    // slabs of the LDS pooling path (NULL: global atomic maxima)
+    int* sort;      // counting-sort scratch of the voxel-sorted walk (tables beyond the LDS pooling) or NULL
 };
 
 // mode 0: pack the weight streams and run; 1: pack only (lidf_pointnet_pack_f32); 2: run on
@@ -1052,7 +1062,16 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
         if (!pp)
             CHECK_HIP(lidf_launch_pack_pointnet(w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_p3, w->w_p4,
                                                 w->b_p4, b.chain, tl_guard, st));
-        if (!po) CHECK_HIP(lidf_launch_pointnet_chain(1, b.chain, inp, vox, nullptr, b.pool1, b.part, n_vox, n, cus, st));
+        const bool sorted = !po && b.sort && n > 0 && n_vox > lidf_pointnet_lds_max_voxels() &&
+                            lidf_pointnet_sort_bytes(n, n_vox) > 0;
+        const int *perm = nullptr, *n_perm = nullptr;
+        if (sorted) {
+            CHECK_HIP(lidf_launch_sort_idx(vox, n, nullptr, n_vox, b.sort, &perm, &n_perm, st));
+            CHECK_HIP(lidf_launch_pointnet_chain_sorted(1, b.chain, inp, vox, nullptr, b.pool1, n_vox, n, perm,
+                                                        n_perm, cus, st));
+        } else if (!po) {
+            CHECK_HIP(lidf_launch_pointnet_chain(1, b.chain, inp, vox, nullptr, b.pool1, b.part, n_vox, n, cus, st));
+        }
         if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
                              b.g1, 64, nullptr, nullptr, b.streams[2], cus, st, po, pp)))
             return rc;
@@ -1060,7 +1079,11 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
         if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, b.g1, 64, n_vox, nullptr, nullptr, 0,
                              b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st, po, pp)))
             return rc;
-        if (!po) CHECK_HIP(lidf_launch_pointnet_chain(2, b.chain, inp, vox, b.gpart, b.pool2, b.part, n_vox, n, cus, st));
+        if (sorted)
+            CHECK_HIP(lidf_launch_pointnet_chain_sorted(2, b.chain, inp, vox, b.gpart, b.pool2, n_vox, n, perm,
+                                                        n_perm, cus, st));
+        else if (!po)
+            CHECK_HIP(lidf_launch_pointnet_chain(2, b.chain, inp, vox, b.gpart, b.pool2, b.part, n_vox, n, cus, st));
         return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, b.pool2, 128, n_vox, nullptr, nullptr, 1,
                           out, 128, nullptr, nullptr, b.streams[6], cus, st, po, pp);
     }
@@ -1113,6 +1136,7 @@ LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const in
         b.streams[i] = w->packed ? (float*)((char*)w->packed + ws.s[i]) : (float*)(base + ws.s[i]);
     b.chain = w->packed ? (float*)((char*)w->packed + ws.chain) : (float*)(base + ws.chain);
     b.part = ws.part_bytes ? (float*)(base + ws.part) : nullptr;
+    b.sort = n_vox > lidf_pointnet_lds_max_voxels() ? (int*)(base + ws.sort) : nullptr;
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     return pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, (hipStream_t)stream, w->packed ? 2 : 0);
@@ -1273,9 +1297,9 @@ LIDF_API int lidf_refine_profile_f32(const LidfRefineArgs* q, void* ev_pnet_begi
 // PointNet2Stage with device-side counts: pointnet_impl's inference branch, every launch sized for
 // the capacities (n_cap points, V_cap voxels) and reading *n_dev / *V_dev on the device.
 struct PnetFrameWs {
-    size_t pool1, g1, gpart, pool2, part, total;
+    size_t pool1, g1, gpart, pool2, part, sort, total;
 };
-static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds) {
+static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds, int64_t n_cap = 0) {
     PnetFrameWs w;
     size_t o = 0;
     const size_t V = (size_t)(v_cap > 0 ? v_cap : 1);
@@ -1284,17 +1308,23 @@ static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds) {
     w.gpart = o; o += align_up(V * 128 * 4, 256);
     w.pool2 = o; o += align_up(V * 128 * 4, 256);
     w.part = o;  o += align_up(lidf_pointnet_pool_scratch_bytes_dev(v_lds), 256);
+    w.sort = o;  o += n_cap > 0 ? align_up(lidf_pointnet_sort_bytes(n_cap, v_cap), 256) : 0;
     w.total = o;
     return w;
 }
 // (pool1 / pool2 of `ws` must be zero on entry: frame_zero_pools, merged with the caller's other scratch)
+// sort_cap > 0 (several frames per batch: the voxel table is expected to exceed the LDS pooling): the
+// global-atomic variant walks the points grouped by voxel (the counting sort runs unconditionally).
 static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_cap,
                           const int* n_dev, int64_t V_cap, int v_lds, const int* V_dev, float* out,
-                          char* ws, int cus, hipStream_t st) {
+                          char* ws, int cus, hipStream_t st, int64_t sort_cap = 0) {
     int rc;
     if ((rc = check_pointnet_w(w))) return rc;
     if (!w->packed) return LIDF_ERR_BAD_ARG;
-    const PnetFrameWs f = pnet_frame_ws(V_cap, v_lds);
+    const PnetFrameWs f = pnet_frame_ws(V_cap, v_lds, sort_cap);
+    const int *perm = nullptr, *n_perm = nullptr;
+    if (sort_cap > 0 && lidf_pointnet_sort_bytes(sort_cap, V_cap) > 0)
+        CHECK_HIP(lidf_launch_sort_idx(vox, n_cap, n_dev, V_cap, ws + f.sort, &perm, &n_perm, st));
     const PnetWs pw = pnet_ws(1, 1);   // offsets of the packed streams
     float* streams[7];
     for (int i = 0; i < 7; ++i) streams[i] = (float*)((char*)w->packed + pw.s[i]);
@@ -1305,7 +1335,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
     float* pool2 = (float*)(ws + f.pool2);
     float* part = (float*)(ws + f.part);
     CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, part, V_cap, v_lds, n_cap,
-                                             n_dev, V_dev, cus, st));
+                                             n_dev, V_dev, perm, n_perm, cus, st));
     if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, V_cap, nullptr, nullptr, 1, g1, 64,
                          nullptr, nullptr, streams[2], cus, st, false, true, V_dev)))
         return rc;
@@ -1313,7 +1343,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
                          128, nullptr, nullptr, streams[3], cus, st, false, true, V_dev)))
         return rc;
     CHECK_HIP(lidf_launch_pointnet_chain_dev(2, chain, inp, vox, gpart, pool2, part, V_cap, v_lds, n_cap,
-                                             n_dev, V_dev, cus, st));
+                                             n_dev, V_dev, perm, n_perm, cus, st));
     return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, pool2, 128, V_cap, nullptr, nullptr, 1, out,
                       128, nullptr, nullptr, streams[6], cus, st, false, true, V_dev);
 }
@@ -1339,7 +1369,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     f.pt_rank = o;   o += align_up((N + 1) * 4, 256);
     f.ray_count = o; o += align_up(N * 4, 256);
     f.scan = o;      o += align_up(lidf_exclusive_scan_workspace_bytes((int64_t)(N > C ? N : C)), 256);
-    f.pnet = o;      o += align_up(pnet_frame_ws((int64_t)C, v_lds).total, 256);
+    f.pnet = o;      o += align_up(pnet_frame_ws((int64_t)C, v_lds, B >= 2 ? (int64_t)(2 * N) : 0).total, 256);
     f.query = o;     o += align_up(lidf_query_workspace_bytes((int64_t)N, (int64_t)C, (int64_t)B * 32 * h * w), 256);
     const int Dmax = 256 + 2 * (3 + 6 * 16);
     const bool rf = refine_times > 0;
@@ -1415,7 +1445,8 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
 
     // 0. every zero-initialised scratch of stage 1 in ONE launch: voxel marks, the max-pool tables of the
     //    PointNet, the clamped-box list length and the tile counter of the query
-    const PnetFrameWs pf = pnet_frame_ws(C, v_lds);
+    const int64_t sort_cap = B >= 2 ? 2 * N : 0;   // several frames: the voxel table outgrows the LDS pooling
+    const PnetFrameWs pf = pnet_frame_ws(C, v_lds, sort_cap);
     const int64_t grid_floats = (int64_t)B * 32 * h * w;
     const QueryWs qw = query_ws(N, C, a->multires, a->multires_views, grid_floats);
     float* pool1 = (float*)(ws + f.pnet + pf.pool1);
@@ -1455,7 +1486,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
                                                a->max_pairs, st));
     // 4. voxel embedding: PointNet over the in-grid valid points
     if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
-                             counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st)))
+                             counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))
         return rc;
     // 5. get_embedding + get_pred + depth
     float* vox_center = nullptr;
@@ -1517,7 +1548,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
                                               inp_embed, D, it == 0 ? 0 : 1, st));
         if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
-                                 v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st)))
+                                 v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st, sort_cap)))
             return rc;
         if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N, offv,
                                         voxpart_r, (char*)a->packed_refine, st, 2, counts + LIDF_FC_RAYS,

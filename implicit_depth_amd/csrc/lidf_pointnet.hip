@@ -66,6 +66,16 @@ struct PnetChainArgs {
     const int* n_dev;
     const int* V_dev;
     int v_lds;
+    // voxel-sorted walk (large tables): point p of the launch is perm[p], the points are grouped by
+    // voxel (lidf_launch_pointnet_sort), points left out of the pooling are not in perm; the number of
+    // points is *n_perm. The global-atomic pooling then meets one or two voxels per wavefront.
+    const int* perm;
+    const int* n_perm;
+    // window > 0 (with perm; the LDS instantiation): the workgroup's table holds `window` rows starting
+    // at the voxel of its first point — its contiguous run of sorted points spans a handful of voxels —
+    // and is flushed into `pool` with atomic maxima at the end; a point beyond the window raises `pool`
+    // directly.
+    int window;
 };
 
 __device__ __forceinline__ int pn_feature(int s, int half) {
@@ -182,6 +192,20 @@ __device__ __forceinline__ void pn_pool(const f32x16 (&acc)[NT], const int T0, c
     }
 }
 
+// lane-level atomic maxima of one accumulator tile straight into the global table (rare path)
+__device__ __forceinline__ void pn_pool_lane(const f32x16& acc, const int T, const int vox, float* pool,
+                                             const int F, const int h) {
+    int* row = (int*)pool + (size_t)vox * F + 32 * T + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = acc[4 * g + i];
+            if (v > 0.f) atomicMax(row + 8 * g + i, __float_as_int(v));
+        }
+    }
+}
+
 // lane-level integer maxima of one accumulator tile into the LDS table row of the lane's voxel
 __device__ __forceinline__ void pn_pool_lds(const f32x16& acc, const int T, const int vox,
                                             const bool valid, int* tab, const int F, const int h) {
@@ -201,10 +225,16 @@ template <int STAGE, bool LDSPOOL>
 __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainArgs a) {
     extern __shared__ int pn_tab[];
     constexpr int F = STAGE == 1 ? 64 : 128;
-    if (a.V_dev && ((*a.V_dev <= a.v_lds) != LDSPOOL)) return;   // the other variant owns this call
-    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;
+    const bool windowed = LDSPOOL && a.window > 0;
+    const bool use_perm = a.perm && (!LDSPOOL || windowed);
+    if (a.V_dev) {   // device-side choice of the variant: full LDS table up to v_lds voxels, else the other one
+        const bool fits = *a.V_dev <= a.v_lds;
+        if (fits != (LDSPOOL && !windowed)) return;
+    }
+    const long long AN = use_perm ? (long long)*a.n_perm : (a.n_dev ? (long long)*a.n_dev : a.n);
+    const int tab_rows = windowed ? a.window : a.V;
     if (LDSPOOL) {
-        for (int i = threadIdx.x; i < a.V * F; i += 256) pn_tab[i] = 0;
+        for (int i = threadIdx.x; i < tab_rows * F; i += 256) pn_tab[i] = 0;
         __syncthreads();
     }
     constexpr int NQ = STAGE == 1 ? PN_S1_QUADS : PN_S2_QUADS;
@@ -230,13 +260,20 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
     f32x4 ring[LIDF_RING];
 #pragma unroll
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+    // windowed table: rows [vbase, vbase + window) of the voxel table (sorted points: ascending voxels)
+    int vbase = 0;
+    if (windowed && tb < te && tb * 128 < AN) vbase = a.vox[a.perm[tb * 128]];
 
     for (long long tile = tb; tile < te; ++tile) {
         if (tile * 128 + wave * 32 >= AN) break;   // wave-uniform
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < AN;
-        const long long pc = valid ? p : AN - 1;
+        long long pc = valid ? p : AN - 1;
+        if (use_perm) pc = a.perm[pc];   // voxel-sorted walk
         const int vox = a.vox[pc];
+        // row of the LDS table; a point beyond the window goes to the global table (vrow = -1)
+        const int vrow = windowed ? ((vox >= vbase && vox - vbase < a.window) ? vox - vbase : -1) : vox;
+        const bool spill = windowed && valid && vox >= 0 && vrow < 0;
         // operand columns of this lane: 4h + {0..3} of [x0..x5, 1, 0]
         float b1[4];
         {
@@ -306,8 +343,12 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
                 }
                 if (kq == 16) {
                     pn_relu(acc);
-                    if (LDSPOOL) pn_pool_lds(acc, T, vox, valid, pn_tab, 128, h);
-                    else F5[(STAGE == 2 && !LDSPOOL) ? T : 0] = acc;
+                    if (LDSPOOL) {
+                        pn_pool_lds(acc, T, vrow, valid, pn_tab, 128, h);
+                        if (spill) pn_pool_lane(acc, T, vox, a.pool, 128, h);
+                    } else {
+                        F5[(STAGE == 2 && !LDSPOOL) ? T : 0] = acc;
+                    }
                 }
             }
             SCHED_FENCE();
@@ -318,14 +359,26 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         }
         if (STAGE == 1) {
             if (LDSPOOL) {
-                pn_pool_lds(F2[0], 0, vox, valid, pn_tab, 64, h);
-                pn_pool_lds(F2[1], 1, vox, valid, pn_tab, 64, h);
+                pn_pool_lds(F2[0], 0, vrow, valid, pn_tab, 64, h);
+                pn_pool_lds(F2[1], 1, vrow, valid, pn_tab, 64, h);
+                if (spill) {
+                    pn_pool_lane(F2[0], 0, vox, a.pool, 64, h);
+                    pn_pool_lane(F2[1], 1, vox, a.pool, 64, h);
+                }
             } else {
                 pn_pool<2>(F2, 0, vox, valid, gpool, 64, h, col);
             }
         }
     }
-    if (LDSPOOL) {
+    if (windowed) {
+        // the window's rows into the global table: one atomic maximum per touched entry and workgroup
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.window * F; i += 256) {
+            const int v = pn_tab[i];
+            const int row = vbase + i / F;
+            if (v > 0 && row < a.V) atomicMax((int*)a.pool + (size_t)row * F + i % F, v);
+        }
+    } else if (LDSPOOL) {
         __syncthreads();
         f32x4* dst = (f32x4*)(a.part + (size_t)blockIdx.x * a.V * F);
         const f32x4* src = (const f32x4*)pn_tab;
@@ -391,6 +444,7 @@ extern "C" size_t lidf_pointnet_chain_stream_bytes(void) { return (size_t)PN_S2_
 
 // Scratch of the pooling: PN_MAX_WGS slabs of V x 128 floats when the table fits LDS, else up to
 // PN_COPIES copies of the table for the global-atomic path (at most 32 MiB).
+#define PN_WINDOW 32     // rows of the windowed table of the voxel-sorted walk (16 KiB at 128 features)
 #define PN_MAX_WGS 512
 #define PN_LDS_LIMIT (144 * 1024)
 #define PN_COPIES 16
@@ -416,7 +470,7 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n;
     a.part = part; a.V = (int)V; a.copies = 0;
-    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0;
+    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0; a.perm = nullptr; a.n_perm = nullptr; a.window = 0;
     const int F = stage == 1 ? 64 : 128;
     const long long count = V * F;
     const long long ntile = (n + 127) / 128;
@@ -470,12 +524,14 @@ extern "C" hipError_t lidf_launch_pointnet_chain_dev(int stage, const float* str
                                                      const int* vox, const float* gpart, float* pool,
                                                      float* part, long long V_cap, int v_lds,
                                                      long long n_cap, const int* n_dev,
-                                                     const int* V_dev, int cus, hipStream_t st) {
+                                                     const int* V_dev, const int* perm,
+                                                     const int* n_perm, int cus, hipStream_t st) {
     if (n_cap <= 0) return hipSuccess;
     if (v_lds <= 0 || (size_t)v_lds * 128 * 4 > PN_LDS_LIMIT || !part || !V_dev) return hipErrorInvalidValue;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
     a.part = part; a.V = v_lds; a.copies = 0; a.n_dev = n_dev; a.V_dev = V_dev; a.v_lds = v_lds;
+    a.perm = nullptr; a.n_perm = nullptr; a.window = 0;
     const int F = stage == 1 ? 64 : 128;
     const long long ntile = (n_cap + 127) / 128;
     const size_t lds = (size_t)v_lds * F * 4;
@@ -499,9 +555,60 @@ extern "C" hipError_t lidf_launch_pointnet_chain_dev(int stage, const float* str
     // the fallback: more occupied voxels than the LDS tables hold
     a.V = (int)V_cap; a.part = nullptr;
     const long long g2 = ntile < 2LL * cus ? ntile : 2LL * cus;
+    if (perm) {   // voxel-sorted walk with a windowed LDS table
+        a.perm = perm; a.n_perm = n_perm; a.window = PN_WINDOW;
+        const size_t wl = (size_t)PN_WINDOW * F * 4;
+        if (stage == 1)
+            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g2), dim3(256), wl, st, a);
+        else
+            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g2), dim3(256), wl, st, a);
+        return hipGetLastError();
+    }
     if (stage == 1)
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Large voxel tables (more rows than the LDS pooling holds: several frames per batch, or a densely
+// occupied grid): the points are grouped by voxel first, so that a wavefront of the chains meets one or
+// two voxels instead of ~28 and its pre-reduced maxima cost a few global atomics per tile — with the
+// points in input order every point raised its own 64 / 128 table entries (86,800 points on 729 voxels:
+// 0.24 ms per PointNet pass, all of it in the pooling). Counting sort, order inside a voxel irrelevant
+// (the pooling is a maximum): count per voxel (global atomics on a [V] table), one-workgroup exclusive
+// scan, placement through per-voxel cursors. Points with a negative voxel are left out.
+// scratch: lidf_pointnet_sort_bytes(n, V) bytes.
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t lidf_sort_idx_ws_bytes(long long P, long long V);
+extern "C" hipError_t lidf_launch_sort_idx(const int* idx, long long P, const int* n_dev, long long V,
+                                           void* ws, const int** perm_out, const int** n_perm_out,
+                                           hipStream_t st);
+extern "C" int lidf_pointnet_lds_max_voxels(void) { return PN_LDS_LIMIT / 512; }
+// scratch of the sort (0: the table is too large for it — the unsorted global-atomic path is taken)
+extern "C" size_t lidf_pointnet_sort_bytes(long long n, long long V) { return lidf_sort_idx_ws_bytes(n, V); }
+
+// One chain stage over the voxel-sorted points: global atomic maxima straight into `pool` ([V, F],
+// zeroed by the caller).
+extern "C" hipError_t lidf_launch_pointnet_chain_sorted(int stage, const float* stream, const float* inp,
+                                                        const int* vox, const float* gpart, float* pool,
+                                                        long long V, long long n_cap, const int* perm,
+                                                        const int* n_perm, int cus, hipStream_t st) {
+    if (n_cap <= 0) return hipSuccess;
+    PnetChainArgs a;
+    a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
+    a.part = nullptr; a.V = (int)V; a.copies = 0;
+    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0;
+    a.n_perm = n_perm; a.perm = perm; a.window = PN_WINDOW;
+    const int F = stage == 1 ? 64 : 128;
+    const size_t wl = (size_t)PN_WINDOW * F * 4;
+    const long long ntile = (n_cap + 127) / 128;
+    const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
+    if (stage == 1)
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), wl, st, a);
+    else
+        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), wl, st, a);
     return hipGetLastError();
 }

@@ -1180,8 +1180,10 @@ extern "C" size_t lidf_seg_sum_idx_ws_bytes(long long P, long long V) {
 
 __global__ void __launch_bounds__(256) lidf_seg_hist_kernel(const int* __restrict__ idx, long long P,
                                                             int V, long long per_blk, int nblk,
-                                                            int* __restrict__ histT) {
+                                                            int* __restrict__ histT,
+                                                            const int* __restrict__ n_dev) {
     extern __shared__ int s_cnt[];
+    if (n_dev) P = *n_dev;   // device-side length (P = the capacity the blocks were cut for)
     for (int i = threadIdx.x; i < V; i += 256) s_cnt[i] = 0;
     __syncthreads();
     const long long p0 = blockIdx.x * per_blk;
@@ -1200,8 +1202,10 @@ __global__ void __launch_bounds__(256) lidf_seg_hist_kernel(const int* __restric
 __global__ void __launch_bounds__(64) lidf_seg_place_kernel(const int* __restrict__ idx, long long P,
                                                             int V, int nbits, long long per_blk,
                                                             int nblk, const int* __restrict__ scanned,
-                                                            int* __restrict__ perm) {
+                                                            int* __restrict__ perm,
+                                                            const int* __restrict__ n_dev) {
     extern __shared__ int s_cur[];
+    if (n_dev) P = *n_dev;
     for (int i = threadIdx.x; i < V; i += 64) s_cur[i] = scanned[(size_t)i * nblk + blockIdx.x];
     __syncthreads();
     const long long p0 = blockIdx.x * per_blk;
@@ -1321,11 +1325,11 @@ extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, lo
     int nbits = 0;
     while ((1LL << nbits) < V) ++nbits;
     hipLaunchKernelGGL(lidf_seg_hist_kernel, dim3((unsigned)s.nblk), dim3(256), (size_t)V * 4, st, idx,
-                       P, (int)V, s.per_blk, (int)s.nblk, hist);
+                       P, (int)V, s.per_blk, (int)s.nblk, hist, (const int*)nullptr);
     hipError_t e = lidf_launch_scan(hist, s.nscan, scanned, (int*)(w + s.sums), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lidf_seg_place_kernel, dim3((unsigned)s.nblk), dim3(64), (size_t)V * 4, st, idx,
-                       P, (int)V, nbits, s.per_blk, (int)s.nblk, scanned, perm);
+                       P, (int)V, nbits, s.per_blk, (int)s.nblk, scanned, perm, (const int*)nullptr);
     hipLaunchKernelGGL(lidf_seg_chunks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
                        scanned, (int)V, (int)s.nblk, P, cnt);
     e = lidf_launch_scan(cnt, V, first, (int*)(w + s.sums2), st);
@@ -1333,6 +1337,38 @@ extern "C" hipError_t lidf_launch_seg_sum_idx(const float* S, const int* idx, lo
     hipLaunchKernelGGL(lidf_seg_chunk_sum_kernel, dim3((unsigned)s.max_chunks), dim3(256), 0, st, S,
                        perm, scanned, first, (int)V, (int)s.nblk, partial);
     hipLaunchKernelGGL(lidf_seg_final_kernel, dim3((unsigned)V), dim3(64), 0, st, partial, first, out);
+    return hipGetLastError();
+}
+
+// The counting sort above on its own: perm[0 .. n_perm) = the items whose index lies in [0, V), grouped by
+// index, order kept inside a group (the PointNet's voxel-sorted walk over large tables, lidf_pointnet.hip).
+// No global atomics: per-block LDS histograms, a scan over [index][block], a placement pass.
+// V <= 16,384 (the histogram of a block lives in LDS). n_dev (optional): the item count on the device, P
+// then bounds the launches. ws: lidf_sort_idx_ws_bytes(P, V) bytes; perm / n_perm point into it.
+extern "C" size_t lidf_sort_idx_ws_bytes(long long P, long long V) {
+    if (V > 16384 || V <= 0) return 0;
+    const SegPlan s = seg_plan(P, V);
+    return s.cnt;   // hist | scanned | sums | perm
+}
+extern "C" hipError_t lidf_launch_sort_idx(const int* idx, long long P, const int* n_dev, long long V,
+                                           void* ws, const int** perm_out, const int** n_perm_out,
+                                           hipStream_t st) {
+    if (V <= 0 || V > 16384 || P <= 0 || !ws) return hipErrorInvalidValue;
+    const SegPlan s = seg_plan(P, V);
+    char* w = (char*)ws;
+    int* hist = (int*)(w + s.hist);
+    int* scanned = (int*)(w + s.scanned);
+    int* perm = (int*)(w + s.perm);
+    int nbits = 0;
+    while ((1LL << nbits) < V) ++nbits;
+    hipLaunchKernelGGL(lidf_seg_hist_kernel, dim3((unsigned)s.nblk), dim3(256), (size_t)V * 4, st, idx,
+                       P, (int)V, s.per_blk, (int)s.nblk, hist, n_dev);
+    hipError_t e = lidf_launch_scan(hist, s.nscan, scanned, (int*)(w + s.sums), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lidf_seg_place_kernel, dim3((unsigned)s.nblk), dim3(64), (size_t)V * 4, st, idx,
+                       P, (int)V, nbits, s.per_blk, (int)s.nblk, scanned, perm, n_dev);
+    *perm_out = perm;
+    *n_perm_out = scanned + s.nscan;   // the scan's grand total = number of placed items
     return hipGetLastError();
 }
 
