@@ -433,19 +433,34 @@ def e2e(args):
                 pl._mark(marks, "metrics")
             return dd, m
     else:
-        runner = pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr)
-        with torch.no_grad():
-            runner.load(batch, feat)
-            if mode == "graph":
-                runner.capture()
+        # --streams S: S runners (each with its own buffers, packed-weight entries and stream) take the
+        # batches in turn, so that the low-occupancy stretches of one frame (PointNet, per-voxel layers,
+        # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
+        S = max(1, args.streams)
+        runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr) for _ in range(S)]
+        lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
+        for r in runners:
+            with torch.no_grad():
+                r.load(batch, feat)
+                if mode == "graph":
+                    r.capture()
+        runner = runners[0]
+        turn = {"i": 0}
 
         def step(marks=None):
+            k = turn["i"] % S
+            turn["i"] += 1
             with torch.no_grad():
-                pl._mark(marks, "start")
-                runner.run(batch, feat)          # input copies + the frame (+ graph replay)
-                pl._mark(marks, "frame")
-                m = runner.metrics(batch)
-                pl._mark(marks, "metrics")
+                if S == 1:
+                    pl._mark(marks, "start")
+                    runner.run(batch, feat)          # input copies + the frame (+ graph replay)
+                    pl._mark(marks, "frame")
+                    m = runner.metrics(batch)
+                    pl._mark(marks, "metrics")
+                else:
+                    with torch.cuda.stream(lanes[k]):
+                        runners[k].run(batch, feat)
+                        m = runners[k].metrics(batch)
             return None, m
 
     for _ in range(args.warmup):
@@ -480,7 +495,7 @@ def e2e(args):
         "config": {"workload": "secondary: whole evaluation path of %d 240x320 frame(s): valid points, "
                                "occupied voxels, PointNet2Stage, miss rays, compact ray/voxel pairs, fused "
                                "query, 2 x get_pred_refine, eval metrics; geometry-derived ragged scene" % B,
-                   "mode": mode, "host_syncs": syncs,
+                   "mode": mode, "host_syncs": syncs, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV},
         "ms_per_frame": round(elapsed / args.steps * 1e3 / B, 4),

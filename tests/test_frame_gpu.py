@@ -165,3 +165,50 @@ def test_frame_pred_mask_early_exits_and_overflow(cuda):
         small.result()
     with pytest.raises(RuntimeError, match="inference path"):
         small.run(b, feat)                                  # autograd recording: refused
+
+
+def test_frames_pipelined_over_streams(cuda):
+    """Evaluation loops run independent frames: several FrameRunners (own buffers, own packed-weight
+    entries — nothing shared but the read-only modules and inputs) take the frames in turn on their own
+    streams, so one frame's low-occupancy stretches are filled by its neighbour's kernels. Every frame's
+    result must equal what a single runner on the default stream produces."""
+    from implicit_depth_amd import _lib, pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 120, 160
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=2)
+    frames = []
+    for seed in (77, 78, 79, 80, 81, 82):
+        batch, feat = synthetic_batch(B, h, w, seed=seed, hole_frac=1.0 + 0.1 * (seed % 3))
+        frames.append((_dev(batch, cuda), feat.to(cuda)))
+    keys = ("pred_pos", "pred_pos_refine", "pair_pred_pos", "pred_depth_refine", "occ_voxel_feat")
+    ref = []
+    single = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+    with torch.no_grad():
+        for batch, feat in frames:
+            single.run(batch, feat)
+            ok, dd = single.result()
+            assert ok
+            ref.append({k: dd[k].clone() for k in keys})
+    S = 3
+    runners = [pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+               for _ in range(S)]
+    lanes = [torch.cuda.Stream(cuda) for _ in range(S)]
+    torch.cuda.synchronize()
+    got = [None] * len(frames)
+    with torch.no_grad():
+        for rnd in range(0, len(frames), S):
+            for k in range(S):                               # enqueue S frames, one per stream, no sync between
+                with torch.cuda.stream(lanes[k]):
+                    runners[k].run(*frames[rnd + k])
+            for k in range(S):
+                with torch.cuda.stream(lanes[k]):
+                    ok, dd = runners[k].result()
+                    assert ok
+                    got[rnd + k] = {key: dd[key].clone() for key in keys}
+    torch.cuda.synchronize()
+    for g, r in zip(got, ref):
+        for k in keys:
+            assert torch.equal(g[k], r[k]), k
+    # one packed-weight entry per stream and module, none shared
+    assert len(_lib.packed_entries(_lib.PACK_CACHE, models[1])) >= S + 1
