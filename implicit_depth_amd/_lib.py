@@ -226,6 +226,9 @@ PACK_CACHE_REFINE = weakref.WeakKeyDictionary()   # stage-2 IEF (lidf_refine_pac
 FROZEN = weakref.WeakSet()                        # modules whose packed streams the caller froze
 
 
+MAX_STREAM_ENTRIES = 16   # packed entries kept per module (one per stream that used it)
+
+
 class PackedEntry:
     """One packed blob with its device-side guard (lidf_*_pack_guarded_f32). `key` holds only
     host-side configuration (never a parameter version: torch's version counter misses `p.data`
@@ -250,6 +253,8 @@ def packed_entry(cache, owner, key, nbytes, device):
     sid = torch.cuda.current_stream(device).cuda_stream
     e = per[1].get(sid)
     if e is None:
+        while len(per[1]) >= MAX_STREAM_ENTRIES:   # short-lived streams must not pile up ~1 MB entries
+            per[1].pop(next(iter(per[1])))          # (the oldest; a dropped stream's entry is simply re-built)
         blob = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         guard = torch.zeros((lib().lidf_pack_guard_bytes(),), dtype=torch.uint8, device=device)
         e = PackedEntry(key, blob, guard)
