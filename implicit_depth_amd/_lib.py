@@ -91,6 +91,7 @@ class LidfRefineArgs(C.Structure):
         ("pred_pos_out", C.c_void_p), ("end_voxel_id", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("precision", C.c_int32), ("pnet_select", C.c_void_p), ("packed", C.c_void_p),
+        ("ray_l1", C.c_void_p), ("ray_l1_ready", C.c_int32),
     ]
 
 

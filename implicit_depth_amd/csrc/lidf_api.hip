@@ -1179,7 +1179,7 @@ LIDF_API int lidf_pointnet_pack_guarded_f32(const LidfPointNet* w, void* packed,
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
 struct RefineWs {
-    size_t pnet_inp, pnet_vox, inp_embed, end_voxel, vox_feat, off, pnet, dec, voxpart, fact, total;
+    size_t pnet_inp, pnet_vox, inp_embed, end_voxel, vox_feat, off, pnet, dec, voxpart, raypart, fact, total;
 };
 // the IEF of stage 2 with the voxel-feature columns of layer 1 as a per-voxel product (defined below)
 static size_t refine_fact_bytes(int D);
@@ -1187,7 +1187,8 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
                                  int pack_mode, const int* R_dev = nullptr, const int* V_dev = nullptr,
-                                 void* const* ev_rows = nullptr);
+                                 void* const* ev_rows = nullptr, const float* rayfeat = nullptr, int Ed = 0,
+                                 float* raypart = nullptr, bool make_raypart = false);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -1201,6 +1202,7 @@ static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     w.pnet = o;      o += align_up(lidf_pointnet_workspace_bytes(R + Nv, V), 256);
     w.dec = o;       o += align_up(lidf_decoders_workspace_bytes(R, D), 256);
     w.voxpart = o;   o += align_up((size_t)(V > 0 ? V : 1) * LIDF_H1 * 4, 256);
+    w.raypart = o;   o += align_up(r * LIDF_H1 * 4, 256);
     w.fact = o;      o += align_up(refine_fact_bytes(D), 256);
     w.total = o;
     return w;
@@ -1251,8 +1253,11 @@ static int refine_impl(const LidfRefineArgs* q, lidf_stream_t stream, void* cons
                                       128 + Ed, q->multires_views, q->multires, q->pnet_pos_rel,
                                       q->pos_rel, R, pnet_inp + (size_t)Nv * 6, pnet_vox + Nv,
                                       inp_embed, D, end_voxel, q->pnet_select, st));
-    CHECK_HIP(lidf_launch_refine_rows(q->pred_pos, end_voxel, q->voxel_bound, q->rayfeat, 128 + Ed,
-                                      q->multires_views, q->multires, q->pos_rel, R, inp_embed, D, st));
+    // f32: only embed(pos) is a per-iteration operand row — the ROI / direction columns enter layer 1
+    // as a per-ray product (refine_ief_factorised); the split-f16 form keeps whole rows
+    CHECK_HIP(lidf_launch_refine_rows_dev(q->pred_pos, end_voxel, q->voxel_bound, q->rayfeat, 128 + Ed,
+                                          q->multires_views, q->multires, q->pos_rel, R, nullptr, inp_embed, D,
+                                          q->precision == LIDF_PRECISION_F32 ? 1 : 0, st));
     if (ev && ev[0]) CHECK_HIP(hipEventRecord((hipEvent_t)ev[0], st));
     if ((rc = lidf_pointnet_f32(q->pnet, pnet_inp, pnet_vox, R + Nv, V, vox_feat, ws + w.pnet,
                                 lidf_pointnet_workspace_bytes(R + Nv, V), stream)))
@@ -1269,7 +1274,9 @@ static int refine_impl(const LidfRefineArgs* q, lidf_stream_t stream, void* cons
         if ((rc = refine_ief_factorised(q->off, D, vox_feat, V, inp_embed, end_voxel, R, off,
                                         (float*)(ws + w.voxpart),
                                         q->packed ? (char*)q->packed : ws + w.fact, st, q->packed ? 2 : 0,
-                                        nullptr, nullptr, ev ? ev + 2 : nullptr)))
+                                        nullptr, nullptr, ev ? ev + 2 : nullptr, q->rayfeat, Ed,
+                                        q->ray_l1 ? q->ray_l1 : (float*)(ws + w.raypart),
+                                        !(q->ray_l1 && q->ray_l1_ready))))
             return rc;
     } else {
         CHECK_HIP(lidf_launch_refine_gather(vox_feat, end_voxel, R, inp_embed, D, st));
@@ -1350,7 +1357,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
 
 struct FrameWs {
     size_t blk_valid, blk_miss, cell_flag, cell_rank, vox_bid, pt_key, pt_valid, pt_rank, ray_count, scan, pnet,
-        query, inp_embed, off, vox_feat_r, voxpart_r, pos_a, pos_b, pnet_abs, sel, total;
+        query, inp_embed, off, vox_feat_r, voxpart_r, raypart_r, pos_a, pos_b, pnet_abs, sel, total;
 };
 static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pairs, int v_lds,
                         int refine_times) {
@@ -1377,6 +1384,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     f.off = o;        o += rf ? align_up(N * 4, 256) : 0;
     f.vox_feat_r = o; o += rf ? align_up(C * 128 * 4, 256) : 0;
     f.voxpart_r = o;  o += rf ? align_up(C * LIDF_H1 * 4, 256) : 0;
+    f.raypart_r = o;  o += rf ? align_up(N * LIDF_H1 * 4, 256) : 0;
     f.pos_a = o;      o += rf ? align_up(N * 12, 256) : 0;
     f.pos_b = o;      o += rf ? align_up(N * 12, 256) : 0;
     f.pnet_abs = o;   o += rf ? align_up(2 * N * 24, 256) : 0;
@@ -1543,16 +1551,18 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
                                               a->voxel_bound, vox_bid, C, a->ray_bid, a->ray_flat, a->rgb, hw,
                                               a->refine_pnet_pos_rel, N, pn_inp, a->revidx, a->end_voxel_id,
                                               sel, counts, counts + LIDF_FC_VALID_IN, st));
-        // (the ROI and direction columns of a ray's row do not change between the iterations)
+        // (only embed(pos) is a per-iteration operand row: the ROI / direction columns enter layer 1 as a
+        // per-ray product formed once, in the first iteration)
         CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
-                                              inp_embed, D, it == 0 ? 0 : 1, st));
+                                              inp_embed, D, 1, st));
         if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
                                  v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st, sort_cap)))
             return rc;
         if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N, offv,
                                         voxpart_r, (char*)a->packed_refine, st, 2, counts + LIDF_FC_RAYS,
-                                        counts + LIDF_FC_VOX)))
+                                        counts + LIDF_FC_VOX, nullptr, a->rayfeat, Ed,
+                                        (float*)(ws + f.raypart_r), it == 0)))
             return rc;
         const bool last = it == a->refine_times - 1;
         CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, a->refine_offset_range0,
@@ -1735,27 +1745,50 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
     return LIDF_OK;
 }
 
-// scratch of refine_ief_factorised: [layer-1 stream of the per-voxel launch | stream + aux of the chain]
-static size_t refine_fact_bytes(int D) { return linex_stream_bytes(128) + chain_stream_bytes(D - 128); }
+// scratch of refine_ief_factorised: [layer-1 stream of the per-voxel launch | of the per-ray launch (ROI +
+// direction columns, sized for the widest direction embedding) | stream + aux of the chain]
+#define REFINE_RAY_K (128 + 3 + 6 * 16)
+static size_t refine_fact_bytes(int D) {
+    return linex_stream_bytes(128) + linex_stream_bytes(REFINE_RAY_K) + chain_stream_bytes(D - 128);
+}
 
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
-                                 int pack_mode, const int* R_dev, const int* V_dev, void* const* ev_rows) {
+                                 int pack_mode, const int* R_dev, const int* V_dev, void* const* ev_rows,
+                                 const float* rayfeat, int Ed, float* raypart, bool make_raypart) {
+    // Layer 1 of the stage-2 decoder on [vox feat 128 | ROI 128 | embed(pos) E | embed(dir) Ed] as three
+    // partial products: per voxel (W1[:, 0:128] vox_feat[v] + b1 (+c), gathered by the end voxel), per
+    // ray (W1[:, ROI | dir] rayfeat[r]: constant over the refine iterations — the frame path forms it
+    // once per frame) and, per iteration, only the E columns of embed(pos): 7 k-quads instead of 26.
     int rc, cus;
     if ((rc = cu_count(&cus))) return rc;
     const int ld1 = D + (off->is_ief ? 16 : 0);
+    const int E = D - 256 - Ed;
+    if (E < 0 || Ed < 0 || 128 + Ed > REFINE_RAY_K) return LIDF_ERR_UNSUPPORTED;
+    char* s_vox = scratch;
+    char* s_ray = scratch + linex_stream_bytes(128);
+    char* s_chain = s_ray + linex_stream_bytes(REFINE_RAY_K);
     LinEx L = {};
     L.w = off->w1; L.b = off->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
     L.ief = off->is_ief ? off : nullptr;   // bias += c
     L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
     L.n_dev = V_dev;
-    if ((rc = run_linex(L, (float*)scratch, cus, st, pack_mode))) return rc;
+    if ((rc = run_linex(L, (float*)s_vox, cus, st, pack_mode))) return rc;
+    if (make_raypart || pack_mode == 1) {
+        LinEx Lr = {};
+        Lr.w = off->w1; Lr.b = nullptr; Lr.ldw = ld1; Lr.nout = LIDF_H1;
+        Lr.k = 128; Lr.c0 = 128;                 // ROI columns
+        Lr.k1 = Ed; Lr.c1 = 256 + E;             // direction embedding
+        Lr.dcore = D;
+        Lr.X = rayfeat; Lr.ldx = 128 + Ed; Lr.n = R; Lr.out = raypart; Lr.ld_out = LIDF_H1;
+        Lr.n_dev = R_dev;
+        if ((rc = run_linex(Lr, (float*)s_ray, cus, st, pack_mode))) return rc;
+    }
     if (ev_rows && ev_rows[0]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[0], st));   // (benchmarks only)
-    rc = run_chain_train(off, D, rows_map(D - 128, 128, 0, 0, 0), inp_embed + 128, D, R, end_voxel,
-                         nullptr, voxpart, nullptr, nullptr, nullptr, out,
-                         scratch + linex_stream_bytes(128), cus, st, LIDF_MODE_ROWS_GATHER, pack_mode,
-                         R_dev);
+    rc = run_chain_train(off, D, rows_map(E, 256, 0, 0, 0), inp_embed ? inp_embed + 256 : nullptr, D, R,
+                         end_voxel, nullptr, voxpart, raypart, nullptr, nullptr, out, s_chain, cus, st,
+                         LIDF_MODE_ROWS_GATHER, pack_mode, R_dev);
     if (!rc && ev_rows && ev_rows[1]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[1], st));
     return rc;
 }
@@ -1776,7 +1809,8 @@ LIDF_API int lidf_refine_pack_f32(const LidfDecoder* off, int32_t multires, int3
     const int D = 256 + 3 + 6 * multires + 3 + 6 * multires_views;
     JobScope js;
     if ((rc = refine_ief_factorised(off, D, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
-                                    (char*)packed, (hipStream_t)stream, 1)))
+                                    (char*)packed, (hipStream_t)stream, 1, nullptr, nullptr, nullptr, nullptr,
+                                    3 + 6 * multires_views, nullptr, false)))
         return rc;
     CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
     return LIDF_OK;

@@ -812,6 +812,22 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                         for (int i = 0; i < 4; ++i) base[t][4 * g + i] = v[i];
                     }
                 }
+                if constexpr (MODE == LIDF_MODE_ROWS_GATHER) {
+                    // stage 2's IEF: the per-ray part of layer 1 (ROI + direction columns, constant over
+                    // the refine iterations) is a [n, 256] table too — row = the ray itself
+                    if (a.raypart) {
+                        const float* rp = a.raypart + (size_t)(a.pair_ray ? a.pair_ray[pc] : pc) * 256 + 4 * h;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = *(const f32x4*)(rp + 32 * t + 8 * g);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) base[t][4 * g + i] += v[i];
+                            }
+                        }
+                    }
+                }
                 if constexpr (MODE == LIDF_MODE_TRAIN) {
                     const float* rp = a.raypart + (size_t)a.pair_ray[pc] * 256 + 4 * h;
 #pragma unroll

@@ -495,6 +495,8 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         packed = e.blob
     cur = pred_pos.contiguous()
     end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
+    # the per-ray part of the decoder's layer 1 is the same in every iteration: formed by the first call
+    ray_l1 = torch.empty((R, 256), dtype=torch.float32, device=dev) if precision == "f32" and forward_times > 1 else None
     if pnet_select is not None:
         pnet_select = (pnet_select.reshape(-1) != 0).to(torch.uint8).contiguous()
         _lib.require_cuda(pnet_select, names=["pnet_select"])
@@ -521,6 +523,8 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         q.precision = PRECISIONS[precision]
         q.pnet_select = pnet_select.data_ptr() if pnet_select is not None else None
         q.packed = packed.data_ptr() if packed is not None else None
+        q.ray_l1 = ray_l1.data_ptr() if ray_l1 is not None else None
+        q.ray_l1_ready = 1 if (ray_l1 is not None and _ > 0) else 0
         with torch.cuda.device(dev):
             if profile_events is not None:   # benchmarks only: forward_times x 4 hipEvent_t (PointNet, IEF)
                 ev = profile_events[_]

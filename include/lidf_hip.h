@@ -386,6 +386,12 @@ typedef struct LidfRefineArgs {
     /* f32 precision: the IEF's packed weight streams (lidf_refine_pack_f32, built once per
      * parameter version) or NULL = packed inside the call, into the workspace.                  */
     const void* packed;
+    /* optional (f32): [R,256] scratch that carries the per-ray part of the decoder's layer 1
+     * (W1[:, ROI | direction columns] rayfeat[r]: the same for every iteration on these rays) from one
+     * call to the next: the call with ray_l1_ready == 0 fills it, later calls with ray_l1_ready != 0
+     * read it. NULL = formed inside every call.                                                     */
+    float* ray_l1;
+    int32_t ray_l1_ready;
 } LidfRefineArgs;
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
 size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views);
