@@ -820,14 +820,15 @@ def main():
                     "note": "whole step; the path is MFMA-bound (>= 3,000 FLOP per HBM byte)"},
         }
         if rpairs:
-            # stage 2 (2 x get_pred_refine) on its own: the IEF rows kernel (lidf_points_kernel<ROWS_GATHER>,
-            # D = 334: 26 layer-1 k-quads x 8 tiles x 4 + 2 passes x 654 v_mfma_f32_32x32x2 per 32 rays) and
+            # stage 2 (2 x get_pred_refine) on its own: the IEF rows kernel (lidf_points_kernel<ROWS_GATHER>) and
             # the PointNet2Stage pass (two register chains: 44 + 444 matrix instructions per 32 points +
             # the per-voxel layers), HIP events recorded by lidf_refine_profile_f32 on the launch stream
             t_pn = sum(ev.elapsed_ms(it[0], it[1]) for st_ in rpairs for it in st_) / args.steps / 2
             t_ief = sum(ev.elapsed_ms(it[2], it[3]) for st_ in rpairs for it in st_) / args.steps / 2
             R = scene["R"]
-            f_ief = (26 * 8 * 4 + 2 * 654) * 4096 / 32.0            # issued FLOP per ray and iteration
+            # issued per 32 rays and iteration: 7 layer-1 k-quads (embed(pos); the ROI / direction columns are
+            # a per-ray product formed once per call) x 8 tiles x 4 + 2 passes x 654 v_mfma_f32_32x32x2
+            f_ief = (7 * 8 * 4 + 2 * 654) * 4096 / 32.0
             n_pn = refine.n_valid + R
             f_pn = (44 + 444) * 4096 / 32.0                          # issued FLOP per PointNet point
             a_ief, a_pn = f_ief * R / (t_ief * 1e-3) / 1e12, f_pn * n_pn / (t_pn * 1e-3) / 1e12
