@@ -1394,7 +1394,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
 }
 
 static int frame_lds_voxels(int32_t v, size_t C) {
-    int l = v > 0 ? v : 128;
+    int l = v > 0 ? v : 128;   // (pipeline.FrameRunner passes 288 for single frames, 128 for batches)
     if (l > 288) l = 288;
     if ((size_t)l > C) l = (int)C;
     return l < 1 ? 1 : l;

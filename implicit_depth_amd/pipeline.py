@@ -233,7 +233,7 @@ class FrameRunner:
     grid); a frame with more pairs raises in result()."""
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
-                 offset_dec_refine=None, max_pairs=None, lds_voxels=128):
+                 offset_dec_refine=None, max_pairs=None, lds_voxels=None):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -260,7 +260,10 @@ class FrameRunner:
         N, Cc = bs * h * w, bs * self.res[0] * self.res[1] * self.res[2]
         self.N, self.Cc = N, Cc
         self.max_pairs = int(max_pairs) if max_pairs else 32 * N
-        self.lds_voxels = int(lds_voxels)
+        # bound of the PointNet's LDS pooling tables. One frame: 288 (the largest table that fits; a frame
+        # with more occupied voxels falls to per-point global atomics, +0.3 ms) at 1.5 % over the 128 that
+        # lets two workgroups share a CU; batches: 128 (their larger tables take the voxel-sorted walk)
+        self.lds_voxels = int(lds_voxels) if lds_voxels else (288 if bs == 1 else 128)
         Ed = 3 + 6 * opt.multires_views
         dev = self.dev
         f32 = dict(dtype=torch.float32, device=dev)

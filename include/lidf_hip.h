@@ -464,8 +464,10 @@ typedef struct LidfFrameArgs {
     float refine_offset_range0, refine_offset_range1;
     /* capacities */
     int64_t max_pairs;
-    int32_t lds_voxels;        /* bound of the PointNet's fast pooling path (<= 288; frames with more
-                                  occupied voxels take global atomic maxima); 0 = 128            */
+    int32_t lds_voxels;        /* bound of the PointNet's LDS pooling tables (<= 288). More occupied voxels:
+                                  batch >= 2 walks the points grouped by voxel (counting sort + windowed
+                                  LDS tables), batch == 1 takes per-point global atomic maxima. 0 = 128
+                                  (two workgroups per CU); 288 costs 1.5 % and covers any real frame  */
     /* outputs (device; capacity in brackets: N = batch*height*width, C = batch*res0*res1*res2)   */
     int32_t* counts;           /* [LIDF_FRAME_COUNTS]                                             */
     int32_t *valid_bid, *valid_flat;       /* [N]   image / flat pixel of the selected valid points */
