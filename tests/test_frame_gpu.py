@@ -212,3 +212,47 @@ def test_frames_pipelined_over_streams(cuda):
             assert torch.equal(g[k], r[k]), k
     # one packed-weight entry per stream and module, none shared
     assert len(_lib.packed_entries(_lib.PACK_CACHE, models[1])) >= S + 1
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_frame_fuzz_against_stepwise(cuda, seed):
+    """Randomised shapes / options of the frame path against the stepwise path (bit-equal): batch size,
+    image size (not a multiple of the 1024-pixel workgroups), valid stride, mask type with random
+    predicted masks, use_all_pix, hole sizes (down to no hole at all: no invalid pixel), pair capacity
+    close to the need."""
+    import random
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    rnd = random.Random(1000 + seed)
+    B = rnd.choice([1, 1, 2, 3, 5])
+    h, w = rnd.choice([(24, 32), (37, 53), (48, 64), (60, 81), (96, 128)])
+    stride = rnd.choice([None, 2, 3, 7])
+    mask_type = rnd.choice(["all", "all", "pred"])
+    use_all = rnd.choice([True, False])
+    hole = rnd.choice([0.0, 0.6, 1.0, 1.6])
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=stride, refine_use_all_pix=use_all, mask_type=mask_type)
+    batch, feat = synthetic_batch(B, h, w, seed=200 + seed, hole_frac=max(hole, 1e-3))
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    pm = None
+    if mask_type == "pred":
+        g = torch.Generator().manual_seed(seed)
+        pm = (torch.rand(B, h, w, generator=g) < rnd.choice([0.05, 0.4, 1.0])).float().to(cuda)
+    with torch.no_grad():
+        ok_ref, ref = pl.lidf_forward(batch, feat, models[0], models[1], models[2], opt, pred_mask=pm)
+        if ok_ref:
+            pl.refine_forward(ref, models[3], models[4], opt)
+    need = ref["pair_ray"].shape[0] if ok_ref else 0
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4],
+                            max_pairs=max(need + rnd.choice([0, 1, 100]), 1))
+    with torch.no_grad():
+        runner.run(batch, feat, pm)
+    ok, dd = runner.result()
+    assert ok == ok_ref, (B, h, w, stride, mask_type, use_all, hole)
+    if ok:
+        _compare(dd, ref)
+    else:   # the same early exit: the counts say which
+        c = dd["counts"]
+        assert c["V"] == ref["voxel_bound"].shape[0]
+        if c["V"] > 0:
+            assert c["R"] == ref.get("total_miss_sample_num", 0)
