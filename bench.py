@@ -417,8 +417,6 @@ def e2e(args):
     opt = pl.LidfOptions(valid_stride=max(1, n_valid // (10000 * B)))
     state = {"ws": None}
     mode = args.e2e_mode
-    if mode != "stepwise" and args.precision != "f32":
-        raise SystemExit("--e2e-mode %s is f32 only (use --e2e-mode stepwise for f16x3)" % mode)
     stages = {}
     if mode == "stepwise":
         def step(marks=None):
@@ -437,7 +435,8 @@ def e2e(args):
         # batches in turn, so that the low-occupancy stretches of one frame (PointNet, per-voxel layers,
         # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
         S = max(1, args.streams)
-        runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr) for _ in range(S)]
+        runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision)
+                   for _ in range(S)]
         lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
         for r in runners:
             with torch.no_grad():

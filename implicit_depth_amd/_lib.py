@@ -112,6 +112,7 @@ class LidfFrameArgs(C.Structure):
         ("refine_pos_rel", C.c_int32), ("refine_pnet_pos_rel", C.c_int32),
         ("refine_use_all_pix", C.c_int32),
         ("refine_offset_range0", C.c_float), ("refine_offset_range1", C.c_float),
+        ("precision", C.c_int32),
         ("max_pairs", C.c_int64), ("lds_voxels", C.c_int32),
         ("counts", C.c_void_p),
         ("valid_bid", C.c_void_p), ("valid_flat", C.c_void_p), ("valid_xyz", C.c_void_p),

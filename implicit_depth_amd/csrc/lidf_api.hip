@@ -146,6 +146,8 @@ hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, l
                                    long long, float*, int*, float*, int, int*, const unsigned char*,
                                    hipStream_t);
 hipError_t lidf_launch_refine_gather(const float*, const int*, long long, float*, int, hipStream_t);
+hipError_t lidf_launch_refine_gather_dev(const float*, const int*, long long, const int*, float*, int,
+                                         hipStream_t);
 hipError_t lidf_launch_refine_rows(const float*, const int*, const float*, const float*, int, int, int, int,
                                    long long, float*, int, hipStream_t);
 hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, float, float,
@@ -309,7 +311,8 @@ LIDF_API size_t lidf_decoders_workspace_bytes(int64_t n, int d) {
 
 static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, const LidfDecoder* prob,
                          const LidfDecoder* off, float* out_prob, float* out_off, void* workspace,
-                         size_t workspace_bytes, int precision, lidf_stream_t stream);
+                         size_t workspace_bytes, int precision, lidf_stream_t stream,
+                         const int* n_dev = nullptr);
 
 LIDF_API int lidf_decoders_f32(const float* inp, int64_t n, int d, int64_t ld_inp,
                                  const LidfDecoder* prob, const LidfDecoder* off, float* out_prob,
@@ -329,7 +332,8 @@ LIDF_API int lidf_decoders_split_f32(const float* inp, int64_t n, int d, int64_t
 
 static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, const LidfDecoder* prob,
                          const LidfDecoder* off, float* out_prob, float* out_off, void* workspace,
-                         size_t workspace_bytes, int precision, lidf_stream_t stream) {
+                         size_t workspace_bytes, int precision, lidf_stream_t stream,
+                         const int* n_dev) {
     if (n < 0 || d <= 0 || ld_inp < d) return LIDF_ERR_BAD_ARG;
     if (d > (1 << 20)) return LIDF_ERR_UNSUPPORTED;
     if (!prob && !off) return LIDF_ERR_BAD_ARG;
@@ -365,6 +369,7 @@ static int decoders_impl(const float* inp, int64_t n, int d, int64_t ld_inp, con
     a.l1_quads = lay.l1_quads;
     a.net_quads = lay.net_quads;
     a.n = n;
+    a.n_dev = n_dev;   // optional device-side row count (the frame path; n = capacity)
     for (int i = 0; i < nets; ++i) fill_net_args(a, i, ds[i], outs[i], 0);
     a.X = inp;
     a.ldx = ld_inp;
@@ -580,7 +585,7 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
                       lidf_stream_t stream, const int* dims = nullptr) {
     if (!q) return LIDF_ERR_BAD_ARG;
-    if (dims && (q->precision != LIDF_PRECISION_F32 || !q->packed)) return LIDF_ERR_UNSUPPORTED;
+    if (dims && !q->packed) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
     if (R < 0 || P < 0 || V < 0) return LIDF_ERR_BAD_ARG;
     // 32-bit lane offsets in the kernels: 12 R bytes of ray directions must fit
@@ -1357,7 +1362,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
 
 struct FrameWs {
     size_t blk_valid, blk_miss, cell_flag, cell_rank, vox_bid, pt_key, pt_valid, pt_rank, ray_count, scan, pnet,
-        query, inp_embed, off, vox_feat_r, voxpart_r, raypart_r, pos_a, pos_b, pnet_abs, sel, total;
+        query, inp_embed, off, vox_feat_r, voxpart_r, raypart_r, pos_a, pos_b, pnet_abs, sel, dec, total;
 };
 static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pairs, int v_lds,
                         int refine_times) {
@@ -1389,6 +1394,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     f.pos_b = o;      o += rf ? align_up(N * 12, 256) : 0;
     f.pnet_abs = o;   o += rf ? align_up(2 * N * 24, 256) : 0;
     f.sel = o;        o += rf ? align_up(N, 256) : 0;
+    f.dec = o;        o += rf ? align_up(lidf_decoders_workspace_bytes((int64_t)N, Dmax), 256) : 0;   // split-f16 IEF
     f.total = o;
     return f;
 }
@@ -1425,11 +1431,12 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         !a->pair_pred_pos || !a->max_pair_id || !a->pred_pos || !a->rayfeat || !a->pred_depth)
         return LIDF_ERR_BAD_ARG;
     const bool rf = a->refine_times > 0;
-    if (rf && (!a->pnet_refine || !a->off_refine || !a->packed_refine || !a->pred_pos_refine ||
+    const bool split = a->precision == LIDF_PRECISION_F16X3;
+    if (rf && (!a->pnet_refine || !a->off_refine || (!split && !a->packed_refine) || !a->pred_pos_refine ||
                !a->end_voxel_id || !a->pred_depth_refine))
         return LIDF_ERR_BAD_ARG;
     int rc, cus;
-    if ((rc = check_query_model(a->prob, a->off, a->multires, a->multires_views, LIDF_PRECISION_F32))) return rc;
+    if ((rc = check_query_model(a->prob, a->off, a->multires, a->multires_views, a->precision))) return rc;
     if (rf && (rc = check_decoder(a->off_refine))) return rc;
     if ((rc = cu_count(&cus))) return rc;
     const int v_lds = frame_lds_voxels(a->lds_voxels, (size_t)C);
@@ -1517,7 +1524,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         q.workspace = ws + f.query;
         q.workspace_bytes = lidf_query_workspace_bytes(N, C, (int64_t)B * 32 * h * w);
         q.rayfeat_out = a->rayfeat;
-        q.precision = LIDF_PRECISION_F32;
+        q.precision = a->precision;
         q.packed = a->packed_query;
         if ((rc = query_impl(&q, nullptr, nullptr, stream, counts))) return rc;
     }
@@ -1555,15 +1562,22 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         // per-ray product formed once, in the first iteration)
         CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
-                                              inp_embed, D, 1, st));
+                                              inp_embed, D, split ? 0 : 1, st));
         if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
                                  v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st, sort_cap)))
             return rc;
-        if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N, offv,
-                                        voxpart_r, (char*)a->packed_refine, st, 2, counts + LIDF_FC_RAYS,
-                                        counts + LIDF_FC_VOX, nullptr, a->rayfeat, Ed,
-                                        (float*)(ws + f.raypart_r), it == 0)))
+        if (split) {   // split-f16 products: whole decoder rows (voxel feature gathered), packed per call
+            CHECK_HIP(lidf_launch_refine_gather_dev(vox_feat_r, a->end_voxel_id, N, counts, inp_embed, D, st));
+            if ((rc = decoders_impl(inp_embed, N, D, D, nullptr, a->off_refine, nullptr, offv, ws + f.dec,
+                                    lidf_decoders_workspace_bytes(N, D), LIDF_PRECISION_F16X3, stream,
+                                    counts + LIDF_FC_RAYS)))
+                return rc;
+        } else if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N,
+                                               offv, voxpart_r, (char*)a->packed_refine, st, 2,
+                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, nullptr, a->rayfeat,
+                                               Ed, (float*)(ws + f.raypart_r), it == 0))) {
             return rc;
+        }
         const bool last = it == a->refine_times - 1;
         CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, a->refine_offset_range0,
                                                 a->refine_offset_range1 - a->refine_offset_range0, N, counts,

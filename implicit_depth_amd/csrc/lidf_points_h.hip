@@ -585,7 +585,8 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
     // issue arbitration), and with a static split the younger one would run the tail alone.
     // Every wavefront of the workgroup runs the same tiles (the stream is shared); out-of-range
     // points are clamped.
-    const long long ntile = (a.n + 127) / 128;
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;   // device-side count (the frame path)
+    const long long ntile = (AN + 127) / 128;
     int* const grab_slot = (int*)(sb + LDS_STREAM_ELEMS + 4 * NK1 * 64);
     // geometry that is only needed again at the end of the tile (the offset net's output, the next
     // tile's indices) waits in LDS instead of occupying registers through every pass
@@ -610,7 +611,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
 
     // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
     auto load_idx = [&](long long tile, GeoH& g) {
-        const long long last = a.n - 1;
+        const long long last = AN - 1;
         long long t0 = tile * 128;                  // uniform
         if (t0 > last) t0 = last & ~127LL;          // a prefetch past the end re-reads the last tile
         const long long rem = last - t0;
@@ -647,7 +648,7 @@ __global__ void __launch_bounds__(256, 2) lidf_points_h_kernel(PointsArgs a) {
     for (long long tile = tb; tile < te_; ++tile) {
         PROF(0)
         const long long p = tile * 128 + wave * 32 + col;
-        const bool valid = p < a.n;
+        const bool valid = p < AN;
         load_dir(nxt);
         load_idx(tile + 2, nx2);
         // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the leave

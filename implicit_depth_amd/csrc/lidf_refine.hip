@@ -224,7 +224,9 @@ extern "C" hipError_t lidf_launch_refine_rows_dev(const float* pred_pos, const i
 // inp_embed[r, 0:128] = occ_voxel_feat[end_voxel[r]]  (pipeline.py:1016); one thread per float4
 __global__ void lidf_refine_gather_kernel(const float* __restrict__ vox_feat,
                                           const int* __restrict__ end_voxel, long long R,
-                                          float* __restrict__ inp_embed, int ld_e) {
+                                          float* __restrict__ inp_embed, int ld_e,
+                                          const int* __restrict__ R_dev) {
+    if (R_dev) R = *R_dev;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * 32) return;
     const long long r = i / 32;
@@ -257,13 +259,18 @@ __global__ void lidf_refine_finish_kernel(const float* __restrict__ pred_pos,
     out[3 * r + 2] = pred_pos[3 * r + 2] + s * ray_dir[3 * r + 2];
 }
 
+extern "C" hipError_t lidf_launch_refine_gather_dev(const float* vox_feat, const int* end_voxel,
+                                                    long long R, const int* R_dev, float* inp_embed,
+                                                    int ld_e, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_gather_kernel, dim3((unsigned)((R * 32 + 255) / 256)),
+                       dim3(256), 0, st, vox_feat, end_voxel, R, inp_embed, ld_e, R_dev);
+    return hipGetLastError();
+}
 extern "C" hipError_t lidf_launch_refine_gather(const float* vox_feat, const int* end_voxel,
                                                 long long R, float* inp_embed, int ld_e,
                                                 hipStream_t st) {
-    if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_refine_gather_kernel, dim3((unsigned)((R * 32 + 255) / 256)),
-                       dim3(256), 0, st, vox_feat, end_voxel, R, inp_embed, ld_e);
-    return hipGetLastError();
+    return lidf_launch_refine_gather_dev(vox_feat, end_voxel, R, nullptr, inp_embed, ld_e, st);
 }
 
 extern "C" hipError_t lidf_launch_refine_finish(const float* pred_pos, const float* off,

@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) lidf_rows_h_kernel(PointsArgs a) {
     c.npass1 = a.npass[1];
     const int nks = c.nk1;
 
-    const long long ntile = (a.n + 127) / 128;
+    const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;   // device-side count (the frame path)
+    const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
     const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
     const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
@@ -410,8 +411,8 @@ __global__ void __launch_bounds__(256) lidf_rows_h_kernel(PointsArgs a) {
 
     for (long long tile = tb; tile < te_; ++tile) {
         const long long p = tile * 128 + wave * 32 + col;
-        const bool valid = p < a.n;
-        const long long pc = valid ? p : a.n - 1;
+        const bool valid = p < AN;
+        const long long pc = valid ? p : AN - 1;
         // this lane's operand columns in k-step ks: 16ks + 8h + {0..7}; column D = 1 (bias)
         const float* xrow = a.X + (size_t)pc * a.ldx + 8 * h;
         auto load_x = [&](int ks, f32x4 (&x)[2]) {

@@ -228,12 +228,14 @@ class FrameRunner:
 
     result() gives the reference's data_dict keys as views of the capacity buffers (int32 index
     tensors; `reference_dtypes=True` adds the int64 forms). mask_type 'all' / 'pred', every valid
-    pixel or every opt.valid_stride-th; intersect_pos_type 'abs' (the shipped configs); f32.
+    pixel or every opt.valid_stride-th; intersect_pos_type 'abs' (the shipped configs); precision "f32"
+    or "f16x3" (as lidf_query / lidf_refine).
     max_pairs bounds the pair list (default 32 per pixel: a ray crosses at most 25 cells of the 9^3
     grid); a frame with more pairs raises in result()."""
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
-                 offset_dec_refine=None, max_pairs=None, lds_voxels=None):
+                 offset_dec_refine=None, max_pairs=None, lds_voxels=None,
+                 precision="f32"):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -244,6 +246,9 @@ class FrameRunner:
             raise RuntimeError("FrameRunner: intersect_pos_type 'abs' only (use lidf_forward for 'rel')")
         if opt.mask_type not in ("all", "pred"):
             raise NotImplementedError("mask_type %s" % opt.mask_type)
+        if precision not in Q.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(Q.PRECISIONS))
+        self.precision = precision
         self.bs, self.h, self.w, self.dev = bs, h, w, torch.device(device)
         self.mods = (pnet_model, prob_dec, offset_dec, pnet_model_refine, offset_dec_refine)
         _check_supported(prob_dec), _check_supported(offset_dec), check_pointnet(pnet_model)
@@ -364,7 +369,7 @@ class FrameRunner:
         dp, do = _decoder_struct(prob, keep), _decoder_struct(off, keep)
         pn = pointnet_struct(pnet, keep)
         keep.append(packed_pointnet(pnet, pn, self.dev))
-        packed_q = _packed_weights(prob, off, opt.multires, opt.multires_views, "f32", dp, do, self.dev)
+        packed_q = _packed_weights(prob, off, opt.multires, opt.multires_views, self.precision, dp, do, self.dev)
         a = _lib.LidfFrameArgs()
         a.batch, a.height, a.width = self.bs, self.h, self.w
         for k in ("rgb", "xyz_corrupt", "valid_mask", "intr", "feat_grid"):
@@ -379,21 +384,25 @@ class FrameRunner:
         a.multires, a.multires_views, a.roi_inp_bbox, a.pos_rel = opt.multires, opt.multires_views, opt.roi_inp_bbox, 0
         a.offset_range0, a.offset_range1 = float(opt.offset_range[0]), float(opt.offset_range[1])
         a.refine_times = self.times
+        a.precision = Q.PRECISIONS[self.precision]
         if self.refine:
             from .query import PRECISIONS  # noqa: F401
             dr = _decoder_struct(off_r, keep)
             pr = pointnet_struct(pnet_r, keep)
             keep.append(packed_pointnet(pnet_r, pr, self.dev))
             L = _lib.lib()
-            e = _lib.packed_entry(_lib.PACK_CACHE_REFINE, off_r, (opt.multires, opt.multires_views, str(self.dev)),
-                                  L.lidf_refine_pack_bytes(opt.multires, opt.multires_views), self.dev)
-            if not (off_r in _lib.FROZEN and e.frozen_ready):
-                with torch.cuda.device(self.dev):
-                    _lib.check(L.lidf_refine_pack_guarded_f32(
-                        C.byref(dr), opt.multires, opt.multires_views, _lib.ptr(e.blob), e.blob.numel(),
-                        _lib.ptr(e.guard), _lib.current_stream(self.dev)))
-                e.frozen_ready = off_r in _lib.FROZEN
-            a.pnet_refine, a.off_refine, a.packed_refine = C.pointer(pr), C.pointer(dr), e.blob.data_ptr()
+            a.pnet_refine, a.off_refine, a.packed_refine = C.pointer(pr), C.pointer(dr), None
+            if self.precision == "f32":   # (the split-f16 IEF packs its rows stream inside the call)
+                e = _lib.packed_entry(_lib.PACK_CACHE_REFINE, off_r,
+                                      (opt.multires, opt.multires_views, str(self.dev)),
+                                      L.lidf_refine_pack_bytes(opt.multires, opt.multires_views), self.dev)
+                if not (off_r in _lib.FROZEN and e.frozen_ready):
+                    with torch.cuda.device(self.dev):
+                        _lib.check(L.lidf_refine_pack_guarded_f32(
+                            C.byref(dr), opt.multires, opt.multires_views, _lib.ptr(e.blob), e.blob.numel(),
+                            _lib.ptr(e.guard), _lib.current_stream(self.dev)))
+                    e.frozen_ready = off_r in _lib.FROZEN
+                a.packed_refine = e.blob.data_ptr()
             a.refine_pos_rel = int(opt.refine_intersect_pos_type == "rel")
             a.refine_pnet_pos_rel = int(opt.refine_pnet_pos_type == "rel")
             a.refine_use_all_pix = int(bool(opt.refine_use_all_pix) or opt.mask_type != "all")

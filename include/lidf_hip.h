@@ -423,7 +423,7 @@ int lidf_refine_profile_f32(const LidfRefineArgs* args, void* ev_pnet_begin, voi
  * max_pairs (a ray crosses at most res0+res1+res2-2 cells of the grid; when a frame has more pairs
  * than max_pairs the list is cut, counts[7] bit 0 is set and the cut rays' results are invalid).
  * Output arrays must hold the capacities; entries beyond the counts are unspecified.
- * f32 precision only; the packed weight streams are mandatory (lidf_*_pack_guarded_f32).          */
+ * The packed weight streams are mandatory (lidf_*_pack_guarded_f32).                              */
 #define LIDF_FRAME_COUNTS 8
 #define LIDF_FC_RAYS 0        /* R:   queried pixels (miss rays)                               */
 #define LIDF_FC_PAIRS 1       /* P:   (ray, occupied voxel) pairs                              */
@@ -462,6 +462,9 @@ typedef struct LidfFrameArgs {
     const void* packed_refine;         /* lidf_refine_pack(_guarded)_f32 blob                     */
     int32_t refine_pos_rel, refine_pnet_pos_rel, refine_use_all_pix;
     float refine_offset_range0, refine_offset_range1;
+    int32_t precision;         /* LIDF_PRECISION_F32 (0) / LIDF_PRECISION_F16X3: both decoders and the stage-2
+                                  IEF (packed_query must be packed for the same precision; the split-f16
+                                  IEF of stage 2 packs inside the call, packed_refine is not read)        */
     /* capacities */
     int64_t max_pairs;
     int32_t lds_voxels;        /* bound of the PointNet's LDS pooling tables (<= 288). More occupied voxels:

@@ -31,13 +31,13 @@ SAME_INT = ("occ_vox_bid", "revidx", "valid_v_pid", "ray_bid", "ray_flat", "ray_
             "pair_vox", "max_pair_id", "end_voxel_id")
 
 
-def _stepwise(batch, feat, models, opt):
+def _stepwise(batch, feat, models, opt, precision="f32"):
     from implicit_depth_amd import pipeline as pl
     pnet, prob, off, pnet_r, offr = models
     with torch.no_grad():
-        ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt)
+        ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=precision)
         if ok:
-            pl.refine_forward(dd, pnet_r, offr, opt)
+            pl.refine_forward(dd, pnet_r, offr, opt, precision=precision)
     return ok, dd
 
 
@@ -256,3 +256,34 @@ def test_frame_fuzz_against_stepwise(cuda, seed):
         assert c["V"] == ref["voxel_bound"].shape[0]
         if c["V"] > 0:
             assert c["R"] == ref.get("total_miss_sample_num", 0)
+
+
+@pytest.mark.parametrize("shape,graph", [((1, 120, 160), False), ((3, 48, 64), True)])
+def test_frame_split_f16_equals_stepwise(cuda, shape, graph):
+    """precision = "f16x3" through the frame path (split-f16 per-point kernel, per-ray rows kernel and
+    stage-2 IEF with device-side counts) against the stepwise path at the same precision (bit-equal) and
+    against the f32 frame (within the f16x3 accuracy)."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = shape
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=2)
+    batch, feat = synthetic_batch(B, h, w, seed=91)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4],
+                            precision="f16x3")
+    with torch.no_grad():
+        runner.load(batch, feat)
+        if graph:
+            runner.capture()
+        runner.run()
+    ok, dd = runner.result()
+    ok_ref, ref = _stepwise(batch, feat, models, opt, precision="f16x3")
+    assert ok and ok_ref
+    _compare(dd, ref)
+    ok32, d32 = _stepwise(batch, feat, models, opt)
+    for k in ("pred_offset", "pred_prob_end"):
+        assert (dd[k] - d32[k]).abs().max().item() <= 2e-5, k
+    same = dd["max_pair_id"] == d32["max_pair_id"]          # (a float-noise tie may pick another pair)
+    assert (~same).sum().item() <= 2
+    assert (dd["pred_pos_refine"] - d32["pred_pos_refine"])[same].abs().max().item() <= TOL
