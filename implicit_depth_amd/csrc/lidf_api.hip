@@ -96,8 +96,8 @@ size_t lidf_pointnet_chain_stream_bytes(void);
 hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int*, const float*, float*,
                                       float*, long long, long long, int, hipStream_t);
 size_t lidf_pointnet_pool_scratch_bytes(long long);
-hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const float*, const float*,
-                                   long long, float, float*, float*, int, float*, int, hipStream_t);
+hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const unsigned*,
+                                   const unsigned*, long long, float, float*, float*, int, float*, int, hipStream_t);
 hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
                                    float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_ief_tail(const float*, const float*, const float*, int, const float*,
@@ -1716,7 +1716,7 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
 
 // partial blocks of the weight-gradient reduction: 512 row slices x (128 x 256 block + its bias part)
 #define WG_SCRATCH_FLOATS ((size_t)512 * (128 * 256 + 128))
-#define ACT_ROW_FLOATS (LIDF_H1 + LIDF_H2 + LIDF_H3 + 1)   // per row and pass: H1 | H2 | H3 | offset in
+#define ACT_ROW_FLOATS LIDF_ACT_ROW_FLOATS   // per row and pass: H1 | H2 | H3 | offset in | sign words (lidf_device.h)
 
 LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
     if (n <= 0 || n_pass <= 0) return 0;
@@ -1872,6 +1872,8 @@ static TrainWs train_ws(int64_t n, int d) {
 }
 LIDF_API size_t lidf_decoder_train_workspace_bytes(int64_t n, int32_t d) { return train_ws(n, d).total; }
 
+static inline const unsigned* act_m1(const float* pass, int64_t n) { return (const unsigned*)(pass + (size_t)n * LIDF_ACT_M1); }
+static inline const unsigned* act_m2(const float* pass, int64_t n) { return (const unsigned*)(pass + (size_t)n * LIDF_ACT_M2); }
 static inline const float* act_h1(const float* act, int64_t n, int k) { return act + (size_t)k * n * ACT_ROW_FLOATS; }
 
 LIDF_API int lidf_decoder_forward_train_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
@@ -1945,7 +1947,7 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         // dZ2 = (dZ3 W3) * lrelu'(Z2), dZ1 = (dZ2 W2) * lrelu'(Z1): one register-chained launch
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, n, 0.02f, dz2, dz1, 0, sbuf, cus, st));
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, n), act_m1(h1, n), n, 0.02f, dz2, dz1, 0, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
         L.mask_src = nullptr;
@@ -2271,7 +2273,7 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
         if (npass == 1) S = dz1;
         const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
         float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, h2, h1, P, 0.02f, dz2, dz1k,
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, P), act_m1(h1, P), P, 0.02f, dz2, dz1k,
                                           first_pass_short ? 1 : 0, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         if (!first_pass_short)

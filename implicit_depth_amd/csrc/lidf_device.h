@@ -36,6 +36,12 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 #define LIDF_H1 256   // gf_dim*4
 #define LIDF_H2 128   // gf_dim*2
 #define LIDF_H3 64    // gf_dim
+// Activations the training forward keeps, per pass and n rows, as plane offsets in floats per row:
+// H1 [n,256] | H2 [n,128] | H3 [n,64] | offset in [n] | sign words of H1 [n,8] | of H2 [n,4]
+#define LIDF_ACT_OIN (LIDF_H1 + LIDF_H2 + LIDF_H3)
+#define LIDF_ACT_M1 (LIDF_ACT_OIN + 1)
+#define LIDF_ACT_M2 (LIDF_ACT_M1 + 8)
+#define LIDF_ACT_ROW_FLOATS (LIDF_ACT_M2 + 4)
 #define LIDF_RING 8
 #define LIDF_L2_QUADS 33   // per output tile: (128 k-steps + 1 bias k-step) / 4, rounded up
 #define LIDF_L3_QUADS 17   // per output tile: (64 k-steps + 1 bias k-step) / 4, rounded up
@@ -178,9 +184,9 @@ struct PointsArgs {
     int dyn_min_tiles;      // fused f32 kernel: dynamic hand-out from this many wave-tiles per wavefront (0: 32)
     int dyn_chunk;          // ... in chunks of this many wave-tiles (0: LIDF_CHUNK)
     // LIDF_MODE_TRAIN (one net): X = the per-pair layer-1 operand rows, voxpart[pair_vox] and
-    // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in at
-    // tr_passes + k * tr_pass_floats ([n,256] | [n,128] | [n,64] | [n]), the pre-activation
-    // output goes to tr_pre [n]
+    // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in | sign words at
+    // tr_passes + k * tr_pass_floats (the LIDF_ACT_* planes above), the pre-activation output
+    // goes to tr_pre [n]
     // (per net; the fused training forward keeps both nets' activations in one launch)
     float* tr_passes[2];
     long long tr_pass_floats;

@@ -3,7 +3,8 @@
 // Backward of models/implicit_net.py:84-90 (IMNet) / :142-146 (IEF), per pass:
 //   dZ2 = (dZ3 W3) * lrelu'(Z2)        [n,64]  -> [n,128]
 //   dZ1 = (dZ2 W2) * lrelu'(Z1)        [n,128] -> [n,256]
-// with lrelu'(Z) read off the kept activations (H > 0 ? 1 : slope; H and Z have the same sign).
+// with lrelu'(Z) read off the sign words the training forward keeps beside the activations (one bit
+// per value, H > 0; H and Z have the same sign: 48 bytes per row instead of the 1.5 KB of H2 | H1).
 // Layer by layer this was two launches of the generic linear kernel, dZ2 written and read back;
 // here a wavefront keeps its 32 rows in the accumulator layout of the forward chain
 // (lidf_points.hip): the 32 x 32 output tile of a layer IS the B operand of the next layer's matrix
@@ -16,8 +17,8 @@
 //   layer A (K = 64, 4 output tiles): quad = 16 pair + 2 kq + t      (kq < 8,  tile 2 pair + t)
 //   layer B (K = 128, 8 output tiles): quad = 32 + 32 pair + 2 kq + t (kq < 16)
 // Two output tiles advance together (their accumulate chains interleave), a tile pair is finished —
-// masked, stored — while the next pair multiplies. Per 32 rows: 640 matrix instructions, 3.3 KB of
-// HBM traffic per row (dZ3, H2, H1 in; dZ2, dZ1 out).
+// masked, stored — while the next pair multiplies. Per 32 rows: 640 matrix instructions, 1.8 KB of
+// HBM traffic per row (dZ3 and the sign words in; dZ2, dZ1 out; ACC: + 1 KB, the running sum).
 #include "lidf_device.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -32,8 +33,8 @@
 struct DgradArgs {
     const float* stream;   // DG_QUADS KiB
     const float* dz3;      // [n,64]
-    const float* h2;       // [n,128]
-    const float* h1;       // [n,256]
+    const unsigned* m2;    // [n,4]  sign words of H2 (the training forward's mask_tile, lidf_points.hip)
+    const unsigned* m1;    // [n,8]  ... of H1
     float* dz2;            // [n,128]
     float* dz1;            // [n,256]
     long long n;
@@ -71,15 +72,20 @@ __device__ __forceinline__ void dg_load_tile(const float* row, int T, f32x4 (&m)
 #pragma unroll
     for (int g = 0; g < 4; ++g) m[g] = *(const f32x4*)(row + 32 * T + 8 * g);
 }
-// acc *= (h > 0 ? 1 : slope), stored to row + 32 T
-__device__ __forceinline__ void dg_finish_tile(f32x16& acc, const f32x4 (&m)[4], float slope,
+// lrelu' of value e of tile T from the lane's sign words: bit 31 - (16 (T & 1) + e) of word T / 2
+// (T and e are constants once the step loop is unrolled)
+__device__ __forceinline__ float dg_factor(const unsigned* mk, int T, int e, float slope) {
+    return (mk[T / 2] & (1u << (31 - (16 * (T & 1) + e)))) ? 1.f : slope;
+}
+// acc *= lrelu', stored to row + 32 T
+__device__ __forceinline__ void dg_finish_tile(f32x16& acc, const unsigned* mk, float slope,
                                                float* row, int T) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            acc[4 * g + i] *= m[g][i] > 0.f ? 1.f : slope;
+            acc[4 * g + i] *= dg_factor(mk, T, 4 * g + i, slope);
             o[i] = acc[4 * g + i];
         }
         *(f32x4*)(row + 32 * T + 8 * g) = o;
@@ -116,16 +122,20 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
         const long long pc = p < a.n ? p : a.n - 1;
         const bool valid = p < a.n;
         const float* z3 = a.dz3 + (size_t)pc * LIDF_H3 + 4 * h;
-        const float* h2r = a.h2 + (size_t)pc * LIDF_H2 + 4 * h;
-        const float* h1r = a.h1 + (size_t)pc * LIDF_H1 + 4 * h;
         float* z2 = a.dz2 + (size_t)pc * LIDF_H2 + 4 * h;
         float* z1 = a.dz1 + (size_t)pc * LIDF_H1 + 4 * h;
 
-        // operand of layer A and the mask tiles of its first output pair, one burst. The mask
-        // tiles of a pair (H2 for layer A's two pairs, then H1 for layer B's four) load into the
-        // buffer the pair before last has finished with, a whole pair of matrix work ahead.
+        // operand of layer A and the lane's sign words of H2 / H1 (24 bytes), one burst
         f32x16 B3[2];
-        f32x4 M[2][2][4];   // [buffer][tile of the pair][group]
+        unsigned MK2[2], MK1[4];
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v2 = *(const u32x2*)(a.m2 + (size_t)pc * 4 + 2 * h);
+            const u32x4 v1 = *(const u32x4*)(a.m1 + (size_t)pc * 8 + 4 * h);
+            MK2[0] = v2[0]; MK2[1] = v2[1];
+            MK1[0] = v1[0]; MK1[1] = v1[1]; MK1[2] = v1[2]; MK1[3] = v1[3];
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -135,8 +145,6 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
                 for (int i = 0; i < 4; ++i) B3[t][4 * g + i] = v[i];
             }
         }
-        dg_load_tile(h2r, 0, M[0][0]);
-        dg_load_tile(h2r, 1, M[0][1]);
         SCHED_FENCE();
 
         f32x16 Z2[4];
@@ -152,30 +160,18 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
             }
             if (s < DG_A_QUADS) {
                 const int pair = s / 16, kq = (s % 16) / 2, t = s % 2;
-                if (s == 0) {
-                    dg_load_tile(h2r, 2, M[1][0]);
-                    dg_load_tile(h2r, 3, M[1][1]);
-                }
-                if (s == 16) {
-                    dg_load_tile(h1r, 0, M[0][0]);
-                    dg_load_tile(h1r, 1, M[0][1]);
-                }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int k = 4 * kq + jj;
                     acc[t] = MFMA(aq[jj], B3[k / 16][k % 16], k == 0 ? zero16 : acc[t]);
                 }
                 if (kq == 7) {
-                    dg_finish_tile(acc[t], M[pair][t], a.slope, z2, 2 * pair + t);
+                    dg_finish_tile(acc[t], MK2, a.slope, z2, 2 * pair + t);
                     Z2[2 * pair + t] = acc[t];
                 }
             } else {
                 const int q = s - DG_A_QUADS;
                 const int pair = q / 32, kq = (q % 32) / 2, t = q % 2;
-                if (kq == 0 && t == 0 && pair + 1 < 4) {
-                    dg_load_tile(h1r, 2 * pair + 2, M[(pair + 1) & 1][0]);
-                    dg_load_tile(h1r, 2 * pair + 3, M[(pair + 1) & 1][1]);
-                }
                 if (ACC && kq == 0) dg_load_tile(z1, 2 * pair + t, SB[ACC ? t : 0]);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -190,11 +186,11 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 o[i] = SB[ACC ? t : 0][g][i] +
-                                       acc[t][4 * g + i] * (M[pair & 1][t][g][i] > 0.f ? 1.f : a.slope);
+                                       acc[t][4 * g + i] * dg_factor(MK1, 2 * pair + t, 4 * g + i, a.slope);
                             if (valid) *(f32x4*)(z1 + 32 * (2 * pair + t) + 8 * g) = o;
                         }
                     } else {
-                        dg_finish_tile(acc[t], M[pair & 1][t], a.slope, z1, 2 * pair + t);
+                        dg_finish_tile(acc[t], MK1, a.slope, z1, 2 * pair + t);
                     }
                 }
             }
@@ -204,13 +200,13 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
 }
 
 extern "C" hipError_t lidf_launch_dgrad_chain(const float* w3, const float* w2, const float* dz3,
-                                              const float* h2, const float* h1, long long n,
+                                              const unsigned* m2, const unsigned* m1, long long n,
                                               float slope, float* dz2, float* dz1, int accumulate,
                                               float* stream, int cus, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_pack_dgrad_kernel, dim3(DG_QUADS), dim3(256), 0, st, w3, w2, stream);
     DgradArgs a;
-    a.stream = stream; a.dz3 = dz3; a.h2 = h2; a.h1 = h1; a.dz2 = dz2; a.dz1 = dz1; a.n = n;
+    a.stream = stream; a.dz3 = dz3; a.m2 = m2; a.m1 = m1; a.dz2 = dz2; a.dz1 = dz1; a.n = n;
     a.slope = slope;
     const long long ntile = (n + 127) / 128;
     const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;

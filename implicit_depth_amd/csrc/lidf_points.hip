@@ -269,7 +269,17 @@ struct TrainRow {
     float* h1;
     float* h2;
     float* h3;
+    unsigned* m1;   // sign words of the lane's H1 values (4 words: tiles 2w | 2w+1), see mask_tile
+    unsigned* m2;   // and of its H2 values (2 words)
 };
+// One bit per value, (v > 0): what the backward chain needs of H1 / H2 (lrelu'), 1/32 of the bytes.
+// 0 - v has its sign bit set exactly when v > 0 (+-0 give +0); v_alignbit shifts it in from the
+// right, so value e of tile T ends at bit 31 - (16 (T & 1) + e) of word T / 2.
+__device__ __forceinline__ void mask_tile(unsigned& word, const f32x16& v) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        word = __builtin_amdgcn_alignbit(word, __builtin_bit_cast(unsigned, 0.f - v[e]), 31);
+}
 template <int W>
 __device__ __forceinline__ void store_tile(float* row, const int t, const f32x16& v) {
 #pragma unroll
@@ -307,6 +317,7 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                            0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 H1[8], H2[4], H3[2];
     f32x4 u0, u1, w4[8];
+    unsigned mk1 = 0u, mk2 = 0u;   // ST only: the sign word being filled (stored once its 2 tiles are in)
     f32x4 pend = {0.f, 0.f, 0.f, 0.f};
     float b4 = 0.f;
 #pragma unroll
@@ -344,7 +355,10 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
             u1 = a;
             H1[0] = MFMA(u0[0], ob, base[0]);
             lrelu_part<0, 16>(H1[0]);
-            if (ST) store_tile<0>(tr.h1, 0, H1[0]);
+            if (ST) {
+                store_tile<0>(tr.h1, 0, H1[0]);
+                mask_tile(mk1, H1[0]);
+            }
         } else if (s < S_L3) {
             // ---- layer 2, k-quad major: all four output tiles advance together, so a layer-1
             // tile is produced right before its four k-quads and is dead after them
@@ -353,7 +367,11 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
                 const int T = kq / 4 + 1;   // needed from the next step on
                 H1[T] = MFMA(T < 4 ? u0[T & 3] : u1[T & 3], ob, base[T]);
                 lrelu_part<0, 16>(H1[T]);
-                if (ST) store_tile<0>(tr.h1, T, H1[T]);
+                if (ST) {
+                    store_tile<0>(tr.h1, T, H1[T]);
+                    mask_tile(mk1, H1[T]);
+                    if (T & 1) tr.m1[T / 2] = mk1;
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -367,7 +385,11 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
             }
             if (kq == LIDF_L2_QUADS - 1) {
                 lrelu_part<0, 16>(H2[t]);   // tile complete (bias quad)
-                if (ST) store_tile<0>(tr.h2, t, H2[t]);
+                if (ST) {
+                    store_tile<0>(tr.h2, t, H2[t]);
+                    mask_tile(mk2, H2[t]);
+                    if (t & 1) tr.m2[t / 2] = mk2;
+                }
             }
         } else {
             // ---- layer 3, k-quad major
@@ -698,6 +720,8 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
                     tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
                     tr.h2 = pk + (size_t)AN * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
                     tr.h3 = pk + (size_t)AN * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                    tr.m1 = (unsigned*)(pk + (size_t)AN * LIDF_ACT_M1) + (size_t)pc * 8 + 4 * h;
+                    tr.m2 = (unsigned*)(pk + (size_t)AN * LIDF_ACT_M2) + (size_t)pc * 4 + 2 * h;
                     if (valid && h == 0) pk[(size_t)AN * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = v;
                 }
                 return tr;
@@ -940,6 +964,8 @@ __device__ __forceinline__ void points_rows_body(const PointsArgs& a, const int 
                         tr.h1 = pk + (size_t)pc * LIDF_H1 + 4 * h;
                         tr.h2 = pk + (size_t)AN * LIDF_H1 + (size_t)pc * LIDF_H2 + 4 * h;
                         tr.h3 = pk + (size_t)AN * (LIDF_H1 + LIDF_H2) + (size_t)pc * LIDF_H3 + 4 * h;
+                        tr.m1 = (unsigned*)(pk + (size_t)AN * LIDF_ACT_M1) + (size_t)pc * 8 + 4 * h;
+                        tr.m2 = (unsigned*)(pk + (size_t)AN * LIDF_ACT_M2) + (size_t)pc * 4 + 2 * h;
                         if (valid && h == 0) pk[(size_t)AN * (LIDF_H1 + LIDF_H2 + LIDF_H3) + p] = val;
                     }
                     val += decoder_pass<false, MODE == LIDF_MODE_TRAIN>(
