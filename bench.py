@@ -588,6 +588,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # LIDF_TEST_SHARE_GPU=1 (tests/test_rccl_gpu.py only): every rank on cuda:0 with the gloo backend, so
+    # that the N > 1 logic (shards, gather slots, max-over-ranks clock) runs on a 1-GPU box. Never a
+    # measurement: the ranks share one GPU and the collective goes through host memory.
+    share_gpu = os.environ.get("LIDF_TEST_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even N=1 goes through RCCL
@@ -595,7 +601,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from implicit_depth_amd import IEF, IMNet
     from implicit_depth_amd.dist import all_gather_depth, all_gather_depth_rows

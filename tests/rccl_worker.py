@@ -15,9 +15,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share_gpu = os.environ.get("LIDF_TEST_SHARE_GPU") == "1"   # every rank on cuda:0, gloo (1-GPU box)
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if share_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from implicit_depth_amd.dist import (all_gather_depth, all_gather_depth_ragged, all_gather_depth_rows,
                                          shard_frames, shard_rays, slice_rays)
     from util import orc, run_query

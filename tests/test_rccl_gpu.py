@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_args, port, timeout=600, nproc=1):
+def _torchrun(script_args, port, timeout=600, nproc=1, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
@@ -53,6 +54,27 @@ def test_bench_ray_row_shards_one_rank(cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert "configs[2]" in rec["config"]["workload"] and rec["config"]["points_per_gpu"] == 4 * 240 * 320 * 64
+
+
+def test_two_ranks_sharing_the_gpu(cuda):
+    """world = 2 on the 1-GPU box: both ranks on cuda:0 with gloo as the transport (LIDF_TEST_SHARE_GPU,
+    test-only) — the worker's gathers and the bench's N = 2 logic (frame shards and ray-row shards,
+    gather slots, ranks_seen, per-rank clocks, whole-job point count) on real device buffers."""
+    share = {"LIDF_TEST_SHARE_GPU": "1"}
+    r = _torchrun([os.path.join(ROOT, "tests", "rccl_worker.py")], 29616, nproc=2, extra_env=share)
+    assert r.returncode == 0 and "RCCL_WORKER_OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    for extra, pts in ([], 2 * 240 * 320 * 64), (["--shard", "rays"], 240 * 320 * 64):
+        r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline"] + extra, 29617, nproc=2, extra_env=share)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        rec = json.loads(lines[0])
+        col = rec["collective"]
+        assert rec["n_gpus"] == 2 and col["ranks_seen"] == 2 and len(col["ms_per_step_by_rank"]) == 2
+        assert col["gathered_equals_local"] is True and col["points_all_ranks"] == pts
+        assert abs(rec["value"] - pts / rec["ms_per_step"] / 1e3) <= 0.01 * rec["value"]
+        assert rec["ms_per_step"] >= max(col["ms_per_step_by_rank"]) - 1e-3
 
 
 def _gpus():
