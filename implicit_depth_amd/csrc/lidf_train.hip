@@ -140,15 +140,20 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 // TWO: the block has a second half of 128 columns (N - n0 > 128); without it the four accumulator
 // tiles of that half and their matrix instructions are left out (N = 102 or 128 operands).
-template <bool TWO>
+// HM (not TWO): M <= 64 (layer 3: dW3 = dZ3^T H2, 64 x 128) — the block is 64 x 128, lane (c, h) takes
+// the A columns {2c, 2c+1}, wavefront w the column 2c + (w & 1) and the two column tiles
+// {2 (w >> 1), 2 (w >> 1) + 1}: two matrix instructions per row pair instead of four on a half-empty
+// block (16 rows per step, so that a step is still 16 matrix instructions between barriers).
+template <bool TWO, bool HM>
 __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
-    // 8 rows of A (128 columns) and of B (256 columns) per step, staged once per workgroup through
+    // RS rows of A (128 columns) and of B (256 columns) per step, staged once per workgroup through
     // LDS (double-buffered): the four wavefronts read the same B rows and the same A float4
-    __shared__ f32x4w sA[2][8][32];   // [buffer][row][float4 column]
-    __shared__ f32x4w sB[2][8][64];
+    constexpr int RS = HM ? 16 : 8;
+    __shared__ f32x4w sA[2][RS][HM ? 16 : 32];   // [buffer][row][float4 column]
+    __shared__ f32x4w sB[2][RS][HM ? 32 : 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 256;
+    const int m0 = HM ? 0 : blockIdx.y * 128, n0 = HM ? 0 : blockIdx.z * 256;
     const long long r0 = (long long)blockIdx.x * a.rows_per_split;
     long long r1 = r0 + a.rows_per_split;
     if (r1 > a.n) r1 = a.n;
@@ -157,14 +162,16 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         (void*)(a.A + (size_t)r0 * a.lda), 0, (int)((size_t)nrows * a.lda * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.B + (size_t)r0 * a.ldb), 0, (int)((size_t)nrows * a.ldb * 4), 0x00020000);
-    // staging role of this thread: row tr (0..7) of the step, float4 column tc (A), tc and tc+32 (B)
+    // staging role of this thread: row tr (0..7) of the step, float4 column tc (A), tc and tc+32 (B);
+    // HM: rows tr and tr + 8, A only from the threads tc < 16
     const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
     const bool second = TWO && n0 + 128 < a.N;
-    const int ga = (int)((tr * a.lda + m0 + 4 * tc) * 4);
+    const int ga = (HM && tc >= 16) ? 0x7ffffff0 : (int)((tr * a.lda + m0 + 4 * tc) * 4);
     const int gb0 = (int)((tr * a.ldb + n0 + 4 * tc) * 4);
     const int gb1 = second ? gb0 + 512 : 0x7ffffff0;
-    const int sa = (int)(a.lda * 32), sbb = (int)(a.ldb * 32);  // eight rows
-    constexpr int NT = TWO ? 8 : 4;
+    const int sa = (int)(a.lda * 4 * RS), sbb = (int)(a.ldb * 4 * RS);  // RS rows
+    const int ha = (int)(a.lda * 32), hb = (int)(a.ldb * 32);           // HM: the thread's second row
+    constexpr int NT = HM ? 2 : (TWO ? 8 : 4);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -172,12 +179,30 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     }
     f32x4w asum = {0.f, 0.f, 0.f, 0.f};
-    const int nstep = (nrows + 7) / 8;
+    float asum1 = 0.f;
+    const int nstep = (nrows + RS - 1) / RS;
     f32x4w ga4 = LDX4(ra, ga, 0), gb4 = LDX4(rb, gb0, 0), gc4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4w ga5 = gc4, gb5 = gc4;
     if (TWO) gc4 = LDX4(rb, gb1, 0);
-    sA[0][tr][tc] = ga4;
-    sB[0][tr][tc] = gb4;
-    if (TWO) sB[0][tr][32 + tc] = gc4;
+    if (HM) {
+        ga5 = LDX4(ra, ga, ha);
+        gb5 = LDX4(rb, gb0, hb);
+    }
+    auto stage = [&](int buf) {
+        if (HM) {
+            if (tc < 16) {
+                sA[buf][tr][tc] = ga4;
+                sA[buf][tr + 8][tc] = ga5;
+            }
+            sB[buf][tr][tc] = gb4;
+            sB[buf][tr + 8][tc] = gb5;
+        } else {
+            sA[buf][tr][tc] = ga4;
+            sB[buf][tr][tc] = gb4;
+            if (TWO) sB[buf][tr][32 + tc] = gc4;
+        }
+    };
+    stage(0);
     __syncthreads();
     for (int st = 0; st < nstep; ++st) {
         const int cur = st & 1;
@@ -185,30 +210,51 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
             ga4 = LDX4(ra, ga, (st + 1) * sa);
             gb4 = LDX4(rb, gb0, (st + 1) * sbb);
             if (TWO) gc4 = LDX4(rb, gb1, (st + 1) * sbb);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4w a4 = sA[cur][2 * u + h][c];
-            const f32x4w b0 = sB[cur][2 * u + h][c];
-            f32x4w b1 = b0;
-            if (TWO) b1 = sB[cur][2 * u + h][32 + c];
-            const float aw = wave == 0 ? a4[0] : wave == 1 ? a4[1] : wave == 2 ? a4[2] : a4[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[e] = MFMA(aw, b0[e], acc[e]);
-                if constexpr (TWO) acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
+            if (HM) {
+                ga5 = LDX4(ra, ga, (st + 1) * sa + ha);
+                gb5 = LDX4(rb, gb0, (st + 1) * sbb + hb);
             }
-            asum += a4;
         }
-        if (st + 1 < nstep) {
-            sA[cur ^ 1][tr][tc] = ga4;
-            sB[cur ^ 1][tr][tc] = gb4;
-            if (TWO) sB[cur ^ 1][tr][32 + tc] = gc4;
+        if constexpr (HM) {
+            const float* fa = (const float*)&sA[cur][0][0];
+            const float* fb = (const float*)&sB[cur][0][0];
+#pragma unroll
+            for (int u = 0; u < RS / 2; ++u) {
+                const float aw = fa[(2 * u + h) * 64 + 2 * c + (wave & 1)];
+                const f32x2 b2 = *(const f32x2*)(fb + (2 * u + h) * 128 + 4 * c + 2 * (wave >> 1));
+                acc[0] = MFMA(aw, b2[0], acc[0]);
+                acc[1] = MFMA(aw, b2[1], acc[1]);
+                asum1 += aw;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4w a4 = sA[cur][2 * u + h][c];
+                const f32x4w b0 = sB[cur][2 * u + h][c];
+                f32x4w b1 = b0;
+                if (TWO) b1 = sB[cur][2 * u + h][32 + c];
+                const float aw = wave == 0 ? a4[0] : wave == 1 ? a4[1] : wave == 2 ? a4[2] : a4[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = MFMA(aw, b0[e], acc[e]);
+                    if constexpr (TWO) acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
+                }
+                asum += a4;
+            }
         }
+        if (st + 1 < nstep) stage(cur ^ 1);
         __syncthreads();
     }
     // register q of lane (c, h) in tile e: C row m0 + 4((q&3) + 8(q>>2) + 4h) + wave,
-    // column n0 + 128(e>>2) + 4c + (e&3)
+    // column n0 + 128(e>>2) + 4c + (e&3); HM: row 2(..) + (wave & 1), column 4c + 2(wave >> 1) + e
+    auto c_row = [&](int q) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
+        return HM ? 2 * i + (wave & 1) : 4 * i + wave;
+    };
+    auto c_col = [&](int e) { return HM ? 4 * c + 2 * (wave >> 1) + e : 128 * (e >> 2) + 4 * c + (e & 3); };
+    if (HM) {   // column sums of A: lanes c and c+32 hold the two rows of a pair
+        asum1 += __shfl_xor(asum1, 32);
+    }
     if (a.part) {
         // deterministic path: this block's partial sums go to its own slab, summed by
         // lidf_wgrad_reduce_kernel in a fixed order
@@ -216,12 +262,11 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ml = 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + wave;
-                slab[ml * 256 + 128 * (e >> 2) + 4 * c + (e & 3)] = acc[e][q];
-            }
+            for (int q = 0; q < 16; ++q) slab[c_row(q) * 256 + c_col(e)] = acc[e][q];
         }
-        if (wave == 0) {
+        if (HM) {
+            if (wave < 2 && h == 0) slab[128 * 256 + 2 * c + wave] = asum1;
+        } else if (wave == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = asum[e];
@@ -233,17 +278,20 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
     }
 #pragma unroll
     for (int e = 0; e < NT; ++e) {
-        const int col = n0 + 128 * (e >> 2) + 4 * c + (e & 3);
+        const int col = n0 + c_col(e);
         if (col >= a.N) continue;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int m = m0 + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + wave;
+            const int m = m0 + c_row(q);
             const float v = acc[e][q];
             if (m < a.M && v != 0.f) atomicAdd(a.C + (size_t)m * a.ldc + col, v);
         }
     }
     // bias gradient: column sums of A (first column block only); lanes c and c+32 hold the two rows
-    if (a.db && blockIdx.z == 0 && wave == 0) {
+    if (HM) {
+        const int m = 2 * c + wave;
+        if (a.db && wave < 2 && h == 0 && m < a.M && asum1 != 0.f) atomicAdd(a.db + m, asum1);
+    } else if (a.db && blockIdx.z == 0 && wave == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = asum[e];
@@ -318,16 +366,20 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
         const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
-        w.rows_per_split = ((n + splits - 1) / splits + 7) / 8 * 8;
+        const bool half_m = M <= 64 && N <= 128 && mb == 1 && nb == 1;   // 64 x 128 block (layer 3)
+        const int rs = half_m ? 16 : 8;
+        w.rows_per_split = ((n + splits - 1) / splits + rs - 1) / rs * rs;
         const long long sp = (n + w.rows_per_split - 1) / w.rows_per_split;
         const size_t slice_bytes = (size_t)w.rows_per_split * (size_t)(lda > ldb ? lda : ldb) * 4;
         const size_t need = (size_t)sp * mb * nb * (128 * 256 + 128);
         w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats) ? g_wgrad_scratch : nullptr;
         if (slice_bytes < 0x7fffffffULL) {
-            if (N - (nb - 1) * 256 > 128 || nb > 1)
-                hipLaunchKernelGGL(lidf_wgrad2_kernel<true>, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+            if (half_m)
+                hipLaunchKernelGGL((lidf_wgrad2_kernel<false, true>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+            else if (N - (nb - 1) * 256 > 128 || nb > 1)
+                hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
             else
-                hipLaunchKernelGGL(lidf_wgrad2_kernel<false>, dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
+                hipLaunchKernelGGL((lidf_wgrad2_kernel<false, false>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
             if (w.part)
                 hipLaunchKernelGGL(lidf_wgrad_reduce_kernel, dim3(((128 * 256 + 128) / 4 + 31) / 32, mb * nb),
                                    dim3(256), 0, st, w.part, (int)sp, mb, nb, M, N, C, ldc, db);
