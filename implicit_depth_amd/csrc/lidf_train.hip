@@ -118,10 +118,10 @@ __global__ void __launch_bounds__(256) lidf_wgrad_kernel(WgradArgs a) {
 // Weight gradient for the wide layers: one workgroup = a 128 x 256 block of C over a slice of rows,
 // so A and B stream from HBM once per block instead of once per 64 x 64 tile (the 64-wide tiling
 // re-reads A N/64 times and B M/64 times: 2.5 GB for the 128 x 256 layer at 614,400 rows).
-// Wavefront w owns the C rows {m0 + 4i + w}; every lane loads ONE float4 of A and two of B per row
-// pair — lane (c, h) reads row r+h, columns 4c..4c+3 — and element e of a float4 feeds the matrix
-// instruction of column tile e: the tiles hold the columns {4c + e}, a permutation that the
-// write-back undoes. Rows past the slice / matrix read as 0 through the buffer descriptors;
+// Lane (c, h) reads row r+h, columns 4c..4c+3 of A — element j of that float4 feeds the matrix
+// instructions of row tile j, which therefore holds the C rows {4i + j} — and the B columns
+// {4c + e} of its wavefront's column tiles (wavefront w: tiles {2w, 2w+1} of the 8, or tile w of 4):
+// a permutation of rows and columns that the write-back undoes. Rows past the slice / matrix read as 0 through the buffer descriptors;
 // columns past M / N accumulate garbage that is never stored.
 // ------------------------------------------------------------------------------------------------
 struct Wgrad2Args {
@@ -227,17 +227,24 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
                 asum1 += aw;
             }
         } else {
+            // wavefront w owns ALL 128 rows of the block (row tile j = element j of the A float4) and
+            // the column tiles {2w, 2w+1} (TWO) or {w}: 24 or 20 bytes of LDS per lane and row pair
+            // instead of the 48 of a row-owning split, where every wavefront reads every B value
+            const float* fb = (const float*)&sB[cur][0][0];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const f32x4w a4 = sA[cur][2 * u + h][c];
-                const f32x4w b0 = sB[cur][2 * u + h][c];
-                f32x4w b1 = b0;
-                if (TWO) b1 = sB[cur][2 * u + h][32 + c];
-                const float aw = wave == 0 ? a4[0] : wave == 1 ? a4[1] : wave == 2 ? a4[2] : a4[3];
+                if constexpr (TWO) {
+                    const f32x2 b2 = *(const f32x2*)(fb + (2 * u + h) * 256 + 128 * (wave >> 1) + 4 * c + 2 * (wave & 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[e] = MFMA(aw, b0[e], acc[e]);
-                    if constexpr (TWO) acc[4 + e] = MFMA(aw, b1[e], acc[4 + e]);
+                    for (int j = 0; j < 4; ++j) {
+                        acc[2 * j] = MFMA(a4[j], b2[0], acc[2 * j]);
+                        acc[2 * j + 1] = MFMA(a4[j], b2[1], acc[2 * j + 1]);
+                    }
+                } else {
+                    const float b1 = fb[(2 * u + h) * 256 + 4 * c + wave];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = MFMA(a4[j], b1, acc[j]);
                 }
                 asum += a4;
             }
@@ -245,13 +252,17 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         if (st + 1 < nstep) stage(cur ^ 1);
         __syncthreads();
     }
-    // register q of lane (c, h) in tile e: C row m0 + 4((q&3) + 8(q>>2) + 4h) + wave,
-    // column n0 + 128(e>>2) + 4c + (e&3); HM: row 2(..) + (wave & 1), column 4c + 2(wave >> 1) + e
-    auto c_row = [&](int q) {
+    // register q of lane (c, h), i = (q&3) + 8(q>>2) + 4h, in tile e:
+    //   TWO: C row m0 + 4i + (e>>1), column n0 + 128(wave>>1) + 4c + 2(wave&1) + (e&1)
+    //   else: C row m0 + 4i + e,     column n0 + 4c + wave
+    //   HM:   C row 2i + (wave&1),   column 4c + 2(wave>>1) + e
+    auto c_row = [&](int q, int e) {
         const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
-        return HM ? 2 * i + (wave & 1) : 4 * i + wave;
+        return HM ? 2 * i + (wave & 1) : TWO ? 4 * i + (e >> 1) : 4 * i + e;
     };
-    auto c_col = [&](int e) { return HM ? 4 * c + 2 * (wave >> 1) + e : 128 * (e >> 2) + 4 * c + (e & 3); };
+    auto c_col = [&](int e) {
+        return HM ? 4 * c + 2 * (wave >> 1) + e : TWO ? 128 * (wave >> 1) + 4 * c + 2 * (wave & 1) + (e & 1) : 4 * c + wave;
+    };
     if (HM) {   // column sums of A: lanes c and c+32 hold the two rows of a pair
         asum1 += __shfl_xor(asum1, 32);
     }
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) slab[c_row(q) * 256 + c_col(e)] = acc[e][q];
+            for (int q = 0; q < 16; ++q) slab[c_row(q, e) * 256 + c_col(e)] = acc[e][q];
         }
         if (HM) {
             if (wave < 2 && h == 0) slab[128 * 256 + 2 * c + wave] = asum1;
@@ -282,7 +293,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         if (col >= a.N) continue;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int m = m0 + c_row(q);
+            const int m = m0 + c_row(q, e);
             const float v = acc[e][q];
             if (m < a.M && v != 0.f) atomicAdd(a.C + (size_t)m * a.ldc + col, v);
         }
