@@ -115,36 +115,50 @@ __global__ void __launch_bounds__(256, 2) lidf_dgrad_chain_kernel(DgradArgs a) {
 #pragma unroll
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
 
+    // operand of layer A (dZ3, 2 tiles) and the lane's sign words of H2 / H1 (24 bytes) of a tile: one
+    // burst, requested a whole tile ahead (the next tile's burst goes out as soon as this tile's
+    // registers are free to take it, so its HBM latency passes under this tile's matrix work)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    f32x4 Bn[2][4];
+    u32x2 M2n;
+    u32x4 M1n;
+    auto request = [&](long long tile) {
+        long long p = tile * 128 + wave * 32 + col;
+        if (p >= a.n) p = a.n - 1;
+        const float* z3 = a.dz3 + (size_t)p * LIDF_H3 + 4 * h;
+        M2n = *(const u32x2*)(a.m2 + (size_t)p * 4 + 2 * h);
+        M1n = *(const u32x4*)(a.m1 + (size_t)p * 8 + 4 * h);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Bn[t][g] = *(const f32x4*)(z3 + 32 * t + 8 * g);
+        }
+    };
+    request(tb);
     for (long long tile = tb; tile < te; ++tile) {
         if (tile * 128 + wave * 32 >= a.n) break;   // wave-uniform
         const long long p = tile * 128 + wave * 32 + col;
         // rows beyond n repeat row n-1: same operands, same values stored twice (ACC: not added)
         const long long pc = p < a.n ? p : a.n - 1;
         const bool valid = p < a.n;
-        const float* z3 = a.dz3 + (size_t)pc * LIDF_H3 + 4 * h;
         float* z2 = a.dz2 + (size_t)pc * LIDF_H2 + 4 * h;
         float* z1 = a.dz1 + (size_t)pc * LIDF_H1 + 4 * h;
 
-        // operand of layer A and the lane's sign words of H2 / H1 (24 bytes), one burst
         f32x16 B3[2];
         unsigned MK2[2], MK1[4];
-        {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 v2 = *(const u32x2*)(a.m2 + (size_t)pc * 4 + 2 * h);
-            const u32x4 v1 = *(const u32x4*)(a.m1 + (size_t)pc * 8 + 4 * h);
-            MK2[0] = v2[0]; MK2[1] = v2[1];
-            MK1[0] = v1[0]; MK1[1] = v1[1]; MK1[2] = v1[2]; MK1[3] = v1[3];
-        }
+        MK2[0] = M2n[0]; MK2[1] = M2n[1];
+        MK1[0] = M1n[0]; MK1[1] = M1n[1]; MK1[2] = M1n[2]; MK1[3] = M1n[3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *(const f32x4*)(z3 + 32 * t + 8 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) B3[t][4 * g + i] = v[i];
+                for (int i = 0; i < 4; ++i) B3[t][4 * g + i] = Bn[t][g][i];
             }
         }
+        SCHED_FENCE();
+        if (tile + 1 < te) request(tile + 1);
         SCHED_FENCE();
 
         f32x16 Z2[4];
