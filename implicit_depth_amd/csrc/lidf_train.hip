@@ -337,7 +337,17 @@ __global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __r
     }
     if (used) {
         const float* p = part + ((size_t)bm * nb + bn) * SLAB + 4 * (size_t)e4;
-        for (int sp = k; sp < splits; sp += 8) s += *(const f32x4w*)(p + (size_t)sp * mb * nb * SLAB);
+        // (eight slices in flight per thread: the loop is a chain of independent 16-byte loads a slab apart)
+        const size_t stride = (size_t)mb * nb * SLAB;
+        int sp = k;
+        for (; sp + 56 < splits; sp += 64) {
+            f32x4w v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4w*)(p + (size_t)(sp + 8 * j) * stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; sp < splits; sp += 8) s += *(const f32x4w*)(p + (size_t)sp * stride);
     }
     red[k][threadIdx.x & 31] = s;
     __syncthreads();
