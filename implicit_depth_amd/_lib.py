@@ -127,6 +127,7 @@ class LidfFrameArgs(C.Structure):
         ("rayfeat", C.c_void_p), ("pred_depth", C.c_void_p), ("pred_pos_refine", C.c_void_p),
         ("end_voxel_id", C.c_void_p), ("pred_depth_refine", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("valid_idx_bid", C.c_void_p), ("valid_idx_flat", C.c_void_p), ("n_valid_idx", C.c_int64),
     ]
 
 

@@ -80,7 +80,7 @@ hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float
 hipError_t lidf_launch_frame_head(const float*, const float*, const float*, const float*, const float*, int,
                                   int, int, int, const GridSpec&, int*, int*, int*, int*, int*, float*,
                                   float*, int*, int*, int*, int*, int*, int*, float*, float*, float*,
-                                  hipStream_t);
+                                  const int*, const int*, long long, hipStream_t);
 size_t lidf_frame_head_blocks(long long);
 hipError_t lidf_launch_frame_points(const float*, const float*, const int*, const int*, const int*,
                                     const GridSpec&, long long, const int*, int*, int*, float*, float*,
@@ -154,7 +154,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 5
+#define LIDF_ABI_VERSION 6
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \
@@ -1430,6 +1430,8 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         !a->pair_ray || !a->pair_vox || !a->pair_t || !a->pred_offset || !a->pred_prob ||
         !a->pair_pred_pos || !a->max_pair_id || !a->pred_pos || !a->rayfeat || !a->pred_depth)
         return LIDF_ERR_BAD_ARG;
+    if (a->n_valid_idx > 0 && (a->n_valid_idx > N || !a->valid_idx_bid || !a->valid_idx_flat))
+        return LIDF_ERR_BAD_ARG;
     const bool rf = a->refine_times > 0;
     const bool split = a->precision == LIDF_PRECISION_F16X3;
     if (rf && (!a->pnet_refine || !a->off_refine || (!split && !a->packed_refine) || !a->pred_pos_refine ||
@@ -1477,7 +1479,9 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
                                      a->valid_stride, g, (int*)(ws + f.blk_valid), (int*)(ws + f.blk_miss),
                                      counts, a->valid_bid, a->valid_flat, a->valid_xyz, a->valid_rgb,
                                      cell_flag, pt_key, pt_valid, a->ray_bid, a->ray_flat, a->ray_pix,
-                                     a->ray_dir, a->pred_depth, rf ? a->pred_depth_refine : nullptr, st));
+                                     a->ray_dir, a->pred_depth, rf ? a->pred_depth_refine : nullptr,
+                                     a->valid_idx_bid, a->valid_idx_flat, a->n_valid_idx > 0 ? a->n_valid_idx : 0,
+                                     st));
     // 2. occupied voxels: cell scan (V), point scan (NV), cells -> voxels, points -> PointNet rows
     CHECK_HIP(lidf_launch_scan_dev(cell_flag, C, nullptr, cell_rank, scan, counts + LIDF_FC_VOX, st));
     CHECK_HIP(lidf_launch_scan_dev(pt_valid, N, counts + LIDF_FC_VALID_SEL, pt_rank, scan,

@@ -40,9 +40,11 @@ __global__ void __launch_bounds__(256) lidf_frame_count_kernel(const float* __re
 }
 
 // pass 2 (one workgroup): exclusive scans of the two count arrays in place; list lengths to `counts`
+// n_list > 0: the valid points come as an explicit list (lidf_frame_valid_list_kernel): NV0 = NVS = n_list
 __global__ void __launch_bounds__(256) lidf_frame_offsets_kernel(int* __restrict__ blk_valid,
                                                                  int* __restrict__ blk_miss, int nb,
-                                                                 int stride, int* __restrict__ counts) {
+                                                                 int stride, int n_list,
+                                                                 int* __restrict__ counts) {
     __shared__ int s_tmp[4];
     int cv = 0, cm = 0;
     for (int b = 0; b < nb; b += 256) {
@@ -60,10 +62,57 @@ __global__ void __launch_bounds__(256) lidf_frame_offsets_kernel(int* __restrict
     }
     if (threadIdx.x == 0) {
         counts[0] = cm;                                   // R
-        counts[4] = cv;                                   // NV0
-        counts[5] = (cv + stride - 1) / stride;           // NVS: valid_idx[::stride]
+        counts[4] = n_list > 0 ? n_list : cv;                                   // NV0
+        counts[5] = n_list > 0 ? n_list : (cv + stride - 1) / stride;           // NVS: valid_idx[::stride]
         counts[7] = 0;
     }
+}
+
+// Selected valid point j = pixel `rem` of image b: its list entries and its cell of the voxel grid
+// (batch_get_occupied_idx, utils/point_utils.py:12-76, pass A)
+__device__ __forceinline__ void frame_valid_point(int j, int b, int rem, const float* px, const float* pc,
+                                                  long long hw, const GridSpec& g, int* valid_bid,
+                                                  int* valid_flat, float* valid_xyz, float* valid_rgb,
+                                                  int* cell_flag, int* pt_key, int* pt_valid) {
+    const float p[3] = {px[0], px[hw], px[2 * hw]};
+    valid_bid[j] = b;
+    valid_flat[j] = rem;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        valid_xyz[3 * j + a] = p[a];
+        valid_rgb[3 * j + a] = pc[a * hw];
+        const float v = p[a] - g.xmin[a];
+        const float q = floorf(v / g.crop);
+        ok = ok && (q >= 0.f) && (q < (float)g.r[a]);
+        c[a] = (int)q;
+    }
+    int key = -1;
+    if (ok) {
+        key = ((b * g.r[0] + c[0]) * g.r[1] + c[1]) * g.r[2] + c[2];
+        cell_flag[key] = 1;
+    }
+    pt_key[j] = key;
+    pt_valid[j] = ok ? 1 : 0;
+}
+
+// The valid points as an explicit list (LidfFrameArgs.valid_idx_*: the reference's sampled valid_idx,
+// pipeline.py:143-158): one thread per entry, in the list's order.
+__global__ void __launch_bounds__(256) lidf_frame_valid_list_kernel(
+    const int* __restrict__ idx_bid, const int* __restrict__ idx_flat, long long n,
+    const float* __restrict__ xyz, const float* __restrict__ rgb, int B, long long hw, GridSpec g,
+    int* __restrict__ valid_bid, int* __restrict__ valid_flat, float* __restrict__ valid_xyz,
+    float* __restrict__ valid_rgb, int* __restrict__ cell_flag, int* __restrict__ pt_key,
+    int* __restrict__ pt_valid) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int b = idx_bid[j], rem = idx_flat[j];
+    // (indices outside the batch are clamped: the reference would raise in index_select)
+    b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+    rem = rem < 0 ? 0 : (rem >= hw ? (int)hw - 1 : rem);
+    frame_valid_point((int)j, b, rem, xyz + (size_t)b * 3 * hw + rem, rgb + (size_t)b * 3 * hw + rem, hw, g,
+                      valid_bid, valid_flat, valid_xyz, valid_rgb, cell_flag, pt_key, pt_valid);
 }
 
 // pass 3: every list of the frame head in one sweep over the pixels.
@@ -81,14 +130,14 @@ __global__ void __launch_bounds__(256) lidf_frame_fill_kernel(
     float* __restrict__ valid_xyz, float* __restrict__ valid_rgb, int* __restrict__ cell_flag,
     int* __restrict__ pt_key, int* __restrict__ pt_valid, int* __restrict__ ray_bid,
     int* __restrict__ ray_flat, int* __restrict__ ray_pix, float* __restrict__ ray_dir,
-    float* __restrict__ depth, float* __restrict__ depth2) {
+    float* __restrict__ depth, float* __restrict__ depth2, int list_mode) {
     __shared__ int s_tmp[4];
     const long long b0 = (long long)blockIdx.x * FRAME_ITEMS + threadIdx.x * 4;
     bool fv[4], fm[4];
     int nv = 0, nm = 0;
     for (int k = 0; k < 4; ++k) {
         const bool in = b0 + k < npix;
-        fv[k] = in && valid_mask[b0 + k] != 0.f;
+        fv[k] = in && !list_mode && valid_mask[b0 + k] != 0.f;
         fm[k] = in && (!miss_mask || miss_mask[b0 + k] != 0.f);
         nv += fv[k] ? 1 : 0;
         nm += fm[k] ? 1 : 0;
@@ -108,29 +157,8 @@ __global__ void __launch_bounds__(256) lidf_frame_fill_kernel(
         if (depth2) depth2[i] = z;
         if (fv[k]) {
             if (iv % stride == 0) {
-                const int j = iv / stride;
-                const float p[3] = {px[0], px[hw], z};
-                const float* pc = rgb + (size_t)b * 3 * hw + rem;
-                valid_bid[j] = b;
-                valid_flat[j] = rem;
-                int c[3];
-                bool ok = true;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    valid_xyz[3 * j + a] = p[a];
-                    valid_rgb[3 * j + a] = pc[a * hw];
-                    const float v = p[a] - g.xmin[a];
-                    const float q = floorf(v / g.crop);
-                    ok = ok && (q >= 0.f) && (q < (float)g.r[a]);
-                    c[a] = (int)q;
-                }
-                int key = -1;
-                if (ok) {
-                    key = ((b * g.r[0] + c[0]) * g.r[1] + c[1]) * g.r[2] + c[2];
-                    cell_flag[key] = 1;
-                }
-                pt_key[j] = key;
-                pt_valid[j] = ok ? 1 : 0;
+                frame_valid_point(iv / stride, b, rem, px, rgb + (size_t)b * 3 * hw + rem, hw, g, valid_bid,
+                                  valid_flat, valid_xyz, valid_rgb, cell_flag, pt_key, pt_valid);
             }
             ++iv;
         }
@@ -216,18 +244,23 @@ extern "C" hipError_t lidf_launch_frame_head(const float* valid_mask, const floa
                                              int* valid_flat, float* valid_xyz, float* valid_rgb,
                                              int* cell_flag, int* pt_key, int* pt_valid, int* ray_bid,
                                              int* ray_flat, int* ray_pix, float* ray_dir, float* depth,
-                                             float* depth2, hipStream_t st) {
+                                             float* depth2, const int* idx_bid, const int* idx_flat,
+                                             long long n_list, hipStream_t st) {
     const long long npix = (long long)B * H * W;
     if (npix <= 0) return hipSuccess;
     const int nb = (int)((npix + FRAME_ITEMS - 1) / FRAME_ITEMS);
     hipLaunchKernelGGL(lidf_frame_count_kernel, dim3(nb), dim3(256), 0, st, valid_mask, miss_mask, npix,
                        blk_valid, blk_miss);
     hipLaunchKernelGGL(lidf_frame_offsets_kernel, dim3(1), dim3(256), 0, st, blk_valid, blk_miss, nb, stride,
-                       counts);
+                       (int)n_list, counts);
     hipLaunchKernelGGL(lidf_frame_fill_kernel, dim3(nb), dim3(256), 0, st, valid_mask, miss_mask, xyz, rgb,
                        intr, npix, H, W, stride, g, blk_valid, blk_miss, valid_bid, valid_flat, valid_xyz,
                        valid_rgb, cell_flag, pt_key, pt_valid, ray_bid, ray_flat, ray_pix, ray_dir, depth,
-                       depth2);
+                       depth2, n_list > 0 ? 1 : 0);
+    if (n_list > 0)
+        hipLaunchKernelGGL(lidf_frame_valid_list_kernel, dim3((unsigned)((n_list + 255) / 256)), dim3(256), 0,
+                           st, idx_bid, idx_flat, n_list, xyz, rgb, B, (long long)H * W, g, valid_bid, valid_flat,
+                           valid_xyz, valid_rgb, cell_flag, pt_key, pt_valid);
     return hipGetLastError();
 }
 

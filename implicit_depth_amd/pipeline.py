@@ -310,14 +310,20 @@ class FrameRunner:
         }
         self.graph = None
         self._keep = None
+        self.vidx, self.n_valid_idx = None, 0      # explicit valid points (load(valid_idx=))
         self.src = dict(self.inp)
         math.isfinite(self.part_size)
 
     # -- inputs -----------------------------------------------------------------------------------
-    def load(self, batch, full_rgb_feat, pred_mask=None, copy=None):
+    def load(self, batch, full_rgb_feat, pred_mask=None, copy=None, valid_idx=None):
         """Hand a batch (the reference's dataset item keys) to the runner. mask_type 'all': valid <=>
         the measured depth is non-zero (prepare_data, pipeline.py:119-121), so depth_corrupt itself is
         the valid mask; 'pred': valid_mask = 1 - pred_mask, rays where pred_mask is non-zero.
+        valid_idx [M,2] (image, flat pixel; any integer dtype, M <= bs*h*w): the valid points as the
+        code upstream sampled them (LIDF.get_valid_points with grid.valid_sample_num != -1 keeps the
+        output of utils/point_utils.py sample_valid_points) instead of every opt.valid_stride-th valid
+        pixel; copied into the runner's static index buffers without a sync. A captured graph replays
+        the M it was captured with.
         copy=True (the default once a graph is captured: a graph replays fixed addresses) copies the
         tensors into the runner's static input buffers — device-to-device, no sync; copy=False passes
         the caller's own contiguous float32 tensors to the library as they lie (kept alive by the
@@ -354,6 +360,21 @@ class FrameRunner:
         if miss is not None:   # valid_mask = 1 - pred_mask (prepare_data, pipeline.py:116-117)
             torch.sub(1.0, self.src["miss_mask"], out=i["valid_mask"])
             self.src["valid_mask"] = i["valid_mask"]
+        m = 0
+        if valid_idx is not None:
+            if valid_idx.dim() != 2 or valid_idx.shape[1] != 2:
+                raise RuntimeError("valid_idx must be [M,2] (image, flat pixel)")
+            m = int(valid_idx.shape[0])
+            if m > self.N:
+                raise RuntimeError("valid_idx holds %d points, the frame buffers %d" % (m, self.N))
+            if self.vidx is None:
+                self.vidx = torch.empty((2, self.N), dtype=torch.int32, device=self.dev)
+            if m:
+                self.vidx[:, :m].copy_(valid_idx.t(), non_blocking=True)
+        if self.graph is not None and m != self.n_valid_idx:
+            raise RuntimeError("the captured graph replays %d listed valid points, this batch has %d"
+                               % (self.n_valid_idx, m))
+        self.n_valid_idx = m
 
     # -- the launch sequence ------------------------------------------------------------------------
     def enqueue(self):
@@ -412,6 +433,9 @@ class FrameRunner:
         for k, t in b.items():
             setattr(a, k, t.data_ptr())
         a.workspace, a.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        if self.n_valid_idx > 0:
+            a.valid_idx_bid, a.valid_idx_flat = self.vidx[0].data_ptr(), self.vidx[1].data_ptr()
+            a.n_valid_idx = self.n_valid_idx
         with torch.cuda.device(self.dev):
             _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))
         self._keep = keep
@@ -437,14 +461,14 @@ class FrameRunner:
         self.graph = g
         return self
 
-    def run(self, batch=None, full_rgb_feat=None, pred_mask=None):
+    def run(self, batch=None, full_rgb_feat=None, pred_mask=None, valid_idx=None):
         """load() (when a batch is given) + the frame (graph replay if captured). No sync."""
         Q._refuse_autograd("pipeline.FrameRunner.run", "query.lidf_query_train (stage-1 training step)",
                            (("full_rgb_feat", full_rgb_feat),),
                            tuple(zip(("pnet_model", "prob_dec", "offset_dec", "pnet_model_refine",
                                       "offset_dec_refine"), self.mods)))
         if batch is not None:
-            self.load(batch, full_rgb_feat, pred_mask)
+            self.load(batch, full_rgb_feat, pred_mask, valid_idx=valid_idx)
         if self.graph is not None:
             self.graph.replay()
         else:

@@ -499,6 +499,16 @@ typedef struct LidfFrameArgs {
     float* pred_depth_refine;              /* [B,h,w]                                             */
     void* workspace;
     size_t workspace_bytes;
+    /* optional: the valid points as an explicit list instead of every valid_stride-th valid pixel —
+     * what LIDF.get_valid_points keeps when grid.valid_sample_num != -1 (models/pipeline.py:143-146:
+     * utils/point_utils.py sample_valid_points, a random block sampler that is host code upstream of
+     * the path). n_valid_idx > 0: point j is pixel valid_idx_flat[j] of image valid_idx_bid[j], in
+     * this order (duplicates allowed, as the sampler produces them for sparse frames);
+     * n_valid_idx <= batch*height*width; valid_mask is then only read by refine_use_all_pix == 0;
+     * counts[LIDF_FC_VALID_PIX] = counts[LIDF_FC_VALID_SEL] = n_valid_idx. (ABI 6)                  */
+    const int32_t* valid_idx_bid;
+    const int32_t* valid_idx_flat;
+    int64_t n_valid_idx;
 } LidfFrameArgs;
 size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, const int32_t* res,
                                   int64_t max_pairs, int32_t lds_voxels, int32_t refine_times);

@@ -31,11 +31,11 @@ SAME_INT = ("occ_vox_bid", "revidx", "valid_v_pid", "ray_bid", "ray_flat", "ray_
             "pair_vox", "max_pair_id", "end_voxel_id")
 
 
-def _stepwise(batch, feat, models, opt, precision="f32"):
+def _stepwise(batch, feat, models, opt, precision="f32", valid_idx=None):
     from implicit_depth_amd import pipeline as pl
     pnet, prob, off, pnet_r, offr = models
     with torch.no_grad():
-        ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=precision)
+        ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=precision, valid_idx=valid_idx)
         if ok:
             pl.refine_forward(dd, pnet_r, offr, opt, precision=precision)
     return ok, dd
@@ -287,3 +287,58 @@ def test_frame_split_f16_equals_stepwise(cuda, shape, graph):
     same = dd["max_pair_id"] == d32["max_pair_id"]          # (a float-noise tie may pick another pair)
     assert (~same).sum().item() <= 2
     assert (dd["pred_pos_refine"] - d32["pred_pos_refine"])[same].abs().max().item() <= TOL
+
+
+def _sampled_valid_idx(batch, n_per_image, seed, B, h, w):
+    """[B * n, 2] (image, flat pixel) int64 as LIDF.get_valid_points keeps it with valid_sample_num != -1:
+    per image n entries drawn from its valid pixels, in shuffled order, with repeats when the image has
+    fewer than n valid pixels (utils/point_utils.py:98-106)."""
+    g = torch.Generator().manual_seed(seed)
+    valid = (batch["depth_corrupt"].reshape(B, h * w) != 0).cpu()
+    out = []
+    for b in range(B):
+        pix = torch.nonzero(valid[b]).flatten()
+        if pix.numel() >= n_per_image:
+            sel = pix[torch.randperm(pix.numel(), generator=g)[:n_per_image]]
+        else:
+            extra = pix[torch.randint(0, pix.numel(), (n_per_image - pix.numel(),), generator=g)]
+            sel = torch.cat([pix, extra])
+        out.append(torch.stack([torch.full_like(sel, b), sel], 1))
+    return torch.cat(out, 0)
+
+
+@pytest.mark.parametrize("shape,n,graph", [((1, 240, 320), 10000, True), ((2, 48, 64), 700, False),
+                                           ((3, 24, 32), 700, True)])
+def test_frame_with_listed_valid_points(cuda, shape, n, graph):
+    """load(valid_idx=): the valid points as the reference's get_valid_points hands them on when
+    grid.valid_sample_num != -1 (a sampled, shuffled list with repeats) — the frame call against the
+    stepwise path fed the same list, bit for bit, through a graph replay and a second batch."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = shape
+    models = _models(cuda)
+    opt = pl.LidfOptions()
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+    for k, seed in enumerate((31, 32)):
+        batch, feat = synthetic_batch(B, h, w, seed=seed, hole_frac=1.0 + 0.2 * k)
+        vidx = _sampled_valid_idx(batch, n, 5 + seed, B, h, w)      # (3, 24, 32): more than the valid pixels -> repeats
+        batch, feat = _dev(batch, cuda), feat.to(cuda)
+        with torch.no_grad():
+            runner.load(batch, feat, valid_idx=vidx.to(cuda) if k else vidx)   # host or device indices
+            if graph and k == 0:
+                runner.capture()
+            runner.run()
+        ok, dd = runner.result()
+        ok_ref, ref = _stepwise(batch, feat, models, opt, valid_idx=vidx.to(cuda))
+        assert ok and ok_ref
+        c = dd["counts"]
+        assert c["NVS"] == B * n and c["NV"] == ref["revidx"].shape[0] and c["V"] == ref["voxel_bound"].shape[0]
+        assert torch.equal(dd["valid_flat_img_id"].long(), vidx[:, 1].to(cuda))
+        assert torch.equal(dd["valid_xyz"], ref["valid_xyz"]) and torch.equal(dd["valid_rgb"], ref["valid_rgb"])
+        _compare(dd, ref)
+    if graph:   # the captured graph replays its own list length
+        with pytest.raises(RuntimeError):
+            runner.load(batch, feat, valid_idx=vidx[:-1])
+    with pytest.raises(RuntimeError):
+        pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt).load(
+            batch, feat, valid_idx=torch.zeros((B * h * w + 1, 2), dtype=torch.int64))

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
         assert n in _lib.SIGNATURES, "ctypes signature missing for " + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert L.lidf_version() == 5
+    assert L.lidf_version() == 6
     assert b"workspace" in L.lidf_strerror(-3)
     assert L.lidf_query_workspace_bytes(76800, 729, 0) > 76800 * 512 * 4
     assert (L.lidf_query_workspace_bytes(76800, 729, 32 * 240 * 320)
@@ -68,7 +68,7 @@ def test_torch_extension_shim_loads():
     """The pybind11 shim over the C ABI is built in-tree and imports without a GPU."""
     from implicit_depth_amd import torch_ext
     m = torch_ext.ext()
-    assert m.abi_version() == 5
+    assert m.abi_version() == 6
     for fn in ("ray_aabb", "pcl_aabb", "compute_ray_aabb", "forward_decoders", "forward_query"):
         assert callable(getattr(m, fn))
     with pytest.raises(RuntimeError, match="CUDA"):   # CHECK_INPUT of the reference bindings: CUDA tensors only
