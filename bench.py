@@ -227,6 +227,60 @@ def profile_record(kernel_name):
     return out
 
 
+def rocprof_live(kernel_name, argv, steps=6, warmup=2, timeout=240):
+    """The dominant kernel's average duration by rocprofv3 --kernel-trace --stats of THIS command
+    (same workload flags, `steps` steps, no CPU baseline), run as a child process once the timed region
+    is over: {"kernel_ms": avg excluding the first launch, "calls": n, "kernel_ms_all": avg of all}.
+    None when rocprofv3 is absent, the child fails or takes longer than `timeout` s (the bench line is
+    then emitted without it)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("LIDF_BENCH_NO_ROCPROF") == "1":
+        return None
+    keep = []
+    skip = False
+    for a in argv:            # the workload flags of this run without its step counts
+        if skip:
+            skip = False
+            continue
+        if a in ("--steps", "--warmup", "--gpus"):
+            skip = True
+            continue
+        if a.startswith(("--steps=", "--warmup=", "--gpus=")) or a in ("--no-cpu-baseline", "--no-rocprof"):
+            continue
+        keep.append(a)
+    d = tempfile.mkdtemp(prefix="lidf_bench_prof_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", LIDF_BENCH_NO_ROCPROF="1")
+    cmd = [exe, "--kernel-trace", "--stats", "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-rocprof"] + keep
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout)
+        db = None
+        for root, _, files in os.walk(d):
+            for f in files:
+                if f.endswith("_results.db"):
+                    db = os.path.join(root, f)
+        if r.returncode != 0 or db is None:
+            return None
+        cur = sqlite3.connect(db).cursor()
+        dur = [row[0] for row in cur.execute(
+            "select duration from kernels where name like ? order by start", ("%" + kernel_name + "%",))]
+        if len(dur) < 2:
+            return None
+        return {"kernel_ms": round(sum(dur[1:]) / (len(dur) - 1) / 1e6, 4), "calls": len(dur),
+                "kernel_ms_all": round(sum(dur) / len(dur) / 1e6, 4),
+                "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d %s"
+                           % (steps, warmup, " ".join(keep))}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # launches per step of the f32 query (for the per-step HBM counter sum)
 PER_STEP_LAUNCHES = {"lidf_pack_kernel": 0, "void lidf_points_kernel<2>": 0,
                      "rowsh::lidf_rows_h_kernel": 0, "_ZN5rowsh18lidf_pack_r_kernelE12StreamLayout4NetWS1_5L1MapPDF16_Pf": 0}
@@ -524,6 +578,10 @@ def main():
     ap.add_argument("--samples", type=int, default=64, help="candidates per ray (N)")
     ap.add_argument("--frames", type=int, default=1, help="frames per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rocprof", action="store_true",
+                    help="skip the rocprofv3 leg of the N = 1 query run (roofline.kernel_ms_rocprof_live: the "
+                         "dominant kernel's average duration by rocprofv3 --kernel-trace of this same command, "
+                         "run as a child process after the timed region)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="arithmetic of the decoders' matrix products: f32 (default, the headline) or "
                          "f16x3 = three f16-piece products per term with f32 accumulation (f32-level "
@@ -781,6 +839,11 @@ def main():
         f_exec = F_EXEC_H if h16 else F_EXEC
         kname = "lidf_points_h_kernel" if h16 else "lidf_points_fused_kernel"
         prof = profile_record(kname)
+        live = None
+        profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)   # already under a profiler
+        if (world == 1 and not use_dist and not args.no_rocprof and not args.no_cpu_baseline and not profiled
+                and args.workload == "query"):
+            live = rocprof_live(kname, sys.argv[1:])
         ach = f_exec * P / (kern_ms * 1e-3) / 1e12          # MFMA FLOP issued / time
         ach_alg = F_ALG * P / (kern_ms * 1e-3) / 1e12       # reference-formulation FLOP / time
         # algorithmic HBM bytes of the fused query: 20 B/point in+out, 32 B/ray,
@@ -815,6 +878,8 @@ def main():
                          # command, for comparison with the live kernel_ms above — not a value of this run)
                          "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
                          "profile": prof.get("profile"),
+                         # (live: rocprofv3 --kernel-trace of this same command, run after the timed region)
+                         "kernel_ms_rocprof_live": live,
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,
                          "flop_per_point_counter": (round(prof["mfma_flop_counter"] / (240 * 320 * 64), 1)
                                                     if prof.get("mfma_flop_counter") and not h16 else None),
