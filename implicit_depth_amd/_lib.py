@@ -210,6 +210,10 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P]),
     "lidf_query_tail_backward_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float,
                                                C.c_float, _P, _P]),
+    "lidf_roi_align_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I64, _I, _I, _P, _I64, _P]),
+    "lidf_linear_workspace_bytes": (_SZ, [_I]),
+    "lidf_linear_f32": (_I, [_P, _I64, _I64, _I, _P, _I64, _P, _I, _I, C.c_float, _P, _P, _I64, _P, _I64, _P, _P,
+                            _I64, _P, _SZ, _P]),
     "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,

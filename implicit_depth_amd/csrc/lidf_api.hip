@@ -82,6 +82,8 @@ hipError_t lidf_launch_frame_head(const float*, const float*, const float*, cons
                                   float*, int*, int*, int*, int*, int*, int*, float*, float*, float*,
                                   const int*, const int*, long long, hipStream_t);
 size_t lidf_frame_head_blocks(long long);
+hipError_t lidf_launch_roi_align(const float*, int, int, int, const int*, const int*, long long, int, int,
+                                 float*, long long, hipStream_t);
 hipError_t lidf_launch_frame_points(const float*, const float*, const int*, const int*, const int*,
                                     const GridSpec&, long long, const int*, int*, int*, float*, float*,
                                     float*, hipStream_t);
@@ -1715,6 +1717,73 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
     const long long nt128 = (L.n + 127) / 128;
     const int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
     CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
+    return LIDF_OK;
+}
+
+// ---- RoIAlign of the per-ray boxes at any channel count / output size ------------------------------
+LIDF_API int lidf_roi_align_f32(const float* feat_grid, int32_t batch, int32_t channels, int32_t height,
+                                  int32_t width, const int32_t* ray_pix, const int32_t* ray_bid,
+                                  int64_t n_rays, int32_t roi_inp_bbox, int32_t roi_out_bbox, float* out,
+                                  int64_t ld_out, lidf_stream_t stream) {
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || n_rays < 0 || roi_inp_bbox < 0 ||
+        roi_out_bbox <= 0 || roi_out_bbox > 64)
+        return LIDF_ERR_BAD_ARG;
+    if (n_rays == 0) return LIDF_OK;
+    if (!feat_grid || !ray_pix || !ray_bid || !out || ld_out < (int64_t)channels * roi_out_bbox * roi_out_bbox)
+        return LIDF_ERR_BAD_ARG;
+    if ((int64_t)height * width > 0x7fffffffLL || n_rays > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    CHECK_HIP(lidf_launch_roi_align(feat_grid, channels, height, width, ray_pix, ray_bid, n_rays,
+                                    roi_inp_bbox / 2, roi_out_bbox, out, ld_out, (hipStream_t)stream));
+    return LIDF_OK;
+}
+
+// ---- a linear layer of any width (the modules at widths other than the shipped ones) ---------------
+LIDF_API size_t lidf_linear_workspace_bytes(int32_t k) {
+    return k > 0 ? linex_stream_bytes(k) : 0;
+}
+
+LIDF_API int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                               const float* b, int32_t nout, int32_t act, float slope,
+                               const float* addrows, const int32_t* addidx, int64_t ld_add, float* out,
+                               int64_t ld_out, float* pool, const int32_t* poolidx, int64_t ld_pool,
+                               void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || k <= 0 || nout <= 0 || ldx < k || ldw < k || act < 0 || act > 1) return LIDF_ERR_BAD_ARG;
+    if (k > (1 << 20) || nout > (1 << 20) || ld_add > 0x7fffffffLL || ld_pool > 0x7fffffffLL)
+        return LIDF_ERR_UNSUPPORTED;
+    if (n == 0) return LIDF_OK;
+    if (!x || !w || (!out && !pool)) return LIDF_ERR_BAD_ARG;
+    if (out && ld_out < nout) return LIDF_ERR_BAD_ARG;
+    if (addrows && (!addidx || ld_add < nout)) return LIDF_ERR_BAD_ARG;
+    // the max-pool epilogue raises whole 32-column tiles of non-negative values
+    if (pool && (!poolidx || ld_pool < nout || nout % 32 != 0 || !act || slope != 0.f)) return LIDF_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < linex_stream_bytes(k)) return LIDF_ERR_WORKSPACE;
+    int rc, cus;
+    if ((rc = cu_count(&cus))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // 256 output columns per launch (8 accumulator tiles); the packed stream of a chunk is consumed by
+    // its launch before the next chunk's pack overwrites it (same stream)
+    for (int c0 = 0; c0 < nout; c0 += 256) {
+        const int cols = nout - c0 < 256 ? nout - c0 : 256;
+        const int nt = nt_for(cols);
+        L1Map m = rows_map(k, 0, 0, 0, b ? 1 : 0);
+        m.KQ1 = (m.D + 2 + 7) / 8;
+        m.nt = nt;
+        m.nout = cols;
+        StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
+        NetW nw = {};
+        nw.w1 = w + (size_t)c0 * ldw; nw.b1 = b ? b + c0 : nullptr; nw.ld1 = (int)ldw; nw.dcore = k; nw.is_ief = 0;
+        CHECK_HIP(pack_stream(lay, nw, nw, m, (float*)workspace, nullptr, st));
+        LinearArgs a = {};
+        a.stream = (const float*)workspace; a.kq1 = m.KQ1; a.X = x; a.ldx = ldx; a.n = n;
+        a.D = m.D; a.has_bias = b ? 1 : 0;
+        a.addrows = addrows ? addrows + c0 : nullptr; a.addidx = addidx; a.ld_add = (int)ld_add;
+        a.relu = act; a.slope = slope;
+        a.out = out ? out + c0 : nullptr; a.ld_out = ld_out; a.nout = cols;
+        a.pool = pool ? pool + c0 : nullptr; a.poolidx = poolidx; a.ld_pool = (int)ld_pool;
+        const long long nt128 = (n + 127) / 128;
+        const int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
+        CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
+    }
     return LIDF_OK;
 }
 

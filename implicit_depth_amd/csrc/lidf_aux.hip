@@ -322,6 +322,53 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
     }
 }
 
+// RoIAlign at any channel count and output size (torchvision.ops.roi_align, aligned = True,
+// sampling_ratio = -1, on the per-ray boxes of models/pipeline.py:374-391; rgb_out / roi_out_bbox other
+// than the shipped 32 / 2): one (ray, channel, bin) item per thread with the ray index fastest, as the
+// border kernel above; out[r, (c * S + ph) * S + pw] = the reference's reshape of [K, C, S, S].
+__global__ void __launch_bounds__(256) lidf_roi_align_kernel(
+    const float* __restrict__ feat, int Cn, int H, int W, const int* __restrict__ ray_pix,
+    const int* __restrict__ ray_bid, long long R, int half, int S, float* __restrict__ out, long long ld) {
+    const long long nitem = R * Cn * S * S;
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < nitem;
+         item += (long long)gridDim.x * 256) {
+        const long long rr = item % R;
+        const int cbin = (int)(item / R);
+        const int bin = cbin % (S * S), c = cbin / (S * S);
+        const int qx = ray_pix[2 * rr], qy = ray_pix[2 * rr + 1];
+        const int u1 = min(max(qx - half, 0), W - 1), u2 = min(max(qx + half, 0), W - 1);
+        const int v1 = min(max(qy - half, 0), H - 1), v2 = min(max(qy + half, 0), H - 1);
+        const float rsw = (float)u1 - 0.5f, rsh = (float)v1 - 0.5f;
+        const float rew = (float)u2 - 0.5f, reh = (float)v2 - 0.5f;
+        const float roi_w = rew - rsw, roi_h = reh - rsh;
+        const float bin_w = roi_w / (float)S, bin_h = roi_h / (float)S;
+        const int gw = (int)ceilf(roi_w / (float)S), gh = (int)ceilf(roi_h / (float)S);
+        const float count = (float)max(gh * gw, 1);
+        const float* img = feat + ((size_t)ray_bid[rr] * Cn + c) * H * W;
+        const int ph = bin / S, pw = bin % S;
+        float acc = 0.f;  // the reference's (iy, ix) order
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                acc += bilinear(img, H, W, y, x);
+            }
+        }
+        out[(size_t)rr * ld + (size_t)c * S * S + bin] = acc / count;
+    }
+}
+
+extern "C" hipError_t lidf_launch_roi_align(const float* feat, int Cn, int H, int W, const int* ray_pix,
+                                            const int* ray_bid, long long R, int half, int S, float* out,
+                                            long long ld, hipStream_t st) {
+    const long long nitem = R * Cn * S * S;
+    if (nitem <= 0) return hipSuccess;
+    const long long blocks = (nitem + 255) / 256;
+    hipLaunchKernelGGL(lidf_roi_align_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                       st, feat, Cn, H, W, ray_pix, ray_bid, R, half, S, out, ld);
+    return hipGetLastError();
+}
+
 // `box` (scratch, B*32*H*W floats, followed by R+1 ints for the clamped-box list) may be NULL:
 // every ray then takes the general path inside the main kernel.
 extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int B, int H, int W,

@@ -105,15 +105,31 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 f32x4 v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * g + i];
+                // (a.nout > 0: columns >= nout are padding of the last tile — no gathered term is read
+                // for them, they are neither stored nor pooled)
+                const int cg = (T0 + t) * 32 + 8 * g + 4 * h;
+                const bool whole = a.nout <= 0 || cg + 3 < a.nout;
                 if (ar) {
-                    const f32x4 r = *(const f32x4*)(ar + (T0 + t) * 32 + 8 * g);
+                    if (whole) {
+                        const f32x4 r = *(const f32x4*)(ar + (T0 + t) * 32 + 8 * g);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += r[i];
+                        for (int i = 0; i < 4; ++i) v[i] += r[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (cg + i < a.nout) v[i] += ar[(T0 + t) * 32 + 8 * g + i];
+                    }
                 }
                 if (ar2) {
-                    const f32x4 r = *(const f32x4*)(ar2 + (T0 + t) * 32 + 8 * g);
+                    if (whole) {
+                        const f32x4 r = *(const f32x4*)(ar2 + (T0 + t) * 32 + 8 * g);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += r[i];
+                        for (int i = 0; i < 4; ++i) v[i] += r[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (cg + i < a.nout) v[i] += ar2[(T0 + t) * 32 + 8 * g + i];
+                    }
                 }
                 if (a.relu) {
 #pragma unroll
@@ -171,6 +187,7 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 int* pp = (int*)a.pool + (size_t)vv * a.ld_pool + 4 * h;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    if (a.nout > 0 && (T0 + t) * 32 >= a.nout) continue;   // padding tile (wave-uniform)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 m;
@@ -195,6 +212,7 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
                 int* pp = (int*)a.pool + (size_t)vox * a.ld_pool + 4 * h;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    if (a.nout > 0 && (T0 + t) * 32 >= a.nout) continue;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 seen = *(const f32x4*)(pp + (T0 + t) * 32 + 8 * g);

@@ -153,11 +153,18 @@ def _get(mod, name):
     return getattr(getattr(mod, layer), attr)
 
 
-def _check_supported(mod):
-    if mod.gf_dim != 64 or mod.linear_4.out_features != 1:
-        raise RuntimeError("lidf_hip decoders are built for gf_dim=64, out_dim=1 "
-                           "(every shipped config); got gf_dim=%d out_dim=%d"
-                           % (mod.gf_dim, mod.linear_4.out_features))
+def is_shipped(mod):
+    """The widths the register-chained kernels are built for (every shipped config): gf_dim 64, out_dim 1."""
+    return mod.gf_dim == 64 and mod.linear_4.out_features == 1
+
+
+def _check_supported(mod, what="this entry"):
+    """Entries without a layer-by-layer counterpart (training, the fused query, stage 2, the frame call)."""
+    if not is_shipped(mod):
+        raise RuntimeError("lidf_hip: %s is built for gf_dim=64, out_dim=1 (every shipped config); got "
+                           "gf_dim=%d out_dim=%d. Inference at other widths runs layer by layer "
+                           "(IMNet / IEF forward without autograd, generic.decoder_forward)"
+                           % (what, mod.gf_dim, mod.linear_4.out_features))
 
 
 def decoders_forward(inp_feat, prob_dec=None, offset_dec=None, precision="f32"):
@@ -180,10 +187,15 @@ def decoders_forward(inp_feat, prob_dec=None, offset_dec=None, precision="f32"):
     keep = []
     dp = do = None
     for m in (prob_dec, offset_dec):
-        if m is not None:
-            _check_supported(m)
-            if m.inp_dim != d:
-                raise RuntimeError("decoder inp_dim %d != input width %d" % (m.inp_dim, d))
+        if m is not None and m.inp_dim != d:
+            raise RuntimeError("decoder inp_dim %d != input width %d" % (m.inp_dim, d))
+    if any(m is not None and not is_shipped(m) for m in (prob_dec, offset_dec)):
+        # widths other than the shipped ones: layer by layer (generic.py), f32 only
+        if precision != "f32":
+            raise RuntimeError("precision %r is built for gf_dim=64, out_dim=1" % precision)
+        from . import generic
+        return (generic.decoder_forward(prob_dec, x) if prob_dec is not None else None,
+                generic.decoder_forward(offset_dec, x) if offset_dec is not None else None)
     if prob_dec is not None:
         dp = _decoder_struct(prob_dec, keep)
     if offset_dec is not None:
@@ -271,7 +283,7 @@ def _has(mod, name):
 class _DecoderBase(nn.Module):
     def _forward_train(self, inp_feat):
         """Differentiable forward through liblidf_hip (training)."""
-        _check_supported(self)
+        _check_supported(self, "the training path (forward under autograd)")
         if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != self.inp_dim:
             raise RuntimeError("inp_feat must be float32 [n, %d]" % self.inp_dim)
         return _DecoderTrainFn.apply(self, inp_feat, *[_get(self, k) for k in _PARAM_ORDER if _has(self, k)])

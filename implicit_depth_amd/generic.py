@@ -1,0 +1,175 @@
+"""generic.py — the reference's modules at widths other than the shipped configuration.
+
+The register-chained kernels of liblidf_hip are built for the widths every shipped config uses
+(imnet_gf 64, pnet_gf 32, pnet_out 128, rgb_out 32, roi_out_bbox 2: models/pipeline.py:56-85 with
+experiments/implicit_depth/*.yaml). The reference's constructors take other values
+(IMNet / IEF gf_dim and out_dim, PointNet2Stage input_channels / gf_dim / output_channels, the
+ROI feature's channels and bins); those run here layer by layer: every nn.Linear is one
+lidf_linear_f32 launch (the same f32 matrix-instruction kernel, 256 output columns per launch,
+fused bias / activation / gathered term / scatter-max), the ROI pooling is lidf_roi_align_f32.
+Same results as the reference's modules to the tolerance of the fast path (the summation order
+inside a dot product differs from cuBLAS as it does there); inference only — the training
+entries are built for the shipped widths.
+
+Nothing here is used when the widths are the shipped ones.
+"""
+import torch
+
+from . import _lib
+
+
+def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None, out=None,
+               pool=None, poolidx=None, w_col0=0, k=None):
+    """out = act(x @ weight[:, w_col0:w_col0+k].T + bias (+ addrows[addidx])) through lidf_linear_f32.
+    x [n, >=k] f32 (row stride free), weight [nout, ldw] f32; act 0 none / 1 max(v, slope*v).
+    pool [V, nout] (zero-initialised) receives the scatter-max over poolidx instead of / beside out."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise RuntimeError("linear_hip: x must be a CUDA float32 matrix (no CPU path)")
+    w = weight.detach()
+    if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("linear_hip: weight must be float32 [nout, k] with unit column stride")
+    n = x.shape[0]
+    k = int(k if k is not None else w.shape[1] - w_col0)
+    nout = int(w.shape[0])
+    if x.stride(1) != 1 or x.shape[1] < k:
+        x = x.contiguous()
+    ldx = x.stride(0) if n > 1 else max(x.shape[1], k)
+    b = bias.detach().contiguous() if bias is not None else None
+    if out is None and pool is None:
+        out = torch.empty((n, nout), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    wsb = L.lidf_linear_workspace_bytes(k)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+    if n == 0:
+        return out
+    with torch.cuda.device(x.device):
+        _lib.check(L.lidf_linear_f32(
+            _lib.ptr(x), ldx, n, k, w.data_ptr() + 4 * w_col0, w.stride(0), _lib.ptr(b), nout, act, float(slope),
+            _lib.ptr(addrows), _lib.ptr(addidx), addrows.stride(0) if addrows is not None else 0,
+            _lib.ptr(out), out.stride(0) if out is not None else 0,
+            _lib.ptr(pool), _lib.ptr(poolidx), pool.stride(0) if pool is not None else 0,
+            _lib.ptr(ws), wsb, _lib.current_stream(x.device)))
+    return out
+
+
+def _out_act(mod, y):
+    # implicit_net.py:93-96 / :148-151 on the [n, out_dim] output
+    if mod.use_sigmoid:
+        return torch.sigmoid(y)
+    return torch.max(torch.min(y, y * 0.01 + 0.99), y * 0.01)
+
+
+def decoder_forward(mod, x):
+    """IMNet.forward / IEF.forward (models/implicit_net.py:81-98 / :131-152) at any gf_dim / out_dim
+    on [n, inp_dim] rows."""
+    from .decoders import IEF
+    x = x.detach()
+    n, d = x.shape
+    if d != mod.inp_dim:
+        raise RuntimeError("decoder inp_dim %d != input width %d" % (mod.inp_dim, d))
+    l1, l2, l3, l4 = mod.linear_1, mod.linear_2, mod.linear_3, mod.linear_4
+    if not isinstance(mod, IEF):
+        h = linear_hip(x, l1.weight, l1.bias, act=1, slope=0.02)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
+        return _out_act(mod, linear_hip(h, l4.weight, l4.bias))
+    if l4.out_features != 1:
+        raise RuntimeError("IEF feeds its output back through offset_enc = Linear(1, 16): out_dim must be 1")
+    # layer 1 = W1[:, :d] x + b1 (the same in every pass) + W1[:, d:] enc(off)
+    base = linear_hip(x, l1.weight, l1.bias, k=d)
+    rows = torch.arange(n, dtype=torch.int32, device=x.device)
+    from .decoders import _init_offset_value
+    off = torch.full((n, 1), _init_offset_value(mod), dtype=torch.float32, device=x.device)
+    for _ in range(int(mod.n_iter)):
+        enc = linear_hip(off, mod.offset_enc.weight, mod.offset_enc.bias)
+        h = linear_hip(enc, l1.weight, None, act=1, slope=0.02, addrows=base, addidx=rows, w_col0=d, k=16)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
+        off = off + linear_hip(h, l4.weight, l4.bias)
+    return _out_act(mod, off)
+
+
+def pointnet_forward(mod, inp_feat, vox2point_idx, n_vox):
+    """PointNet2Stage.forward (models/pointnet.py:22-38) at any input_channels / gf_dim /
+    output_channels: torch_scatter's max becomes the scatter-max epilogue of the producing layer
+    (values are post-ReLU, a voxel without points keeps 0)."""
+    x = inp_feat.detach().contiguous()
+    idx = vox2point_idx.detach().to(torch.int32).contiguous()
+    dev = x.device
+    half, outc = mod.point_lin2.out_features, mod.point_lin4.out_features
+    if half % 32 or outc % 32:
+        raise RuntimeError("PointNet2Stage: output_channels must be a multiple of 64 on this path "
+                           "(the scatter-max epilogue raises whole 32-column tiles)")
+    f1 = linear_hip(x, mod.point_lin1.weight, mod.point_lin1.bias, act=1)
+    pool1 = torch.zeros((max(n_vox, 1), half), dtype=torch.float32, device=dev)
+    f2 = linear_hip(f1, mod.point_lin2.weight, mod.point_lin2.bias, act=1, pool=pool1, poolidx=idx,
+                    out=torch.empty((x.shape[0], half), dtype=torch.float32, device=dev))
+    g1 = linear_hip(pool1[:n_vox], mod.vox_lin1.weight, mod.vox_lin1.bias, act=1)
+    # point_lin3 on cat(g1[idx], f2): the voxel half once per voxel, gathered into the point half
+    gpart = linear_hip(g1, mod.point_lin3.weight, mod.point_lin3.bias, k=half)
+    f4 = linear_hip(f2, mod.point_lin3.weight, None, act=1, addrows=gpart, addidx=idx, w_col0=half, k=half)
+    pool2 = torch.zeros((max(n_vox, 1), outc), dtype=torch.float32, device=dev)
+    linear_hip(f4, mod.point_lin4.weight, mod.point_lin4.bias, act=1, pool=pool2, poolidx=idx)
+    return linear_hip(pool2[:n_vox], mod.vox_lin2.weight, mod.vox_lin2.bias, act=1)
+
+
+def roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox=8, roi_out_bbox=2):
+    """The per-ray ROI feature (models/pipeline.py:374-391) at any channel count / output size:
+    [R, C * roi_out_bbox^2] through lidf_roi_align_f32."""
+    B, Cn, h, w = feat_grid.shape
+    R = ray_pix.shape[0]
+    out = torch.empty((R, Cn * roi_out_bbox * roi_out_bbox), dtype=torch.float32, device=feat_grid.device)
+    fg = feat_grid.detach().contiguous()
+    with torch.cuda.device(fg.device):
+        _lib.check(_lib.lib().lidf_roi_align_f32(_lib.ptr(fg), B, Cn, h, w, _lib.ptr(ray_pix), _lib.ptr(ray_bid), R,
+                                                 int(roi_inp_bbox), int(roi_out_bbox), _lib.ptr(out), out.shape[1],
+                                                 _lib.current_stream(fg.device)))
+    return out
+
+
+def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid, vox_feat, prob_dec,
+          offset_dec, multires, multires_views, roi_inp_bbox, roi_out_bbox, offset_range, part_size,
+          vox_center, pos_rel, ray_flat, depth, want_rayfeat):
+    """get_embedding + get_pred (models/pipeline.py:338-466) at widths other than the shipped ones:
+    the decoder input rows are materialised as the reference does ([P, pnet_out + rgb_out * roi^2 +
+    2E + Ed]) and the decoders run layer by layer. The pieces: lidf_roi_align_f32, lidf_embed_f32,
+    lidf_pe_rows_f32, lidf_linear_f32 per layer, lidf_query_tail_f32 (pair positions, per-ray softmax /
+    arg-max, select); gathers and the concat are torch indexing on the device."""
+    from .decoders import get_embedder
+    dev = ray_dir.device
+    R, P = ray_dir.shape[0], pair_ray.shape[0]
+    E = 3 + 6 * multires
+    L = _lib.lib()
+    roi = roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox, roi_out_bbox)
+    edir = get_embedder(multires_views)[0](ray_dir.detach().contiguous())
+    pe = torch.empty((P, 2 * E), dtype=torch.float32, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_pe_rows_f32(_lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                                          _lib.ptr(vox_center), 1 if pos_rel else 0, multires, P, _lib.ptr(pe),
+                                          _lib.current_stream(dev)))
+    pr, pv = pair_ray.long(), pair_vox.long()
+    rows = torch.cat((vox_feat.detach()[pv], roi[pr], pe, edir[pr]), 1)
+    if rows.shape[1] != prob_dec.inp_dim or rows.shape[1] != offset_dec.inp_dim:
+        raise RuntimeError("decoder inp_dim must be %d for this configuration" % rows.shape[1])
+    pred_prob = decoder_forward(prob_dec, rows)
+    pred_offset = decoder_forward(offset_dec, rows)
+    if pred_prob.shape[1] != 1 or pred_offset.shape[1] != 1:
+        raise RuntimeError("get_pred takes one logit and one offset per pair (out_dim 1)")
+    f32 = dict(dtype=torch.float32, device=dev)
+    pos, sm = torch.empty((P, 3), **f32), torch.empty((P,), **f32)
+    mid, pred = torch.empty((R,), dtype=torch.int64, device=dev), torch.empty((R, 3), **f32)
+    off1, prob1 = pred_offset.reshape(-1).contiguous(), pred_prob.reshape(-1).contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(L.lidf_query_tail_f32(_lib.ptr(off1), _lib.ptr(prob1), _lib.ptr(pair_off), _lib.ptr(pair_ray),
+                                         _lib.ptr(pair_t), _lib.ptr(ray_dir), R, P, float(offset_range[0]),
+                                         float(offset_range[1]), float(part_size), None, _lib.ptr(pos), _lib.ptr(sm),
+                                         _lib.ptr(mid), _lib.ptr(pred), _lib.current_stream(dev)))
+    if depth is not None:   # pipeline.py:593-596: the queried pixels take the predicted z
+        hw = depth.shape[1] * depth.shape[2]
+        depth.view(-1)[ray_bid.long() * hw + ray_flat.long()] = pred[:, 2]
+    out = {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pos,
+           "pred_prob_end_softmax": sm, "max_pair_id": mid, "pred_pos": pred, "workspace": None}
+    if want_rayfeat:
+        out["rayfeat"] = torch.cat((roi, edir), 1)
+    return out

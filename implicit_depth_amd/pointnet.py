@@ -62,10 +62,16 @@ def packed_pointnet(mod, s, dev):
     return e.blob
 
 
-def check_pointnet(mod):
-    if (mod.input_channels, mod.gf_dim, mod.point_lin4.out_features) != (6, 32, 128):
-        raise RuntimeError("lidf_hip PointNet2Stage is built for input_channels=6, gf_dim=32, "
-                           "output_channels=128 (every shipped config)")
+def is_shipped(mod):
+    """The widths the register-chained kernels are built for (every shipped config)."""
+    return (mod.input_channels, mod.gf_dim, mod.point_lin4.out_features) == (6, 32, 128)
+
+
+def check_pointnet(mod, what="this entry"):
+    if not is_shipped(mod):
+        raise RuntimeError("lidf_hip: %s is built for PointNet2Stage(input_channels=6, gf_dim=32, "
+                           "output_channels=128) (every shipped config); inference at other widths runs "
+                           "layer by layer (PointNet2Stage.forward without autograd)" % what)
 
 
 _PN_ORDER = ("point_lin1", "point_lin2", "vox_lin1", "point_lin3", "point_lin4", "vox_lin2")
@@ -154,11 +160,16 @@ class PointNet2Stage(nn.Module):
             n_vox = int(vox2point_idx.max().item()) + 1 if vox2point_idx.numel() else 0
         needs_grad = torch.is_grad_enabled() and (
             inp_feat.requires_grad or any(p.requires_grad for p in self.parameters()))
-        check_pointnet(self)
-        if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != 6:
-            raise RuntimeError("inp_feat must be float32 [N,6]")
+        if (inp_feat.dtype != torch.float32 or inp_feat.dim() != 2
+                or inp_feat.shape[1] != self.input_channels):
+            raise RuntimeError("inp_feat must be float32 [N,%d]" % self.input_channels)
         if tuple(vox2point_idx.shape) != (inp_feat.shape[0],) or vox2point_idx.device != inp_feat.device:
             raise RuntimeError("vox2point_idx must be [N] on the device of inp_feat")
+        if not is_shipped(self):   # other widths: layer by layer (generic.py), inference only
+            if needs_grad:
+                check_pointnet(self, "the training path (forward under autograd)")
+            from . import generic
+            return generic.pointnet_forward(self, inp_feat, vox2point_idx, int(n_vox))
         if needs_grad:   # the library's training path: forward that keeps activations + backward
             params = [t for name in _PN_ORDER for t in (getattr(self, name).weight, getattr(self, name).bias)]
             return _PointNetTrainFn.apply(inp_feat, vox2point_idx.detach().to(torch.int32).contiguous(),

@@ -279,8 +279,12 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
                ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None,
-               want_rayfeat=False, precision="f32"):
+               want_rayfeat=False, precision="f32", roi_out_bbox=2):
     """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
+
+    Widths other than the shipped configuration (feat_grid channels != 32, roi_out_bbox != 2, vox_feat
+    width != 128, decoders with gf_dim != 64): the same function layer by layer on materialised rows
+    (generic.query; f32 only).
 
     precision: "f32" (default) or "f16x3" — the decoders' matrix products evaluated as three
     f16-piece products per term with f32 accumulation (f32-level accuracy, see lidf_hip.h).
@@ -308,13 +312,13 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
             _f32(t, n)
     for t, n in ((pair_off, "pair_off"), (pair_ray, "pair_ray"), (pair_vox, "pair_vox")):
         _i32(t, n)
-    if feat_grid.dim() != 4 or feat_grid.shape[1] != 32:
-        raise RuntimeError("feat_grid must be [B,32,h,w] (rgb_out=32)")
-    if vox_feat.dim() != 2 or vox_feat.shape[1] != 128:
-        raise RuntimeError("vox_feat must be [V,128] (pnet_out=128)")
-    _check_supported(prob_dec), _check_supported(offset_dec)
+    if feat_grid.dim() != 4 or vox_feat.dim() != 2:
+        raise RuntimeError("feat_grid must be [B,C,h,w], vox_feat [V,F]")
+    from .decoders import is_shipped
+    shipped = (feat_grid.shape[1] == 32 and vox_feat.shape[1] == 128 and roi_out_bbox == 2
+               and is_shipped(prob_dec) and is_shipped(offset_dec))
     E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
-    D = 256 + 2 * E + Ed
+    D = vox_feat.shape[1] + feat_grid.shape[1] * roi_out_bbox * roi_out_bbox + 2 * E + Ed
     if prob_dec.inp_dim != D or offset_dec.inp_dim != D:
         raise RuntimeError("decoder inp_dim must be %d for this configuration" % D)
     dev = ray_dir.device
@@ -335,6 +339,13 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if tuple(pair_vox.shape) != (P,) or tuple(pair_t.shape) != (P, 2) or pair_ray.dim() != 1:
         raise RuntimeError("pair_ray / pair_vox / pair_t must be [P] / [P] / [P,2]")
 
+    if not shipped:
+        if precision != "f32":
+            raise RuntimeError("precision %r is built for the shipped widths" % precision)
+        from . import generic
+        return generic.query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid, vox_feat,
+                             prob_dec, offset_dec, multires, multires_views, roi_inp_bbox, roi_out_bbox,
+                             offset_range, part_size, vox_center, pos_rel, ray_flat, depth, want_rayfeat)
     f32 = dict(dtype=torch.float32, device=dev)
     out = {
         "pred_offset": torch.empty((P, 1), **f32),

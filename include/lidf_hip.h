@@ -514,6 +514,37 @@ size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, 
                                   int64_t max_pairs, int32_t lds_voxels, int32_t refine_times);
 int lidf_frame_f32(const LidfFrameArgs* args, lidf_stream_t stream);
 
+/* ---- One linear layer of any width ------------------------------------------------------------
+ * out[r, 0:nout] = act( x[r, 0:k] . w[0:nout, 0:k]^T + b  (+ addrows[addidx[r], 0:nout]) ), torch.nn.Linear's
+ * weight layout ([nout, k], row stride ldw), through the same f32 matrix-instruction kernel the fixed-width
+ * paths use (lidf_linear.hip; 256 output columns per launch). It is what the Python modules are built from
+ * when a width differs from the shipped configuration (models/implicit_net.py IMNet / IEF with
+ * gf_dim != 64 or out_dim != 1, models/pointnet.py PointNet2Stage with gf_dim != 32 or
+ * output_channels != 128): those run layer by layer instead of as one register-chained launch.
+ *   act     0 = none, 1 = max(v, slope * v)  (slope 0: ReLU; 0.02: the decoders' leaky ReLU)
+ *   addrows optional gathered term (row stride ld_add >= nout), added before the activation
+ *   out     optional [n, nout] (row stride ld_out)
+ *   pool    optional [*, nout] (row stride ld_pool), pool[poolidx[r], c] = max(pool[...], value): the
+ *           scatter-max of models/pointnet.py:27,35; needs act = 1, slope = 0, nout % 32 == 0 and a
+ *           zero-initialised table (values are >= 0, a voxel without points keeps 0 as torch_scatter does)
+ *   workspace  lidf_linear_workspace_bytes(k)                                                        */
+size_t lidf_linear_workspace_bytes(int32_t k);
+int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                    const float* b, int32_t nout, int32_t act, float slope, const float* addrows,
+                    const int32_t* addidx, int64_t ld_add, float* out, int64_t ld_out, float* pool,
+                    const int32_t* poolidx, int64_t ld_pool, void* workspace, size_t workspace_bytes,
+                    lidf_stream_t stream);
+
+/* RoIAlign of the per-ray boxes at any channel count and output size (models/pipeline.py:374-391:
+ * box = pixel +- roi_inp_bbox / 2, corners clamped to the image, torchvision.ops.roi_align with
+ * output_size = roi_out_bbox, spatial_scale 1, sampling_ratio -1, aligned = True). out[r, (c*S + ph)*S + pw]
+ * (the reference's reshape of [K, C, S, S]), row stride ld_out >= C*S*S. The shipped rgb_out = 32 /
+ * roi_out_bbox = 2 run inside lidf_query_f32 / lidf_ray_features_f32 (box sums); this is the kernel for
+ * the other settings (implicit_depth_amd/generic.py). Invalid ray_bid / pixel values are not checked. */
+int lidf_roi_align_f32(const float* feat_grid, int32_t batch, int32_t channels, int32_t height, int32_t width,
+                       const int32_t* ray_pix, const int32_t* ray_bid, int64_t n_rays, int32_t roi_inp_bbox,
+                       int32_t roi_out_bbox, float* out, int64_t ld_out, lidf_stream_t stream);
+
 /* ---- Eval depth metrics ----------------------------------------------------------------------
  * Replaces the bs == 1 evaluation branch of LIDF.compute_loss (models/pipeline.py:577-627): the
  * predicted depth map, the ground-truth depth map and the segmentation mask ([src_h, src_w],

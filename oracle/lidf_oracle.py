@@ -426,13 +426,17 @@ def build_inp_embed(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, feat_
 def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_grid, vox_feat,
           prob_p, off_p, off_kind="IEF", n_iter=2, use_sigmoid=False, multires=8, multires_views=4,
           roi_inp_bbox=8, offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-          chunk=262144, fast_roi=False):
-    """get_embedding + get_pred (models/pipeline.py:338-466) + depth z. Pairs are ray-major."""
+          chunk=262144, fast_roi=False, roi_out_bbox=2):
+    """get_embedding + get_pred (models/pipeline.py:338-466) + depth z. Pairs are ray-major.
+    roi_out_bbox: model.roi_out_bbox (:387), 2 in every shipped config."""
     R = ray_dir.shape[0]
     P = pair_ray.shape[0]
     boxes = roi_boxes(ray_pix.long(), ray_bid.long(), feat_grid.shape[2], feat_grid.shape[3],
                       roi_inp_bbox)
-    ray_rgb = (roi_align_fast if fast_roi else roi_align)(feat_grid, boxes).reshape(R, -1)
+    if fast_roi and roi_out_bbox == 2:
+        ray_rgb = roi_align_fast(feat_grid, boxes).reshape(R, -1)
+    else:
+        ray_rgb = roi_align(feat_grid, boxes, output_size=roi_out_bbox).reshape(R, -1)
     e_dir_ray = embed(ray_dir, multires_views)
     pred_offset = torch.empty(P, 1)
     pred_prob = torch.empty(P, 1)

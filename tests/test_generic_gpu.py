@@ -1,0 +1,139 @@
+"""Widths other than the shipped configuration (implicit_depth_amd/generic.py): every layer through
+lidf_linear_f32, against the same function in torch ops on the CPU in float64 (the modules'
+forward_composite: models/implicit_net.py:81-98 / :131-152, models/pointnet.py:22-38)."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("n,k,nout,bias,act,slope", [(1000, 37, 70, True, 1, 0.02), (5, 300, 520, False, 0, 0.0),
+                                                     (129, 1, 16, True, 0, 0.0), (4097, 64, 256, True, 1, 0.0),
+                                                     (33, 513, 31, True, 1, 0.02)])
+def test_linear_any_width(cuda, n, k, nout, bias, act, slope):
+    from implicit_depth_amd.generic import linear_hip
+    g = torch.Generator().manual_seed(n + k)
+    x, w = torch.randn(n, k + 3, generator=g), torch.randn(nout, k + 5, generator=g) * 0.2
+    b = torch.randn(nout, generator=g) if bias else None
+    got = linear_hip(x.to(cuda)[:, :k], w.to(cuda), b.to(cuda) if bias else None, act=act, slope=slope, w_col0=2, k=k)
+    ref = F.linear(x[:, :k].double(), w[:, 2:2 + k].double(), b.double() if bias else None)
+    if act:
+        ref = torch.max(ref, ref * slope)
+    assert got.shape == (n, nout) and _rel(got, ref) <= 2e-6
+
+
+def test_linear_gathered_term_and_scatter_max(cuda):
+    from implicit_depth_amd.generic import linear_hip
+    g = torch.Generator().manual_seed(3)
+    n, k, nout, V = 3000, 40, 96, 57
+    x, w, b = torch.randn(n, k, generator=g), torch.randn(nout, k, generator=g) * 0.3, torch.randn(nout, generator=g)
+    add = torch.randn(V, nout + 8, generator=g)
+    idx = torch.randint(0, V - 1, (n,), generator=g).int()          # the last voxel stays empty
+    pool = torch.zeros(V, nout, device=cuda)
+    out = torch.empty(n, nout, device=cuda)
+    linear_hip(x.to(cuda), w.to(cuda), b.to(cuda), act=1, addrows=add.to(cuda)[:, :nout], addidx=idx.to(cuda),
+               out=out, pool=pool, poolidx=idx.to(cuda))
+    ref = torch.relu(F.linear(x.double(), w.double(), b.double()) + add[idx.long(), :nout].double())
+    assert _rel(out, ref) <= 2e-6
+    rp = torch.zeros(V, nout, dtype=torch.float64)
+    rp.scatter_reduce_(0, idx.long().view(-1, 1).expand(n, nout), ref, "amax", include_self=True)
+    assert _rel(pool, rp) <= 2e-6 and float(pool[V - 1].abs().max()) == 0.0
+    # the scatter-max of the kept rows equals the table (bit for bit: the same values were raised)
+    chk = torch.zeros(V, nout, device=cuda)
+    chk.scatter_reduce_(0, idx.long().to(cuda).view(-1, 1).expand(n, nout), out, "amax", include_self=True)
+    assert torch.equal(chk, pool)
+
+
+@pytest.mark.parametrize("kind,inp,out_dim,gf,n_iter,sig", [("IMNET", 50, 3, 24, 1, False), ("IMNET", 385, 1, 128, 1, True),
+                                                            ("IEF", 385, 1, 32, 3, False), ("IEF", 77, 1, 96, 2, True),
+                                                            ("IMNET", 385, 2, 64, 1, False)])
+def test_decoders_at_other_widths(cuda, kind, inp, out_dim, gf, n_iter, sig):
+    from implicit_depth_amd import IEF, IMNet
+    torch.manual_seed(gf + inp)
+    mod = IMNet(inp, out_dim, gf, use_sigmoid=sig) if kind == "IMNET" else IEF("cpu", inp, out_dim, gf, n_iter=n_iter,
+                                                                               use_sigmoid=sig)
+    for p in mod.parameters():                     # the reference's init (std 0.02) leaves the output flat
+        p.data.mul_(6.0)
+    ref_mod = copy.deepcopy(mod).double()
+    if kind == "IEF":
+        ref_mod.init_offset = ref_mod.init_offset.double()
+    x = torch.randn(1500, inp)
+    with torch.no_grad():
+        ref = ref_mod.forward_composite(x.double())
+    mod = mod.to(cuda).eval()
+    if kind == "IEF":
+        mod.device, mod.init_offset = cuda, mod.init_offset.to(cuda)
+    with torch.no_grad():
+        got = mod(x.to(cuda))
+    assert got.shape == (1500, out_dim)
+    assert float((got.double().cpu() - ref).abs().max()) <= 1e-5
+    # the training entries are built for the shipped widths: a clear error, not a detached result
+    if gf != 64 or out_dim != 1:
+        with pytest.raises(RuntimeError, match="shipped"):
+            mod(x.to(cuda).requires_grad_(True))
+
+
+@pytest.mark.parametrize("cin,outc,gf,n,V", [(9, 192, 48, 5000, 40), (6, 64, 16, 700, 3), (6, 128, 64, 2000, 300)])
+def test_pointnet_at_other_widths(cuda, cin, outc, gf, n, V):
+    from implicit_depth_amd import PointNet2Stage
+    torch.manual_seed(cin + outc)
+    mod = PointNet2Stage(cin, outc, gf)
+    ref_mod = copy.deepcopy(mod).double()
+    x = torch.randn(n, cin)
+    idx = torch.randint(0, V, (n,))
+    idx[:V] = torch.arange(V)                      # every voxel has a point (torch_scatter's dim_size)
+    with torch.no_grad():
+        ref = ref_mod.forward_composite(x.double(), idx, V)
+    mod = mod.to(cuda).eval()
+    with torch.no_grad():
+        got = mod(x.to(cuda), idx.to(cuda), n_vox=V)
+    assert got.shape == (V, outc) and _rel(got, ref) <= 5e-6
+
+
+@pytest.mark.parametrize("Cr,roi_out,Co,gf,off_kind,Lm,Lv,pos_rel", [(16, 3, 64, 32, "IEF", 8, 4, False),
+                                                                     (32, 2, 128, 96, "IMNET", 4, 2, True),
+                                                                     (5, 1, 96, 64, "IEF", 0, 0, False),
+                                                                     (48, 2, 128, 64, "IEF", 8, 4, False)])
+def test_query_at_other_widths(cuda, Cr, roi_out, Co, gf, off_kind, Lm, Lv, pos_rel):
+    """lidf_query with rgb_out / roi_out_bbox / pnet_out / imnet_gf other than the shipped values
+    (models/pipeline.py:62-85) against the oracle's get_embedding + get_pred on the same inputs."""
+    from implicit_depth_amd import IEF, IMNet
+    from implicit_depth_amd.query import lidf_query
+    from util import orc, to_dev
+    scene = orc.synthetic_scene(2, 13, 17, 6, seed=40 + Cr, ragged=True, multires=Lm, multires_views=Lv)
+    g = torch.Generator().manual_seed(Cr + Co)
+    scene["vox_feat"] = torch.relu(torch.randn(scene["V"], Co, generator=g))
+    coarse = torch.randn(2, Cr, 4, 5, generator=g)
+    scene["feat_grid"] = F.interpolate(coarse, size=(13, 17), mode="bilinear", align_corners=False).contiguous()
+    D = Co + Cr * roi_out * roi_out + 2 * orc.embed_dim(Lm) + orc.embed_dim(Lv)
+    prob_p, off_p = orc.init_decoder("IMNET", D, 7, 5.0, gf=gf), orc.init_decoder(off_kind, D, 8, 5.0, gf=gf)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], scene["feat_grid"],
+                    scene["vox_feat"], prob_p, off_p, off_kind=off_kind, n_iter=2, multires=Lm, multires_views=Lv,
+                    roi_out_bbox=roi_out, vox_center=scene["vox_center"], pos_rel=pos_rel)
+    prob = IMNet(D, 1, gf)
+    off = IEF(cuda, D, 1, gf, n_iter=2) if off_kind == "IEF" else IMNet(D, 1, gf)
+    prob.load_state_dict(prob_p), off.load_state_dict(off_p)
+    prob, off = prob.to(cuda).eval(), off.to(cuda).eval()
+    s = to_dev(scene, cuda)
+    depth = torch.zeros((2, 13, 17), device=cuda)
+    with torch.no_grad():
+        out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                         s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off, multires=Lm, multires_views=Lv,
+                         roi_out_bbox=roi_out, vox_center=s["vox_center"], pos_rel=pos_rel, ray_flat=s["ray_flat"],
+                         depth=depth, want_rayfeat=True)
+    assert float((out["rayfeat"][:, :Cr * roi_out * roi_out].cpu() - ref["ray_rgb"]).abs().max()) <= 2e-6
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_prob_end_softmax"):
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= 1e-4, k
+    same = out["max_pair_id"].cpu() == ref["max_pair_id"]
+    assert float(same.float().mean()) >= 0.99                      # float-noise ties aside
+    assert float((out["pred_pos"].cpu() - ref["pred_pos"])[same].abs().max()) <= 1e-4
+    z = depth.view(-1)[(s["ray_bid"].long() * 13 * 17 + s["ray_flat"].long())]
+    assert torch.equal(z, out["pred_pos"][:, 2])
