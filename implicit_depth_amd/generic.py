@@ -173,3 +173,47 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     if want_rayfeat:
         out["rayfeat"] = torch.cat((roi, edir), 1)
     return out
+
+
+def refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound, voxel_bid, rgb_img,
+           feat_grid, valid_inp, valid_vox, pnet_model, offset_dec, forward_times, multires, multires_views,
+           roi_inp_bbox, roi_out_bbox, offset_range, pos_rel, pnet_pos_rel, ray_rgb, pnet_select):
+    """forward_times x RefineNet.get_pred_refine (models/pipeline.py:922-1030, eval flavour) at widths other
+    than the shipped ones, step by step as the reference writes it: the end voxel of every ray
+    (lidf_pcl_aabb_last_f32 over the arg-max pair's voxel), the PointNet over valid + predicted points,
+    the decoder rows [R, pnet_out + rgb_out * roi^2 + E + Ed], the decoder, the offset along the ray. The
+    modules run through their own forward (layer by layer where a width differs)."""
+    from .decoders import get_embedder
+    from .extensions import pcl_aabb
+    dev = ray_dir.device
+    R, P, V = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0]
+    hw = rgb_img.shape[2] * rgb_img.shape[3]
+    if ray_rgb is None:
+        ray_rgb = roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox, roi_out_bbox)
+    edir = get_embedder(multires_views)[0](ray_dir.detach().contiguous())
+    embed = get_embedder(multires)[0]
+    miss_rgb = rgb_img.permute(0, 2, 3, 1).reshape(-1, 3)[ray_bid.long() * hw + ray_flat.long()]
+    pv = torch.cat((pair_vox.long(), torch.zeros(1, dtype=torch.long, device=dev)))
+    first = pv[max_pair_id.clamp(max=P)]                       # the dummy row's voxel is 0 (pipeline.py:933)
+    sel = None
+    if pnet_select is not None:
+        sel = torch.nonzero(pnet_select.reshape(-1) != 0, as_tuple=False)[:, 0]
+    cur = pred_pos.detach().contiguous()
+    end_voxel = first.int()
+    for _ in range(int(forward_times)):
+        last = pcl_aabb.last_voxel(cur, voxel_bound, ray_bid, voxel_bid).long()     # -1: in no voxel
+        end = torch.maximum(first, last)                       # (:939-944: scatter of the containing voxels)
+        end_voxel = end.int()
+        eb = voxel_bound[end]
+        center = (eb[:, :3] + eb[:, 3:]) / 2.0
+        pred_inp = torch.cat(((cur - center) if pnet_pos_rel else cur, miss_rgb), 1)
+        if sel is not None:
+            pn_inp, pn_vox = torch.cat((valid_inp, pred_inp[sel]), 0), torch.cat((valid_vox.long(), end[sel]), 0)
+        else:
+            pn_inp, pn_vox = torch.cat((valid_inp, pred_inp), 0), torch.cat((valid_vox.long(), end), 0)
+        occ = pnet_model(pn_inp.contiguous(), pn_vox.int(), n_vox=V)
+        enter = (cur - center) if pos_rel else cur
+        rows = torch.cat((occ[end], ray_rgb, embed(enter.contiguous()), edir), 1)
+        off = offset_dec(rows)
+        cur = (cur + (off * (offset_range[1] - offset_range[0]) + offset_range[0]) * ray_dir).contiguous()
+    return cur, end_voxel

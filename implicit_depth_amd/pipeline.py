@@ -28,6 +28,7 @@ class LidfOptions:
         self.mask_type = "all"                 # 'all' | 'pred'
         self.multires, self.multires_views = 8, 4
         self.roi_inp_bbox = 8
+        self.roi_out_bbox = 2                  # model.roi_out_bbox (2 in every shipped config)
         self.intersect_pos_type = "abs"
         self.offset_range = (0.0, 1.0)
         self.grid_res = 8
@@ -157,7 +158,7 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
     out = Q.lidf_query(dd["miss_ray_dir"], dd["ray_pix"], dd["ray_bid"], pair_off, pair_ray, pair_vox,
                        pair_t, full_rgb_feat, dd["occ_voxel_feat"], prob_dec, offset_dec,
                        multires=opt.multires, multires_views=opt.multires_views,
-                       roi_inp_bbox=opt.roi_inp_bbox, offset_range=opt.offset_range,
+                       roi_inp_bbox=opt.roi_inp_bbox, roi_out_bbox=opt.roi_out_bbox, offset_range=opt.offset_range,
                        part_size=occ["part_size"], vox_center=vox_center,
                        pos_rel=opt.intersect_pos_type == "rel", ray_flat=dd["ray_flat"], depth=depth,
                        want_rayfeat=True, precision=precision, workspace=workspace)
@@ -188,7 +189,7 @@ def refine_forward(dd, pnet_model_refine, offset_dec_refine, opt=None, precision
         dd["max_pair_id"], dd["pair_vox"], dd["voxel_bound"], dd["voxel_bid"], dd["rgb_img"],
         dd["full_rgb_feat"], valid_inp.contiguous(), occ_rev, pnet_model_refine, offset_dec_refine,
         forward_times=opt.refine_forward_times, multires=opt.multires,
-        multires_views=opt.multires_views, roi_inp_bbox=opt.roi_inp_bbox,
+        multires_views=opt.multires_views, roi_inp_bbox=opt.roi_inp_bbox, roi_out_bbox=opt.roi_out_bbox,
         offset_range=opt.refine_offset_range, pos_rel=opt.refine_intersect_pos_type == "rel",
         pnet_pos_rel=opt.refine_pnet_pos_type == "rel", rayfeat=dd.get("rayfeat"),
         precision=precision, pnet_select=sel)
@@ -251,10 +252,13 @@ class FrameRunner:
         self.precision = precision
         self.bs, self.h, self.w, self.dev = bs, h, w, torch.device(device)
         self.mods = (pnet_model, prob_dec, offset_dec, pnet_model_refine, offset_dec_refine)
-        _check_supported(prob_dec), _check_supported(offset_dec), check_pointnet(pnet_model)
+        what = "FrameRunner (use lidf_forward / refine_forward, which run other widths layer by layer)"
+        _check_supported(prob_dec, what), _check_supported(offset_dec, what), check_pointnet(pnet_model, what)
+        if opt.roi_out_bbox != 2:
+            raise RuntimeError("lidf_hip: %s is built for roi_out_bbox = 2" % what)
         self.refine = pnet_model_refine is not None
         if self.refine:
-            _check_supported(offset_dec_refine), check_pointnet(pnet_model_refine)
+            _check_supported(offset_dec_refine, what), check_pointnet(pnet_model_refine, what)
         # the widened grid of LIDF.get_occ_vox_bound (models/pipeline.py:167-173), in the reference's f32
         t32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
         lo, hi = t32(opt.xmin), t32(opt.xmax)

@@ -428,7 +428,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                 forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
                 offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None,
-                precision="f32", pnet_select=None, profile_events=None):
+                precision="f32", pnet_select=None, profile_events=None, roi_out_bbox=2):
     """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
     `forward_times` iterations of get_pred_refine through lidf_refine_f32.
 
@@ -458,11 +458,29 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         _i32(t, n)
     if max_pair_id.dtype != torch.int64:
         raise RuntimeError("max_pair_id must be int64")
-    _check_supported(offset_dec)
-    check_pointnet(pnet_model)
+    from .decoders import is_shipped
+    from .pointnet import is_shipped as pnet_shipped
     E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
-    if offset_dec.inp_dim != 256 + E + Ed:
-        raise RuntimeError("refine offset_dec inp_dim must be %d" % (256 + E + Ed))
+    roi_w = feat_grid.shape[1] * roi_out_bbox * roi_out_bbox
+    D = pnet_model.point_lin4.out_features + roi_w + E + Ed
+    if offset_dec.inp_dim != D:
+        raise RuntimeError("refine offset_dec inp_dim must be %d" % D)
+    if not (is_shipped(offset_dec) and pnet_shipped(pnet_model) and feat_grid.shape[1] == 32 and roi_out_bbox == 2):
+        # widths other than the shipped ones: step by step through the modules (generic.refine), f32 only
+        if precision != "f32":
+            raise RuntimeError("precision %r is built for the shipped widths" % precision)
+        if valid_inp.dim() != 2 or valid_inp.shape[1] != pnet_model.input_channels:
+            raise RuntimeError("valid_inp must be [Nv,%d]" % pnet_model.input_channels)
+        from . import generic
+        ray_rgb = None
+        if rayfeat is not None:
+            if tuple(rayfeat.shape) != (ray_dir.shape[0], roi_w + Ed):
+                raise RuntimeError("rayfeat must be [R,%d]" % (roi_w + Ed))
+            ray_rgb = rayfeat[:, :roi_w]
+        return generic.refine(ray_dir, _as_i32(ray_pix, "ray_pix"), ray_bid, ray_flat, pred_pos, max_pair_id,
+                              pair_vox, voxel_bound, voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox,
+                              pnet_model, offset_dec, forward_times, multires, multires_views, roi_inp_bbox,
+                              roi_out_bbox, offset_range, pos_rel, pnet_pos_rel, ray_rgb, pnet_select)
     dev = ray_dir.device
     R, P, V, Nv = ray_dir.shape[0], pair_vox.shape[0], voxel_bound.shape[0], valid_inp.shape[0]
     B, _, h, w = rgb_img.shape

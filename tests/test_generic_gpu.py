@@ -137,3 +137,65 @@ def test_query_at_other_widths(cuda, Cr, roi_out, Co, gf, off_kind, Lm, Lv, pos_
     assert float((out["pred_pos"].cpu() - ref["pred_pos"])[same].abs().max()) <= 1e-4
     z = depth.view(-1)[(s["ray_bid"].long() * 13 * 17 + s["ray_flat"].long())]
     assert torch.equal(z, out["pred_pos"][:, 2])
+
+
+def _pointnet_params(cin, outc, gf, seed, scale=1.5):
+    g = torch.Generator().manual_seed(seed)
+    half = outc // 2
+    p = {}
+    for name, (dout, din) in {"point_lin1": (gf, cin), "point_lin2": (half, gf), "vox_lin1": (half, half),
+                              "point_lin3": (outc, outc), "point_lin4": (outc, outc), "vox_lin2": (outc, outc)}.items():
+        b = 1.0 / din ** 0.5
+        p[name + ".weight"] = (torch.rand(dout, din, generator=g) * 2 - 1) * b * scale
+        p[name + ".bias"] = (torch.rand(dout, generator=g) * 2 - 1) * b
+    return p
+
+
+def test_eval_chain_at_other_widths(cuda):
+    """pipeline.lidf_forward + refine_forward with rgb_out 16, pnet_out 64, pnet_gf 16, imnet_gf 32 (every
+    shipped config: 32 / 128 / 32 / 64) against the oracle chain: the geometry runs through the same
+    kernels as ever, every network layer by layer."""
+    from implicit_depth_amd import IEF, IMNet, PointNet2Stage, pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    from util import orc
+    B, h, w, Cr, Co, gfp, gf = 2, 48, 64, 16, 64, 16, 32
+    batch, feat = synthetic_batch(B, h, w, seed=77)
+    feat = feat[:, :Cr].contiguous()
+    D1 = Co + Cr * 4 + 2 * 51 + 27
+    D2 = Co + Cr * 4 + 51 + 27
+    pnet_p, pnet_r = _pointnet_params(6, Co, gfp, 3), _pointnet_params(6, Co, gfp, 4)
+    prob_p, off_p = orc.init_decoder("IMNET", D1, 7, 5.0, gf=gf), orc.init_decoder("IEF", D1, 8, 5.0, gf=gf)
+    offr_p = orc.init_decoder("IEF", D2, 9, 5.0, gf=gf)
+    ok_ref, ref = orc.lidf_forward(batch, feat, pnet_p, prob_p, off_p, fast_roi=False)
+    assert ok_ref
+    cur = ref["pred_pos"]
+    for _ in range(2):
+        cur, end_ref, _ = orc.refine_step(cur, ref["miss_ray_dir"], ref["miss_img_ind"], ref["miss_bid"],
+                                          ref["miss_flat_img_id"], ref["max_pair_id"], ref["pair_vox"],
+                                          ref["voxel_bound"], ref["occ_vox_bid"], batch["rgb"], feat, ref["pnet_inp"],
+                                          ref["revidx"], pnet_r, offr_p, ray_rgb=ref["ray_rgb"])
+
+    def mod(m, p):
+        m.load_state_dict(p)
+        return m.to(cuda).eval()
+    pnet, pnetr = mod(PointNet2Stage(6, Co, gfp), pnet_p), mod(PointNet2Stage(6, Co, gfp), pnet_r)
+    prob, off = mod(IMNet(D1, 1, gf), prob_p), mod(IEF(cuda, D1, 1, gf, n_iter=2), off_p)
+    offr = mod(IEF(cuda, D2, 1, gf, n_iter=2), offr_p)
+    opt = pl.LidfOptions()
+    dev_batch = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        ok, dd = pl.lidf_forward(dev_batch, feat.to(cuda), pnet, prob, off, opt)
+        assert ok
+        pl.refine_forward(dd, pnetr, offr, opt)
+    assert (dd["pair_ray"].cpu().long() == ref["pair_ray"]).all() and (dd["pair_vox"].cpu().long() == ref["pair_vox"]).all()
+    assert float((dd["occ_voxel_feat"].cpu() - ref["occ_voxel_feat"]).abs().max()) <= 2e-5
+    for k in ("pred_offset", "pred_prob_end", "pair_pred_pos"):
+        assert float((dd[k].cpu() - ref[k]).abs().max()) <= 1e-4, k
+    same = dd["max_pair_id"].cpu() == ref["max_pair_id"]
+    assert float(same.float().mean()) >= 0.99
+    assert float((dd["pred_pos"].cpu() - ref["pred_pos"])[same].abs().max()) <= 1e-4
+    assert (dd["end_voxel_id"].cpu().long() == end_ref)[same].all()
+    assert float((dd["pred_pos_refine"].cpu() - cur)[same].abs().max()) <= 2e-4
+    # the frame call is built for the shipped widths: a clear error
+    with pytest.raises(RuntimeError, match="FrameRunner"):
+        pl.FrameRunner(B, h, w, cuda, pnet, prob, off, opt)
