@@ -42,7 +42,8 @@ const char* lidf_strerror(int status);
  * One implicit decoder: IMNet (models/implicit_net.py:60-98) or IEF (:100-152).
  * Weights are nn.Linear storage, row-major [out,in], borrowed (never cached across calls:
  * parameters change every optimizer step). Hidden widths are fixed to gf_dim=64
- * (256 -> 128 -> 64 -> 1), the value of every shipped config.
+ * (256 -> 128 -> 64 -> 1), the value of every shipped config; other widths run layer by layer
+ * through lidf_linear_f32 (below).
  */
 typedef struct LidfDecoder {
     const float* w1; /* [256, d_in]  (IEF: d_in = D + 16; IMNet: d_in = D) */
@@ -319,7 +320,8 @@ int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n_pts, int b
 /* ---- PointNet2Stage ------------------------------------------------------------------------
  * Replaces PointNet2Stage.forward (models/pointnet.py:22-38) incl. its two
  * torch_scatter.scatter(..., reduce='max') poolings, for the shipped dimensions
- * (input_channels 6, gf_dim 32, output_channels 128). Weights: nn.Linear storage [out,in].
+ * (input_channels 6, gf_dim 32, output_channels 128; other widths: lidf_linear_f32 with its scatter-max
+ * epilogue, layer by layer). Weights: nn.Linear storage [out,in].
  * inp [N,6] f32, vox [N] i32 (vox2point_idx: voxel of every point, < n_vox; a negative entry
  * leaves that point out of both poolings) -> out [n_vox,128].                                    */
 typedef struct LidfPointNet {
