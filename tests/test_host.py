@@ -283,3 +283,25 @@ def test_c_abi_argument_errors_without_gpu():
     assert L.lidf_query_pack_bytes() > 0 and L.lidf_pointnet_pack_bytes() > 0
     assert L.lidf_miss_ray_workspace_bytes(76800) > 0
     assert L.lidf_ray_features_workspace_bytes(1, 240, 320, 76800) >= 32 * 240 * 320 * 4
+
+
+def test_generic_width_paths_have_no_cpu_route():
+    """Widths other than the shipped ones run layer by layer on the device (generic.py): CPU tensors
+    are refused there as everywhere, and the any-width entries check their arguments without a GPU."""
+    import ctypes as C
+    from implicit_depth_amd import IMNet, _lib
+    from implicit_depth_amd.generic import linear_hip
+    with pytest.raises(RuntimeError, match="CUDA"):
+        linear_hip(torch.zeros(4, 8), torch.zeros(3, 8))
+    m = IMNet(20, 2, 24)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        m(torch.zeros(5, 20))
+    L = _lib.lib()
+    assert L.lidf_linear_workspace_bytes(0) == 0 and L.lidf_linear_workspace_bytes(385) > 0
+    null = C.c_void_p(None)
+    bad = L.lidf_linear_f32(null, 8, 4, 0, null, 8, null, 3, 0, 0.0, null, null, 0, null, 0, null, null, 0, null, 0, null)
+    assert bad == -1                                            # k <= 0: LIDF_ERR_BAD_ARG
+    assert L.lidf_linear_f32(null, 8, 0, 8, null, 8, null, 3, 0, 0.0, null, null, 0, null, 0, null, null, 0,
+                             null, 0, null) == 0              # n == 0: nothing to do
+    assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 0, 8, 3, null, 0, null) == 0
+    assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 5, 8, 0, null, 0, null) == -1
