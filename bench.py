@@ -7,8 +7,11 @@ query (lidf_query_f32) over one synthetic 240x320 frame with 64 candidates per r
 on every rank (BASELINE.json configs[1]; weak scaling: each rank owns one frame), followed — for
 N>1 — by the RCCL all-gather of the per-rank depth maps (the only collective on the path).
 Rank 0 prints ONE JSON line with the metric, the MFMA roofline of the dominant kernel (HIP events
-recorded by the library around lidf_points_kernel on the launch stream) and, at N=1, the CPU
-baseline (oracle port timed on the host cores on a bounded sample of the same workload).
+recorded by the library around lidf_points_fused_kernel on the launch stream) and, at N=1, the CPU
+baseline (the oracle port on the host cores over the same frame in 614,400-point slabs, ~20 s) and
+the kernel's average duration by rocprofv3 --kernel-trace of this same command, run as a child
+process after the timed region (roofline.kernel_ms_rocprof_live; --no-rocprof to skip).
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
 """
 import argparse
 import ctypes as C
