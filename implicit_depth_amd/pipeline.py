@@ -411,7 +411,6 @@ class FrameRunner:
         a.refine_times = self.times
         a.precision = Q.PRECISIONS[self.precision]
         if self.refine:
-            from .query import PRECISIONS  # noqa: F401
             dr = _decoder_struct(off_r, keep)
             pr = pointnet_struct(pnet_r, keep)
             keep.append(packed_pointnet(pnet_r, pr, self.dev))

@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .decoders import _check_supported, _decoder_struct
+from .decoders import _decoder_struct
 
 
 def _i32(t, name):
@@ -440,7 +440,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     non-zero = selected) = the mask_type 'all', use_all_pix False branch (pipeline.py:987-996): pass
     inp_zero_mask = 1 - valid_mask at the rays' pixels.
     Returns pred_pos_refine [R,3] and the last iteration's end_voxel_id [R] i32."""
-    from .pointnet import check_pointnet, pointnet_struct
+    from .pointnet import pointnet_struct
     _refuse_autograd("lidf_refine", "the modules on their own (PointNet2Stage, IEF and get_embedder are "
                      "differentiable; the fused stage-2 call has no backward)",
                      (("pred_pos", pred_pos), ("feat_grid", feat_grid), ("valid_inp", valid_inp),
@@ -576,7 +576,6 @@ def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=
     part_size, xmin (widened), revidx [Nv] i64, valid_v_pid [Nv] i64, valid_v_rel_coord [Nv,3],
     occ_vox_bid [V] i64, occ_vox_global_coord [V,3] i64, voxel_bound [V,6]; V == 0 is the
     reference's 'No occupied voxel' early exit."""
-    import math
     _lib.require_cuda(valid_xyz, valid_bid, names=["valid_xyz", "valid_bid"])
     _f32(valid_xyz, "valid_xyz"), _i32(valid_bid, "valid_bid")
     t32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731  (the reference's f32 maths)
