@@ -530,3 +530,59 @@ class FrameRunner:
         key = key or ("pred_depth_refine" if self.refine else "pred_depth")
         seg = batch["corrupt_mask"].reshape(self.bs, self.h, self.w)[frame]
         return Q.depth_metrics(self.buf[key][frame], batch["xyz"][frame, 2], seg)
+
+
+class FramePipeline:
+    """Independent frames pipelined over S streams (2.09 -> 1.61 ms per 240x320 frame at
+    S = 3 on one MI355X): S FrameRunners, each with its own buffers, packed-weight entries and HIP
+    stream, take the batches in turn, so that one frame's low-occupancy stretches (PointNet chains, the
+    per-voxel layers, scans, the partial last round of the matrix kernels) are filled by its neighbours'
+    kernels. Frames come back in submission order, each with its one size read.
+
+        pipe = FramePipeline(3, bs, h, w, device, pnet, prob_dec, offset_dec, opt, pnet_refine, offset_refine)
+        for batch in loader:
+            if pipe.full:
+                ok, data_dict, metrics = pipe.collect()            # the oldest frame; frees its runner
+                ...                                                # use (or clone) data_dict here
+            pipe.submit(batch, lidf.resnet_model(batch['rgb']))   # enqueue only
+        while pipe.pending:
+            ok, data_dict, metrics = pipe.collect()
+
+    data_dict holds views of a runner's buffers, valid until the submit() that reuses the runner (the one
+    after S - 1 further submits). A runner's stream waits for the caller's current stream before it starts
+    a frame: inputs produced there and reads of the previous result enqueued there are ordered before it."""
+
+    def __init__(self, streams, bs, h, w, device, *models, with_metrics=True, **kw):
+        if streams < 1:
+            raise ValueError("streams must be >= 1")
+        self.dev = torch.device(device)
+        self.runners = [FrameRunner(bs, h, w, device, *models, **kw) for _ in range(streams)]
+        self.lanes = [torch.cuda.Stream(self.dev) for _ in range(streams)]
+        self.with_metrics = with_metrics
+        self.pending = []          # [(slot, metrics)] in submission order
+        self.n = 0
+
+    @property
+    def full(self):
+        return len(self.pending) == len(self.runners)
+
+    def submit(self, batch, full_rgb_feat, pred_mask=None, valid_idx=None):
+        if self.full:
+            raise RuntimeError("FramePipeline: %d frames in flight — collect() the oldest first" % len(self.pending))
+        slot = self.n % len(self.runners)
+        self.n += 1
+        lane = self.lanes[slot]
+        lane.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(lane), torch.no_grad():
+            self.runners[slot].run(batch, full_rgb_feat, pred_mask, valid_idx=valid_idx)
+            m = self.runners[slot].metrics(batch) if self.with_metrics else None
+        self.pending.append((slot, m))
+
+    def collect(self):
+        """(success, data_dict, metrics) of the oldest frame in flight (waits for that frame only)."""
+        if not self.pending:
+            raise RuntimeError("FramePipeline: nothing in flight")
+        slot, m = self.pending.pop(0)
+        with torch.cuda.stream(self.lanes[slot]):
+            ok, dd = self.runners[slot].result()
+        return ok, dd, m

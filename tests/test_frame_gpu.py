@@ -342,3 +342,47 @@ def test_frame_with_listed_valid_points(cuda, shape, n, graph):
     with pytest.raises(RuntimeError):
         pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt).load(
             batch, feat, valid_idx=torch.zeros((B * h * w + 1, 2), dtype=torch.int64))
+
+
+def test_frame_pipeline_helper(cuda):
+    """pipeline.FramePipeline: frames submitted back to back over 3 streams come back in order, each
+    equal to what a single runner produces."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 96, 128
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=2)
+    frames = []
+    for seed in range(60, 67):                                  # 7 frames over 3 slots
+        batch, feat = synthetic_batch(B, h, w, seed=seed, hole_frac=1.0 + 0.1 * (seed % 4))
+        frames.append((_dev(batch, cuda), feat.to(cuda)))
+    keys = ("pred_pos_refine", "pred_depth_refine", "pair_pred_pos")
+    single = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    ref = []
+    with torch.no_grad():
+        for batch, feat in frames:
+            single.run(batch, feat)
+            ok, dd = single.result()
+            ref.append(({k: dd[k].clone() for k in keys}, {k: float(v) for k, v in single.metrics(batch).items()}))
+    pipe = pl.FramePipeline(3, B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    got = []
+
+    def take():
+        ok, dd, m = pipe.collect()
+        assert ok
+        got.append(({k: dd[k].clone() for k in keys}, {k: float(v) for k, v in m.items()}))
+    for i, (batch, feat) in enumerate(frames):
+        assert pipe.full == (i >= 3)
+        if pipe.full:
+            take()
+        pipe.submit(batch, feat)
+    with pytest.raises(RuntimeError):
+        pipe.submit(*frames[0])                                  # 3 in flight
+    while pipe.pending:
+        take()
+    assert len(got) == len(frames) and not pipe.pending
+    for (g, gm), (r, rm) in zip(got, ref):
+        for k in keys:
+            assert torch.equal(g[k], r[k]), k
+        for k in rm:
+            assert gm[k] == rm[k] or (gm[k] != gm[k] and rm[k] != rm[k]), k
