@@ -506,7 +506,8 @@ typedef struct LidfFrameArgs {
      * utils/point_utils.py sample_valid_points, a random block sampler that is host code upstream of
      * the path). n_valid_idx > 0: point j is pixel valid_idx_flat[j] of image valid_idx_bid[j], in
      * this order (duplicates allowed, as the sampler produces them for sparse frames);
-     * n_valid_idx <= batch*height*width; valid_mask is then only read by refine_use_all_pix == 0;
+     * n_valid_idx <= batch*height*width (image / pixel indices outside the batch are clamped into it,
+     * where the reference's index_select would raise); valid_mask is then only read by refine_use_all_pix == 0;
      * counts[LIDF_FC_VALID_PIX] = counts[LIDF_FC_VALID_SEL] = n_valid_idx. (ABI 6)                  */
     const int32_t* valid_idx_bid;
     const int32_t* valid_idx_flat;
