@@ -211,6 +211,8 @@ SIGNATURES = {
     "lidf_query_tail_backward_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float,
                                                C.c_float, _P, _P]),
     "lidf_roi_align_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I64, _I, _I, _P, _I64, _P]),
+    "lidf_wgrad_workspace_bytes": (_SZ, []),
+    "lidf_wgrad_f32": (_I, [_P, _I64, _I, _P, _I64, _I, _I64, _P, _I64, _P, _P, _SZ, _P]),
     "lidf_linear_workspace_bytes": (_SZ, [_I]),
     "lidf_linear_f32": (_I, [_P, _I64, _I64, _I, _P, _I64, _P, _I, _I, C.c_float, _P, _P, _I64, _P, _I64, _P, _P,
                             _I64, _P, _SZ, _P]),

@@ -1791,6 +1791,23 @@ LIDF_API int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, 
 #define WG_SCRATCH_FLOATS ((size_t)512 * (128 * 256 + 128))
 #define ACT_ROW_FLOATS LIDF_ACT_ROW_FLOATS   // per row and pass: H1 | H2 | H3 | offset in | sign words (lidf_device.h)
 
+// ---- weight gradient of a linear layer of any width: C += A^T B, db += column sums of A -----------
+LIDF_API size_t lidf_wgrad_workspace_bytes(void) { return WG_SCRATCH_FLOATS * 4; }
+
+LIDF_API int lidf_wgrad_f32(const float* a, int64_t lda, int32_t m, const float* b, int64_t ldb, int32_t n_cols,
+                              int64_t n, float* c, int64_t ldc, float* db, void* workspace,
+                              size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || m <= 0 || n_cols <= 0 || lda < m || ldb < n_cols || ldc < n_cols) return LIDF_ERR_BAD_ARG;
+    if (m > (1 << 20) || n_cols > (1 << 20) || ldc > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    if (n == 0) return LIDF_OK;
+    if (!a || !b || !c) return LIDF_ERR_BAD_ARG;
+    // without the scratch area the partial blocks are added with float atomics (order not fixed)
+    float* wgs = (workspace && workspace_bytes >= WG_SCRATCH_FLOATS * 4) ? (float*)workspace : nullptr;
+    CHECK_HIP(lidf_launch_wgrad(a, lda, m, b, ldb, n_cols, n, c, (int)ldc, db, wgs, wgs ? WG_SCRATCH_FLOATS : 0,
+                                (hipStream_t)stream));
+    return LIDF_OK;
+}
+
 LIDF_API size_t lidf_decoder_train_act_floats(int64_t n, int32_t n_pass) {
     if (n <= 0 || n_pass <= 0) return 0;
     return (size_t)n * ((size_t)n_pass * ACT_ROW_FLOATS + 1);  // + the pre-activation output

@@ -283,7 +283,11 @@ def _has(mod, name):
 class _DecoderBase(nn.Module):
     def _forward_train(self, inp_feat):
         """Differentiable forward through liblidf_hip (training)."""
-        _check_supported(self, "the training path (forward under autograd)")
+        if not is_shipped(self):   # other widths: every layer its own autograd function (generic.py)
+            if not inp_feat.is_cuda or inp_feat.dtype != torch.float32 or inp_feat.dim() != 2:
+                raise RuntimeError("inp_feat must be a CUDA float32 [n, %d]" % self.inp_dim)
+            from . import generic
+            return generic.decoder_forward_train(self, inp_feat)
         if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != self.inp_dim:
             raise RuntimeError("inp_feat must be float32 [n, %d]" % self.inp_dim)
         return _DecoderTrainFn.apply(self, inp_feat, *[_get(self, k) for k in _PARAM_ORDER if _has(self, k)])

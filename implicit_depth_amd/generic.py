@@ -8,8 +8,10 @@ ROI feature's channels and bins); those run here layer by layer: every nn.Linear
 lidf_linear_f32 launch (the same f32 matrix-instruction kernel, 256 output columns per launch,
 fused bias / activation / gathered term / scatter-max), the ROI pooling is lidf_roi_align_f32.
 Same results as the reference's modules to the tolerance of the fast path (the summation order
-inside a dot product differs from cuBLAS as it does there); inference only — the training
-entries are built for the shipped widths.
+inside a dot product differs from cuBLAS as it does there). The decoders also train at other
+widths: every layer is an autograd function whose backward runs lidf_linear_f32 (input gradient)
+and lidf_wgrad_f32 (weight and bias gradients); the PointNet and the fused query / stage-2 calls
+train at the shipped widths only.
 
 Nothing here is used when the widths are the shipped ones.
 """
@@ -26,7 +28,7 @@ def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
         raise RuntimeError("linear_hip: x must be a CUDA float32 matrix (no CPU path)")
     w = weight.detach()
-    if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+    if w.dtype != torch.float32 or w.dim() != 2 or (w.shape[1] > 1 and w.stride(1) != 1):
         raise RuntimeError("linear_hip: weight must be float32 [nout, k] with unit column stride")
     n = x.shape[0]
     k = int(k if k is not None else w.shape[1] - w_col0)
@@ -44,7 +46,8 @@ def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None
         return out
     with torch.cuda.device(x.device):
         _lib.check(L.lidf_linear_f32(
-            _lib.ptr(x), ldx, n, k, w.data_ptr() + 4 * w_col0, w.stride(0), _lib.ptr(b), nout, act, float(slope),
+            _lib.ptr(x), ldx, n, k, w.data_ptr() + 4 * w_col0, max(w.stride(0), w.shape[1]) if nout > 1 else w.shape[1],
+            _lib.ptr(b), nout, act, float(slope),
             _lib.ptr(addrows), _lib.ptr(addidx), addrows.stride(0) if addrows is not None else 0,
             _lib.ptr(out), out.stride(0) if out is not None else 0,
             _lib.ptr(pool), _lib.ptr(poolidx), pool.stride(0) if pool is not None else 0,
@@ -217,3 +220,68 @@ def refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox,
         off = offset_dec(rows)
         cur = (cur + (off * (offset_range[1] - offset_range[0]) + offset_range[0]) * ray_dir).contiguous()
     return cur, end_voxel
+
+
+class _LinearFn(torch.autograd.Function):
+    """act(x W^T + b) through lidf_linear_f32 with a backward through the library: d x = (g * act') W
+    (lidf_linear_f32 on W^T), d W = (g * act')^T x and d b = its column sums (lidf_wgrad_f32, fixed
+    summation order). act' is read off the output (leaky ReLU keeps the sign)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        out = linear_hip(x.detach(), weight, bias, act=act, slope=slope)
+        ctx.cfg = (act, slope, bias is not None)
+        ctx.save_for_backward(x, weight, out if act else None)   # (version counters catch in-place updates)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        x, w = x.detach(), w.detach()
+        act, slope, has_bias = ctx.cfg
+        g = g.detach().contiguous().float()
+        if act:
+            g = g * torch.where(out > 0, torch.ones((), device=g.device), torch.full((), slope, device=g.device))
+        n, nout, k = x.shape[0], w.shape[0], w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_hip(g, w.t().contiguous())
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            L = _lib.lib()
+            dw = torch.zeros((nout, k), dtype=torch.float32, device=g.device)
+            db = torch.zeros((nout,), dtype=torch.float32, device=g.device) if has_bias else None
+            xc = x if x.stride(1) == 1 else x.contiguous()
+            wsb = L.lidf_wgrad_workspace_bytes()
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device)
+            if n:
+                with torch.cuda.device(g.device):
+                    _lib.check(L.lidf_wgrad_f32(_lib.ptr(g), g.stride(0), nout, _lib.ptr(xc), xc.stride(0) if n > 1 else k,
+                                                k, n, _lib.ptr(dw), k, _lib.ptr(db), _lib.ptr(ws), wsb,
+                                                _lib.current_stream(g.device)))
+        return dx, dw, db if has_bias else None, None, None
+
+
+def _lin(x, layer, act=0, slope=0.0):
+    return _LinearFn.apply(x, layer.weight, layer.bias, act, slope)
+
+
+def decoder_forward_train(mod, x):
+    """IMNet / IEF forward under autograd at any gf_dim / out_dim: the reference's own sequence of
+    operations (implicit_net.py:81-98 / :131-152) with every nn.Linear as a _LinearFn; the concat, the
+    running offset and the output activation are torch ops that autograd differentiates itself."""
+    from .decoders import IEF, _init_offset_value
+    if x.shape[1] != mod.inp_dim:
+        raise RuntimeError("decoder inp_dim %d != input width %d" % (mod.inp_dim, x.shape[1]))
+
+    def trunk(h):
+        for layer in (mod.linear_1, mod.linear_2, mod.linear_3):
+            h = _lin(h, layer, 1, 0.02)
+        return _lin(h, mod.linear_4)
+    if not isinstance(mod, IEF):
+        return _out_act(mod, trunk(x))
+    if mod.linear_4.out_features != 1:
+        raise RuntimeError("IEF feeds its output back through offset_enc = Linear(1, 16): out_dim must be 1")
+    off = torch.full((x.shape[0], 1), _init_offset_value(mod), dtype=torch.float32, device=x.device)
+    for _ in range(int(mod.n_iter)):
+        off = off + trunk(torch.cat((x, _lin(off, mod.offset_enc)), 1))
+    return _out_act(mod, off)

@@ -538,6 +538,16 @@ int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const flo
                     const int32_t* poolidx, int64_t ld_pool, void* workspace, size_t workspace_bytes,
                     lidf_stream_t stream);
 
+/* Weight gradient of such a layer: c[i, j] += sum_r a[r, i] * b[r, j] (a = dL/d(pre-activation) [n, m],
+ * b = the layer's input rows [n, n_cols]: c is dL/dW in nn.Linear's [out, in] layout), db[i] += sum_r a[r, i]
+ * (optional). c / db are accumulated into: zero them for a fresh gradient. With workspace
+ * (lidf_wgrad_workspace_bytes() bytes) the partial sums of the row slices are reduced in a fixed order
+ * (run-to-run identical); workspace NULL: float atomics.                                               */
+size_t lidf_wgrad_workspace_bytes(void);
+int lidf_wgrad_f32(const float* a, int64_t lda, int32_t m, const float* b, int64_t ldb, int32_t n_cols,
+                   int64_t n, float* c, int64_t ldc, float* db, void* workspace, size_t workspace_bytes,
+                   lidf_stream_t stream);
+
 /* RoIAlign of the per-ray boxes at any channel count and output size (models/pipeline.py:374-391:
  * box = pixel +- roi_inp_bbox / 2, corners clamped to the image, torchvision.ops.roi_align with
  * output_size = roi_out_bbox, spatial_scale 1, sampling_ratio -1, aligned = True). out[r, (c*S + ph)*S + pw]

@@ -74,10 +74,23 @@ def test_decoders_at_other_widths(cuda, kind, inp, out_dim, gf, n_iter, sig):
         got = mod(x.to(cuda))
     assert got.shape == (1500, out_dim)
     assert float((got.double().cpu() - ref).abs().max()) <= 1e-5
-    # the training entries are built for the shipped widths: a clear error, not a detached result
-    if gf != 64 or out_dim != 1:
-        with pytest.raises(RuntimeError, match="shipped"):
-            mod(x.to(cuda).requires_grad_(True))
+    # under autograd: every layer its own autograd function (lidf_linear_f32 / lidf_wgrad_f32 backward),
+    # gradients against torch autograd through the float64 definition
+    xr = x.double().requires_grad_(True)
+    for p in ref_mod.parameters():
+        p.requires_grad_(True)
+    wgt = torch.randn(1500, out_dim, generator=torch.Generator().manual_seed(1)).double()
+    (ref_mod.forward_composite(xr) * wgt).sum().backward()
+    xg = x.to(cuda).requires_grad_(True)
+    mod.train()
+    out = mod(xg)
+    assert out.requires_grad and float((out.detach().double().cpu() - ref).abs().max()) <= 1e-5
+    (out * wgt.float().to(cuda)).sum().backward()
+    gmax = float(xr.grad.abs().max())
+    assert float((xg.grad.double().cpu() - xr.grad).abs().max()) <= 5e-5 * max(gmax, 1.0)
+    for (name, p), q in zip(mod.named_parameters(), ref_mod.parameters()):
+        assert p.grad is not None, name
+        assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 2e-5 * max(float(q.grad.abs().max()), 1.0), name
 
 
 @pytest.mark.parametrize("cin,outc,gf,n,V", [(9, 192, 48, 5000, 40), (6, 64, 16, 700, 3), (6, 128, 64, 2000, 300)])
