@@ -10,8 +10,9 @@ fused bias / activation / gathered term / scatter-max), the ROI pooling is lidf_
 Same results as the reference's modules to the tolerance of the fast path (the summation order
 inside a dot product differs from cuBLAS as it does there). The decoders also train at other
 widths: every layer is an autograd function whose backward runs lidf_linear_f32 (input gradient)
-and lidf_wgrad_f32 (weight and bias gradients); the PointNet and the fused query / stage-2 calls
-train at the shipped widths only.
+and lidf_wgrad_f32 (weight and bias gradients), the PointNet's two poolings and its gather are
+torch indexing that autograd differentiates itself; the fused query / stage-2 calls train at the
+shipped widths only.
 
 Nothing here is used when the widths are the shipped ones.
 """
@@ -285,3 +286,16 @@ def decoder_forward_train(mod, x):
     for _ in range(int(mod.n_iter)):
         off = off + trunk(torch.cat((x, _lin(off, mod.offset_enc)), 1))
     return _out_act(mod, off)
+
+
+def pointnet_forward_train(mod, inp_feat, vox2point_idx, n_vox):
+    """PointNet2Stage.forward under autograd at any width: the reference's sequence (models/pointnet.py:
+    22-38) with every nn.Linear as a _LinearFn. The scatter-max and the gather are device-side torch
+    indexing (scatter_reduce 'amax' / index): their backward routes a voxel's gradient to its maximal
+    point as torch_scatter does (exactly equal positive maxima — ties — share it instead)."""
+    from .pointnet import _segment_max
+    idx = vox2point_idx.long()
+    f2 = _lin(_lin(inp_feat, mod.point_lin1, 1), mod.point_lin2, 1)
+    g1 = _lin(_segment_max(f2, idx, n_vox), mod.vox_lin1, 1)
+    f5 = _lin(_lin(torch.cat((g1[idx], f2), -1), mod.point_lin3, 1), mod.point_lin4, 1)
+    return _lin(_segment_max(f5, idx, n_vox), mod.vox_lin2, 1)

@@ -166,9 +166,9 @@ class PointNet2Stage(nn.Module):
         if tuple(vox2point_idx.shape) != (inp_feat.shape[0],) or vox2point_idx.device != inp_feat.device:
             raise RuntimeError("vox2point_idx must be [N] on the device of inp_feat")
         if not is_shipped(self):   # other widths: layer by layer (generic.py), inference only
-            if needs_grad:
-                check_pointnet(self, "the training path (forward under autograd)")
             from . import generic
+            if needs_grad:   # every layer its own autograd function
+                return generic.pointnet_forward_train(self, inp_feat, vox2point_idx, int(n_vox))
             return generic.pointnet_forward(self, inp_feat, vox2point_idx, int(n_vox))
         if needs_grad:   # the library's training path: forward that keeps activations + backward
             params = [t for name in _PN_ORDER for t in (getattr(self, name).weight, getattr(self, name).bias)]

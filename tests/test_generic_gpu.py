@@ -108,6 +108,18 @@ def test_pointnet_at_other_widths(cuda, cin, outc, gf, n, V):
     with torch.no_grad():
         got = mod(x.to(cuda), idx.to(cuda), n_vox=V)
     assert got.shape == (V, outc) and _rel(got, ref) <= 5e-6
+    # under autograd (per-layer autograd functions + torch indexing for the poolings): against torch
+    # autograd through the float64 definition
+    xr = x.double().requires_grad_(True)
+    wgt = torch.randn(V, outc, generator=torch.Generator().manual_seed(2)).double()
+    (ref_mod.forward_composite(xr, idx, V) * wgt).sum().backward()
+    xg = x.to(cuda).requires_grad_(True)
+    out = mod(xg, idx.to(cuda), n_vox=V)
+    assert out.requires_grad and _rel(out.detach(), ref) <= 5e-6
+    (out * wgt.float().to(cuda)).sum().backward()
+    assert float((xg.grad.double().cpu() - xr.grad).abs().max()) <= 2e-5 * max(float(xr.grad.abs().max()), 1.0)
+    for (name, p), q in zip(mod.named_parameters(), ref_mod.parameters()):
+        assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 2e-5 * max(float(q.grad.abs().max()), 1.0), name
 
 
 @pytest.mark.parametrize("Cr,roi_out,Co,gf,off_kind,Lm,Lv,pos_rel", [(16, 3, 64, 32, "IEF", 8, 4, False),
