@@ -224,3 +224,23 @@ def test_eval_chain_at_other_widths(cuda):
     # the frame call is built for the shipped widths: a clear error
     with pytest.raises(RuntimeError, match="FrameRunner"):
         pl.FrameRunner(B, h, w, cuda, pnet, prob, off, opt)
+
+
+def test_query_at_other_widths_without_pairs(cuda):
+    """No ray / voxel pair at all (the reference's 'no intersecting pair' frame): empty per-pair outputs,
+    every ray takes the dummy row (max_pair_id = P = 0, pred_pos = 0) — as on the fused path."""
+    from implicit_depth_amd import IEF, IMNet
+    from implicit_depth_amd.query import lidf_query
+    from util import orc, to_dev
+    scene = orc.synthetic_scene(1, 6, 8, 4, seed=3)
+    R, Cr, Co, gf = scene["R"], 8, 32, 16
+    D = Co + Cr * 4 + 2 * 51 + 27
+    s = to_dev(scene, cuda)
+    prob, off = IMNet(D, 1, gf).to(cuda).eval(), IEF(cuda, D, 1, gf, n_iter=2).to(cuda).eval()
+    empty_i = torch.zeros((0,), dtype=torch.int32, device=cuda)
+    with torch.no_grad():
+        out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], torch.zeros((R + 1,), dtype=torch.int32, device=cuda),
+                         empty_i, empty_i, torch.zeros((0, 2), device=cuda), torch.randn(1, Cr, 6, 8, device=cuda),
+                         torch.randn(5, Co, device=cuda), prob, off)
+    assert out["pred_offset"].shape == (0, 1) and out["pair_pred_pos"].shape == (0, 3)
+    assert (out["max_pair_id"] == 0).all() and float(out["pred_pos"].abs().max()) == 0.0
