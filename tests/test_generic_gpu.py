@@ -244,3 +244,41 @@ def test_query_at_other_widths_without_pairs(cuda):
                          torch.randn(5, Co, device=cuda), prob, off)
     assert out["pred_offset"].shape == (0, 1) and out["pair_pred_pos"].shape == (0, 3)
     assert (out["max_pair_id"] == 0).all() and float(out["pred_pos"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_linear_fuzz(cuda, seed):
+    """Random shapes and option sets of lidf_linear_f32 / lidf_wgrad_f32 against float64."""
+    import random
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.generic import linear_hip
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    n = rnd.choice([1, 31, 128, 129, 2047, 5000])
+    k = rnd.choice([1, 3, 8, 9, 64, 155, 385, 600])
+    nout = rnd.choice([1, 5, 32, 33, 96, 256, 257, 700])
+    act, slope = rnd.choice([(0, 0.0), (1, 0.0), (1, 0.02)])
+    use_bias, use_add = rnd.random() < 0.7, rnd.random() < 0.5
+    x, w = torch.randn(n, k, generator=g), torch.randn(nout, k, generator=g) / max(k, 1) ** 0.5
+    b = torch.randn(nout, generator=g) if use_bias else None
+    V = rnd.choice([1, 7, 300])
+    add = torch.randn(V, nout, generator=g) if use_add else None
+    idx = torch.randint(0, V, (n,), generator=g).int()
+    got = linear_hip(x.to(cuda), w.to(cuda), b.to(cuda) if use_bias else None, act=act, slope=slope,
+                     addrows=add.to(cuda) if use_add else None, addidx=idx.to(cuda) if use_add else None)
+    ref = F.linear(x.double(), w.double(), b.double() if use_bias else None)
+    if use_add:
+        ref = ref + add[idx.long()].double()
+    if act:
+        ref = torch.max(ref, ref * slope)
+    assert _rel(got, ref) <= 3e-6, (n, k, nout, act, use_bias, use_add)
+    # C += A^T B, db += column sums of A
+    L = _lib.lib()
+    a = torch.randn(n, nout, generator=g)
+    c, db = torch.ones(nout, k, device=cuda), torch.ones(nout, device=cuda)
+    ws = torch.empty((L.lidf_wgrad_workspace_bytes(),), dtype=torch.uint8, device=cuda)
+    ad, xd = a.to(cuda), x.to(cuda)
+    _lib.check(L.lidf_wgrad_f32(_lib.ptr(ad), nout, nout, _lib.ptr(xd), k, k, n, _lib.ptr(c), k, _lib.ptr(db),
+                                _lib.ptr(ws), ws.numel(), _lib.current_stream(cuda)))
+    rc, rb = 1.0 + a.double().t() @ x.double(), 1.0 + a.double().sum(0)
+    assert _rel(c, rc) <= 5e-6 and _rel(db, rb) <= 5e-6, (n, k, nout)
