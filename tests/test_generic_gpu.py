@@ -246,7 +246,7 @@ def test_query_at_other_widths_without_pairs(cuda):
     assert (out["max_pair_id"] == 0).all() and float(out["pred_pos"].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(32))
 def test_linear_fuzz(cuda, seed):
     """Random shapes and option sets of lidf_linear_f32 / lidf_wgrad_f32 against float64."""
     import random
