@@ -11,6 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LIDF_HIP_LIB") or os.path.join(_HERE, "csrc", "liblidf_hip.so")
 
 LIDF_OK = 0
+# The ABI this binding is written against: LIDF_ABI_VERSION of include/lidf_hip.h (the struct mirrors
+# below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
+# lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
+# outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
+ABI = 7
 
 
 class LidfDecoder(C.Structure):
@@ -303,6 +308,16 @@ def lib():
                 "liblidf_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (there is no CPU fallback)" % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
+        try:
+            handle.lidf_version.restype, handle.lidf_version.argtypes = C.c_int, []
+            have = handle.lidf_version()
+        except AttributeError:
+            have = None
+        if have != ABI:
+            raise RuntimeError(
+                "%s was built for ABI %s, this binding (implicit_depth_amd/_lib.py) is written against ABI %d "
+                "of include/lidf_hip.h — rebuild it: `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or implicit_depth_amd/csrc/build.py --force)" % (LIB_PATH, have, ABI))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

@@ -156,7 +156,6 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
                                      long long, float*, hipStream_t);
 }
 
-#define LIDF_ABI_VERSION 6
 #define LIDF_API extern "C" __attribute__((visibility("default")))
 #define CHECK_HIP(x)                       \
     do {                                   \

@@ -272,6 +272,10 @@ std::vector<Tensor> forward_query(Tensor ray_dir, Tensor ray_pix, Tensor ray_bid
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "liblidf_hip torch-extension shim (C ABI: include/lidf_hip.h)";
+    // the shim was compiled against LIDF_ABI_VERSION of the header; a liblidf_hip.so of another
+    // version beside it (stale build: both are git-ignored artefacts) must not be driven
+    TORCH_CHECK(lidf_version() == LIDF_ABI_VERSION, "liblidf_hip.so answers ABI ", lidf_version(),
+                ", lidf_torch_ext was compiled against ABI ", LIDF_ABI_VERSION, " — rebuild both");
     m.def("abi_version", []() { return lidf_version(); });
     m.def("ray_aabb", &ray_aabb, "dense ray/voxel slab test: [mask, dist] (extensions/ray_aabb forward)");
     m.def("pcl_aabb", &pcl_aabb, "dense point/voxel inside test: mask (extensions/pcl_aabb forward)");

@@ -33,7 +33,10 @@ enum lidf_status {
     LIDF_ERR_HIP = -4           /* a HIP runtime call failed (launch, attribute query)     */
 };
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any signature or struct-layout change. lidf_version() returns the value the
+ * library was BUILT with; a binding compiled / written against this header must refuse a library that
+ * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
+#define LIDF_ABI_VERSION 7
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);

@@ -18,6 +18,36 @@ def header_functions():
     return sorted(set(re.findall(r"\b(lidf_[a-z0-9_]+)\s*\(", src)))
 
 
+def header_abi_version():
+    src = open(os.path.join(ROOT, "include", "lidf_hip.h")).read()
+    return int(re.search(r"#define\s+LIDF_ABI_VERSION\s+(\d+)", src).group(1))
+
+
+def test_stale_library_is_refused_at_load(tmp_path):
+    """SURVEY 8b error convention: a liblidf_hip.so built for another ABI (the .so is a git-ignored
+    artefact that travels outside history) must raise at load, before any struct is marshalled."""
+    import subprocess
+    import sys
+    src = tmp_path / "stub.c"
+    src.write_text("int lidf_version(void) { return 5; }\n")
+    so = tmp_path / "libstub.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from implicit_depth_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept RuntimeError as e:\n"
+            "    assert 'ABI 5' in str(e) and 'ABI %%d' %% _lib.ABI in str(e), e; print('refused')\n"
+            "else:\n    raise SystemExit('a stale library was accepted')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LIDF_HIP_LIB=str(so)),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stdout + r.stderr
+    # a library without the symbol at all (not ours) is refused the same way
+    src.write_text("int other(void) { return 0; }\n")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    r = subprocess.run([sys.executable, "-c", code.replace("'ABI 5'", "'ABI None'")],
+                       env=dict(os.environ, LIDF_HIP_LIB=str(so)), capture_output=True, text=True)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stdout + r.stderr
+
+
 def test_library_exports_every_declared_symbol():
     from implicit_depth_amd import _lib
     names = header_functions()
@@ -27,7 +57,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
         assert n in _lib.SIGNATURES, "ctypes signature missing for " + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert L.lidf_version() == 6
+    assert L.lidf_version() == _lib.ABI == header_abi_version()
     assert b"workspace" in L.lidf_strerror(-3)
     assert L.lidf_query_workspace_bytes(76800, 729, 0) > 76800 * 512 * 4
     assert (L.lidf_query_workspace_bytes(76800, 729, 32 * 240 * 320)
@@ -68,7 +98,8 @@ def test_torch_extension_shim_loads():
     """The pybind11 shim over the C ABI is built in-tree and imports without a GPU."""
     from implicit_depth_amd import torch_ext
     m = torch_ext.ext()
-    assert m.abi_version() == 6
+    from implicit_depth_amd import _lib
+    assert m.abi_version() == _lib.ABI
     for fn in ("ray_aabb", "pcl_aabb", "compute_ray_aabb", "forward_decoders", "forward_query"):
         assert callable(getattr(m, fn))
     with pytest.raises(RuntimeError, match="CUDA"):   # CHECK_INPUT of the reference bindings: CUDA tensors only
