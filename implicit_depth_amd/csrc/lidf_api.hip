@@ -9,7 +9,8 @@ extern "C" {
 hipError_t lidf_launch_pack(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                             float*, hipStream_t);
 hipError_t lidf_launch_points(int mode, const PointsArgs&, int grid, hipStream_t);
-hipError_t lidf_launch_l1only_pair(const PointsArgs&, const PointsArgs&, int cus, hipStream_t);
+hipError_t lidf_launch_l1only_pair(const PointsArgs&, const PointsArgs&, const PointsArgs*, int cus, hipStream_t);
+hipError_t lidf_launch_refine_step(const RefineStepArgs&, long long, hipStream_t);
 hipError_t lidf_launch_pack_h(const StreamLayout&, const NetW&, const NetW&, const L1Map&, float*,
                               float*, hipStream_t);
 hipError_t lidf_launch_points_h(const PointsArgs&, int cus, hipStream_t);
@@ -58,8 +59,9 @@ hipError_t lidf_launch_ray_aabb_compact_dev(bool, const float*, const float*, co
                                             long long, long long, const int*, const int*, int*,
                                             const int*, int*, int*, float*, long long, hipStream_t);
 hipError_t lidf_launch_pointnet_chain_dev(int, const float*, const float*, const int*, const float*,
-                                          float*, float*, long long, int, long long, const int*,
+                                          float*, long long, int, long long, const int*,
                                           const int*, const int*, const int*, int, hipStream_t);
+hipError_t lidf_launch_vox2(const Vox2Args&, hipStream_t);
 int lidf_pointnet_lds_max_voxels(void);
 size_t lidf_pointnet_sort_bytes(long long, long long);
 hipError_t lidf_launch_sort_idx(const int*, long long, const int*, long long, void*, const int**,
@@ -67,7 +69,6 @@ hipError_t lidf_launch_sort_idx(const int*, long long, const int*, long long, vo
 hipError_t lidf_launch_pointnet_chain_sorted(int, const float*, const float*, const int*, const float*,
                                              float*, long long, long long, const int*, const int*, int,
                                              hipStream_t);
-size_t lidf_pointnet_pool_scratch_bytes_dev(long long);
 hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int*, long long, const float*,
                                        const int*, long long, const int*, const int*, const float*,
                                        long long, int, long long, float*, int*, int*,
@@ -78,16 +79,21 @@ hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float
                                          const int*, float*, const int*, const int*, long long, float*,
                                          hipStream_t);
 hipError_t lidf_launch_frame_head(const float*, const float*, const float*, const float*, const float*, int,
-                                  int, int, int, const GridSpec&, int*, int*, int*, int*, int*, float*,
+                                  int, int, int, const GridSpec&, void*, int*, int*, int*, float*,
                                   float*, int*, int*, int*, int*, int*, int*, float*, float*, float*,
                                   const int*, const int*, long long, hipStream_t);
 size_t lidf_frame_head_blocks(long long);
+size_t lidf_frame_head_lb_bytes(long long);
+hipError_t lidf_launch_frame_cells(const int*, long long, const GridSpec&, int*, int*, float*, int*, int*,
+                                   hipStream_t);
+size_t lidf_ray_aabb_onepass_lb_bytes(long long);
+hipError_t lidf_launch_ray_aabb_onepass(const float*, const float*, const int*, const int*, long long, int*,
+                                        void*, int*, int*, int*, float*, long long, hipStream_t);
 hipError_t lidf_launch_roi_align(const float*, int, int, int, const int*, const int*, long long, int, int,
                                  float*, long long, hipStream_t);
 hipError_t lidf_launch_frame_points(const float*, const float*, const int*, const int*, const int*,
                                     const GridSpec&, long long, const int*, int*, int*, float*, float*,
                                     float*, hipStream_t);
-hipError_t lidf_launch_frame_pairs(int*, int*, long long, long long, hipStream_t);
 hipError_t lidf_launch_vox_cells_bid(const int*, const int*, long long, const GridSpec&, int*, float*, int*,
                                      hipStream_t);
 hipError_t lidf_launch_frame_select(const float*, const int*, const int*, long long, long long, const int*,
@@ -163,6 +169,7 @@ hipError_t lidf_launch_refine_finish(const float*, const float*, const float*, f
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static size_t linex_stream_bytes(int k);
 
 extern "C" hipError_t lidf_launch_zero_segments(float* const* ptrs, const long long* counts, int n,
                                                 hipStream_t st);
@@ -583,8 +590,10 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
 // dims (optional): device int32 {R, P, V} — the sync-free frame path. n_rays / n_pairs / n_vox of `q`
 // are then the capacities the launches (and the workspace) are sized for, and every kernel reads its
 // count on the device.
+// extra_l1 (optional, f32): a third layer-1 table over the same rayfeat rows, formed in the launch of
+// voxpart / raypart (the frame path: the per-ray part of the stage-2 decoder's layer 1; X is set here).
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
-                      lidf_stream_t stream, const int* dims = nullptr) {
+                      lidf_stream_t stream, const int* dims = nullptr, PointsArgs* extra_l1 = nullptr) {
     if (!q) return LIDF_ERR_BAD_ARG;
     if (dims && !q->packed) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
@@ -664,6 +673,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0;
             a.out_base = raypart;
             long long nt = (R + 127) / 128;
+            if (extra_l1) { extra_l1->X = rayfeat; extra_l1->ldx = 128 + Ed; }
             if (split) {
                 CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, av, (int)(ntv < 2 * cus ? ntv : 2 * cus), st));
                 // the per-ray partial products with the split-f16 rows kernel (layer 1 only)
@@ -673,7 +683,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
                 CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
             } else {
                 // one launch over the (tile, net, half) items of both tables
-                CHECK_HIP(lidf_launch_l1only_pair(a, av, cus, st));
+                CHECK_HIP(lidf_launch_l1only_pair(a, av, extra_l1, cus, st));
             }
         }
         // 4. per-point kernel
@@ -1002,6 +1012,21 @@ static int run_linear(const LinSpec& L, const float* X, long long ldx, long long
     return LIDF_OK;
 }
 
+
+// The per-voxel layers of PointNet2Stage in pairs (lidf_vox2_kernel): layer 1 on X [n, k1] through the
+// rows-mode stream s1 (nt1 tiles), optionally layer 2 on its activated output through s2. Streams as
+// run_linear / run_linex pack them (kq = k-quads per tile).
+static int run_vox2(const float* X, int k1, int64_t n, const int* n_dev, const float* s1, int nt1, int relu1,
+                    float* out1, const float* s2, int kq2, int nt2, int relu2, float* out2, hipStream_t st) {
+    Vox2Args a = {};
+    a.X = X; a.ldx = k1; a.n = n; a.n_dev = n_dev;
+    a.s1 = s1; a.kq1 = (k1 + 1 + 7) / 8; a.nt1 = nt1; a.D1 = k1; a.bias1 = 1; a.relu1 = relu1;
+    a.out1 = out1; a.ld1 = 32 * nt1;
+    a.s2 = s2; a.kq2 = kq2; a.nt2 = nt2; a.bias2 = 1; a.relu2 = relu2; a.out2 = out2; a.ld2 = 32 * nt2;
+    CHECK_HIP(lidf_launch_vox2(a, st));
+    return LIDF_OK;
+}
+
 struct PnetWs {
     size_t s[7], chain, f1, f2, pool1, g1, gpart, f4, pool2, part, part_bytes, sort, total;
 };
@@ -1052,9 +1077,17 @@ struct PnetBufs {
 
 // mode 0: pack the weight streams and run; 1: pack only (lidf_pointnet_pack_f32); 2: run on
 // streams packed earlier
+// tail (inference, optional): one more per-voxel layer on the PointNet's output in the launch of
+// vox_lin2 — the voxel columns of the stage-2 decoder's layer 1 (a rows-mode stream of nt tiles, kq
+// k-quads per tile, bias column at 128; out [n_vox, 32 nt])
+struct VoxTail {
+    const float* stream;
+    int kq, nt;
+    float* out;
+};
 static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n,
                          int64_t n_vox, float* out, const PnetBufs& b, int cus, hipStream_t st,
-                         int mode = 0) {
+                         int mode = 0, const VoxTail* tail = nullptr) {
     int rc;
     const bool po = mode == 1, pp = mode == 2;
     if (!po) {
@@ -1078,20 +1111,30 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
         } else if (!po) {
             CHECK_HIP(lidf_launch_pointnet_chain(1, b.chain, inp, vox, nullptr, b.pool1, b.part, n_vox, n, cus, st));
         }
-        if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, b.pool1, 64, n_vox, nullptr, nullptr, 1,
-                             b.g1, 64, nullptr, nullptr, b.streams[2], cus, st, po, pp)))
+        // the weight streams of the per-voxel layers (pack_only / prepacked as before)
+        if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, nullptr, 64, 0, nullptr, nullptr, 1,
+                             nullptr, 64, nullptr, nullptr, b.streams[2], cus, st, true, pp)))
             return rc;
-        // gpart[v] = W3[:, :64] g1[v] + b3: what the layer-3 accumulators of a point start from
-        if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, b.g1, 64, n_vox, nullptr, nullptr, 0,
-                             b.gpart, 128, nullptr, nullptr, b.streams[3], cus, st, po, pp)))
+        if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, nullptr, 64, 0, nullptr, nullptr, 0,
+                             nullptr, 128, nullptr, nullptr, b.streams[3], cus, st, true, pp)))
+            return rc;
+        if ((rc = run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, nullptr, 128, 0, nullptr, nullptr, 1,
+                             nullptr, 128, nullptr, nullptr, b.streams[6], cus, st, true, pp)))
+            return rc;
+        if (po) return LIDF_OK;
+        // g1 = relu(vox_lin1(pool1)); gpart[v] = W3[:, :64] g1[v] + b3 (what the layer-3 accumulators of
+        // a point start from): one launch over the voxels
+        if ((rc = run_vox2(b.pool1, 64, n_vox, nullptr, b.streams[2], 2, 1, b.g1, b.streams[3], 9, 4, 0,
+                           b.gpart, st)))
             return rc;
         if (sorted)
             CHECK_HIP(lidf_launch_pointnet_chain_sorted(2, b.chain, inp, vox, b.gpart, b.pool2, n_vox, n, perm,
                                                         n_perm, cus, st));
-        else if (!po)
+        else
             CHECK_HIP(lidf_launch_pointnet_chain(2, b.chain, inp, vox, b.gpart, b.pool2, b.part, n_vox, n, cus, st));
-        return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, b.pool2, 128, n_vox, nullptr, nullptr, 1,
-                          out, 128, nullptr, nullptr, b.streams[6], cus, st, po, pp);
+        // out = relu(vox_lin2(pool2)) (+ the caller's per-voxel layer on it, same launch)
+        return run_vox2(b.pool2, 128, n_vox, nullptr, b.streams[6], 4, 1, out, tail ? tail->stream : nullptr,
+                        tail ? tail->kq : 0, tail ? tail->nt : 0, 0, tail ? tail->out : nullptr, st);
     }
     // with the rows kept (training forward): layer by layer
     // point_feat1 = relu(point_lin1(inp)); point_feat2 = relu(point_lin2(.)); pool per voxel
@@ -1194,7 +1237,8 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
                                  int pack_mode, const int* R_dev = nullptr, const int* V_dev = nullptr,
                                  void* const* ev_rows = nullptr, const float* rayfeat = nullptr, int Ed = 0,
-                                 float* raypart = nullptr, bool make_raypart = false);
+                                 float* raypart = nullptr, bool make_raypart = false,
+                                 bool voxpart_ready = false);
 static RefineWs refine_ws(int64_t R, int64_t Nv, int64_t V, int D) {
     RefineWs w;
     size_t o = 0;
@@ -1310,9 +1354,10 @@ LIDF_API int lidf_refine_profile_f32(const LidfRefineArgs* q, void* ev_pnet_begi
 // PointNet2Stage with device-side counts: pointnet_impl's inference branch, every launch sized for
 // the capacities (n_cap points, V_cap voxels) and reading *n_dev / *V_dev on the device.
 struct PnetFrameWs {
-    size_t pool1, g1, gpart, pool2, part, sort, total;
+    size_t pool1, g1, gpart, pool2, sort, total;
 };
 static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds, int64_t n_cap = 0) {
+    (void)v_lds;
     PnetFrameWs w;
     size_t o = 0;
     const size_t V = (size_t)(v_cap > 0 ? v_cap : 1);
@@ -1320,17 +1365,18 @@ static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds, int64_t n_cap = 0) {
     w.g1 = o;    o += align_up(V * 64 * 4, 256);
     w.gpart = o; o += align_up(V * 128 * 4, 256);
     w.pool2 = o; o += align_up(V * 128 * 4, 256);
-    w.part = o;  o += align_up(lidf_pointnet_pool_scratch_bytes_dev(v_lds), 256);
     w.sort = o;  o += n_cap > 0 ? align_up(lidf_pointnet_sort_bytes(n_cap, v_cap), 256) : 0;
     w.total = o;
     return w;
 }
-// (pool1 / pool2 of `ws` must be zero on entry: frame_zero_pools, merged with the caller's other scratch)
-// sort_cap > 0 (several frames per batch: the voxel table is expected to exceed the LDS pooling): the
-// global-atomic variant walks the points grouped by voxel (the counting sort runs unconditionally).
+// (pool1 / pool2 of `ws` must be zero on entry: merged with the caller's other zeroed scratch)
+// sort_cap > 0 (several frames per batch: the voxel table is expected to exceed the LDS pooling): beyond
+// v_lds voxels the chains walk the points grouped by voxel (the counting sort runs unconditionally).
+// Four launches: chain 1 -> [vox_lin1 | voxel half of point_lin3] -> chain 2 -> [vox_lin2 | tail].
 static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n_cap,
                           const int* n_dev, int64_t V_cap, int v_lds, const int* V_dev, float* out,
-                          char* ws, int cus, hipStream_t st, int64_t sort_cap = 0) {
+                          char* ws, int cus, hipStream_t st, int64_t sort_cap = 0,
+                          const VoxTail* tail = nullptr) {
     int rc;
     if ((rc = check_pointnet_w(w))) return rc;
     if (!w->packed) return LIDF_ERR_BAD_ARG;
@@ -1346,24 +1392,20 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
     float* g1 = (float*)(ws + f.g1);
     float* gpart = (float*)(ws + f.gpart);
     float* pool2 = (float*)(ws + f.pool2);
-    float* part = (float*)(ws + f.part);
-    CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, part, V_cap, v_lds, n_cap,
+    CHECK_HIP(lidf_launch_pointnet_chain_dev(1, chain, inp, vox, nullptr, pool1, V_cap, v_lds, n_cap,
                                              n_dev, V_dev, perm, n_perm, cus, st));
-    if ((rc = run_linear({w->w_v1, w->b_v1, 64, 64, 0, 64}, pool1, 64, V_cap, nullptr, nullptr, 1, g1, 64,
-                         nullptr, nullptr, streams[2], cus, st, false, true, V_dev)))
+    if ((rc = run_vox2(pool1, 64, V_cap, V_dev, streams[2], 2, 1, g1, streams[3], 9, 4, 0, gpart, st)))
         return rc;
-    if ((rc = run_linear({w->w_p3, w->b_p3, 128, 128, 0, 64}, g1, 64, V_cap, nullptr, nullptr, 0, gpart,
-                         128, nullptr, nullptr, streams[3], cus, st, false, true, V_dev)))
-        return rc;
-    CHECK_HIP(lidf_launch_pointnet_chain_dev(2, chain, inp, vox, gpart, pool2, part, V_cap, v_lds, n_cap,
+    CHECK_HIP(lidf_launch_pointnet_chain_dev(2, chain, inp, vox, gpart, pool2, V_cap, v_lds, n_cap,
                                              n_dev, V_dev, perm, n_perm, cus, st));
-    return run_linear({w->w_v2, w->b_v2, 128, 128, 0, 128}, pool2, 128, V_cap, nullptr, nullptr, 1, out,
-                      128, nullptr, nullptr, streams[6], cus, st, false, true, V_dev);
+    return run_vox2(pool2, 128, V_cap, V_dev, streams[6], 4, 1, out, tail ? tail->stream : nullptr,
+                    tail ? tail->kq : 0, tail ? tail->nt : 0, 0, tail ? tail->out : nullptr, st);
 }
 
 struct FrameWs {
-    size_t blk_valid, blk_miss, cell_flag, cell_rank, vox_bid, pt_key, pt_valid, pt_rank, ray_count, scan, pnet,
+    size_t lb_head, lb_pairs, cell_flag, cell_rank, vox_bid, pt_key, pt_rank, pnet,
         query, inp_embed, off, vox_feat_r, voxpart_r, raypart_r, pos_a, pos_b, pnet_abs, sel, dec, total;
+    size_t lb_bytes;   // lb_head .. cell_flag: the look-back tickets / status words, zeroed with cell_flag
 };
 static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pairs, int v_lds,
                         int refine_times) {
@@ -1371,17 +1413,14 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     FrameWs f;
     size_t o = 0;
     const size_t N = (size_t)B * h * w, C = (size_t)B * res[0] * res[1] * res[2];
-    const size_t nb = lidf_frame_head_blocks((long long)N);
-    f.blk_valid = o; o += align_up((nb + 1) * 4, 256);
-    f.blk_miss = o;  o += align_up((nb + 1) * 4, 256);
+    f.lb_head = o;   o += align_up(lidf_frame_head_lb_bytes((long long)N), 256);
+    f.lb_pairs = o;  o += align_up(lidf_ray_aabb_onepass_lb_bytes((long long)N), 256);
+    f.lb_bytes = o;
     f.cell_flag = o; o += align_up(C * 4, 256);
     f.cell_rank = o; o += align_up((C + 1) * 4, 256);
     f.vox_bid = o;   o += align_up(C * 4, 256);
     f.pt_key = o;    o += align_up(N * 4, 256);
-    f.pt_valid = o;  o += align_up(N * 4, 256);
     f.pt_rank = o;   o += align_up((N + 1) * 4, 256);
-    f.ray_count = o; o += align_up(N * 4, 256);
-    f.scan = o;      o += align_up(lidf_exclusive_scan_workspace_bytes((int64_t)(N > C ? N : C)), 256);
     f.pnet = o;      o += align_up(pnet_frame_ws((int64_t)C, v_lds, B >= 2 ? (int64_t)(2 * N) : 0).total, 256);
     f.query = o;     o += align_up(lidf_query_workspace_bytes((int64_t)N, (int64_t)C, (int64_t)B * 32 * h * w), 256);
     const int Dmax = 256 + 2 * (3 + 6 * 16);
@@ -1451,18 +1490,16 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     int* cell_flag = (int*)(ws + f.cell_flag);
     int* cell_rank = (int*)(ws + f.cell_rank);
     int* pt_key = (int*)(ws + f.pt_key);
-    int* pt_valid = (int*)(ws + f.pt_valid);
     int* pt_rank = (int*)(ws + f.pt_rank);
-    int* ray_count = (int*)(ws + f.ray_count);
-    int* scan = (int*)(ws + f.scan);
     GridSpec g;
     for (int k = 0; k < 3; ++k) { g.xmin[k] = a->xmin[k]; g.r[k] = a->res[k]; }
     g.crop = a->part_size;
     g.B = B;
     const long long hw = (long long)h * w;
 
-    // 0. every zero-initialised scratch of stage 1 in ONE launch: voxel marks, the max-pool tables of the
-    //    PointNet, the clamped-box list length and the tile counter of the query
+    // 0. every zero-initialised scratch of stage 1 in ONE launch: the look-back tickets / status words
+    //    and the voxel marks (adjacent), the max-pool tables of the PointNet, the clamped-box list length
+    //    and the tile counter of the query
     const int64_t sort_cap = B >= 2 ? 2 * N : 0;   // several frames: the voxel table outgrows the LDS pooling
     const PnetFrameWs pf = pnet_frame_ws(C, v_lds, sort_cap);
     const int64_t grid_floats = (int64_t)B * 32 * h * w;
@@ -1470,40 +1507,32 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     float* pool1 = (float*)(ws + f.pnet + pf.pool1);
     float* pool2 = (float*)(ws + f.pnet + pf.pool2);
     {
-        float* zp[5] = {(float*)cell_flag, pool1, pool2, (float*)(ws + f.query + qw.counter),
+        float* zp[5] = {(float*)(ws + f.lb_head), pool1, pool2, (float*)(ws + f.query + qw.counter),
                         (float*)(ws + f.query + qw.box) + grid_floats};
-        const long long zc[5] = {(long long)C, (long long)C * 64, (long long)C * 128, 1, 1};
+        const long long zc[5] = {(long long)(f.lb_bytes / 4) + (long long)C, (long long)C * 64,
+                                 (long long)C * 128, 1, 1};
         CHECK_HIP(lidf_launch_zero_segments(zp, zc, 5, st));
     }
-    // 1. valid points, rays, depth map, voxel marks: three launches over the pixels
+    // 1. valid points (with their rows of the PointNet input), rays, depth map, voxel marks: ONE launch
+    //    over the pixels (look-back prefix over its workgroups)
     CHECK_HIP(lidf_launch_frame_head(a->valid_mask, a->miss_mask, a->xyz_corrupt, a->rgb, a->intr, B, h, w,
-                                     a->valid_stride, g, (int*)(ws + f.blk_valid), (int*)(ws + f.blk_miss),
-                                     counts, a->valid_bid, a->valid_flat, a->valid_xyz, a->valid_rgb,
-                                     cell_flag, pt_key, pt_valid, a->ray_bid, a->ray_flat, a->ray_pix,
-                                     a->ray_dir, a->pred_depth, rf ? a->pred_depth_refine : nullptr,
-                                     a->valid_idx_bid, a->valid_idx_flat, a->n_valid_idx > 0 ? a->n_valid_idx : 0,
-                                     st));
-    // 2. occupied voxels: cell scan (V), point scan (NV), cells -> voxels, points -> PointNet rows
-    CHECK_HIP(lidf_launch_scan_dev(cell_flag, C, nullptr, cell_rank, scan, counts + LIDF_FC_VOX, st));
-    CHECK_HIP(lidf_launch_scan_dev(pt_valid, N, counts + LIDF_FC_VALID_SEL, pt_rank, scan,
-                                   counts + LIDF_FC_VALID_IN, st));
+                                     a->valid_stride, g, ws + f.lb_head, counts, a->valid_bid, a->valid_flat,
+                                     a->valid_xyz, a->valid_rgb, cell_flag, pt_key, pt_rank, a->ray_bid,
+                                     a->ray_flat, a->ray_pix, a->ray_dir, a->pred_depth,
+                                     rf ? a->pred_depth_refine : nullptr, a->valid_idx_bid, a->valid_idx_flat,
+                                     a->n_valid_idx > 0 ? a->n_valid_idx : 0, st));
+    // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
-    CHECK_HIP(lidf_launch_vox_cells_bid(cell_flag, cell_rank, C, g, a->occ_bid_coord, a->voxel_bound, vox_bid,
-                                        st));
+    CHECK_HIP(lidf_launch_frame_cells(cell_flag, C, g, cell_rank, a->occ_bid_coord, a->voxel_bound, vox_bid,
+                                      counts, st));
     float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
     CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
                                        a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
                                        pnet_abs, st));
-    // 3. ray / voxel pairs: count -> scan -> (cut at max_pairs, P) -> fill
-    CHECK_HIP(lidf_launch_ray_aabb_compact_dev(false, a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, C,
-                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, ray_count,
-                                               nullptr, nullptr, nullptr, nullptr, 0, st));
-    CHECK_HIP(lidf_launch_scan_dev(ray_count, N, counts + LIDF_FC_RAYS, a->pair_off, scan, nullptr, st));
-    CHECK_HIP(lidf_launch_frame_pairs(a->pair_off, counts, N, a->max_pairs, st));
-    CHECK_HIP(lidf_launch_ray_aabb_compact_dev(true, a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, C,
-                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, ray_count,
-                                               a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
-                                               a->max_pairs, st));
+    // 3. ray / voxel pairs: count, offsets (cut at max_pairs, P) and fill in ONE launch
+    CHECK_HIP(lidf_launch_ray_aabb_onepass(a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, counts,
+                                           ws + f.lb_pairs, a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
+                                           a->max_pairs, st));
     // 4. voxel embedding: PointNet over the in-grid valid points
     if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
                              counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))
@@ -1531,7 +1560,20 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         q.rayfeat_out = a->rayfeat;
         q.precision = a->precision;
         q.packed = a->packed_query;
-        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts))) return rc;
+        // (f32 stage 2: the per-ray part of its decoder's layer 1, W1[:, ROI | dir] rayfeat[r] — constant
+        // over the refine iterations — is a third table of the query's layer-1 launch)
+        PointsArgs xr = {};
+        if (rf && !split) {
+            const int Edr = 3 + 6 * a->multires_views;
+            xr.stream = (const float*)((const char*)a->packed_refine + linex_stream_bytes(128));
+            xr.nets = 1;
+            xr.KQ1 = (128 + Edr + 2 + 7) / 8;
+            xr.l1_quads = xr.net_quads = xr.KQ1 * 8;
+            xr.n = N; xr.n_dev = counts;
+            xr.D = 128 + Edr; xr.has_bias = 0;
+            xr.out_base = (float*)(ws + f.raypart_r);
+        }
+        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr))) return rc;
     }
     if (!rf) return LIDF_OK;
 
@@ -1551,7 +1593,46 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
     // behind the NV valid rows of the same buffer (no copy of the valid rows)
     float* pn_inp = a->refine_pnet_pos_rel ? a->pnet_inp : pnet_abs;
     const float* cur = a->pred_pos;
-    for (int it = 0; it < a->refine_times; ++it) {
+    const float rr0 = a->refine_offset_range0, rrs = a->refine_offset_range1 - a->refine_offset_range0;
+    if (!split) {
+        // f32: per iteration ONE per-ray launch (the previous iteration's finish, end voxel through the
+        // cell table, PointNet rows, embed(pos) rows, the max-pool tables zeroed), the PointNet in four
+        // (its last per-voxel launch also forms the voxel columns of the decoder's layer 1), the decoder.
+        const VoxTail tail = {(const float*)a->packed_refine, (128 + 2 + 7) / 8, 8, voxpart_r};
+        for (int it = 0; it < a->refine_times; ++it) {
+            RefineStepArgs sa = {};
+            sa.prev_pos = cur;
+            sa.prev_off = it > 0 ? offv : nullptr;
+            sa.r0 = rr0; sa.rs = rrs;
+            sa.cur_pos = it > 0 ? (float*)(ws + ((it & 1) ? f.pos_b : f.pos_a)) : nullptr;
+            sa.ray_dir = a->ray_dir; sa.ray_bid = a->ray_bid; sa.ray_flat = a->ray_flat;
+            sa.max_pair_id = (const long long*)a->max_pair_id; sa.pair_vox = a->pair_vox;
+            sa.vbound = a->voxel_bound; sa.vox_bid = vox_bid;
+            sa.g = g; sa.cell_flag = cell_flag; sa.cell_rank = cell_rank;
+            sa.rgb = a->rgb; sa.hw = hw;
+            sa.pnet_rel = a->refine_pnet_pos_rel; sa.pos_rel = a->refine_pos_rel; sa.L = a->multires;
+            sa.pnet_inp = pn_inp; sa.pnet_vox = a->revidx; sa.sel = sel;
+            sa.end_voxel = a->end_voxel_id; sa.inp_embed = inp_embed; sa.ld_e = D;
+            sa.dims = counts; sa.row0_dev = counts + LIDF_FC_VALID_IN;
+            sa.zero0 = pool1; sa.nzero0 = (long long)C * 64;
+            sa.zero1 = pool2; sa.nzero1 = (long long)C * 128;
+            CHECK_HIP(lidf_launch_refine_step(sa, N, st));
+            if (it > 0) cur = sa.cur_pos;
+            if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
+                                     v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st, sort_cap,
+                                     &tail)))
+                return rc;
+            if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N,
+                                            offv, voxpart_r, (char*)a->packed_refine, st, 2,
+                                            counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, nullptr, a->rayfeat,
+                                            Ed, (float*)(ws + f.raypart_r), false, true)))
+                return rc;
+        }
+        CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, rr0, rrs, N, counts, a->pred_pos_refine,
+                                                a->ray_bid, a->ray_flat, hw, a->pred_depth_refine, st));
+        return LIDF_OK;
+    }
+    for (int it = 0; it < a->refine_times; ++it) {   // split-f16 products: whole decoder rows, layer by layer
         float* out = it == a->refine_times - 1 ? a->pred_pos_refine
                                                : (float*)(ws + ((it & 1) ? f.pos_b : f.pos_a));
         {   // this iteration's zero-initialised scratch in one launch: end voxels + the max-pool tables
@@ -1563,29 +1644,20 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
                                               a->voxel_bound, vox_bid, C, a->ray_bid, a->ray_flat, a->rgb, hw,
                                               a->refine_pnet_pos_rel, N, pn_inp, a->revidx, a->end_voxel_id,
                                               sel, counts, counts + LIDF_FC_VALID_IN, st));
-        // (only embed(pos) is a per-iteration operand row: the ROI / direction columns enter layer 1 as a
-        // per-ray product formed once, in the first iteration)
         CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
-                                              inp_embed, D, split ? 0 : 1, st));
+                                              inp_embed, D, 0, st));
         if ((rc = pointnet_frame(a->pnet_refine, pn_inp, a->revidx, 2 * N, counts + LIDF_FC_PNET_REFINE, C,
                                  v_lds, counts + LIDF_FC_VOX, vox_feat_r, ws + f.pnet, cus, st, sort_cap)))
             return rc;
-        if (split) {   // split-f16 products: whole decoder rows (voxel feature gathered), packed per call
-            CHECK_HIP(lidf_launch_refine_gather_dev(vox_feat_r, a->end_voxel_id, N, counts, inp_embed, D, st));
-            if ((rc = decoders_impl(inp_embed, N, D, D, nullptr, a->off_refine, nullptr, offv, ws + f.dec,
-                                    lidf_decoders_workspace_bytes(N, D), LIDF_PRECISION_F16X3, stream,
-                                    counts + LIDF_FC_RAYS)))
-                return rc;
-        } else if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N,
-                                               offv, voxpart_r, (char*)a->packed_refine, st, 2,
-                                               counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, nullptr, a->rayfeat,
-                                               Ed, (float*)(ws + f.raypart_r), it == 0))) {
+        // (the voxel feature gathered into the rows, the weights packed per call)
+        CHECK_HIP(lidf_launch_refine_gather_dev(vox_feat_r, a->end_voxel_id, N, counts, inp_embed, D, st));
+        if ((rc = decoders_impl(inp_embed, N, D, D, nullptr, a->off_refine, nullptr, offv, ws + f.dec,
+                                lidf_decoders_workspace_bytes(N, D), LIDF_PRECISION_F16X3, stream,
+                                counts + LIDF_FC_RAYS)))
             return rc;
-        }
         const bool last = it == a->refine_times - 1;
-        CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, a->refine_offset_range0,
-                                                a->refine_offset_range1 - a->refine_offset_range0, N, counts,
+        CHECK_HIP(lidf_launch_refine_finish_dev(cur, offv, a->ray_dir, rr0, rrs, N, counts,
                                                 out, a->ray_bid, a->ray_flat, hw,
                                                 last ? a->pred_depth_refine : nullptr, st));
         cur = out;
@@ -1859,7 +1931,8 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
                                  const float* inp_embed, const int32_t* end_voxel, int64_t R,
                                  float* out, float* voxpart, char* scratch, hipStream_t st,
                                  int pack_mode, const int* R_dev, const int* V_dev, void* const* ev_rows,
-                                 const float* rayfeat, int Ed, float* raypart, bool make_raypart) {
+                                 const float* rayfeat, int Ed, float* raypart, bool make_raypart,
+                                 bool voxpart_ready) {
     // Layer 1 of the stage-2 decoder on [vox feat 128 | ROI 128 | embed(pos) E | embed(dir) Ed] as three
     // partial products: per voxel (W1[:, 0:128] vox_feat[v] + b1 (+c), gathered by the end voxel), per
     // ray (W1[:, ROI | dir] rayfeat[r]: constant over the refine iterations — the frame path forms it
@@ -1877,7 +1950,9 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
     L.ief = off->is_ief ? off : nullptr;   // bias += c
     L.X = vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
     L.n_dev = V_dev;
-    if ((rc = run_linex(L, (float*)s_vox, cus, st, pack_mode))) return rc;
+    // (voxpart_ready: the frame path forms the per-voxel rows in the launch of the PointNet's last
+    // per-voxel layer — VoxTail, the same stream)
+    if (!(voxpart_ready && pack_mode == 2) && (rc = run_linex(L, (float*)s_vox, cus, st, pack_mode))) return rc;
     if (make_raypart || pack_mode == 1) {
         LinEx Lr = {};
         Lr.w = off->w1; Lr.b = nullptr; Lr.ldw = ld1; Lr.nout = LIDF_H1;
@@ -2270,7 +2345,7 @@ LIDF_API int lidf_query_forward_train_f32(const LidfQueryTrainArgs* q, const Lid
         a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
         a.n = R; a.X = q->rayfeat; a.ldx = 128 + Ed;
         a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0; a.out_base = raypart;
-        CHECK_HIP(lidf_launch_l1only_pair(a, av, cus, st));
+        CHECK_HIP(lidf_launch_l1only_pair(a, av, nullptr, cus, st));
     }
     PointsArgs a = {};
     a.stream = (const float*)(ws + w.stream_pts); a.aux = aux_pts;

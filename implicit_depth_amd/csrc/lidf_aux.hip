@@ -819,6 +819,123 @@ extern "C" hipError_t lidf_launch_ray_aabb_compact_dev(bool fill, const float* r
     return hipGetLastError();
 }
 
+// The compact list in ONE launch with device-side sizes (the sync-free frame path; rounds 2-3: count ->
+// three scan launches -> cut at the capacity -> fill): a workgroup of 256 rays counts its hits — keeping
+// the first AABB_HITS voxel indices of every ray in LDS —, obtains the number of pairs before it by a
+// decoupled look-back over the workgroups (lb_* in lidf_device.h), writes pair_off and fills its pairs
+// from the kept indices (a ray with more hits walks the voxels again). The list is cut at pair_cap
+// (pair_off clamped, counts[7] bit 0 set); the workgroup of the last ray leaves P and NV + R in `counts`.
+// Same slab_test on the same bounds in the same voxel order as the two-pass kernel: bit-identical lists.
+#define AABB_HITS 32
+__global__ void __launch_bounds__(256) lidf_ray_aabb_onepass_kernel(
+    const float* __restrict__ ray_dir, const float* __restrict__ vbound, const int* __restrict__ ray_bid,
+    const int* __restrict__ vox_bid, int* __restrict__ counts, int* __restrict__ ticket,
+    unsigned long long* __restrict__ status, int* __restrict__ pair_off, int* __restrict__ pair_ray,
+    int* __restrict__ pair_vox, float* __restrict__ pair_t, long long pair_cap) {
+    __shared__ float s_vb[256 * 6];
+    __shared__ int s_vbid[256];
+    __shared__ int s_hit[AABB_HITS * 256];
+    __shared__ int s_tmp[4];
+    __shared__ int s_bid;
+    __shared__ unsigned long long s_pre;
+    const long long R = counts[0], V = counts[2];
+    const int bid = lb_ticket(ticket, &s_bid);
+    if ((long long)bid * 256 >= R && !(R == 0 && bid == 0)) return;   // (workgroup-uniform)
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)bid * 256 + threadIdx.x;
+    const bool live = r < R;
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    int rb = -1;
+    if (live) {
+        dx = ray_dir[3 * r];
+        dy = ray_dir[3 * r + 1];
+        dz = ray_dir[3 * r + 2];
+        rb = ray_bid[r];
+    }
+    const RayInv inv = ray_inv(dx, dy, dz);
+    int n = 0;
+    for (long long v0 = 0; v0 < V; v0 += 256) {
+        const int nv = (int)min((long long)256, V - v0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * 6; i += blockDim.x) s_vb[i] = vbound[6 * v0 + i];
+        for (int i = threadIdx.x; i < nv; i += blockDim.x) s_vbid[i] = vox_bid[v0 + i];
+        __syncthreads();
+        if (!live) continue;
+        for (int j = 0; j < nv; ++j) {
+            if (s_vbid[j] != rb) continue;
+            float t0, t1;
+            if (!slab_test(inv, s_vb + 6 * j, t0, t1)) continue;
+            if (n < AABB_HITS) s_hit[n * 256 + threadIdx.x] = (int)(v0 + j);
+            ++n;
+        }
+    }
+    int tot;
+    const int ex = block_scan_256(n, s_tmp, tot);
+    if (threadIdx.x == 0) lb_store(status, bid, bid == 0 ? LIDF_LB_INC : LIDF_LB_AGG, (unsigned)tot);
+    if (threadIdx.x < 64) {
+        const unsigned long long pre = bid > 0 ? lb_exclusive(status, bid, lane) : 0ull;
+        if (lane == 0) {
+            if (bid > 0) lb_store(status, bid, LIDF_LB_INC, pre + (unsigned)tot);
+            s_pre = pre;
+        }
+    }
+    __syncthreads();
+    const long long o = (long long)s_pre + ex;   // (the uncut offset: < 2^31 * ... kept in 64 bits)
+    if (live) pair_off[r] = (int)(o > pair_cap ? pair_cap : o);
+    if ((live && r == R - 1) || (R == 0 && threadIdx.x == 0)) {
+        const long long total = o + n;
+        pair_off[R] = (int)(total > pair_cap ? pair_cap : total);
+        counts[1] = (int)(total > pair_cap ? pair_cap : total);   // P
+        if (total > pair_cap) counts[7] |= 1;
+        counts[6] = counts[3] + (int)R;                           // NV + R
+    }
+    if (!live || n == 0) return;
+    if (n <= AABB_HITS) {
+        for (int i = 0; i < n; ++i) {
+            const long long p = o + i;
+            if (p >= pair_cap) break;
+            const int v = s_hit[i * 256 + threadIdx.x];
+            float vb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vb[k] = vbound[6 * (size_t)v + k];
+            float t0 = 0.f, t1 = 0.f;
+            slab_test(inv, vb, t0, t1);
+            pair_ray[p] = (int)r;
+            pair_vox[p] = v;
+            *(f32x2*)(pair_t + 2 * p) = f32x2{t0, t1};
+        }
+    } else {   // more hits than the LDS list holds (cannot happen on a 9^3 grid: <= 25 cells per ray)
+        int m = 0;
+        for (long long v = 0; v < V; ++v) {
+            if (vox_bid[v] != rb) continue;
+            float vb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vb[k] = vbound[6 * (size_t)v + k];
+            float t0, t1;
+            if (!slab_test(inv, vb, t0, t1)) continue;
+            const long long p = o + m;
+            ++m;
+            if (p >= pair_cap) break;
+            pair_ray[p] = (int)r;
+            pair_vox[p] = (int)v;
+            *(f32x2*)(pair_t + 2 * p) = f32x2{t0, t1};
+        }
+    }
+}
+
+// lb: 64 bytes (ticket) + one status word per 256 rays of capacity, zeroed before the launch
+extern "C" size_t lidf_ray_aabb_onepass_lb_bytes(long long R_cap) { return 64 + (size_t)((R_cap + 255) / 256) * 8; }
+extern "C" hipError_t lidf_launch_ray_aabb_onepass(const float* ray_dir, const float* vbound, const int* ray_bid,
+                                                   const int* vox_bid, long long R_cap, int* counts, void* lb,
+                                                   int* pair_off, int* pair_ray, int* pair_vox, float* pair_t,
+                                                   long long pair_cap, hipStream_t st) {
+    if (R_cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_ray_aabb_onepass_kernel, dim3((unsigned)((R_cap + 255) / 256)), dim3(256), 0, st,
+                       ray_dir, vbound, ray_bid, vox_bid, counts, (int*)lb,
+                       (unsigned long long*)((char*)lb + 64), pair_off, pair_ray, pair_vox, pair_t, pair_cap);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // The same compact list when the voxels are cells of a regular grid (LIDF.get_occ_vox_bound,
 // models/pipeline.py:162-201: bound_min = xmin + coord * part_size, so a bound depends on the cell
@@ -1575,5 +1692,102 @@ extern "C" hipError_t lidf_launch_fingerprint(const float* const* ptrs, const lo
     s.nseg = nseg;
     if (blk == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(lidf_fingerprint_kernel, dim3(blk), dim3(256), 0, st, s, salt, guard);
+    return hipGetLastError();
+}
+
+// The same fingerprint over several module groups in ONE launch (the frame path: query decoders,
+// PointNet, stage-2 PointNet, stage-2 decoder — four launches of ~11 us each before): segment i belongs
+// to group grp[i] and is hashed with its word index inside the group; every group has its own guard,
+// salt and block count, and the block of a group that finishes last leaves that group's verdict.
+struct FpSegsM {
+    const unsigned* p[LIDF_FP_MULTI_SEGS];
+    unsigned n[LIDF_FP_MULTI_SEGS];        // words
+    unsigned base[LIDF_FP_MULTI_SEGS];     // index of the segment's first word in its group's concatenation
+    unsigned blk0[LIDF_FP_MULTI_SEGS + 1]; // first workgroup of the segment
+    unsigned char grp[LIDF_FP_MULTI_SEGS];
+    unsigned gblocks[LIDF_FP_GROUPS];      // workgroups of the group
+    unsigned long long salt[LIDF_FP_GROUPS];
+    int nseg;
+};
+
+__global__ void __launch_bounds__(256) lidf_fingerprint_multi_kernel(FpSegsM s, LidfPackGuardState* guards,
+                                                                     int guard_stride) {
+    int seg = 0;
+    for (int k = 1; k < LIDF_FP_MULTI_SEGS; ++k) seg += (k < s.nseg && blockIdx.x >= s.blk0[k]) ? 1 : 0;
+    const unsigned n = s.n[seg], base = s.base[seg];
+    const int grp = s.grp[seg];
+    LidfPackGuardState* g = (LidfPackGuardState*)((char*)guards + (size_t)grp * guard_stride);
+    const unsigned* __restrict__ p = s.p[seg];
+    const unsigned w0 = (blockIdx.x - s.blk0[seg]) * FP_WORDS;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int r = 0; r < FP_WORDS / 1024; ++r) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = w0 + (4 * r + j) * 256 + threadIdx.x;
+            w[j] = i < n ? p[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = w0 + (4 * r + j) * 256 + threadIdx.x;
+            if (i < n) acc += fp_mix(((unsigned long long)(base + i) << 32) | w[j]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)acc, o), hi = __shfl_xor((unsigned)(acc >> 32), o);
+        acc += ((unsigned long long)hi << 32) | lo;
+    }
+    __shared__ unsigned long long part[4];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        last = atomicAdd(&g->ticket, 1u) == s.gblocks[grp] - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long h = atomicAdd(&g->acc, 0ull) + s.salt[grp];
+        g->dirty = (!g->valid || g->hash != h) ? 1 : 0;
+        g->hash = h;
+        g->valid = 1;
+        g->acc = 0;
+        g->ticket = 0;
+    }
+}
+
+// segments sorted by group (grp ascending, every group non-empty); guards: ngrp states guard_stride bytes apart
+extern "C" hipError_t lidf_launch_fingerprint_multi(const float* const* ptrs, const long long* floats,
+                                                    const int* grp, int nseg,
+                                                    const unsigned long long* salts, int ngrp,
+                                                    void* guards, int guard_stride, hipStream_t st) {
+    if (nseg <= 0 || nseg > LIDF_FP_MULTI_SEGS || ngrp <= 0 || ngrp > LIDF_FP_GROUPS) return hipErrorInvalidValue;
+    FpSegsM s = {};
+    unsigned blk = 0;
+    unsigned base[LIDF_FP_GROUPS] = {};
+    for (int i = 0; i < nseg; ++i) {
+        const int g = grp[i];
+        if (g < 0 || g >= ngrp || (i > 0 && g < grp[i - 1])) return hipErrorInvalidValue;
+        s.p[i] = (const unsigned*)ptrs[i];
+        s.n[i] = (unsigned)floats[i];
+        s.base[i] = base[g];
+        s.blk0[i] = blk;
+        s.grp[i] = (unsigned char)g;
+        base[g] += s.n[i];
+        const unsigned nb = (s.n[i] + FP_WORDS - 1) / FP_WORDS;
+        blk += nb;
+        s.gblocks[g] += nb;
+    }
+    s.blk0[nseg] = blk;
+    s.nseg = nseg;
+    for (int g = 0; g < ngrp; ++g) {
+        if (s.gblocks[g] == 0) return hipErrorInvalidValue;
+        s.salt[g] = salts[g];
+    }
+    hipLaunchKernelGGL(lidf_fingerprint_multi_kernel, dim3(blk), dim3(256), 0, st, s,
+                       (LidfPackGuardState*)guards, guard_stride);
     return hipGetLastError();
 }

@@ -55,7 +55,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_LINEAR = 3,
        LIDF_MODE_FUSED_H = 4,   // split-f16 stream of lidf_points_h.hip
        LIDF_MODE_TRAIN = 5,     // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
-       LIDF_MODE_ROWS_GATHER = 6 };  // rows mode whose layer-1 accumulators start from gathered rows
+       LIDF_MODE_ROWS_GATHER = 6,    // rows mode whose layer-1 accumulators start from gathered rows
+       LIDF_MODE_PNET_CHAIN = 7 };   // pack jobs only: the per-point chain stream of a PointNet2Stage (PN_* below)
 
 // One decoder's parameters as the packer sees them.
 struct NetW {
@@ -94,6 +95,8 @@ struct StreamLayout {
 };
 
 #define LIDF_FP_MAX_SEGS 24   // parameter buffers per fingerprint launch (two decoders: 18)
+#define LIDF_FP_MULTI_SEGS 56 // ... of the frame's one fingerprint launch over all its modules (18 + 12 + 12 + 10)
+#define LIDF_FP_GROUPS 4      // ... which keeps one guard per module group
 
 // Device-side state of a guarded pack (lidf_pack_guard_bytes() bytes, zero-filled by the caller once):
 // the fingerprint the packed streams were built from and the verdict of the latest comparison.
@@ -107,7 +110,7 @@ struct LidfPackGuardState {
 };
 
 // One stream to pack (lidf_pack_multi_kernel packs up to LIDF_PACK_JOBS of them per launch).
-#define LIDF_PACK_JOBS 4
+#define LIDF_PACK_JOBS 8
 struct PackJob {
     StreamLayout lay;
     NetW n0, n1;
@@ -119,6 +122,58 @@ struct PackJobs {
     PackJob job[LIDF_PACK_JOBS];
     int n;
 };
+
+
+// ---- stream of the per-point chains of PointNet2Stage (lidf_pointnet.hip), 1 KiB quads consumed in order:
+//   P1  1 quad            K = 6 inputs + bias (operand columns 4h + {0..3}: 6 = 1.0, 7 = 0)
+//   P2  2 x 5 quads       K = 32 + bias, quad = 2 kq + t
+//   P3  4 x 8 quads       K = 64 (second half of W3's columns), quad = 8 T + kq   [stage 2]
+//   P4  4 x 17 quads      K = 128 + bias, quad = 17 T + kq                         [stage 2]
+//   (+ 1 padding quad)
+#define PN_P1 1
+#define PN_P2 10
+#define PN_P3 32
+#define PN_P4 68
+// per tile a stage walks a multiple of the ring's 8 quads, so that the ring slot of quad 0 is the
+// same for every tile (stage 1 skips over five quads of P3, stage 2 over one padding quad)
+#define PN_S1_QUADS 16
+#define PN_S2_QUADS 112
+struct PnetW {
+    const float *w_p1, *b_p1, *w_p2, *b_p2, *w_p3, *w_p4, *b_p4;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int pn_feature(int s, int half) {
+    const int T = s >> 4, r = s & 15;
+    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+// element e of the chain stream (PN_S2_QUADS * 256 floats)
+__device__ __forceinline__ float pn_stream_value(const PnetW& w, int e) {
+    int quad = e / 256;
+    const int lane = (e % 256) / 4, jj = e & 3;
+    const int half = lane >> 5, c32 = lane & 31;
+    float v = 0.f;
+    if (quad < PN_P1) {
+        const int x = 4 * half + jj;                       // operand column
+        if (x < 6) v = w.w_p1[c32 * 6 + x];
+        else if (x == 6) v = w.b_p1[c32];
+    } else if (quad < PN_P1 + PN_P2) {
+        quad -= PN_P1;
+        const int kq = quad / 2, t = quad % 2, s = 4 * kq + jj, out = 32 * t + c32;
+        if (s < 16) v = w.w_p2[out * 32 + pn_feature(s, half)];
+        else if (s == 16 && half == 0) v = w.b_p2[out];
+    } else if (quad < PN_P1 + PN_P2 + PN_P3) {
+        quad -= PN_P1 + PN_P2;
+        const int T = quad / 8, kq = quad % 8, s = 4 * kq + jj, out = 32 * T + c32;
+        v = w.w_p3[out * 128 + 64 + pn_feature(s, half)];  // columns 64..127 multiply f2
+    } else if (quad < PN_P1 + PN_P2 + PN_P3 + PN_P4) {
+        quad -= PN_P1 + PN_P2 + PN_P3;
+        const int T = quad / 17, kq = quad % 17, s = 4 * kq + jj, out = 32 * T + c32;
+        if (s < 64) v = w.w_p4[out * 128 + pn_feature(s, half)];
+        else if (s == 64 && half == 0) v = w.b_p4[out];
+    }
+    return v;
+}
+#endif  // __HIPCC__
 
 static inline int lidf_l1_quads(int mode, const L1Map& m) {
     if (mode == LIDF_MODE_FUSED) return 24 * ((m.L + 1) / 2) + 8;
@@ -224,6 +279,59 @@ struct LinearArgs {
     int ld_add2;
 };
 
+// Regular voxel grid of LIDF.get_occ_vox_bound (models/pipeline.py:162-201): lower corner (already
+// widened by half a voxel), voxel size, cells per axis, frames.
+struct GridSpec {
+    float xmin[3];
+    float crop;
+    int r[3];
+    int B;
+};
+
+// Arguments of one refine iteration's per-ray launch (lidf_refine.hip: lidf_refine_step_kernel).
+struct RefineStepArgs {
+    const float* prev_pos;     // [R,3]
+    const float* prev_off;     // [R] offsets of the previous iteration, or NULL (first iteration)
+    float r0, rs;
+    float* cur_pos;            // [R,3] written when prev_off (else the iteration starts from prev_pos)
+    const float* ray_dir;
+    const int *ray_bid, *ray_flat;
+    const long long* max_pair_id;
+    const int* pair_vox;
+    const float* vbound;
+    const int* vox_bid;
+    GridSpec g;
+    const int *cell_flag, *cell_rank;
+    const float* rgb;
+    long long hw;
+    int pnet_rel, pos_rel, L;
+    float* pnet_inp;           // rows behind the *row0_dev valid points
+    int* pnet_vox;
+    const unsigned char* sel;
+    int* end_voxel;
+    float* inp_embed;          // embed(pos) lands at columns [256, 256 + E)
+    int ld_e;
+    const int* dims;           // device {R, P, V}
+    const int* row0_dev;
+    float *zero0, *zero1;
+    long long nzero0, nzero1;
+};
+
+// Arguments of the two-layer per-voxel kernel (lidf_linear.hip: lidf_vox2_kernel).
+struct Vox2Args {
+    const float* X;          // [n, D1] rows, stride ldx
+    long long ldx, n;
+    const int* n_dev;        // optional device-side row count (n = capacity of the launch)
+    const float* s1;         // layer 1: rows-mode stream, quad (kq * nt1 + t)
+    int kq1, nt1, D1, bias1, relu1;
+    float* out1;             // optional store [n, 32 nt1], stride ld1
+    long long ld1;
+    const float* s2;         // layer 2 (NULL: none): K = 32 nt1 (+ bias column), quad (kq * nt2 + t)
+    int kq2, nt2, bias2, relu2;
+    float* out2;             // [n, 32 nt2], stride ld2
+    long long ld2;
+};
+
 #ifdef __HIPCC__
 // sin/cos of x*2^o for the positional encoding (implicit_net.py:30-32: freq bands are exact powers
 // of two). x/(2 pi) is formed once as hi + lo (fma residual + low part of 1/(2 pi)); scaling by
@@ -249,14 +357,6 @@ __device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, flo
 
 #endif  // __HIPCC__
 
-// Regular voxel grid of LIDF.get_occ_vox_bound (models/pipeline.py:162-201): lower corner (already
-// widened by half a voxel), voxel size, cells per axis, frames.
-struct GridSpec {
-    float xmin[3];
-    float crop;
-    int r[3];
-    int B;
-};
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int block_scan_256(int v, int* s_tmp, int& total) {
@@ -277,6 +377,60 @@ __device__ __forceinline__ int block_scan_256(int v, int* s_tmp, int& total) {
     return wpre + inc - v;
 }
 
+#endif  // __HIPCC__
+
+#ifdef __HIPCC__
+// ---- decoupled look-back: an exclusive prefix over the workgroups of ONE launch ------------------
+// (the frame path: a count -> scan -> fill chain of three or five launches becomes one.) One status
+// word per workgroup, zeroed before the launch: bits 63..62 = 0 nothing yet / 1 the workgroup's own
+// aggregate / 2 the inclusive prefix up to and including it; the low 62 bits hold the value (one count,
+// or two counts of < 2^31 packed side by side: fields add independently). A workgroup publishes its
+// aggregate as soon as it has it, then one of its wavefronts walks back over its predecessors, 64 at a
+// time, adding aggregates until it meets an inclusive prefix. Workgroups take their index from an
+// atomic ticket (not blockIdx), so a predecessor is always a workgroup that already runs. The words are
+// relaxed agent-scope atomics: a word carries its value itself, nothing else is published through it
+// (release / acquire would write back and invalidate the L2 at every step).
+#define LIDF_LB_AGG 1ull
+#define LIDF_LB_INC 2ull
+#define LIDF_LB_MASK 0x3fffffffffffffffull
+__device__ __forceinline__ void lb_store(unsigned long long* st, long long i, unsigned long long flag,
+                                         unsigned long long v) {
+    __hip_atomic_store(st + i, (flag << 62) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+// exclusive prefix of workgroup `bid`; every lane of ONE wavefront calls it and receives the result
+__device__ __forceinline__ unsigned long long lb_exclusive(const unsigned long long* st, long long bid,
+                                                           int lane) {
+    unsigned long long run = 0;
+    for (long long j = bid - 1; j >= 0; j -= 64) {
+        const long long idx = j - lane;
+        unsigned long long w;
+        for (;;) {
+            w = idx >= 0 ? __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : (LIDF_LB_INC << 62);
+            if (__ballot((w >> 62) == 0) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const unsigned long long inc = __ballot((w >> 62) == LIDF_LB_INC);
+        const int first = inc ? __builtin_ctzll(inc) : 64;
+        run += lb_wave_sum(lane <= first ? (w & LIDF_LB_MASK) : 0ull);
+        if (inc) break;
+    }
+    return run;
+}
+// the workgroup's ticket (its index in the prefix order), broadcast through `s_bid`
+__device__ __forceinline__ int lb_ticket(int* counter, int* s_bid) {
+    if (threadIdx.x == 0) *s_bid = atomicAdd(counter, 1);
+    __syncthreads();
+    return *s_bid;
+}
 #endif  // __HIPCC__
 
 #ifdef __HIPCC__

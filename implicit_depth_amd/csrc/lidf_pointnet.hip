@@ -37,81 +37,45 @@
 #define LDQ(rs, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
 
-#define PN_P1 1
-#define PN_P2 10
-#define PN_P3 32
-#define PN_P4 68
-// per tile a stage walks a multiple of the ring's 8 quads, so that the ring slot of quad 0 is the
-// same for every tile (stage 1 skips over five quads of P3, stage 2 over one padding quad)
-#define PN_S1_QUADS 16
-#define PN_S2_QUADS 112
 static_assert(PN_P1 + PN_P2 <= PN_S1_QUADS && PN_P1 + PN_P2 + PN_P3 + PN_P4 <= PN_S2_QUADS, "stream");
 static_assert(PN_S1_QUADS % LIDF_RING == 0 && PN_S2_QUADS % LIDF_RING == 0, "ring phase");
 
-struct PnetW {
-    const float *w_p1, *b_p1, *w_p2, *b_p2, *w_p3, *w_p4, *b_p4;
-};
 struct PnetChainArgs {
     const float* stream;   // PN_S2_QUADS KiB
     const float* inp;      // [n,6]
     const int* vox;        // [n] (negative: the row is left out)
     const float* gpart;    // [V,128] = W3[:, :64] g1 + b3 (stage 2)
-    float* pool;           // stage 1: [V,64], stage 2: [V,128]  (global-atomic path; zeroed)
-    float* part;           // LDS path: [gridDim.x, V * F] slabs; atomic path: [copies, V * F] (zeroed)
-    int V, copies;
+    float* pool;           // stage 1: [V,64], stage 2: [V,128]  (zeroed by the caller; takes integer maxima)
+    float* part;           // global-atomic path with copies: [copies, V * F] (zeroed)
+    int V, copies;         // V: rows of `pool`
+    int v_tab;             // LDS instantiation: rows of the workgroup's full table (rows [0, v_tab) of the voxels)
     long long n;
     // sync-free frame path: device-side counts. n_dev overrides n (n = capacity of the launch).
-    // V_dev selects the variant on the device: the LDS-table launch (table of a.V rows, a.V = the
-    // caller's bound) runs iff *V_dev <= a.V, the global-atomic launch iff *V_dev > v_lds.
+    // V_dev selects the walk on the device inside ONE launch of the LDS instantiation: *V_dev <= v_tab
+    // -> every voxel has a row of the workgroup's table; else, with perm, the voxel-sorted walk over a
+    // windowed table; else the full table for the first v_tab voxels and lane-level global maxima for
+    // the rest (correct, slow: a single frame with more occupied voxels than the table holds).
     const int* n_dev;
     const int* V_dev;
-    int v_lds;
     // voxel-sorted walk (large tables): point p of the launch is perm[p], the points are grouped by
     // voxel (lidf_launch_pointnet_sort), points left out of the pooling are not in perm; the number of
     // points is *n_perm. The global-atomic pooling then meets one or two voxels per wavefront.
     const int* perm;
     const int* n_perm;
     // window > 0 (with perm; the LDS instantiation): the workgroup's table holds `window` rows starting
-    // at the voxel of its first point — its contiguous run of sorted points spans a handful of voxels —
-    // and is flushed into `pool` with atomic maxima at the end; a point beyond the window raises `pool`
-    // directly.
+    // at the voxel of its first point — its contiguous run of sorted points spans a handful of voxels;
+    // a point beyond the table raises `pool` directly. Either table is flushed into `pool` with one
+    // atomic maximum per touched entry at the end of the workgroup (round 4; rounds 2-3 wrote the full
+    // table to a slab per workgroup and reduced the slabs in a second launch).
     int window;
 };
-
-__device__ __forceinline__ int pn_feature(int s, int half) {
-    const int T = s >> 4, r = s & 15;
-    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half;
-}
 
 __global__ void lidf_pack_pointnet_kernel(PnetW w, float* __restrict__ stream,
                                           const LidfPackGuardState* guard) {
     if (guard && guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= PN_S2_QUADS * 256) return;
-    int quad = e / 256;
-    const int lane = (e % 256) / 4, jj = e & 3;
-    const int half = lane >> 5, c32 = lane & 31;
-    float v = 0.f;
-    if (quad < PN_P1) {
-        const int x = 4 * half + jj;                       // operand column
-        if (x < 6) v = w.w_p1[c32 * 6 + x];
-        else if (x == 6) v = w.b_p1[c32];
-    } else if (quad < PN_P1 + PN_P2) {
-        quad -= PN_P1;
-        const int kq = quad / 2, t = quad % 2, s = 4 * kq + jj, out = 32 * t + c32;
-        if (s < 16) v = w.w_p2[out * 32 + pn_feature(s, half)];
-        else if (s == 16 && half == 0) v = w.b_p2[out];
-    } else if (quad < PN_P1 + PN_P2 + PN_P3) {
-        quad -= PN_P1 + PN_P2;
-        const int T = quad / 8, kq = quad % 8, s = 4 * kq + jj, out = 32 * T + c32;
-        v = w.w_p3[out * 128 + 64 + pn_feature(s, half)];  // columns 64..127 multiply f2
-    } else if (quad < PN_P1 + PN_P2 + PN_P3 + PN_P4) {
-        quad -= PN_P1 + PN_P2 + PN_P3;
-        const int T = quad / 17, kq = quad % 17, s = 4 * kq + jj, out = 32 * T + c32;
-        if (s < 64) v = w.w_p4[out * 128 + pn_feature(s, half)];
-        else if (s == 64 && half == 0) v = w.b_p4[out];
-    }
-    stream[e] = v;
+    stream[e] = pn_stream_value(w, e);
 }
 
 __device__ __forceinline__ void pn_relu(f32x16& v) {
@@ -225,14 +189,11 @@ template <int STAGE, bool LDSPOOL>
 __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainArgs a) {
     extern __shared__ int pn_tab[];
     constexpr int F = STAGE == 1 ? 64 : 128;
-    const bool windowed = LDSPOOL && a.window > 0;
+    bool windowed = LDSPOOL && a.window > 0 && a.perm;
+    if (LDSPOOL && a.V_dev) windowed = windowed && *a.V_dev > a.v_tab;   // device-side choice of the walk
     const bool use_perm = a.perm && (!LDSPOOL || windowed);
-    if (a.V_dev) {   // device-side choice of the variant: full LDS table up to v_lds voxels, else the other one
-        const bool fits = *a.V_dev <= a.v_lds;
-        if (fits != (LDSPOOL && !windowed)) return;
-    }
     const long long AN = use_perm ? (long long)*a.n_perm : (a.n_dev ? (long long)*a.n_dev : a.n);
-    const int tab_rows = windowed ? a.window : a.V;
+    const int tab_rows = windowed ? a.window : a.v_tab;
     if (LDSPOOL) {
         for (int i = threadIdx.x; i < tab_rows * F; i += 256) pn_tab[i] = 0;
         __syncthreads();
@@ -271,9 +232,9 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         long long pc = valid ? p : AN - 1;
         if (use_perm) pc = a.perm[pc];   // voxel-sorted walk
         const int vox = a.vox[pc];
-        // row of the LDS table; a point beyond the window goes to the global table (vrow = -1)
-        const int vrow = windowed ? ((vox >= vbase && vox - vbase < a.window) ? vox - vbase : -1) : vox;
-        const bool spill = windowed && valid && vox >= 0 && vrow < 0;
+        // row of the LDS table; a point beyond the table goes to the global table (vrow = -1)
+        const int vrow = (vox >= vbase && vox - vbase < tab_rows) ? vox - vbase : -1;
+        const bool spill = LDSPOOL && valid && vox >= 0 && vrow < 0;
         // operand columns of this lane: 4h + {0..3} of [x0..x5, 1, 0]
         float b1[4];
         {
@@ -370,19 +331,14 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
             }
         }
     }
-    if (windowed) {
-        // the window's rows into the global table: one atomic maximum per touched entry and workgroup
+    if (LDSPOOL) {
+        // the table's rows into the global table: one atomic maximum per touched entry and workgroup
         __syncthreads();
-        for (int i = threadIdx.x; i < a.window * F; i += 256) {
+        for (int i = threadIdx.x; i < tab_rows * F; i += 256) {
             const int v = pn_tab[i];
             const int row = vbase + i / F;
             if (v > 0 && row < a.V) atomicMax((int*)a.pool + (size_t)row * F + i % F, v);
         }
-    } else if (LDSPOOL) {
-        __syncthreads();
-        f32x4* dst = (f32x4*)(a.part + (size_t)blockIdx.x * a.V * F);
-        const f32x4* src = (const f32x4*)pn_tab;
-        for (int i = threadIdx.x; i < a.V * F / 4; i += 256) dst[i] = src[i];
     }
 }
 
@@ -391,11 +347,8 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
 // are combined through LDS.
 __global__ void __launch_bounds__(256) lidf_pointnet_poolmax_kernel(const float* __restrict__ part, int G,
                                                                     long long count,
-                                                                    float* __restrict__ pool,
-                                                                    const int* __restrict__ V_dev,
-                                                                    int v_lds) {
+                                                                    float* __restrict__ pool) {
     __shared__ f32x4 red[16][16];
-    if (V_dev && *V_dev > v_lds) return;   // frame path: the global-atomic variant wrote `pool` itself
     const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
     const long long e = ((long long)blockIdx.x * 16 + c) * 4;
     f32x4 m = {0.f, 0.f, 0.f, 0.f};
@@ -442,8 +395,6 @@ extern "C" hipError_t lidf_launch_pack_pointnet(const float* w_p1, const float* 
 
 extern "C" size_t lidf_pointnet_chain_stream_bytes(void) { return (size_t)PN_S2_QUADS * 1024; }
 
-// Scratch of the pooling: PN_MAX_WGS slabs of V x 128 floats when the table fits LDS, else up to
-// PN_COPIES copies of the table for the global-atomic path (at most 32 MiB).
 #define PN_WINDOW 32     // rows of the windowed table of the voxel-sorted walk (16 KiB at 128 features)
 #define PN_MAX_WGS 512
 #define PN_LDS_LIMIT (144 * 1024)
@@ -452,16 +403,27 @@ static int pn_copies(long long V) {
     long long c = (32LL << 20) / (V * 512);
     return (int)(c > PN_COPIES ? PN_COPIES : (c < 1 ? 1 : c));
 }
+// Scratch of the pooling: none when the table fits LDS (the workgroups flush their tables into `pool`),
+// else up to PN_COPIES copies of the table for the unsorted global-atomic path (at most 32 MiB).
 extern "C" size_t lidf_pointnet_pool_scratch_bytes(long long V) {
     if (V <= 0) return 0;
     if ((size_t)V * 128 * 4 > PN_LDS_LIMIT) return (size_t)pn_copies(V) * V * 128 * 4;
-    return (size_t)PN_MAX_WGS * V * 128 * 4;
+    return 0;
 }
 
-// stage 1: pool = pool1 [V,64]; stage 2: gpart [V,128], pool = pool2 [V,128]. With `part`
-// (lidf_pointnet_pool_scratch_bytes(V) bytes) `pool` is written: through per-workgroup LDS tables
-// when V x 128 floats fit, else through a few zeroed copies of the table that take global atomic
-// maxima; without `part`, `pool` itself must be zeroed and takes the atomic maxima.
+template <int STAGE>
+static hipError_t launch_chain_lds(const PnetChainArgs& a, long long g, size_t lds, hipStream_t st) {
+    static bool configured[64];
+    hipError_t e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<STAGE, true>, PN_LDS_LIMIT);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((lidf_pointnet_chain_kernel<STAGE, true>), dim3((unsigned)g), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// stage 1: pool = pool1 [V,64]; stage 2: gpart [V,128], pool = pool2 [V,128]. `pool` must be zeroed by the
+// caller and takes integer maxima: through per-workgroup LDS tables when V x 128 floats fit, else (with
+// `part`, lidf_pointnet_pool_scratch_bytes(V) bytes) through a few zeroed copies of the table that take
+// global atomic maxima and a reduce, else straight into `pool`.
 extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream, const float* inp,
                                                  const int* vox, const float* gpart, float* pool,
                                                  float* part, long long V, long long n, int cus,
@@ -469,32 +431,19 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
     if (n <= 0) return hipSuccess;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n;
-    a.part = part; a.V = (int)V; a.copies = 0;
-    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0; a.perm = nullptr; a.n_perm = nullptr; a.window = 0;
+    a.part = part; a.V = (int)V; a.copies = 0; a.v_tab = (int)V;
+    a.n_dev = nullptr; a.V_dev = nullptr; a.perm = nullptr; a.n_perm = nullptr; a.window = 0;
     const int F = stage == 1 ? 64 : 128;
     const long long count = V * F;
     const long long ntile = (n + 127) / 128;
     const size_t lds = (size_t)V * F * 4;
-    if (part && (size_t)V * 128 * 4 <= PN_LDS_LIMIT) {
+    if ((size_t)V * 128 * 4 <= PN_LDS_LIMIT) {
         // two workgroups per CU while two tables fit, else one
         long long g = lds <= 65536 ? 2LL * cus : cus;
         if (g > PN_MAX_WGS) g = PN_MAX_WGS;
         if (g > ntile) g = ntile;
-        hipError_t e;
-        if (stage == 1) {
-            static bool configured[64];
-            e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<1, true>, PN_LDS_LIMIT);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), lds, st, a);
-        } else {
-            static bool configured[64];
-            e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<2, true>, PN_LDS_LIMIT);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
-        }
-        hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
-                           st, part, (int)g, count, pool, (const int*)nullptr, 0);
-        return hipGetLastError();
+        a.part = nullptr;
+        return stage == 1 ? launch_chain_lds<1>(a, g, lds, st) : launch_chain_lds<2>(a, g, lds, st);
     }
     if (part) {
         a.copies = pn_copies(V);
@@ -508,67 +457,35 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
         hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g), dim3(256), 0, st, a);
     if (part)
         hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0,
-                           st, part, a.copies, count, pool, (const int*)nullptr, 0);
+                           st, part, a.copies, count, pool);
     return hipGetLastError();
 }
 
-// The same stage with device-side counts (the sync-free frame path): n_cap / V_cap bound the launch,
-// *n_dev / *V_dev are the sizes. Two launches, one of which returns at once: per-workgroup LDS tables
-// of v_lds rows (the caller's bound for typical frames, <= 288) when *V_dev <= v_lds, else global
-// atomic maxima straight into `pool` (zeroed by the caller, [V_cap, F]). `part`: PN_MAX_WGS slabs of
-// v_lds x F floats. `pool` rows >= *V_dev stay zero.
-extern "C" size_t lidf_pointnet_pool_scratch_bytes_dev(long long v_lds) {
-    return (size_t)PN_MAX_WGS * (v_lds > 0 ? v_lds : 1) * 128 * 4;
-}
+// The same stage with device-side counts (the sync-free frame path) in ONE launch: n_cap / V_cap bound
+// it, *n_dev / *V_dev are the sizes. Per-workgroup LDS tables of v_lds rows (the caller's bound for
+// typical frames, <= 288) serve *V_dev <= v_lds; beyond it the voxel-sorted walk over a windowed table
+// when `perm` is given (several frames per batch), else the first v_lds voxels through the table and the
+// others through lane-level global maxima. `pool` ([V_cap, F]) is zeroed by the caller.
 extern "C" hipError_t lidf_launch_pointnet_chain_dev(int stage, const float* stream, const float* inp,
                                                      const int* vox, const float* gpart, float* pool,
-                                                     float* part, long long V_cap, int v_lds,
+                                                     long long V_cap, int v_lds,
                                                      long long n_cap, const int* n_dev,
                                                      const int* V_dev, const int* perm,
                                                      const int* n_perm, int cus, hipStream_t st) {
     if (n_cap <= 0) return hipSuccess;
-    if (v_lds <= 0 || (size_t)v_lds * 128 * 4 > PN_LDS_LIMIT || !part || !V_dev) return hipErrorInvalidValue;
+    if (v_lds <= 0 || (size_t)v_lds * 128 * 4 > PN_LDS_LIMIT || !V_dev) return hipErrorInvalidValue;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
-    a.part = part; a.V = v_lds; a.copies = 0; a.n_dev = n_dev; a.V_dev = V_dev; a.v_lds = v_lds;
-    a.perm = nullptr; a.n_perm = nullptr; a.window = 0;
+    a.part = nullptr; a.V = (int)V_cap; a.copies = 0; a.n_dev = n_dev; a.V_dev = V_dev; a.v_tab = v_lds;
+    a.perm = perm; a.n_perm = n_perm; a.window = perm ? PN_WINDOW : 0;
     const int F = stage == 1 ? 64 : 128;
     const long long ntile = (n_cap + 127) / 128;
-    const size_t lds = (size_t)v_lds * F * 4;
+    size_t lds = (size_t)v_lds * F * 4;
+    if (perm && lds < (size_t)PN_WINDOW * F * 4) lds = (size_t)PN_WINDOW * F * 4;
     long long g = lds <= 65536 ? 2LL * cus : cus;
     if (g > PN_MAX_WGS) g = PN_MAX_WGS;
     if (g > ntile) g = ntile;
-    hipError_t e;
-    if (stage == 1) {
-        static bool configured[64];
-        e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<1, true>, PN_LDS_LIMIT);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), lds, st, a);
-    } else {
-        static bool configured[64];
-        e = lidf_max_lds_once(configured, (const void*)lidf_pointnet_chain_kernel<2, true>, PN_LDS_LIMIT);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), lds, st, a);
-    }
-    hipLaunchKernelGGL(lidf_pointnet_poolmax_kernel, dim3((unsigned)(((long long)v_lds * F + 63) / 64)),
-                       dim3(256), 0, st, part, (int)g, (long long)v_lds * F, pool, V_dev, v_lds);
-    // the fallback: more occupied voxels than the LDS tables hold
-    a.V = (int)V_cap; a.part = nullptr;
-    const long long g2 = ntile < 2LL * cus ? ntile : 2LL * cus;
-    if (perm) {   // voxel-sorted walk with a windowed LDS table
-        a.perm = perm; a.n_perm = n_perm; a.window = PN_WINDOW;
-        const size_t wl = (size_t)PN_WINDOW * F * 4;
-        if (stage == 1)
-            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g2), dim3(256), wl, st, a);
-        else
-            hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g2), dim3(256), wl, st, a);
-        return hipGetLastError();
-    }
-    if (stage == 1)
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, false>), dim3((unsigned)g2), dim3(256), 0, st, a);
-    return hipGetLastError();
+    return stage == 1 ? launch_chain_lds<1>(a, g, lds, st) : launch_chain_lds<2>(a, g, lds, st);
 }
 
 
@@ -599,16 +516,12 @@ extern "C" hipError_t lidf_launch_pointnet_chain_sorted(int stage, const float* 
     if (n_cap <= 0) return hipSuccess;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
-    a.part = nullptr; a.V = (int)V; a.copies = 0;
-    a.n_dev = nullptr; a.V_dev = nullptr; a.v_lds = 0;
+    a.part = nullptr; a.V = (int)V; a.copies = 0; a.v_tab = PN_WINDOW;
+    a.n_dev = nullptr; a.V_dev = nullptr;
     a.n_perm = n_perm; a.perm = perm; a.window = PN_WINDOW;
     const int F = stage == 1 ? 64 : 128;
     const size_t wl = (size_t)PN_WINDOW * F * 4;
     const long long ntile = (n_cap + 127) / 128;
     const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
-    if (stage == 1)
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<1, true>), dim3((unsigned)g), dim3(256), wl, st, a);
-    else
-        hipLaunchKernelGGL((lidf_pointnet_chain_kernel<2, true>), dim3((unsigned)g), dim3(256), wl, st, a);
-    return hipGetLastError();
+    return stage == 1 ? launch_chain_lds<1>(a, g, wl, st) : launch_chain_lds<2>(a, g, wl, st);
 }

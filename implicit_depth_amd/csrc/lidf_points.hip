@@ -140,8 +140,14 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
 __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& net0, const NetW& net1,
                                           const L1Map& m, float* stream, float* aux) {
     if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
-    NetW nets[2] = {net0, net1};
     int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lay.mode == LIDF_MODE_PNET_CHAIN) {   // a PointNet2Stage's per-point chain stream riding as a job
+        // (net0 carries w_p1, b_p1, w_p2, b_p2, w_p3, w_p4, b_p4 in w1, b1, w2, b2, w3, b3, w4)
+        const PnetW w = {net0.w1, net0.b1, net0.w2, net0.b2, net0.w3, net0.b3, net0.w4};
+        if (e < lay.total) stream[e] = pn_stream_value(w, e);
+        return;
+    }
+    NetW nets[2] = {net0, net1};
     if (e < lay.total) stream[e] = stream_value(lay, nets, m, e);
     if (lay.mode != LIDF_MODE_L1ONLY && lay.mode != LIDF_MODE_LINEAR && e < lay.nets * LIDF_AUX_FLOATS) {
         int sec = e / LIDF_AUX_FLOATS, i = e % LIDF_AUX_FLOATS;
@@ -1096,24 +1102,30 @@ __device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long
     }
 }
 
-// Flat list of items (problem a then problem b; the 2*nets parts of a tile adjacent, so that the
+// Flat list of items (problem a, then b, then c; the 2*nets parts of a tile adjacent, so that the
 // operand rows of a tile are fetched from HBM once and found in L2 by the other parts), cut into
-// equal contiguous runs over the grid.
-__global__ void __launch_bounds__(256) lidf_l1part_pair_kernel(PointsArgs a, PointsArgs b) {
+// equal contiguous runs over the grid. c (optional, c.stream == NULL: none) is a third table with its
+// own stream — the frame path's per-ray part of the stage-2 decoder's layer 1, which reads the same
+// rayfeat rows as the query's raypart (a launch of its own over 76,800 rows before).
+__global__ void __launch_bounds__(256) lidf_l1part_pair_kernel(PointsArgs a, PointsArgs b, PointsArgs c) {
     __shared__ float s_stage[4 * 32 * 33];
-    const int parts = a.nets * 2;
+    const int pa = a.nets * 2, pb = b.nets * 2, pc = c.stream ? c.nets * 2 : 0;
     const long long an = a.n_dev ? (long long)*a.n_dev : a.n, bn = b.n_dev ? (long long)*b.n_dev : b.n;
-    const long long na = (an + 127) / 128 * parts, nb = (bn + 127) / 128 * parts;
-    const long long tot = na + nb, per = tot / gridDim.x, rem = tot % gridDim.x;
+    const long long cn = pc ? (c.n_dev ? (long long)*c.n_dev : c.n) : 0;
+    const long long na = (an + 127) / 128 * pa, nb = (bn + 127) / 128 * pb, nc = (cn + 127) / 128 * pc;
+    const long long tot = na + nb + nc, per = tot / gridDim.x, rem = tot % gridDim.x;
     const long long bx = blockIdx.x;
     const long long ib = bx * per + (bx < rem ? bx : rem), ie = ib + per + (bx < rem ? 1 : 0);
     for (long long i = ib; i < ie; ++i) {
         if (i < na) {
-            const int part = (int)(i % parts);
-            l1part_item(a, an, i / parts, part >> 1, part & 1, s_stage);
+            const int part = (int)(i % pa);
+            l1part_item(a, an, i / pa, part >> 1, part & 1, s_stage);
+        } else if (i < na + nb) {
+            const int part = (int)((i - na) % pb);
+            l1part_item(b, bn, (i - na) / pb, part >> 1, part & 1, s_stage);
         } else {
-            const int part = (int)((i - na) % parts);
-            l1part_item(b, bn, (i - na) / parts, part >> 1, part & 1, s_stage);
+            const int part = (int)((i - na - nb) % pc);
+            l1part_item(c, cn, (i - na - nb) / pc, part >> 1, part & 1, s_stage);
         }
     }
 }
@@ -1124,14 +1136,16 @@ static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
 }
 
-extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, const PointsArgs& b, int cus,
-                                               hipStream_t st) {
-    if (a.nets != b.nets) return hipErrorInvalidValue;
-    const long long items = ((a.n + 127) / 128 + (b.n + 127) / 128) * a.nets * 2;
+extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, const PointsArgs& b, const PointsArgs* c,
+                                               int cus, hipStream_t st) {
+    PointsArgs cc = {};
+    if (c) cc = *c;
+    const long long items = (a.n + 127) / 128 * a.nets * 2 + (b.n + 127) / 128 * b.nets * 2 +
+                            (cc.stream ? (cc.n + 127) / 128 * cc.nets * 2 : 0);
     if (items <= 0) return hipSuccess;
     // two workgroups per CU: 9600 wavefront items of a 240x320 frame leave 10 per SIMD at best
     const int grid = (int)(items < 2LL * cus ? items : 2LL * cus);
-    hipLaunchKernelGGL(lidf_l1part_pair_kernel, dim3(grid), dim3(256), 0, st, a, b);
+    hipLaunchKernelGGL(lidf_l1part_pair_kernel, dim3(grid), dim3(256), 0, st, a, b, cc);
     return hipGetLastError();
 }
 

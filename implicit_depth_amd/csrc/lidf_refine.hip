@@ -153,6 +153,122 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
     inp_embed[(size_t)r * ld_e + 128 + c] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One refine iteration's per-ray work in ONE launch (the sync-free frame path, round 4; rounds 2-3:
+// zero -> end voxel -> PointNet rows -> embed(pos) rows, and the previous iteration's finish = 5
+// launches): a workgroup owns 64 rays.
+//   phase 1 (one thread per ray): the position this iteration starts from — pred_pos of stage 1, or
+//     prev + (off * rs + r0) * dir of the previous iteration (pipeline.py:1028-1029; the expressions
+//     of lidf_refine_finish_kernel) —, the end voxel, the PointNet row (lidf_refine_prep_kernel);
+//   phase 2 (all threads): the 64 x E block embed(pos) of the decoder rows, written as row segments
+//     (lidf_refine_rows_kernel's expressions).
+// End voxel = the largest occupied voxel of the ray's image whose box contains the point (the
+// reference's pcl_aabb + scatter max, pipeline.py:939-944). The voxels are cells of the frame's grid:
+// the cell of the point is estimated from (p - xmin) / crop and the 27 cells around it are tested with
+// the reference's own inclusive predicate on the voxels' stored bounds — the estimate only has to be
+// right to within one cell, the decision is inside_box's. Voxel indices ascend with the cell key. A
+// NaN coordinate fails no comparison of inside_box (the point is "inside" every voxel of its image):
+// such a ray walks the voxel list as the reference does.
+// The workgroups also zero the PointNet's max-pool tables of this iteration (zero0 / zero1).
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a) {
+    __shared__ float s_q[64 * 3];
+    {   // this iteration's zero-initialised scratch
+        const long long tot = a.nzero0 + a.nzero1;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+            if (i < a.nzero0) a.zero0[i] = 0.f;
+            else a.zero1[i - a.nzero0] = 0.f;
+        }
+    }
+    const long long R = a.dims[0], P = a.dims[1], V = a.dims[2];
+    const long long r0w = (long long)blockIdx.x * 64;
+    if (r0w >= R) return;
+    if (threadIdx.x < 64) {
+        const long long r = r0w + threadIdx.x;
+        if (r < R) {
+            float x = a.prev_pos[3 * r], y = a.prev_pos[3 * r + 1], z = a.prev_pos[3 * r + 2];
+            if (a.prev_off) {
+                const float s = a.prev_off[r] * a.rs + a.r0;
+                x = x + s * a.ray_dir[3 * r];
+                y = y + s * a.ray_dir[3 * r + 1];
+                z = z + s * a.ray_dir[3 * r + 2];
+                a.cur_pos[3 * r] = x;
+                a.cur_pos[3 * r + 1] = y;
+                a.cur_pos[3 * r + 2] = z;
+            }
+            const int bid = a.ray_bid[r];
+            const long long m = a.max_pair_id[r];
+            int ev = (m >= 0 && m < P) ? a.pair_vox[m] : 0;
+            const float pp[3] = {x, y, z};
+            if (x != x || y != y || z != z) {
+                for (long long j = 0; j < V; ++j)
+                    if (a.vox_bid[j] == bid && inside_box(x, y, z, a.vbound + 6 * j)) ev = max(ev, (int)j);
+            } else {
+                int c0[3], c1[3];
+                bool any = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float v = (pp[k] - a.g.xmin[k]) / a.g.crop;
+                    if (!(v > -2.f && v < (float)a.g.r[k] + 2.f)) { any = false; c0[k] = 0; c1[k] = -1; continue; }
+                    const int q = (int)floorf(v);
+                    c0[k] = max(q - 1, 0);
+                    c1[k] = min(q + 1, a.g.r[k] - 1);
+                }
+                if (any) {
+                    for (int cx = c0[0]; cx <= c1[0]; ++cx)
+                        for (int cy = c0[1]; cy <= c1[1]; ++cy)
+                            for (int cz = c0[2]; cz <= c1[2]; ++cz) {
+                                const int key = ((bid * a.g.r[0] + cx) * a.g.r[1] + cy) * a.g.r[2] + cz;
+                                if (!a.cell_flag[key]) continue;
+                                const int j = a.cell_rank[key];
+                                if (inside_box(x, y, z, a.vbound + 6 * (size_t)j)) ev = max(ev, j);
+                            }
+                }
+            }
+            a.end_voxel[r] = ev;
+            const float* vb = a.vbound + 6 * (size_t)ev;
+            const float cxx = (vb[0] + vb[3]) / 2.f, cyy = (vb[1] + vb[4]) / 2.f, czz = (vb[2] + vb[5]) / 2.f;
+            const long long row = *a.row0_dev + r;
+            a.pnet_vox[row] = (!a.sel || a.sel[r]) ? ev : -1;
+            float* pi = a.pnet_inp + 6 * row;
+            pi[0] = a.pnet_rel ? x - cxx : x;
+            pi[1] = a.pnet_rel ? y - cyy : y;
+            pi[2] = a.pnet_rel ? z - czz : z;
+            const float* px = a.rgb + (size_t)bid * 3 * a.hw + a.ray_flat[r];
+            pi[3] = px[0];
+            pi[4] = px[a.hw];
+            pi[5] = px[2 * a.hw];
+            s_q[3 * threadIdx.x] = a.pos_rel ? x - cxx : x;
+            s_q[3 * threadIdx.x + 1] = a.pos_rel ? y - cyy : y;
+            s_q[3 * threadIdx.x + 2] = a.pos_rel ? z - czz : z;
+        }
+    }
+    __syncthreads();
+    const int E = 3 + 6 * a.L;
+    const int nr = (int)min((long long)64, R - r0w);
+    for (int i = threadIdx.x; i < nr * E; i += 256) {
+        const int rr = i / E, k = i % E;
+        const int ax = k < 3 ? k : (k - 3) % 3;    // coordinate
+        const float q = s_q[3 * rr + ax];
+        float v;
+        if (k < 3) {
+            v = q;
+        } else {
+            const int l = (k - 3) / 6;
+            const float f = (float)(1 << l);
+            v = ((k - 3) % 6) < 3 ? sinf(q * f) : cosf(q * f);
+        }
+        a.inp_embed[(size_t)(r0w + rr) * a.ld_e + 256 + k] = v;
+    }
+}
+
+extern "C" hipError_t lidf_launch_refine_step(const RefineStepArgs& a, long long R_cap, hipStream_t st) {
+    if (R_cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_step_kernel, dim3((unsigned)((R_cap + 63) / 64)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long long* max_pair_id,
                                               const int* pair_vox, long long P, const float* vbound,
                                               const int* vox_bid, long long V, const int* ray_bid,
