@@ -133,6 +133,8 @@ class LidfFrameArgs(C.Structure):
         ("end_voxel_id", C.c_void_p), ("pred_depth_refine", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("valid_idx_bid", C.c_void_p), ("valid_idx_flat", C.c_void_p), ("n_valid_idx", C.c_int64),
+        ("pack_blob", C.c_void_p), ("pack_blob_bytes", C.c_size_t), ("pack_guard", C.c_void_p),
+        ("pack_mode", C.c_int32),
     ]
 
 
@@ -191,6 +193,8 @@ SIGNATURES = {
     "lidf_frame_workspace_bytes": (_SZ, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _I64,
                                          C.c_int32, C.c_int32]),
     "lidf_frame_f32": (C.c_int, [C.POINTER(LidfFrameArgs), _P]),
+    "lidf_frame_pack_bytes": (_SZ, []),
+    "lidf_frame_pack_guard_bytes": (_SZ, []),
     "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),

@@ -100,6 +100,8 @@ hipError_t lidf_launch_frame_select(const float*, const int*, const int*, long l
                                     unsigned char*, hipStream_t);
 hipError_t lidf_launch_fingerprint(const float* const*, const long long*, int, unsigned long long,
                                    LidfPackGuardState*, hipStream_t);
+hipError_t lidf_launch_fingerprint_multi(const float* const*, const long long*, const int*, int,
+                                         const unsigned long long*, int, void*, int, hipStream_t);
 size_t lidf_pointnet_chain_stream_bytes(void);
 hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int*, const float*, float*,
                                       float*, long long, long long, int, hipStream_t);
@@ -559,6 +561,33 @@ static unsigned long long decoder_salt(unsigned long long h, const LidfDecoder* 
     return salt_mix(h, init_bits);
 }
 
+static unsigned long long query_salt(const LidfDecoder* prob, const LidfDecoder* off, int multires,
+                                     int multires_views, int precision) {
+    unsigned long long salt = salt_mix(0x51ED270B1ull, ((unsigned long long)multires << 32) |
+                                                           ((unsigned long long)multires_views << 8) |
+                                                           (unsigned long long)precision);
+    return decoder_salt(decoder_salt(salt, prob), off);
+}
+static unsigned long long refine_salt(const LidfDecoder* off, int multires, int multires_views) {
+    return decoder_salt(salt_mix(0x2EF19Eull, ((unsigned long long)multires << 32) |
+                                                  (unsigned long long)multires_views), off);
+}
+#define PNET_SALT 0x9071E7ull
+static int pnet_segs(const LidfPointNet* w, const float** ptrs, long long* n, int k) {
+    const float* p[12] = {w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_v1, w->b_v1,
+                          w->w_p3, w->b_p3, w->w_p4, w->b_p4, w->w_v2, w->b_v2};
+    const long long c[12] = {32 * 6, 32, 64 * 32, 64, 64 * 64, 64, 128 * 128, 128, 128 * 128, 128,
+                             128 * 128, 128};
+    for (int i = 0; i < 12; ++i) { ptrs[k] = p[i]; n[k] = c[i]; ++k; }
+    return k;
+}
+// a guarded call that failed after its fingerprint launch must not leave a guard that matches the
+// parameters beside streams that were not (completely) re-packed: forget the fingerprint
+static int guard_fail(void* guard, size_t bytes, hipStream_t st, int rc) {
+    (void)hipMemsetAsync(guard, 0, bytes, st);
+    return rc;
+}
+
 LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDecoder* off, int multires,
                                            int multires_views, int precision, void* packed,
                                            size_t packed_bytes, void* guard, lidf_stream_t stream) {
@@ -572,18 +601,16 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
     long long cnt[LIDF_FP_MAX_SEGS];
     int k = decoder_segs(prob, D + (prob->is_ief ? 16 : 0), ptrs, cnt, 0);
     k = decoder_segs(off, D + (off->is_ief ? 16 : 0), ptrs, cnt, k);
-    unsigned long long salt = salt_mix(0x51ED270B1ull, ((unsigned long long)multires << 32) |
-                                                           ((unsigned long long)multires_views << 8) |
-                                                           (unsigned long long)precision);
-    salt = decoder_salt(decoder_salt(salt, prob), off);
+    const unsigned long long salt = query_salt(prob, off, multires, multires_views, precision);
     CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, k, salt, (LidfPackGuardState*)guard,
                                       (hipStream_t)stream));
     GuardScope scope((const LidfPackGuardState*)guard);
     JobScope js;
     if ((rc = pack_query_weights(prob, off, multires, multires_views, precision, (char*)packed,
                                  (hipStream_t)stream)))
-        return rc;
-    CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
+        return guard_fail(guard, sizeof(LidfPackGuardState), (hipStream_t)stream, rc);
+    if (flush_jobs(js.jobs, (hipStream_t)stream) != hipSuccess)
+        return guard_fail(guard, sizeof(LidfPackGuardState), (hipStream_t)stream, LIDF_ERR_HIP);
     return LIDF_OK;
 }
 
@@ -1098,9 +1125,21 @@ static int pointnet_impl(const LidfPointNet* w, const float* inp, const int32_t*
     if (!b.f5) {
         // inference: the per-point layers are two register chains (lidf_pointnet.hip), no per-point
         // intermediate is written; the per-voxel layers stay launches over V rows
-        if (!pp)
-            CHECK_HIP(lidf_launch_pack_pointnet(w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_p3, w->w_p4,
-                                                w->b_p4, b.chain, tl_guard, st));
+        if (!pp) {
+            if (tl_jobs) {   // collected with the module's other streams (lidf_pack_multi_kernel)
+                StreamLayout lay = {};
+                lay.nets = 1; lay.mode = LIDF_MODE_PNET_CHAIN;
+                lay.total = (int)(lidf_pointnet_chain_stream_bytes() / 4);
+                NetW nw = {};
+                nw.w1 = w->w_p1; nw.b1 = w->b_p1; nw.w2 = w->w_p2; nw.b2 = w->b_p2; nw.w3 = w->w_p3;
+                nw.b3 = w->w_p4; nw.w4 = w->b_p4;
+                L1Map m0 = {};
+                CHECK_HIP(pack_stream(lay, nw, nw, m0, b.chain, nullptr, st));
+            } else {
+                CHECK_HIP(lidf_launch_pack_pointnet(w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_p3, w->w_p4,
+                                                    w->b_p4, b.chain, tl_guard, st));
+            }
+        }
         const bool sorted = !po && b.sort && n > 0 && n_vox > lidf_pointnet_lds_max_voxels() &&
                             lidf_pointnet_sort_bytes(n, n_vox) > 0;
         const int *perm = nullptr, *n_perm = nullptr;
@@ -1193,19 +1232,24 @@ LIDF_API int lidf_pointnet_f32(const LidfPointNet* w, const float* inp, const in
 
 LIDF_API size_t lidf_pointnet_pack_bytes(void) { return pnet_ws(1, 1).f1; }   // the stream slots
 
+// the module's streams into `packed` as pack jobs of the caller's JobScope (or direct launches without one)
+static int pointnet_pack_into(const LidfPointNet* w, void* packed, hipStream_t st) {
+    const PnetWs ws = pnet_ws(1, 1);
+    PnetBufs b = {};
+    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)((char*)packed + ws.s[i]);
+    b.chain = (float*)((char*)packed + ws.chain);
+    int rc, cus;
+    if ((rc = cu_count(&cus))) return rc;
+    return pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, st, 1);
+}
+
 LIDF_API int lidf_pointnet_pack_f32(const LidfPointNet* w, void* packed, size_t packed_bytes,
                                       lidf_stream_t stream) {
     int rc;
     if ((rc = check_pointnet_w(w))) return rc;
     if (!packed || packed_bytes < lidf_pointnet_pack_bytes()) return LIDF_ERR_WORKSPACE;
-    const PnetWs ws = pnet_ws(1, 1);
-    PnetBufs b = {};
-    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)((char*)packed + ws.s[i]);
-    b.chain = (float*)((char*)packed + ws.chain);
-    int cus;
-    if ((rc = cu_count(&cus))) return rc;
     JobScope js;
-    if ((rc = pointnet_impl(w, nullptr, nullptr, 0, 0, nullptr, b, cus, (hipStream_t)stream, 1))) return rc;
+    if ((rc = pointnet_pack_into(w, packed, (hipStream_t)stream))) return rc;
     CHECK_HIP(flush_jobs(js.jobs, (hipStream_t)stream));
     return LIDF_OK;
 }
@@ -1216,14 +1260,15 @@ LIDF_API int lidf_pointnet_pack_guarded_f32(const LidfPointNet* w, void* packed,
     if ((rc = check_pointnet_w(w))) return rc;
     if (!guard) return LIDF_ERR_BAD_ARG;
     if (!packed || packed_bytes < lidf_pointnet_pack_bytes()) return LIDF_ERR_WORKSPACE;
-    const float* ptrs[12] = {w->w_p1, w->b_p1, w->w_p2, w->b_p2, w->w_v1, w->b_v1,
-                             w->w_p3, w->b_p3, w->w_p4, w->b_p4, w->w_v2, w->b_v2};
-    const long long cnt[12] = {32 * 6, 32, 64 * 32, 64, 64 * 64, 64, 128 * 128, 128, 128 * 128, 128,
-                               128 * 128, 128};
-    CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, 12, 0x9071E7ull, (LidfPackGuardState*)guard,
+    const float* ptrs[12];
+    long long cnt[12];
+    pnet_segs(w, ptrs, cnt, 0);
+    CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, 12, PNET_SALT, (LidfPackGuardState*)guard,
                                       (hipStream_t)stream));
     GuardScope scope((const LidfPackGuardState*)guard);
-    return lidf_pointnet_pack_f32(w, packed, packed_bytes, stream);
+    if ((rc = lidf_pointnet_pack_f32(w, packed, packed_bytes, stream)))
+        return guard_fail(guard, sizeof(LidfPackGuardState), (hipStream_t)stream, rc);
+    return LIDF_OK;
 }
 
 // ---- stage-2 refinement ----------------------------------------------------------------------
@@ -1453,16 +1498,100 @@ LIDF_API size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_
     return frame_ws(batch, height, width, res, max_pairs, frame_lds_voxels(lds_voxels, C), refine_times).total;
 }
 
-LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
-    if (!a) return LIDF_ERR_BAD_ARG;
+
+// ---- the weight streams of every module of a frame in one blob, validated by ONE fingerprint launch ----
+struct FramePackLay {
+    size_t query, pnet, pnet_r, refine, total;
+};
+static FramePackLay frame_pack_lay() {
+    FramePackLay l;
+    size_t o = 0;
+    l.query = o;  o += align_up(lidf_query_pack_bytes(), 256);
+    l.pnet = o;   o += align_up(lidf_pointnet_pack_bytes(), 256);
+    l.pnet_r = o; o += align_up(lidf_pointnet_pack_bytes(), 256);
+    l.refine = o; o += align_up(lidf_refine_pack_bytes(16, 16), 256);
+    l.total = o;
+    return l;
+}
+#define FRAME_GUARD_STRIDE 64
+static_assert(sizeof(LidfPackGuardState) <= FRAME_GUARD_STRIDE, "guard stride");
+LIDF_API size_t lidf_frame_pack_bytes(void) { return frame_pack_lay().total; }
+LIDF_API size_t lidf_frame_pack_guard_bytes(void) { return (size_t)LIDF_FP_GROUPS * FRAME_GUARD_STRIDE; }
+
+// groups: 0 the query's two decoders, 1 the PointNet, 2 the stage-2 PointNet, 3 the stage-2 decoder (f32)
+static int frame_pack_guarded(const LidfFrameArgs* a, char* blob, char* guards, hipStream_t st) {
+    const bool rf = a->refine_times > 0, split = a->precision == LIDF_PRECISION_F16X3;
+    const int L = a->multires, Lv = a->multires_views;
+    const int D = 256 + 2 * (3 + 6 * L) + 3 + 6 * Lv, Dr = 256 + 3 + 6 * L + 3 + 6 * Lv;
+    const FramePackLay l = frame_pack_lay();
+    const float* ptrs[LIDF_FP_MULTI_SEGS];
+    long long cnt[LIDF_FP_MULTI_SEGS];
+    int grp[LIDF_FP_MULTI_SEGS];
+    unsigned long long salts[LIDF_FP_GROUPS] = {};
+    int k = decoder_segs(a->prob, D + (a->prob->is_ief ? 16 : 0), ptrs, cnt, 0);
+    k = decoder_segs(a->off, D + (a->off->is_ief ? 16 : 0), ptrs, cnt, k);
+    for (int i = 0; i < k; ++i) grp[i] = 0;
+    salts[0] = query_salt(a->prob, a->off, L, Lv, a->precision);
+    int k0 = k, ngrp = 2;
+    k = pnet_segs(a->pnet, ptrs, cnt, k);
+    for (int i = k0; i < k; ++i) grp[i] = 1;
+    salts[1] = PNET_SALT;
+    if (rf) {
+        k0 = k;
+        k = pnet_segs(a->pnet_refine, ptrs, cnt, k);
+        for (int i = k0; i < k; ++i) grp[i] = 2;
+        salts[2] = PNET_SALT;
+        ngrp = 3;
+        if (!split) {   // (the split-f16 IEF of stage 2 packs its rows stream inside the call)
+            k0 = k;
+            k = decoder_segs(a->off_refine, Dr + (a->off_refine->is_ief ? 16 : 0), ptrs, cnt, k);
+            for (int i = k0; i < k; ++i) grp[i] = 3;
+            salts[3] = refine_salt(a->off_refine, L, Lv);
+            ngrp = 4;
+        }
+    }
+    const size_t gbytes = (size_t)LIDF_FP_GROUPS * FRAME_GUARD_STRIDE;
+    CHECK_HIP(lidf_launch_fingerprint_multi(ptrs, cnt, grp, k, salts, ngrp, guards, FRAME_GUARD_STRIDE, st));
+    int rc = LIDF_OK;
+    JobScope js;
+    {
+        GuardScope g((const LidfPackGuardState*)guards);
+        rc = pack_query_weights(a->prob, a->off, L, Lv, a->precision, blob + l.query, st);
+    }
+    if (!rc) {
+        GuardScope g((const LidfPackGuardState*)(guards + FRAME_GUARD_STRIDE));
+        rc = pointnet_pack_into(a->pnet, blob + l.pnet, st);
+    }
+    if (!rc && rf) {
+        GuardScope g((const LidfPackGuardState*)(guards + 2 * FRAME_GUARD_STRIDE));
+        rc = pointnet_pack_into(a->pnet_refine, blob + l.pnet_r, st);
+    }
+    if (!rc && rf && !split) {
+        GuardScope g((const LidfPackGuardState*)(guards + 3 * FRAME_GUARD_STRIDE));
+        rc = refine_ief_factorised(a->off_refine, Dr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr,
+                                   blob + l.refine, st, 1, nullptr, nullptr, nullptr, nullptr, 3 + 6 * Lv,
+                                   nullptr, false);
+    }
+    if (!rc && flush_jobs(js.jobs, st) != hipSuccess) rc = LIDF_ERR_HIP;
+    return rc ? guard_fail(guards, gbytes, st, rc) : LIDF_OK;
+}
+
+LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
+    if (!a_in) return LIDF_ERR_BAD_ARG;
+    LidfFrameArgs a_loc = *a_in;
+    LidfFrameArgs* a = &a_loc;
     const int B = a->batch, h = a->height, w = a->width;
     if (B <= 0 || h <= 0 || w <= 0 || a->valid_stride < 1 || a->max_pairs <= 0 || !(a->part_size > 0.f))
         return LIDF_ERR_BAD_ARG;
     if (a->res[0] <= 0 || a->res[1] <= 0 || a->res[2] <= 0 || a->refine_times < 0) return LIDF_ERR_BAD_ARG;
     const int64_t N = (int64_t)B * h * w, C = (int64_t)B * a->res[0] * a->res[1] * a->res[2];
     if (N > 0x15555555LL || C > 0x7fffffffLL || a->max_pairs > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+    const bool own_pack = a->pack_mode != LIDF_FRAME_PACK_CALLER;
+    if (a->pack_mode != LIDF_FRAME_PACK_CALLER && a->pack_mode != LIDF_FRAME_PACK_GUARDED &&
+        a->pack_mode != LIDF_FRAME_PACK_TRUSTED)
+        return LIDF_ERR_BAD_ARG;
     if (!a->rgb || !a->xyz_corrupt || !a->valid_mask || !a->intr || !a->feat_grid || !a->pnet || !a->prob ||
-        !a->off || !a->packed_query || !a->counts)
+        !a->off || (!own_pack && !a->packed_query) || !a->counts)
         return LIDF_ERR_BAD_ARG;
     if (!a->valid_bid || !a->valid_flat || !a->valid_xyz || !a->valid_rgb || !a->occ_bid_coord ||
         !a->voxel_bound || !a->valid_v_pid || !a->revidx || !a->valid_v_rel_coord || !a->pnet_inp ||
@@ -1474,13 +1603,32 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a, lidf_stream_t stream) {
         return LIDF_ERR_BAD_ARG;
     const bool rf = a->refine_times > 0;
     const bool split = a->precision == LIDF_PRECISION_F16X3;
-    if (rf && (!a->pnet_refine || !a->off_refine || (!split && !a->packed_refine) || !a->pred_pos_refine ||
-               !a->end_voxel_id || !a->pred_depth_refine))
+    if (rf && (!a->pnet_refine || !a->off_refine || (!split && !own_pack && !a->packed_refine) ||
+               !a->pred_pos_refine || !a->end_voxel_id || !a->pred_depth_refine))
         return LIDF_ERR_BAD_ARG;
     int rc, cus;
     if ((rc = check_query_model(a->prob, a->off, a->multires, a->multires_views, a->precision))) return rc;
     if (rf && (rc = check_decoder(a->off_refine))) return rc;
+    if ((rc = check_pointnet_w(a->pnet)) || (rf && (rc = check_pointnet_w(a->pnet_refine)))) return rc;
     if ((rc = cu_count(&cus))) return rc;
+    // the weight streams: the caller's blobs, or the frame's own blob (validated here by one fingerprint
+    // launch over every module, or trusted)
+    LidfPointNet pn_loc = *a->pnet, pnr_loc = {};
+    if (rf) pnr_loc = *a->pnet_refine;
+    if (own_pack) {
+        const FramePackLay pl = frame_pack_lay();
+        if (!a->pack_blob || !a->pack_guard || a->pack_blob_bytes < pl.total) return LIDF_ERR_WORKSPACE;
+        char* blob = (char*)a->pack_blob;
+        if (a->pack_mode == LIDF_FRAME_PACK_GUARDED &&
+            (rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, (hipStream_t)stream)))
+            return rc;
+        a->packed_query = blob + pl.query;
+        pn_loc.packed = blob + pl.pnet;
+        pnr_loc.packed = blob + pl.pnet_r;
+        a->packed_refine = blob + pl.refine;
+    }
+    a->pnet = &pn_loc;
+    if (rf) a->pnet_refine = &pnr_loc;
     const int v_lds = frame_lds_voxels(a->lds_voxels, (size_t)C);
     const FrameWs f = frame_ws(B, h, w, a->res, a->max_pairs, v_lds, a->refine_times);
     if (!a->workspace || a->workspace_bytes < f.total) return LIDF_ERR_WORKSPACE;
@@ -2007,13 +2155,13 @@ LIDF_API int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multir
     const float* ptrs[LIDF_FP_MAX_SEGS];
     long long cnt[LIDF_FP_MAX_SEGS];
     const int k = decoder_segs(off, D + (off->is_ief ? 16 : 0), ptrs, cnt, 0);
-    unsigned long long salt = salt_mix(0x2EF19Eull, ((unsigned long long)multires << 32) |
-                                                        (unsigned long long)multires_views);
-    salt = decoder_salt(salt, off);
+    const unsigned long long salt = refine_salt(off, multires, multires_views);
     CHECK_HIP(lidf_launch_fingerprint(ptrs, cnt, k, salt, (LidfPackGuardState*)guard,
                                       (hipStream_t)stream));
     GuardScope scope((const LidfPackGuardState*)guard);
-    return lidf_refine_pack_f32(off, multires, multires_views, packed, packed_bytes, stream);
+    if ((rc = lidf_refine_pack_f32(off, multires, multires_views, packed, packed_bytes, stream)))
+        return guard_fail(guard, sizeof(LidfPackGuardState), (hipStream_t)stream, rc);
+    return LIDF_OK;
 }
 
 struct TrainWs {

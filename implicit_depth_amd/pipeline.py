@@ -232,11 +232,21 @@ class FrameRunner:
     pixel or every opt.valid_stride-th; intersect_pos_type 'abs' (the shipped configs); precision "f32"
     or "f16x3" (as lidf_query / lidf_refine).
     max_pairs bounds the pair list (default 32 per pixel: a ray crosses at most 25 cells of the 9^3
-    grid); a frame with more pairs raises in result()."""
+    grid); a frame with more pairs raises in result().
+
+    Weight streams: the runner owns ONE blob with the packed streams of all its modules and the
+    device-side fingerprints they were built from (nothing of it lives in the per-module caches, so a
+    captured graph never references memory another call can free). Every frame re-validates them with one
+    fingerprint launch over all parameter buffers (+ two early-exit pack launches, ~20 us) — in-place
+    updates, `p.data` writes and load_state_dict are picked up by the next frame. guard_every = N > 1
+    validates every N-th frame only and trusts the blob in between (evaluation loops whose parameters do
+    not change: the reference's eval runs under torch.no_grad() with the modules in eval());
+    `invalidate()` forces the check on the next frame; modules frozen with _lib.freeze_packed are
+    validated once."""
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
                  offset_dec_refine=None, max_pairs=None, lds_voxels=None,
-                 precision="f32"):
+                 precision="f32", guard_every=1):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -313,7 +323,12 @@ class FrameRunner:
             "miss_mask": torch.empty((bs, h, w), **f32) if opt.mask_type == "pred" else None,
         }
         self.graph = None
+        self.graph_trusted = None                  # the same launch sequence without the guard (guard_every > 1)
         self._keep = None
+        self.guard_every = max(1, int(guard_every))
+        self._frames_since_guard = None            # None: the next frame validates
+        self.pack_blob = torch.empty((L.lidf_frame_pack_bytes(),), dtype=torch.uint8, device=dev)
+        self.pack_guard = torch.zeros((L.lidf_frame_pack_guard_bytes(),), dtype=torch.uint8, device=dev)
         self.vidx, self.n_valid_idx = None, 0      # explicit valid points (load(valid_idx=))
         self.src = dict(self.inp)
         math.isfinite(self.part_size)
@@ -381,20 +396,30 @@ class FrameRunner:
         self.n_valid_idx = m
 
     # -- the launch sequence ------------------------------------------------------------------------
-    def enqueue(self):
-        """lidf_frame_f32 on the static inputs: guarded weight packs (fingerprints compared on the
-        device) + the frame; nothing here reads a size or waits for the device."""
+    def invalidate(self):
+        """The next frame re-validates the packed weight streams (guard_every > 1, frozen modules)."""
+        self._frames_since_guard = None
+
+    def _guard_due(self):
+        """Whether the coming frame fingerprints the parameters (and re-packs what changed)."""
+        n = self._frames_since_guard
+        if n is None:
+            return True
+        if all(m is None or m in _lib.FROZEN for m in self.mods):
+            return False
+        return n >= self.guard_every
+
+    def enqueue(self, guard=True):
+        """lidf_frame_f32 on the static inputs: one fingerprint launch over every module's parameters +
+        the early-exit packs (guard=True) + the frame; nothing here reads a size or waits for the device."""
         from .decoders import _decoder_struct
-        from .pointnet import packed_pointnet, pointnet_struct
-        from .query import _packed_weights
+        from .pointnet import pointnet_struct
         C = self.C
         pnet, prob, off, pnet_r, off_r = self.mods
         opt, b, i = self.opt, self.buf, self.src
         keep = []
         dp, do = _decoder_struct(prob, keep), _decoder_struct(off, keep)
         pn = pointnet_struct(pnet, keep)
-        keep.append(packed_pointnet(pnet, pn, self.dev))
-        packed_q = _packed_weights(prob, off, opt.multires, opt.multires_views, self.precision, dp, do, self.dev)
         a = _lib.LidfFrameArgs()
         a.batch, a.height, a.width = self.bs, self.h, self.w
         for k in ("rgb", "xyz_corrupt", "valid_mask", "intr", "feat_grid"):
@@ -405,7 +430,7 @@ class FrameRunner:
         a.part_size = self.part_size
         a.valid_stride = int(opt.valid_stride) if opt.valid_stride and opt.valid_stride > 1 else 1
         a.pnet, a.prob, a.off = C.pointer(pn), C.pointer(dp), C.pointer(do)
-        a.packed_query = packed_q.data_ptr()
+        a.packed_query = None
         a.multires, a.multires_views, a.roi_inp_bbox, a.pos_rel = opt.multires, opt.multires_views, opt.roi_inp_bbox, 0
         a.offset_range0, a.offset_range1 = float(opt.offset_range[0]), float(opt.offset_range[1])
         a.refine_times = self.times
@@ -413,20 +438,7 @@ class FrameRunner:
         if self.refine:
             dr = _decoder_struct(off_r, keep)
             pr = pointnet_struct(pnet_r, keep)
-            keep.append(packed_pointnet(pnet_r, pr, self.dev))
-            L = _lib.lib()
             a.pnet_refine, a.off_refine, a.packed_refine = C.pointer(pr), C.pointer(dr), None
-            if self.precision == "f32":   # (the split-f16 IEF packs its rows stream inside the call)
-                e = _lib.packed_entry(_lib.PACK_CACHE_REFINE, off_r,
-                                      (opt.multires, opt.multires_views, str(self.dev)),
-                                      L.lidf_refine_pack_bytes(opt.multires, opt.multires_views), self.dev)
-                if not (off_r in _lib.FROZEN and e.frozen_ready):
-                    with torch.cuda.device(self.dev):
-                        _lib.check(L.lidf_refine_pack_guarded_f32(
-                            C.byref(dr), opt.multires, opt.multires_views, _lib.ptr(e.blob), e.blob.numel(),
-                            _lib.ptr(e.guard), _lib.current_stream(self.dev)))
-                    e.frozen_ready = off_r in _lib.FROZEN
-                a.packed_refine = e.blob.data_ptr()
             a.refine_pos_rel = int(opt.refine_intersect_pos_type == "rel")
             a.refine_pnet_pos_rel = int(opt.refine_pnet_pos_type == "rel")
             a.refine_use_all_pix = int(bool(opt.refine_use_all_pix) or opt.mask_type != "all")
@@ -439,29 +451,45 @@ class FrameRunner:
         if self.n_valid_idx > 0:
             a.valid_idx_bid, a.valid_idx_flat = self.vidx[0].data_ptr(), self.vidx[1].data_ptr()
             a.n_valid_idx = self.n_valid_idx
-        with torch.cuda.device(self.dev):
-            _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))
+        # the runner's own packed streams + fingerprints (lidf_hip.h: LIDF_FRAME_PACK_GUARDED / _TRUSTED)
+        a.pack_blob, a.pack_blob_bytes = self.pack_blob.data_ptr(), self.pack_blob.numel()
+        a.pack_guard = self.pack_guard.data_ptr()
+        a.pack_mode = 1 if guard else 2
+        try:
+            with torch.cuda.device(self.dev):
+                _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))
+        except RuntimeError:
+            self._frames_since_guard = None   # (the library reset the fingerprints; validate again)
+            raise
         self._keep = keep
 
     def capture(self):
         """Record enqueue() into a HIP graph (torch.cuda.CUDAGraph) after one eager warm-up call; run()
         then replays it. The graph holds the parameters' CURRENT storage pointers: in-place updates are
-        picked up by the fingerprint check inside the graph, a replaced `.data` needs a new capture."""
+        picked up by the fingerprint check inside the graph, a replaced `.data` needs a new capture.
+        With guard_every > 1 (or frozen modules) a second graph without the check is recorded as well."""
         for k, t in self.src.items():        # a batch handed over in place moves into the static buffers:
             if t is not None and self.inp.get(k) is not None and t is not self.inp[k]:
                 self.inp[k].copy_(t)         # the graph reads those
         self.src = dict(self.inp)
         # warm-up on the stream the capture will use: kernel attributes are set, the packed weight
-        # streams of that stream exist (and are valid), nothing is allocated during the capture
+        # streams exist (and are valid), nothing is allocated during the capture
         st = torch.cuda.Stream(self.dev)
         st.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(st):
-            self.enqueue()
+            self.enqueue(True)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
-            self.enqueue()
+            self.enqueue(True)
         self.graph = g
+        self.graph_trusted = None
+        if self.guard_every > 1 or all(m is None or m in _lib.FROZEN for m in self.mods):
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=st):
+                self.enqueue(False)
+            self.graph_trusted = g2
+        self._frames_since_guard = None
         return self
 
     def run(self, batch=None, full_rgb_feat=None, pred_mask=None, valid_idx=None):
@@ -472,10 +500,12 @@ class FrameRunner:
                                       "offset_dec_refine"), self.mods)))
         if batch is not None:
             self.load(batch, full_rgb_feat, pred_mask, valid_idx=valid_idx)
+        guard = self._guard_due()
         if self.graph is not None:
-            self.graph.replay()
+            (self.graph if guard or self.graph_trusted is None else self.graph_trusted).replay()
         else:
-            self.enqueue()
+            self.enqueue(guard)
+        self._frames_since_guard = 1 if guard else self._frames_since_guard + 1
         return self
 
     # -- outputs ------------------------------------------------------------------------------------
@@ -573,6 +603,13 @@ class FramePipeline:
         self.n += 1
         lane = self.lanes[slot]
         lane.wait_stream(torch.cuda.current_stream(self.dev))
+        # the lane reads the caller's tensors (copies into the runner's static buffers, the library call when
+        # they are handed over in place, the metrics kernel): tell the caching allocator, or a tensor the
+        # caller drops on its next loop iteration could be handed out again on the caller's stream while the
+        # lane's reads are still queued
+        for t in list(batch.values()) + [full_rgb_feat, pred_mask, valid_idx]:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(lane)
         with torch.cuda.stream(lane), torch.no_grad():
             self.runners[slot].run(batch, full_rgb_feat, pred_mask, valid_idx=valid_idx)
             m = self.runners[slot].metrics(batch) if self.with_metrics else None

@@ -515,7 +515,27 @@ typedef struct LidfFrameArgs {
     const int32_t* valid_idx_bid;
     const int32_t* valid_idx_flat;
     int64_t n_valid_idx;
+    /* weight streams of ALL modules of the frame kept and validated by the call itself (ABI 7).
+     * pack_mode LIDF_FRAME_PACK_CALLER (0): the caller's blobs above (pnet->packed, packed_query,
+     *   pnet_refine->packed, packed_refine), each validated by its own lidf_*_pack_guarded_f32 call
+     *   (4 fingerprint + 6 pack launches per frame);
+     * LIDF_FRAME_PACK_GUARDED (1): pack_blob (lidf_frame_pack_bytes() bytes, owned by the caller, only
+     *   ever touched by launches of ONE stream) holds the streams of every module, pack_guard
+     *   (lidf_frame_pack_guard_bytes() bytes, zero-filled once) their fingerprints: ONE fingerprint
+     *   launch over all parameter buffers + two early-exit pack launches per frame; the caller's blob
+     *   pointers above are not read;
+     * LIDF_FRAME_PACK_TRUSTED (2): pack_blob as the last GUARDED call left it, no check (parameters known
+     *   not to have changed since: eval loops re-validate every so many frames).                        */
+    void* pack_blob;
+    size_t pack_blob_bytes;
+    void* pack_guard;
+    int32_t pack_mode;
 } LidfFrameArgs;
+#define LIDF_FRAME_PACK_CALLER 0
+#define LIDF_FRAME_PACK_GUARDED 1
+#define LIDF_FRAME_PACK_TRUSTED 2
+size_t lidf_frame_pack_bytes(void);
+size_t lidf_frame_pack_guard_bytes(void);
 size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, const int32_t* res,
                                   int64_t max_pairs, int32_t lds_voxels, int32_t refine_times);
 int lidf_frame_f32(const LidfFrameArgs* args, lidf_stream_t stream);

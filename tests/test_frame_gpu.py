@@ -210,8 +210,95 @@ def test_frames_pipelined_over_streams(cuda):
     for g, r in zip(got, ref):
         for k in keys:
             assert torch.equal(g[k], r[k]), k
-    # one packed-weight entry per stream and module, none shared
-    assert len(_lib.packed_entries(_lib.PACK_CACHE, models[1])) >= S + 1
+    # every runner owns its packed weight streams and their fingerprints: nothing shared between streams,
+    # nothing left in the per-module caches (a captured graph must not reference memory another call frees)
+    blobs = {r.pack_blob.data_ptr() for r in runners + [single]} | {r.pack_guard.data_ptr() for r in runners}
+    assert len(blobs) == 2 * S + 1
+    assert all(m not in _lib.PACK_CACHE and m not in _lib.PACK_CACHE_REFINE for m in models)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_frame_weight_streams_follow_parameter_updates(cuda, graph):
+    """The runner's own packed streams (one fingerprint launch over every module per frame): in-place
+    updates, `p.data` writes the version counter misses, load_state_dict — picked up by the next frame,
+    eager and through a captured graph; guard_every > 1 trusts the blob between checks until the N-th
+    frame or invalidate(); an unchanged frame re-packs nothing (the guards' verdicts read back)."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 48, 64
+    models = _models(cuda)
+    opt = pl.LidfOptions()
+    batch, feat = synthetic_batch(B, h, w, seed=77)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    keys = ("pred_offset", "pred_prob_end", "occ_voxel_feat", "pred_pos_refine")
+
+    def frame(r):
+        with torch.no_grad():
+            r.run(batch, feat)
+        ok, dd = r.result()
+        assert ok
+        return {k: dd[k].clone() for k in keys}
+
+    def fresh():
+        ok, ref = _stepwise(batch, feat, models, opt)
+        assert ok
+        return {k: ref[k].clone() for k in keys}
+
+    def dirty(r):   # verdicts of the four guards (query, pnet, pnet_refine, off_refine): int32 at byte 20
+        return r.pack_guard.view(torch.int32).reshape(4, 16)[:, 5].tolist()
+
+    runner = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    if graph:
+        with torch.no_grad():
+            runner.load(batch, feat)
+            runner.capture()
+    a = frame(runner)
+    ref = fresh()
+    assert all(torch.equal(a[k], ref[k]) for k in keys)
+    a2 = frame(runner)
+    assert dirty(runner) == [0, 0, 0, 0] and all(torch.equal(a[k], a2[k]) for k in keys)   # nothing re-packed
+    # every way a parameter can change, one module at a time
+    edits = [
+        (0, lambda: models[1].linear_2.weight.data.mul_(1.25)),                  # prob_dec, version untouched
+        (0, lambda: models[2].offset_enc.bias.data.add_(0.01)),                  # offset_dec
+        (1, lambda: models[0].point_lin3.weight.mul_(0.9)),                      # PointNet, in place
+        (2, lambda: models[3].load_state_dict({k: v * 1.1 for k, v in models[3].state_dict().items()})),
+        (3, lambda: models[4].linear_1.weight.data.copy_(models[4].linear_1.weight.data * 0.95)),
+    ]
+    for grp, edit in edits:
+        with torch.no_grad():
+            edit()
+        b = frame(runner)
+        d = dirty(runner)
+        assert d[grp] == 1 and sum(d) == 1, (grp, d)
+        ref = fresh()
+        assert all(torch.equal(b[k], ref[k]) for k in keys), grp
+        assert not all(torch.equal(b[k], a[k]) for k in keys)
+        a = b
+    # guard_every = 3: frames 2 and 3 after a check trust the blob, the 4th validates again
+    lazy = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], guard_every=3)
+    if graph:
+        with torch.no_grad():
+            lazy.load(batch, feat)
+            lazy.capture()
+        assert lazy.graph_trusted is not None
+    c0 = frame(lazy)
+    assert all(torch.equal(c0[k], a[k]) for k in keys)
+    with torch.no_grad():
+        models[1].linear_3.bias.data.add_(0.05)
+    c1 = frame(lazy)                                   # trusted: still the old weights
+    assert all(torch.equal(c1[k], c0[k]) for k in keys)
+    lazy.invalidate()
+    c2 = frame(lazy)
+    ref = fresh()
+    assert all(torch.equal(c2[k], ref[k]) for k in keys) and not torch.equal(c2["pred_prob_end"], c1["pred_prob_end"])
+    with torch.no_grad():
+        models[1].linear_3.bias.data.sub_(0.02)
+    seen = [frame(lazy) for _ in range(3)]             # frames 2, 3 trusted; frame 4 validates
+    assert torch.equal(seen[0]["pred_prob_end"], c2["pred_prob_end"])
+    assert torch.equal(seen[1]["pred_prob_end"], c2["pred_prob_end"])
+    ref = fresh()
+    assert all(torch.equal(seen[2][k], ref[k]) for k in keys)
 
 
 @pytest.mark.parametrize("seed", range(10))
