@@ -195,7 +195,8 @@ SIGNATURES = {
     "lidf_frame_f32": (C.c_int, [C.POINTER(LidfFrameArgs), _P]),
     "lidf_frame_pack_bytes": (_SZ, []),
     "lidf_frame_pack_guard_bytes": (_SZ, []),
-    "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "lidf_depth_metrics_workspace_bytes": (_SZ, []),
+    "lidf_depth_metrics_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "lidf_build_rows_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I64, _P, _P]),
     "lidf_rows_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P]),
     "lidf_ray_features_backward_f32": (C.c_int, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P]),

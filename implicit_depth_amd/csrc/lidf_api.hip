@@ -142,8 +142,9 @@ hipError_t lidf_launch_segmax_backward(const float*, const int*, const int*, con
                                        int, float*, hipStream_t);
 hipError_t lidf_launch_seg_sum_rows(const float*, const int*, long long, int, float*, hipStream_t);
 hipError_t lidf_launch_embed_backward(const float*, const float*, long long, int, float*, hipStream_t);
-hipError_t lidf_launch_depth_metrics(const float*, const float*, const unsigned char*, int, int, int,
-                                     int, float*, hipStream_t);
+hipError_t lidf_launch_depth_metrics(const float*, const float*, const void*, int, int, int, int, int,
+                                     float*, void*, hipStream_t);
+size_t lidf_depth_metrics_ws_bytes(void);
 hipError_t lidf_launch_vox_mark(const float*, const int*, long long, const GridSpec&, int*, int*,
                                 int*, hipStream_t);
 hipError_t lidf_launch_vox_cells(const int*, const int*, long long, const GridSpec&, int*, float*,
@@ -1872,15 +1873,19 @@ LIDF_API int lidf_voxelize_f32(const float* xyz, const int32_t* bid, int64_t n, 
 }
 
 // ---- eval depth metrics ---------------------------------------------------------------------------
+LIDF_API size_t lidf_depth_metrics_workspace_bytes(void) { return lidf_depth_metrics_ws_bytes(); }
+
 LIDF_API int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth,
-                                      const uint8_t* seg_mask, int32_t src_h, int32_t src_w,
-                                      int32_t dst_h, int32_t dst_w, float* out,
-                                      lidf_stream_t stream) {
+                                      const void* seg_mask, int32_t seg_dtype, int32_t src_h, int32_t src_w,
+                                      int32_t dst_h, int32_t dst_w, float* out, void* workspace,
+                                      size_t workspace_bytes, lidf_stream_t stream) {
     if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return LIDF_ERR_BAD_ARG;
     if (!pred_depth || !gt_depth || !out) return LIDF_ERR_BAD_ARG;
+    if (seg_dtype < 0 || seg_dtype > 2 || (seg_dtype != 0 && !seg_mask)) return LIDF_ERR_BAD_ARG;
     if ((int64_t)dst_h * dst_w > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
-    CHECK_HIP(lidf_launch_depth_metrics(pred_depth, gt_depth, seg_mask, src_h, src_w, dst_h, dst_w,
-                                        out, (hipStream_t)stream));
+    if (!workspace || workspace_bytes < lidf_depth_metrics_ws_bytes()) return LIDF_ERR_WORKSPACE;
+    CHECK_HIP(lidf_launch_depth_metrics(pred_depth, gt_depth, seg_mask, seg_mask ? seg_dtype : 0, src_h, src_w,
+                                        dst_h, dst_w, out, workspace, (hipStream_t)stream));
     return LIDF_OK;
 }
 

@@ -1392,24 +1392,42 @@ extern "C" hipError_t lidf_launch_vox_points(const float* xyz, const int* pt_key
 // pixels; sums are carried in double.
 // ------------------------------------------------------------------------------------------------
 #define METRIC_SUMS 10
+#define METRIC_MAX_WGS 64
+// workspace (lidf_depth_metrics_workspace_bytes(), zero-filled ONCE by the caller; a call leaves it as it
+// found it): [0] ticket, then METRIC_MAX_WGS x METRIC_SUMS doubles of per-workgroup partial sums.
+// seg_dtype: 0 no mask, 1 uint8 / bool, 2 float32 (the reference's corrupt_mask: `astype(np.uint8)`,
+// pipeline.py:588 — a C cast, truncation toward zero, modulo 256).
+__device__ __forceinline__ bool metric_mask(const void* seg, int dtype, size_t i) {
+    if (dtype == 1) return ((const unsigned char*)seg)[i] != 0;
+    if (dtype == 2) {
+        const float m = ((const float*)seg)[i];
+        return m == m && (((long long)m) & 255) != 0;
+    }
+    return true;
+}
+// The 144 x 256 statistics image is 36,864 pixels of f64 arithmetic: one workgroup (rounds 2-3) took
+// 36 us; here every workgroup of 1024 threads sums its share in the strided order of the one-workgroup
+// kernel, leaves ten partial sums, and the workgroup that arrives last adds the partials in workgroup
+// order (a fixed order: run-to-run identical) and forms the statistics.
 __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
-    const float* __restrict__ pred, const float* __restrict__ gt, const unsigned char* __restrict__ seg,
-    int src_h, int src_w, int dst_h, int dst_w, float* __restrict__ out) {
+    const float* __restrict__ pred, const float* __restrict__ gt, const void* __restrict__ seg, int seg_dtype,
+    int src_h, int src_w, int dst_h, int dst_w, float* __restrict__ out, unsigned* __restrict__ ticket,
+    unsigned long long* __restrict__ partial) {
     __shared__ double red[METRIC_SUMS][16];
+    __shared__ bool s_last;
     double acc[METRIC_SUMS];
 #pragma unroll
     for (int i = 0; i < METRIC_SUMS; ++i) acc[i] = 0.0;
     const double ifx = 1.0 / ((double)dst_w / (double)src_w);
     const double ify = 1.0 / ((double)dst_h / (double)src_h);
     const int n = dst_h * dst_w;
-    // four pixels per thread in flight (the loads of a batch are requested together; the sums keep the
-    // order i, i + blockDim, i + 2 blockDim, ... of a plain strided loop)
-    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
         float gv[4], pv[4];
         bool mv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * (int)blockDim.x;
+            const int i = i0 + k * stride;
             gv[k] = 0.f;
             pv[k] = 1.f;
             mv[k] = false;
@@ -1421,7 +1439,7 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
                 const size_t si = (size_t)sy * src_w + sx;
                 gv[k] = gt[si];
                 pv[k] = pred[si];
-                mv[k] = !seg || seg[si] != 0;
+                mv[k] = metric_mask(seg, seg_dtype, si);
             }
         }
 #pragma unroll
@@ -1454,12 +1472,29 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
         if (lane == 0) red[i][wave] = v;
     }
     __syncthreads();
+    if (threadIdx.x < METRIC_SUMS) {
+        double sum = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[threadIdx.x][w];
+        __hip_atomic_store(partial + (size_t)blockIdx.x * METRIC_SUMS + threadIdx.x, __double_as_longlong(sum),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < METRIC_SUMS) {
+        double sum = 0.0;
+        for (unsigned g = 0; g < gridDim.x; ++g)
+            sum += __longlong_as_double((long long)__hip_atomic_load(partial + (size_t)g * METRIC_SUMS + threadIdx.x,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        red[threadIdx.x][0] = sum;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double s[METRIC_SUMS];
-        for (int i = 0; i < METRIC_SUMS; ++i) {
-            s[i] = 0.0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s[i] += red[i][w];
-        }
+        for (int i = 0; i < METRIC_SUMS; ++i) s[i] = red[i][0];
         const double c = s[9];  // 0 valid pixels: torch's mean of an empty tensor is NaN, so is 0/0
         out[0] = (float)(s[0] / c);
         out[1] = (float)(s[1] / c);
@@ -1471,14 +1506,19 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
         out[7] = (float)(s[7] / c);
         out[8] = (float)(s[8] / c);
         out[9] = (float)c;
+        *ticket = 0;   // the workspace is left as it was found
     }
 }
 
-extern "C" hipError_t lidf_launch_depth_metrics(const float* pred, const float* gt,
-                                                const unsigned char* seg, int src_h, int src_w,
-                                                int dst_h, int dst_w, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(lidf_depth_metrics_kernel, dim3(1), dim3(1024), 0, st, pred, gt, seg, src_h,
-                       src_w, dst_h, dst_w, out);
+extern "C" size_t lidf_depth_metrics_ws_bytes(void) { return 64 + (size_t)METRIC_MAX_WGS * METRIC_SUMS * 8; }
+extern "C" hipError_t lidf_launch_depth_metrics(const float* pred, const float* gt, const void* seg,
+                                                int seg_dtype, int src_h, int src_w, int dst_h, int dst_w,
+                                                float* out, void* ws, hipStream_t st) {
+    long long g = ((long long)dst_h * dst_w + 1023) / 1024;
+    if (g > METRIC_MAX_WGS) g = METRIC_MAX_WGS;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(lidf_depth_metrics_kernel, dim3((unsigned)g), dim3(1024), 0, st, pred, gt, seg, seg_dtype,
+                       src_h, src_w, dst_h, dst_w, out, (unsigned*)ws, (unsigned long long*)((char*)ws + 64));
     return hipGetLastError();
 }
 

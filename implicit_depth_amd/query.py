@@ -618,6 +618,9 @@ def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=
 METRIC_NAMES = ("a1", "a2", "a3", "rmse", "rmse_log", "log10", "abs_rel", "mae", "sq_rel")
 
 
+_METRICS_WS = {}   # (device index, stream) -> zeroed workspace of lidf_depth_metrics_f32
+
+
 def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
     """The evaluation statistics of LIDF.compute_loss (models/pipeline.py:577-627, the bs == 1
     branch) on the device: cv2.resize(..., (256, 144), INTER_NEAREST) of the predicted depth, the
@@ -630,17 +633,36 @@ def depth_metrics(pred_depth, gt_depth, seg_mask=None, out_size=(144, 256)):
     if pred_depth.dim() != 2 or pred_depth.shape != gt_depth.shape:
         raise RuntimeError("pred_depth and gt_depth must be [h,w] tensors of the same shape")
     h, w = pred_depth.shape
+    seg_dtype = 0
     if seg_mask is not None:
         if seg_mask.shape != pred_depth.shape:
             raise RuntimeError("seg_mask must have the shape of the depth maps")
-        seg_mask = seg_mask.to(torch.uint8).contiguous()
+        # the reference's float corrupt_mask is read as it lies (cast per pixel as its astype(np.uint8),
+        # models/pipeline.py:588); bool / uint8 masks byte-wise; other integer types are converted
+        if seg_mask.dtype == torch.float32:
+            seg_dtype = 2
+        elif seg_mask.dtype in (torch.bool, torch.uint8):
+            seg_dtype = 1
+            if seg_mask.dtype == torch.bool:
+                seg_mask = seg_mask.view(torch.uint8)
+        else:
+            seg_mask, seg_dtype = seg_mask.to(torch.uint8), 1
+        seg_mask = seg_mask.contiguous()
         _lib.require_cuda(seg_mask, names=["seg_mask"])
     dh, dw = (h, w) if out_size is None else out_size
-    out = torch.empty((10,), dtype=torch.float32, device=pred_depth.device)
-    with torch.cuda.device(pred_depth.device):
-        _lib.check(_lib.lib().lidf_depth_metrics_f32(
+    dev = pred_depth.device
+    out = torch.empty((10,), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    # partial sums + arrival ticket of the statistics kernel: zero-filled once per (device, stream); every
+    # call leaves the buffer as it found it
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _METRICS_WS.get(key)
+    if ws is None:
+        ws = _METRICS_WS[key] = torch.zeros((L.lidf_depth_metrics_workspace_bytes(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.lidf_depth_metrics_f32(
             _lib.ptr(pred_depth), _lib.ptr(gt_depth), _lib.ptr(seg_mask) if seg_mask is not None else None,
-            h, w, dh, dw, _lib.ptr(out), _lib.current_stream(pred_depth.device)))
+            seg_dtype, h, w, dh, dw, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)))
     res = {k: out[i] for i, k in enumerate(METRIC_NAMES)}
     res["count"] = out[9]
     return res

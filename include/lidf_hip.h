@@ -584,16 +584,22 @@ int lidf_roi_align_f32(const float* feat_grid, int32_t batch, int32_t channels, 
 /* ---- Eval depth metrics ----------------------------------------------------------------------
  * Replaces the bs == 1 evaluation branch of LIDF.compute_loss (models/pipeline.py:577-627): the
  * predicted depth map, the ground-truth depth map and the segmentation mask ([src_h, src_w],
- * device; seg_mask uint8 or NULL = all ones) are resized to dst_h x dst_w (144 x 256 in the
+ * device; seg_dtype 0 = no mask, 1 = uint8 / bool, 2 = float32 — the reference's corrupt_mask, cast
+ * as its `astype(np.uint8)` casts it, :588) are resized to dst_h x dst_w (144 x 256 in the
  * reference) with cv2.resize's INTER_NEAREST rule, non-finite ground truth counts as 0, valid =
  * gt > 0 and mask != 0, and out (device float[10]) receives
  *   a1, a2, a3 (thresholds 1.05, 1.10, 1.25), rmse, rmse_log, log10 (natural log, as the
  *   reference computes it), abs_rel, mae, sq_rel, number of valid pixels
  * — no .cpu() round trip. dst == src gives the plain masked statistics. 0 valid pixels: NaN, as
- * torch's mean of an empty tensor.                                                              */
-int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const uint8_t* seg_mask,
-                           int32_t src_h, int32_t src_w, int32_t dst_h, int32_t dst_w, float* out,
-                           lidf_stream_t stream);
+ * torch's mean of an empty tensor.
+ * workspace: lidf_depth_metrics_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller; a call leaves
+ * it as it found it, so one buffer serves every later call of the same stream (the statistics image is
+ * summed by several workgroups, the one that arrives last adds their partial sums in a fixed order:
+ * run-to-run identical). (ABI 7)                                                                 */
+size_t lidf_depth_metrics_workspace_bytes(void);
+int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const void* seg_mask,
+                           int32_t seg_dtype, int32_t src_h, int32_t src_w, int32_t dst_h, int32_t dst_w,
+                           float* out, void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Decoders, training path (first step) -------------------------------------
  * What autograd does for models/implicit_net.py IMNet / IEF on [n, d] rows: a forward that keeps
