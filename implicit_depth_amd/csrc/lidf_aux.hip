@@ -832,8 +832,6 @@ __global__ void __launch_bounds__(256) lidf_ray_aabb_onepass_kernel(
     const int* __restrict__ vox_bid, int* __restrict__ counts, int* __restrict__ ticket,
     unsigned long long* __restrict__ status, int* __restrict__ pair_off, int* __restrict__ pair_ray,
     int* __restrict__ pair_vox, float* __restrict__ pair_t, long long pair_cap) {
-    __shared__ float s_vb[256 * 6];
-    __shared__ int s_vbid[256];
     __shared__ int s_hit[AABB_HITS * 256];
     __shared__ int s_tmp[4];
     __shared__ int s_bid;
@@ -854,18 +852,32 @@ __global__ void __launch_bounds__(256) lidf_ray_aabb_onepass_kernel(
     }
     const RayInv inv = ray_inv(dx, dy, dz);
     int n = 0;
-    for (long long v0 = 0; v0 < V; v0 += 256) {
-        const int nv = (int)min((long long)256, V - v0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nv * 6; i += blockDim.x) s_vb[i] = vbound[6 * v0 + i];
-        for (int i = threadIdx.x; i < nv; i += blockDim.x) s_vbid[i] = vox_bid[v0 + i];
-        __syncthreads();
-        if (!live) continue;
-        for (int j = 0; j < nv; ++j) {
-            if (s_vbid[j] != rb) continue;
-            float t0, t1;
-            if (!slab_test(inv, s_vb + 6 * j, t0, t1)) continue;
-            if (n < AABB_HITS) s_hit[n * 256 + threadIdx.x] = (int)(v0 + j);
+    // the voxel index is wave-uniform: the bounds arrive through the scalar cache as SGPR operands (eight
+    // voxels per batch of scalar loads), no LDS staging, no barrier in the loop; the hit decision is
+    // slab_test's, comparison by comparison
+    // (read through the constant address space: the tables are not written by this launch, and the
+    // ticket atomic above would otherwise keep the compiler from scalarising the loads)
+    typedef const float __attribute__((address_space(4))) * cf_ptr;
+    typedef const int __attribute__((address_space(4))) * ci_ptr;
+    const cf_ptr vbc = (cf_ptr)(unsigned long long)vbound;
+    const ci_ptr vbidc = (ci_ptr)(unsigned long long)vox_bid;
+    const int Vi = (int)V;
+#pragma unroll 8
+    for (int j = 0; j < Vi; ++j) {
+        const cf_ptr vb = vbc + 6 * (size_t)j;
+        // ((c ? lo : hi) * i written as c ? lo * i : hi * i — the same product, and the six bounds stay
+        // wave-uniform scalar loads instead of one load through a per-lane selected address)
+        const float lx = vb[0] * inv.ix, hx = vb[3] * inv.ix, ly = vb[1] * inv.iy, hy = vb[4] * inv.iy;
+        const float lz = vb[2] * inv.iz, hz = vb[5] * inv.iz;
+        const float tx0 = inv.ix >= 0 ? lx : hx, tx1 = inv.ix >= 0 ? hx : lx;
+        const float ty0 = inv.iy >= 0 ? ly : hy, ty1 = inv.iy >= 0 ? hy : ly;
+        const float tz0 = inv.iz >= 0 ? lz : hz, tz1 = inv.iz >= 0 ? hz : lz;
+        const bool missxy = (tx0 > ty1) | (tx1 < ty0);
+        const float a0 = fmaxf(tx0, ty0), a1 = fminf(tx1, ty1);
+        const bool missz = (a0 > tz1) | (a1 < tz0);
+        const bool hit = live & (vbidc[j] == rb) & !missxy & !missz;
+        if (hit) {
+            if (n < AABB_HITS) s_hit[n * 256 + threadIdx.x] = j;
             ++n;
         }
     }
@@ -1484,11 +1496,16 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    // (every partial is requested by a thread of its own — one memory round trip —, then added in
+    // workgroup order)
+    __shared__ double s_part[METRIC_MAX_WGS * METRIC_SUMS];
+    if (threadIdx.x < gridDim.x * METRIC_SUMS)
+        s_part[threadIdx.x] = __longlong_as_double((long long)__hip_atomic_load(
+            partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
     if (threadIdx.x < METRIC_SUMS) {
         double sum = 0.0;
-        for (unsigned g = 0; g < gridDim.x; ++g)
-            sum += __longlong_as_double((long long)__hip_atomic_load(partial + (size_t)g * METRIC_SUMS + threadIdx.x,
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (unsigned g = 0; g < gridDim.x; ++g) sum += s_part[g * METRIC_SUMS + threadIdx.x];
         red[threadIdx.x][0] = sum;
     }
     __syncthreads();

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
         }
         const int v = carry + wpre + inc - f;
         if (k < ncell) {
-            cell_rank[k] = v;
+            cell_rank[k] = f ? v : -1;   // cell -> voxel table (-1: not occupied)
             if (f) {
                 int rem = (int)k;
                 const int cz = rem % g.r[2]; rem /= g.r[2];

@@ -193,11 +193,11 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
     if (LDSPOOL && a.V_dev) windowed = windowed && *a.V_dev > a.v_tab;   // device-side choice of the walk
     const bool use_perm = a.perm && (!LDSPOOL || windowed);
     const long long AN = use_perm ? (long long)*a.n_perm : (a.n_dev ? (long long)*a.n_dev : a.n);
-    const int tab_rows = windowed ? a.window : a.v_tab;
-    if (LDSPOOL) {
-        for (int i = threadIdx.x; i < tab_rows * F; i += 256) pn_tab[i] = 0;
-        __syncthreads();
-    }
+    // rows of the workgroup's table in play: the window, or one row per voxel up to the table's capacity
+    // (a frame has 50-150 occupied voxels: zeroing and flushing all 288 rows the launch reserves LDS for
+    // was a third of the stage-1 chain's time)
+    const int v_now = a.V_dev ? *a.V_dev : a.V;
+    const int tab_rows = windowed ? a.window : (v_now < a.v_tab ? v_now : a.v_tab);
     constexpr int NQ = STAGE == 1 ? PN_S1_QUADS : PN_S2_QUADS;
     // global-atomic path: the workgroup's copy of the table (thousands of wavefronts raising the
     // same few rows serialise on their addresses; `copies` tables divide that, a reduce follows)
@@ -218,33 +218,46 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
     const long long te = tb + per + (bx < rem ? 1 : 0);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    if (tb >= te || tb * 128 >= AN) return;   // (workgroup-uniform: nothing to pool, nothing to flush)
+    if (LDSPOOL) {
+        for (int i = threadIdx.x; i < tab_rows * F; i += 256) pn_tab[i] = 0;
+        __syncthreads();
+    }
     f32x4 ring[LIDF_RING];
 #pragma unroll
     for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
     // windowed table: rows [vbase, vbase + window) of the voxel table (sorted points: ascending voxels)
     int vbase = 0;
-    if (windowed && tb < te && tb * 128 < AN) vbase = a.vox[a.perm[tb * 128]];
+    if (windowed) vbase = a.vox[a.perm[tb * 128]];
+
+    // a tile's point index, voxel and operand columns (4h + {0..3} of [x0..x5, 1, 0]) are requested while
+    // the tile before it runs: the chain of a tile is ~1 us of matrix instructions in stage 1, and the
+    // dependent index -> voxel / input round trips at its head were most of a tile's time
+    auto fetch = [&](long long tile, int& vox_o, float (&b)[4]) {
+        const long long p = tile * 128 + wave * 32 + col;
+        long long pc = p < AN ? p : AN - 1;
+        if (use_perm) pc = a.perm[pc];   // voxel-sorted walk
+        vox_o = a.vox[pc];
+        const float* x = a.inp + (size_t)pc * 6;
+        if (h == 0) {
+            b[0] = x[0]; b[1] = x[1]; b[2] = x[2]; b[3] = x[3];
+        } else {
+            b[0] = x[4]; b[1] = x[5]; b[2] = 1.f; b[3] = 0.f;
+        }
+    };
+    int vox_n = 0;
+    float b1n[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tb * 128 + wave * 32 < AN) fetch(tb, vox_n, b1n);
 
     for (long long tile = tb; tile < te; ++tile) {
         if (tile * 128 + wave * 32 >= AN) break;   // wave-uniform
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < AN;
-        long long pc = valid ? p : AN - 1;
-        if (use_perm) pc = a.perm[pc];   // voxel-sorted walk
-        const int vox = a.vox[pc];
+        const int vox = vox_n;
+        const float b1[4] = {b1n[0], b1n[1], b1n[2], b1n[3]};
         // row of the LDS table; a point beyond the table goes to the global table (vrow = -1)
         const int vrow = (vox >= vbase && vox - vbase < tab_rows) ? vox - vbase : -1;
         const bool spill = LDSPOOL && valid && vox >= 0 && vrow < 0;
-        // operand columns of this lane: 4h + {0..3} of [x0..x5, 1, 0]
-        float b1[4];
-        {
-            const float* x = a.inp + (size_t)pc * 6;
-            if (h == 0) {
-                b1[0] = x[0]; b1[1] = x[1]; b1[2] = x[2]; b1[3] = x[3];
-            } else {
-                b1[0] = x[4]; b1[1] = x[5]; b1[2] = 1.f; b1[3] = 0.f;
-            }
-        }
         // stage 2: the gathered per-voxel row the layer-3 accumulators start from
         f32x16 F4[STAGE == 2 ? 4 : 1];
         if (STAGE == 2) {
@@ -259,6 +272,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
                 }
             }
         }
+        if (tile + 1 < te && (tile + 1) * 128 + wave * 32 < AN) fetch(tile + 1, vox_n, b1n);
         SCHED_FENCE();
 
         f32x16 F1, F2[2], acc;

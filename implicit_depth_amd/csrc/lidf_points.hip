@@ -1102,31 +1102,172 @@ __device__ __forceinline__ void l1part_item(const PointsArgs& a, const long long
     }
 }
 
+// The same item with the operand rows of its tile already in registers (round 4): the 2 * nets parts of a
+// tile are adjacent in the flat list, so a workgroup's contiguous run of items re-used the same 32 rows
+// per wavefront up to six times — fetched again for every part (from L2, behind a dependent address
+// chain at the head of each item). Here lane (col, h) keeps its 4 columns of every k-quad (<= L1X_KQ
+// k-quads: 80 registers at D = 155) across the items of a tile; weight quads run two k-quads ahead.
+// Same products in the same order as l1part_item: bit-identical rows.
+#define L1X_KQ 20
+__device__ __forceinline__ void l1part_load_x(const PointsArgs& a, const long long AN, const long long tile,
+                                              f32x4 (&xr)[L1X_KQ]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    if (tile * 128 + wave * 32 >= AN) return;
+    const long long p = tile * 128 + wave * 32 + col;
+    const long long pc = p < AN ? p : AN - 1;
+    const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+#pragma unroll
+    for (int kq = 0; kq < L1X_KQ; ++kq) {
+        xr[kq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int x0 = 8 * kq + 4 * h;
+        if (kq < a.KQ1) {
+            if (x0 + 3 < a.D) {
+                const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+                xr[kq] = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    xr[kq][jj] = x0 + jj < a.D ? xrow[8 * kq + jj] : ((x0 + jj == a.D && a.has_bias) ? 1.f : 0.f);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void l1part_item_x(const PointsArgs& a, const long long AN, const long long tile,
+                                              const int net, const int hf, const f32x4 (&xr)[L1X_KQ],
+                                              float* s_stage) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
+    const int col = lane & 31;
+    const int net_bytes = a.net_quads * 1024;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.stream, 0, a.nets * net_bytes, 0x00020000);
+    const int vq = lane * 16;
+    const int sbase = net * net_bytes + 4 * hf * 1024;
+    float* stage = s_stage + wave * (32 * 33);
+    if (tile * 128 + wave * 32 >= AN) return;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    }
+    // weight quads two k-quads ahead (reads beyond the net's section are never multiplied)
+    f32x4 q[3][4];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[d][t] = LDQ(srs, vq, sbase + (d * 8 + t) * 1024);
+    }
+#pragma unroll
+    for (int kq = 0; kq < L1X_KQ; ++kq) {
+        if (kq < a.KQ1) {
+            if (kq + 2 < a.KQ1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) q[(kq + 2) % 3][t] = LDQ(srs, vq, sbase + ((kq + 2) * 8 + t) * 1024);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x16 c = acc[t];
+                c = MFMA(q[kq % 3][t][0], xr[kq][0], c);
+                c = MFMA(q[kq % 3][t][1], xr[kq][1], c);
+                c = MFMA(q[kq % 3][t][2], xr[kq][2], c);
+                c = MFMA(q[kq % 3][t][3], xr[kq][3], c);
+                acc[t] = c;
+            }
+            SCHED_FENCE();
+        }
+    }
+    // register 4g+i of lane (col, h) in tile t = output 32(4hf+t) + 8g + 4h + i of row `col`
+    float* ob = a.out_base + ((size_t)(tile * 128 + wave * 32) * a.nets + net) * 256 + 128 * hf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage[col * 33 + 8 * g + 4 * h + i] = acc[t][4 * g + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 8 * j + (lane >> 3), f4 = (lane & 7) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = stage[row * 33 + f4 + i];
+            if (tile * 128 + wave * 32 + row < AN)
+                *(f32x4*)(ob + (size_t)row * a.nets * 256 + 32 * t + f4) = o;
+        }
+    }
+}
+
 // Flat list of items (problem a, then b, then c; the 2*nets parts of a tile adjacent, so that the
-// operand rows of a tile are fetched from HBM once and found in L2 by the other parts), cut into
+// operand rows of a tile are loaded once per wavefront for the parts a workgroup's run holds), cut into
 // equal contiguous runs over the grid. c (optional, c.stream == NULL: none) is a third table with its
 // own stream — the frame path's per-ray part of the stage-2 decoder's layer 1, which reads the same
 // rayfeat rows as the query's raypart (a launch of its own over 76,800 rows before).
-__global__ void __launch_bounds__(256) lidf_l1part_pair_kernel(PointsArgs a, PointsArgs b, PointsArgs c) {
+struct L1Problems {
+    PointsArgs p[3];   // p[k].stream == NULL: absent
+};
+__device__ __forceinline__ long long l1_rows(const PointsArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }
+
+// (one instance of the item code: the problem is picked by a uniform index into the kernel argument)
+__global__ void __launch_bounds__(256, 2) lidf_l1part_pair_kernel(L1Problems P) {
     __shared__ float s_stage[4 * 32 * 33];
-    const int pa = a.nets * 2, pb = b.nets * 2, pc = c.stream ? c.nets * 2 : 0;
-    const long long an = a.n_dev ? (long long)*a.n_dev : a.n, bn = b.n_dev ? (long long)*b.n_dev : b.n;
-    const long long cn = pc ? (c.n_dev ? (long long)*c.n_dev : c.n) : 0;
-    const long long na = (an + 127) / 128 * pa, nb = (bn + 127) / 128 * pb, nc = (cn + 127) / 128 * pc;
-    const long long tot = na + nb + nc, per = tot / gridDim.x, rem = tot % gridDim.x;
+    long long n[3], cnt[3];
+    int parts[3];
+    long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        parts[k] = P.p[k].stream ? P.p[k].nets * 2 : 0;
+        n[k] = parts[k] ? l1_rows(P.p[k]) : 0;
+        cnt[k] = (n[k] + 127) / 128 * parts[k];
+        tot += cnt[k];
+    }
+    const long long per = tot / gridDim.x, rem = tot % gridDim.x;
+    const long long bx = blockIdx.x;
+    const long long ib = bx * per + (bx < rem ? bx : rem), ie = ib + per + (bx < rem ? 1 : 0);
+    f32x4 xr[L1X_KQ];
+    long long have = -1;   // (problem, tile) whose rows xr holds
+    for (long long i = ib; i < ie; ++i) {
+        const int k = i < cnt[0] ? 0 : (i < cnt[0] + cnt[1] ? 1 : 2);
+        const long long j = i - (k > 0 ? cnt[0] : 0) - (k > 1 ? cnt[1] : 0);
+        const int pk = k == 0 ? parts[0] : (k == 1 ? parts[1] : parts[2]);
+        const long long nk = k == 0 ? n[0] : (k == 1 ? n[1] : n[2]);
+        const long long tile = j / pk, key = ((long long)k << 40) + tile;
+        const int part = (int)(j % pk);
+        const PointsArgs& a = P.p[k];
+        if (key != have) {
+            l1part_load_x(a, nk, tile, xr);
+            have = key;
+        }
+        l1part_item_x(a, nk, tile, part >> 1, part & 1, xr, s_stage);
+    }
+}
+
+// wider embeddings (multires_views > 4: more than L1X_KQ k-quads per row): operand rows streamed per item
+__global__ void __launch_bounds__(256) lidf_l1part_pair_stream_kernel(L1Problems P) {
+    __shared__ float s_stage[4 * 32 * 33];
+    long long n[3], cnt[3];
+    int parts[3];
+    long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        parts[k] = P.p[k].stream ? P.p[k].nets * 2 : 0;
+        n[k] = parts[k] ? l1_rows(P.p[k]) : 0;
+        cnt[k] = (n[k] + 127) / 128 * parts[k];
+        tot += cnt[k];
+    }
+    const long long per = tot / gridDim.x, rem = tot % gridDim.x;
     const long long bx = blockIdx.x;
     const long long ib = bx * per + (bx < rem ? bx : rem), ie = ib + per + (bx < rem ? 1 : 0);
     for (long long i = ib; i < ie; ++i) {
-        if (i < na) {
-            const int part = (int)(i % pa);
-            l1part_item(a, an, i / pa, part >> 1, part & 1, s_stage);
-        } else if (i < na + nb) {
-            const int part = (int)((i - na) % pb);
-            l1part_item(b, bn, (i - na) / pb, part >> 1, part & 1, s_stage);
-        } else {
-            const int part = (int)((i - na - nb) % pc);
-            l1part_item(c, cn, (i - na - nb) / pc, part >> 1, part & 1, s_stage);
-        }
+        const int k = i < cnt[0] ? 0 : (i < cnt[0] + cnt[1] ? 1 : 2);
+        const long long j = i - (k > 0 ? cnt[0] : 0) - (k > 1 ? cnt[1] : 0);
+        const int pk = k == 0 ? parts[0] : (k == 1 ? parts[1] : parts[2]);
+        const long long nk = k == 0 ? n[0] : (k == 1 ? n[1] : n[2]);
+        const int part = (int)(j % pk);
+        l1part_item(P.p[k], nk, j / pk, part >> 1, part & 1, s_stage);
     }
 }
 
@@ -1138,14 +1279,24 @@ static hipError_t launch_points(const PointsArgs& a, int grid, hipStream_t st) {
 
 extern "C" hipError_t lidf_launch_l1only_pair(const PointsArgs& a, const PointsArgs& b, const PointsArgs* c,
                                                int cus, hipStream_t st) {
-    PointsArgs cc = {};
-    if (c) cc = *c;
-    const long long items = (a.n + 127) / 128 * a.nets * 2 + (b.n + 127) / 128 * b.nets * 2 +
-                            (cc.stream ? (cc.n + 127) / 128 * cc.nets * 2 : 0);
+    L1Problems P = {};
+    P.p[0] = a;
+    P.p[1] = b;
+    if (c) P.p[2] = *c;
+    long long items = 0;
+    bool fits = true;
+    for (int k = 0; k < 3; ++k) {
+        if (!P.p[k].stream) continue;
+        items += (P.p[k].n + 127) / 128 * P.p[k].nets * 2;
+        fits = fits && P.p[k].KQ1 <= L1X_KQ;
+    }
     if (items <= 0) return hipSuccess;
     // two workgroups per CU: 9600 wavefront items of a 240x320 frame leave 10 per SIMD at best
     const int grid = (int)(items < 2LL * cus ? items : 2LL * cus);
-    hipLaunchKernelGGL(lidf_l1part_pair_kernel, dim3(grid), dim3(256), 0, st, a, b, cc);
+    if (fits)
+        hipLaunchKernelGGL(lidf_l1part_pair_kernel, dim3(grid), dim3(256), 0, st, P);
+    else
+        hipLaunchKernelGGL(lidf_l1part_pair_stream_kernel, dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 

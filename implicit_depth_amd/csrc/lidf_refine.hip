@@ -156,11 +156,11 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
 // ------------------------------------------------------------------------------------------------
 // One refine iteration's per-ray work in ONE launch (the sync-free frame path, round 4; rounds 2-3:
 // zero -> end voxel -> PointNet rows -> embed(pos) rows, and the previous iteration's finish = 5
-// launches): a workgroup owns 64 rays.
+// launches): a workgroup owns 128 rays.
 //   phase 1 (one thread per ray): the position this iteration starts from — pred_pos of stage 1, or
 //     prev + (off * rs + r0) * dir of the previous iteration (pipeline.py:1028-1029; the expressions
 //     of lidf_refine_finish_kernel) —, the end voxel, the PointNet row (lidf_refine_prep_kernel);
-//   phase 2 (all threads): the 64 x E block embed(pos) of the decoder rows, written as row segments
+//   phase 2 (all threads): the 128 x E block embed(pos) of the decoder rows, written as row segments
 //     (lidf_refine_rows_kernel's expressions).
 // End voxel = the largest occupied voxel of the ray's image whose box contains the point (the
 // reference's pcl_aabb + scatter max, pipeline.py:939-944). The voxels are cells of the frame's grid:
@@ -172,8 +172,9 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
 // The workgroups also zero the PointNet's max-pool tables of this iteration (zero0 / zero1).
 // ------------------------------------------------------------------------------------------------
 
+#define STEP_RAYS 128   // rays per workgroup: phase 1 on threads 0..127, phase 2 on all 256
 __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a) {
-    __shared__ float s_q[64 * 3];
+    __shared__ float s_q[STEP_RAYS * 3];
     {   // this iteration's zero-initialised scratch
         const long long tot = a.nzero0 + a.nzero1;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
@@ -182,9 +183,9 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
         }
     }
     const long long R = a.dims[0], P = a.dims[1], V = a.dims[2];
-    const long long r0w = (long long)blockIdx.x * 64;
+    const long long r0w = (long long)blockIdx.x * STEP_RAYS;
     if (r0w >= R) return;
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < STEP_RAYS) {
         const long long r = r0w + threadIdx.x;
         if (r < R) {
             float x = a.prev_pos[3 * r], y = a.prev_pos[3 * r + 1], z = a.prev_pos[3 * r + 2];
@@ -199,31 +200,48 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
             }
             const int bid = a.ray_bid[r];
             const long long m = a.max_pair_id[r];
+            const int rflat = a.ray_flat[r];
             int ev = (m >= 0 && m < P) ? a.pair_vox[m] : 0;
+            const float* px = a.rgb + (size_t)bid * 3 * a.hw + rflat;
+            const float c0r = px[0], c1r = px[a.hw], c2r = px[2 * a.hw];
             const float pp[3] = {x, y, z};
             if (x != x || y != y || z != z) {
                 for (long long j = 0; j < V; ++j)
                     if (a.vox_bid[j] == bid && inside_box(x, y, z, a.vbound + 6 * j)) ev = max(ev, (int)j);
             } else {
-                int c0[3], c1[3];
+                // per axis: the estimated cell q and, for the cells q-1, q, q+1, the reference's inclusive
+                // test on the bounds of that cell — bound_min = xmin + c * crop, bound_max = bound_min + crop,
+                // the expressions (and so the bits) lidf_frame_cells_kernel stored in voxel_bound
+                int q[3];
+                bool in[3][3];
                 bool any = true;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float v = (pp[k] - a.g.xmin[k]) / a.g.crop;
-                    if (!(v > -2.f && v < (float)a.g.r[k] + 2.f)) { any = false; c0[k] = 0; c1[k] = -1; continue; }
-                    const int q = (int)floorf(v);
-                    c0[k] = max(q - 1, 0);
-                    c1[k] = min(q + 1, a.g.r[k] - 1);
+                    const bool near = v > -2.f && v < (float)a.g.r[k] + 2.f;
+                    any = any && near;
+                    q[k] = near ? (int)floorf(v) : 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int c = q[k] + d - 1;
+                        const float lo = a.g.xmin[k] + (float)c * a.g.crop;
+                        const float hi = lo + a.g.crop;
+                        in[k][d] = near && c >= 0 && c < a.g.r[k] && !(pp[k] < lo) && !(pp[k] > hi);
+                    }
                 }
                 if (any) {
-                    for (int cx = c0[0]; cx <= c1[0]; ++cx)
-                        for (int cy = c0[1]; cy <= c1[1]; ++cy)
-                            for (int cz = c0[2]; cz <= c1[2]; ++cz) {
-                                const int key = ((bid * a.g.r[0] + cx) * a.g.r[1] + cy) * a.g.r[2] + cz;
-                                if (!a.cell_flag[key]) continue;
-                                const int j = a.cell_rank[key];
-                                if (inside_box(x, y, z, a.vbound + 6 * (size_t)j)) ev = max(ev, j);
-                            }
+                    // the 27 cell -> voxel entries are requested together (independent loads)
+                    int cv[27];
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) {
+                        const int dx = i / 9, dy = (i / 3) % 3, dz = i % 3;
+                        const bool ok = in[0][dx] && in[1][dy] && in[2][dz];
+                        const int cx = q[0] + dx - 1, cy = q[1] + dy - 1, cz = q[2] + dz - 1;
+                        const int key = ((bid * a.g.r[0] + cx) * a.g.r[1] + cy) * a.g.r[2] + cz;
+                        cv[i] = ok ? a.cell_rank[key] : -1;   // (cell -> voxel, -1 = not occupied)
+                    }
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) ev = max(ev, cv[i]);
                 }
             }
             a.end_voxel[r] = ev;
@@ -235,10 +253,9 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
             pi[0] = a.pnet_rel ? x - cxx : x;
             pi[1] = a.pnet_rel ? y - cyy : y;
             pi[2] = a.pnet_rel ? z - czz : z;
-            const float* px = a.rgb + (size_t)bid * 3 * a.hw + a.ray_flat[r];
-            pi[3] = px[0];
-            pi[4] = px[a.hw];
-            pi[5] = px[2 * a.hw];
+            pi[3] = c0r;
+            pi[4] = c1r;
+            pi[5] = c2r;
             s_q[3 * threadIdx.x] = a.pos_rel ? x - cxx : x;
             s_q[3 * threadIdx.x + 1] = a.pos_rel ? y - cyy : y;
             s_q[3 * threadIdx.x + 2] = a.pos_rel ? z - czz : z;
@@ -246,7 +263,7 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
     }
     __syncthreads();
     const int E = 3 + 6 * a.L;
-    const int nr = (int)min((long long)64, R - r0w);
+    const int nr = (int)min((long long)STEP_RAYS, R - r0w);
     for (int i = threadIdx.x; i < nr * E; i += 256) {
         const int rr = i / E, k = i % E;
         const int ax = k < 3 ? k : (k - 3) % 3;    // coordinate
@@ -265,7 +282,7 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
 
 extern "C" hipError_t lidf_launch_refine_step(const RefineStepArgs& a, long long R_cap, hipStream_t st) {
     if (R_cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_refine_step_kernel, dim3((unsigned)((R_cap + 63) / 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lidf_refine_step_kernel, dim3((unsigned)((R_cap + STEP_RAYS - 1) / STEP_RAYS)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
