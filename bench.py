@@ -190,61 +190,52 @@ def parity_record(got, ref, scene, depth):
             "tolerance": 1e-4, "ok": bool(max(mx.values()) <= 1e-4 and float(d.mean()) <= 1e-4)}
 
 
-def profile_record(kernel_name):
-    """Numbers of the committed rocprofv3 summaries for the dominant kernel (profiles/, written by
-    scripts/prof_summary.py from the same bench command): average duration of the kernel-trace
-    run and the PMC HBM bytes per launch / per step. Absent files -> empty record."""
-    out = {}
-    for tag in ("r03", "r02", "r01"):
-        ks = os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag)
-        if not os.path.exists(ks):
-            continue
-        try:
-            for ln in open(ks):
-                if ln.startswith('"') and kernel_name in ln.split('",')[0]:
-                    out["kernel_ms_rocprof"] = round(float(ln.rsplit('",', 1)[1].split(",")[2]) / 1e6, 4)
-                    out["profile"] = "profiles/%s_kernel_stats.csv" % tag
-                    break
-            hp = os.path.join(ROOT, "profiles", "%s_hbm_pmc.csv" % tag)
-            tot = 0.0
-            for ln in open(hp) if os.path.exists(hp) else ():
-                if not ln.startswith('"'):
-                    continue
-                name, rest = ln.rsplit('",', 1)
-                f = rest.strip().split(",")
-                if kernel_name in name:
-                    out["hbm_bytes_counter"] = float(f[4])
-                if "lidf_" in name and "_h_kernel" not in name and "pack_h" not in name:
-                    tot += float(f[4]) * (PER_STEP_LAUNCHES.get(name.strip('"').split("(")[0], 1))
-            if tot:
-                out["hbm_bytes_step_counter"] = tot
-            mp = os.path.join(ROOT, "profiles", "%s_mfma_pmc.csv" % tag)
-            for ln in open(mp) if os.path.exists(mp) else ():
-                if ln.startswith('"') and kernel_name in ln and "SQ_INSTS_VALU_MFMA_MOPS_F32" in ln:
-                    # the counter ticks once per 512 FLOP (8 per v_mfma_f32_32x32x2_f32)
-                    out["mfma_flop_counter"] = float(ln.strip().rsplit(",", 1)[1]) * 512.0
-        except Exception:
-            pass
-        if out:
-            break
-    return out
+def _short(name):
+    """Kernel name without its argument list (rocprofv3 reports the demangled signature)."""
+    return name.split("(")[0].replace("void ", "").strip()
 
 
-def rocprof_live(kernel_name, argv, steps=6, warmup=2, timeout=240):
-    """The dominant kernel's average duration by rocprofv3 --kernel-trace --stats of THIS command
-    (same workload flags, `steps` steps, no CPU baseline), run as a child process once the timed region
-    is over: {"kernel_ms": avg excluding the first launch, "calls": n, "kernel_ms_all": avg of all}.
-    None when rocprofv3 is absent, the child fails or takes longer than `timeout` s (the bench line is
-    then emitted without it)."""
+def _rocprof_child(opts, keep, steps, warmup, timeout):
+    """This script as a child process under `rocprofv3 <opts>` (same workload flags, `steps` steps, no CPU
+    baseline, no nested profiling); returns (results db path, temp dir) or (None, temp dir)."""
     import shutil
-    import sqlite3
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None or os.environ.get("LIDF_BENCH_NO_ROCPROF") == "1":
+    d = tempfile.mkdtemp(prefix="lidf_bench_prof_", dir="/tmp")
+    if exe is None:
+        return None, d
+    env = dict(os.environ, TMPDIR="/tmp", LIDF_BENCH_NO_ROCPROF="1")
+    cmd = [exe] + opts + ["-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+                          "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-rocprof"] + keep
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout)
+    except Exception:
+        return None, d
+    db = None
+    for root, _, files in os.walk(d):
+        for f in files:
+            if f.endswith("_results.db"):
+                db = os.path.join(root, f)
+    return (db if r.returncode == 0 else None), d
+
+
+def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300):
+    """rocprofv3 legs of THIS command, run as child processes once the timed region is over — every number
+    of the record is a number of this run on this box, none is read from a committed file:
+      kernel trace (--kernel-trace --stats): per kernel the calls and the average duration (all launches,
+        and excluding each kernel's first launch), launches per step (a step = one launch of `dominant`);
+      pmc=True: two more passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; the TCC block cannot hold both) -> HBM
+        bytes per launch, corrected as MI355X_MICROARCH.md §HBM prescribes for gfx950 (FETCH_SIZE tallies 64 B
+        per 128-B request of a wide coalesced read: 2 x FETCH_SIZE + WRITE_SIZE, an upper bound for mixed
+        access widths; the counters are KiB per dispatch).
+    None when rocprofv3 is absent, disabled (LIDF_BENCH_NO_ROCPROF=1) or a child fails."""
+    import shutil
+    import sqlite3
+    if os.environ.get("LIDF_BENCH_NO_ROCPROF") == "1":
         return None
-    keep = []
-    skip = False
+    keep, skip = [], False
     for a in argv:            # the workload flags of this run without its step counts
         if skip:
             skip = False
@@ -252,36 +243,107 @@ def rocprof_live(kernel_name, argv, steps=6, warmup=2, timeout=240):
         if a in ("--steps", "--warmup", "--gpus"):
             skip = True
             continue
-        if a.startswith(("--steps=", "--warmup=", "--gpus=")) or a in ("--no-cpu-baseline", "--no-rocprof"):
+        if a.startswith(("--steps=", "--warmup=", "--gpus=")) or a in ("--no-cpu-baseline", "--no-rocprof", "--pmc"):
             continue
         keep.append(a)
-    d = tempfile.mkdtemp(prefix="lidf_bench_prof_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", LIDF_BENCH_NO_ROCPROF="1")
-    cmd = [exe, "--kernel-trace", "--stats", "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
-           "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-rocprof"] + keep
+    out = None
+    dirs = []
     try:
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=timeout)
-        db = None
-        for root, _, files in os.walk(d):
-            for f in files:
-                if f.endswith("_results.db"):
-                    db = os.path.join(root, f)
-        if r.returncode != 0 or db is None:
+        db, d = _rocprof_child(["--kernel-trace", "--stats"], keep, steps, warmup, timeout)
+        dirs.append(d)
+        if db is None:
             return None
         cur = sqlite3.connect(db).cursor()
-        dur = [row[0] for row in cur.execute(
-            "select duration from kernels where name like ? order by start", ("%" + kernel_name + "%",))]
-        if len(dur) < 2:
+        per = {}
+        for name, dur in cur.execute("select name, duration from kernels order by start"):
+            per.setdefault(_short(name), []).append(dur)
+        dom = [k for k in per if dominant in k]
+        if not dom or len(per[dom[0]]) < 2:
             return None
-        return {"kernel_ms": round(sum(dur[1:]) / (len(dur) - 1) / 1e6, 4), "calls": len(dur),
-                "kernel_ms_all": round(sum(dur) / len(dur) / 1e6, 4),
-                "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d %s"
-                           % (steps, warmup, " ".join(keep))}
+        nstep = len(per[dom[0]])
+        kern = {}
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            kern[k] = {"calls_per_step": round(len(v) / nstep, 2), "avg_ms": round(sum(v) / len(v) / 1e6, 5),
+                       "avg_ms_after_first": round(sum(v[1:]) / max(len(v) - 1, 1) / 1e6, 5)}
+        out = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d %s"
+                          % (steps, warmup, " ".join(keep)),
+               "steps_seen": nstep,
+               "launches_per_step": round(sum(len(v) for v in per.values()) / nstep, 1),
+               "busy_ms_per_step": round(sum(sum(v) for v in per.values()) / nstep / 1e6, 4),
+               "kernels": dict(list(kern.items())[:24])}
+        if pmc:
+            vals = {}
+            for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+                dbc, d = _rocprof_child(["--pmc", cname], keep, 3, 1, timeout)
+                dirs.append(d)
+                if dbc is None:
+                    vals = None
+                    break
+                c2 = sqlite3.connect(dbc).cursor()
+                for kn, n, avg in c2.execute("select kernel_name, count(*), avg(value) from counters_collection "
+                                             "where counter_name=? group by kernel_name", (cname,)):
+                    vals.setdefault(_short(kn), {})[cname] = (n, avg)
+            if vals:
+                hb, step_bytes = {}, 0.0
+                ndom = [v for k, v in vals.items() if dominant in k]
+                nst = ndom[0].get("FETCH_SIZE", (1, 0))[0] if ndom else 1
+                for k, v in vals.items():
+                    f, w = v.get("FETCH_SIZE", (0, 0.0)), v.get("WRITE_SIZE", (0, 0.0))
+                    cor = (2.0 * f[1] + w[1]) * 1024.0
+                    hb[k] = {"fetch_kib": round(f[1], 1), "write_kib": round(w[1], 1),
+                             "bytes_corrected": round(cor), "calls_per_step": round(f[0] / max(nst, 1), 2)}
+                    if "lidf_" in k and "_h_kernel" not in k and "pack_h" not in k and "rows_h" not in k:
+                        step_bytes += cor * f[0] / max(nst, 1)
+                out["hbm"] = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 3 "
+                                         "--warmup 1 %s (two passes)" % " ".join(keep),
+                              "correction": "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, gfx950), KiB per dispatch",
+                              "bytes_per_step": round(step_bytes),
+                              "kernels": dict(sorted(hb.items(), key=lambda kv: -kv[1]["bytes_corrected"])[:12])}
+            # matrix-pipe counters (their own pass): MFMA FLOP issued, the shader clock the launch ran at
+            # (SQ_BUSY_CYCLES / 32 shader engines / duration) and the share of those cycles the matrix pipe
+            # was busy (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles) — meaningful for launches that fill
+            # all 32 shader engines
+            dbm, d = _rocprof_child(["--kernel-trace", "--pmc", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES",
+                                     "SQ_VALU_MFMA_BUSY_CYCLES"], keep, 3, 1, timeout)
+            dirs.append(d)
+            if dbm is not None:
+                c3 = sqlite3.connect(dbm).cursor()
+                dur = {_short(r[0]): r[1] for r in c3.execute("select name, avg(duration) from kernels group by name")}
+                by = {}
+                for kn, cn, avg in c3.execute("select kernel_name, counter_name, avg(value) from counters_collection "
+                                              "group by kernel_name, counter_name"):
+                    by.setdefault(_short(kn), {})[cn] = avg
+                mf = {}
+                for k, v in by.items():
+                    t = dur.get(k, 0.0) * 1e-9
+                    if t <= 0 or not v.get("SQ_BUSY_CYCLES"):
+                        continue
+                    clk = v["SQ_BUSY_CYCLES"] / 32.0 / t
+                    mf[k] = {"us": round(t * 1e6, 1), "ghz": round(clk / 1e9, 3),
+                             "mfma_busy": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / (clk * t), 3),
+                             # (the counter ticks once per 512 f32 MFMA FLOP)
+                             "mfma_flop": round(v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0)}
+                out["mfma"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES "
+                                          "SQ_VALU_MFMA_BUSY_CYCLES -- python bench.py --steps 3 --warmup 1 %s"
+                                          % " ".join(keep),
+                               "kernels": dict(sorted(mf.items(), key=lambda kv: -kv[1]["us"])[:10])}
+        return out
     except Exception:
-        return None
+        return out
     finally:
-        shutil.rmtree(d, ignore_errors=True)
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def live_kernel(live, name):
+    """(avg ms after the first launch, avg ms of all launches, calls per step) of the kernel whose short name
+    contains `name` in a live_profile record, or None."""
+    if not live:
+        return None
+    for k, v in live["kernels"].items():
+        if name in k:
+            return v
+    return None
 
 
 # launches per step of the f32 query (for the per-step HBM counter sum)
@@ -542,6 +604,33 @@ def e2e(args):
         assert not c["OVERFLOW"]
         P, R, V, NV = c["P"], c["R"], c["V"], c["NVS"]
         syncs = "none inside the step (list lengths stay on the device)"
+    # rocprofv3 legs of this same command (child processes after the timed region): launches per step, busy
+    # time, the kernels of a step, and the issued-FLOP fractions of its three matrix kernels
+    live = None
+    profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
+    if not args.no_rocprof and not profiled and max(1, args.streams) == 1:
+        live = live_profile(sys.argv[1:], "lidf_points_fused_kernel" if args.precision == "f32" else "lidf_points_h_kernel",
+                            pmc=args.pmc)
+    roof = None
+    if live and args.precision == "f32" and mode != "stepwise":
+        def frac(name, flop):
+            k = live_kernel(live, name)
+            if not k:
+                return None
+            t = k["avg_ms_after_first"] * 1e-3
+            return {"kernel_ms": k["avg_ms_after_first"], "calls_per_step": k["calls_per_step"],
+                    "achieved": round(flop / t / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(flop / t / 1e12 / PEAK_F32_TFLOPS, 4)}
+        npn = c["NPN"] if mode != "stepwise" else 0
+        roof = {
+            "points": dict(frac("lidf_points_fused_kernel", F_EXEC * P) or {}, flop_per_point_exec=F_EXEC),
+            # stage-2 decoder rows: 7 layer-1 k-quads x 8 tiles x 4 + 2 passes x 654 matrix instructions per 32 rays
+            "ief_rows": dict(frac("lidf_points_kernel<6>", (7 * 8 * 4 + 2 * 654) * 4096 / 32.0 * R) or {},
+                             wave_tiles=(R + 31) // 32),
+            # PointNet2Stage chains of one refine pass: 44 (stage 1) and 444 (stage 2) matrix instructions per 32 points
+            "pointnet_chain2": frac("lidf_pointnet_chain_kernel<2, true>", 444 * 4096 / 32.0 * (NV + 2 * npn) / 3.0),
+            "l1part": frac("lidf_l1part_pair_kernel", 2.0 * 155 * (512 + 256) * R + 2.0 * 129 * 512 * V),
+        }
     emit({
         "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -558,6 +647,9 @@ def e2e(args):
         "frames_per_s": round(B * args.steps / elapsed, 2),
         "rays_per_s": round(R * args.steps / elapsed, 1),
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        "roofline_kernels": roof,
+        "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels", "hbm", "mfma")
+                     if k in live} if live else None),
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
 
 
@@ -582,9 +674,13 @@ def main():
     ap.add_argument("--frames", type=int, default=1, help="frames per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rocprof", action="store_true",
-                    help="skip the rocprofv3 leg of the N = 1 query run (roofline.kernel_ms_rocprof_live: the "
-                         "dominant kernel's average duration by rocprofv3 --kernel-trace of this same command, "
-                         "run as a child process after the timed region)")
+                    help="skip the rocprofv3 legs of an N = 1 run (roofline.kernel_ms_rocprof_live and the "
+                         "\"profile\" block: per-kernel durations and launches per step by rocprofv3 --kernel-trace "
+                         "of this same command, run as a child process after the timed region)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="also run the two HBM counter passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE) of "
+                         "this command -> roofline.traffic, hbm.bytes_counter; the default headline run does so "
+                         "by itself")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="arithmetic of the decoders' matrix products: f32 (default, the headline) or "
                          "f16x3 = three f16-piece products per term with f32 accumulation (f32-level "
@@ -841,12 +937,20 @@ def main():
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
         kname = "lidf_points_h_kernel" if h16 else "lidf_points_fused_kernel"
-        prof = profile_record(kname)
+        # rocprofv3 legs of this very command (child processes after the timed region). Every N = 1 query run
+        # gets the kernel trace; the HBM counter passes run for the default headline command (the line the
+        # driver records) and wherever --pmc asks for them. Nothing is read from committed files.
         live = None
         profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)   # already under a profiler
-        if (world == 1 and not use_dist and not args.no_rocprof and not args.no_cpu_baseline and not profiled
-                and args.workload == "query"):
-            live = rocprof_live(kname, sys.argv[1:])
+        headline = dense and B == 1 and N == 64 and refine is None and not h16 and S == 1
+        if world == 1 and not use_dist and not args.no_rocprof and not profiled:
+            live = live_profile(sys.argv[1:], kname, pmc=args.pmc or (headline and not args.no_cpu_baseline))
+        lk = live_kernel(live, kname)
+        lh = (live or {}).get("hbm")
+        lhk = None
+        if lh:
+            lhk = next((v for k, v in lh["kernels"].items() if kname in k), None)
+        lmk = next((v for k, v in ((live or {}).get("mfma") or {"kernels": {}})["kernels"].items() if kname in k), None)
         ach = f_exec * P / (kern_ms * 1e-3) / 1e12          # MFMA FLOP issued / time
         ach_alg = F_ALG * P / (kern_ms * 1e-3) / 1e12       # reference-formulation FLOP / time
         # algorithmic HBM bytes of the fused query: 20 B/point in+out, 32 B/ray,
@@ -875,22 +979,22 @@ def main():
             # that model-FLOPs rate is reported separately as achieved_alg / frac_alg.
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": prof.get("hbm_bytes_counter"),
+                         # HBM bytes of one launch of the kernel by the PMC counters of this run (null: no pass)
+                         "traffic": lhk["bytes_corrected"] if lhk else None,
                          "kernel": kname, "kernel_ms": round(kern_ms, 4),
-                         # (static: the average of the committed rocprofv3 summary of an earlier run of this
-                         # command, for comparison with the live kernel_ms above — not a value of this run)
-                         "kernel_ms_rocprof": prof.get("kernel_ms_rocprof"),
-                         "profile": prof.get("profile"),
-                         # (live: rocprofv3 --kernel-trace of this same command, run after the timed region)
-                         "kernel_ms_rocprof_live": live,
+                         # (rocprofv3 --kernel-trace of this same command, run after the timed region: average
+                         # duration of the kernel's launches after its first / of all of them)
+                         "kernel_ms_rocprof_live": ({"kernel_ms": lk["avg_ms_after_first"], "kernel_ms_all": lk["avg_ms"],
+                                                     "calls": live["steps_seen"], "command": live["command"]}
+                                                    if lk else None),
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,
-                         "flop_per_point_counter": (round(prof["mfma_flop_counter"] / (240 * 320 * 64), 1)
-                                                    if prof.get("mfma_flop_counter") and not h16 else None),
+                         "flop_per_point_counter": (round(lmk["mfma_flop"] / P, 1) if lmk and not h16 else None),
+                         "pipe": ({"ghz": lmk["ghz"], "mfma_busy": lmk["mfma_busy"]} if lmk else None),
                          "achieved_alg": round(ach_alg, 2), "frac_alg": round(ach_alg / peak, 4)},
-            "hbm": {"bytes_alg": round(bytes_alg), "bytes_counter": prof.get("hbm_bytes_step_counter"),
+            "hbm": {"bytes_alg": round(bytes_alg), "bytes_counter": lh["bytes_per_step"] if lh else None,
                     "gbps_alg": round(bytes_alg / (elapsed / args.steps) / 1e9, 2),
-                    "gbps_counter": (round(prof["hbm_bytes_step_counter"] / (elapsed / args.steps) / 1e9, 2)
-                                     if prof.get("hbm_bytes_step_counter") else None),
+                    "gbps_counter": (round(lh["bytes_per_step"] / (elapsed / args.steps) / 1e9, 2) if lh else None),
+                    "counter_source": lh["command"] if lh else None,
                     "peak_gbps": 8000.0,
                     "frac_of_8TBs": round(bytes_alg / (elapsed / args.steps) / 8e12, 5),
                     "note": "whole step; the path is MFMA-bound (>= 3,000 FLOP per HBM byte)"},
@@ -923,6 +1027,12 @@ def main():
                              "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_pn / PEAK_F32_TFLOPS, 4)},
             }
             del line["roofline_stage2"]["refine_ms_per_step"]
+        if live:
+            line["profile"] = {k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels")}
+            if lh:
+                line["profile"]["hbm"] = lh
+            if live.get("mfma"):
+                line["profile"]["mfma"] = live["mfma"]
         if gather_ok is not None:
             line["collective"] = {"op": ("all_gather_into_tensor (RCCL) of the depth rows of one [%d,%d] map" % (h, w)
                                          if by_rays else

@@ -1487,15 +1487,18 @@ __global__ void __launch_bounds__(1024) lidf_depth_metrics_kernel(
     if (threadIdx.x < METRIC_SUMS) {
         double sum = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[threadIdx.x][w];
-        __hip_atomic_store(partial + (size_t)blockIdx.x * METRIC_SUMS + threadIdx.x, __double_as_longlong(sum),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (an exchange: its returned value arrives once the write is performed at the coherent level, so the
+        // ticket below is taken after the partials are visible — without a release fence, which on this
+        // device writes back the whole L2, megabytes of the frame's outputs)
+        const unsigned long long was = __hip_atomic_exchange(
+            partial + (size_t)blockIdx.x * METRIC_SUMS + threadIdx.x, (unsigned long long)__double_as_longlong(sum),
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(was));
     }
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     // (every partial is requested by a thread of its own — one memory round trip —, then added in
     // workgroup order)
     __shared__ double s_part[METRIC_MAX_WGS * METRIC_SUMS];
@@ -1715,13 +1718,13 @@ __global__ void __launch_bounds__(256) lidf_fingerprint_kernel(FpSegs s, unsigne
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
-        __threadfence();
+        // (the returned value orders the ticket behind the sum without a release fence = an L2 write-back)
+        const unsigned long long was = atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
+        asm volatile("" ::"v"(was));
         last = atomicAdd(&g->ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long h = atomicAdd(&g->acc, 0ull) + salt;
         g->dirty = (!g->valid || g->hash != h) ? 1 : 0;
         g->hash = h;
@@ -1800,13 +1803,12 @@ __global__ void __launch_bounds__(256) lidf_fingerprint_multi_kernel(FpSegsM s, 
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
-        __threadfence();
+        const unsigned long long was = atomicAdd(&g->acc, part[0] + part[1] + part[2] + part[3]);
+        asm volatile("" ::"v"(was));
         last = atomicAdd(&g->ticket, 1u) == s.gblocks[grp] - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long h = atomicAdd(&g->acc, 0ull) + s.salt[grp];
         g->dirty = (!g->valid || g->hash != h) ? 1 : 0;
         g->hash = h;
