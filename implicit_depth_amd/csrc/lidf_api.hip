@@ -84,8 +84,8 @@ hipError_t lidf_launch_frame_head(const float*, const float*, const float*, cons
                                   const int*, const int*, long long, hipStream_t);
 size_t lidf_frame_head_blocks(long long);
 size_t lidf_frame_head_lb_bytes(long long);
-hipError_t lidf_launch_frame_cells(const int*, long long, const GridSpec&, int*, int*, float*, int*, int*,
-                                   hipStream_t);
+hipError_t lidf_launch_frame_cells(const int*, long long, const GridSpec&, int*, int*, float*, int*, float*,
+                                   int*, hipStream_t);
 size_t lidf_ray_aabb_onepass_lb_bytes(long long);
 hipError_t lidf_launch_ray_aabb_onepass(const float*, const float*, const int*, const int*, long long, int*,
                                         void*, int*, int*, int*, float*, long long, hipStream_t);
@@ -1449,7 +1449,7 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
 }
 
 struct FrameWs {
-    size_t lb_head, lb_pairs, cell_flag, cell_rank, vox_bid, pt_key, pt_rank, pnet,
+    size_t lb_head, lb_pairs, cell_flag, cell_rank, vox_bid, vox_center, pt_key, pt_rank, pnet,
         query, inp_embed, off, vox_feat_r, voxpart_r, raypart_r, pos_a, pos_b, pnet_abs, sel, dec, total;
     size_t lb_bytes;   // lb_head .. cell_flag: the look-back tickets / status words, zeroed with cell_flag
 };
@@ -1465,6 +1465,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     f.cell_flag = o; o += align_up(C * 4, 256);
     f.cell_rank = o; o += align_up((C + 1) * 4, 256);
     f.vox_bid = o;   o += align_up(C * 4, 256);
+    f.vox_center = o; o += align_up(C * 12, 256);
     f.pt_key = o;    o += align_up(N * 4, 256);
     f.pt_rank = o;   o += align_up((N + 1) * 4, 256);
     f.pnet = o;      o += align_up(pnet_frame_ws((int64_t)C, v_lds, B >= 2 ? (int64_t)(2 * N) : 0).total, 256);
@@ -1672,8 +1673,9 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
                                      a->n_valid_idx > 0 ? a->n_valid_idx : 0, st));
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
+    float* vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;   // intersect_pos_type 'rel'
     CHECK_HIP(lidf_launch_frame_cells(cell_flag, C, g, cell_rank, a->occ_bid_coord, a->voxel_bound, vox_bid,
-                                      counts, st));
+                                      vox_center, counts, st));
     float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
     CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
                                        a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
@@ -1687,8 +1689,6 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
                              counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))
         return rc;
     // 5. get_embedding + get_pred + depth
-    float* vox_center = nullptr;
-    if (a->pos_rel) return LIDF_ERR_UNSUPPORTED;   // intersect_pos_type 'rel': not on this path (shipped: 'abs')
     {
         LidfQueryArgs q = {};
         q.n_rays = N; q.ray_dir = a->ray_dir; q.ray_pix = a->ray_pix; q.ray_bid = a->ray_bid;
@@ -1699,7 +1699,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         q.n_vox = C; q.vox_feat = a->occ_voxel_feat; q.vox_center = vox_center;
         q.prob = a->prob; q.off = a->off;
         q.multires = a->multires; q.multires_views = a->multires_views; q.roi_inp_bbox = a->roi_inp_bbox;
-        q.pos_rel = 0;
+        q.pos_rel = a->pos_rel ? 1 : 0;
         q.offset_range0 = a->offset_range0; q.offset_range1 = a->offset_range1; q.part_size = a->part_size;
         q.pred_offset = a->pred_offset; q.pred_prob = a->pred_prob; q.pair_pred_pos = a->pair_pred_pos;
         q.pred_prob_softmax = a->pred_prob_softmax; q.max_pair_id = a->max_pair_id; q.pred_pos = a->pred_pos;

@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
                                                                  int* __restrict__ cell_rank,
                                                                  int* __restrict__ occ, float* __restrict__ vbound,
                                                                  int* __restrict__ vox_bid,
+                                                                 float* __restrict__ vox_center,
                                                                  int* __restrict__ counts) {
     __shared__ int s_w[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,6 +260,8 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
                     const float lo = g.xmin[a] + (float)c[a] * g.crop;  // pipeline.py:186
                     vbound[6 * v + a] = lo;
                     vbound[6 * v + 3 + a] = lo + g.crop;               // :187
+                    // intersect_pos_type 'rel': the voxel centre (bound_min + bound_max) / 2 (pipeline.py:355-360)
+                    if (vox_center) vox_center[3 * v + a] = (lo + (lo + g.crop)) / 2.f;
                 }
             }
         }
@@ -349,10 +352,10 @@ extern "C" hipError_t lidf_launch_frame_head(const float* valid_mask, const floa
 
 extern "C" hipError_t lidf_launch_frame_cells(const int* cell_flag, long long ncell, const GridSpec& g,
                                               int* cell_rank, int* occ, float* vbound, int* vox_bid,
-                                              int* counts, hipStream_t st) {
+                                              float* vox_center, int* counts, hipStream_t st) {
     if (ncell <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_frame_cells_kernel, dim3(1), dim3(1024), 0, st, cell_flag, ncell, g, cell_rank, occ,
-                       vbound, vox_bid, counts);
+                       vbound, vox_bid, vox_center, counts);
     return hipGetLastError();
 }
 

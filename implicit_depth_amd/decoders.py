@@ -22,6 +22,20 @@ import torch.nn.functional as F
 
 from . import _lib
 
+# SURVEY 8b asked the drop-in modules to fall back to composite PyTorch where the HIP op does not apply.
+# The product path has no CPU fallback — a CPU tensor raises, as the reference's CHECK_CUDA does — because
+# a silent fallback would let "GPU" results come from torch ops. For checkpoint conversion or unit tests of
+# code that merely CALLS the modules on the CPU, LIDF_ALLOW_CPU_COMPOSITE=1 routes CPU tensors (only those)
+# through forward_composite — the same function in plain torch ops, never the oracle, never a CUDA tensor.
+_CPU_HINT = "set LIDF_ALLOW_CPU_COMPOSITE=1 to run CPU tensors through the torch-op definition"
+
+
+def _cpu_composite_allowed():
+    import os
+    return os.environ.get("LIDF_ALLOW_CPU_COMPOSITE") == "1"
+
+
+
 
 # --------------------------------------------------------------------------------------------
 # Positional encoding
@@ -326,7 +340,9 @@ class IMNet(_DecoderBase):
 
     def forward(self, inp_feat):
         if not inp_feat.is_cuda:
-            raise RuntimeError("IMNet.forward: CUDA tensor required (no CPU path)")
+            if _cpu_composite_allowed():
+                return self.forward_composite(inp_feat)
+            raise RuntimeError("IMNet.forward: CUDA tensor required (no CPU path; " + _CPU_HINT + ")")
         if self._needs_autograd(inp_feat):
             return self._forward_train(inp_feat)
         return decoders_forward(inp_feat, prob_dec=self)[0]
@@ -363,7 +379,9 @@ class IEF(_DecoderBase):
 
     def forward(self, inp_feat):
         if not inp_feat.is_cuda:
-            raise RuntimeError("IEF.forward: CUDA tensor required (no CPU path)")
+            if _cpu_composite_allowed():
+                return self.forward_composite(inp_feat)
+            raise RuntimeError("IEF.forward: CUDA tensor required (no CPU path; " + _CPU_HINT + ")")
         if self._needs_autograd(inp_feat):
             return self._forward_train(inp_feat)
         return decoders_forward(inp_feat, offset_dec=self)[1]

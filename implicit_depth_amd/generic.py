@@ -34,9 +34,11 @@ def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None
     n = x.shape[0]
     k = int(k if k is not None else w.shape[1] - w_col0)
     nout = int(w.shape[0])
-    if x.stride(1) != 1 or x.shape[1] < k:
+    if x.shape[1] < k:
+        raise RuntimeError("linear_hip: x has %d columns, the layer contracts over %d" % (x.shape[1], k))
+    if x.stride(1) != 1:
         x = x.contiguous()
-    ldx = x.stride(0) if n > 1 else max(x.shape[1], k)
+    ldx = x.stride(0) if n > 1 else x.shape[1]   # (a single row: its real width, never a fabricated stride)
     b = bias.detach().contiguous() if bias is not None else None
     if out is None and pool is None:
         out = torch.empty((n, nout), dtype=torch.float32, device=x.device)
@@ -225,8 +227,10 @@ def refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox,
 
 class _LinearFn(torch.autograd.Function):
     """act(x W^T + b) through lidf_linear_f32 with a backward through the library: d x = (g * act') W
-    (lidf_linear_f32 on W^T), d W = (g * act')^T x and d b = its column sums (lidf_wgrad_f32, fixed
-    summation order). act' is read off the output (leaky ReLU keeps the sign)."""
+    (lidf_linear_f32 on W^T), d W = (g * act')^T x and d b = its column sums (lidf_wgrad_f32: fixed
+    summation order for layers of >= 32 outputs and >= 4 inputs; the 1-wide output layer and offset_enc =
+    Linear(1, 16) add their row slices with float atomics — correct to rounding, not bit-reproducible run
+    to run, lidf_hip.h). act' is read off the output (leaky ReLU keeps the sign)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, slope):

@@ -229,7 +229,8 @@ class FrameRunner:
 
     result() gives the reference's data_dict keys as views of the capacity buffers (int32 index
     tensors; `reference_dtypes=True` adds the int64 forms). mask_type 'all' / 'pred', every valid
-    pixel or every opt.valid_stride-th; intersect_pos_type 'abs' (the shipped configs); precision "f32"
+    pixel or every opt.valid_stride-th; intersect_pos_type / refine_intersect_pos_type / refine_pnet_pos_type 'abs' or
+    'rel'; precision "f32"
     or "f16x3" (as lidf_query / lidf_refine).
     max_pairs bounds the pair list (default 32 per pixel: a ray crosses at most 25 cells of the 9^3
     grid); a frame with more pairs raises in result().
@@ -253,8 +254,8 @@ class FrameRunner:
         from .pointnet import check_pointnet
         self.C = C
         self.opt = opt = opt or LidfOptions()
-        if opt.intersect_pos_type != "abs":
-            raise RuntimeError("FrameRunner: intersect_pos_type 'abs' only (use lidf_forward for 'rel')")
+        if opt.intersect_pos_type not in ("abs", "rel"):
+            raise NotImplementedError("intersect_pos_type %s" % opt.intersect_pos_type)
         if opt.mask_type not in ("all", "pred"):
             raise NotImplementedError("mask_type %s" % opt.mask_type)
         if precision not in Q.PRECISIONS:
@@ -431,7 +432,8 @@ class FrameRunner:
         a.valid_stride = int(opt.valid_stride) if opt.valid_stride and opt.valid_stride > 1 else 1
         a.pnet, a.prob, a.off = C.pointer(pn), C.pointer(dp), C.pointer(do)
         a.packed_query = None
-        a.multires, a.multires_views, a.roi_inp_bbox, a.pos_rel = opt.multires, opt.multires_views, opt.roi_inp_bbox, 0
+        a.multires, a.multires_views, a.roi_inp_bbox = opt.multires, opt.multires_views, opt.roi_inp_bbox
+        a.pos_rel = int(opt.intersect_pos_type == "rel")
         a.offset_range0, a.offset_range1 = float(opt.offset_range[0]), float(opt.offset_range[1])
         a.refine_times = self.times
         a.precision = Q.PRECISIONS[self.precision]

@@ -154,10 +154,13 @@ class PointNet2Stage(nn.Module):
         self.vox_lin2 = nn.Linear(output_channels, output_channels, bias=True)
 
     def forward(self, inp_feat, vox2point_idx, n_vox=None):
-        if not inp_feat.is_cuda:
-            raise RuntimeError("PointNet2Stage.forward: CUDA tensor required (no CPU path)")
         if n_vox is None:
             n_vox = int(vox2point_idx.max().item()) + 1 if vox2point_idx.numel() else 0
+        if not inp_feat.is_cuda:
+            from .decoders import _CPU_HINT, _cpu_composite_allowed
+            if _cpu_composite_allowed():   # CPU tensors only, opt-in (decoders.py): the torch-op definition
+                return self.forward_composite(inp_feat, vox2point_idx, n_vox)
+            raise RuntimeError("PointNet2Stage.forward: CUDA tensor required (no CPU path; " + _CPU_HINT + ")")
         needs_grad = torch.is_grad_enabled() and (
             inp_feat.requires_grad or any(p.requires_grad for p in self.parameters()))
         if (inp_feat.dtype != torch.float32 or inp_feat.dim() != 2

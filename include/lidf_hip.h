@@ -565,7 +565,11 @@ int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const flo
  * b = the layer's input rows [n, n_cols]: c is dL/dW in nn.Linear's [out, in] layout), db[i] += sum_r a[r, i]
  * (optional). c / db are accumulated into: zero them for a fresh gradient. With workspace
  * (lidf_wgrad_workspace_bytes() bytes) the partial sums of the row slices are reduced in a fixed order
- * (run-to-run identical); workspace NULL: float atomics.                                               */
+ * (run-to-run identical) — for m >= 32 and n_cols >= 4, the block path. Narrower layers (m < 32: a 1-wide
+ * output layer; n_cols < 4: the IEF's offset_enc = Linear(1, 16)) and calls whose partial blocks do not
+ * fit the workspace take the column kernel, which adds its row slices with float atomics once n > 512:
+ * their gradients are correct to rounding but NOT bit-reproducible run to run. workspace NULL: float
+ * atomics throughout.                                                                                   */
 size_t lidf_wgrad_workspace_bytes(void);
 int lidf_wgrad_f32(const float* a, int64_t lda, int32_t m, const float* b, int64_t ldb, int32_t n_cols,
                    int64_t n, float* c, int64_t ldc, float* db, void* workspace, size_t workspace_bytes,

@@ -217,6 +217,31 @@ def test_frames_pipelined_over_streams(cuda):
     assert all(m not in _lib.PACK_CACHE and m not in _lib.PACK_CACHE_REFINE for m in models)
 
 
+@pytest.mark.parametrize("pos,rpos,rpnet", [("rel", "abs", "rel"), ("rel", "rel", "abs"), ("abs", "rel", "abs")])
+def test_frame_position_types(cuda, pos, rpos, rpnet):
+    """intersect_pos_type / refine.intersect_pos_type / refine.pnet_pos_type 'rel' and 'abs'
+    (models/pipeline.py:355-360, :975-986, :1019-1023) through the sync-free call: bit-equal to the stepwise
+    path, which test_e2e_gpu.py checks against the oracle."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 2, 48, 64
+    models = _models(cuda)
+    opt = pl.LidfOptions(intersect_pos_type=pos, refine_intersect_pos_type=rpos, refine_pnet_pos_type=rpnet)
+    batch, feat = synthetic_batch(B, h, w, seed=91)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    runner = pl.FrameRunner(B, h, w, cuda, models[0], models[1], models[2], opt, models[3], models[4])
+    with torch.no_grad():
+        runner.run(batch, feat)
+    ok, dd = runner.result()
+    ok_ref, ref = _stepwise(batch, feat, models, opt)
+    assert ok and ok_ref
+    _compare(dd, ref)
+    # and the option does something: another result than the shipped combination
+    if pos == "rel":
+        ok0, ref0 = _stepwise(batch, feat, models, pl.LidfOptions())
+        assert not torch.equal(ref0["pred_offset"], ref["pred_offset"])
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_frame_weight_streams_follow_parameter_updates(cuda, graph):
     """The runner's own packed streams (one fingerprint launch over every module per frame): in-place

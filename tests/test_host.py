@@ -336,3 +336,30 @@ def test_generic_width_paths_have_no_cpu_route():
                              null, 0, null) == 0              # n == 0: nothing to do
     assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 0, 8, 3, null, 0, null) == 0
     assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 5, 8, 0, null, 0, null) == -1
+
+
+def test_cpu_tensors_refused_unless_composite_is_allowed(monkeypatch):
+    """SURVEY 8b (CPU behaviour of the drop-in modules): no silent CPU path — a CPU tensor raises, as the
+    reference's CHECK_CUDA does — but LIDF_ALLOW_CPU_COMPOSITE=1 routes CPU tensors (only) through the
+    modules' own torch-op definition, for checkpoint conversion and callers' unit tests."""
+    from implicit_depth_amd import IEF, IMNet, PointNet2Stage
+    torch.manual_seed(0)
+    x = torch.randn(5, 385)
+    mods = (IMNet(385, 1, 64), IEF(torch.device("cpu"), 385, 1, 64, n_iter=2))
+    pn = PointNet2Stage(6, 128, 32)
+    pts, idx = torch.randn(9, 6), torch.tensor([0, 0, 1, 2, 2, 2, 1, 0, 2])
+    monkeypatch.delenv("LIDF_ALLOW_CPU_COMPOSITE", raising=False)
+    for m in mods:
+        with pytest.raises(RuntimeError, match="LIDF_ALLOW_CPU_COMPOSITE"):
+            m(x)
+    with pytest.raises(RuntimeError, match="LIDF_ALLOW_CPU_COMPOSITE"):
+        pn(pts, idx)
+    monkeypatch.setenv("LIDF_ALLOW_CPU_COMPOSITE", "1")
+    for m in mods:
+        y = m(x)
+        assert y.shape == (5, 1) and torch.equal(y, m.forward_composite(x))
+    out = pn(pts, idx)
+    assert out.shape == (3, 128) and torch.equal(out, pn.forward_composite(pts, idx, 3))
+    # gradients flow through the composite definition (a caller's CPU unit test of a training step)
+    mods[0](x).sum().backward()
+    assert mods[0].linear_1.weight.grad is not None
