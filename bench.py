@@ -709,6 +709,10 @@ def main():
                          "another. Measured on MI355X (DESIGN.md 7): 388.4 / 388.2 / 391.1 Mpoints/s at 1 / 2 / 3 "
                          "streams — the per-point kernel already fills the matrix pipes, what is overlapped "
                          "comes back as a longer kernel")
+    ap.add_argument("--imnet-gf", type=int, default=64,
+                    help="query workload: gf_dim of both decoders (model.imnet_gf; 64 in every shipped config = "
+                         "the fused kernels). Another value runs the layer-by-layer path of implicit_depth_amd/"
+                         "generic.py (rows materialised in 614,400-pair slabs): a secondary record, no roofline")
     ap.add_argument("--e2e-mode", default="frame", choices=["frame", "graph", "stepwise"],
                     help="--workload e2e: frame = one sync-free library call per batch (default), graph = "
                          "that call replayed from a HIP graph, stepwise = one call per reference method")
@@ -775,11 +779,15 @@ def main():
     if by_rays and (B != 1 or args.pairs == "scene" or args.workload != "query"):
         raise SystemExit("--shard rays splits the rows of ONE frame of the query workload")
     scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.pairs == "ragged")
-    rows = (0, h)
+    rows, row0 = (0, h), 0
     if by_rays:   # image rows [lo, hi) of the one frame; maps, voxel features and weights replicated
-        from implicit_depth_amd.dist import shard_rays, slice_rays
+        from implicit_depth_amd.dist import crop_rows, shard_rays, slice_rays
         rows = shard_rays(h, world, rank)
         scene = slice_rays(scene, rows[0] * w, rows[1] * w)
+        # (the feature map cut to the rank's rows + the 4-pixel RoIAlign halo: box sums and depth map of a
+        # rank shrink with its shard; results bit-equal to the uncut map, tests/rccl_worker.py)
+        scene, fg_cut, row0 = crop_rows(scene, scene["feat_grid"], rows[0], rows[1], 4)
+        scene["feat_grid"] = fg_cut
     s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
     if args.pairs == "scene":
         # rays, voxels and pairs as the candidate generator produces them on real geometry
@@ -802,13 +810,20 @@ def main():
         scene = dict(scene, P=int(dd["pair_ray"].shape[0]), V=int(dd["occ_voxel_feat"].shape[0]))
     P = scene["P"]
     dense = args.pairs == "dense"
-    prob = IMNet(scene["D"], 1, 64).to(dev).eval()
-    prob.load_state_dict(scene["prob_p"])
-    off = IEF(dev, scene["D"], 1, 64, n_iter=2).to(dev).eval()
-    off.load_state_dict(scene["off_p"])
+    gf = args.imnet_gf
+    prob = IMNet(scene["D"], 1, gf).to(dev).eval()
+    off = IEF(dev, scene["D"], 1, gf, n_iter=2).to(dev).eval()
+    if gf == 64:
+        prob.load_state_dict(scene["prob_p"]), off.load_state_dict(scene["off_p"])
+    else:   # the scene's seeds and scale at another width
+        from implicit_depth_amd.synthetic import init_decoder_params
+        prob.load_state_dict(init_decoder_params("IMNET", scene["D"], 7, 5.0, gf=gf))
+        off.load_state_dict(init_decoder_params("IEF", scene["D"], 8, 5.0, gf=gf))
+        prob, off = prob.to(dev), off.to(dev)
     S = max(1, args.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
-    depths = [torch.zeros((B, h, w), device=dev) for _ in range(S)]      # per stream: steps in flight
+    hl = s["feat_grid"].shape[2]    # rows of this rank's maps (the whole image, or its row shard + halo)
+    depths = [torch.zeros((B, hl, w), device=dev) for _ in range(S)]     # per stream: steps in flight
     gathers = [torch.empty((world * B, h, w), device=dev) if use_dist and not by_rays else None
                for _ in range(S)]
     depth, gathered = depths[0], gathers[0]
@@ -833,11 +848,11 @@ def main():
             if refine is not None:
                 out["pred_pos_refine"] = refine(out, rpairs[state["step"]] if (rpairs and events is not None
                                                                                  and state["step"] is not None) else None)
-                depth.view(-1)[s["ray_bid"].long() * (h * w) + s["ray_flat"].long()] = \
+                depth.view(-1)[s["ray_bid"].long() * (hl * w) + s["ray_flat"].long()] = \
                     out["pred_pos_refine"][:, 2]
         state["ws"][lane] = out["workspace"]
         if use_dist and by_rays:
-            state["full"] = all_gather_depth_rows(depth[0, rows[0]:rows[1]], h)
+            state["full"] = all_gather_depth_rows(depth[0, rows[0] - row0:rows[1] - row0], h)
         elif use_dist:
             all_gather_depth(depth, gathered)
         return out
@@ -863,7 +878,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         state["step"] = i
-        lane_step(i, pairs[i])
+        lane_step(i, None if gf != 64 else pairs[i])
     state["step"] = None
     torch.cuda.synchronize()
     barrier()
@@ -885,13 +900,14 @@ def main():
         dist.all_reduce(pts)                                # points of the whole job (shards may differ)
         points_all = int(pts.item())
 
-    kern_ms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
+    # (widths other than the shipped ones run layer by layer: no single dominant kernel to time)
+    kern_ms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps if gf == 64 else float("nan")
     gather_ok = None
     if use_dist:   # the collective's result: every rank's slot holds that rank's depth maps
         import torch.distributed as dist
         if by_rays:
             full = state["full"]
-            mine = bool((full[rows[0]:rows[1]] == depth[0, rows[0]:rows[1]]).all()) and \
+            mine = bool((full[rows[0]:rows[1]] == depth[0, rows[0] - row0:rows[1] - row0]).all()) and \
                 bool(torch.isfinite(full).all()) and tuple(full.shape) == (h, w)
         else:
             mine = bool((gathered[rank * B:(rank + 1) * B] == depth).all()) and bool(torch.isfinite(gathered).all())
@@ -900,13 +916,13 @@ def main():
         gather_ok = bool(t.item())
     split = None
     hip_f32 = None
-    if world == 1 and refine is None and dense:
+    if world == 1 and refine is None and dense and gf == 64:
         hip_f32 = step()   # outputs of the measured configuration, kept for the parity record
         hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos",
                                                    "pred_pos", "max_pair_id")}
         hip_f32["depth"] = depth.clone()
     hip_h = None
-    if world == 1 and args.precision == "f32" and refine is None:
+    if world == 1 and args.precision == "f32" and refine is None and gf == 64:
         if hip_f32 is None:
             hip_f32 = step()
             hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos")}
@@ -936,13 +952,13 @@ def main():
         h16 = args.precision == "f16x3"
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
-        kname = "lidf_points_h_kernel" if h16 else "lidf_points_fused_kernel"
+        kname = "lidf_points_h_kernel" if h16 else ("lidf_points_fused_kernel" if gf == 64 else "lidf_linear_kernel<8>")
         # rocprofv3 legs of this very command (child processes after the timed region). Every N = 1 query run
         # gets the kernel trace; the HBM counter passes run for the default headline command (the line the
         # driver records) and wherever --pmc asks for them. Nothing is read from committed files.
         live = None
         profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)   # already under a profiler
-        headline = dense and B == 1 and N == 64 and refine is None and not h16 and S == 1
+        headline = dense and B == 1 and N == 64 and refine is None and not h16 and S == 1 and gf == 64
         if world == 1 and not use_dist and not args.no_rocprof and not profiled:
             live = live_profile(sys.argv[1:], kname, pmc=args.pmc or (headline and not args.no_cpu_baseline))
         lk = live_kernel(live, kname)
@@ -955,7 +971,7 @@ def main():
         ach_alg = F_ALG * P / (kern_ms * 1e-3) / 1e12       # reference-formulation FLOP / time
         # algorithmic HBM bytes of the fused query: 20 B/point in+out, 32 B/ray,
         # per frame the feature map + voxel features + weights
-        bytes_alg = 20.0 * P + 32.0 * scene["R"] + B * (32 * h * w * 4 + 729 * 128 * 4) + 1136776
+        bytes_alg = 20.0 * P + 32.0 * scene["R"] + B * (32 * hl * w * 4 + 729 * 128 * 4) + 1136776
         line = {
             "metric": "Mpoints/sec implicit-MLP query, 240x320x%d samples; depth L1 vs ref" % N,
             "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
@@ -1048,7 +1064,13 @@ def main():
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "configs[1]", "secondary (not the headline shape): %s candidate list" % args.pairs)
             line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.pairs
-        if world == 1 and not args.no_cpu_baseline and dense:
+        if gf != 64:
+            line["roofline"] = None
+            line["config"]["workload"] = ("secondary: imnet_gf %d (not a shipped width): get_embedding + get_pred layer by "
+                                          "layer on rows materialised in %d-pair slabs (implicit_depth_amd/generic.py), "
+                                          "%d x 240x320 frame(s), %d candidates/ray" % (gf, 614400, B, N))
+            line["metric"] = "Mpoints/sec implicit-MLP query at imnet_gf %d (layer by layer)" % gf
+        if world == 1 and not args.no_cpu_baseline and dense and gf == 64:
             cb, ref = cpu_baseline(scene)
             line["cpu_baseline"] = cb
             if hip_f32 is not None:

@@ -79,6 +79,26 @@ def slice_rays(rays, lo, hi):
     return out
 
 
+def crop_rows(rays, feat_grid, lo, hi, halo):
+    """Row shard [lo, hi) of ONE image without the rows it never reads: the feature map cut to rows
+    [lo - halo, hi + halo) (clamped to the image), the rays' pixel rows and flat pixel indices re-based to
+    the cut. halo >= roi_inp_bbox // 2: a ray's RoIAlign box is pixel +- roi_inp_bbox // 2, clamped on the
+    IMAGE (models/pipeline.py:374-380) — with that halo a box reaches the cut's first / last row only where
+    it is the image's own, so the per-ray features are those of the whole map, bit for bit, while the
+    box-sum image and the depth map of a rank cover (hi - lo + 2 halo) rows instead of all of them (at 8 GPUs
+    38 of 240: the part of a row-sharded step that did not shrink with the shard before).
+    `rays`: slice_rays' output (ray_pix [R,2] (x, y), ray_flat [R]); returns (rays', feat_grid', row0):
+    row r of the cut is image row row0 + r; the rank's own rows are [lo - row0, hi - row0) of its local map."""
+    h, w = feat_grid.shape[2], feat_grid.shape[3]
+    r0, r1 = max(0, lo - halo), min(h, hi + halo)
+    out = dict(rays)
+    pix = rays["ray_pix"].clone()
+    pix[:, 1] -= r0
+    out["ray_pix"] = pix
+    out["ray_flat"] = rays["ray_flat"] - r0 * w
+    return out, feat_grid[:, :, r0:r1].contiguous(), r0
+
+
 def all_gather_depth_rows(local_rows, height, group=None):
     """All-gather of the row shards of one depth map: rank r holds rows shard_rays(height, world, r)
     of a [height, w] map ([rows_r, w] f32); returns the whole [height, w] map on every rank. Shards

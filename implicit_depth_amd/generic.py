@@ -133,6 +133,9 @@ def roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox=8, roi_out_bbox=2):
     return out
 
 
+QUERY_SLAB = 614400   # pairs per slab of the layer-by-layer query (rows [slab, D]: 0.95 GB at D = 385)
+
+
 def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid, vox_feat, prob_dec,
           offset_dec, multires, multires_views, roi_inp_bbox, roi_out_bbox, offset_range, part_size,
           vox_center, pos_rel, ray_flat, depth, want_rayfeat):
@@ -148,20 +151,30 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     L = _lib.lib()
     roi = roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox, roi_out_bbox)
     edir = get_embedder(multires_views)[0](ray_dir.detach().contiguous())
-    pe = torch.empty((P, 2 * E), dtype=torch.float32, device=dev)
-    if P:
+    D = vox_feat.shape[1] + roi.shape[1] + 2 * E + edir.shape[1]
+    if D != prob_dec.inp_dim or D != offset_dec.inp_dim:
+        raise RuntimeError("decoder inp_dim must be %d for this configuration" % D)
+    # The reference materialises cat(...) [P, D] and every activation [P, 4 gf] at once (7.6 GB at the
+    # configs[1] shape for D = 385 alone). Here the pairs go through in slabs of QUERY_SLAB rows (the slab the
+    # CPU baseline uses): rows, positional encodings and activations of one slab are live at a time — about
+    # 1 GB at D = 385, gf_dim = 64 —, the per-pair outputs [P, 1] are the only full-length arrays.
+    vf = vox_feat.detach()
+    pred_prob = torch.empty((P, prob_dec.linear_4.out_features), dtype=torch.float32, device=dev)
+    pred_offset = torch.empty((P, offset_dec.linear_4.out_features), dtype=torch.float32, device=dev)
+    for p0 in range(0, P, QUERY_SLAB):
+        p1 = min(P, p0 + QUERY_SLAB)
+        n = p1 - p0
+        pr_s, pv_s, pt_s = pair_ray[p0:p1], pair_vox[p0:p1], pair_t[p0:p1]
+        pe = torch.empty((n, 2 * E), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.lidf_pe_rows_f32(_lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
-                                          _lib.ptr(vox_center), 1 if pos_rel else 0, multires, P, _lib.ptr(pe),
+            _lib.check(L.lidf_pe_rows_f32(_lib.ptr(pr_s), _lib.ptr(pv_s), _lib.ptr(pt_s), _lib.ptr(ray_dir),
+                                          _lib.ptr(vox_center), 1 if pos_rel else 0, multires, n, _lib.ptr(pe),
                                           _lib.current_stream(dev)))
-    pr, pv = pair_ray.long(), pair_vox.long()
-    rows = torch.cat((vox_feat.detach()[pv], roi[pr], pe, edir[pr]), 1)
-    if rows.shape[1] != prob_dec.inp_dim or rows.shape[1] != offset_dec.inp_dim:
-        raise RuntimeError("decoder inp_dim must be %d for this configuration" % rows.shape[1])
-    pred_prob = decoder_forward(prob_dec, rows)
-    pred_offset = decoder_forward(offset_dec, rows)
-    if pred_prob.shape[1] != 1 or pred_offset.shape[1] != 1:
-        raise RuntimeError("get_pred takes one logit and one offset per pair (out_dim 1)")
+        pr, pv = pr_s.long(), pv_s.long()
+        rows = torch.cat((vf[pv], roi[pr], pe, edir[pr]), 1)
+        pred_prob[p0:p1] = decoder_forward(prob_dec, rows)
+        pred_offset[p0:p1] = decoder_forward(offset_dec, rows)
+        del rows, pe
     f32 = dict(dtype=torch.float32, device=dev)
     pos, sm = torch.empty((P, 3), **f32), torch.empty((P,), **f32)
     mid, pred = torch.empty((R,), dtype=torch.int64, device=dev), torch.empty((R, 3), **f32)

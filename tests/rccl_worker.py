@@ -25,7 +25,7 @@ def main():
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from implicit_depth_amd.dist import (all_gather_depth, all_gather_depth_ragged, all_gather_depth_rows,
-                                         shard_frames, shard_rays, slice_rays)
+                                         crop_rows, shard_frames, shard_rays, slice_rays)
     from util import orc, run_query
 
     # equal shards
@@ -53,6 +53,13 @@ def main():
     part = run_query(dict(slice_rays(whole, lo * w, hi * w), B=1, h=h, w=w), dev)
     rows = all_gather_depth_rows(part["depth"][0, lo:hi], h)
     ref = run_query(whole, dev)
+    assert rows.shape == (h, w) and torch.equal(rows, ref["depth"][0])
+    # the same with the feature map cut to the rank's rows + the RoIAlign halo (dist.crop_rows): the per-ray
+    # features, and so the whole map, are those of the uncut query bit for bit
+    mine = slice_rays(whole, lo * w, hi * w)
+    cut, fg, r0 = crop_rows(mine, whole["feat_grid"], lo, hi, 4)
+    part = run_query(dict(cut, feat_grid=fg, B=1, h=fg.shape[2], w=w), dev)
+    rows = all_gather_depth_rows(part["depth"][0, lo - r0:hi - r0], h)
     assert rows.shape == (h, w) and torch.equal(rows, ref["depth"][0])
     dist.barrier()
     if rank == 0:

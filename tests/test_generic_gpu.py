@@ -164,6 +164,33 @@ def test_query_at_other_widths(cuda, Cr, roi_out, Co, gf, off_kind, Lm, Lv, pos_
     assert torch.equal(z, out["pred_pos"][:, 2])
 
 
+def test_query_at_other_widths_in_slabs(cuda, monkeypatch):
+    """The layer-by-layer query walks the pairs in slabs (bounded memory: rows [slab, D] instead of the
+    reference's [P, D]); slab boundaries anywhere give the same bits as one slab (every step is row-local)."""
+    from implicit_depth_amd import IEF, IMNet, generic
+    from implicit_depth_amd.query import lidf_query
+    from util import orc, to_dev
+    scene = orc.synthetic_scene(2, 13, 17, 6, seed=5, ragged=True)
+    D, gf = scene["D"], 128
+    prob_p, off_p = orc.init_decoder("IMNET", D, 7, 5.0, gf=gf), orc.init_decoder("IEF", D, 8, 5.0, gf=gf)
+    prob, off = IMNet(D, 1, gf), IEF(cuda, D, 1, gf, n_iter=2)
+    prob.load_state_dict(prob_p), off.load_state_dict(off_p)
+    prob, off = prob.to(cuda).eval(), off.to(cuda).eval()
+    s = to_dev(scene, cuda)
+
+    def run():
+        with torch.no_grad():
+            return lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                              s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
+    whole = run()
+    assert scene["P"] > 300
+    for slab in (1, 97, 128, scene["P"] - 1):
+        monkeypatch.setattr(generic, "QUERY_SLAB", slab)
+        part = run()
+        for k in ("pred_offset", "pred_prob_end", "pair_pred_pos", "pred_prob_end_softmax", "pred_pos", "max_pair_id"):
+            assert torch.equal(part[k], whole[k]), (slab, k)
+
+
 def _pointnet_params(cin, outc, gf, seed, scale=1.5):
     g = torch.Generator().manual_seed(seed)
     half = outc // 2

@@ -234,6 +234,18 @@ def _gloo_rows_worker(rank, world, port, h, q):
             (mine["pair_ray"] < mine["R"]).all()
         full = all_gather_depth_rows(fake_query(mine).reshape(hi - lo, w), h)
         ok = ok and full.shape == (h, w) and torch.equal(full, fake_query(scene).reshape(h, w))
+        # dist.crop_rows: the feature map cut to the shard's rows + halo. A stand-in for the RoIAlign box
+        # (pixel +- 2 rows, clamped on the image it is given) reads the same values from the cut map
+        from implicit_depth_amd.dist import crop_rows
+
+        def fake_roi(s, fg):   # per ray: sum of channel 0 over rows y-2 .. y+2 (clamped) of its column
+            hh = fg.shape[2]
+            x, y = s["ray_pix"][:, 0].long(), s["ray_pix"][:, 1].long()
+            return sum(fg[0, 0, (y + d).clamp(0, hh - 1), x] for d in range(-2, 3))
+        cut, fg, r0 = crop_rows(mine, scene["feat_grid"], lo, hi, 2)
+        ok = ok and fg.shape[2] == min(h, hi + 2) - max(0, lo - 2) and r0 == max(0, lo - 2)
+        ok = ok and torch.equal(fake_roi(cut, fg), fake_roi(mine, scene["feat_grid"]))
+        ok = ok and torch.equal(cut["ray_flat"] + r0 * w, mine["ray_flat"])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

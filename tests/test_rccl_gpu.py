@@ -77,6 +77,36 @@ def test_two_ranks_sharing_the_gpu(cuda):
         assert rec["ms_per_step"] >= max(col["ms_per_step_by_rank"]) - 1e-3
 
 
+def test_eight_ranks_sharing_the_gpu(cuda):
+    """The shapes of the 8-GPU run that no box of this work could make: world = 8 on
+    cuda:0 with gloo as the transport (LIDF_TEST_SHARE_GPU, test-only, never a measurement) — the worker's
+    gathers (equal, ragged and row shards, feature map cut to the shard), BASELINE configs[2] (32 frames:
+    4 per rank), configs[4] (4 frames x 256 candidates per rank) and one frame split into 8 row shards
+    (240 rows: 30 per rank, feature map cut to 38): every rank joins, its slot of the gather holds its own
+    maps, ONE line on stdout, the whole-job point count and the max-over-ranks clock are consistent."""
+    share = {"LIDF_TEST_SHARE_GPU": "1"}
+    r = _torchrun([os.path.join(ROOT, "tests", "rccl_worker.py")], 29621, nproc=8, extra_env=share)
+    assert r.returncode == 0 and "RCCL_WORKER_OK world=8" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    frame = 240 * 320
+    for extra, pts, scaling in ((["--config", "2"], 8 * 4 * frame * 64, "weak"),
+                                (["--config", "4"], 8 * 4 * frame * 256, "weak"),
+                                (["--shard", "rays"], frame * 64, "strong")):
+        r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                       "--no-cpu-baseline"] + extra, 29622, nproc=8, extra_env=share, timeout=1200)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        rec = json.loads(lines[0])
+        col = rec["collective"]
+        assert rec["n_gpus"] == 8 and rec["scaling"] == scaling
+        assert col["ranks_seen"] == 8 and len(col["ms_per_step_by_rank"]) == 8
+        assert col["gathered_equals_local"] is True and col["points_all_ranks"] == pts
+        assert abs(rec["value"] - pts / rec["ms_per_step"] / 1e3) <= 0.01 * rec["value"]
+        assert rec["ms_per_step"] >= max(col["ms_per_step_by_rank"]) - 1e-3
+        if scaling == "strong":
+            assert rec["config"]["rays_per_gpu"] == 30 * 320
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
