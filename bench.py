@@ -428,6 +428,64 @@ def secondary(args):
         what = ("training step of the query (lidf_query_train): ROI pooling, decoder input rows, both "
                 "decoders forward + backward, gradients to feat_grid / vox_feat / parameters; "
                 "240x320 rays x %d candidates; FLOP = 3 x forward" % max(args.samples // 8, 1))
+    elif args.workload == "train-refine":
+        # one training step of stage 2 at the reference's per-GPU shape (trainers/train_refine.py:393-399,
+        # train_lidf.yaml: batch 8 per GPU, 20,000 miss rays + 10,000 valid points per image): RefineNet.forward
+        # (2 x get_pred_refine) + backward to every PointNet2Stage / IEF parameter; stage 1 is frozen there
+        # (its pred_pos / max_pair_id arrive detached)
+        from implicit_depth_amd import PointNet2Stage
+        from implicit_depth_amd.query import lidf_refine_train
+        from implicit_depth_amd.synthetic import synthetic_scene
+        Bt, n_miss, n_val = 8, 20000, 10000
+        scene = synthetic_scene(Bt, 240, 320, 1, seed=1236)
+        gc = torch.Generator().manual_seed(77)
+        sel = torch.cat([torch.randperm(240 * 320, generator=gc)[:n_miss].sort().values + b * 240 * 320
+                         for b in range(Bt)])
+        rays = {k: scene[k][sel].contiguous().to(dev) for k in ("ray_dir", "ray_pix", "ray_bid", "ray_flat")}
+        # occupied voxels = the cells the rays' candidates fall into (a real frame has 50-150 of the 729)
+        occ, inv = torch.unique(scene["pair_vox"][sel].long(), return_inverse=True)
+        V = int(occ.numel())
+        pair_vox = inv.int().contiguous().to(dev)                        # one candidate per ray: pair r = ray r
+        t_mid = scene["pair_t"][sel].mean(1, keepdim=True)
+        pred_pos = (scene["ray_dir"][sel] * t_mid).contiguous().to(dev)  # stage 1's prediction, detached
+        max_pair_id = torch.arange(sel.numel(), dtype=torch.int64, device=dev)
+        vc = scene["vox_center"][occ]
+        vb = torch.cat((vc - 0.125, vc + 0.125), 1).to(dev)
+        vbid_h = (occ // 729).int()
+        vbid = vbid_h.to(dev)
+        rgb = torch.randn(Bt, 3, 240, 320, generator=gc).to(dev)
+        feat = scene["feat_grid"].to(dev)
+        valid_inp = (torch.randn(Bt * n_val, 6, generator=gc) * 0.2).to(dev)
+        parts = []
+        for b in range(Bt):   # the valid points of a frame fall into that frame's voxels
+            own = torch.nonzero(vbid_h == b)[:, 0]
+            parts.append(own[torch.randint(0, own.numel(), (n_val,), generator=gc)])
+        valid_vox = torch.cat(parts).int().to(dev)
+        torch.manual_seed(99)
+        pnet = PointNet2Stage(6, 128, 32).to(dev).train()
+        offr = IEF(dev, 334, 1, 64, n_iter=2).to(dev).train()
+        offr.load_state_dict(init_decoder_params("IEF", 334, 9, 5.0))
+        offr = offr.to(dev)
+        P = sel.numel()                                                  # "points" of this record = rays
+
+        def step():
+            for m in (pnet, offr):
+                for p in m.parameters():
+                    p.grad = None
+            pos, _ = lidf_refine_train(rays["ray_dir"], rays["ray_pix"], rays["ray_bid"], rays["ray_flat"], pred_pos,
+                                       max_pair_id, pair_vox, vb, vbid, rgb, feat, valid_inp, valid_vox, pnet, offr,
+                                       forward_times=2)
+            pos.sum().backward()
+        flop_alg, bytes_alg, name = 0.0, 0.0, ("lidf_points_kernel<TRAIN> + lidf_linear_kernel (PointNet2Stage layers) "
+                                              "+ lidf_dgrad_chain_kernel + lidf_wgrad2_kernel")
+        what = ("training step of stage 2 (lidf_refine_train = RefineNet.forward 'train', trainers/train_refine.py:"
+                "393-399): 2 x get_pred_refine over %d frames x %d miss rays + %d valid points, %d voxels, forward "
+                "+ backward to every PointNet2Stage / IEF(D=334) parameter; rows = rays" % (Bt, n_miss, n_val, V))
+        # forward FLOP per ray and iteration: IEF(334 + 16) layer 1 once + per pass the encoding columns and
+        # layers 2-4; PointNet2Stage 35,008 MAC per point over (valid + predicted) points
+        ief = 2.0 * 256 * 334 + 2 * (2.0 * 256 * 16 + 2.0 * (256 * 128 + 128 * 64 + 64))
+        pn = 2.0 * (6 * 32 + 32 * 64 + 128 * 128 + 128 * 128) * (Bt * n_val + P) / P
+        train_refine_fwd = 2 * (ief + pn)
     elif args.workload == "train":
         # one training step of both decoders at the decoder boundary: forward that keeps the
         # activations + backward (input and parameter gradients), liblidf_hip on both sides
@@ -478,6 +536,9 @@ def secondary(args):
     elif args.workload == "decoders":
         # rows mode: 2 nets x 49 k-quads x 8 tiles x 4 + 3 passes x 654 v_mfma_f32_32x32x2_f32 per 32 rows
         flop_exec, basis = (2 * 49 * 8 * 4 + 3 * 654) * 4096 / 32.0, "issued MFMA FLOP"
+    elif args.workload == "train-refine":
+        flop_exec, basis = 3.0 * train_refine_fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
+        flop_alg = flop_exec
     elif args.workload in ("train", "train-query"):
         # 3 x the forward FLOP of the formulation that runs (forward, input gradient, weight
         # gradient), without tile padding: layers 2-4 per pass 2 (256*128 + 128*64 + 64); layer 1
@@ -717,7 +778,8 @@ def main():
                     help="--workload e2e: frame = one sync-free library call per batch (default), graph = "
                          "that call replayed from a HIP graph, stepwise = one call per reference method")
     ap.add_argument("--workload", default="query",
-                    choices=["query", "query+refine", "decoders", "embed", "train", "train-query", "e2e"],
+                    choices=["query", "query+refine", "decoders", "embed", "train", "train-query", "train-refine",
+                             "e2e"],
                     help="query = BASELINE configs[1] (default, the headline metric); query+refine = "
                          "configs[3] (stage 1 + 2 x get_pred_refine); decoders = IMNet+IEF on a "
                          "materialised [P,385] input (the reference's decoder boundary); embed = "
@@ -739,7 +801,7 @@ def main():
                                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     claim_stdout()
-    if args.workload in ("decoders", "embed", "train", "train-query"):
+    if args.workload in ("decoders", "embed", "train", "train-query", "train-refine"):
         return secondary(args)
     if args.workload == "e2e":
         return e2e(args)

@@ -62,6 +62,7 @@ hipError_t lidf_launch_pointnet_chain_dev(int, const float*, const float*, const
                                           float*, long long, int, long long, const int*,
                                           const int*, const int*, const int*, int, hipStream_t);
 hipError_t lidf_launch_vox2(const Vox2Args&, hipStream_t);
+hipError_t lidf_launch_ief16(const Ief16Args&, int, hipStream_t);
 int lidf_pointnet_lds_max_voxels(void);
 size_t lidf_pointnet_sort_bytes(long long, long long);
 hipError_t lidf_launch_sort_idx(const int*, long long, const int*, long long, void*, const int**,
@@ -2076,8 +2077,20 @@ static int run_chain_train(const LidfDecoder* dec, int dcore, const L1Map& m, co
 // scratch of refine_ief_factorised: [layer-1 stream of the per-voxel launch | of the per-ray launch (ROI +
 // direction columns, sized for the widest direction embedding) | stream + aux of the chain]
 #define REFINE_RAY_K (128 + 3 + 6 * 16)
+// ... | stream + aux of the 16 x 16 x 4 decoder (lidf_ief16.hip): E <= 99 embed(pos) columns = 7 k-quads]
+static size_t ief16_stream_bytes(int E) { return (size_t)(((E + 15) / 16) * 16 + IEF16_PASS_QUADS) * 1024; }
 static size_t refine_fact_bytes(int D) {
-    return linex_stream_bytes(128) + linex_stream_bytes(REFINE_RAY_K) + chain_stream_bytes(D - 128);
+    return linex_stream_bytes(128) + linex_stream_bytes(REFINE_RAY_K) + chain_stream_bytes(D - 128) +
+           align_up(ief16_stream_bytes(3 + 6 * 16), 256) + align_up(IEF16_AUX_FLOATS * 4, 256);
+}
+// LIDF_IEF16=0 in the environment: the 32 x 32 rows kernel of rounds 2-3 instead (A/B measurements)
+static bool use_ief16() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LIDF_IEF16");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
 }
 
 static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox_feat, int64_t V,
@@ -2116,12 +2129,40 @@ static int refine_ief_factorised(const LidfDecoder* off, int D, const float* vox
         Lr.n_dev = R_dev;
         if ((rc = run_linex(Lr, (float*)s_ray, cus, st, pack_mode))) return rc;
     }
+    // the decoder on 16-ray sub-tiles (lidf_ief16.hip): its stream rides behind the others
+    char* s16 = s_chain + chain_stream_bytes(D - 128);
+    float* aux16 = (float*)(s16 + align_up(ief16_stream_bytes(3 + 6 * 16), 256));
+    if (pack_mode != 2) {
+        StreamLayout lay = {};
+        lay.nets = 1; lay.mode = LIDF_MODE_IEF16;
+        lay.total = (int)(ief16_stream_bytes(E) / 4);
+        L1Map m16 = {};
+        m16.n0 = E; m16.c0 = 256;
+        const NetW nw = to_netw(off, D);
+        CHECK_HIP(pack_stream(lay, nw, nw, m16, (float*)s16, aux16, st));
+    }
+    if (!use_ief16() || pack_mode == 1) {
+        if (ev_rows && ev_rows[0] && pack_mode != 1) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[0], st));
+        rc = run_chain_train(off, D, rows_map(E, 256, 0, 0, 0), inp_embed ? inp_embed + 256 : nullptr, D, R,
+                             end_voxel, nullptr, voxpart, raypart, nullptr, nullptr, out, s_chain, cus, st,
+                             LIDF_MODE_ROWS_GATHER, pack_mode, R_dev);
+        if (!rc && ev_rows && ev_rows[1] && pack_mode != 1) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[1], st));
+        return rc;
+    }
+    if (R <= 0) return LIDF_OK;
     if (ev_rows && ev_rows[0]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[0], st));   // (benchmarks only)
-    rc = run_chain_train(off, D, rows_map(E, 256, 0, 0, 0), inp_embed ? inp_embed + 256 : nullptr, D, R,
-                         end_voxel, nullptr, voxpart, raypart, nullptr, nullptr, out, s_chain, cus, st,
-                         LIDF_MODE_ROWS_GATHER, pack_mode, R_dev);
-    if (!rc && ev_rows && ev_rows[1]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[1], st));
-    return rc;
+    Ief16Args ia = {};
+    ia.stream = (const float*)s16; ia.aux = aux16; ia.KQ = (E + 15) / 16; ia.E = E;
+    ia.n = R; ia.n_dev = R_dev;
+    ia.X = inp_embed + 256; ia.ldx = D;
+    ia.vox = end_voxel; ia.voxpart = voxpart; ia.raypart = raypart;
+    ia.npass = off->is_ief ? off->n_iter : 1;
+    ia.init = off->is_ief ? off->init_offset : 0.f;
+    ia.sigmoid = off->use_sigmoid;
+    ia.out = out;
+    CHECK_HIP(lidf_launch_ief16(ia, cus, st));
+    if (ev_rows && ev_rows[1]) CHECK_HIP(hipEventRecord((hipEvent_t)ev_rows[1], st));
+    return LIDF_OK;
 }
 
 LIDF_API size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views) {

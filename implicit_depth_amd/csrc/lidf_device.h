@@ -56,7 +56,10 @@ enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_
        LIDF_MODE_FUSED_H = 4,   // split-f16 stream of lidf_points_h.hip
        LIDF_MODE_TRAIN = 5,     // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
        LIDF_MODE_ROWS_GATHER = 6,    // rows mode whose layer-1 accumulators start from gathered rows
-       LIDF_MODE_PNET_CHAIN = 7 };   // pack jobs only: the per-point chain stream of a PointNet2Stage (PN_* below)
+       LIDF_MODE_PNET_CHAIN = 7,     // pack jobs only: the per-point chain stream of a PointNet2Stage (PN_* below)
+       LIDF_MODE_IEF16 = 8 };        // pack jobs only: the stage-2 decoder's 16 x 16 x 4 stream (lidf_ief16.hip)
+#define IEF16_PASS_QUADS 168   // 2 + 1 bias quads, 4 u quads, 128 layer-2 quads, 32 layer-3 quads, 1 padding quad
+#define IEF16_AUX_FLOATS 72    // w4 [64] | b4 [1] (+ padding)
 
 // One decoder's parameters as the packer sees them.
 struct NetW {
@@ -315,6 +318,25 @@ struct RefineStepArgs {
     const int* row0_dev;
     float *zero0, *zero1;
     long long nzero0, nzero1;
+};
+
+// Arguments of the stage-2 decoder on 16 x 16 x 4 tiles (lidf_ief16.hip).
+struct Ief16Args {
+    const float* stream;   // (16 KQ + IEF16_PASS_QUADS) KiB
+    const float* aux;      // IEF16_AUX_FLOATS
+    int KQ;                // layer-1 k-quads of 16 columns
+    int E;                 // embed(pos) columns (operand columns beyond it are zero)
+    long long n;           // rays
+    const int* n_dev;      // optional device-side count (n = capacity)
+    const float* X;        // [n, ldx]: embed(pos) columns start at X (the caller offsets the row)
+    long long ldx;
+    const int* vox;        // [n] row of voxpart (the end voxel)
+    const float* voxpart;  // [V, 256]  W1[:, vox feat] f + b1 (+ c)
+    const float* raypart;  // [n, 256]  W1[:, ROI | dir] rayfeat
+    int npass;
+    float init;
+    int sigmoid;
+    float* out;            // [n]
 };
 
 // Arguments of the two-layer per-voxel kernel (lidf_linear.hip: lidf_vox2_kernel).

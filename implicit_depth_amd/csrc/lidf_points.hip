@@ -137,6 +137,38 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
     }
 }
 
+// element e of the stage-2 decoder's 16 x 16 x 4 stream (layout: lidf_ief16.hip); m.n0 = E embed(pos)
+// columns starting at w1 column m.c0
+__device__ float ief16_stream_value(const NetW& n, const L1Map& m, int e) {
+    const int KQ = (m.n0 + 15) / 16;
+    int quad = e / 256;
+    const int lane = (e % 256) / 4, r = e & 3;
+    const int j = lane & 15, g = lane >> 4;
+    if (quad < KQ * 16) {
+        const int kq = quad / 16, To = quad % 16;
+        const int x = 16 * kq + 4 * g + r;
+        return x < m.n0 ? n.w1[(size_t)(16 * To + j) * n.ld1 + m.c0 + x] : 0.f;
+    }
+    quad -= KQ * 16;
+    if (quad < 2)   // bias quads of layer 2: component r = b2 of output tile 4 quad + r, in group 0
+        return g == 0 ? n.b2[16 * (4 * quad + r) + j] : 0.f;
+    quad -= 2;
+    if (quad < 132) {   // layer 2, k-major: a u quad in front of every fourth input tile
+        const int blk = quad / 33, in = quad % 33;
+        if (in == 0) return (g == 0 && n.is_ief) ? ief_u(n, 16 * (4 * blk + r) + j) : 0.f;
+        const int T = 4 * blk + (in - 1) / 8, To = (in - 1) % 8;
+        return n.w2[(size_t)(16 * To + j) * LIDF_H1 + 16 * T + 4 * g + r];
+    }
+    quad -= 132;
+    if (quad < 1) return g == 0 ? n.b3[16 * r + j] : 0.f;   // bias quad of layer 3
+    quad -= 1;
+    if (quad < 32) {
+        const int T = quad / 4, To = quad % 4;
+        return n.w3[(size_t)(16 * To + j) * LIDF_H2 + 16 * T + 4 * g + r];
+    }
+    return 0.f;
+}
+
 __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& net0, const NetW& net1,
                                           const L1Map& m, float* stream, float* aux) {
     if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
@@ -145,6 +177,12 @@ __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& n
         // (net0 carries w_p1, b_p1, w_p2, b_p2, w_p3, w_p4, b_p4 in w1, b1, w2, b2, w3, b3, w4)
         const PnetW w = {net0.w1, net0.b1, net0.w2, net0.b2, net0.w3, net0.b3, net0.w4};
         if (e < lay.total) stream[e] = pn_stream_value(w, e);
+        return;
+    }
+    if (lay.mode == LIDF_MODE_IEF16) {
+        if (e < lay.total) stream[e] = ief16_stream_value(net0, m, e);
+        if (e < IEF16_AUX_FLOATS)
+            aux[e] = e < 64 ? net0.w4[e] : (e == 64 ? net0.b4[0] : 0.f);
         return;
     }
     NetW nets[2] = {net0, net1};
