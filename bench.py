@@ -615,7 +615,8 @@ def e2e(args):
         # batches in turn, so that the low-occupancy stretches of one frame (PointNet, per-voxel layers,
         # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
         S = max(1, args.streams)
-        runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision)
+        runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision,
+                                  guard_every=args.guard_every)
                    for _ in range(S)]
         lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
         for r in runners:
@@ -701,7 +702,7 @@ def e2e(args):
         "config": {"workload": "secondary: whole evaluation path of %d 240x320 frame(s): valid points, "
                                "occupied voxels, PointNet2Stage, miss rays, compact ray/voxel pairs, fused "
                                "query, 2 x get_pred_refine, eval metrics; geometry-derived ragged scene" % B,
-                   "mode": mode, "host_syncs": syncs, "streams": max(1, args.streams) if mode != "stepwise" else 1,
+                   "mode": mode, "host_syncs": syncs, "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV},
         "ms_per_frame": round(elapsed / args.steps * 1e3 / B, 4),
@@ -774,6 +775,10 @@ def main():
                     help="query workload: gf_dim of both decoders (model.imnet_gf; 64 in every shipped config = "
                          "the fused kernels). Another value runs the layer-by-layer path of implicit_depth_amd/"
                          "generic.py (rows materialised in 614,400-pair slabs): a secondary record, no roofline")
+    ap.add_argument("--guard-every", type=int, default=1,
+                    help="--workload e2e (frame / graph): FrameRunner(guard_every=N) — the packed weight streams are "
+                         "re-validated (one fingerprint launch over every module + two early-exit pack launches) on "
+                         "every N-th frame only; 1 (default) = every frame")
     ap.add_argument("--e2e-mode", default="frame", choices=["frame", "graph", "stepwise"],
                     help="--workload e2e: frame = one sync-free library call per batch (default), graph = "
                          "that call replayed from a HIP graph, stepwise = one call per reference method")
