@@ -36,6 +36,9 @@ PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 F_EXEC_H = 3 * 406 * 32768 / 32.0  # = 1,247,232
 PEAK_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (sustained under the power
 #                           cap with random operands: ~1.4-1.6 PFLOP/s, scripts/mfma_power_ubench.hip)
+# stage-2 decoder, issued FLOP per ray: on 16 x 16 x 4 sub-tiles (lidf_ief16.hip) / on 32 x 32 x 2 tiles (rounds 2-3)
+F_IEF16 = (4 * 16 * 4 + 2 * (12 + 16 + 512 + 128)) * 2048 / 16.0   # = 203,776
+F_IEF32 = (7 * 8 * 4 + 2 * 654) * 4096 / 32.0                      # = 196,096
 DTYPE_F16X3 = "f16x3 (f32 operands split into two f16 pieces, 3 products per term, f32 accumulate)"
 
 
@@ -686,9 +689,10 @@ def e2e(args):
         npn = c["NPN"] if mode != "stepwise" else 0
         roof = {
             "points": dict(frac("lidf_points_fused_kernel", F_EXEC * P) or {}, flop_per_point_exec=F_EXEC),
-            # stage-2 decoder rows: 7 layer-1 k-quads x 8 tiles x 4 + 2 passes x 654 matrix instructions per 32 rays
-            "ief_rows": dict(frac("lidf_points_kernel<6>", (7 * 8 * 4 + 2 * 654) * 4096 / 32.0 * R) or {},
-                             wave_tiles=(R + 31) // 32),
+            # stage-2 decoder (lidf_ief16_kernel): per 16 rays 4 x 16 x 4 layer-1 + 2 passes x (12 bias + 16 rank-1 +
+            # 512 + 128) v_mfma_f32_16x16x4_f32 of 2048 FLOP
+            "ief": dict(frac("lidf_ief16_kernel", F_IEF16 * R) or frac("lidf_points_kernel<6>", F_IEF32 * R) or {},
+                        sub_tiles=(R + 15) // 16, flop_per_ray_exec=F_IEF16),
             # PointNet2Stage chains of one refine pass: 44 (stage 1) and 444 (stage 2) matrix instructions per 32 points
             "pointnet_chain2": frac("lidf_pointnet_chain_kernel<2, true>", 444 * 4096 / 32.0 * (NV + 2 * npn) / 3.0),
             "l1part": frac("lidf_l1part_pair_kernel", 2.0 * 155 * (512 + 256) * R + 2.0 * 129 * 512 * V),
@@ -1091,20 +1095,24 @@ def main():
             R = scene["R"]
             # issued per 32 rays and iteration: 7 layer-1 k-quads (embed(pos); the ROI / direction columns are
             # a per-ray product formed once per call) x 8 tiles x 4 + 2 passes x 654 v_mfma_f32_32x32x2
-            f_ief = (7 * 8 * 4 + 2 * 654) * 4096 / 32.0
+            ief16 = os.environ.get("LIDF_IEF16", "1") != "0"
+            f_ief = F_IEF16 if ief16 else F_IEF32
             n_pn = refine.n_valid + R
             f_pn = (44 + 444) * 4096 / 32.0                          # issued FLOP per PointNet point
             a_ief, a_pn = f_ief * R / (t_ief * 1e-3) / 1e12, f_pn * n_pn / (t_pn * 1e-3) / 1e12
             wt = (R + 31) // 32
             line["roofline_stage2"] = {
                 "refine_ms_per_step": round(elapsed / args.steps * 1e3 - 0.0, 4),
-                "ief_rows": {"kernel": "lidf_points_kernel<LIDF_MODE_ROWS_GATHER>", "bound": "mfma",
+                "ief_rows": {"kernel": "lidf_ief16_kernel" if ief16 else "lidf_points_kernel<LIDF_MODE_ROWS_GATHER>", "bound": "mfma",
                              "kernel_ms": round(t_ief, 4), "launches_per_step": 2,
                              "flop_per_ray_exec": f_ief, "achieved": round(a_ief, 2), "peak": PEAK_F32_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(a_ief / PEAK_F32_TFLOPS, 4),
-                             "wave_tiles": wt, "rounds": "%d wave-tiles over 1024 SIMDs = %.2f -> %d rounds"
-                             % (wt, wt / 1024.0, -(-wt // 1024))},
-                "pointnet": {"kernel": "lidf_pointnet_chain_kernel<1|2> + per-voxel lidf_linear_kernel",
+                             "wave_tiles": wt,
+                             "rounds": ("%d 16-ray sub-tiles over 1024 wavefronts = %.2f -> %d half-rounds"
+                                        % (2 * wt, 2 * wt / 1024.0, -(-2 * wt // 1024)) if ief16 else
+                                        "%d wave-tiles over 1024 SIMDs = %.2f -> %d rounds"
+                                        % (wt, wt / 1024.0, -(-wt // 1024)))},
+                "pointnet": {"kernel": "lidf_pointnet_chain_kernel<1|2> + lidf_vox2_kernel (per-voxel layers)",
                              "bound": "mfma / atomic max-pool", "ms": round(t_pn, 4), "launches_per_step": 2,
                              "points": n_pn, "flop_per_point_exec": f_pn, "achieved": round(a_pn, 2),
                              "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_pn / PEAK_F32_TFLOPS, 4)},

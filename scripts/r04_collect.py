@@ -11,7 +11,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r4p")
-OUT = os.path.join(ROOT, "profiles")
+# run on the GPU box (the rocprofv3 databases are too large to travel back): summaries land in
+# gpurun_out/r4prof, which is then copied into profiles/
+OUT = os.path.join(ROOT, sys.argv[1]) if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
+os.makedirs(OUT, exist_ok=True)
 
 
 def stats(db, out, cmd):
@@ -69,9 +72,10 @@ def main():
     # headline counters through the round-2 summariser (HBM: corrected 2 x FETCH + WRITE; matrix-pipe counters)
     subprocess.run([sys.executable, j(ROOT, "scripts", "prof_summary.py"), "r04tmp", j(SRC, "kt.db"), j(SRC, "fetch.db"),
                     j(SRC, "write.db"), j(SRC, "mfma.db")], check=True, stdout=subprocess.DEVNULL)
-    os.replace(j(OUT, "r04tmp_hbm_pmc.csv"), j(OUT, "r04_hbm_pmc.csv"))
-    os.replace(j(OUT, "r04tmp_mfma_pmc.csv"), j(OUT, "r04_mfma_pmc.csv"))
-    os.remove(j(OUT, "r04tmp_kernel_stats.csv"))
+    P = j(ROOT, "profiles")
+    os.replace(j(P, "r04tmp_hbm_pmc.csv"), j(OUT, "r04_hbm_pmc.csv"))
+    os.replace(j(P, "r04tmp_mfma_pmc.csv"), j(OUT, "r04_mfma_pmc.csv"))
+    os.remove(j(P, "r04tmp_kernel_stats.csv"))
     r = json.load(open(j(OUT, "r04_bench_n1.json")))
     print("headline", r["value"], r["ms_per_step"], r["roofline"]["frac"], r["roofline"]["traffic"])
 

@@ -32,5 +32,8 @@ cp /tmp/p_kt/r_results.db $O/kt.db; cp /tmp/p_kr/r_results.db $O/kt_refine.db; c
 cp /tmp/p_tr/r_results.db $O/kt_train_refine.db
 cp /tmp/p_f/r_results.db $O/fetch.db; cp /tmp/p_w/r_results.db $O/write.db; cp /tmp/p_m/r_results.db $O/mfma.db 2>/dev/null
 cp /tmp/p_ce/r_results.db $O/clock_e2e.db 2>/dev/null
+cp profiles/hbm_traffic.json /tmp/hbm_traffic.keep 2>/dev/null
+python scripts/r04_collect.py gpurun_out/r4prof
+rm -f $O/*.db
 tail -n 5 $O/err.txt
-head -c 300 $O/bench_n1.json; echo; ls -la $O | head -50
+head -c 300 $O/bench_n1.json; echo; ls gpurun_out/r4prof | wc -l
