@@ -605,7 +605,7 @@ def e2e(args):
         def step(marks=None):
             with torch.no_grad():
                 ok, dd = pl.lidf_forward(batch, feat, pnet, prob, off, opt, precision=args.precision,
-                                         workspace=state["ws"], marks=marks)
+                                         workspace=state["ws"], marks=marks, offsets=args.offsets)
                 assert ok
                 state["ws"] = dd["workspace"]
                 pl.refine_forward(dd, pnet_r, offr, opt, precision=args.precision)
@@ -619,7 +619,7 @@ def e2e(args):
         # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
         S = max(1, args.streams)
         runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision,
-                                  guard_every=args.guard_every)
+                                  guard_every=args.guard_every, offsets=args.offsets)
                    for _ in range(S)]
         lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
         for r in runners:
@@ -706,7 +706,11 @@ def e2e(args):
         "config": {"workload": "secondary: whole evaluation path of %d 240x320 frame(s): valid points, "
                                "occupied voxels, PointNet2Stage, miss rays, compact ray/voxel pairs, fused "
                                "query, 2 x get_pred_refine, eval metrics; geometry-derived ragged scene" % B,
-                   "mode": mode, "host_syncs": syncs, "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
+                   "mode": mode, "host_syncs": syncs,
+                   "offsets": ("selected pairs only (opt-in: pred_offset / pair_pred_pos undefined elsewhere; pred_pos, "
+                               "depth, stage 2 and statistics bit-identical)" if args.offsets == "selected"
+                               else "every pair (the reference's data flow)"),
+                   "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV},
         "ms_per_frame": round(elapsed / args.steps * 1e3 / B, 4),
@@ -779,6 +783,11 @@ def main():
                     help="query workload: gf_dim of both decoders (model.imnet_gf; 64 in every shipped config = "
                          "the fused kernels). Another value runs the layer-by-layer path of implicit_depth_amd/"
                          "generic.py (rows materialised in 614,400-pair slabs): a secondary record, no roofline")
+    ap.add_argument("--offsets", default="all", choices=["all", "selected"],
+                    help="--workload e2e (frame / graph / stepwise): 'selected' = the offset decoder on the arg-max pair "
+                         "of every ray only (opt-in, FrameRunner(offsets=...)): pred_pos / depth / stage 2 / statistics "
+                         "bit-identical, pred_offset / pair_pred_pos defined at the selected pairs only. A secondary "
+                         "record that says so; the default and every other record compute the reference's full data flow")
     ap.add_argument("--guard-every", type=int, default=1,
                     help="--workload e2e (frame / graph): FrameRunner(guard_every=N) — the packed weight streams are "
                          "re-validated (one fingerprint launch over every module + two early-exit pack launches) on "

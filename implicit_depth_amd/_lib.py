@@ -49,6 +49,7 @@ class LidfQueryArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("rayfeat_out", C.c_void_p),
         ("precision", C.c_int32), ("packed", C.c_void_p),
+        ("offsets_selected", C.c_int32),
     ]
 
 
@@ -134,7 +135,7 @@ class LidfFrameArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("valid_idx_bid", C.c_void_p), ("valid_idx_flat", C.c_void_p), ("n_valid_idx", C.c_int64),
         ("pack_blob", C.c_void_p), ("pack_blob_bytes", C.c_size_t), ("pack_guard", C.c_void_p),
-        ("pack_mode", C.c_int32),
+        ("pack_mode", C.c_int32), ("offsets_selected", C.c_int32),
     ]
 
 

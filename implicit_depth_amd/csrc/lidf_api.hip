@@ -53,7 +53,11 @@ hipError_t lidf_launch_rayfeat_dev(const float*, float*, int, int, int, const fl
                                    const int*, long long, const int*, int, int, float*, int, hipStream_t);
 hipError_t lidf_launch_ray_reduce_dev(const float*, const float*, const int*, long long, long long,
                                       const int*, const int*, const int*, const int*, long long, float*,
-                                      long long*, float*, float*, hipStream_t);
+                                      long long*, float*, float*, hipStream_t, const int*, const float*, int*,
+                                      int*, float*);
+hipError_t lidf_launch_selected_finish(const long long*, const float*, const float*, long long, long long,
+                                       const int*, const int*, const int*, const int*, long long, float*,
+                                       float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_scan_dev(const int*, long long, const int*, int*, int*, int*, hipStream_t);
 hipError_t lidf_launch_ray_aabb_compact_dev(bool, const float*, const float*, const int*, const int*,
                                             long long, long long, const int*, const int*, int*,
@@ -444,7 +448,7 @@ LIDF_API int lidf_ray_reduce_f32(const float* pred_prob, const float* pair_pred_
 struct QueryWs {
     // the first four slots hold the packed weights (lidf_query_pack_f32 writes exactly this prefix)
     size_t stream_pts, aux_pts, stream_vox, stream_ray, packed_end, counter, voxpart, raypart, rayfeat,
-        box, total;
+        sel, box, total;
 };
 
 static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats = 0) {
@@ -470,6 +474,8 @@ static QueryWs query_ws(int64_t R, int64_t V, int L, int Lv, int64_t grid_floats
     w.voxpart = o;    o += align_up((size_t)(V > 0 ? V : 1) * 512 * 4, 256);
     w.raypart = o;    o += align_up((size_t)(R > 0 ? R : 1) * 512 * 4, 256);
     w.rayfeat = o;    o += align_up((size_t)(R > 0 ? R : 1) * (128 + Ed) * 4, 256);
+    // offsets_selected: the one-pair-per-ray list [ray | vox | t (2) | offset | position (3)]
+    w.sel = o;        o += align_up((size_t)(R > 0 ? R : 1) * 32, 256);
     // optional box-sum image + the list of clamped-box rays (last)
     w.box = o;        o += grid_floats > 0 ? align_up((size_t)(grid_floats + R + 1) * 4, 256) : 0;
     w.total = o;
@@ -637,6 +643,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
     const int D = 256 + 2 * E + Ed;
 
+    if (q->offsets_selected && q->precision != LIDF_PRECISION_F32) return LIDF_ERR_UNSUPPORTED;
     if (R == 0) return LIDF_OK;  // nothing to write (pipeline.py:686-687 early exit)
     if (!q->ray_dir || !q->ray_pix || !q->ray_bid || !q->pair_off) return LIDF_ERR_BAD_ARG;
     if (q->depth && !q->ray_flat) return LIDF_ERR_BAD_ARG;
@@ -740,10 +747,50 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
 #endif
             long long nt = (P + 127) / 128;
             if (ev_points_begin) CHECK_HIP(hipEventRecord((hipEvent_t)ev_points_begin, st));
-            if (split)
+            if (split) {
                 CHECK_HIP(lidf_launch_points_h(a, cus, st));
-            else
+            } else if (!q->offsets_selected) {
                 CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
+            } else {
+                // Offsets for the selected pairs only (LidfQueryArgs.offsets_selected): prob_dec on every pair
+                // (ONE net of the two-net stream and tables), the per-ray softmax / arg-max — which also leaves
+                // the selected pair of every ray as a one-pair-per-ray list —, offset_dec on that list (R
+                // points instead of P), then positions / depth / the selected pairs' slots of the per-pair arrays.
+                if (!q->max_pair_id) return LIDF_ERR_BAD_ARG;
+                PointsArgs ap = a;
+                ap.nets = 1; ap.part_ld = 512; ap.part_off = 0;
+                ap.out[1] = nullptr; ap.is_offset[0] = 0; ap.pair_pred_pos = nullptr;
+                CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, ap, (int)(nt < cus ? nt : cus), st));
+                char* sb = ws + w.sel;
+                const size_t Rc = (size_t)R;
+                int* sel_ray = (int*)sb;
+                int* sel_vox = (int*)(sb + Rc * 4);
+                float* sel_t = (float*)(sb + Rc * 8);
+                float* off_sel = (float*)(sb + Rc * 16);
+                float* pos_sel = (float*)(sb + Rc * 20);
+                CHECK_HIP(lidf_launch_ray_reduce_dev(q->pred_prob, nullptr, q->pair_off, R, P, dims,
+                                                     dims ? dims + 1 : nullptr, q->ray_bid, q->ray_flat,
+                                                     (long long)q->height * q->width, q->pred_prob_softmax,
+                                                     (long long*)q->max_pair_id, nullptr, nullptr, st, q->pair_vox,
+                                                     q->pair_t, sel_ray, sel_vox, sel_t));
+                PointsArgs ao = a;
+                ao.stream = stream_pts + (size_t)lf.net_quads * 256; ao.aux = aux_pts + LIDF_AUX_FLOATS;
+                ao.nets = 1; ao.part_ld = 512; ao.part_off = 256;
+                ao.n = R; ao.n_dev = dims;   // (dims[0] = R)
+                fill_net_args(ao, 0, q->off, off_sel, 1);
+                ao.out[1] = nullptr;
+                ao.pair_ray = sel_ray; ao.pair_vox = sel_vox; ao.pair_t = sel_t;
+                ao.pair_pred_pos = pos_sel;
+                ao.tile_counter = nullptr;   // (static split: R / 32 wave-tiles)
+                const long long ntr = (R + 127) / 128;
+                CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, ao, (int)(ntr < cus ? ntr : cus), st));
+                CHECK_HIP(lidf_launch_selected_finish((const long long*)q->max_pair_id, off_sel, pos_sel, R, P, dims,
+                                                      dims ? dims + 1 : nullptr, q->ray_bid, q->ray_flat,
+                                                      (long long)q->height * q->width, q->pred_offset,
+                                                      q->pair_pred_pos, q->pred_pos, q->depth, st));
+                if (ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)ev_points_end, st));
+                return LIDF_OK;
+            }
             if (ev_points_end) CHECK_HIP(hipEventRecord((hipEvent_t)ev_points_end, st));
         }
     }
@@ -752,7 +799,8 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         CHECK_HIP(lidf_launch_ray_reduce_dev(q->pred_prob, q->pair_pred_pos, q->pair_off, R, P, dims,
                                              dims ? dims + 1 : nullptr, q->ray_bid, q->ray_flat,
                                              (long long)q->height * q->width, q->pred_prob_softmax,
-                                             (long long*)q->max_pair_id, q->pred_pos, q->depth, st));
+                                             (long long*)q->max_pair_id, q->pred_pos, q->depth, st, nullptr,
+                                             nullptr, nullptr, nullptr, nullptr));
     }
     return LIDF_OK;
 }
@@ -1710,6 +1758,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         q.rayfeat_out = a->rayfeat;
         q.precision = a->precision;
         q.packed = a->packed_query;
+        q.offsets_selected = a->offsets_selected;
         // (f32 stage 2: the per-ray part of its decoder's layer 1, W1[:, ROI | dir] rayfeat[r] — constant
         // over the refine iterations — is a third table of the query's layer-1 launch)
         PointsArgs xr = {};

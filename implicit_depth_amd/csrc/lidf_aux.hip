@@ -486,7 +486,10 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                                        const int* __restrict__ ray_flat, long long hw,
                                        float* __restrict__ softmax, long long* __restrict__ maxid,
                                        float* __restrict__ pred_pos, float* __restrict__ depth,
-                                       const int* __restrict__ R_dev, const int* __restrict__ P_dev) {
+                                       const int* __restrict__ R_dev, const int* __restrict__ P_dev,
+                                       const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
+                                       int* __restrict__ sel_ray, int* __restrict__ sel_vox,
+                                       float* __restrict__ sel_t) {
     if (R_dev) R = *R_dev;   // device-side counts (the sync-free frame path)
     if (P_dev) P = *P_dev;
     const int lane = threadIdx.x & (G - 1);
@@ -590,6 +593,12 @@ __global__ void lidf_ray_reduce_kernel(const float* __restrict__ prob,
                 z = pos[3 * (size_t)my_bi + 2];
             }
             if (maxid) maxid[my_ray] = empty ? P : (long long)my_bi;
+            if (sel_ray) {   // the selected pair of the ray as a one-pair-per-ray list (offsets for those only)
+                sel_ray[my_ray] = (int)my_ray;
+                sel_vox[my_ray] = empty ? 0 : pair_vox[my_bi];
+                const f32x2 tt = empty ? f32x2{0.f, 0.f} : *(const f32x2*)(pair_t + 2 * (size_t)my_bi);
+                *(f32x2*)(sel_t + 2 * my_ray) = tt;
+            }
             if (pred_pos) {
                 pred_pos[3 * my_ray] = x;
                 pred_pos[3 * my_ray + 1] = y;
@@ -606,18 +615,63 @@ extern "C" hipError_t lidf_launch_ray_reduce_dev(const float* prob, const float*
                                                  const int* P_dev, const int* ray_bid,
                                                  const int* ray_flat, long long hw, float* softmax,
                                                  long long* maxid, float* pred_pos, float* depth,
-                                                 hipStream_t st) {
+                                                 hipStream_t st, const int* pair_vox = nullptr,
+                                                 const float* pair_t = nullptr, int* sel_ray = nullptr,
+                                                 int* sel_vox = nullptr, float* sel_t = nullptr) {
     if (R <= 0) return hipSuccess;
     const long long groups = (R + REDUCE_U - 1) / REDUCE_U;
     // (with device-side counts the list is a geometry-derived one: a handful of pairs per ray)
     if (P <= 8 * R || P_dev)
         hipLaunchKernelGGL((lidf_ray_reduce_kernel<8, REDUCE_U>), dim3((unsigned)((groups + 31) / 32)),
                            dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
-                           pred_pos, depth, R_dev, P_dev);
+                           pred_pos, depth, R_dev, P_dev, pair_vox, pair_t, sel_ray, sel_vox, sel_t);
     else
         hipLaunchKernelGGL((lidf_ray_reduce_kernel<64, REDUCE_U>), dim3((unsigned)((groups + 3) / 4)),
                            dim3(256), 0, st, prob, pos, off, R, P, ray_bid, ray_flat, hw, softmax, maxid,
-                           pred_pos, depth, R_dev, P_dev);
+                           pred_pos, depth, R_dev, P_dev, pair_vox, pair_t, sel_ray, sel_vox, sel_t);
+    return hipGetLastError();
+}
+
+// Offsets for the selected pairs only (LidfQueryArgs.offsets_selected): after the offset decoder ran on the
+// one-pair-per-ray list, ray r takes its position (or the dummy row's zeros, pipeline.py:452-454), the depth
+// map its z, and the selected pair's own slots of the per-pair arrays receive the values.
+__global__ void lidf_selected_finish_kernel(const long long* __restrict__ maxid, const float* __restrict__ off_sel,
+                                            const float* __restrict__ pos_sel, long long R, long long P,
+                                            const int* __restrict__ R_dev, const int* __restrict__ P_dev,
+                                            const int* __restrict__ ray_bid, const int* __restrict__ ray_flat,
+                                            long long hw, float* __restrict__ pred_offset,
+                                            float* __restrict__ pair_pred_pos, float* __restrict__ pred_pos,
+                                            float* __restrict__ depth) {
+    if (R_dev) R = *R_dev;
+    if (P_dev) P = *P_dev;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long m = maxid[r];
+    const bool empty = m < 0 || m >= P;
+    const float x = empty ? 0.f : pos_sel[3 * r], y = empty ? 0.f : pos_sel[3 * r + 1],
+                z = empty ? 0.f : pos_sel[3 * r + 2];
+    if (!empty) {
+        pred_offset[m] = off_sel[r];
+        pair_pred_pos[3 * m] = x;
+        pair_pred_pos[3 * m + 1] = y;
+        pair_pred_pos[3 * m + 2] = z;
+    }
+    if (pred_pos) {
+        pred_pos[3 * r] = x;
+        pred_pos[3 * r + 1] = y;
+        pred_pos[3 * r + 2] = z;
+    }
+    if (depth) depth[(long long)ray_bid[r] * hw + ray_flat[r]] = z;
+}
+extern "C" hipError_t lidf_launch_selected_finish(const long long* maxid, const float* off_sel, const float* pos_sel,
+                                                  long long R, long long P, const int* R_dev, const int* P_dev,
+                                                  const int* ray_bid, const int* ray_flat, long long hw,
+                                                  float* pred_offset, float* pair_pred_pos, float* pred_pos,
+                                                  float* depth, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_selected_finish_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, maxid,
+                       off_sel, pos_sel, R, P, R_dev, P_dev, ray_bid, ray_flat, hw, pred_offset, pair_pred_pos,
+                       pred_pos, depth);
     return hipGetLastError();
 }
 extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos, const int* off,

@@ -234,6 +234,8 @@ struct PointsArgs {
     const float* ray_dir;
     const float* voxpart;   // [V, nets*256]
     const float* raypart;   // [R, nets*256]
+    int part_ld, part_off;  // fused mode: row stride / first column (floats) of this launch's nets inside the two
+                            // tables (0, 0 = nets * 256, 0; one net of a two-net table: 512 and 0 or 256)
     const float* vox_center;
     int pos_rel, L;
     float r0, rscale, sqrt3, part_size;

@@ -592,8 +592,11 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
         g.dy = *(const float*)(rd + 4);
         g.dz = *(const float*)(rd + 8);
     };
+    // (the tables hold part_ld floats per row; this launch's nets start at column part_off — a launch may run
+    // one net of a two-net table)
+    const int part_ld = a.part_ld > 0 ? a.part_ld : a.nets * 256, part_off = a.part_ld > 0 ? a.part_off : 0;
     auto vox_row = [&](int vid, int net) {
-        return a.voxpart + ((size_t)vid * a.nets + net) * 256 + 4 * h;
+        return a.voxpart + (size_t)vid * part_ld + part_off + net * 256 + 4 * h;
     };
 
     // two-stage geometry prefetch: `cur` complete, `nxt` has its indices (directions are fetched
@@ -668,7 +671,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
                     todo &= ~m1;
                 }
                 bs = (((h ? m1 : m0) >> col) & 1u) ? 1.f : 0.f;
-                const float* rp = a.raypart + ((size_t)(h ? r1 : r0) * a.nets + net) * 256 + col;
+                const float* rp = a.raypart + (size_t)(h ? r1 : r0) * part_ld + part_off + net * 256 + col;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) arow[t] = rp[t * 32];
             };
@@ -750,7 +753,8 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
             // of this tile, or the first net of the next tile — into LDS while its layer 2 runs
             const bool last_net = net + 1 == a.nets;
             const unsigned vp_off =
-                (unsigned)(((last_net ? nxt.vid : cur.vid) * a.nets + (last_net ? 0 : net + 1)) * 1024 + 16 * h);
+                (unsigned)(((last_net ? nxt.vid : cur.vid) * part_ld + part_off + (last_net ? 0 : net + 1) * 256) * 4 +
+                           16 * h);
             float val = a.init[net];
             const int pass_base = nsb + l1_bytes;
             const float* ax = a.aux + net * LIDF_AUX_FLOATS;

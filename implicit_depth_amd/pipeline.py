@@ -103,7 +103,7 @@ def _mark(marks, name):
 
 
 def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=None, pred_mask=None,
-                 valid_idx=None, precision="f32", workspace=None, marks=None):
+                 valid_idx=None, precision="f32", workspace=None, marks=None, offsets="all"):
     """LIDF.forward for evaluation (models/pipeline.py:652-717): returns (success, data_dict).
     success False = one of the reference's early exits (no occupied voxel / no miss ray / no
     intersecting pair); data_dict then holds what was computed up to that point."""
@@ -161,7 +161,7 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
                        roi_inp_bbox=opt.roi_inp_bbox, roi_out_bbox=opt.roi_out_bbox, offset_range=opt.offset_range,
                        part_size=occ["part_size"], vox_center=vox_center,
                        pos_rel=opt.intersect_pos_type == "rel", ray_flat=dd["ray_flat"], depth=depth,
-                       want_rayfeat=True, precision=precision, workspace=workspace)
+                       want_rayfeat=True, precision=precision, workspace=workspace, offsets=offsets)
     dd.update(out)
     dd["pred_depth"] = depth
     _mark(marks, "query")
@@ -234,6 +234,9 @@ class FrameRunner:
     or "f16x3" (as lidf_query / lidf_refine).
     max_pairs bounds the pair list (default 32 per pixel: a ray crosses at most 25 cells of the 9^3
     grid); a frame with more pairs raises in result().
+    offsets="selected" (opt-in; see query.lidf_query): the offset decoder runs on the arg-max pair of every ray
+    only — pred_pos, the depth maps, stage 2 and the statistics are bit-identical, pred_offset / pair_pred_pos
+    are meaningful at the selected pairs only (other rows: NaN, or a previous frame's selected values).
 
     Weight streams: the runner owns ONE blob with the packed streams of all its modules and the
     device-side fingerprints they were built from (nothing of it lives in the per-module caches, so a
@@ -247,7 +250,7 @@ class FrameRunner:
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
                  offset_dec_refine=None, max_pairs=None, lds_voxels=None,
-                 precision="f32", guard_every=1):
+                 precision="f32", guard_every=1, offsets="all"):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -261,6 +264,9 @@ class FrameRunner:
         if precision not in Q.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(Q.PRECISIONS))
         self.precision = precision
+        if offsets not in ("all", "selected") or (offsets == "selected" and precision != "f32"):
+            raise ValueError("offsets must be 'all' or 'selected' (f32)")
+        self.offsets = offsets      # 'selected': offset_dec on the arg-max pair of every ray only (lidf_query)
         self.bs, self.h, self.w, self.dev = bs, h, w, torch.device(device)
         self.mods = (pnet_model, prob_dec, offset_dec, pnet_model_refine, offset_dec_refine)
         what = "FrameRunner (use lidf_forward / refine_forward, which run other widths layer by layer)"
@@ -307,6 +313,9 @@ class FrameRunner:
             "pred_pos": torch.empty((N, 3), **f32), "rayfeat": torch.empty((N, 128 + Ed), **f32),
             "pred_depth": torch.empty((bs, h, w), **f32),
         }
+        if self.offsets == "selected":   # rows of the per-pair outputs that no frame writes must not look like results
+            self.buf["pred_offset"].fill_(float("nan"))
+            self.buf["pair_pred_pos"].fill_(float("nan"))
         if self.refine:
             self.buf.update({"pred_pos_refine": torch.empty((N, 3), **f32),
                              "end_voxel_id": torch.empty((N,), **i32),
@@ -457,6 +466,7 @@ class FrameRunner:
         a.pack_blob, a.pack_blob_bytes = self.pack_blob.data_ptr(), self.pack_blob.numel()
         a.pack_guard = self.pack_guard.data_ptr()
         a.pack_mode = 1 if guard else 2
+        a.offsets_selected = int(self.offsets == "selected")
         try:
             with torch.cuda.device(self.dev):
                 _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))

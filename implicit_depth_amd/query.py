@@ -279,8 +279,14 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
                vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
                ray_flat=None, depth=None, want_softmax=True, workspace=None, profile_events=None,
-               want_rayfeat=False, precision="f32", roi_out_bbox=2):
+               want_rayfeat=False, precision="f32", roi_out_bbox=2, offsets="all"):
     """Fused get_embedding + get_pred (+ depth write-back) through lidf_query_f32.
+
+    offsets="selected" (opt-in, f32, shipped widths): offset_dec runs on the arg-max pair of every ray only —
+    everything downstream of get_pred reads pair_pred_pos through max_pair_id alone (models/pipeline.py:
+    453-454), so pred_prob_end, the softmax, max_pair_id, pred_pos and the depth map are bit-identical to the
+    default while pred_offset / pair_pred_pos are written ONLY at the selected pairs (the other rows are left
+    as NaN); about half the matrix work on a real frame.
 
     Widths other than the shipped configuration (feat_grid channels != 32, roi_out_bbox != 2, vox_feat
     width != 128, decoders with gf_dim != 64): the same function layer by layer on materialised rows
@@ -342,6 +348,8 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if not shipped:
         if precision != "f32":
             raise RuntimeError("precision %r is built for the shipped widths" % precision)
+        if offsets != "all":
+            raise RuntimeError("offsets='selected' is built for the shipped widths")
         from . import generic
         return generic.query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid, vox_feat,
                              prob_dec, offset_dec, multires, multires_views, roi_inp_bbox, roi_out_bbox,
@@ -389,6 +397,14 @@ def lidf_query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, 
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     q.precision = PRECISIONS[precision]
+    if offsets not in ("all", "selected"):
+        raise ValueError("offsets must be 'all' or 'selected'")
+    if offsets == "selected":
+        if precision != "f32":
+            raise RuntimeError("offsets='selected' runs the f32 kernels")
+        q.offsets_selected = 1
+        out["pred_offset"].fill_(float("nan"))      # rows that are not written must not look like results
+        out["pair_pred_pos"].fill_(float("nan"))
     packed = _packed_weights(prob_dec, offset_dec, multires, multires_views, precision, dp, do, dev)
     q.packed = packed.data_ptr()
     with torch.cuda.device(dev):

@@ -151,6 +151,15 @@ typedef struct LidfQueryArgs {
      * (3 small launches); eval loops pack once per checkpoint, training loops once per optimizer
      * step. The LidfDecoder pointers are then only consulted for n_iter / init_offset / sigmoid. */
     const void* packed;
+    /* Opt-in (0 = off, the reference's data flow; f32 only): run the offset decoder on the SELECTED pair
+     * of every ray only. get_pred (models/pipeline.py:427-466) evaluates offset_dec on every pair but
+     * everything downstream — pred_pos (:453-454), the depth map, the losses and statistics of
+     * compute_loss, stage 2 — reads pair_pred_pos through max_pair_id alone. With this flag prob_dec runs
+     * on all pairs, the per-ray softmax / arg-max follows, and offset_dec (two of the three decoder passes)
+     * runs on one pair per ray: pred_prob, softmax, max_pair_id, pred_pos and depth are bit-identical to
+     * the default; pred_offset / pair_pred_pos hold values ONLY at the selected pairs (other entries are
+     * not written). About half the matrix work on a real frame (3.6 pairs per ray). (ABI 7)            */
+    int32_t offsets_selected;
 } LidfQueryArgs;
 
 /* Packed weights of the fused query: the parameters of prob_dec / offset_dec re-ordered into the
@@ -530,6 +539,7 @@ typedef struct LidfFrameArgs {
     size_t pack_blob_bytes;
     void* pack_guard;
     int32_t pack_mode;
+    int32_t offsets_selected;   /* as LidfQueryArgs.offsets_selected (opt-in; f32) */
 } LidfFrameArgs;
 #define LIDF_FRAME_PACK_CALLER 0
 #define LIDF_FRAME_PACK_GUARDED 1

@@ -242,6 +242,56 @@ def test_frame_position_types(cuda, pos, rpos, rpnet):
         assert not torch.equal(ref0["pred_offset"], ref["pred_offset"])
 
 
+@pytest.mark.parametrize("shape,graph", [((1, 240, 320), True), ((3, 37, 53), False)])
+def test_frame_offsets_for_selected_pairs_only(cuda, shape, graph):
+    """offsets='selected' (opt-in): offset_dec on the arg-max pair of every ray only. Everything the reference
+    reads downstream of get_pred (pred_prob_end, softmax, max_pair_id, pred_pos — models/pipeline.py:453-454 —,
+    depth, stage 2, the statistics) is bit-identical to the default; pred_offset / pair_pred_pos agree at the
+    selected pairs; frame and stepwise paths agree with each other in this mode too."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = shape
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=3)
+    batch, feat = synthetic_batch(B, h, w, seed=83)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    full = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    sel = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets="selected")
+    with torch.no_grad():
+        full.run(batch, feat)
+        sel.load(batch, feat)
+        if graph:
+            sel.capture()
+        sel.run()
+    ok, a = full.result()
+    ok2, b = sel.result()
+    assert ok and ok2 and a["counts"] == b["counts"]
+    for k in ("pred_prob_end", "pred_prob_end_softmax", "pred_pos", "pred_depth", "pred_pos_refine",
+              "pred_depth_refine", "occ_voxel_feat", "rayfeat"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["max_pair_id"], b["max_pair_id"]) and torch.equal(a["end_voxel_id"], b["end_voxel_id"])
+    P = a["counts"]["P"]
+    m = a["max_pair_id"]
+    m = m[m < P]
+    assert m.numel() > 0
+    assert torch.equal(a["pred_offset"][m], b["pred_offset"][m])
+    assert torch.equal(a["pair_pred_pos"][m], b["pair_pred_pos"][m])
+    rest = torch.ones(P, dtype=torch.bool, device=cuda)
+    rest[m] = False
+    assert torch.isnan(b["pred_offset"][rest]).all()          # never written: not mistaken for results
+    ma, mb = full.metrics(batch), sel.metrics(batch)
+    for k in ma:
+        assert float(ma[k]) == float(mb[k]) or (ma[k] != ma[k] and mb[k] != mb[k]), k
+    # the stepwise path in the same mode
+    with torch.no_grad():
+        ok3, c = pl.lidf_forward(batch, feat, models[0], models[1], models[2], opt, offsets="selected")
+        pl.refine_forward(c, models[3], models[4], opt)
+    assert ok3
+    for k in ("pred_prob_end", "pred_pos", "pred_depth", "pred_pos_refine"):
+        assert torch.equal(b[k], c[k]), k
+    assert torch.equal(b["pred_offset"][m], c["pred_offset"][m])
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_frame_weight_streams_follow_parameter_updates(cuda, graph):
     """The runner's own packed streams (one fingerprint launch over every module per frame): in-place
