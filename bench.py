@@ -619,7 +619,8 @@ def e2e(args):
         # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
         S = max(1, args.streams)
         runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision,
-                                  guard_every=args.guard_every, offsets=args.offsets)
+                                  guard_every=args.guard_every, offsets=args.offsets,
+                                  side_stream=args.side_stream, lds_voxels=args.lds_voxels or None)
                    for _ in range(S)]
         lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
         for r in runners:
@@ -710,6 +711,7 @@ def e2e(args):
                    "offsets": ("selected pairs only (opt-in: pred_offset / pair_pred_pos undefined elsewhere; pred_pos, "
                                "depth, stage 2 and statistics bit-identical)" if args.offsets == "selected"
                                else "every pair (the reference's data flow)"),
+                   "side_stream": bool(args.side_stream) if mode != "stepwise" else None,
                    "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV},
@@ -788,6 +790,11 @@ def main():
                          "of every ray only (opt-in, FrameRunner(offsets=...)): pred_pos / depth / stage 2 / statistics "
                          "bit-identical, pred_offset / pair_pred_pos defined at the selected pairs only. A secondary "
                          "record that says so; the default and every other record compute the reference's full data flow")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="--workload e2e (frame / graph): FrameRunner(side_stream=True) — the ray / voxel pair and "
+                         "per-ray feature launches of a frame run on a second stream beside its PointNet launches")
+    ap.add_argument("--lds-voxels", type=int, default=0,
+                    help="--workload e2e (frame / graph): FrameRunner(lds_voxels=N) (0 = the runner's default)")
     ap.add_argument("--guard-every", type=int, default=1,
                     help="--workload e2e (frame / graph): FrameRunner(guard_every=N) — the packed weight streams are "
                          "re-validated (one fingerprint launch over every module + two early-exit pack launches) on "

@@ -136,6 +136,7 @@ class LidfFrameArgs(C.Structure):
         ("valid_idx_bid", C.c_void_p), ("valid_idx_flat", C.c_void_p), ("n_valid_idx", C.c_int64),
         ("pack_blob", C.c_void_p), ("pack_blob_bytes", C.c_size_t), ("pack_guard", C.c_void_p),
         ("pack_mode", C.c_int32), ("offsets_selected", C.c_int32),
+        ("aux_stream", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
     ]
 
 
@@ -358,3 +359,21 @@ def require_cuda(*tensors, names=None):
             raise RuntimeError("%s must be a CUDA tensor" % name)
         if not t.is_contiguous():
             raise RuntimeError("%s must be contiguous" % name)
+
+
+_HIP = None
+
+
+def hip_event():
+    """A raw hipEvent_t (timing disabled) for the C-ABI's event arguments (LidfFrameArgs.ev_fork / ev_join):
+    torch.cuda.Event creates its handle lazily at the first record(), the library needs it up front.
+    Lives for the process (a few bytes; a captured graph may reference it)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    e = C.c_void_p()
+    err = _HIP.hipEventCreateWithFlags(C.byref(e), 0x2)   # hipEventDisableTiming
+    if err != 0:
+        raise RuntimeError("hipEventCreateWithFlags failed (%d)" % err)
+    return e.value

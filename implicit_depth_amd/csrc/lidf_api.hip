@@ -51,6 +51,8 @@ hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, c
                                      hipStream_t);
 hipError_t lidf_launch_rayfeat_dev(const float*, float*, int, int, int, const float*, const int*,
                                    const int*, long long, const int*, int, int, float*, int, hipStream_t);
+hipError_t lidf_launch_rayfeat_phase(const float*, float*, int, int, int, const float*, const int*,
+                                     const int*, long long, const int*, int, int, float*, int, int, hipStream_t);
 hipError_t lidf_launch_ray_reduce_dev(const float*, const float*, const int*, long long, long long,
                                       const int*, const int*, const int*, const int*, long long, float*,
                                       long long*, float*, float*, hipStream_t, const int*, const float*, int*,
@@ -627,8 +629,11 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
 // count on the device.
 // extra_l1 (optional, f32): a third layer-1 table over the same rayfeat rows, formed in the launch of
 // voxpart / raypart (the frame path: the per-ray part of the stage-2 decoder's layer 1; X is set here).
+// rayfeat_done: the caller already launched the per-ray features into q->rayfeat_out with this workspace's
+// box-sum image (the frame path's side stream).
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
-                      lidf_stream_t stream, const int* dims = nullptr, PointsArgs* extra_l1 = nullptr) {
+                      lidf_stream_t stream, const int* dims = nullptr, PointsArgs* extra_l1 = nullptr,
+                      bool rayfeat_done = false) {
     if (!q) return LIDF_ERR_BAD_ARG;
     if (dims && !q->packed) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
@@ -686,10 +691,11 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
 
         // 2. per-ray features [ROI 2x2 of the feature map | embed(dir)]
-        CHECK_HIP(lidf_launch_rayfeat_dev(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
-                                          q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
-                                          q->ray_bid, R, dims, q->roi_inp_bbox / 2, Lv, rayfeat,
-                                          128 + Ed, st));
+        if (!rayfeat_done)
+            CHECK_HIP(lidf_launch_rayfeat_dev(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
+                                              q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
+                                              q->ray_bid, R, dims, q->roi_inp_bbox / 2, Lv, rayfeat,
+                                              128 + Ed, st));
         // 3. layer-1 partial products: per voxel  voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+c),
         //    per ray  raypart[r] = W1[:, rgb|dir] rayfeat[r]
         {
@@ -1666,13 +1672,37 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     // launch over every module, or trusted)
     LidfPointNet pn_loc = *a->pnet, pnr_loc = {};
     if (rf) pnr_loc = *a->pnet_refine;
+    if (own_pack && (!a->pack_blob || !a->pack_guard || a->pack_blob_bytes < frame_pack_lay().total))
+        return LIDF_ERR_WORKSPACE;
+    const int v_lds = frame_lds_voxels(a->lds_voxels, (size_t)C);
+    const FrameWs f = frame_ws(B, h, w, a->res, a->max_pairs, v_lds, a->refine_times);
+    if (!a->workspace || a->workspace_bytes < f.total) return LIDF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    const int64_t grid_floats = (int64_t)B * 32 * h * w;
+    const QueryWs qw = query_ws(N, C, a->multires, a->multires_views, grid_floats);
+    // side stream (optional): the per-ray RoIAlign features need the feature map (box sums: from the start of
+    // the frame) and the rays (the two per-ray launches: after the head kernel) only — they run beside the
+    // voxel list, the pairs and the PointNet, whose launches fill a fraction of the device each
+    const bool two = a->aux_stream && a->ev_fork && a->ev_join;
+    hipStream_t sx = (hipStream_t)a->aux_stream;
+    const int Edv = 3 + 6 * a->multires_views;
+    if (two) {
+        CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_fork, st));
+        CHECK_HIP(hipStreamWaitEvent(sx, (hipEvent_t)a->ev_fork, 0));
+        CHECK_HIP(lidf_launch_rayfeat_phase(a->feat_grid, (float*)(ws + f.query + qw.box), B, h, w, a->ray_dir,
+                                            a->ray_pix, a->ray_bid, N, a->counts, a->roi_inp_bbox / 2,
+                                            a->multires_views, a->rayfeat, 128 + Edv, 1, sx));
+    }
     if (own_pack) {
         const FramePackLay pl = frame_pack_lay();
-        if (!a->pack_blob || !a->pack_guard || a->pack_blob_bytes < pl.total) return LIDF_ERR_WORKSPACE;
         char* blob = (char*)a->pack_blob;
         if (a->pack_mode == LIDF_FRAME_PACK_GUARDED &&
-            (rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, (hipStream_t)stream)))
+            (rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, (hipStream_t)stream))) {
+            if (two && hipEventRecord((hipEvent_t)a->ev_join, sx) == hipSuccess)   // (never leave a fork open)
+                (void)hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0);
             return rc;
+        }
         a->packed_query = blob + pl.query;
         pn_loc.packed = blob + pl.pnet;
         pnr_loc.packed = blob + pl.pnet_r;
@@ -1680,11 +1710,6 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     }
     a->pnet = &pn_loc;
     if (rf) a->pnet_refine = &pnr_loc;
-    const int v_lds = frame_lds_voxels(a->lds_voxels, (size_t)C);
-    const FrameWs f = frame_ws(B, h, w, a->res, a->max_pairs, v_lds, a->refine_times);
-    if (!a->workspace || a->workspace_bytes < f.total) return LIDF_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)a->workspace;
     int* counts = a->counts;
     int* cell_flag = (int*)(ws + f.cell_flag);
     int* cell_rank = (int*)(ws + f.cell_rank);
@@ -1701,8 +1726,6 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     //    and the tile counter of the query
     const int64_t sort_cap = B >= 2 ? 2 * N : 0;   // several frames: the voxel table outgrows the LDS pooling
     const PnetFrameWs pf = pnet_frame_ws(C, v_lds, sort_cap);
-    const int64_t grid_floats = (int64_t)B * 32 * h * w;
-    const QueryWs qw = query_ws(N, C, a->multires, a->multires_views, grid_floats);
     float* pool1 = (float*)(ws + f.pnet + pf.pool1);
     float* pool2 = (float*)(ws + f.pnet + pf.pool2);
     {
@@ -1720,23 +1743,32 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
                                      a->ray_flat, a->ray_pix, a->ray_dir, a->pred_depth,
                                      rf ? a->pred_depth_refine : nullptr, a->valid_idx_bid, a->valid_idx_flat,
                                      a->n_valid_idx > 0 ? a->n_valid_idx : 0, st));
+    if (two) {
+        CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_fork, st));   // (a second record: the rays exist)
+        CHECK_HIP(hipStreamWaitEvent(sx, (hipEvent_t)a->ev_fork, 0));
+        CHECK_HIP(lidf_launch_rayfeat_phase(a->feat_grid, (float*)(ws + f.query + qw.box), B, h, w, a->ray_dir,
+                                            a->ray_pix, a->ray_bid, N, counts, a->roi_inp_bbox / 2,
+                                            a->multires_views, a->rayfeat, 128 + Edv, 2, sx));
+        CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));
+    }
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
     float* vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;   // intersect_pos_type 'rel'
     CHECK_HIP(lidf_launch_frame_cells(cell_flag, C, g, cell_rank, a->occ_bid_coord, a->voxel_bound, vox_bid,
                                       vox_center, counts, st));
-    float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
-    CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
-                                       a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
-                                       pnet_abs, st));
     // 3. ray / voxel pairs: count, offsets (cut at max_pairs, P) and fill in ONE launch
     CHECK_HIP(lidf_launch_ray_aabb_onepass(a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, counts,
                                            ws + f.lb_pairs, a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
                                            a->max_pairs, st));
+    float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
+    CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
+                                       a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
+                                       pnet_abs, st));
     // 4. voxel embedding: PointNet over the in-grid valid points
     if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
                              counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))
         return rc;
+    if (two) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
     // 5. get_embedding + get_pred + depth
     {
         LidfQueryArgs q = {};
@@ -1772,7 +1804,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
             xr.D = 128 + Edr; xr.has_bias = 0;
             xr.out_base = (float*)(ws + f.raypart_r);
         }
-        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr))) return rc;
+        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr, two))) return rc;
     }
     if (!rf) return LIDF_OK;
 

@@ -385,15 +385,19 @@ extern "C" hipError_t lidf_launch_rayfeat(const float* feat, float* box, int B, 
                                    out, ld, st);
 }
 // R_dev (optional): the ray count on the device, R then bounds the launch
-extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int B, int H, int W,
-                                              const float* ray_dir, const int* ray_pix,
-                                              const int* ray_bid, long long R, const int* R_dev,
-                                              int half, int Lv, float* out, int ld, hipStream_t st) {
+// phase: 0 = everything; 1 = the box-sum image only (needs the feature map alone: the frame path's side
+// stream forms it before the rays exist); 2 = the per-ray launches over an image formed by phase 1
+extern "C" hipError_t lidf_launch_rayfeat_phase(const float* feat, float* box, int B, int H, int W,
+                                                const float* ray_dir, const int* ray_pix,
+                                                const int* ray_bid, long long R, const int* R_dev,
+                                                int half, int Lv, float* out, int ld, int phase,
+                                                hipStream_t st) {
     if (R <= 0) return hipSuccess;
     int* border = nullptr;
     if (box && half > 0) {
         const long long total = (long long)B * 32 * H * W;
-        if (half <= 8 && (long long)B * 32 <= 65535)
+        if (phase == 2) {
+        } else if (half <= 8 && (long long)B * 32 <= 65535)
             hipLaunchKernelGGL(lidf_boxsum_lds_kernel,
                                dim3((unsigned)((W + BOX_TX - 1) / BOX_TX), (unsigned)((H + BOX_TY - 1) / BOX_TY),
                                     (unsigned)(B * 32)),
@@ -401,6 +405,7 @@ extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int
         else
             hipLaunchKernelGGL(lidf_boxsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                st, feat, B * 32, H, W, half, box);
+        if (phase == 1) return hipGetLastError();
         border = (int*)(box + total);
         // (the frame path — R_dev — zeroes the list length with its other scratch, in one launch up front)
         if (!R_dev) {
@@ -416,6 +421,13 @@ extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int
         hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(2048), dim3(256), 0, st, feat, H, W,
                            ray_pix, ray_bid, half, border, out, ld);
     return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_rayfeat_dev(const float* feat, float* box, int B, int H, int W,
+                                              const float* ray_dir, const int* ray_pix,
+                                              const int* ray_bid, long long R, const int* R_dev,
+                                              int half, int Lv, float* out, int ld, hipStream_t st) {
+    return lidf_launch_rayfeat_phase(feat, box, B, H, W, ray_dir, ray_pix, ray_bid, R, R_dev, half, Lv, out, ld,
+                                     0, st);
 }
 
 // ------------------------------------------------------------------------------------------------

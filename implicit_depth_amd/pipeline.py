@@ -250,7 +250,7 @@ class FrameRunner:
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
                  offset_dec_refine=None, max_pairs=None, lds_voxels=None,
-                 precision="f32", guard_every=1, offsets="all"):
+                 precision="f32", guard_every=1, offsets="all", side_stream=False):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -337,6 +337,12 @@ class FrameRunner:
         self._keep = None
         self.guard_every = max(1, int(guard_every))
         self._frames_since_guard = None            # None: the next frame validates
+        # side_stream: the [ray / voxel pairs, per-ray features] branch of the frame runs on a second stream
+        # beside the PointNet branch (lidf_hip.h: LidfFrameArgs.aux_stream); results are bit-identical
+        self.side = None
+        if side_stream:
+            with torch.cuda.device(dev):
+                self.side = (torch.cuda.Stream(dev), _lib.hip_event(), _lib.hip_event())
         self.pack_blob = torch.empty((L.lidf_frame_pack_bytes(),), dtype=torch.uint8, device=dev)
         self.pack_guard = torch.zeros((L.lidf_frame_pack_guard_bytes(),), dtype=torch.uint8, device=dev)
         self.vidx, self.n_valid_idx = None, 0      # explicit valid points (load(valid_idx=))
@@ -467,6 +473,8 @@ class FrameRunner:
         a.pack_guard = self.pack_guard.data_ptr()
         a.pack_mode = 1 if guard else 2
         a.offsets_selected = int(self.offsets == "selected")
+        if self.side is not None:
+            a.aux_stream, a.ev_fork, a.ev_join = self.side[0].cuda_stream, self.side[1], self.side[2]
         try:
             with torch.cuda.device(self.dev):
                 _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))

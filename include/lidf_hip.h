@@ -540,6 +540,17 @@ typedef struct LidfFrameArgs {
     void* pack_guard;
     int32_t pack_mode;
     int32_t offsets_selected;   /* as LidfQueryArgs.offsets_selected (opt-in; f32) */
+    /* optional second stream (ABI 7): the per-ray RoIAlign features of a frame need the feature map and the
+     * rays only; with a side stream they run beside the voxel list, the ray / voxel pairs and the PointNet
+     * (launches that fill a fraction of the device each). `ev_fork` is recorded on `stream` at the start of
+     * the frame and again once the rays exist, `aux_stream` awaits it each time (box sums, then the two
+     * per-ray launches) and records `ev_join`, which `stream` awaits before the layer-1 tables. Results are
+     * bit-identical. All three NULL = one stream (the default). ev_fork / ev_join: two hipEvent_t of the
+     * caller (hipEventDisableTiming is enough), not shared with a frame in flight on another stream.
+     * Capturable: the side stream joins the capture through the events.                                */
+    lidf_stream_t aux_stream;
+    void* ev_fork;
+    void* ev_join;
 } LidfFrameArgs;
 #define LIDF_FRAME_PACK_CALLER 0
 #define LIDF_FRAME_PACK_GUARDED 1

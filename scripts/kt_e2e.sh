@@ -2,7 +2,7 @@
 # the wall clock of a step, and the launches of one step in time order with the gaps between them
 F=${1:-1}; M=${2:-frame}; O=gpurun_out/e2e_kt${F}_$M; mkdir -p $O; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p_e; rocprofv3 --kernel-trace --stats -d /tmp/p_e -o r -- python $R/bench.py --workload e2e --frames $F --e2e-mode $M --steps 10 --warmup 3 > $R/$O/bench.json 2>/dev/null
+rm -rf /tmp/p_e; rocprofv3 --kernel-trace --stats -d /tmp/p_e -o r -- python $R/bench.py --workload e2e --frames $F --e2e-mode $M --steps 10 --warmup 3 $KT_OPTS > $R/$O/bench.json 2>/dev/null
 cd $R
 python - > $O/summary.txt <<PY
 import sqlite3

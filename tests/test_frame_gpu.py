@@ -293,6 +293,42 @@ def test_frame_offsets_for_selected_pairs_only(cuda, shape, graph):
 
 
 @pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("offsets", ["all", "selected"])
+def test_frame_with_a_side_stream(cuda, graph, offsets):
+    """side_stream=True (LidfFrameArgs.aux_stream / ev_fork / ev_join): the ray / voxel pair + per-ray feature
+    branch runs beside the PointNet branch. Same kernels on the same data: every output is bit-identical,
+    eager and through a captured graph, over several frames with different inputs on the same runner."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 2, 60, 80
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=2)
+    one = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets=offsets)
+    two = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets=offsets,
+                         side_stream=True)
+    for it, seed in enumerate((5, 6, 7)):
+        batch, feat = synthetic_batch(B, h, w, seed=seed)
+        batch, feat = _dev(batch, cuda), feat.to(cuda)
+        with torch.no_grad():
+            one.run(batch, feat)
+            two.load(batch, feat)
+            if graph and it == 0:
+                two.capture()
+            two.run()
+        ok, a = one.result()
+        ok2, b = two.result()
+        assert ok and ok2 and a["counts"] == b["counts"]
+        P = a["counts"]["P"]
+        for k in ("pred_prob_end", "pred_prob_end_softmax", "pred_pos", "pred_depth", "pred_pos_refine",
+                  "pred_depth_refine", "occ_voxel_feat", "rayfeat", "max_pair_id", "end_voxel_id"):
+            assert torch.equal(a[k], b[k]), (k, seed)
+        for k in ("pair_ray", "pair_vox", "pair_t"):
+            assert torch.equal(a[k][:P], b[k][:P]), (k, seed)
+        if offsets == "all":
+            assert torch.equal(a["pred_offset"][:P], b["pred_offset"][:P])
+
+
+@pytest.mark.parametrize("graph", [False, True])
 def test_frame_weight_streams_follow_parameter_updates(cuda, graph):
     """The runner's own packed streams (one fingerprint launch over every module per frame): in-place
     updates, `p.data` writes the version counter misses, load_state_dict — picked up by the next frame,
