@@ -629,11 +629,13 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
 // count on the device.
 // extra_l1 (optional, f32): a third layer-1 table over the same rayfeat rows, formed in the launch of
 // voxpart / raypart (the frame path: the per-ray part of the stage-2 decoder's layer 1; X is set here).
-// rayfeat_done: the caller already launched the per-ray features into q->rayfeat_out with this workspace's
-// box-sum image (the frame path's side stream).
+// phases: which launches this call makes — the frame path's side stream takes the per-ray ones (the caller
+// launched the per-ray features into q->rayfeat_out with this workspace's box-sum image, then calls with
+// QP_RAYTAB on the side stream and with QP_MAIN on the main one; both need q->packed).
+enum { QP_RAYFEAT = 1, QP_RAYTAB = 2, QP_MAIN = 4, QP_ALL = 7 };
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
                       lidf_stream_t stream, const int* dims = nullptr, PointsArgs* extra_l1 = nullptr,
-                      bool rayfeat_done = false) {
+                      int phases = QP_ALL) {
     if (!q) return LIDF_ERR_BAD_ARG;
     if (dims && !q->packed) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
@@ -669,6 +671,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         // 1. weight streams: the caller's packed blob (lidf_query_pack_f32, built once per
         // parameter version) or packed here, into the head of the workspace, for this call
         const char* pk = q->packed ? (const char*)q->packed : ws;
+        if (!q->packed && phases != QP_ALL) return LIDF_ERR_BAD_ARG;
         if (!q->packed &&
             (rc = pack_query_weights(q->prob, q->off, L, Lv, q->precision, ws, st)))
             return rc;
@@ -691,7 +694,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
         StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
 
         // 2. per-ray features [ROI 2x2 of the feature map | embed(dir)]
-        if (!rayfeat_done)
+        if (phases & QP_RAYFEAT)
             CHECK_HIP(lidf_launch_rayfeat_dev(q->feat_grid, use_box ? (float*)(ws + w.box) : nullptr,
                                               q->batch, q->height, q->width, q->ray_dir, q->ray_pix,
                                               q->ray_bid, R, dims, q->roi_inp_bbox / 2, Lv, rayfeat,
@@ -717,17 +720,21 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
             long long nt = (R + 127) / 128;
             if (extra_l1) { extra_l1->X = rayfeat; extra_l1->ldx = 128 + Ed; }
             if (split) {
-                CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, av, (int)(ntv < 2 * cus ? ntv : 2 * cus), st));
+                if (phases & QP_MAIN)
+                    CHECK_HIP(lidf_launch_points(LIDF_MODE_L1ONLY, av, (int)(ntv < 2 * cus ? ntv : 2 * cus), st));
                 // the per-ray partial products with the split-f16 rows kernel (layer 1 only)
                 StreamLayout lh = lidf_make_layout_rows_h(2, mr.D, 1);
                 a.l1_quads = lh.l1_quads; a.net_quads = lh.net_quads;
                 a.npass[0] = a.npass[1] = 0;
-                CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
+                if (phases & QP_RAYTAB) CHECK_HIP(lidf_launch_rows_h(a, (int)(nt < cus ? nt : cus), st));
             } else {
-                // one launch over the (tile, net, half) items of both tables
-                CHECK_HIP(lidf_launch_l1only_pair(a, av, extra_l1, cus, st));
+                // one launch over the (tile, net, half) items of the tables (an absent one: stream == NULL)
+                const PointsArgs none = {};
+                CHECK_HIP(lidf_launch_l1only_pair((phases & QP_RAYTAB) ? a : none, (phases & QP_MAIN) ? av : none,
+                                                  (phases & QP_RAYTAB) ? extra_l1 : nullptr, cus, st));
             }
         }
+        if (!(phases & QP_MAIN)) return LIDF_OK;
         // 4. per-point kernel
         {
             PointsArgs a = {};
@@ -1735,6 +1742,41 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
                                  (long long)C * 128, 1, 1};
         CHECK_HIP(lidf_launch_zero_segments(zp, zc, 5, st));
     }
+    // the query of step 5 (its per-ray launches go to the side stream when there is one)
+    LidfQueryArgs q = {};
+    q.n_rays = N; q.ray_dir = a->ray_dir; q.ray_pix = a->ray_pix; q.ray_bid = a->ray_bid;
+    q.ray_flat = a->ray_flat;
+    q.n_pairs = a->max_pairs; q.pair_off = a->pair_off; q.pair_ray = a->pair_ray;
+    q.pair_vox = a->pair_vox; q.pair_t = a->pair_t;
+    q.batch = B; q.height = h; q.width = w; q.feat_grid = a->feat_grid;
+    q.n_vox = C; q.vox_feat = a->occ_voxel_feat;
+    q.vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;
+    q.prob = a->prob; q.off = a->off;
+    q.multires = a->multires; q.multires_views = a->multires_views; q.roi_inp_bbox = a->roi_inp_bbox;
+    q.pos_rel = a->pos_rel ? 1 : 0;
+    q.offset_range0 = a->offset_range0; q.offset_range1 = a->offset_range1; q.part_size = a->part_size;
+    q.pred_offset = a->pred_offset; q.pred_prob = a->pred_prob; q.pair_pred_pos = a->pair_pred_pos;
+    q.pred_prob_softmax = a->pred_prob_softmax; q.max_pair_id = a->max_pair_id; q.pred_pos = a->pred_pos;
+    q.depth = a->pred_depth;
+    q.workspace = ws + f.query;
+    q.workspace_bytes = lidf_query_workspace_bytes(N, C, (int64_t)B * 32 * h * w);
+    q.rayfeat_out = a->rayfeat;
+    q.precision = a->precision;
+    q.packed = a->packed_query;
+    q.offsets_selected = a->offsets_selected;
+    // (f32 stage 2: the per-ray part of its decoder's layer 1, W1[:, ROI | dir] rayfeat[r] — constant
+    // over the refine iterations — is a third table of the query's layer-1 launch)
+    PointsArgs xr = {};
+    if (rf && !split) {
+        const int Edr = 3 + 6 * a->multires_views;
+        xr.stream = (const float*)((const char*)a->packed_refine + linex_stream_bytes(128));
+        xr.nets = 1;
+        xr.KQ1 = (128 + Edr + 2 + 7) / 8;
+        xr.l1_quads = xr.net_quads = xr.KQ1 * 8;
+        xr.n = N; xr.n_dev = counts;
+        xr.D = 128 + Edr; xr.has_bias = 0;
+        xr.out_base = (float*)(ws + f.raypart_r);
+    }
     // 1. valid points (with their rows of the PointNet input), rays, depth map, voxel marks: ONE launch
     //    over the pixels (look-back prefix over its workgroups)
     CHECK_HIP(lidf_launch_frame_head(a->valid_mask, a->miss_mask, a->xyz_corrupt, a->rgb, a->intr, B, h, w,
@@ -1749,6 +1791,8 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         CHECK_HIP(lidf_launch_rayfeat_phase(a->feat_grid, (float*)(ws + f.query + qw.box), B, h, w, a->ray_dir,
                                             a->ray_pix, a->ray_bid, N, counts, a->roi_inp_bbox / 2,
                                             a->multires_views, a->rayfeat, 128 + Edv, 2, sx));
+        // (the per-ray layer-1 tables stay on the main stream: a launch that fills the device starves the
+        // PointNet's light launches beside it — measured, fused kernel start 326 -> 354 us)
         CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));
     }
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
@@ -1770,42 +1814,9 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         return rc;
     if (two) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
     // 5. get_embedding + get_pred + depth
-    {
-        LidfQueryArgs q = {};
-        q.n_rays = N; q.ray_dir = a->ray_dir; q.ray_pix = a->ray_pix; q.ray_bid = a->ray_bid;
-        q.ray_flat = a->ray_flat;
-        q.n_pairs = a->max_pairs; q.pair_off = a->pair_off; q.pair_ray = a->pair_ray;
-        q.pair_vox = a->pair_vox; q.pair_t = a->pair_t;
-        q.batch = B; q.height = h; q.width = w; q.feat_grid = a->feat_grid;
-        q.n_vox = C; q.vox_feat = a->occ_voxel_feat; q.vox_center = vox_center;
-        q.prob = a->prob; q.off = a->off;
-        q.multires = a->multires; q.multires_views = a->multires_views; q.roi_inp_bbox = a->roi_inp_bbox;
-        q.pos_rel = a->pos_rel ? 1 : 0;
-        q.offset_range0 = a->offset_range0; q.offset_range1 = a->offset_range1; q.part_size = a->part_size;
-        q.pred_offset = a->pred_offset; q.pred_prob = a->pred_prob; q.pair_pred_pos = a->pair_pred_pos;
-        q.pred_prob_softmax = a->pred_prob_softmax; q.max_pair_id = a->max_pair_id; q.pred_pos = a->pred_pos;
-        q.depth = a->pred_depth;
-        q.workspace = ws + f.query;
-        q.workspace_bytes = lidf_query_workspace_bytes(N, C, (int64_t)B * 32 * h * w);
-        q.rayfeat_out = a->rayfeat;
-        q.precision = a->precision;
-        q.packed = a->packed_query;
-        q.offsets_selected = a->offsets_selected;
-        // (f32 stage 2: the per-ray part of its decoder's layer 1, W1[:, ROI | dir] rayfeat[r] — constant
-        // over the refine iterations — is a third table of the query's layer-1 launch)
-        PointsArgs xr = {};
-        if (rf && !split) {
-            const int Edr = 3 + 6 * a->multires_views;
-            xr.stream = (const float*)((const char*)a->packed_refine + linex_stream_bytes(128));
-            xr.nets = 1;
-            xr.KQ1 = (128 + Edr + 2 + 7) / 8;
-            xr.l1_quads = xr.net_quads = xr.KQ1 * 8;
-            xr.n = N; xr.n_dev = counts;
-            xr.D = 128 + Edr; xr.has_bias = 0;
-            xr.out_base = (float*)(ws + f.raypart_r);
-        }
-        if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr, two))) return rc;
-    }
+    if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr,
+                         two ? (QP_RAYTAB | QP_MAIN) : QP_ALL)))
+        return rc;
     if (!rf) return LIDF_OK;
 
     // 6. stage 2: refine_times x get_pred_refine on the device-resident state
