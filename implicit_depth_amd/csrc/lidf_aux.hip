@@ -90,6 +90,29 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ img, int H, 
     return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
 }
 
+// The same value without a branch in front of the loads (the four taps are always read — their addresses are
+// clamped into the plane — and the result selected afterwards): samples unrolled side by side then have all
+// their taps in flight at once instead of one dependent round trip per sample.
+__device__ __forceinline__ float bilinear_nb(const float* __restrict__ img, int H, int W, float y, float x) {
+    const bool outside = y < -1.0f || y > (float)H || x < -1.0f || x > (float)W;
+    y = y <= 0.f ? 0.f : y;
+    x = x <= 0.f ? 0.f : x;
+    int y_low = outside ? 0 : (int)y, x_low = outside ? 0 : (int)x;
+    const bool yc = y_low >= H - 1, xc = x_low >= W - 1;
+    y_low = yc ? H - 1 : y_low;
+    x_low = xc ? W - 1 : x_low;
+    const int y_high = yc ? y_low : y_low + 1, x_high = xc ? x_low : x_low + 1;
+    y = yc ? (float)y_low : y;
+    x = xc ? (float)x_low : x;
+    const float ly = y - (float)y_low, lx = x - (float)x_low;
+    const float v1 = img[y_low * W + x_low], v2 = img[y_low * W + x_high];
+    const float v3 = img[y_high * W + x_low], v4 = img[y_high * W + x_high];
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float r = (ly == 0.f && lx == 0.f) ? v1 : w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+    return outside ? 0.f : r;
+}
+
 // Box-sum image: box[b,c,y,x] = sum of feat[b,c,y..y+k-1,x..x+k-1] (k = roi_inp_bbox/2), zero where
 // the window leaves the image. For a ray whose 2k x 2k box is not clamped every RoIAlign sample
 // falls on a pixel centre (weights 1,0,0,0), so each of the 2x2 bins is exactly such a window
@@ -310,12 +333,34 @@ __global__ void __launch_bounds__(256) lidf_rayfeat_border_kernel(
         const float count = (float)max(gh * gw, 1);
         const float* img = feat + ((size_t)ray_bid[rr] * 32 + c) * H * W;
         const int ph = bin >> 1, pw = bin & 1;
-        float acc = 0.f;  // the reference's (iy, ix) order
-        for (int iy = 0; iy < gh; ++iy) {
-            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
-            for (int ix = 0; ix < gw; ++ix) {
-                const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
-                acc += bilinear(img, H, W, y, x);
+        // boxes of up to 4 x 4 samples per bin (roi_inp_bbox <= 8): the samples are independent loads,
+        // requested back to back with the loops unrolled (predicated), then summed in the reference's
+        // (iy, ix) order; larger bins take the plain loops (same order)
+        float acc = 0.f;
+        if (gh <= 4 && gw <= 4) {
+            float v[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float y = rsh + (float)ph * bin_h + ((float)a + .5f) * bin_h / (float)gh;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const float x = rsw + (float)pw * bin_w + ((float)bb + .5f) * bin_w / (float)gw;
+                    v[a][bb] = (a < gh && bb < gw) ? bilinear_nb(img, H, W, y, x) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+                    if (a < gh && bb < gw) acc += v[a][bb];
+            }
+        } else {
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                    acc += bilinear(img, H, W, y, x);
+                }
             }
         }
         out[(size_t)rr * ld + 4 * c + bin] = acc / count;
@@ -418,7 +463,9 @@ extern "C" hipError_t lidf_launch_rayfeat_phase(const float* feat, float* box, i
                        (size_t)(64 * ts + 65) * 4, st, feat, box, B, H, W, ray_dir, ray_pix, ray_bid,
                        R, half, Lv, out, ld, border, R_dev);
     if (border)
-        hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(2048), dim3(256), 0, st, feat, H, W,
+        // (grid-stride over the device-side list; 4096 workgroups hold the ~4,400 clamped boxes x 128 items
+        // of a 240x320 frame in one pass)
+        hipLaunchKernelGGL(lidf_rayfeat_border_kernel, dim3(4096), dim3(256), 0, st, feat, H, W,
                            ray_pix, ray_bid, half, border, out, ld);
     return hipGetLastError();
 }

@@ -113,7 +113,7 @@ struct LidfPackGuardState {
 };
 
 // One stream to pack (lidf_pack_multi_kernel packs up to LIDF_PACK_JOBS of them per launch).
-#define LIDF_PACK_JOBS 8
+#define LIDF_PACK_JOBS 13   // (13 x 296 B of kernel arguments: under the 4 KiB limit; a frame has 11)
 struct PackJob {
     StreamLayout lay;
     NetW n0, n1;

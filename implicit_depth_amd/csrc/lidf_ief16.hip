@@ -275,18 +275,30 @@ __device__ __forceinline__ void ief16_tiles(const Ief16Args& a, const long long 
     }
 }
 
-__global__ void __launch_bounds__(256) lidf_ief16_kernel(Ief16Args a) {
+// SLOTS = wavefronts per SIMD (wavefronts w and w + 4 of a workgroup share one). A SIMD owns a balanced,
+// contiguous range of 16-ray sub-tiles (4 or 5 of the 4,800 of a 240x320 frame).
+//  SLOTS = 1: one wavefront walks it two sub-tiles at a time (every weight quad feeds 8 matrix instructions),
+//             then the odd one; 256 + 78 registers: one wavefront per SIMD is all that fits.
+//  SLOTS = 2: two wavefronts split it ceil / floor and walk one sub-tile at a time (half the accumulators: both
+//             fit the register file); the gaps of one instruction stream are filled by the other, at twice
+//             the weight-stream traffic per sub-tile.
+template <int SLOTS>
+__global__ void __launch_bounds__(256 * SLOTS) lidf_ief16_kernel(Ief16Args a) {
     const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;
     const int lane = threadIdx.x & 63;
     const long long nhalf = (AN + 15) / 16;
     // (the wavefront index through readfirstlane: the compiler then knows the sub-tile range, the loop trip
     // counts and the running stream position to be wave-uniform — scalar registers, scalar adds)
-    const long long nw = (long long)gridDim.x * 4,
-                    wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // contiguous, balanced ranges of 16-ray sub-tiles per wavefront
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long nw = (long long)gridDim.x * 4, wv = (long long)blockIdx.x * 4 + (w & 3);
+    // contiguous, balanced ranges of 16-ray sub-tiles per SIMD
     const long long per = nhalf / nw, rem = nhalf % nw;
     long long t = wv * per + (wv < rem ? wv : rem);
-    const long long te = t + per + (wv < rem ? 1 : 0);
+    long long te = t + per + (wv < rem ? 1 : 0);
+    if (SLOTS == 2) {
+        const long long mid = t + (te - t + 1) / 2;
+        if (w >> 2) t = mid; else te = mid;
+    }
     if (t >= te) return;
     const int total_bytes = (a.KQ * 16 + IEF16_PASS_QUADS) * 1024;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)a.stream, 0, total_bytes, 0x00020000);
@@ -295,15 +307,23 @@ __global__ void __launch_bounds__(256) lidf_ief16_kernel(Ief16Args a) {
 #pragma unroll
     for (int i = 0; i < IEF16_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
     int pos = IEF16_RING * 1024;   // byte offset of the next quad to request
-    f32x4 base[16][2], xpre[IEF16_XPRE][2];
-    while (te - t >= 2) {
-        ief16_fetch(a, AN, t, base, xpre);
-        ief16_tiles<2>(a, AN, t, srs, vq, ring, pos, base, xpre, -1);
-        t += 2;
-    }
-    if (t < te) {
-        ief16_fetch(a, AN, t, base, xpre);
-        ief16_tiles<1>(a, AN, t, srs, vq, ring, pos, base, xpre, -1);
+    if (SLOTS == 1) {
+        f32x4 base[16][2], xpre[IEF16_XPRE][2];
+        while (te - t >= 2) {
+            ief16_fetch(a, AN, t, base, xpre);
+            ief16_tiles<2>(a, AN, t, srs, vq, ring, pos, base, xpre, -1);
+            t += 2;
+        }
+        if (t < te) {
+            ief16_fetch(a, AN, t, base, xpre);
+            ief16_tiles<1>(a, AN, t, srs, vq, ring, pos, base, xpre, -1);
+        }
+    } else {
+        f32x4 base[16][2], xpre[IEF16_XPRE][2];
+        for (; t < te; ++t) {
+            ief16_fetch(a, AN, t, base, xpre);
+            ief16_tiles<1>(a, AN, t, srs, vq, ring, pos, base, xpre, -1);
+        }
     }
 }
 
@@ -313,6 +333,11 @@ extern "C" hipError_t lidf_launch_ief16(const Ief16Args& a, int cus, hipStream_t
     const long long nhalf = (a.n + 15) / 16;
     long long g = (nhalf + 3) / 4;
     if (g > cus) g = cus;
-    hipLaunchKernelGGL(lidf_ief16_kernel, dim3((unsigned)g), dim3(256), 0, st, a);
+    static int slots = -1;   // development knob: 1 = one wavefront per SIMD (the round-4 first version)
+    if (slots < 0) { const char* e = getenv("LIDF_IEF16_SLOTS"); slots = (e && atoi(e) == 1) ? 1 : 2; }
+    if (slots == 2)
+        hipLaunchKernelGGL(lidf_ief16_kernel<2>, dim3((unsigned)g), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL(lidf_ief16_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -9,6 +9,13 @@ python bench.py --workload e2e --e2e-mode $M --frames $F --steps 40 --warmup 5 $
 for S in 2 3; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 60 --warmup 6 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
 python bench.py --workload e2e --e2e-mode graph --guard-every 32 --steps 64 --warmup 5 > $O/bench_e2e_graph_f1_guard32.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --frames 4 --streams 2 --steps 30 --warmup 6 > $O/bench_e2e_frame_f4_streams2.json 2>> $O/err.txt
+# opt-in variants: a side stream inside the frame call; the offset decoder on the selected pairs only
+python bench.py --workload e2e --e2e-mode frame --side-stream --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_side.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --side-stream --guard-every 32 --steps 128 --warmup 10 > $O/bench_e2e_frame_f1_side_guard32.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_selected.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --side-stream --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_selected_side.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --streams 3 --steps 120 --warmup 12 > $O/bench_e2e_frame_f1_selected_streams3.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --frames 4 --steps 40 --warmup 5 > $O/bench_e2e_frame_f4_selected.json 2>> $O/err.txt
 for p in ragged n1 scene; do python bench.py --pairs $p --steps 20 --warmup 3 --no-cpu-baseline $( [ $p = scene ] && echo --pmc ) > $O/bench_pairs_$p.json 2>> $O/err.txt; done
 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_config2.json 2>> $O/err.txt
 python bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --pmc > $O/bench_config3.json 2>> $O/err.txt
