@@ -287,11 +287,8 @@ __global__ void lidf_rayfeat_kernel(const float* __restrict__ feat,
         if (cg == 0)
             for (int i = 0; i < 3; ++i) e[i] = d[i];
         for (int l = cg; l < Lv; l += 4) {
-            const float f = (float)(1 << l);
-            for (int i = 0; i < 3; ++i) {
-                e[3 + 6 * l + i] = sinf(d[i] * f);
-                e[3 + 6 * l + 3 + i] = cosf(d[i] * f);
-            }
+            const float sc = (float)(1 << l);
+            for (int i = 0; i < 3; ++i) rev_sincos(to_rev(d[i]), sc, e[3 + 6 * l + i], e[3 + 6 * l + 3 + i]);
         }
     }
     __syncthreads();

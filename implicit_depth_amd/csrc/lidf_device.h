@@ -113,7 +113,7 @@ struct LidfPackGuardState {
 };
 
 // One stream to pack (lidf_pack_multi_kernel packs up to LIDF_PACK_JOBS of them per launch).
-#define LIDF_PACK_JOBS 13   // (13 x 296 B of kernel arguments: under the 4 KiB limit; a frame has 11)
+#define LIDF_PACK_JOBS 13   // (13 x 296 B of kernel arguments: under the 4 KiB limit; a frame with stage 2 has 22: two launches)
 struct PackJob {
     StreamLayout lay;
     NetW n0, n1;
@@ -377,6 +377,15 @@ __device__ __forceinline__ void rev_sincos(const Rev& r, float sc, float& s, flo
     const float t = __builtin_amdgcn_fractf(r.hi * sc) + r.lo * sc;
     s = __builtin_amdgcn_sinf(t);
     c = __builtin_amdgcn_cosf(t);
+}
+// element k >= 3 of [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] for one coordinate value q (the per-ray rows
+// of stage 2 and the per-ray direction embedding: same arithmetic as the per-point kernel's embedding)
+__device__ __forceinline__ float pe_value(float q, int k) {
+    const int l = (k - 3) / 6;
+    const float sc = (float)(1 << l);
+    const Rev r = to_rev(q);
+    const float t = __builtin_amdgcn_fractf(r.hi * sc) + r.lo * sc;
+    return ((k - 3) % 6) < 3 ? __builtin_amdgcn_sinf(t) : __builtin_amdgcn_cosf(t);
 }
 
 #endif  // __HIPCC__

@@ -143,9 +143,7 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
         if (k < 3) {
             v = q;
         } else {
-            const int l = (k - 3) / 6;
-            const float f = (float)(1 << l);
-            v = ((k - 3) % 6) < 3 ? sinf(q * f) : cosf(q * f);
+            v = pe_value(q, k);   // (5 VALU; |err| <= 4.2e-7 — lidf_device.h: to_rev / rev_sincos)
         }
     } else {
         v = rf[128 + (c - 128 - E)];
@@ -272,9 +270,7 @@ __global__ void __launch_bounds__(256) lidf_refine_step_kernel(RefineStepArgs a)
         if (k < 3) {
             v = q;
         } else {
-            const int l = (k - 3) / 6;
-            const float f = (float)(1 << l);
-            v = ((k - 3) % 6) < 3 ? sinf(q * f) : cosf(q * f);
+            v = pe_value(q, k);   // (5 VALU; |err| <= 4.2e-7 — lidf_device.h: to_rev / rev_sincos)
         }
         a.inp_embed[(size_t)(r0w + rr) * a.ld_e + 256 + k] = v;
     }
