@@ -618,9 +618,11 @@ def e2e(args):
         # batches in turn, so that the low-occupancy stretches of one frame (PointNet, per-voxel layers,
         # scans, the partial last round of the matrix kernels) are filled by its neighbour's kernels
         S = max(1, args.streams)
+        # FrameRunner's default: a side stream inside eager single-stream frames only (as FramePipeline does)
+        side_mode = True if args.side_stream else (False if (args.no_side_stream or S > 1) else None)
         runners = [pl.FrameRunner(B, h, w, dev, pnet, prob, off, opt, pnet_r, offr, precision=args.precision,
                                   guard_every=args.guard_every, offsets=args.offsets,
-                                  side_stream=args.side_stream, lds_voxels=args.lds_voxels or None)
+                                  side_stream=side_mode, lds_voxels=args.lds_voxels or None)
                    for _ in range(S)]
         lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [None]
         for r in runners:
@@ -711,7 +713,8 @@ def e2e(args):
                    "offsets": ("selected pairs only (opt-in: pred_offset / pair_pred_pos undefined elsewhere; pred_pos, "
                                "depth, stage 2 and statistics bit-identical)" if args.offsets == "selected"
                                else "every pair (the reference's data flow)"),
-                   "side_stream": bool(args.side_stream) if mode != "stepwise" else None,
+                   "side_stream": (None if mode == "stepwise" else
+                                   bool(side_mode or (side_mode is None and mode == "frame"))),
                    "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV},
@@ -791,8 +794,10 @@ def main():
                          "bit-identical, pred_offset / pair_pred_pos defined at the selected pairs only. A secondary "
                          "record that says so; the default and every other record compute the reference's full data flow")
     ap.add_argument("--side-stream", action="store_true",
-                    help="--workload e2e (frame / graph): FrameRunner(side_stream=True) — the ray / voxel pair and "
-                         "per-ray feature launches of a frame run on a second stream beside its PointNet launches")
+                    help="--workload e2e (frame / graph): FrameRunner(side_stream=True) — the weight-stream guard, box "
+                         "sums and per-ray features of a frame on a second stream beside its head, pairs and PointNet. "
+                         "Default: FrameRunner's own (on for eager single-stream frames, off under a graph / --streams)")
+    ap.add_argument("--no-side-stream", action="store_true", help="--workload e2e: FrameRunner(side_stream=False)")
     ap.add_argument("--lds-voxels", type=int, default=0,
                     help="--workload e2e (frame / graph): FrameRunner(lds_voxels=N) (0 = the runner's default)")
     ap.add_argument("--guard-every", type=int, default=1,

@@ -1688,33 +1688,41 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     char* ws = (char*)a->workspace;
     const int64_t grid_floats = (int64_t)B * 32 * h * w;
     const QueryWs qw = query_ws(N, C, a->multires, a->multires_views, grid_floats);
-    // side stream (optional): the per-ray RoIAlign features need the feature map (box sums: from the start of
-    // the frame) and the rays (the two per-ray launches: after the head kernel) only — they run beside the
-    // voxel list, the pairs and the PointNet, whose launches fill a fraction of the device each
+    // side stream (optional): launches that fill a fraction of the device each run side by side —
+    //   side: weight-stream guard (fingerprint + early-exit packs), box sums | per-ray features
+    //   main: zeroed scratch, head                                           | cells, pairs, points, (guard done) PointNet
+    // ev_fork is recorded on the main stream twice (start, rays exist), ev_join on the side stream twice (guard
+    // done, per-ray features done); each wait refers to the record issued before it.
     const bool two = a->aux_stream && a->ev_fork && a->ev_join;
     hipStream_t sx = (hipStream_t)a->aux_stream;
     const int Edv = 3 + 6 * a->multires_views;
+    bool guard_on_side = false;
     if (two) {
         CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_fork, st));
         CHECK_HIP(hipStreamWaitEvent(sx, (hipEvent_t)a->ev_fork, 0));
-        CHECK_HIP(lidf_launch_rayfeat_phase(a->feat_grid, (float*)(ws + f.query + qw.box), B, h, w, a->ray_dir,
-                                            a->ray_pix, a->ray_bid, N, a->counts, a->roi_inp_bbox / 2,
-                                            a->multires_views, a->rayfeat, 128 + Edv, 1, sx));
     }
     if (own_pack) {
         const FramePackLay pl = frame_pack_lay();
         char* blob = (char*)a->pack_blob;
-        if (a->pack_mode == LIDF_FRAME_PACK_GUARDED &&
-            (rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, (hipStream_t)stream))) {
-            if (two && hipEventRecord((hipEvent_t)a->ev_join, sx) == hipSuccess)   // (never leave a fork open)
-                (void)hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0);
-            return rc;
+        if (a->pack_mode == LIDF_FRAME_PACK_GUARDED) {
+            rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, two ? sx : st);
+            if (two) {   // (also on failure: never leave a fork open)
+                const bool ok = hipEventRecord((hipEvent_t)a->ev_join, sx) == hipSuccess;
+                if (rc && ok) (void)hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0);
+                if (!rc && !ok) rc = LIDF_ERR_HIP;
+                guard_on_side = true;
+            }
+            if (rc) return rc;
         }
         a->packed_query = blob + pl.query;
         pn_loc.packed = blob + pl.pnet;
         pnr_loc.packed = blob + pl.pnet_r;
         a->packed_refine = blob + pl.refine;
     }
+    if (two)
+        CHECK_HIP(lidf_launch_rayfeat_phase(a->feat_grid, (float*)(ws + f.query + qw.box), B, h, w, a->ray_dir,
+                                            a->ray_pix, a->ray_bid, N, a->counts, a->roi_inp_bbox / 2,
+                                            a->multires_views, a->rayfeat, 128 + Edv, 1, sx));
     a->pnet = &pn_loc;
     if (rf) a->pnet_refine = &pnr_loc;
     int* counts = a->counts;
@@ -1793,14 +1801,14 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
                                             a->multires_views, a->rayfeat, 128 + Edv, 2, sx));
         // (the per-ray layer-1 tables stay on the main stream: a launch that fills the device starves the
         // PointNet's light launches beside it — measured, fused kernel start 326 -> 354 us)
-        CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));
     }
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
     float* vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;   // intersect_pos_type 'rel'
     CHECK_HIP(lidf_launch_frame_cells(cell_flag, C, g, cell_rank, a->occ_bid_coord, a->voxel_bound, vox_bid,
                                       vox_center, counts, st));
-    // 3. ray / voxel pairs: count, offsets (cut at max_pairs, P) and fill in ONE launch
+    // 3. ray / voxel pairs: count, offsets (cut at max_pairs, P) and fill in ONE launch (on the main stream:
+    //    behind the per-ray features it made the side branch the longer one — measured)
     CHECK_HIP(lidf_launch_ray_aabb_onepass(a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, counts,
                                            ws + f.lb_pairs, a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
                                            a->max_pairs, st));
@@ -1808,6 +1816,8 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
                                        a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
                                        pnet_abs, st));
+    if (guard_on_side) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));   // weight streams valid
+    if (two) CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));   // (second record: the per-ray features)
     // 4. voxel embedding: PointNet over the in-grid valid points
     if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
                              counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))

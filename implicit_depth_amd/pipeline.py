@@ -250,7 +250,7 @@ class FrameRunner:
 
     def __init__(self, bs, h, w, device, pnet_model, prob_dec, offset_dec, opt=None, pnet_model_refine=None,
                  offset_dec_refine=None, max_pairs=None, lds_voxels=None,
-                 precision="f32", guard_every=1, offsets="all", side_stream=False):
+                 precision="f32", guard_every=1, offsets="all", side_stream=None):
         import ctypes as C
         import math
         from .decoders import _check_supported
@@ -337,10 +337,14 @@ class FrameRunner:
         self._keep = None
         self.guard_every = max(1, int(guard_every))
         self._frames_since_guard = None            # None: the next frame validates
-        # side_stream: the [ray / voxel pairs, per-ray features] branch of the frame runs on a second stream
-        # beside the PointNet branch (lidf_hip.h: LidfFrameArgs.aux_stream); results are bit-identical
+        # side_stream (lidf_hip.h: LidfFrameArgs.aux_stream): the weight-stream guard, the box sums and the
+        # per-ray features of a frame run on a second stream beside its head, voxel list, pairs and PointNet;
+        # bit-identical results. None (default) = for eager calls only: a replayed graph pays more for the
+        # cross-stream edges than they save, and frames pipelined over several streams fill each other's gaps
+        # already (FramePipeline passes False). True / False force it.
+        self.side_mode = side_stream
         self.side = None
-        if side_stream:
+        if side_stream is None or side_stream:
             with torch.cuda.device(dev):
                 self.side = (torch.cuda.Stream(dev), _lib.hip_event(), _lib.hip_event())
         self.pack_blob = torch.empty((L.lidf_frame_pack_bytes(),), dtype=torch.uint8, device=dev)
@@ -473,7 +477,7 @@ class FrameRunner:
         a.pack_guard = self.pack_guard.data_ptr()
         a.pack_mode = 1 if guard else 2
         a.offsets_selected = int(self.offsets == "selected")
-        if self.side is not None:
+        if self.side is not None and (self.side_mode or not torch.cuda.is_current_stream_capturing()):
             a.aux_stream, a.ev_fork, a.ev_join = self.side[0].cuda_stream, self.side[1], self.side[2]
         try:
             with torch.cuda.device(self.dev):
@@ -606,6 +610,8 @@ class FramePipeline:
         if streams < 1:
             raise ValueError("streams must be >= 1")
         self.dev = torch.device(device)
+        if streams > 1:
+            kw.setdefault("side_stream", False)   # (the lanes fill each other's gaps: see FrameRunner)
         self.runners = [FrameRunner(bs, h, w, device, *models, **kw) for _ in range(streams)]
         self.lanes = [torch.cuda.Stream(self.dev) for _ in range(streams)]
         self.with_metrics = with_metrics

@@ -295,15 +295,17 @@ def test_frame_offsets_for_selected_pairs_only(cuda, shape, graph):
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("offsets", ["all", "selected"])
 def test_frame_with_a_side_stream(cuda, graph, offsets):
-    """side_stream=True (LidfFrameArgs.aux_stream / ev_fork / ev_join): the ray / voxel pair + per-ray feature
-    branch runs beside the PointNet branch. Same kernels on the same data: every output is bit-identical,
-    eager and through a captured graph, over several frames with different inputs on the same runner."""
+    """side_stream=True (LidfFrameArgs.aux_stream / ev_fork / ev_join): the weight-stream guard, the box sums and
+    the per-ray features run beside the head, the pairs and the PointNet. Same kernels on the same data: every
+    output is bit-identical to the one-stream call, eager and through a captured graph, over several frames
+    with different inputs on the same runner (FrameRunner's default: side stream for eager calls only)."""
     from implicit_depth_amd import pipeline as pl
     from implicit_depth_amd.synthetic import synthetic_batch
     B, h, w = 2, 60, 80
     models = _models(cuda)
     opt = pl.LidfOptions(valid_stride=2)
-    one = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets=offsets)
+    one = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets=offsets,
+                         side_stream=False)
     two = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], offsets=offsets,
                          side_stream=True)
     for it, seed in enumerate((5, 6, 7)):
