@@ -691,7 +691,9 @@ def e2e(args):
                     "frac": round(flop / t / 1e12 / PEAK_F32_TFLOPS, 4)}
         npn = c["NPN"] if mode != "stepwise" else 0
         roof = {
-            "points": dict(frac("lidf_points_fused_kernel", F_EXEC * P) or {}, flop_per_point_exec=F_EXEC),
+            # (offsets='selected': two launches of one net each — P points, then R — : no single-launch fraction)
+            "points": (dict(frac("lidf_points_fused_kernel", F_EXEC * P) or {}, flop_per_point_exec=F_EXEC)
+                       if args.offsets == "all" else None),
             # stage-2 decoder (lidf_ief16_kernel): per 16 rays 4 x 16 x 4 layer-1 + 2 passes x (12 bias + 16 rank-1 +
             # 512 + 128) v_mfma_f32_16x16x4_f32 of 2048 FLOP
             "ief": dict(frac("lidf_ief16_kernel", F_IEF16 * R) or frac("lidf_points_kernel<6>", F_IEF32 * R) or {},

@@ -5,17 +5,16 @@ O=gpurun_out/r4p; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/err.txt
 for M in stepwise frame graph; do for F in 1 4; do
-python bench.py --workload e2e --e2e-mode $M --frames $F --steps 40 --warmup 5 $( [ $M = frame ] && [ $F = 1 ] && echo --pmc ) > $O/bench_e2e_${M}_f$F.json 2>> $O/err.txt; done; done
-for S in 2 3; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 60 --warmup 6 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
-python bench.py --workload e2e --e2e-mode graph --guard-every 32 --steps 64 --warmup 5 > $O/bench_e2e_graph_f1_guard32.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --frames 4 --streams 2 --steps 30 --warmup 6 > $O/bench_e2e_frame_f4_streams2.json 2>> $O/err.txt
-# opt-in variants: a side stream inside the frame call; the offset decoder on the selected pairs only
-python bench.py --workload e2e --e2e-mode frame --side-stream --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_side.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --side-stream --guard-every 32 --steps 128 --warmup 10 > $O/bench_e2e_frame_f1_side_guard32.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --offsets selected --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_selected.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --offsets selected --side-stream --steps 100 --warmup 10 > $O/bench_e2e_frame_f1_selected_side.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --offsets selected --streams 3 --steps 120 --warmup 12 > $O/bench_e2e_frame_f1_selected_streams3.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --offsets selected --frames 4 --steps 40 --warmup 5 > $O/bench_e2e_frame_f4_selected.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode $M --frames $F --steps $( [ $F = 1 ] && echo 300 || echo 80 ) --warmup 10 $( [ $M = frame ] && [ $F = 1 ] && echo --pmc ) > $O/bench_e2e_${M}_f$F.json 2>> $O/err.txt; done; done
+for S in 2 3; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
+python bench.py --workload e2e --e2e-mode graph --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_graph_f1_guard32.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --frames 4 --streams 2 --steps 80 --warmup 8 > $O/bench_e2e_frame_f4_streams2.json 2>> $O/err.txt
+# variants: one stream inside the frame call; guard every 32nd frame; the offset decoder on the selected pairs only (opt-in)
+python bench.py --workload e2e --e2e-mode frame --no-side-stream --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_onestream.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_frame_f1_guard32.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_selected.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --streams 3 --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_selected_streams3.json 2>> $O/err.txt
+python bench.py --workload e2e --e2e-mode frame --offsets selected --frames 4 --steps 80 --warmup 8 > $O/bench_e2e_frame_f4_selected.json 2>> $O/err.txt
 for p in ragged n1 scene; do python bench.py --pairs $p --steps 20 --warmup 3 --no-cpu-baseline $( [ $p = scene ] && echo --pmc ) > $O/bench_pairs_$p.json 2>> $O/err.txt; done
 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_config2.json 2>> $O/err.txt
 python bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --pmc > $O/bench_config3.json 2>> $O/err.txt
