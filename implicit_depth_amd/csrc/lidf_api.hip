@@ -92,10 +92,10 @@ hipError_t lidf_launch_frame_head(const float*, const float*, const float*, cons
 size_t lidf_frame_head_blocks(long long);
 size_t lidf_frame_head_lb_bytes(long long);
 hipError_t lidf_launch_frame_cells(const int*, long long, const GridSpec&, int*, int*, float*, int*, float*,
-                                   int*, hipStream_t);
+                                   int*, int*, hipStream_t);
 size_t lidf_ray_aabb_onepass_lb_bytes(long long);
 hipError_t lidf_launch_ray_aabb_onepass(const float*, const float*, const int*, const int*, long long, int*,
-                                        void*, int*, int*, int*, float*, long long, hipStream_t);
+                                        void*, int*, int*, int*, float*, long long, const int*, hipStream_t);
 hipError_t lidf_launch_roi_align(const float*, int, int, int, const int*, const int*, long long, int, int,
                                  float*, long long, hipStream_t);
 hipError_t lidf_launch_frame_points(const float*, const float*, const int*, const int*, const int*,
@@ -1526,7 +1526,7 @@ static FrameWs frame_ws(int B, int h, int w, const int32_t* res, int64_t max_pai
     f.lb_bytes = o;
     f.cell_flag = o; o += align_up(C * 4, 256);
     f.cell_rank = o; o += align_up((C + 1) * 4, 256);
-    f.vox_bid = o;   o += align_up(C * 4, 256);
+    f.vox_bid = o;   o += align_up((C + (size_t)B + 1) * 4, 256);   // [V] image of a voxel | [B + 1] first voxel of an image
     f.vox_center = o; o += align_up(C * 12, 256);
     f.pt_key = o;    o += align_up(N * 4, 256);
     f.pt_rank = o;   o += align_up((N + 1) * 4, 256);
@@ -1805,13 +1805,14 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
     float* vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;   // intersect_pos_type 'rel'
+    int* vox_start = B > 1 ? vox_bid + C : nullptr;   // (one image: every voxel is its image's)
     CHECK_HIP(lidf_launch_frame_cells(cell_flag, C, g, cell_rank, a->occ_bid_coord, a->voxel_bound, vox_bid,
-                                      vox_center, counts, st));
+                                      vox_center, counts, vox_start, st));
     // 3. ray / voxel pairs: count, offsets (cut at max_pairs, P) and fill in ONE launch (on the main stream:
     //    behind the per-ray features it made the side branch the longer one — measured)
     CHECK_HIP(lidf_launch_ray_aabb_onepass(a->ray_dir, a->voxel_bound, a->ray_bid, vox_bid, N, counts,
                                            ws + f.lb_pairs, a->pair_off, a->pair_ray, a->pair_vox, a->pair_t,
-                                           a->max_pairs, st));
+                                           a->max_pairs, vox_start, st));
     float* pnet_abs = (rf && !a->refine_pnet_pos_rel) ? (float*)(ws + f.pnet_abs) : nullptr;
     CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
                                        a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,

@@ -941,7 +941,8 @@ __global__ void __launch_bounds__(256) lidf_ray_aabb_onepass_kernel(
     const float* __restrict__ ray_dir, const float* __restrict__ vbound, const int* __restrict__ ray_bid,
     const int* __restrict__ vox_bid, int* __restrict__ counts, int* __restrict__ ticket,
     unsigned long long* __restrict__ status, int* __restrict__ pair_off, int* __restrict__ pair_ray,
-    int* __restrict__ pair_vox, float* __restrict__ pair_t, long long pair_cap) {
+    int* __restrict__ pair_vox, float* __restrict__ pair_t, long long pair_cap,
+    const int* __restrict__ vox_start) {
     __shared__ int s_hit[AABB_HITS * 256];
     __shared__ int s_tmp[4];
     __shared__ int s_bid;
@@ -971,9 +972,29 @@ __global__ void __launch_bounds__(256) lidf_ray_aabb_onepass_kernel(
     typedef const int __attribute__((address_space(4))) * ci_ptr;
     const cf_ptr vbc = (cf_ptr)(unsigned long long)vbound;
     const ci_ptr vbidc = (ci_ptr)(unsigned long long)vox_bid;
-    const int Vi = (int)V;
+    // vox_start (optional; several images per batch): the voxels are grouped by image, image i owns
+    // [vox_start[i], vox_start[i + 1]) — a wavefront's rays are consecutive pixels of one image (two at a
+    // seam), so it walks the voxels of its first to its last image only instead of the whole batch's
+    int j0 = 0, Vi = (int)V;
+    if (vox_start) {
+        int b_lo = live ? rb : 0x7fffffff, b_hi = live ? rb : -1;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            b_lo = min(b_lo, __shfl_xor(b_lo, sft));
+            b_hi = max(b_hi, __shfl_xor(b_hi, sft));
+        }
+        b_lo = __builtin_amdgcn_readfirstlane(b_lo);
+        b_hi = __builtin_amdgcn_readfirstlane(b_hi);
+        if (b_hi >= 0) {
+            const ci_ptr vsc = (ci_ptr)(unsigned long long)vox_start;
+            j0 = vsc[b_lo];
+            Vi = vsc[b_hi + 1];
+        } else {
+            Vi = 0;   // (no live ray in this wavefront)
+        }
+    }
 #pragma unroll 8
-    for (int j = 0; j < Vi; ++j) {
+    for (int j = j0; j < Vi; ++j) {
         const cf_ptr vb = vbc + 6 * (size_t)j;
         // ((c ? lo : hi) * i written as c ? lo * i : hi * i — the same product, and the six bounds stay
         // wave-uniform scalar loads instead of one load through a per-lane selected address)
@@ -1050,11 +1071,12 @@ extern "C" size_t lidf_ray_aabb_onepass_lb_bytes(long long R_cap) { return 64 + 
 extern "C" hipError_t lidf_launch_ray_aabb_onepass(const float* ray_dir, const float* vbound, const int* ray_bid,
                                                    const int* vox_bid, long long R_cap, int* counts, void* lb,
                                                    int* pair_off, int* pair_ray, int* pair_vox, float* pair_t,
-                                                   long long pair_cap, hipStream_t st) {
+                                                   long long pair_cap, const int* vox_start, hipStream_t st) {
     if (R_cap <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_ray_aabb_onepass_kernel, dim3((unsigned)((R_cap + 255) / 256)), dim3(256), 0, st,
                        ray_dir, vbound, ray_bid, vox_bid, counts, (int*)lb,
-                       (unsigned long long*)((char*)lb + 64), pair_off, pair_ray, pair_vox, pair_t, pair_cap);
+                       (unsigned long long*)((char*)lb + 64), pair_off, pair_ray, pair_vox, pair_t, pair_cap,
+                       vox_start);
     return hipGetLastError();
 }
 

@@ -219,8 +219,10 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
                                                                  int* __restrict__ occ, float* __restrict__ vbound,
                                                                  int* __restrict__ vox_bid,
                                                                  float* __restrict__ vox_center,
-                                                                 int* __restrict__ counts) {
+                                                                 int* __restrict__ counts,
+                                                                 int* __restrict__ vox_start) {
     __shared__ int s_w[16];
+    const long long cpi = (long long)g.r[0] * g.r[1] * g.r[2];   // cells per image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int carry = 0;
     for (long long b = 0; b < ncell; b += 1024) {
@@ -243,6 +245,8 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
         }
         const int v = carry + wpre + inc - f;
         if (k < ncell) {
+            // the voxels are in cell order, image-major: image i owns voxels [vox_start[i], vox_start[i + 1])
+            if (vox_start && k % cpi == 0) vox_start[k / cpi] = v;
             cell_rank[k] = f ? v : -1;   // cell -> voxel table (-1: not occupied)
             if (f) {
                 int rem = (int)k;
@@ -270,6 +274,7 @@ __global__ void __launch_bounds__(1024) lidf_frame_cells_kernel(const int* __res
     if (threadIdx.x == 0) {
         cell_rank[ncell] = carry;
         counts[2] = carry;   // V
+        if (vox_start) vox_start[ncell / cpi] = carry;
     }
 }
 
@@ -352,10 +357,11 @@ extern "C" hipError_t lidf_launch_frame_head(const float* valid_mask, const floa
 
 extern "C" hipError_t lidf_launch_frame_cells(const int* cell_flag, long long ncell, const GridSpec& g,
                                               int* cell_rank, int* occ, float* vbound, int* vox_bid,
-                                              float* vox_center, int* counts, hipStream_t st) {
+                                              float* vox_center, int* counts, int* vox_start,
+                                              hipStream_t st) {
     if (ncell <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_frame_cells_kernel, dim3(1), dim3(1024), 0, st, cell_flag, ncell, g, cell_rank, occ,
-                       vbound, vox_bid, vox_center, counts);
+                       vbound, vox_bid, vox_center, counts, vox_start);
     return hipGetLastError();
 }
 

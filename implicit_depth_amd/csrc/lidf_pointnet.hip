@@ -189,6 +189,10 @@ template <int STAGE, bool LDSPOOL>
 __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainArgs a) {
     extern __shared__ int pn_tab[];
     constexpr int F = STAGE == 1 ? 64 : 128;
+    // rows of the LDS table are F + 1 words apart: with a stride of 64 / 128 words every row starts in the same
+    // bank, and the 32 points of a wavefront — mostly different voxels, the same feature index — hit ONE
+    // bank with every atomic (SQ_LDS_BANK_CONFLICT 92 % of the LDS cycles of the stage-2 chain)
+    constexpr int FP = F + 1;
     bool windowed = LDSPOOL && a.window > 0 && a.perm;
     if (LDSPOOL && a.V_dev) windowed = windowed && *a.V_dev > a.v_tab;   // device-side choice of the walk
     const bool use_perm = a.perm && (!LDSPOOL || windowed);
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
 
     if (tb >= te || tb * 128 >= AN) return;   // (workgroup-uniform: nothing to pool, nothing to flush)
     if (LDSPOOL) {
-        for (int i = threadIdx.x; i < tab_rows * F; i += 256) pn_tab[i] = 0;
+        for (int i = threadIdx.x; i < tab_rows * FP; i += 256) pn_tab[i] = 0;
         __syncthreads();
     }
     f32x4 ring[LIDF_RING];
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
                 if (kq == 16) {
                     pn_relu(acc);
                     if (LDSPOOL) {
-                        pn_pool_lds(acc, T, vrow, valid, pn_tab, 128, h);
+                        pn_pool_lds(acc, T, vrow, valid, pn_tab, 129, h);
                         if (spill) pn_pool_lane(acc, T, vox, a.pool, 128, h);
                     } else {
                         F5[(STAGE == 2 && !LDSPOOL) ? T : 0] = acc;
@@ -334,8 +338,8 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         }
         if (STAGE == 1) {
             if (LDSPOOL) {
-                pn_pool_lds(F2[0], 0, vrow, valid, pn_tab, 64, h);
-                pn_pool_lds(F2[1], 1, vrow, valid, pn_tab, 64, h);
+                pn_pool_lds(F2[0], 0, vrow, valid, pn_tab, 65, h);
+                pn_pool_lds(F2[1], 1, vrow, valid, pn_tab, 65, h);
                 if (spill) {
                     pn_pool_lane(F2[0], 0, vox, a.pool, 64, h);
                     pn_pool_lane(F2[1], 1, vox, a.pool, 64, h);
@@ -349,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) lidf_pointnet_chain_kernel(PnetChainAr
         // the table's rows into the global table: one atomic maximum per touched entry and workgroup
         __syncthreads();
         for (int i = threadIdx.x; i < tab_rows * F; i += 256) {
-            const int v = pn_tab[i];
+            const int v = pn_tab[(i / F) * FP + i % F];
             const int row = vbase + i / F;
             if (v > 0 && row < a.V) atomicMax((int*)a.pool + (size_t)row * F + i % F, v);
         }
@@ -411,7 +415,7 @@ extern "C" size_t lidf_pointnet_chain_stream_bytes(void) { return (size_t)PN_S2_
 
 #define PN_WINDOW 32     // rows of the windowed table of the voxel-sorted walk (16 KiB at 128 features)
 #define PN_MAX_WGS 512
-#define PN_LDS_LIMIT (144 * 1024)
+#define PN_LDS_LIMIT (288 * 129 * 4)   // 288 rows of 128 + 1 words
 #define PN_COPIES 16
 static int pn_copies(long long V) {
     long long c = (32LL << 20) / (V * 512);
@@ -421,7 +425,7 @@ static int pn_copies(long long V) {
 // else up to PN_COPIES copies of the table for the unsorted global-atomic path (at most 32 MiB).
 extern "C" size_t lidf_pointnet_pool_scratch_bytes(long long V) {
     if (V <= 0) return 0;
-    if ((size_t)V * 128 * 4 > PN_LDS_LIMIT) return (size_t)pn_copies(V) * V * 128 * 4;
+    if ((size_t)V * 129 * 4 > PN_LDS_LIMIT) return (size_t)pn_copies(V) * V * 128 * 4;
     return 0;
 }
 
@@ -450,10 +454,10 @@ extern "C" hipError_t lidf_launch_pointnet_chain(int stage, const float* stream,
     const int F = stage == 1 ? 64 : 128;
     const long long count = V * F;
     const long long ntile = (n + 127) / 128;
-    const size_t lds = (size_t)V * F * 4;
-    if ((size_t)V * 128 * 4 <= PN_LDS_LIMIT) {
+    const size_t lds = (size_t)V * (F + 1) * 4;
+    if ((size_t)V * 129 * 4 <= PN_LDS_LIMIT) {
         // two workgroups per CU while two tables fit, else one
-        long long g = lds <= 65536 ? 2LL * cus : cus;
+        long long g = lds <= 80 * 1024 ? 2LL * cus : cus;
         if (g > PN_MAX_WGS) g = PN_MAX_WGS;
         if (g > ntile) g = ntile;
         a.part = nullptr;
@@ -487,16 +491,16 @@ extern "C" hipError_t lidf_launch_pointnet_chain_dev(int stage, const float* str
                                                      const int* V_dev, const int* perm,
                                                      const int* n_perm, int cus, hipStream_t st) {
     if (n_cap <= 0) return hipSuccess;
-    if (v_lds <= 0 || (size_t)v_lds * 128 * 4 > PN_LDS_LIMIT || !V_dev) return hipErrorInvalidValue;
+    if (v_lds <= 0 || (size_t)v_lds * 129 * 4 > PN_LDS_LIMIT || !V_dev) return hipErrorInvalidValue;
     PnetChainArgs a;
     a.stream = stream; a.inp = inp; a.vox = vox; a.gpart = gpart; a.pool = pool; a.n = n_cap;
     a.part = nullptr; a.V = (int)V_cap; a.copies = 0; a.n_dev = n_dev; a.V_dev = V_dev; a.v_tab = v_lds;
     a.perm = perm; a.n_perm = n_perm; a.window = perm ? PN_WINDOW : 0;
     const int F = stage == 1 ? 64 : 128;
     const long long ntile = (n_cap + 127) / 128;
-    size_t lds = (size_t)v_lds * F * 4;
-    if (perm && lds < (size_t)PN_WINDOW * F * 4) lds = (size_t)PN_WINDOW * F * 4;
-    long long g = lds <= 65536 ? 2LL * cus : cus;
+    size_t lds = (size_t)v_lds * (F + 1) * 4;
+    if (perm && lds < (size_t)PN_WINDOW * (F + 1) * 4) lds = (size_t)PN_WINDOW * (F + 1) * 4;
+    long long g = lds <= 80 * 1024 ? 2LL * cus : cus;   // two tables per CU while they fit
     if (g > PN_MAX_WGS) g = PN_MAX_WGS;
     if (g > ntile) g = ntile;
     return stage == 1 ? launch_chain_lds<1>(a, g, lds, st) : launch_chain_lds<2>(a, g, lds, st);
@@ -517,7 +521,7 @@ extern "C" size_t lidf_sort_idx_ws_bytes(long long P, long long V);
 extern "C" hipError_t lidf_launch_sort_idx(const int* idx, long long P, const int* n_dev, long long V,
                                            void* ws, const int** perm_out, const int** n_perm_out,
                                            hipStream_t st);
-extern "C" int lidf_pointnet_lds_max_voxels(void) { return PN_LDS_LIMIT / 512; }
+extern "C" int lidf_pointnet_lds_max_voxels(void) { return PN_LDS_LIMIT / 516; }
 // scratch of the sort (0: the table is too large for it — the unsorted global-atomic path is taken)
 extern "C" size_t lidf_pointnet_sort_bytes(long long n, long long V) { return lidf_sort_idx_ws_bytes(n, V); }
 
@@ -534,7 +538,7 @@ extern "C" hipError_t lidf_launch_pointnet_chain_sorted(int stage, const float* 
     a.n_dev = nullptr; a.V_dev = nullptr;
     a.n_perm = n_perm; a.perm = perm; a.window = PN_WINDOW;
     const int F = stage == 1 ? 64 : 128;
-    const size_t wl = (size_t)PN_WINDOW * F * 4;
+    const size_t wl = (size_t)PN_WINDOW * (F + 1) * 4;
     const long long ntile = (n_cap + 127) / 128;
     const long long g = ntile < 2LL * cus ? ntile : 2LL * cus;
     return stage == 1 ? launch_chain_lds<1>(a, g, wl, st) : launch_chain_lds<2>(a, g, wl, st);
