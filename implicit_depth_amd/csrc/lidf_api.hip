@@ -633,9 +633,11 @@ LIDF_API int lidf_query_pack_guarded_f32(const LidfDecoder* prob, const LidfDeco
 // launched the per-ray features into q->rayfeat_out with this workspace's box-sum image, then calls with
 // QP_RAYTAB on the side stream and with QP_MAIN on the main one; both need q->packed).
 enum { QP_RAYFEAT = 1, QP_RAYTAB = 2, QP_MAIN = 4, QP_ALL = 7 };
+// ev_l1 (optional): recorded on the stream behind the layer-1 table launch (the frame path's side stream starts
+// the stage-2 table there, beside the per-point kernel).
 static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_points_end,
                       lidf_stream_t stream, const int* dims = nullptr, PointsArgs* extra_l1 = nullptr,
-                      int phases = QP_ALL) {
+                      int phases = QP_ALL, void* ev_l1 = nullptr) {
     if (!q) return LIDF_ERR_BAD_ARG;
     if (dims && !q->packed) return LIDF_ERR_UNSUPPORTED;
     const int64_t R = q->n_rays, P = q->n_pairs, V = q->n_vox;
@@ -734,6 +736,7 @@ static int query_impl(const LidfQueryArgs* q, void* ev_points_begin, void* ev_po
                                                   (phases & QP_RAYTAB) ? extra_l1 : nullptr, cus, st));
             }
         }
+        if (ev_l1) CHECK_HIP(hipEventRecord((hipEvent_t)ev_l1, st));
         if (!(phases & QP_MAIN)) return LIDF_OK;
         // 4. per-point kernel
         {
@@ -1825,9 +1828,21 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         return rc;
     if (two) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
     // 5. get_embedding + get_pred + depth
-    if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split) ? &xr : nullptr,
-                         two ? (QP_RAYTAB | QP_MAIN) : QP_ALL)))
+    // (with a side stream the stage-2 table — a third of the layer-1 launch, not read before the first refine
+    // iteration — leaves that launch and runs beside the per-point kernel: 104 registers and 17 KiB of LDS next
+    // to its 220 and 128 KiB, in the matrix-pipe slots its one wavefront per SIMD leaves free, and in its tail)
+    const bool xr_aside = two && rf && !split;
+    if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split && !xr_aside) ? &xr : nullptr,
+                         two ? (QP_RAYTAB | QP_MAIN) : QP_ALL, xr_aside ? a->ev_fork : nullptr)))
         return rc;
+    if (xr_aside) {
+        const PointsArgs none = {};
+        xr.X = a->rayfeat; xr.ldx = 128 + Edv;
+        CHECK_HIP(hipStreamWaitEvent(sx, (hipEvent_t)a->ev_fork, 0));   // (third record: the layer-1 launch is out)
+        CHECK_HIP(lidf_launch_l1only_pair(none, none, &xr, cus, sx));
+        CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));          // (third record)
+        CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
+    }
     if (!rf) return LIDF_OK;
 
     // 6. stage 2: refine_times x get_pred_refine on the device-resident state
