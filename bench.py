@@ -680,6 +680,7 @@ def e2e(args):
         live = live_profile(sys.argv[1:], "lidf_points_fused_kernel" if args.precision == "f32" else "lidf_points_h_kernel",
                             pmc=args.pmc)
     roof = None
+    side_on = mode != "stepwise" and bool(side_mode or (side_mode is None and mode == "frame"))
     if live and args.precision == "f32" and mode != "stepwise":
         def frac(name, flop):
             k = live_kernel(live, name)
@@ -700,7 +701,10 @@ def e2e(args):
                         sub_tiles=(R + 15) // 16, flop_per_ray_exec=F_IEF16),
             # PointNet2Stage chains of one refine pass: 44 (stage 1) and 444 (stage 2) matrix instructions per 32 points
             "pointnet_chain2": frac("lidf_pointnet_chain_kernel<2, true>", 444 * 4096 / 32.0 * (NV + 2 * npn) / 3.0),
-            "l1part": frac("lidf_l1part_pair_kernel", 2.0 * 155 * (512 + 256) * R + 2.0 * 129 * 512 * V),
+            # (with the side stream the stage-2 table is a second launch of this kernel that runs beside — and is
+            # stretched over — the per-point kernel: no per-launch fraction; the one-stream record carries it)
+            "l1part": (frac("lidf_l1part_pair_kernel", 2.0 * 155 * (512 + 256) * R + 2.0 * 129 * 512 * V)
+                       if not side_on else None),
         }
     emit({
         "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),

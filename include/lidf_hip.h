@@ -544,13 +544,15 @@ typedef struct LidfFrameArgs {
      * side. On `aux_stream`: the weight-stream guard (pack_mode GUARDED: fingerprint + early-exit packs), the
      * box sums of the feature map, then — once the rays exist — the per-ray RoIAlign features; on `stream`
      * meanwhile: zeroed scratch, frame head, voxel list, ray / voxel pairs, PointNet rows and (after the
-     * guard) PointNet2Stage. `ev_fork` is recorded on `stream` twice (start of the frame, rays exist) and
-     * awaited by `aux_stream` each time; `ev_join` is recorded on `aux_stream` twice (guard done, per-ray
-     * features done) and awaited by `stream` before the first weight stream is read / before the layer-1
-     * tables. Results are bit-identical. All three NULL = one stream (the default). ev_fork / ev_join: two
+     * guard) PointNet2Stage; with stage 2, the per-ray layer-1 table of its decoder then runs on
+     * `aux_stream` beside the per-point kernel instead of inside the query's layer-1 launch. `ev_fork` is
+     * recorded on `stream` three times (start of the frame, rays exist, layer-1 launch done) and awaited by
+     * `aux_stream` each time; `ev_join` is recorded on `aux_stream` three times (guard done, per-ray
+     * features done, stage-2 table done) and awaited by `stream` before the first weight stream is read /
+     * before the layer-1 tables / before stage 2. Results are bit-identical. All three NULL = one stream (the default). ev_fork / ev_join: two
      * hipEvent_t of the caller (hipEventDisableTiming is enough), not shared with a frame in flight on
      * another stream. Capturable (the side stream joins the capture through the events); measured on
-     * MI355X: eager 1.715 -> 1.683 ms per 240x320 frame, under a replayed graph no gain.                */
+     * MI355X: eager 1.71 -> 1.66 ms per 240x320 frame, under a replayed graph no gain.                */
     lidf_stream_t aux_stream;
     void* ev_fork;
     void* ev_join;
