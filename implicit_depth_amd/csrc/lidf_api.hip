@@ -68,6 +68,9 @@ hipError_t lidf_launch_pointnet_chain_dev(int, const float*, const float*, const
                                           float*, long long, int, long long, const int*,
                                           const int*, const int*, const int*, int, hipStream_t);
 hipError_t lidf_launch_vox2(const Vox2Args&, hipStream_t);
+size_t lidf_group_idx_bytes(long long, long long);
+hipError_t lidf_launch_group_idx(const int*, long long, const int*, long long, void*, const int**, const int**,
+                                 hipStream_t);
 hipError_t lidf_launch_ief16(const Ief16Args&, int, hipStream_t);
 int lidf_pointnet_lds_max_voxels(void);
 size_t lidf_pointnet_sort_bytes(long long, long long);
@@ -1476,7 +1479,8 @@ static PnetFrameWs pnet_frame_ws(int64_t v_cap, int v_lds, int64_t n_cap = 0) {
     w.g1 = o;    o += align_up(V * 64 * 4, 256);
     w.gpart = o; o += align_up(V * 128 * 4, 256);
     w.pool2 = o; o += align_up(V * 128 * 4, 256);
-    w.sort = o;  o += n_cap > 0 ? align_up(lidf_pointnet_sort_bytes(n_cap, v_cap), 256) : 0;
+    // (the grouping of a batch's points by voxel: its table of counts, V words at the head, starts zeroed)
+    w.sort = o;  o += n_cap > 0 ? align_up(lidf_group_idx_bytes(n_cap, v_cap), 256) : 0;
     w.total = o;
     return w;
 }
@@ -1493,8 +1497,8 @@ static int pointnet_frame(const LidfPointNet* w, const float* inp, const int32_t
     if (!w->packed) return LIDF_ERR_BAD_ARG;
     const PnetFrameWs f = pnet_frame_ws(V_cap, v_lds, sort_cap);
     const int *perm = nullptr, *n_perm = nullptr;
-    if (sort_cap > 0 && lidf_pointnet_sort_bytes(sort_cap, V_cap) > 0)
-        CHECK_HIP(lidf_launch_sort_idx(vox, n_cap, n_dev, V_cap, ws + f.sort, &perm, &n_perm, st));
+    if (sort_cap > 0)
+        CHECK_HIP(lidf_launch_group_idx(vox, n_cap, n_dev, V_cap, ws + f.sort, &perm, &n_perm, st));
     const PnetWs pw = pnet_ws(1, 1);   // offsets of the packed streams
     float* streams[7];
     for (int i = 0; i < 7; ++i) streams[i] = (float*)((char*)w->packed + pw.s[i]);
@@ -1747,11 +1751,11 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     float* pool1 = (float*)(ws + f.pnet + pf.pool1);
     float* pool2 = (float*)(ws + f.pnet + pf.pool2);
     {
-        float* zp[5] = {(float*)(ws + f.lb_head), pool1, pool2, (float*)(ws + f.query + qw.counter),
-                        (float*)(ws + f.query + qw.box) + grid_floats};
-        const long long zc[5] = {(long long)(f.lb_bytes / 4) + (long long)C, (long long)C * 64,
-                                 (long long)C * 128, 1, 1};
-        CHECK_HIP(lidf_launch_zero_segments(zp, zc, 5, st));
+        float* zp[6] = {(float*)(ws + f.lb_head), pool1, pool2, (float*)(ws + f.query + qw.counter),
+                        (float*)(ws + f.query + qw.box) + grid_floats, (float*)(ws + f.pnet + pf.sort)};
+        const long long zc[6] = {(long long)(f.lb_bytes / 4) + (long long)C, (long long)C * 64,
+                                 (long long)C * 128, 1, 1, sort_cap > 0 ? (long long)C : 0};
+        CHECK_HIP(lidf_launch_zero_segments(zp, zc, 6, st));
     }
     // the query of step 5 (its per-ray launches go to the side stream when there is one)
     LidfQueryArgs q = {};
