@@ -729,6 +729,9 @@ def e2e(args):
         "rays_per_s": round(R * args.steps / elapsed, 1),
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         "roofline_kernels": roof,
+        "roofline_kernels_note": ("side stream: the stage-2 layer-1 table runs beside (in the tail of) the per-point "
+                                  "kernel, whose duration then includes the shared rounds; per-kernel fractions of "
+                                  "launches that never overlap: --no-side-stream" if side_on and roof else None),
         "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels", "hbm", "mfma")
                      if k in live} if live else None),
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
