@@ -52,7 +52,8 @@ def _compare(dd, ref):
                                                             ((1, 240, 320), None, True, False),
                                                             ((2, 48, 64), None, False, True),
                                                             ((4, 60, 80), 3, True, True),
-                                                            ((4, 240, 320), 6, True, True)])
+                                                            ((4, 240, 320), 6, True, True),
+                                                            ((4, 240, 320), None, True, False)])
 def test_frame_equals_stepwise_path(cuda, shape, stride, use_all_pix, graph):
     from implicit_depth_amd import pipeline as pl
     from implicit_depth_amd.synthetic import synthetic_batch
