@@ -15,7 +15,7 @@ LIDF_OK = 0
 # below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
 # lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
 # outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
-ABI = 7
+ABI = 8
 
 
 class LidfDecoder(C.Structure):
@@ -98,6 +98,8 @@ class LidfRefineArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("precision", C.c_int32), ("pnet_select", C.c_void_p), ("packed", C.c_void_p),
         ("ray_l1", C.c_void_p), ("ray_l1_ready", C.c_int32),
+        ("voxel_coord", C.c_void_p), ("grid_res", C.c_int32 * 3), ("grid_xmin", C.c_float * 3),
+        ("grid_part", C.c_float), ("cell_table", C.c_void_p), ("cell_table_ready", C.c_int32),
     ]
 
 
@@ -137,6 +139,7 @@ class LidfFrameArgs(C.Structure):
         ("pack_blob", C.c_void_p), ("pack_blob_bytes", C.c_size_t), ("pack_guard", C.c_void_p),
         ("pack_mode", C.c_int32), ("offsets_selected", C.c_int32),
         ("aux_stream", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
+        ("fail_after", C.c_int32),
     ]
 
 
@@ -195,6 +198,8 @@ SIGNATURES = {
     "lidf_frame_workspace_bytes": (_SZ, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _I64,
                                          C.c_int32, C.c_int32]),
     "lidf_frame_f32": (C.c_int, [C.POINTER(LidfFrameArgs), _P]),
+    "lidf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "lidf_event_destroy": (C.c_int, [_P]),
     "lidf_frame_pack_bytes": (_SZ, []),
     "lidf_frame_pack_guard_bytes": (_SZ, []),
     "lidf_depth_metrics_workspace_bytes": (_SZ, []),
@@ -361,19 +366,17 @@ def require_cuda(*tensors, names=None):
             raise RuntimeError("%s must be contiguous" % name)
 
 
-_HIP = None
-
-
 def hip_event():
-    """A raw hipEvent_t (timing disabled) for the C-ABI's event arguments (LidfFrameArgs.ev_fork / ev_join):
-    torch.cuda.Event creates its handle lazily at the first record(), the library needs it up front.
-    Lives for the process (a few bytes; a captured graph may reference it)."""
-    global _HIP
-    if _HIP is None:
-        _HIP = C.CDLL("libamdhip64.so")
-        _HIP.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    """A raw hipEvent_t (timing disabled) for the C-ABI's event arguments (LidfFrameArgs.ev_fork / ev_join),
+    created by the HIP runtime liblidf_hip.so itself is linked against (lidf_event_create): torch.cuda.Event
+    creates its handle lazily at the first record(), the library needs it up front, and a second copy of the
+    runtime opened from here would hand out handles that are foreign to the library's hipEventRecord.
+    Release it with hip_event_destroy()."""
     e = C.c_void_p()
-    err = _HIP.hipEventCreateWithFlags(C.byref(e), 0x2)   # hipEventDisableTiming
-    if err != 0:
-        raise RuntimeError("hipEventCreateWithFlags failed (%d)" % err)
+    check(lib().lidf_event_create(C.byref(e)))
     return e.value
+
+
+def hip_event_destroy(e):
+    if e:
+        lib().lidf_event_destroy(C.c_void_p(e))

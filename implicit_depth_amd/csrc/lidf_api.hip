@@ -82,7 +82,8 @@ hipError_t lidf_launch_pointnet_chain_sorted(int, const float*, const float*, co
 hipError_t lidf_launch_refine_prep_dev(const float*, const long long*, const int*, long long, const float*,
                                        const int*, long long, const int*, const int*, const float*,
                                        long long, int, long long, float*, int*, int*,
-                                       const unsigned char*, const int*, const int*, hipStream_t);
+                                       const unsigned char*, const int*, const int*, hipStream_t,
+                                       const CellLookup*);
 hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int, int, int,
                                        int, long long, const int*, float*, int, int, hipStream_t);
 hipError_t lidf_launch_refine_finish_dev(const float*, const float*, const float*, float, float, long long,
@@ -165,7 +166,7 @@ hipError_t lidf_launch_refine_prep(const float*, const long long*, const int*, l
                                    const float*, const int*, long long, const int*, const int*,
                                    const float*, long long, const float*, int, int, int, int, int,
                                    long long, float*, int*, float*, int, int*, const unsigned char*,
-                                   hipStream_t);
+                                   hipStream_t, const CellLookup*);
 hipError_t lidf_launch_refine_gather(const float*, const int*, long long, float*, int, hipStream_t);
 hipError_t lidf_launch_refine_gather_dev(const float*, const int*, long long, const int*, float*, int,
                                          hipStream_t);
@@ -1405,6 +1406,23 @@ static int refine_impl(const LidfRefineArgs* q, lidf_stream_t stream, void* cons
     float* off = (float*)(ws + w.off);
     // final_pnet_inp = cat(valid points, predicted points), final_revidx likewise
     // (pipeline.py:1007-1008)
+    CellLookup cells = {};
+    if (q->voxel_coord) {   // the voxels are cells of a regular grid: end voxel through a cell table
+        if (!q->cell_table || q->batch <= 0 || !(q->grid_part > 0.f)) return LIDF_ERR_BAD_ARG;
+        long long nc = q->batch;
+        for (int k = 0; k < 3; ++k) {
+            if (q->grid_res[k] <= 0) return LIDF_ERR_BAD_ARG;
+            cells.g.xmin[k] = q->grid_xmin[k];
+            cells.g.r[k] = q->grid_res[k];
+            nc *= q->grid_res[k];
+        }
+        if (nc > 0x7fffffffLL) return LIDF_ERR_UNSUPPORTED;
+        cells.g.crop = q->grid_part;
+        cells.g.B = q->batch;
+        cells.coord = q->voxel_coord;
+        cells.table = q->cell_table;
+        cells.ready = q->cell_table_ready;
+    }
     if (Nv > 0) {
         CHECK_HIP(hipMemcpyAsync(pnet_inp, q->valid_inp, (size_t)Nv * 6 * 4,
                                  hipMemcpyDeviceToDevice, st));
@@ -1416,7 +1434,8 @@ static int refine_impl(const LidfRefineArgs* q, lidf_stream_t stream, void* cons
                                       q->rgb_img, (long long)q->height * q->width, q->rayfeat,
                                       128 + Ed, q->multires_views, q->multires, q->pnet_pos_rel,
                                       q->pos_rel, R, pnet_inp + (size_t)Nv * 6, pnet_vox + Nv,
-                                      inp_embed, D, end_voxel, q->pnet_select, st));
+                                      inp_embed, D, end_voxel, q->pnet_select, st,
+                                      q->voxel_coord ? &cells : nullptr));
     // f32: only embed(pos) is a per-iteration operand row — the ROI / direction columns enter layer 1
     // as a per-ray product (refine_ief_factorised); the split-f16 form keeps whole rows
     CHECK_HIP(lidf_launch_refine_rows_dev(q->pred_pos, end_voxel, q->voxel_bound, q->rayfeat, 128 + Ed,
@@ -1647,7 +1666,42 @@ static int frame_pack_guarded(const LidfFrameArgs* a, char* blob, char* guards, 
     return rc ? guard_fail(guards, gbytes, st, rc) : LIDF_OK;
 }
 
+// Side-stream bookkeeping of one lidf_frame_f32 call: `open` once the first fork was recorded. Every non-zero
+// return then joins (lidf_frame_f32 below): ev_join is recorded behind whatever the side stream has queued and
+// the caller's stream waits for it — no fork is left open (a capture stays joinable) and nothing of the
+// frame still runs on the side stream when the caller's next launch (or free) reaches its stream.
+struct ForkState {
+    bool open = false;
+};
+static int frame_impl(const LidfFrameArgs* a_in, lidf_stream_t stream, ForkState* fork);
+
 LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
+    ForkState fork;
+    const int rc = frame_impl(a_in, stream, &fork);
+    if (rc != LIDF_OK && fork.open) {
+        if (hipEventRecord((hipEvent_t)a_in->ev_join, (hipStream_t)a_in->aux_stream) == hipSuccess)
+            (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)a_in->ev_join, 0);
+    }
+    return rc;
+}
+
+LIDF_API int lidf_event_create(void** out) {
+    if (!out) return LIDF_ERR_BAD_ARG;
+    hipEvent_t e = nullptr;
+    CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = (void*)e;
+    return LIDF_OK;
+}
+LIDF_API int lidf_event_destroy(void* event) {
+    if (!event) return LIDF_OK;
+    CHECK_HIP(hipEventDestroy((hipEvent_t)event));
+    return LIDF_OK;
+}
+
+// test hook (LidfFrameArgs.fail_after): leave as a failed launch of stage k would
+#define FRAME_FAIL_AFTER(k) do { if (a->fail_after == (k)) return LIDF_ERR_HIP; } while (0)
+
+static int frame_impl(const LidfFrameArgs* a_in, lidf_stream_t stream, ForkState* fork) {
     if (!a_in) return LIDF_ERR_BAD_ARG;
     LidfFrameArgs a_loc = *a_in;
     LidfFrameArgs* a = &a_loc;
@@ -1706,6 +1760,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     bool guard_on_side = false;
     if (two) {
         CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_fork, st));
+        fork->open = true;   // from here on every error exit joins (lidf_frame_f32)
         CHECK_HIP(hipStreamWaitEvent(sx, (hipEvent_t)a->ev_fork, 0));
     }
     if (own_pack) {
@@ -1713,10 +1768,8 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         char* blob = (char*)a->pack_blob;
         if (a->pack_mode == LIDF_FRAME_PACK_GUARDED) {
             rc = frame_pack_guarded(a, blob, (char*)a->pack_guard, two ? sx : st);
-            if (two) {   // (also on failure: never leave a fork open)
-                const bool ok = hipEventRecord((hipEvent_t)a->ev_join, sx) == hipSuccess;
-                if (rc && ok) (void)hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0);
-                if (!rc && !ok) rc = LIDF_ERR_HIP;
+            if (two && !rc) {   // (first record of ev_join: the weight streams are valid; a failure joins at the exit)
+                if (hipEventRecord((hipEvent_t)a->ev_join, sx) != hipSuccess) rc = LIDF_ERR_HIP;
                 guard_on_side = true;
             }
             if (rc) return rc;
@@ -1809,6 +1862,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         // (the per-ray layer-1 tables stay on the main stream: a launch that fills the device starves the
         // PointNet's light launches beside it — measured, fused kernel start 326 -> 354 us)
     }
+    FRAME_FAIL_AFTER(1);
     // 2. occupied voxels: cells -> voxels (V) in one workgroup, points -> PointNet rows
     int* vox_bid = (int*)(ws + f.vox_bid);   // [V] image index of every occupied voxel
     float* vox_center = a->pos_rel ? (float*)(ws + f.vox_center) : nullptr;   // intersect_pos_type 'rel'
@@ -1824,12 +1878,14 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
     CHECK_HIP(lidf_launch_frame_points(a->valid_xyz, a->valid_rgb, pt_key, pt_rank, cell_rank, g, N, counts,
                                        a->valid_v_pid, a->revidx, a->valid_v_rel_coord, a->pnet_inp,
                                        pnet_abs, st));
+    FRAME_FAIL_AFTER(2);
     if (guard_on_side) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));   // weight streams valid
     if (two) CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));   // (second record: the per-ray features)
     // 4. voxel embedding: PointNet over the in-grid valid points
     if ((rc = pointnet_frame(a->pnet, a->pnet_inp, a->revidx, N, counts + LIDF_FC_VALID_IN, C, v_lds,
                              counts + LIDF_FC_VOX, a->occ_voxel_feat, ws + f.pnet, cus, st, sort_cap)))
         return rc;
+    FRAME_FAIL_AFTER(3);
     if (two) CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
     // 5. get_embedding + get_pred + depth
     // (with a side stream the stage-2 table — a third of the layer-1 launch, not read before the first refine
@@ -1847,6 +1903,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         CHECK_HIP(hipEventRecord((hipEvent_t)a->ev_join, sx));          // (third record)
         CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_join, 0));
     }
+    FRAME_FAIL_AFTER(4);
     if (!rf) return LIDF_OK;
 
     // 6. stage 2: refine_times x get_pred_refine on the device-resident state
@@ -1915,7 +1972,7 @@ LIDF_API int lidf_frame_f32(const LidfFrameArgs* a_in, lidf_stream_t stream) {
         CHECK_HIP(lidf_launch_refine_prep_dev(cur, (const long long*)a->max_pair_id, a->pair_vox, a->max_pairs,
                                               a->voxel_bound, vox_bid, C, a->ray_bid, a->ray_flat, a->rgb, hw,
                                               a->refine_pnet_pos_rel, N, pn_inp, a->revidx, a->end_voxel_id,
-                                              sel, counts, counts + LIDF_FC_VALID_IN, st));
+                                              sel, counts, counts + LIDF_FC_VALID_IN, st, nullptr));
         CHECK_HIP(lidf_launch_refine_rows_dev(cur, a->end_voxel_id, a->voxel_bound, a->rayfeat, 128 + Ed,
                                               a->multires_views, a->multires, a->refine_pos_rel, N, counts,
                                               inp_embed, D, 0, st));

@@ -28,6 +28,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// "Last workgroup reduces" without a release fence (lidf_aux.hip: depth metrics, the two fingerprint kernels;
+// lidf_frame.hip / lidf_device.h: the decoupled look-back): a workgroup publishes its partial result with an
+// agent-scope atomic read-modify-write, keeps the RETURNED value alive (asm volatile) and only then takes its
+// ticket with a second agent-scope atomic; the last arriver reads the partials with agent-scope atomics. The
+// HIP memory model does not promise that order for relaxed atomics — the hardware this library is built for
+// does: on gfx942 / gfx950 an atomic with return is performed at the device-coherent level (L2 / memory side
+// for the other XCDs) before its value comes back, and every access involved is such an atomic, so nothing is
+// read from a non-coherent cache. __ATOMIC_RELEASE on the ticket would be the portable form; on this device
+// it is a write-back of the whole L2 (megabytes of the frame's dirty outputs: 24 -> 11 us for the metrics
+// kernel, measured). Another target must not inherit the shortcut silently:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "liblidf_hip orders its ticket reductions by returned atomic values (gfx942/gfx950 behaviour); use release/acquire on other targets"
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -291,6 +305,14 @@ struct GridSpec {
     float crop;
     int r[3];
     int B;
+};
+
+// Optional cell table of the stepwise end-voxel lookup (lidf_refine.hip: lidf_refine_endvox_cells_kernel).
+struct CellLookup {
+    GridSpec g;
+    const int* coord;   // [V,3] cell of every voxel
+    int* table;         // [B * r0 * r1 * r2] cell -> largest voxel index, -1 = empty
+    int ready;          // the table already holds this voxel list
 };
 
 // Arguments of one refine iteration's per-ray launch (lidf_refine.hip: lidf_refine_step_kernel).

@@ -14,7 +14,7 @@ extern "C" hipError_t lidf_launch_refine_prep_dev(const float*, const long long*
                                                   const float*, const int*, long long, const int*,
                                                   const int*, const float*, long long, int, long long,
                                                   float*, int*, int*, const unsigned char*, const int*,
-                                                  const int*, hipStream_t);
+                                                  const int*, hipStream_t, const CellLookup*);
 extern "C" hipError_t lidf_launch_refine_rows_dev(const float*, const int*, const float*, const float*, int,
                                                   int, int, int, long long, const int*, float*, int, int,
                                                   hipStream_t);
@@ -73,6 +73,62 @@ __global__ void __launch_bounds__(256) lidf_refine_endvox_kernel(
         ev = in ? max(ev, (int)j) : ev;
     }
     if (live && ev > 0) atomicMax(end_voxel + r, ev);
+}
+
+// The same end voxel through a cell table (stepwise API, LidfRefineArgs.voxel_coord): O(1) per ray.
+// cell_table[cell] = largest voxel index occupying the cell (-1 = empty), scattered from the caller's
+// voxel_coord / voxel_bid by the kernel below. The cell of a point is estimated from (p - xmin) / crop; the
+// voxels of the 27 cells around it are tested with the reference's inclusive predicate on their STORED
+// bounds, so the decision is inside_box's and the estimate only has to be right to within one cell — true
+// for boxes that are the grid's cells up to rounding. A NaN coordinate fails no comparison (the point is
+// "inside" every voxel of its image): such a ray walks the list, as the every-voxel kernel decides.
+__global__ void lidf_cell_table_kernel(const int* __restrict__ voxel_coord, const int* __restrict__ vox_bid,
+                                       long long V, GridSpec g, int* __restrict__ cell_table) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int b = vox_bid[v], cx = voxel_coord[3 * v], cy = voxel_coord[3 * v + 1], cz = voxel_coord[3 * v + 2];
+    if (b < 0 || b >= g.B || cx < 0 || cx >= g.r[0] || cy < 0 || cy >= g.r[1] || cz < 0 || cz >= g.r[2]) return;
+    atomicMax(cell_table + (((long long)b * g.r[0] + cx) * g.r[1] + cy) * g.r[2] + cz, (int)v);
+}
+
+__global__ void __launch_bounds__(256) lidf_refine_endvox_cells_kernel(
+    const float* __restrict__ pred_pos, const long long* __restrict__ max_pair_id,
+    const int* __restrict__ pair_vox, long long P, const float* __restrict__ vbound,
+    const int* __restrict__ vox_bid, long long V, GridSpec g, const int* __restrict__ cell_table,
+    const int* __restrict__ ray_bid, long long R, int* __restrict__ end_voxel) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float x = pred_pos[3 * r], y = pred_pos[3 * r + 1], z = pred_pos[3 * r + 2];
+    const int bid = ray_bid[r];
+    const long long m = max_pair_id[r];
+    int ev = (m >= 0 && m < P) ? pair_vox[m] : 0;
+    const float pp[3] = {x, y, z};
+    int q[3];
+    bool near = bid >= 0 && bid < g.B;
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = (pp[k] - g.xmin[k]) / g.crop;
+        nan = nan || (pp[k] != pp[k]);
+        near = near && v > -2.f && v < (float)g.r[k] + 2.f;   // (false for NaN)
+        q[k] = near ? (int)floorf(v) : 0;
+    }
+    if (nan) {
+        for (long long j = 0; j < V; ++j)
+            if (vox_bid[j] == bid && inside_box(x, y, z, vbound + 6 * j)) ev = max(ev, (int)j);
+    } else if (near) {
+        int cv[27];   // the 27 cell -> voxel entries are requested together (independent loads)
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+            const int cx = q[0] + i / 9 - 1, cy = q[1] + (i / 3) % 3 - 1, cz = q[2] + i % 3 - 1;
+            const bool ok = cx >= 0 && cx < g.r[0] && cy >= 0 && cy < g.r[1] && cz >= 0 && cz < g.r[2];
+            cv[i] = ok ? cell_table[(((long long)bid * g.r[0] + cx) * g.r[1] + cy) * g.r[2] + cz] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 27; ++i)
+            if (cv[i] > ev && inside_box(x, y, z, vbound + 6 * (size_t)cv[i])) ev = cv[i];
+    }
+    end_voxel[r] = ev;
 }
 
 // Pass 2, one thread per ray: pnet_vox, pnet_inp from the end voxel.
@@ -290,10 +346,11 @@ extern "C" hipError_t lidf_launch_refine_prep(const float* pred_pos, const long 
                                               int pnet_rel, int pos_rel, long long R,
                                               float* pnet_inp, int* pnet_vox, float* inp_embed,
                                               int ld_e, int* end_voxel,
-                                              const unsigned char* pnet_select, hipStream_t st) {
+                                              const unsigned char* pnet_select, hipStream_t st,
+                                              const CellLookup* cells) {
     return lidf_launch_refine_prep_dev(pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, ray_bid, ray_flat,
                                        rgb, hw, pnet_rel, R, pnet_inp, pnet_vox, end_voxel, pnet_select,
-                                       nullptr, nullptr, st);
+                                       nullptr, nullptr, st, cells);
     (void)rayfeat; (void)ld_rf; (void)Lv; (void)L; (void)pos_rel; (void)inp_embed; (void)ld_e;
 }
 
@@ -306,8 +363,26 @@ extern "C" hipError_t lidf_launch_refine_prep_dev(const float* pred_pos, const l
                                                   int pnet_rel, long long R, float* pnet_inp,
                                                   int* pnet_vox, int* end_voxel,
                                                   const unsigned char* pnet_select, const int* dims,
-                                                  const int* row0_dev, hipStream_t st) {
+                                                  const int* row0_dev, hipStream_t st,
+                                                  const CellLookup* cells) {
     if (R <= 0) return hipSuccess;
+    if (cells && cells->table) {   // end voxel through the cell table (stepwise API with a grid)
+        const long long nc = (long long)cells->g.B * cells->g.r[0] * cells->g.r[1] * cells->g.r[2];
+        if (!cells->ready) {
+            hipError_t e = hipMemsetAsync(cells->table, 0xff, (size_t)nc * 4, st);
+            if (e != hipSuccess) return e;
+            if (V > 0)
+                hipLaunchKernelGGL(lidf_cell_table_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
+                                   cells->coord, vox_bid, V, cells->g, cells->table);
+        }
+        hipLaunchKernelGGL(lidf_refine_endvox_cells_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                           pred_pos, max_pair_id, pair_vox, P, vbound, vox_bid, V, cells->g, cells->table, ray_bid,
+                           R, end_voxel);
+        hipLaunchKernelGGL(lidf_refine_prep_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                           pred_pos, vbound, ray_bid, ray_flat, rgb, hw, pnet_rel, R, pnet_inp, pnet_vox,
+                           end_voxel, pnet_select, dims, row0_dev);
+        return hipGetLastError();
+    }
     // (the frame path — dims — zeroes end_voxel with its other scratch of the iteration, in one launch)
     if (!dims) {
         hipError_t e = hipMemsetAsync(end_voxel, 0, (size_t)R * 4, st);

@@ -158,6 +158,11 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     # configs[1] shape for D = 385 alone). Here the pairs go through in slabs of QUERY_SLAB rows (the slab the
     # CPU baseline uses): rows, positional encodings and activations of one slab are live at a time — about
     # 1 GB at D = 385, gf_dim = 64 —, the per-pair outputs [P, 1] are the only full-length arrays.
+    # lidf_query_tail_f32 reads both arrays as [P]: the reference's own use (pred_prob_end[:, 0] and a 1-wide
+    # offset, pipeline.py:437-442). A wider head would be read interleaved, so it is refused here.
+    if prob_dec.linear_4.out_features != 1 or offset_dec.linear_4.out_features != 1:
+        raise RuntimeError("the query takes decoders with out_dim == 1 (got prob_dec %d, offset_dec %d)"
+                           % (prob_dec.linear_4.out_features, offset_dec.linear_4.out_features))
     vf = vox_feat.detach()
     pred_prob = torch.empty((P, prob_dec.linear_4.out_features), dtype=torch.float32, device=dev)
     pred_offset = torch.empty((P, offset_dec.linear_4.out_features), dtype=torch.float32, device=dev)

@@ -168,9 +168,11 @@ def lidf_forward(batch, full_rgb_feat, pnet_model, prob_dec, offset_dec, opt=Non
     return True, dd
 
 
-def refine_forward(dd, pnet_model_refine, offset_dec_refine, opt=None, precision="f32"):
+def refine_forward(dd, pnet_model_refine, offset_dec_refine, opt=None, precision="f32", cell_lookup=True):
     """RefineNet.forward for evaluation (models/pipeline.py:1032-1041) on lidf_forward's data_dict:
-    opt.refine_forward_times x get_pred_refine; adds pred_pos_refine and pred_depth_refine."""
+    opt.refine_forward_times x get_pred_refine; adds pred_pos_refine and pred_depth_refine.
+    cell_lookup: the end voxel of a ray through the cell table of get_occ_vox_bound's grid (the same ids as
+    the reference's every-ray x every-voxel pcl_aabb, lidf_refine(grid=)); False tests every voxel."""
     opt = opt or LidfOptions()
     Q._refuse_autograd("pipeline.refine_forward", "the modules on their own (the fused stage-2 call has "
                        "no backward)", (("pred_pos", dd.get("pred_pos")),),
@@ -192,7 +194,8 @@ def refine_forward(dd, pnet_model_refine, offset_dec_refine, opt=None, precision
         multires_views=opt.multires_views, roi_inp_bbox=opt.roi_inp_bbox, roi_out_bbox=opt.roi_out_bbox,
         offset_range=opt.refine_offset_range, pos_rel=opt.refine_intersect_pos_type == "rel",
         pnet_pos_rel=opt.refine_pnet_pos_type == "rel", rayfeat=dd.get("rayfeat"),
-        precision=precision, pnet_select=sel)
+        precision=precision, pnet_select=sel,
+        grid=dd if (cell_lookup and all(k in dd for k in ("voxel_coord", "grid_dims", "xmin", "part_size"))) else None)
     dd["pred_pos_refine"], dd["end_voxel_id"] = pos, end_voxel
     depth = dd["xyz_corrupt_flat"][:, :, 2].reshape(-1).clone()
     depth[dd["miss_bid"] * (h * w) + dd["miss_flat_img_id"]] = pos[:, 2]
@@ -343,10 +346,8 @@ class FrameRunner:
         # cross-stream edges than they save, and frames pipelined over several streams fill each other's gaps
         # already (FramePipeline passes False). True / False force it.
         self.side_mode = side_stream
-        self.side = None
-        if side_stream is None or side_stream:
-            with torch.cuda.device(dev):
-                self.side = (torch.cuda.Stream(dev), _lib.hip_event(), _lib.hip_event())
+        self.side = None                           # (stream, ev_fork, ev_join): created by the first frame that forks
+        self._fail_after = 0                       # LidfFrameArgs.fail_after (test hook: a mid-frame failure)
         self.pack_blob = torch.empty((L.lidf_frame_pack_bytes(),), dtype=torch.uint8, device=dev)
         self.pack_guard = torch.zeros((L.lidf_frame_pack_guard_bytes(),), dtype=torch.uint8, device=dev)
         self.vidx, self.n_valid_idx = None, 0      # explicit valid points (load(valid_idx=))
@@ -477,8 +478,12 @@ class FrameRunner:
         a.pack_guard = self.pack_guard.data_ptr()
         a.pack_mode = 1 if guard else 2
         a.offsets_selected = int(self.offsets == "selected")
-        if self.side is not None and (self.side_mode or not torch.cuda.is_current_stream_capturing()):
+        if self.side_mode or (self.side_mode is None and not torch.cuda.is_current_stream_capturing()):
+            if self.side is None:   # the side stream and its two events exist only for runners that fork
+                with torch.cuda.device(self.dev):
+                    self.side = (torch.cuda.Stream(self.dev), _lib.hip_event(), _lib.hip_event())
             a.aux_stream, a.ev_fork, a.ev_join = self.side[0].cuda_stream, self.side[1], self.side[2]
+        a.fail_after = int(self._fail_after)
         try:
             with torch.cuda.device(self.dev):
                 _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))
@@ -486,6 +491,17 @@ class FrameRunner:
             self._frames_since_guard = None   # (the library reset the fingerprints; validate again)
             raise
         self._keep = keep
+
+    def __del__(self):
+        # the two raw events of the side stream are the runner's (created through the library)
+        side, self.side = getattr(self, "side", None), None
+        if side is not None:
+            try:
+                self.graph = self.graph_trusted = None   # (a captured graph may reference them)
+                torch.cuda.synchronize(self.dev)
+                _lib.hip_event_destroy(side[1]), _lib.hip_event_destroy(side[2])
+            except Exception:   # interpreter shutdown: the process releases them
+                pass
 
     def capture(self):
         """Record enqueue() into a HIP graph (torch.cuda.CUDAGraph) after one eager warm-up call; run()

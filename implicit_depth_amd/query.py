@@ -444,7 +444,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
                 voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                 forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
                 offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, rayfeat=None,
-                precision="f32", pnet_select=None, profile_events=None, roi_out_bbox=2):
+                precision="f32", pnet_select=None, profile_events=None, roi_out_bbox=2, grid=None):
     """Stage-2 refinement (RefineNet.forward, models/pipeline.py:1032-1041, eval flavour):
     `forward_times` iterations of get_pred_refine through lidf_refine_f32.
 
@@ -455,6 +455,10 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     pnet_select: None = refine.use_all_pix True (shipped configs); [R] mask (bool / uint8 / float,
     non-zero = selected) = the mask_type 'all', use_all_pix False branch (pipeline.py:987-996): pass
     inp_zero_mask = 1 - valid_mask at the rays' pixels.
+    grid (optional): the voxel list as cells of its grid — a dict with get_occ_vox_bound's entries 'xmin'
+    (widened lower corner), 'grid_dims', 'part_size' and 'voxel_coord' [V,3] i32. The end voxel of a ray
+    (pcl_aabb + scatter max, pipeline.py:939-944) is then looked up in a cell table — the same ids as
+    testing every ray against every voxel (LidfRefineArgs.voxel_coord), O(R) instead of O(R V).
     Returns pred_pos_refine [R,3] and the last iteration's end_voxel_id [R] i32."""
     from .pointnet import pointnet_struct
     _refuse_autograd("lidf_refine", "the modules on their own (PointNet2Stage, IEF and get_embedder are "
@@ -547,9 +551,14 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         _lib.require_cuda(pnet_select, names=["pnet_select"])
         if pnet_select.shape[0] != R:
             raise RuntimeError("pnet_select must have one entry per ray")
+    cells = _cell_lookup(grid, V, B, dev)
     for _ in range(forward_times):
         out = torch.empty((R, 3), dtype=torch.float32, device=dev)
         q = _lib.LidfRefineArgs()
+        if cells is not None:
+            q.voxel_coord, q.cell_table = cells["coord"].data_ptr(), cells["table"].data_ptr()
+            q.grid_res, q.grid_xmin, q.grid_part = cells["res"], cells["xmin"], cells["part"]
+            q.cell_table_ready = int(_ > 0)
         q.n_rays, q.ray_dir, q.ray_bid, q.ray_flat = R, ray_dir.data_ptr(), ray_bid.data_ptr(), ray_flat.data_ptr()
         q.pred_pos, q.max_pair_id = cur.data_ptr(), max_pair_id.data_ptr()
         q.pair_vox, q.n_pairs = pair_vox.data_ptr(), P
@@ -579,6 +588,25 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
                 _lib.check(L.lidf_refine_f32(C.byref(q), _lib.current_stream(dev)))
         cur = out
     return cur, end_voxel
+
+
+def _cell_lookup(grid, V, B, dev):
+    """LidfRefineArgs' optional cell table from get_occ_vox_bound's entries (None: every voxel is tested)."""
+    if grid is None or V == 0:
+        return None
+    coord = grid["voxel_coord"]
+    _lib.require_cuda(coord, names=["grid['voxel_coord']"])
+    _i32(coord, "grid['voxel_coord']")
+    if tuple(coord.shape) != (V, 3):
+        raise RuntimeError("grid['voxel_coord'] must be [V,3]")
+    res = [int(v) for v in grid["grid_dims"]]
+    xmin = grid["xmin"]
+    xmin = [float(v) for v in (xmin.tolist() if torch.is_tensor(xmin) else xmin)]
+    if len(res) != 3 or len(xmin) != 3 or min(res) <= 0:
+        raise RuntimeError("grid['grid_dims'] / grid['xmin'] must hold three entries")
+    return {"coord": coord, "res": (C.c_int32 * 3)(*res), "xmin": (C.c_float * 3)(*xmin),
+            "part": float(grid["part_size"]),
+            "table": torch.empty((B * res[0] * res[1] * res[2],), dtype=torch.int32, device=dev)}
 
 
 def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=(1.0, 1.0, 2.0),

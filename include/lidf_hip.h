@@ -36,7 +36,7 @@ enum lidf_status {
 /* ABI version, bumped on any signature or struct-layout change. lidf_version() returns the value the
  * library was BUILT with; a binding compiled / written against this header must refuse a library that
  * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
-#define LIDF_ABI_VERSION 7
+#define LIDF_ABI_VERSION 8
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);
@@ -406,6 +406,24 @@ typedef struct LidfRefineArgs {
      * read it. NULL = formed inside every call.                                                     */
     float* ray_l1;
     int32_t ray_l1_ready;
+    /* optional (ABI 8): the end voxel through a cell table instead of testing every ray against every voxel
+     * (models/pipeline.py:939-944: pcl_aabb + scatter max = the largest voxel of the ray's image whose box
+     * contains pred_pos). For voxel lists that are cells of a regular grid — what LIDF.get_occ_vox_bound
+     * (:162-201) / lidf_voxelize_f32 build: voxel j of image voxel_bid[j] is cell voxel_coord[j] of the
+     * grid_res cells that start at grid_xmin with edge grid_part, and voxel_bound[j] is that cell's box up to
+     * rounding. The call scatters the voxels into cell_table (cell -> largest voxel index, -1 = empty),
+     * estimates the cell of a point from (p - grid_xmin) / grid_part and applies the reference's inclusive
+     * test to the STORED bounds of the voxels in the 27 cells around it: the same end_voxel_id as the
+     * every-voxel test (tests/test_refine_gpu.py), O(R) instead of O(R V). A NaN coordinate is "inside" every
+     * voxel of its image for the reference's predicate; such a ray walks the list.
+     * voxel_coord NULL = test every voxel. cell_table: caller scratch of batch * res0 * res1 * res2 int32;
+     * cell_table_ready != 0: it already holds this voxel list (a later iteration on the same frame).   */
+    const int32_t* voxel_coord;  /* [V,3] */
+    int32_t grid_res[3];
+    float grid_xmin[3];
+    float grid_part;
+    int32_t* cell_table;
+    int32_t cell_table_ready;
 } LidfRefineArgs;
 size_t lidf_refine_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox);
 size_t lidf_refine_pack_bytes(int32_t multires, int32_t multires_views);
@@ -556,6 +574,14 @@ typedef struct LidfFrameArgs {
     lidf_stream_t aux_stream;
     void* ev_fork;
     void* ev_join;
+    /* Error exits with a side stream (ABI 8): once the first fork is recorded, ANY non-zero return of the call
+     * first records ev_join on aux_stream and makes `stream` wait for it — the side stream's queued launches
+     * are ordered before whatever the caller enqueues next on `stream` (no open fork under capture, no launch
+     * still reading feat_grid / writing rayfeat after the caller frees them).
+     * fail_after (test hook, 0 = off): the call returns LIDF_ERR_HIP right after enqueuing stage k, exactly as
+     * a failed launch there would — 1 frame head (second fork open), 2 pairs / PointNet rows, 3 PointNet,
+     * 4 query. tests/test_frame_gpu.py forces mid-frame failures with it.                             */
+    int32_t fail_after;
 } LidfFrameArgs;
 #define LIDF_FRAME_PACK_CALLER 0
 #define LIDF_FRAME_PACK_GUARDED 1
@@ -565,6 +591,11 @@ size_t lidf_frame_pack_guard_bytes(void);
 size_t lidf_frame_workspace_bytes(int32_t batch, int32_t height, int32_t width, const int32_t* res,
                                   int64_t max_pairs, int32_t lds_voxels, int32_t refine_times);
 int lidf_frame_f32(const LidfFrameArgs* args, lidf_stream_t stream);
+/* The two events of LidfFrameArgs.ev_fork / ev_join, created and destroyed by the runtime this library is
+ * linked against (a binding that opened its own copy of the HIP runtime would hand over foreign handles).
+ * hipEventDisableTiming. Host calls; *out receives the hipEvent_t. (ABI 8)                               */
+int lidf_event_create(void** out);
+int lidf_event_destroy(void* event);
 
 /* ---- One linear layer of any width ------------------------------------------------------------
  * out[r, 0:nout] = act( x[r, 0:k] . w[0:nout, 0:k]^T + b  (+ addrows[addidx[r], 0:nout]) ), torch.nn.Linear's

@@ -331,6 +331,45 @@ def test_frame_with_a_side_stream(cuda, graph, offsets):
             assert torch.equal(a["pred_offset"][:P], b["pred_offset"][:P])
 
 
+@pytest.mark.parametrize("stage", [1, 2, 3, 4])
+def test_side_stream_is_joined_on_every_error_exit(cuda, stage):
+    """A frame that fails between its fork and its joins (LidfFrameArgs.fail_after: the return a failed launch of
+    that stage would take — stage 1: second fork just recorded, per-ray features queued on the side stream and
+    no join recorded; 3: join recorded but not awaited) must leave nothing of itself running on the side
+    stream beside the caller's next work: lidf_frame_f32 records ev_join behind the side stream's queue and
+    makes the caller's stream wait for it on every non-zero return. Checked where it shows: the failed frame's
+    side launches write `rayfeat` / the box sums of ITS inputs; the good frame that follows on the same runner
+    (other inputs, same buffers) must be bit-identical to a fresh runner's — repeatedly, since a race is a
+    matter of timing."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 240, 320
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=4)
+    bad_in = synthetic_batch(B, h, w, seed=31, hole_frac=1.4)
+    good_in = synthetic_batch(B, h, w, seed=32)
+    bad, bad_feat = _dev(bad_in[0], cuda), bad_in[1].to(cuda)
+    good, good_feat = _dev(good_in[0], cuda), good_in[1].to(cuda)
+    fresh = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], side_stream=True)
+    with torch.no_grad():
+        fresh.run(good, good_feat)
+    ok, ref = fresh.result()
+    assert ok
+    runner = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], side_stream=True)
+    for rep in range(4):
+        runner._fail_after = stage
+        with torch.no_grad(), pytest.raises(RuntimeError):
+            runner.run(bad, bad_feat)
+        runner._fail_after = 0
+        with torch.no_grad():
+            runner.run(good, good_feat)     # no sync in between: ordered by the streams alone
+        ok2, dd = runner.result()
+        assert ok2 and dd["counts"] == ref["counts"]
+        for k in ("rayfeat", "pred_prob_end", "pred_offset", "pred_pos", "pred_depth", "pred_pos_refine",
+                  "pred_depth_refine", "occ_voxel_feat", "max_pair_id", "end_voxel_id"):
+            assert torch.equal(dd[k], ref[k]), (k, stage, rep)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_frame_weight_streams_follow_parameter_updates(cuda, graph):
     """The runner's own packed streams (one fingerprint launch over every module per frame): in-place

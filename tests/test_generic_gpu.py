@@ -309,3 +309,21 @@ def test_linear_fuzz(cuda, seed):
                                 _lib.ptr(ws), ws.numel(), _lib.current_stream(cuda)))
     rc, rb = 1.0 + a.double().t() @ x.double(), 1.0 + a.double().sum(0)
     assert _rel(c, rc) <= 5e-6 and _rel(db, rb) <= 5e-6, (n, k, nout)
+
+
+def test_query_refuses_decoders_with_a_wide_head(cuda):
+    """generic.query hands pred_prob / pred_offset to lidf_query_tail_f32 as [P] arrays (the reference reads
+    pred_prob_end[:, 0] and a 1-wide offset, models/pipeline.py:437-442): an IMNet with out_dim != 1 —
+    which decoder_forward itself accepts — must raise instead of being read interleaved."""
+    from implicit_depth_amd import IEF, IMNet
+    from implicit_depth_amd.query import lidf_query
+    from util import orc, to_dev
+    scene = orc.synthetic_scene(1, 9, 11, 4, seed=5, ragged=True)
+    D = scene["D"]
+    s = to_dev(scene, cuda)
+    wide, one = IMNet(D, 2, 32).to(cuda).eval(), IMNet(D, 1, 32).to(cuda).eval()
+    ief = IEF(cuda, D, 1, 32, n_iter=2).to(cuda).eval()
+    for prob, off in ((wide, ief), (one, wide)):
+        with torch.no_grad(), pytest.raises(RuntimeError, match="out_dim == 1"):
+            lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                       s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)

@@ -230,3 +230,75 @@ def test_refine_packed_weights_follow_parameter_updates(cuda):
     pn3["point_lin1.weight"] = pn3["point_lin1.weight"] * 1.2
     ref = orc.pointnet2stage(pn3, valid_inp, valid_vox.long(), scene["V"])
     assert (f1.cpu() - ref).abs().max().item() <= 2e-5 and (f1 - f0).abs().max().item() > 1e-5
+
+
+@pytest.mark.parametrize("frames,occupancy", [(1, 0.1), (3, 0.4), (2, 1.0)])
+def test_refine_end_voxel_through_the_cell_table(cuda, frames, occupancy):
+    """LidfRefineArgs.voxel_coord / lidf_refine(grid=): the end voxel of a ray looked up in the cell table of
+    get_occ_vox_bound's grid instead of testing every ray against every voxel (the reference's pcl_aabb +
+    scatter max, models/pipeline.py:939-944). Same ids and — the rest of the iteration being the same kernels —
+    bit-identical positions, on points inside cells, exactly on cell faces / edges / corners (inclusive bounds:
+    the larger voxel wins), outside the grid, far away, +-inf and NaN (a NaN coordinate fails no comparison of
+    the reference's predicate: "inside" every voxel of its image), rays without a pair, random arg-max pairs."""
+    from implicit_depth_amd.query import get_occ_vox_bound, lidf_refine
+    g = torch.Generator().manual_seed(100 + frames)
+    h, w = 24, 32
+    # occupied cells: random valid points (occupancy 1.0: a point in every cell)
+    res, part = 9, 0.25
+    lo = torch.tensor([-1.125, -1.125, -0.125])
+    ncell = frames * res ** 3
+    cells = torch.nonzero(torch.rand(ncell, generator=g) < occupancy)[:, 0]
+    if cells.numel() == 0:
+        cells = torch.tensor([5])
+    cb, cr = cells // res ** 3, cells % res ** 3
+    cxyz = torch.stack((cr // 81, (cr // 9) % 9, cr % 9), 1).float()
+    pts = lo + (cxyz + 0.2 + 0.6 * torch.rand(cells.numel(), 3, generator=g)) * part
+    occ = get_occ_vox_bound(pts.to(cuda), cb.int().to(cuda), frames, res=8)
+    vb, vbid = occ["voxel_bound"], occ["occ_vox_bid"].int().contiguous()
+    V = vb.shape[0]
+    assert V == cells.numel() and tuple(occ["grid_dims"]) == (9, 9, 9)
+    # query points
+    R = 6000
+    bid = torch.randint(0, frames, (R,), generator=g)
+    pos = lo + torch.rand(R, 3, generator=g) * (res * part)
+    k = R // 6
+    face = torch.randint(0, res + 1, (k, 3), generator=g).float()
+    pos[:k] = lo + face * part                                            # cell corners
+    pos[k:2 * k, 0] = (lo + torch.randint(0, res + 1, (k, 3), generator=g).float() * part)[:, 0]   # on x faces
+    pos[2 * k:3 * k] = vb.cpu()[torch.randint(0, V, (k,), generator=g)][:, [0, 4, 2]]   # stored bounds themselves
+    pos[3 * k:3 * k + 50] = lo - 0.3                                       # outside, near
+    pos[3 * k + 50:3 * k + 100] = 1e6
+    pos[3 * k + 100:3 * k + 120, 1] = float("nan")
+    pos[3 * k + 120:3 * k + 130, 2] = float("inf")
+    pos[3 * k + 130:3 * k + 140, 0] = -float("inf")
+    P = 4000
+    pair_vox = torch.randint(0, V, (P,), generator=g).int()
+    mid = torch.randint(0, P + 1, (R,), generator=g)                       # P = a ray without pairs
+    ray_dir = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=1)
+    flat = torch.randint(0, h * w, (R,), generator=g)
+    ray_pix = torch.stack((flat % w, flat // w), 1).int()
+    rgb = torch.randn(frames, 3, h, w, generator=g)
+    feat = torch.randn(frames, 32, h, w, generator=g)
+    valid_inp = torch.randn(300, 6, generator=g) * 0.2
+    valid_vox = torch.randint(0, V, (300,), generator=g).int()
+    pnet = make_pointnet(orc.init_pointnet(5, 1.5), cuda)
+    offr = make_module("IEF", orc.init_decoder("IEF", 334, 77, 5.0), 334, cuda)
+    args = [t.to(cuda) for t in (ray_dir, ray_pix, bid.int(), flat.int(), pos, mid, pair_vox)]
+    rest = [rgb.to(cuda), feat.to(cuda), valid_inp.to(cuda), valid_vox.to(cuda), pnet, offr]
+    with torch.no_grad():
+        ref_pos, ref_ev = lidf_refine(*args, vb, vbid, *rest, forward_times=1)
+        got_pos, got_ev = lidf_refine(*args, vb, vbid, *rest, forward_times=1, grid=occ)
+        got2_pos, got2_ev = lidf_refine(*args, vb, vbid, *rest, forward_times=2, grid=occ)
+        ref2_pos, ref2_ev = lidf_refine(*args, vb, vbid, *rest, forward_times=2)
+    assert torch.equal(ref_ev, got_ev)
+    assert torch.equal(ref2_ev, got2_ev)
+    assert torch.equal(ref_pos.nan_to_num(1.0, 2.0, 3.0), got_pos.nan_to_num(1.0, 2.0, 3.0))
+    assert torch.equal(ref2_pos.nan_to_num(1.0, 2.0, 3.0), got2_pos.nan_to_num(1.0, 2.0, 3.0))
+    # and against the definition itself on the CPU: largest voxel of the image containing the point, or the
+    # arg-max pair's voxel (0 for the dummy row) when that is larger
+    vbc, vbidc = vb.cpu(), vbid.cpu()
+    inside = ~((pos[:, None, :] < vbc[None, :, :3]) | (pos[:, None, :] > vbc[None, :, 3:])).any(2)
+    inside &= vbidc[None, :] == bid[:, None]
+    last = torch.where(inside, torch.arange(V)[None, :], torch.zeros(1, dtype=torch.long)).max(1).values
+    argv = torch.cat((pair_vox.long(), torch.zeros(1, dtype=torch.long)))[mid]
+    assert torch.equal(got_ev.cpu().long(), torch.maximum(last, argv))
