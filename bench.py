@@ -30,6 +30,9 @@ F_ALG = 853952.0       # FLOP per point, reference formulation (SURVEY.md §8d /
 # 2 nets x (6*8+3) layer-1 k-steps x 8 tiles + 3 passes x (8 u + 129*4 layer-2 + 65*2 layer-3)
 # v_mfma_f32_32x32x2 instructions of 4096 FLOP each.
 F_EXEC = (2 * 51 * 8 + 3 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0  # = 355,584
+# per net (one launch of the per-point kernel with ONE net, lidf_query(offsets="selected")): layer 1 + n passes
+F_EXEC_PROB = (51 * 8 + 1 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0   # = 135,936 per pair   (prob_dec, IMNet)
+F_EXEC_OFF = (51 * 8 + 2 * (8 + 129 * 4 + 65 * 2)) * 4096 / 32.0    # = 219,648 per pair   (offset_dec, IEF n_iter 2)
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 # split-f16 kernel (lidf_points_h.hip): per wave-tile 3 passes x 406 v_mfma_f32_32x32x16_f16
 # (8 tiles x (18 embedding + 2 mixed xyz/ray/IEF + 24 layer-2) + 6 bias + 48 layer-3) of 32,768 FLOP
@@ -210,7 +213,8 @@ def _rocprof_child(opts, keep, steps, warmup, timeout):
         return None, d
     env = dict(os.environ, TMPDIR="/tmp", LIDF_BENCH_NO_ROCPROF="1")
     cmd = [exe] + opts + ["-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
-                          "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-rocprof"] + keep
+                          "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-rocprof",
+                          "--no-split-f16"] + keep
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=timeout)
@@ -224,7 +228,7 @@ def _rocprof_child(opts, keep, steps, warmup, timeout):
     return (db if r.returncode == 0 else None), d
 
 
-def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300):
+def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300, per_step=1):
     """rocprofv3 legs of THIS command, run as child processes once the timed region is over — every number
     of the record is a number of this run on this box, none is read from a committed file:
       kernel trace (--kernel-trace --stats): per kernel the calls and the average duration (all launches,
@@ -246,7 +250,8 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300):
         if a in ("--steps", "--warmup", "--gpus"):
             skip = True
             continue
-        if a.startswith(("--steps=", "--warmup=", "--gpus=")) or a in ("--no-cpu-baseline", "--no-rocprof", "--pmc"):
+        if a.startswith(("--steps=", "--warmup=", "--gpus=")) or a in ("--no-cpu-baseline", "--no-rocprof", "--pmc",
+                                                                        "--no-split-f16"):
             continue
         keep.append(a)
     out = None
@@ -263,7 +268,7 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300):
         dom = [k for k in per if dominant in k]
         if not dom or len(per[dom[0]]) < 2:
             return None
-        nstep = len(per[dom[0]])
+        nstep = max(len(per[dom[0]]) // per_step, 1)   # (per_step launches of `dominant` make one step)
         kern = {}
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
             kern[k] = {"calls_per_step": round(len(v) / nstep, 2), "avg_ms": round(sum(v) / len(v) / 1e6, 5),
@@ -289,13 +294,15 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300):
             if vals:
                 hb, step_bytes = {}, 0.0
                 ndom = [v for k, v in vals.items() if dominant in k]
-                nst = ndom[0].get("FETCH_SIZE", (1, 0))[0] if ndom else 1
+                nst = max(ndom[0].get("FETCH_SIZE", (1, 0))[0] // per_step, 1) if ndom else 1
                 for k, v in vals.items():
                     f, w = v.get("FETCH_SIZE", (0, 0.0)), v.get("WRITE_SIZE", (0, 0.0))
                     cor = (2.0 * f[1] + w[1]) * 1024.0
                     hb[k] = {"fetch_kib": round(f[1], 1), "write_kib": round(w[1], 1),
                              "bytes_corrected": round(cor), "calls_per_step": round(f[0] / max(nst, 1), 2)}
-                    if "lidf_" in k and "_h_kernel" not in k and "pack_h" not in k and "rows_h" not in k:
+                    # (the children run the timed step's precision only — --no-split-f16 —, so every library
+                    # kernel of the pass belongs to the step)
+                    if "lidf_" in k:
                         step_bytes += cor * f[0] / max(nst, 1)
                 out["hbm"] = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 3 "
                                          "--warmup 1 %s (two passes)" % " ".join(keep),
@@ -580,10 +587,38 @@ def e2e(args):
                                   nonzero()/unique() have)"""
     from implicit_depth_amd import IEF, IMNet, PointNet2Stage, pipeline as pl
     from implicit_depth_amd.synthetic import init_decoder_params, synthetic_batch
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    # --gpus N (SURVEY 8e; the reference refuses multi-GPU evaluation, trainers/train_lidf.py:693-694, and
+    # shards its training batch over the ranks, :162-164): the frames of an evaluation stream are sharded over
+    # the ranks (dist.shard_frames: rank g owns frames [g B, (g+1) B) of the world * B frames of a step), one
+    # FrameRunner per rank, weights replicated, no data-path collective; the refined depth maps of all ranks
+    # are all-gathered inside the timed region. Weak scaling: every rank runs --frames frames per step.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    share_gpu = os.environ.get("LIDF_TEST_SHARE_GPU") == "1"   # (tests only: all ranks on cuda:0 over gloo)
+    if share_gpu:
+        local = 0
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.e2e_mode == "stepwise" or max(1, args.streams) != 1:
+            raise SystemExit("--workload e2e --gpus N shards frames over FrameRunners (frame / graph mode, one stream)")
     B, h, w = args.frames, 240, 320
-    batch, feat = synthetic_batch(B, h, w, seed=77)
+    from implicit_depth_amd.dist import shard_frames
+    f0, _f1 = shard_frames(world * B, world, rank)
+    # (frame f of the stream is synthetic frame seed 77 + f // B: rank g's batch is the one a single GPU
+    # would have met as its g-th batch)
+    batch, feat = synthetic_batch(B, h, w, seed=77 + f0 // B)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     feat = feat.to(dev)
     torch.manual_seed(3)
@@ -633,6 +668,8 @@ def e2e(args):
         runner = runners[0]
         turn = {"i": 0}
 
+        gathered = torch.empty((world * B, h, w), device=dev) if use_dist else None
+
         def step(marks=None):
             k = turn["i"] % S
             turn["i"] += 1
@@ -643,14 +680,24 @@ def e2e(args):
                     pl._mark(marks, "frame")
                     m = runner.metrics(batch)
                     pl._mark(marks, "metrics")
+                    if use_dist:                     # the one collective: every rank's refined depth maps
+                        from implicit_depth_amd.dist import all_gather_depth
+                        all_gather_depth(runner.buf["pred_depth_refine"], gathered)
+                        pl._mark(marks, "all_gather")
                 else:
                     with torch.cuda.stream(lanes[k]):
                         runners[k].run(batch, feat)
                         m = runners[k].metrics(batch)
             return None, m
 
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     all_marks = []
@@ -658,6 +705,8 @@ def e2e(args):
         mk = []
         dd, m = step(mk)
         all_marks.append(mk)
+    torch.cuda.synchronize()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     for mk in all_marks:
@@ -672,11 +721,35 @@ def e2e(args):
         assert not c["OVERFLOW"]
         P, R, V, NV = c["P"], c["R"], c["V"], c["NVS"]
         syncs = "none inside the step (list lengths stay on the device)"
+    coll = None
+    P_all, R_all = P, R
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.empty((world,), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, t)               # every rank's own clock
+        rank_ms = [round(float(v) / args.steps * 1e3, 4) for v in every.tolist()]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())                           # the step time of the job = the slowest rank's
+        cnt = torch.tensor([1, P, R], device=dev, dtype=torch.int64)
+        dist.all_reduce(cnt)                                # ranks that joined; pairs / rays of all ranks
+        ranks_seen, P_all, R_all = (int(v) for v in cnt.tolist())
+        mine = bool((gathered[rank * B:(rank + 1) * B] == runner.buf["pred_depth_refine"]).all()) and \
+            bool(torch.isfinite(gathered).all())
+        okt = torch.tensor([1 if mine else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        coll = {"op": "all_gather_into_tensor (RCCL) of [%d,%d,%d] f32 refined depth maps per rank" % (B, h, w),
+                "inside_timed_region": True, "gathered_equals_local": bool(okt.item()), "ranks_seen": ranks_seen,
+                "ms_per_step_by_rank": rank_ms, "pairs_all_ranks": P_all, "rays_all_ranks": R_all,
+                "frames_all_ranks": world * B}
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        return
     # rocprofv3 legs of this same command (child processes after the timed region): launches per step, busy
     # time, the kernels of a step, and the issued-FLOP fractions of its three matrix kernels
     live = None
     profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
-    if not args.no_rocprof and not profiled and max(1, args.streams) == 1:
+    if not args.no_rocprof and not profiled and max(1, args.streams) == 1 and not use_dist:
         live = live_profile(sys.argv[1:], "lidf_points_fused_kernel" if args.precision == "f32" else "lidf_points_h_kernel",
                             pmc=args.pmc)
     roof = None
@@ -707,8 +780,8 @@ def e2e(args):
                        if not side_on else None),
         }
     emit({
-        "metric": "Mpoints/sec, e2e evaluation path", "value": round(P * args.steps / elapsed / 1e6, 3),
-        "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": "Mpoints/sec, e2e evaluation path", "value": round(P_all * args.steps / elapsed / 1e6, 3),
+        "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_F16X3 if args.precision == "f16x3" else "f32",
         "data": "synthetic",
@@ -723,10 +796,14 @@ def e2e(args):
                                    bool(side_mode or (side_mode is None and mode == "frame"))),
                    "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
-                   "voxels": V, "valid_points": NV},
-        "ms_per_frame": round(elapsed / args.steps * 1e3 / B, 4),
-        "frames_per_s": round(B * args.steps / elapsed, 2),
-        "rays_per_s": round(R * args.steps / elapsed, 1),
+                   "voxels": V, "valid_points": NV,
+                   "parallelism": "frames of the evaluation stream sharded over %d GPU(s), one FrameRunner per rank, "
+                                  "%d frame(s) per rank per step%s" %
+                                  (world, B, "; RCCL all-gather of the refined depth maps" if use_dist else "")},
+        "ms_per_frame": round(elapsed / args.steps * 1e3 / (B * world), 4),
+        "frames_per_s": round(B * world * args.steps / elapsed, 2),
+        "rays_per_s": round(R_all * args.steps / elapsed, 1),
+        "collective": coll,
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         "roofline_kernels": roof,
         "roofline_kernels_note": ("side stream: the stage-2 layer-1 table runs beside (in the tail of) the per-point "
@@ -735,6 +812,8 @@ def e2e(args):
         "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels", "hbm", "mfma")
                      if k in live} if live else None),
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def config_name(args, refine):
@@ -761,6 +840,12 @@ def main():
                     help="skip the rocprofv3 legs of an N = 1 run (roofline.kernel_ms_rocprof_live and the "
                          "\"profile\" block: per-kernel durations and launches per step by rocprofv3 --kernel-trace "
                          "of this same command, run as a child process after the timed region)")
+    ap.add_argument("--no-split-f16", action="store_true",
+                    help="query workload: skip the secondary legs of the default f32 run (the same workload through "
+                         "the split-f16 kernel -> \"split_f16\", and with offsets for the selected pairs only -> "
+                         "\"offsets_selected\") and the extra step that keeps outputs for the parity record. The "
+                         "rocprofv3 children of a run pass it, so that profile.* and hbm.* are numbers of the timed "
+                         "f32 step alone")
     ap.add_argument("--pmc", action="store_true",
                     help="also run the two HBM counter passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE) of "
                          "this command -> roofline.traffic, hbm.bytes_counter; the default headline run does so "
@@ -938,14 +1023,14 @@ def main():
         if refine is not None and args.precision == "f32" else None
     state = {"ws": [None] * S, "step": None}
 
-    def step(events=None, precision=args.precision, lane=0):
+    def step(events=None, precision=args.precision, lane=0, offsets=args.offsets):
         depth, gathered = depths[lane], gathers[lane]
         with torch.no_grad():
             out = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"],
                              s["pair_vox"], s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off,
                              ray_flat=s["ray_flat"], depth=depth, workspace=state["ws"][lane],
                              profile_events=events, want_rayfeat=refine is not None,
-                             precision=precision)
+                             precision=precision, offsets=offsets)
             if refine is not None:
                 out["pred_pos_refine"] = refine(out, rpairs[state["step"]] if (rpairs and events is not None
                                                                                  and state["step"] is not None) else None)
@@ -1017,13 +1102,48 @@ def main():
         gather_ok = bool(t.item())
     split = None
     hip_f32 = None
-    if world == 1 and refine is None and dense and gf == 64:
+    legs = not args.no_split_f16
+    sel_leg = None
+    if world == 1 and refine is None and dense and gf == 64 and legs and not args.no_cpu_baseline:
         hip_f32 = step()   # outputs of the measured configuration, kept for the parity record
         hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos",
                                                    "pred_pos", "max_pair_id")}
         hip_f32["depth"] = depth.clone()
     hip_h = None
-    if world == 1 and args.precision == "f32" and refine is None and gf == 64:
+    if world == 1 and args.precision == "f32" and refine is None and gf == 64 and legs and args.offsets == "all":
+        # the same workload with the offset decoder on the arg-max pair of every ray only (opt-in,
+        # lidf_query(offsets="selected")): a labelled secondary rate beside the headline, with the FLOP its two
+        # launches of the per-point kernel issue (prob net over the P pairs, offset net over the R selected ones)
+        for _ in range(args.warmup):
+            step(offsets="selected")
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(args.steps):
+            got = step(pairs[i], offsets="selected")
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        kms = sum(ev.elapsed_ms(a, b) for a, b in pairs) / args.steps
+        fl = F_EXEC_PROB * P + F_EXEC_OFF * scene["R"]
+        sel_leg = {"what": "opt-in lidf_query(offsets='selected'): offset_dec on the arg-max pair of every ray only; "
+                           "pred_prob_end, softmax, max_pair_id, pred_pos and depth bit-identical to the headline "
+                           "step, pred_offset / pair_pred_pos defined at the selected pairs only (NaN elsewhere) — "
+                           "NOT the reference's data flow, never the headline",
+                   "value": round(P * args.steps / el / 1e6, 2), "unit": "Mpoints/s",
+                   "ms_per_step": round(el / args.steps * 1e3, 4),
+                   "kernel": "lidf_points_fused_kernel x 2 (prob net over P pairs | offset net over R selected pairs) "
+                             "+ lidf_ray_reduce_kernel + lidf_selected_finish_kernel between the events",
+                   "kernel_ms": round(kms, 4), "flop_issued": fl,
+                   "achieved": round(fl / (kms * 1e-3) / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit_roofline": "TFLOP/s",
+                   "frac": round(fl / (kms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)}
+        if hip_f32 is not None and "pred_pos" in hip_f32:
+            sel_leg["bit_identical_to_headline"] = {
+                k: bool(torch.equal(got[k].reshape(-1), hip_f32[k].reshape(-1)))
+                for k in ("pred_prob_end", "pred_pos", "max_pair_id")}
+            sel_leg["bit_identical_to_headline"]["depth"] = bool(torch.equal(depth, hip_f32["depth"]))
+            m_ = hip_f32["max_pair_id"].clamp(max=P - 1)
+            sel_leg["bit_identical_to_headline"]["pred_offset_at_selected_pairs"] = bool(torch.equal(
+                got["pred_offset"].reshape(-1)[m_], hip_f32["pred_offset"].reshape(-1)[m_]))
+    if world == 1 and args.precision == "f32" and refine is None and gf == 64 and legs and args.offsets == "all":
         if hip_f32 is None:
             hip_f32 = step()
             hip_f32 = {k: hip_f32[k].clone() for k in ("pred_offset", "pred_prob_end", "pair_pred_pos")}
@@ -1059,9 +1179,11 @@ def main():
         # driver records) and wherever --pmc asks for them. Nothing is read from committed files.
         live = None
         profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)   # already under a profiler
-        headline = dense and B == 1 and N == 64 and refine is None and not h16 and S == 1 and gf == 64
+        headline = (dense and B == 1 and N == 64 and refine is None and not h16 and S == 1 and gf == 64
+                    and args.offsets == "all")
         if world == 1 and not use_dist and not args.no_rocprof and not profiled:
-            live = live_profile(sys.argv[1:], kname, pmc=args.pmc or (headline and not args.no_cpu_baseline))
+            live = live_profile(sys.argv[1:], kname, pmc=args.pmc or (headline and not args.no_cpu_baseline),
+                                per_step=2 if (args.offsets == "selected" and gf == 64 and not h16) else 1)
         lk = live_kernel(live, kname)
         lh = (live or {}).get("hbm")
         lhk = None
@@ -1104,6 +1226,11 @@ def main():
                          "kernel_ms_rocprof_live": ({"kernel_ms": lk["avg_ms_after_first"], "kernel_ms_all": lk["avg_ms"],
                                                      "calls": live["steps_seen"], "command": live["command"]}
                                                     if lk else None),
+                         # the same issued FLOP over the profiler's average duration (after the first launch / all)
+                         "frac_rocprof": (round(f_exec * P / (lk["avg_ms_after_first"] * 1e-3) / 1e12 / peak, 4)
+                                          if lk and args.offsets == "all" else None),
+                         "frac_rocprof_all": (round(f_exec * P / (lk["avg_ms"] * 1e-3) / 1e12 / peak, 4)
+                                              if lk and args.offsets == "all" else None),
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,
                          "flop_per_point_counter": (round(lmk["mfma_flop"] / P, 1) if lmk and not h16 else None),
                          "pipe": ({"ghz": lmk["ghz"], "mfma_busy": lmk["mfma_busy"]} if lmk else None),
@@ -1163,6 +1290,22 @@ def main():
                                   "points_all_ranks": points_all}
         if split is not None:
             line["split_f16"] = split
+        if sel_leg is not None:
+            line["offsets_selected"] = sel_leg
+        if args.offsets == "selected":   # `--offsets selected`: the opt-in mode as the measured step (secondary record)
+            fl = F_EXEC_PROB * P + F_EXEC_OFF * scene["R"]
+            a_ = fl / (kern_ms * 1e-3) / 1e12
+            line["metric"] = "Mpoints/sec implicit-MLP query, offsets for the selected pairs only (opt-in)"
+            line["config"]["workload"] = "secondary (opt-in lidf_query(offsets='selected'), not the reference's data " \
+                "flow: pred_offset / pair_pred_pos defined at the arg-max pairs only): " + line["config"]["workload"]
+            rl = line["roofline"]
+            rl.update({"achieved": round(a_, 2), "frac": round(a_ / peak, 4), "flop_issued_per_step": fl,
+                       "kernel": "lidf_points_fused_kernel x 2 (prob net over P pairs | offset net over R selected "
+                                 "pairs) + lidf_ray_reduce_kernel + lidf_selected_finish_kernel between the events",
+                       "flop_per_point_exec": None, "achieved_alg": None, "frac_alg": None,
+                       "frac_rocprof": (round(fl / (lk["avg_ms_after_first"] * lk["calls_per_step"] * 1e-3) / 1e12 / peak, 4)
+                                        if lk else None),
+                       "frac_rocprof_note": "issued FLOP of both launches / (their profiler average x launches per step)"})
         if not dense:
             line["config"]["pairs"] = {"kind": args.pairs, "points": P, "rays": scene["R"],
                                        "pairs_per_ray": round(P / scene["R"], 3)}

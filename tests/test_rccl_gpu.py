@@ -107,6 +107,32 @@ def test_eight_ranks_sharing_the_gpu(cuda):
             assert rec["config"]["rays_per_gpu"] == 30 * 320
 
 
+@pytest.mark.parametrize("world,mode", [(1, "frame"), (2, "frame"), (8, "graph")])
+def test_eval_stream_sharded_over_ranks(cuda, world, mode):
+    """bench.py --workload e2e --gpus N: the frames of an evaluation stream sharded over the ranks
+    (dist.shard_frames), one FrameRunner per rank, the refined depth maps all-gathered inside the timed
+    region — world 1 through RCCL, worlds 2 and 8 with all ranks on the one GPU (gloo transport, test-only).
+    Rank g runs the batch a single GPU would have met as its g-th: the ranks' scenes differ, so do their
+    pair counts, and the whole-job totals are sums."""
+    share = {"LIDF_TEST_SHARE_GPU": "1"} if world > 1 else {}
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--workload", "e2e", "--e2e-mode", mode, "--gpus", str(world),
+                   "--steps", "2", "--warmup", "1", "--no-rocprof"], 29630 + world, nproc=world, extra_env=share,
+                  timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    col = rec["collective"]
+    assert rec["n_gpus"] == world and rec["scaling"] == "weak"
+    assert col["ranks_seen"] == world and len(col["ms_per_step_by_rank"]) == world
+    assert col["gathered_equals_local"] is True and col["frames_all_ranks"] == world
+    assert col["rays_all_ranks"] == world * 240 * 320
+    assert col["pairs_all_ranks"] >= world * 200000 and (world == 1) == (col["pairs_all_ranks"] == rec["config"]["pairs"])
+    assert abs(rec["value"] - col["pairs_all_ranks"] / rec["ms_per_step"] / 1e3) <= 0.01 * rec["value"]
+    assert rec["ms_per_step"] >= max(col["ms_per_step_by_rank"]) - 1e-3
+    assert abs(rec["frames_per_s"] - world / rec["ms_per_step"] * 1e3) <= 0.01 * rec["frames_per_s"]
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
