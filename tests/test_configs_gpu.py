@@ -42,6 +42,33 @@ def test_config0_64x64x16_whole_frame(cuda, precision, ragged):
         assert gid[r] < scene["P"] and rid[r] < scene["P"] and abs(sm[gid[r]] - sm[rid[r]]) <= 1e-6
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_config0_offsets_for_the_selected_pairs_only(cuda, ragged):
+    """lidf_query(offsets="selected") (opt-in, LidfQueryArgs.offsets_selected) on configs[0], whole frame, against
+    the oracle and against the default call: the offset decoder runs on the arg-max pair of every ray only —
+    pred_prob_end, softmax, max_pair_id, pred_pos and the depth map are bit-identical to the default (the
+    reference reads per-pair offsets only through pred_pos, models/pipeline.py:452-454), pred_offset /
+    pair_pred_pos hold the default's values at the selected rows (<= 1e-4 of the oracle) and NaN elsewhere."""
+    scene = _scene(1, 64, 64, 16, 1234, ragged)
+    ref = oracle_query(scene, fast_roi=True)
+    full = run_query(scene, cuda)
+    got = run_query(scene, cuda, offsets="selected")
+    for k in ("pred_prob_end", "pred_prob_end_softmax", "max_pair_id", "pred_pos", "depth"):
+        assert torch.equal(got[k], full[k]), k
+    P = scene["P"]
+    mid = got["max_pair_id"]
+    has = mid < P                                   # rays with at least one candidate
+    sel = mid[has]
+    assert bool(has.all()) == (not ragged)
+    for k in ("pred_offset", "pair_pred_pos"):
+        assert torch.equal(got[k][sel], full[k][sel]), k
+        assert (got[k][sel].cpu() - ref[k][sel.cpu()]).abs().max().item() <= TOL, k
+        rest = torch.ones(P, dtype=torch.bool, device=cuda)
+        rest[sel] = False
+        assert torch.isnan(got[k][rest]).all(), k   # rows no launch writes do not look like results
+    assert (got["pred_pos"].cpu() - ref["pred_pos"]).abs().max().item() <= TOL
+
+
 def check_full_size(scene, got, cuda, rays_per_frame=96):
     B, N, R, P = scene["B"], scene["N"], scene["R"], scene["P"]
     assert P == R * N
