@@ -278,6 +278,9 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300, per_
                "steps_seen": nstep,
                "launches_per_step": round(sum(len(v) for v in per.values()) / nstep, 1),
                "busy_ms_per_step": round(sum(sum(v) for v in per.values()) / nstep / 1e6, 4),
+               # (the same sum without every kernel's first launch — code load, cold caches, clock ramp)
+               "busy_ms_per_step_after_first": round(sum(sum(v[1:]) / max(len(v) - 1, 1) * len(v) for v in per.values())
+                                                     / nstep / 1e6, 4),
                "kernels": dict(list(kern.items())[:24])}
         if pmc:
             vals = {}
@@ -809,7 +812,8 @@ def e2e(args):
         "roofline_kernels_note": ("side stream: the stage-2 layer-1 table runs beside (in the tail of) the per-point "
                                   "kernel, whose duration then includes the shared rounds; per-kernel fractions of "
                                   "launches that never overlap: --no-side-stream" if side_on and roof else None),
-        "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels", "hbm", "mfma")
+        "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step",
+                                          "busy_ms_per_step_after_first", "kernels", "hbm", "mfma")
                      if k in live} if live else None),
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
     if use_dist:
@@ -1276,7 +1280,8 @@ def main():
             }
             del line["roofline_stage2"]["refine_ms_per_step"]
         if live:
-            line["profile"] = {k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step", "kernels")}
+            line["profile"] = {k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step",
+                                                    "busy_ms_per_step_after_first", "kernels")}
             if lh:
                 line["profile"]["hbm"] = lh
             if live.get("mfma"):

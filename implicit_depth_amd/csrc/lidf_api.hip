@@ -2629,6 +2629,43 @@ static int check_qtrain(const LidfQueryTrainArgs* q) {
     return check_decoder(q->dec);
 }
 
+// The factorised decoder forward with kept activations. E2 = width of the per-pair operand `pe` (the query:
+// embed(enter) | embed(leave); stage 2: embed(pos)); W1's columns are [voxel feature 128 | ROI 128 | pe E2 |
+// embed(dir) Ed | (IEF) offset encoding 16]. Three weight streams: the per-voxel layer-1 launch (s_vox), the
+// per-ray one (s_ray) and the chain (s_chain): pack_mode 0 = pack and run, 1 = pack only, 2 = run on streams
+// packed earlier. parts: 1 = voxpart, 2 = raypart, 4 = chain (which of the three launches to run).
+static int qdec_forward_impl(const LidfQueryTrainArgs* q, int E2, float* out, float* voxpart, float* raypart,
+                             float* passes, float* pre, float* s_vox, float* s_ray, char* s_chain, int cus,
+                             hipStream_t st, int pack_mode = 0, int parts = 7) {
+    int rc;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    const LidfDecoder* dec = q->dec;
+    const int Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    LinEx L = {};
+    // voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c) ; raypart[r] = W1[:, rgb | dir] rayfeat[r]
+    if (parts & 1) {
+        L.w = dec->w1; L.b = dec->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
+        L.ief = dec->is_ief ? dec : nullptr;   // bias += c (no offset operand: xoff stays NULL)
+        L.X = q->vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, s_vox, cus, st, pack_mode))) return rc;
+    }
+    if (parts & 2) {
+        L = {};
+        L.w = dec->w1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.c0 = 128; L.k1 = Ed; L.c1 = 256 + E2;
+        L.X = q->rayfeat; L.ldx = 128 + Ed; L.n = R; L.out = raypart; L.ld_out = LIDF_H1;
+        if ((rc = run_linex(L, s_ray, cus, st, pack_mode))) return rc;
+    }
+    // layer 1 = W1[:, pe columns] PE + voxpart[voxel] + raypart[ray] (+ u * off), then the chain,
+    // in registers; every pass's H1 | H2 | H3 | offset-in is kept
+    if (parts & 4) {
+        if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, E2, P, q->pair_vox, q->pair_ray,
+                                  voxpart, raypart, passes, pre, out, s_chain, cus, st, LIDF_MODE_TRAIN, pack_mode)))
+            return rc;
+    }
+    return LIDF_OK;
+}
+
 LIDF_API int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* q, float* out, float* act,
                                                     void* workspace, size_t workspace_bytes,
                                                     lidf_stream_t stream) {
@@ -2644,29 +2681,15 @@ LIDF_API int lidf_query_decoder_forward_train_f32(const LidfQueryTrainArgs* q, f
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     const LidfDecoder* dec = q->dec;
-    const int E2 = 2 * (3 + 6 * q->multires), Ed = 3 + 6 * q->multires_views;
-    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    const int E2 = 2 * (3 + 6 * q->multires);
     const int npass = dec->is_ief ? dec->n_iter : 1;
     float* voxpart = act;
     float* raypart = voxpart + (size_t)V * LIDF_H1;
     float* passes = raypart + (size_t)R * LIDF_H1;
     float* pre = passes + (size_t)npass * qact_pass(P);
-    LinEx L = {};
-    // voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c) ; raypart[r] = W1[:, rgb | dir] rayfeat[r]
-    L.w = dec->w1; L.b = dec->b1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.dcore = D;
-    L.ief = dec->is_ief ? dec : nullptr;   // bias += c (no offset operand: xoff stays NULL)
-    L.X = q->vox_feat; L.ldx = 128; L.n = V; L.out = voxpart; L.ld_out = LIDF_H1;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    L = {};
-    L.w = dec->w1; L.ldw = ld1; L.nout = LIDF_H1; L.k = 128; L.c0 = 128; L.k1 = Ed; L.c1 = 256 + E2;
-    L.X = q->rayfeat; L.ldx = 128 + Ed; L.n = R; L.out = raypart; L.ld_out = LIDF_H1;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    // layer 1 = W1[:, enter|leave] PE + voxpart[voxel] + raypart[ray] (+ u * off), then the chain,
-    // in registers; every pass's H1 | H2 | H3 | offset-in is kept
-    if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, E2, P, q->pair_vox, q->pair_ray,
-                              voxpart, raypart, passes, pre, out, (char*)workspace + w.chain, cus, st)))
-        return rc;
-    return LIDF_OK;
+    // (one stream slot serves the two layer-1 launches in turn: each is consumed before the next pack)
+    return qdec_forward_impl(q, E2, out, voxpart, raypart, passes, pre, sbuf, sbuf, (char*)workspace + w.chain,
+                             cus, st);
 }
 
 LIDF_API size_t lidf_query_forward_train_workspace_bytes(int64_t n_rays, int64_t n_vox) {
@@ -2744,6 +2767,106 @@ LIDF_API int lidf_query_forward_train_f32(const LidfQueryTrainArgs* q, const Lid
     return LIDF_OK;
 }
 
+// The factorised decoder backward (see qdec_forward_impl for E2 and the column layout of W1).
+struct QdecBwd {
+    int E2;
+    bool zero_grads;       // false: the parameter gradients are accumulated into (a later iteration of stage 2)
+    float* S_keep;         // != NULL: the running sum S of dZ1 over the passes lands here and everything per ray
+                           // (segment sums per ray, dW1[:, ROI | dir], d_rayfeat) is left to the caller
+    float* d_pe;           // optional [P, E2]: dL/d pe = S W1[:, 256 : 256 + E2]
+    float *s_dvox, *s_dpe; // stream slots of the transposed launches (d_vox_feat, d_pe); NULL: the workspace's
+    int pack_mode;         // of those two launches: 0 pack and run, 2 packed earlier
+};
+static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, const float* passes, const float* pre,
+                              const float* g_out, float* d_vox_feat, float* d_rayfeat, int accumulate_inputs,
+                              const LidfDecoderGrads* grads, char* ws, const QTrainWs& w, int cus, hipStream_t st) {
+    int rc;
+    const LidfDecoder* dec = q->dec;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    const int E2 = o.E2, Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    float* sbuf = (float*)(ws + w.stream);
+    float* dz1 = (float*)(ws + w.dz1);
+    float* dz2 = (float*)(ws + w.dz2);
+    float* dz3 = (float*)(ws + w.dz3);
+    float* S = o.S_keep ? o.S_keep : (float*)(ws + w.S);
+    float* goff = (float*)(ws + w.goff);
+    float* wgs = (float*)(ws + w.wg);
+    float* dvox = (float*)(ws + w.dvox);
+    float* dray = (float*)(ws + w.dray);
+    float* small = (float*)(ws + w.small);
+    CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
+    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
+    for (int k = npass - 1; k >= 0; --k) {
+        const float* h1 = passes + (size_t)k * qact_pass(P);
+        const float* h2 = h1 + (size_t)P * LIDF_H1;
+        const float* h3 = h2 + (size_t)P * LIDF_H2;
+        const float* offin = h3 + (size_t)P * LIDF_H3;
+        CHECK_HIP(lidf_launch_l4_backward(goff, h3, dec->w4, 0.02f, P, dz3, grads->w4, grads->b4, wgs, st));
+        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
+        // dZ2, dZ1 of this pass: one register-chained launch. S = the running sum of dZ1 over the
+        // passes (everything of layer 1 except the offset encoding sees the same operand in every
+        // pass): the first pass processed writes its dZ1 straight into S, the others add theirs in
+        // the same sweep over dZ1 that handles the offset-encoding columns of layer 1
+        // The IEF's first pass (k = 0, the last one processed) has the constant initial offset as
+        // its offset-in: its share of the offset-encoding gradients follows from column sums of S
+        // (lidf_ief_finish_kernel), so its dZ1 is added into S by the chained launch itself and never
+        // swept again.
+        if (npass == 1) {
+            if (o.S_keep) dz1 = S;
+            else S = dz1;
+        }
+        const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
+        float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
+        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, P), act_m1(h1, P), P, 0.02f, dz2, dz1k,
+                                          first_pass_short ? 1 : 0, sbuf, cus, st));
+        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
+        if (!first_pass_short)
+            CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
+                                           dec->benc, P, k == npass - 1 ? 0 : 2, S, goff,
+                                           grads->w1 + D, grads->wenc, grads->benc,
+                                           dec->is_ief && npass > 1 ? small : nullptr, wgs, st));
+    }
+    // layer 1, the pass-independent operands: S = sum over passes of dZ1
+    const bool short_first = dec->is_ief && npass > 1;
+    // (column sums of S through the weight-gradient launch's bias path when the first pass needs them)
+    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1,
+                                short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    if (short_first)
+        CHECK_HIP(lidf_launch_ief_first_pass(small + 256, small, dec->init_offset, dec->w1 + D, ld1,
+                                             dec->wenc, dec->benc, grads->w1 + D, grads->wenc,
+                                             grads->benc, st));
+    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
+                                      w.seg_bytes, st));
+    // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
+    CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
+    if (!o.S_keep) {
+        CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
+        // ray part: raypart[r] = W1[:, 128:256] roi[r] + W1[:, 256+E2:] embed(dir)[r]
+        CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat, 128 + Ed, 128, R, grads->w1 + 128, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+        CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat + 128, 128 + Ed, Ed, R, grads->w1 + 256 + E2, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    }
+    LinEx L = {};
+    L.transposed = 1; L.ldw = ld1; L.k = LIDF_H1; L.ldx = LIDF_H1; L.accumulate = accumulate_inputs ? 1 : 0;
+    if (d_vox_feat) {
+        L.w = dec->w1; L.nout = 128; L.X = dvox; L.n = V; L.out = d_vox_feat; L.ld_out = 128;
+        if ((rc = run_linex(L, o.s_dvox ? o.s_dvox : sbuf, cus, st, o.s_dvox ? o.pack_mode : 0))) return rc;
+    }
+    if (o.d_pe) {
+        L.w = dec->w1 + 256; L.nout = E2; L.X = S; L.n = P; L.out = o.d_pe; L.ld_out = E2; L.accumulate = 0;
+        if ((rc = run_linex(L, o.s_dpe ? o.s_dpe : sbuf, cus, st, o.s_dpe ? o.pack_mode : 0))) return rc;
+        L.accumulate = accumulate_inputs ? 1 : 0;
+    }
+    if (d_rayfeat && !o.S_keep) {
+        L.w = dec->w1 + 128; L.nout = 128; L.X = dray; L.n = R; L.out = d_rayfeat; L.ld_out = 128 + Ed;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+        L.w = dec->w1 + 256 + E2; L.nout = Ed; L.out = d_rayfeat + 128;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    }
+    return LIDF_OK;
+}
+
 LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const float* act,
                                                const float* g_out, float* d_vox_feat,
                                                float* d_rayfeat, int32_t accumulate_inputs,
@@ -2770,85 +2893,16 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
     if (!act || !g_out) return LIDF_ERR_BAD_ARG;
     const QTrainWs w = qtrain_ws(P, R, V);
     if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
-    char* ws = (char*)workspace;
-    float* sbuf = (float*)(ws + w.stream);
-    float* dz1 = (float*)(ws + w.dz1);
-    float* dz2 = (float*)(ws + w.dz2);
-    float* dz3 = (float*)(ws + w.dz3);
-    float* S = (float*)(ws + w.S);
-    float* goff = (float*)(ws + w.goff);
-    float* wgs = (float*)(ws + w.wg);
-    float* dvox = (float*)(ws + w.dvox);
-    float* dray = (float*)(ws + w.dray);
-    float* small = (float*)(ws + w.small);
-    CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     const float* voxpart = act;
     const float* raypart = voxpart + (size_t)V * LIDF_H1;
     const float* passes = raypart + (size_t)R * LIDF_H1;
     const float* pre = passes + (size_t)npass * qact_pass(P);
-    (void)voxpart; (void)raypart;
-    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
-    for (int k = npass - 1; k >= 0; --k) {
-        const float* h1 = passes + (size_t)k * qact_pass(P);
-        const float* h2 = h1 + (size_t)P * LIDF_H1;
-        const float* h3 = h2 + (size_t)P * LIDF_H2;
-        const float* offin = h3 + (size_t)P * LIDF_H3;
-        CHECK_HIP(lidf_launch_l4_backward(goff, h3, dec->w4, 0.02f, P, dz3, grads->w4, grads->b4, wgs, st));
-        LinEx L = {};
-        L.n = P; L.transposed = 1; L.mask_slope = 0.02f;
-        CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, P, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
-        // dZ2, dZ1 of this pass: one register-chained launch. S = the running sum of dZ1 over the
-        // passes (everything of layer 1 except the offset encoding sees the same operand in every
-        // pass): the first pass processed writes its dZ1 straight into S, the others add theirs in
-        // the same sweep over dZ1 that handles the offset-encoding columns of layer 1
-        // The IEF's first pass (k = 0, the last one processed) has the constant initial offset as
-        // its offset-in: its share of the offset-encoding gradients follows from column sums of S
-        // (lidf_ief_finish_kernel), so its dZ1 is added into S by the chained launch itself and never
-        // swept again.
-        if (npass == 1) S = dz1;
-        const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
-        float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, P), act_m1(h1, P), P, 0.02f, dz2, dz1k,
-                                          first_pass_short ? 1 : 0, sbuf, cus, st));
-        CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        if (!first_pass_short)
-            CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
-                                           dec->benc, P, k == npass - 1 ? 0 : 2, S, goff,
-                                           grads->w1 + D, grads->wenc, grads->benc,
-                                           dec->is_ief && npass > 1 ? small : nullptr, wgs, st));
-    }
-    // layer 1, the pass-independent operands: S = sum over passes of dZ1
-    const bool short_first = dec->is_ief && npass > 1;
-    // (column sums of S through the weight-gradient launch's bias path when the first pass needs them)
-    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1,
-                                short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
-    if (short_first)
-        CHECK_HIP(lidf_launch_ief_first_pass(small + 256, small, dec->init_offset, dec->w1 + D, ld1,
-                                             dec->wenc, dec->benc, grads->w1 + D, grads->wenc,
-                                             grads->benc, st));
-    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
-                                      w.seg_bytes, st));
-    CHECK_HIP(lidf_launch_seg_sum_ray(S, LIDF_H1, q->pair_off, R, dray, st));
-    // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
-    CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
-    // ray part: raypart[r] = W1[:, 128:256] roi[r] + W1[:, 256+E2:] embed(dir)[r]
-    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat, 128 + Ed, 128, R, grads->w1 + 128, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-    CHECK_HIP(lidf_launch_wgrad(dray, LIDF_H1, LIDF_H1, q->rayfeat + 128, 128 + Ed, Ed, R, grads->w1 + 256 + E2, ld1, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-    LinEx L = {};
-    L.transposed = 1; L.ldw = ld1; L.k = LIDF_H1; L.ldx = LIDF_H1; L.accumulate = accumulate_inputs ? 1 : 0;
-    if (d_vox_feat) {
-        L.w = dec->w1; L.nout = 128; L.X = dvox; L.n = V; L.out = d_vox_feat; L.ld_out = 128;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    }
-    if (d_rayfeat) {
-        L.w = dec->w1 + 128; L.nout = 128; L.X = dray; L.n = R; L.out = d_rayfeat; L.ld_out = 128 + Ed;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-        L.w = dec->w1 + 256 + E2; L.nout = Ed; L.out = d_rayfeat + 128;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    }
-    return LIDF_OK;
+    QdecBwd o = {};
+    o.E2 = E2; o.zero_grads = true;
+    return qdec_backward_impl(q, o, passes, pre, g_out, d_vox_feat, d_rayfeat, accumulate_inputs, grads,
+                              (char*)workspace, w, cus, st);
 }
 
 // ---- per-pair / per-ray tail of get_pred, forward and adjoint -------------------------------------
@@ -2959,6 +3013,30 @@ LIDF_API size_t lidf_pointnet_train_workspace_bytes(int64_t n_pts, int64_t n_vox
     return pnet_train_ws(n_pts, n_vox).total;
 }
 
+// forward with the rows kept: layer by layer through lidf_linear_kernel (mode 0: pack and run, 2: streams packed
+// earlier), then the arg row of every pooled entry
+static int pointnet_train_forward_impl(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n,
+                                       int64_t n_vox, float* out, float* act, float* gpart,
+                                       float* const streams[7], int cus, hipStream_t st, int mode) {
+    int rc;
+    const PnetAct a = pnet_act(n, n_vox);
+    PnetBufs b = {};
+    b.f1 = act + a.f1; b.f2 = act + a.f2; b.f4 = act + a.f4; b.f5 = act + a.f5;
+    b.pool1 = act + a.pool1; b.g1 = act + a.g1; b.pool2 = act + a.pool2;
+    b.gpart = gpart;
+    for (int i = 0; i < 7; ++i) b.streams[i] = streams[i];
+    if ((rc = pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, st, mode))) return rc;
+    if (mode == 1) return LIDF_OK;
+    if (out != act + a.out)
+        CHECK_HIP(hipMemcpyAsync(act + a.out, out, (size_t)n_vox * 128 * 4, hipMemcpyDeviceToDevice, st));
+    // arg of every pooled entry: the lowest row attaining the maximum
+    CHECK_HIP(hipMemsetAsync(act + a.arg1, 0x7f, (size_t)n_vox * 64 * 4, st));
+    CHECK_HIP(hipMemsetAsync(act + a.arg2, 0x7f, (size_t)n_vox * 128 * 4, st));
+    CHECK_HIP(lidf_launch_segmax_arg(b.f2, vox, b.pool1, n, 64, (int*)(act + a.arg1), st));
+    CHECK_HIP(lidf_launch_segmax_arg(b.f5, vox, b.pool2, n, 128, (int*)(act + a.arg2), st));
+    return LIDF_OK;
+}
+
 LIDF_API int lidf_pointnet_forward_train_f32(const LidfPointNet* w, const float* inp,
                                                const int32_t* vox, int64_t n, int64_t n_vox,
                                                float* out, float* act, void* workspace,
@@ -2970,25 +3048,105 @@ LIDF_API int lidf_pointnet_forward_train_f32(const LidfPointNet* w, const float*
     if ((rc = check_pointnet_w(w))) return rc;
     const PnetTrainWs ws = pnet_train_ws(n, n_vox);
     if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
-    const PnetAct a = pnet_act(n, n_vox);
     char* base = (char*)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    PnetBufs b = {};
-    b.f1 = act + a.f1; b.f2 = act + a.f2; b.f4 = act + a.f4; b.f5 = act + a.f5;
-    b.pool1 = act + a.pool1; b.g1 = act + a.g1; b.pool2 = act + a.pool2;
-    b.gpart = (float*)(base + ws.gpart);
-    for (int i = 0; i < 7; ++i) b.streams[i] = (float*)(base + ws.s[i]);
+    float* streams[7];
+    for (int i = 0; i < 7; ++i) streams[i] = (float*)(base + ws.s[i]);
     int cus;
     if ((rc = cu_count(&cus))) return rc;
-    if ((rc = pointnet_impl(w, inp, vox, n, n_vox, out, b, cus, st))) return rc;
-    CHECK_HIP(hipMemcpyAsync(act + a.out, out, (size_t)n_vox * 128 * 4, hipMemcpyDeviceToDevice, st));
-    // arg of every pooled entry: the lowest row attaining the maximum
-    CHECK_HIP(hipMemsetAsync(act + a.arg1, 0x7f, (size_t)n_vox * 64 * 4, st));
-    CHECK_HIP(hipMemsetAsync(act + a.arg2, 0x7f, (size_t)n_vox * 128 * 4, st));
-    CHECK_HIP(lidf_launch_segmax_arg(b.f2, vox, b.pool1, n, 64, (int*)(act + a.arg1), st));
-    CHECK_HIP(lidf_launch_segmax_arg(b.f5, vox, b.pool2, n, 128, (int*)(act + a.arg2), st));
+    return pointnet_train_forward_impl(w, inp, vox, n, n_vox, out, act, (float*)(base + ws.gpart), streams, cus,
+                                       (hipStream_t)stream, 0);
+}
+
+// The backward. slots: stream slots of its seven transposed launches (NULL: one slot of the workspace serves
+// them in turn), pack_mode of those launches (0 pack and run, 1 pack only, 2 packed earlier); zero_grads false:
+// the parameter gradients are accumulated into.
+static int pointnet_backward_impl(const LidfPointNet* w, const float* inp, const int32_t* vox, int64_t n,
+                                  int64_t n_vox, const float* act, const float* g_out, float* d_inp,
+                                  const LidfPointNetGrads* g, char* base, const PnetTrainWs& ws, bool zero_grads,
+                                  float* const* slots, int pack_mode, int cus, hipStream_t st) {
+    int rc;
+    const bool po = pack_mode == 1;
+    if (zero_grads && !po) {
+        float* const zp[12] = {g->w_p1, g->b_p1, g->w_p2, g->b_p2, g->w_v1, g->b_v1, g->w_p3, g->b_p3,
+                               g->w_p4, g->b_p4, g->w_v2, g->b_v2};
+        const long long zc[12] = {32 * 6, 32, 64 * 32, 64, 64 * 64, 64, 128 * 128, 128, 128 * 128, 128, 128 * 128, 128};
+        CHECK_HIP(lidf_launch_zero_segments(zp, zc, 12, st));
+    }
+    if (d_inp && n > 0 && !po) CHECK_HIP(hipMemsetAsync(d_inp, 0, (size_t)n * 6 * 4, st));
+    if (n_vox == 0 && !po) return LIDF_OK;
+    const PnetAct a = pnet_act(n, n_vox);
+    float* sbuf = (float*)(base + ws.stream);
+    float* dz_out = (float*)(base + ws.dz_out);
+    float* dp2 = (float*)(base + ws.dp2);
+    float* dz5 = (float*)(base + ws.dz5);
+    float* dz4 = (float*)(base + ws.dz4);
+    float* s4 = (float*)(base + ws.s4);
+    float* dg1 = (float*)(base + ws.dg1);
+    float* df2 = (float*)(base + ws.df2);
+    float* dp1 = (float*)(base + ws.dp1);
+    float* dz1 = (float*)(base + ws.dz1);
+    float* wgs = (float*)(base + ws.wg);
+    const float *f1 = act + a.f1, *f2 = act + a.f2, *f4 = act + a.f4;
+    const float *pool1 = act + a.pool1, *g1 = act + a.g1, *pool2 = act + a.pool2, *outv = act + a.out;
+    const int *arg1 = (const int*)(act + a.arg1), *arg2 = (const int*)(act + a.arg2);
+    const int64_t V = n_vox;
+    int slot = 0;
+    auto lin = [&](const LinEx& L) { float* sp = slots ? slots[slot] : sbuf; ++slot; return run_linex(L, sp, cus, st, pack_mode); };
+    // out = relu(vox_lin2(pool2))
+    if (!po) {
+        CHECK_HIP(lidf_launch_relu_mask(g_out, outv, V * 128, dz_out, st));
+        CHECK_HIP(lidf_launch_wgrad(dz_out, 128, 128, pool2, 128, 128, V, g->w_v2, 128, g->b_v2, wgs, WG_SCRATCH_FLOATS, st));
+    }
+    LinEx L = {};
+    L.transposed = 1; L.mask_slope = 0.f;
+    L.n = V; L.w = w->w_v2; L.ldw = 128; L.nout = 128; L.k = 128; L.X = dz_out; L.ldx = 128;
+    L.out = dp2; L.ld_out = 128;
+    if ((rc = lin(L))) return rc;
+    if (n == 0 && !po) return LIDF_OK;   // no points: the pooled inputs were the zero fill
+    // pool2 = segmax(f5): d f5 goes to the arg rows; f5 = relu(point_lin4(f4))
+    if (!po) {
+        CHECK_HIP(lidf_launch_segmax_backward(dp2, arg2, vox, pool2, n, 128, 0, dz5, st));
+        CHECK_HIP(lidf_launch_wgrad(dz5, 128, 128, f4, 128, 128, n, g->w_p4, 128, g->b_p4, wgs, WG_SCRATCH_FLOATS, st));
+    }
+    L.n = n; L.w = w->w_p4; L.X = dz5; L.mask_src = f4; L.ld_mask = 128; L.out = dz4;
+    if ((rc = lin(L))) return rc;
+    // f4 = relu(point_lin3(cat(g1[vox], f2))): weight columns 0..63 meet g1[vox], 64..127 meet f2
+    if (!po) {
+        CHECK_HIP(hipMemsetAsync(s4, 0, (size_t)V * 128 * 4, st));
+        CHECK_HIP(lidf_launch_seg_sum_rows(dz4, vox, n, 128, s4, st));
+        CHECK_HIP(lidf_launch_wgrad(s4, 128, 128, g1, 64, 64, V, g->w_p3, 128, nullptr, wgs, WG_SCRATCH_FLOATS, st));
+        CHECK_HIP(lidf_launch_wgrad(dz4, 128, 128, f2, 64, 64, n, g->w_p3 + 64, 128, g->b_p3, wgs, WG_SCRATCH_FLOATS, st));
+    }
+    L.mask_src = nullptr;
+    L.n = n; L.w = w->w_p3 + 64; L.ldw = 128; L.nout = 64; L.k = 128; L.X = dz4; L.ldx = 128;
+    L.out = df2; L.ld_out = 64;
+    if ((rc = lin(L))) return rc;
+    // g1 = relu(vox_lin1(pool1))
+    L.n = V; L.w = w->w_p3; L.X = s4; L.mask_src = g1; L.ld_mask = 64; L.out = dg1;
+    if ((rc = lin(L))) return rc;
+    if (!po) CHECK_HIP(lidf_launch_wgrad(dg1, 64, 64, pool1, 64, 64, V, g->w_v1, 64, g->b_v1, wgs, WG_SCRATCH_FLOATS, st));
+    L.mask_src = nullptr;
+    L.w = w->w_v1; L.ldw = 64; L.nout = 64; L.k = 64; L.X = dg1; L.ldx = 64; L.out = dp1; L.ld_out = 64;
+    if ((rc = lin(L))) return rc;
+    // pool1 = segmax(f2): added to the gradient f2 receives through the concat; f2 = relu(point_lin2(f1))
+    if (!po) {
+        CHECK_HIP(lidf_launch_segmax_backward(dp1, arg1, vox, pool1, n, 64, 1, df2, st));
+        CHECK_HIP(lidf_launch_relu_mask(df2, f2, n * 64, df2, st));
+        CHECK_HIP(lidf_launch_wgrad(df2, 64, 64, f1, 32, 32, n, g->w_p2, 32, g->b_p2, wgs, WG_SCRATCH_FLOATS, st));
+    }
+    L.n = n; L.w = w->w_p2; L.ldw = 32; L.nout = 32; L.k = 64; L.X = df2; L.ldx = 64;
+    L.mask_src = f1; L.ld_mask = 32; L.out = dz1; L.ld_out = 32;
+    if ((rc = lin(L))) return rc;
+    if (!po) CHECK_HIP(lidf_launch_wgrad(dz1, 32, 32, inp, 6, 6, n, g->w_p1, 6, g->b_p1, wgs, WG_SCRATCH_FLOATS, st));
+    if (d_inp || po) {
+        L.mask_src = nullptr;
+        L.w = w->w_p1; L.ldw = 6; L.nout = 6; L.k = 32; L.X = dz1; L.ldx = 32; L.out = d_inp; L.ld_out = 6;
+        if ((rc = lin(L))) return rc;
+    }
     return LIDF_OK;
 }
+#define PNET_BWD_SLOTS 7
+static const int PNET_BWD_SLOT_K[PNET_BWD_SLOTS] = {128, 128, 128, 128, 64, 64, 32};   // contraction lengths, in launch order
 
 LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
                                           int64_t n, int64_t n_vox, const float* act,
@@ -3002,78 +3160,11 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
         !g->w_p4 || !g->b_p4 || !g->w_v2 || !g->b_v2)
         return LIDF_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const struct { float* p; size_t n; } zero[12] = {
-        {g->w_p1, 32 * 6}, {g->b_p1, 32}, {g->w_p2, 64 * 32}, {g->b_p2, 64}, {g->w_v1, 64 * 64}, {g->b_v1, 64},
-        {g->w_p3, 128 * 128}, {g->b_p3, 128}, {g->w_p4, 128 * 128}, {g->b_p4, 128}, {g->w_v2, 128 * 128},
-        {g->b_v2, 128}};
-    for (int i = 0; i < 12; ++i) CHECK_HIP(hipMemsetAsync(zero[i].p, 0, zero[i].n * 4, st));
-    if (d_inp && n > 0) CHECK_HIP(hipMemsetAsync(d_inp, 0, (size_t)n * 6 * 4, st));
-    if (n_vox == 0) return LIDF_OK;
-    if (!act || !g_out || (n > 0 && (!inp || !vox))) return LIDF_ERR_BAD_ARG;
+    if (n_vox > 0 && (!act || !g_out || (n > 0 && (!inp || !vox)))) return LIDF_ERR_BAD_ARG;
     const PnetTrainWs ws = pnet_train_ws(n, n_vox);
-    if (!workspace || workspace_bytes < ws.total) return LIDF_ERR_WORKSPACE;
-    const PnetAct a = pnet_act(n, n_vox);
-    char* base = (char*)workspace;
-    float* sbuf = (float*)(base + ws.stream);
-    float* dz_out = (float*)(base + ws.dz_out);
-    float* dp2 = (float*)(base + ws.dp2);
-    float* dz5 = (float*)(base + ws.dz5);
-    float* dz4 = (float*)(base + ws.dz4);
-    float* s4 = (float*)(base + ws.s4);
-    float* dg1 = (float*)(base + ws.dg1);
-    float* df2 = (float*)(base + ws.df2);
-    float* dp1 = (float*)(base + ws.dp1);
-    float* dz1 = (float*)(base + ws.dz1);
-    float* wgs = (float*)(base + ws.wg);
-    const float *f1 = act + a.f1, *f2 = act + a.f2, *f4 = act + a.f4, *f5 = act + a.f5;
-    const float *pool1 = act + a.pool1, *g1 = act + a.g1, *pool2 = act + a.pool2, *outv = act + a.out;
-    const int *arg1 = (const int*)(act + a.arg1), *arg2 = (const int*)(act + a.arg2);
-    (void)f5;
+    if (n_vox > 0 && (!workspace || workspace_bytes < ws.total)) return LIDF_ERR_WORKSPACE;
     int cus;
     if ((rc = cu_count(&cus))) return rc;
-    const int64_t V = n_vox;
-    // out = relu(vox_lin2(pool2))
-    CHECK_HIP(lidf_launch_relu_mask(g_out, outv, V * 128, dz_out, st));
-    CHECK_HIP(lidf_launch_wgrad(dz_out, 128, 128, pool2, 128, 128, V, g->w_v2, 128, g->b_v2, wgs, WG_SCRATCH_FLOATS, st));
-    LinEx L = {};
-    L.transposed = 1; L.mask_slope = 0.f;
-    L.n = V; L.w = w->w_v2; L.ldw = 128; L.nout = 128; L.k = 128; L.X = dz_out; L.ldx = 128;
-    L.out = dp2; L.ld_out = 128;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    if (n == 0) return LIDF_OK;   // no points: the pooled inputs were the zero fill
-    // pool2 = segmax(f5): d f5 goes to the arg rows; f5 = relu(point_lin4(f4))
-    CHECK_HIP(lidf_launch_segmax_backward(dp2, arg2, vox, pool2, n, 128, 0, dz5, st));
-    CHECK_HIP(lidf_launch_wgrad(dz5, 128, 128, f4, 128, 128, n, g->w_p4, 128, g->b_p4, wgs, WG_SCRATCH_FLOATS, st));
-    L.n = n; L.w = w->w_p4; L.X = dz5; L.mask_src = f4; L.ld_mask = 128; L.out = dz4;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    // f4 = relu(point_lin3(cat(g1[vox], f2))): weight columns 0..63 meet g1[vox], 64..127 meet f2
-    CHECK_HIP(hipMemsetAsync(s4, 0, (size_t)V * 128 * 4, st));
-    CHECK_HIP(lidf_launch_seg_sum_rows(dz4, vox, n, 128, s4, st));
-    CHECK_HIP(lidf_launch_wgrad(s4, 128, 128, g1, 64, 64, V, g->w_p3, 128, nullptr, wgs, WG_SCRATCH_FLOATS, st));
-    CHECK_HIP(lidf_launch_wgrad(dz4, 128, 128, f2, 64, 64, n, g->w_p3 + 64, 128, g->b_p3, wgs, WG_SCRATCH_FLOATS, st));
-    L.mask_src = nullptr;
-    L.n = n; L.w = w->w_p3 + 64; L.ldw = 128; L.nout = 64; L.k = 128; L.X = dz4; L.ldx = 128;
-    L.out = df2; L.ld_out = 64;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    // g1 = relu(vox_lin1(pool1))
-    L.n = V; L.w = w->w_p3; L.X = s4; L.mask_src = g1; L.ld_mask = 64; L.out = dg1;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    CHECK_HIP(lidf_launch_wgrad(dg1, 64, 64, pool1, 64, 64, V, g->w_v1, 64, g->b_v1, wgs, WG_SCRATCH_FLOATS, st));
-    L.mask_src = nullptr;
-    L.w = w->w_v1; L.ldw = 64; L.nout = 64; L.k = 64; L.X = dg1; L.ldx = 64; L.out = dp1; L.ld_out = 64;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    // pool1 = segmax(f2): added to the gradient f2 receives through the concat; f2 = relu(point_lin2(f1))
-    CHECK_HIP(lidf_launch_segmax_backward(dp1, arg1, vox, pool1, n, 64, 1, df2, st));
-    CHECK_HIP(lidf_launch_relu_mask(df2, f2, n * 64, df2, st));
-    CHECK_HIP(lidf_launch_wgrad(df2, 64, 64, f1, 32, 32, n, g->w_p2, 32, g->b_p2, wgs, WG_SCRATCH_FLOATS, st));
-    L.n = n; L.w = w->w_p2; L.ldw = 32; L.nout = 32; L.k = 64; L.X = df2; L.ldx = 64;
-    L.mask_src = f1; L.ld_mask = 32; L.out = dz1; L.ld_out = 32;
-    if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    CHECK_HIP(lidf_launch_wgrad(dz1, 32, 32, inp, 6, 6, n, g->w_p1, 6, g->b_p1, wgs, WG_SCRATCH_FLOATS, st));
-    if (d_inp) {
-        L.mask_src = nullptr;
-        L.w = w->w_p1; L.ldw = 6; L.nout = 6; L.k = 32; L.X = dz1; L.ldx = 32; L.out = d_inp; L.ld_out = 6;
-        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-    }
-    return LIDF_OK;
+    return pointnet_backward_impl(w, inp, vox, n, n_vox, act, g_out, d_inp, g, (char*)workspace, ws, true, nullptr,
+                                  0, cus, st);
 }
