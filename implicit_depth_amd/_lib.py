@@ -223,6 +223,11 @@ SIGNATURES = {
     "lidf_pointnet_forward_train_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "lidf_pointnet_backward_f32": (C.c_int, [C.POINTER(LidfPointNet), _P, _P, _I64, _I64, _P, _P, _P,
                                              C.POINTER(LidfPointNetGrads), _P, _SZ, _P]),
+    "lidf_refine_train_act_bytes": (_SZ, [_I64, _I64, _I64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "lidf_refine_train_workspace_bytes": (_SZ, [_I64, _I64, _I64, C.c_int32]),
+    "lidf_refine_train_forward_f32": (C.c_int, [C.POINTER(LidfRefineArgs), C.c_int32, _P, _SZ, _P]),
+    "lidf_refine_train_backward_f32": (C.c_int, [C.POINTER(LidfRefineArgs), C.c_int32, _P, _SZ, _P, _P, _P,
+                                                 C.POINTER(LidfPointNetGrads), C.POINTER(LidfDecoderGrads), _P]),
     "lidf_query_tail_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float, C.c_float,
                                       _P, _P, _P, _P, _P, _P]),
     "lidf_query_tail_backward_f32": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.c_float, C.c_float,

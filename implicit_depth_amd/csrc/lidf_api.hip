@@ -3168,3 +3168,5 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
     return pointnet_backward_impl(w, inp, vox, n, n_vox, act, g_out, d_inp, g, (char*)workspace, ws, true, nullptr,
                                   0, cus, st);
 }
+
+#include "lidf_api_refine_train.inc"

@@ -495,3 +495,92 @@ extern "C" hipError_t lidf_launch_refine_finish_dev(const float* pred_pos, const
                        st, pred_pos, off, ray_dir, r0, rs, R, out, R_dev, ray_bid, ray_flat, hw, depth);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training path of stage 2 (lidf_refine_train_forward_f32 / _backward_f32): the per-ray pieces of the
+// adjoint of one get_pred_refine (models/pipeline.py:1019-1029 under autograd).
+//   pred_pos_out = pred_pos + (off * rs + r0) * dir   =>   d off = rs * <g, dir>,  d pred_pos += g
+//   pred_pos also enters the iteration as embed(pos [- centre]) (decoder rows) and as the PointNet row
+//   [pos - centre | rgb] of its predicted point: d pred_pos += embed'(x)^T d_pe + d_inp[:, 0:3]
+//   (the centre belongs to the end voxel, an index: no gradient).
+// ------------------------------------------------------------------------------------------------
+__global__ void lidf_refine_train_goff_kernel(const float* __restrict__ g, const float* __restrict__ dir,
+                                              float rs, long long R, float* __restrict__ goff) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float s = g[3 * r] * dir[3 * r] + g[3 * r + 1] * dir[3 * r + 1] + g[3 * r + 2] * dir[3 * r + 2];
+    goff[r] = s * rs;
+}
+
+// out[r, c] = g[r, c] (+ sum_o 2^o (cos(2^o x) d_sin[o, c] - sin(2^o x) d_cos[o, c]) + d_pe[r, c]) (+ d_inp[r, c])
+// with x = cur[r, c] (- centre of the end voxel when pos_rel); d_pe [R, 3 + 6 L] / d_inp (row stride 6) may be NULL
+__global__ void lidf_refine_train_dcur_kernel(const float* __restrict__ g, const float* __restrict__ cur,
+                                              const int* __restrict__ end_voxel, const float* __restrict__ vbound,
+                                              int pos_rel, const float* __restrict__ d_pe, int L,
+                                              const float* __restrict__ d_inp, long long R,
+                                              float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 3) return;
+    const long long r = i / 3;
+    const int c = (int)(i % 3);
+    float acc = g[i];
+    if (d_pe) {
+        float v = cur[i];
+        if (pos_rel) {
+            const float* vb = vbound + 6 * (size_t)end_voxel[r];
+            v = v - (vb[c] + vb[3 + c]) / 2.f;
+        }
+        const float* gr = d_pe + (size_t)r * (3 + 6 * L);
+        float e = gr[c];
+        float f = 1.f;
+        for (int o = 0; o < L; ++o) {
+            const float a = v * f;
+            e += f * (cosf(a) * gr[3 + 6 * o + c] - sinf(a) * gr[3 + 6 * o + 3 + c]);
+            f *= 2.f;
+        }
+        acc += e;
+    }
+    if (d_inp) acc += d_inp[6 * r + c];
+    out[i] = acc;
+}
+
+__global__ void lidf_add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 x = ((const f32x4*)a)[i];
+    const f32x4 y = ((const f32x4*)b)[i];
+    x[0] += y[0]; x[1] += y[1]; x[2] += y[2]; x[3] += y[3];
+    ((f32x4*)a)[i] = x;
+}
+
+__global__ void lidf_iota_kernel(int* __restrict__ p, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int)i;
+}
+
+extern "C" hipError_t lidf_launch_refine_train_goff(const float* g, const float* dir, float rs, long long R,
+                                                    float* goff, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_train_goff_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, g, dir, rs,
+                       R, goff);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_refine_train_dcur(const float* g, const float* cur, const int* end_voxel,
+                                                    const float* vbound, int pos_rel, const float* d_pe, int L,
+                                                    const float* d_inp, long long R, float* out, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_refine_train_dcur_kernel, dim3((unsigned)((3 * R + 255) / 256)), dim3(256), 0, st, g, cur,
+                       end_voxel, vbound, pos_rel, d_pe, L, d_inp, R, out);
+    return hipGetLastError();
+}
+// a[0:n] += b[0:n], n a multiple of 4, both 16-byte aligned
+extern "C" hipError_t lidf_launch_add_inplace(float* a, const float* b, long long n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a, b, n / 4);
+    return hipGetLastError();
+}
+extern "C" hipError_t lidf_launch_iota(int* p, long long n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+}

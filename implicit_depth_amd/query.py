@@ -1063,11 +1063,184 @@ def refine_perturb_noise(perturb_prob=0.8):
     return np.random.random() * (0.1 - 0.05) + 0.05
 
 
+class _RefineTrainFn(torch.autograd.Function):
+    """RefineNet.forward 'train' as ONE autograd node: lidf_refine_train_forward_f32 keeps what
+    lidf_refine_train_backward_f32 needs in one `act` buffer (weight streams of the step, the per-ray layer-1
+    table, per iteration the end voxels, PointNet rows / activations / arg rows, embed(pos) rows and the
+    decoder's activations); the backward returns the gradient of every PointNet2Stage / decoder parameter
+    (summed over the iterations inside the call), of pred_pos and of the per-ray features."""
+
+    @staticmethod
+    def forward(ctx, pred_pos, rayfeat, cfg, *params):
+        from .decoders import _decoder_struct
+        from .pointnet import _pn_struct_from
+        t = cfg["tensors"]
+        dev = pred_pos.device
+        R, P, V, Nv = pred_pos.shape[0], t["pair_vox"].shape[0], t["voxel_bound"].shape[0], t["valid_inp"].shape[0]
+        B, _, h, w = t["rgb_img"].shape
+        T, L_, Lv = cfg["forward_times"], cfg["multires"], cfg["multires_views"]
+        dec = cfg["offset_dec"]
+        npn = 12
+        pn_params, dec_params = params[:npn], params[npn:]
+        keep = []
+        pn = _pn_struct_from(pn_params, keep)
+        do = _decoder_struct(dec, keep, tensors=dict(zip(cfg["dec_names"], dec_params)))
+        L = _lib.lib()
+        npass = dec.n_iter if do.is_ief else 1
+        act = torch.empty((max(L.lidf_refine_train_act_bytes(R, Nv, V, L_, Lv, npass, T), 1),), dtype=torch.uint8,
+                          device=dev)
+        ws = torch.empty((max(L.lidf_refine_train_workspace_bytes(R, Nv, V, L_), 1),), dtype=torch.uint8, device=dev)
+        out = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
+        x = pred_pos.detach().contiguous()
+        rf = rayfeat.detach().contiguous()
+        cells = _cell_lookup(cfg["grid"], V, B, dev)
+
+        def args():
+            q = _lib.LidfRefineArgs()
+            q.n_rays, q.ray_dir, q.ray_bid, q.ray_flat = R, t["ray_dir"].data_ptr(), t["ray_bid"].data_ptr(), \
+                t["ray_flat"].data_ptr()
+            q.pred_pos, q.max_pair_id = x.data_ptr(), t["max_pair_id"].data_ptr()
+            q.pair_vox, q.n_pairs = t["pair_vox"].data_ptr(), P
+            q.n_vox, q.voxel_bound, q.voxel_bid = V, t["voxel_bound"].data_ptr(), t["voxel_bid"].data_ptr()
+            q.rgb_img, q.batch, q.height, q.width = t["rgb_img"].data_ptr(), B, h, w
+            q.rayfeat = rf.data_ptr()
+            q.n_valid, q.valid_inp, q.valid_vox = Nv, t["valid_inp"].data_ptr(), t["valid_vox"].data_ptr()
+            q.pnet, q.off = C.pointer(pn), C.pointer(do)
+            q.multires, q.multires_views = L_, Lv
+            q.pos_rel, q.pnet_pos_rel = int(bool(cfg["pos_rel"])), int(bool(cfg["pnet_pos_rel"]))
+            q.offset_range0, q.offset_range1 = float(cfg["offset_range"][0]), float(cfg["offset_range"][1])
+            q.pred_pos_out, q.end_voxel_id = out.data_ptr(), end_voxel.data_ptr()
+            q.workspace, q.workspace_bytes = ws.data_ptr(), ws.numel()
+            q.precision = PRECISIONS["f32"]
+            if cells is not None:
+                q.voxel_coord, q.cell_table = cells["coord"].data_ptr(), cells["table"].data_ptr()
+                q.grid_res, q.grid_xmin, q.grid_part = cells["res"], cells["xmin"], cells["part"]
+            return q
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_refine_train_forward_f32(C.byref(args()), T, _lib.ptr(act), act.numel(),
+                                                       _lib.current_stream(dev)))
+        ctx.cfg, ctx.args, ctx.keep, ctx.ws, ctx.cells = cfg, args, keep, ws, cells
+        ctx.mark_non_differentiable(end_voxel)
+        ctx.save_for_backward(x, rf, act, *params)   # (saved: an in-place update before backward raises)
+        return out, end_voxel
+
+    @staticmethod
+    def backward(ctx, g_pos, _g_end):
+        from .decoders import _decoder_struct
+        from .pointnet import _PN_FIELDS, _pn_struct_from
+        cfg = ctx.cfg
+        x, rf, act = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        npn = 12
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = [torch.empty(p.shape, **f32) for p in params]
+        gp = _lib.LidfPointNetGrads()
+        for i, f in enumerate(_PN_FIELDS):
+            setattr(gp, "w_" + f, grads[2 * i].data_ptr())
+            setattr(gp, "b_" + f, grads[2 * i + 1].data_ptr())
+        gd = _lib.LidfDecoderGrads()
+        _map = {"linear_1.weight": "w1", "linear_1.bias": "b1", "linear_2.weight": "w2", "linear_2.bias": "b2",
+                "linear_3.weight": "w3", "linear_3.bias": "b3", "linear_4.weight": "w4", "linear_4.bias": "b4",
+                "offset_enc.weight": "wenc", "offset_enc.bias": "benc"}
+        for name, gr in zip(cfg["dec_names"], grads[npn:]):
+            setattr(gd, _map[name], gr.data_ptr())
+        d_pos = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_rf = torch.empty_like(rf) if ctx.needs_input_grad[1] else None
+        g = g_pos.detach().contiguous().float()
+        # (the argument block is rebuilt from the SAVED tensors: same buffers as the forward's)
+        keep = []
+        pn = _pn_struct_from(params[:npn], keep)
+        do = _decoder_struct(cfg["offset_dec"], keep, tensors=dict(zip(cfg["dec_names"], params[npn:])))
+        q = ctx.args()
+        q.pnet, q.off = C.pointer(pn), C.pointer(do)
+        q.cell_table_ready = 1 if ctx.cells is not None else 0
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lidf_refine_train_backward_f32(
+                C.byref(q), cfg["forward_times"], _lib.ptr(act), act.numel(), _lib.ptr(g), _lib.ptr(d_pos),
+                _lib.ptr(d_rf), C.byref(gp), C.byref(gd), _lib.current_stream(dev)))
+        return (d_pos, d_rf, None) + tuple(gr if ctx.needs_input_grad[3 + i] else None for i, gr in enumerate(grads))
+
+
 def lidf_refine_train(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
                       voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
                       forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
-                      offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, perturb_noise=None):
+                      offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, perturb_noise=None, grid=None):
     """Differentiable RefineNet.forward (models/pipeline.py:922-1041, exp_type 'train'): the same
+    arguments as lidf_refine; gradients reach every parameter of pnet_model (PointNet2Stage) and
+    offset_dec (IEF / IMNet) — through the second and later iterations also via the refined position
+    (PointNet input, embed(pos) and the additive term, as in the reference's autograd graph) — and
+    feat_grid when it requires grad (RoIAlign backward). Stage 1 is frozen in train_refine.py:73, so
+    pred_pos / max_pair_id arrive detached (a pred_pos that requires grad receives its gradient all the same).
+
+    The whole step is two library calls (lidf_refine_train_forward_f32 / _backward_f32, one autograd node):
+    one multi-pack of every weight stream per step, the decoder in its factorised form (per-voxel / per-ray /
+    embed(pos) parts of layer 1; no [R, 334] row or input gradient is formed), parameter gradients summed
+    over the iterations inside the call, no torch op between the launches. Widths other than the shipped
+    ones (and decoders that are neither IEF nor IMNet of gf_dim 64) take the composed path
+    (_lidf_refine_train_composed: the modules' own autograd functions joined by torch ops).
+    perturb_noise: the scalar of refine_perturb_noise() — or None — applied in the first iteration
+    (pipeline.py:937). grid: as lidf_refine (the end voxels through the cell table).
+    Returns pred_pos_refine [R,3] (with grad) and the last end_voxel_id [R] i32."""
+    from .decoders import is_shipped
+    from .pointnet import _PN_ORDER, is_shipped as pnet_shipped
+    E, Ed = 3 + 6 * multires, 3 + 6 * multires_views
+    if not (is_shipped(offset_dec) and pnet_shipped(pnet_model) and feat_grid.shape[1] == 32
+            and multires > 0 and offset_dec.inp_dim == 256 + E + Ed):
+        return _lidf_refine_train_composed(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox,
+                                           voxel_bound, voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox,
+                                           pnet_model, offset_dec, forward_times, multires, multires_views,
+                                           roi_inp_bbox, offset_range, pos_rel, pnet_pos_rel, perturb_noise)
+    ray_pix, ray_bid = _as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid")
+    ray_flat, voxel_bid = _as_i32(ray_flat, "ray_flat"), _as_i32(voxel_bid, "voxel_bid")
+    pair_vox, valid_vox = _as_i32(pair_vox, "pair_vox"), _as_i32(valid_vox, "valid_vox")
+    ts = dict(ray_dir=ray_dir, ray_bid=ray_bid, ray_flat=ray_flat, max_pair_id=max_pair_id, pair_vox=pair_vox,
+              voxel_bound=voxel_bound, voxel_bid=voxel_bid, rgb_img=rgb_img, valid_inp=valid_inp, valid_vox=valid_vox)
+    _lib.require_cuda(pred_pos, feat_grid, *ts.values(), names=["pred_pos", "feat_grid"] + list(ts))
+    for n in ("ray_dir", "voxel_bound", "rgb_img", "valid_inp"):
+        _f32(ts[n], n)
+    _f32(pred_pos, "pred_pos")
+    if max_pair_id.dtype != torch.int64:
+        raise RuntimeError("max_pair_id must be int64")
+    R, V, Nv = ray_dir.shape[0], voxel_bound.shape[0], valid_inp.shape[0]
+    if (tuple(ray_dir.shape) != (R, 3) or tuple(pred_pos.shape) != (R, 3) or tuple(max_pair_id.shape) != (R,)
+            or tuple(ray_bid.shape) != (R,) or tuple(ray_flat.shape) != (R,)):
+        raise RuntimeError("ray_dir / pred_pos must be [R,3]; ray_bid / ray_flat / max_pair_id [R]")
+    if tuple(voxel_bound.shape) != (V, 6) or tuple(voxel_bid.shape) != (V,):
+        raise RuntimeError("voxel_bound / voxel_bid must be [V,6] / [V]")
+    if tuple(valid_inp.shape) != (Nv, 6) or tuple(valid_vox.shape) != (Nv,):
+        raise RuntimeError("valid_inp / valid_vox must be [Nv,6] / [Nv]")
+    if rgb_img.dim() != 4 or rgb_img.shape[1] != 3:
+        raise RuntimeError("rgb_img must be [B,3,h,w]")
+    if valid_inp.requires_grad:
+        raise RuntimeError("lidf_refine_train: valid_inp carries no gradient (the valid points are inputs of the "
+                           "frozen stage 1, trainers/train_refine.py:73)")
+    # per-ray [ROI | embed(dir)] rows: constants of the iterations (RoIAlign backward when feat_grid trains)
+    if torch.is_grad_enabled() and feat_grid.requires_grad:
+        rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    else:
+        rayfeat = ray_features(feat_grid.detach(), ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    cur = pred_pos
+    if perturb_noise is not None:
+        cur = cur + float(perturb_noise) * ray_dir
+    dec_names = [n for n, _ in offset_dec.named_parameters()]
+    params = [t for name in _PN_ORDER for t in (getattr(pnet_model, name).weight, getattr(pnet_model, name).bias)]
+    params += [p for _, p in offset_dec.named_parameters()]
+    cfg = dict(tensors={k: v.detach() for k, v in ts.items()}, forward_times=int(forward_times), multires=multires,
+               multires_views=multires_views, pos_rel=pos_rel, pnet_pos_rel=pnet_pos_rel, offset_range=offset_range,
+               offset_dec=offset_dec, dec_names=dec_names, grid=grid)
+    pos, end_voxel = _RefineTrainFn.apply(cur, rayfeat, cfg, *params)
+    return pos, end_voxel
+
+
+def _lidf_refine_train_composed(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair_vox, voxel_bound,
+                      voxel_bid, rgb_img, feat_grid, valid_inp, valid_vox, pnet_model, offset_dec,
+                      forward_times=2, multires=8, multires_views=4, roi_inp_bbox=8,
+                      offset_range=(-0.2, 0.2), pos_rel=False, pnet_pos_rel=True, perturb_noise=None):
+    """lidf_refine_train composed from the modules' own autograd functions (rounds 3-4; the path for widths
+    other than the shipped ones, and the definition tests/test_train_gpu.py compares the fused step with).
+    Differentiable RefineNet.forward (models/pipeline.py:922-1041, exp_type 'train'): the same
     arguments as lidf_refine; gradients reach every parameter of pnet_model (PointNet2Stage) and
     offset_dec (IEF / IMNet) — through the second and later iterations also via the refined position
     (PointNet input, embed(pos) and the additive term, as in the reference's autograd graph) — and

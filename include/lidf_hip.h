@@ -779,6 +779,44 @@ int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const in
                                float* d_inp, const LidfPointNetGrads* grads, void* workspace,
                                size_t workspace_bytes, lidf_stream_t stream);
 
+/* ---- Stage 2, one training step in two calls (ABI 8) --------------------------------------------
+ * RefineNet.forward with exp_type 'train' (models/pipeline.py:1032-1041: forward_times x get_pred_refine,
+ * :922-1030) and what loss.backward() derives for it (trainers/train_refine.py:393-399): gradients of every
+ * PointNet2Stage (pnet_model_refine) and decoder (offset_dec_refine, IEF or IMNet) parameter, of the
+ * per-ray features (RoIAlign of full_rgb_feat | embed(dir): optional) and of the incoming position
+ * (optional; stage 1 is frozen in train_refine.py:73, so it normally arrives detached).
+ *
+ * `args` is the argument block of lidf_refine_f32 (the train-only perturbation of :925-937 is the
+ * caller's: pred_pos = stage-1 pred_pos + noise * ray_dir); precision must be LIDF_PRECISION_F32,
+ * pnet_select NULL; packed / ray_l1 are not read; voxel_coord (optional) selects the cell-table end-voxel
+ * lookup; workspace >= lidf_refine_train_workspace_bytes; pred_pos_out [R,3] receives the refined
+ * position, end_voxel_id (optional) the last iteration's end voxels.
+ *
+ * What runs: one guarded-free multi-pack of every weight stream of both modules per step (forward AND
+ * backward launches read the streams the forward call left in `act`); per iteration the end voxel, the
+ * PointNet2Stage training forward, the decoder in its factorised form — layer 1 = W1[:, 0:128]
+ * vox_feat[end voxel] (one row per voxel) + W1[:, ROI | dir] rayfeat[r] (one row per ray, formed ONCE per
+ * step: the same in every iteration) + W1[:, embed(pos)] embed(pos) inside the register-chained kernel that
+ * keeps the activations — and the position update. The backward walks the iterations in reverse: chained
+ * input gradients, per-voxel segment sums of the layer-1 gradient (no [R,334] input gradient is formed:
+ * only its embed(pos) columns and the per-voxel sums are needed), PointNet2Stage backward, the adjoint of
+ * embed(pos) and of the PointNet rows of the predicted points; parameter gradients are accumulated over the
+ * iterations inside the call (buffers shaped like the parameters, overwritten). No torch op in between.
+ *
+ * act: lidf_refine_train_act_bytes(...) bytes, written by the forward, read by the backward (the
+ * parameters must not change in between). n_pass = off->n_iter for an IEF, 1 for an IMNet.
+ * backward: g_pos [R,3] = dL/d pred_pos_out; d_pred_pos [R,3] / d_rayfeat [R, 128 + 3+6*multires_views]
+ * optional outputs (NULL: not formed).                                                              */
+size_t lidf_refine_train_act_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox, int32_t multires,
+                                   int32_t multires_views, int32_t n_pass, int32_t forward_times);
+size_t lidf_refine_train_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox, int32_t multires);
+int lidf_refine_train_forward_f32(const LidfRefineArgs* args, int32_t forward_times, void* act,
+                                  size_t act_bytes, lidf_stream_t stream);
+int lidf_refine_train_backward_f32(const LidfRefineArgs* args, int32_t forward_times, const void* act,
+                                   size_t act_bytes, const float* g_pos, float* d_pred_pos, float* d_rayfeat,
+                                   const LidfPointNetGrads* pnet_grads, const LidfDecoderGrads* dec_grads,
+                                   lidf_stream_t stream);
+
 /* ---- Per-pair / per-ray tail of get_pred with its adjoint --------------------------------------
  * models/pipeline.py:437-454 for the training path (the inference path has it inside
  * lidf_query_f32): pair_pred_pos = dir t_enter + ((off (r1-r0) + r0) sqrt(3) part_size) dir, the

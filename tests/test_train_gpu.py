@@ -238,3 +238,76 @@ def test_refine_train_gradients_vs_oracle(cuda):
     assert (inf - got.detach()).abs().max().item() <= 2e-5
     with pytest.raises(RuntimeError, match="inference path"):
         lidf_refine(*args)       # autograd recording + trainable modules: refused, not silently detached
+
+
+@pytest.mark.parametrize("pos_rel,pnet_pos_rel,kind,use_grid", [(False, True, "IEF", False), (True, False, "IEF", True),
+                                                                (False, True, "IMNET", False)])
+def test_refine_train_fused_step_vs_composed(cuda, pos_rel, pnet_pos_rel, kind, use_grid):
+    """lidf_refine_train as two library calls (one autograd node: lidf_refine_train_forward_f32 / _backward_f32,
+    the decoder factorised, parameter gradients summed over the iterations inside the call) against the same
+    step composed from the modules' own autograd functions joined by torch ops (rounds 3-4, itself checked
+    against the oracle's autograd above): positions, end voxels, the gradient of every PointNet2Stage / decoder
+    parameter, of the incoming position and of the feature map (RoIAlign backward behind the per-ray layer-1
+    table); three iterations; both position types; the end voxels through the cell table; and run to run the
+    fused step's gradients are bit-identical."""
+    from implicit_depth_amd.query import (_lidf_refine_train_composed, get_occ_vox_bound, lidf_refine_train)
+    from util import make_module, make_pointnet
+    g = torch.Generator().manual_seed(17)
+    B, h, w = 2, 20, 24
+    # occupied voxels from random points (so that the cell table of get_occ_vox_bound applies)
+    pts = torch.rand(600, 3, generator=g) * torch.tensor([1.6, 1.6, 1.6]) + torch.tensor([-0.8, -0.8, 0.2])
+    pb = torch.randint(0, B, (600,), generator=g).int()
+    occ = get_occ_vox_bound(pts.to(cuda), pb.to(cuda), B, res=8)
+    vb, vbid = occ["voxel_bound"], occ["occ_vox_bid"].int().contiguous()
+    V = vb.shape[0]
+    R = 700
+    bid = torch.randint(0, B, (R,), generator=g)
+    ctr = ((vb[:, :3] + vb[:, 3:]) / 2).cpu()
+    own = [torch.nonzero(vbid.cpu() == b)[:, 0] for b in range(B)]
+    pick = torch.stack([own[int(b)][torch.randint(0, own[int(b)].numel(), (1,), generator=g)][0] for b in bid])
+    pos0 = ctr[pick] + (torch.rand(R, 3, generator=g) - 0.5) * 0.3
+    ray_dir = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=1)
+    flat = torch.randint(0, h * w, (R,), generator=g)
+    ray_pix = torch.stack((flat % w, flat // w), 1).int()
+    P = 900
+    pair_vox = torch.randint(0, V, (P,), generator=g).int()
+    mid = torch.randint(0, P + 1, (R,), generator=g)
+    rgb = torch.randn(B, 3, h, w, generator=g)
+    feat = torch.randn(B, 32, h, w, generator=g)
+    valid_inp = torch.randn(500, 6, generator=g) * 0.2
+    valid_vox = torch.randint(0, V, (500,), generator=g).int()
+    wgt = torch.randn(R, 3, generator=g).to(cuda)
+    pnet_p = orc.init_pointnet(5, 1.5)
+    dec_p = orc.randomize_biases(orc.init_decoder(kind, 334, 77, 5.0), 78)
+
+    def run(fn, **kw):
+        pnet, dec = make_pointnet(pnet_p, cuda).train(), make_module(kind, dec_p, 334, cuda).train()
+        pp = pos0.to(cuda).requires_grad_(True)
+        fg = feat.to(cuda).requires_grad_(True)
+        got, ev = fn(ray_dir.to(cuda), ray_pix.to(cuda), bid.int().to(cuda), flat.int().to(cuda), pp, mid.to(cuda),
+                     pair_vox.to(cuda), vb, vbid, rgb.to(cuda), fg, valid_inp.to(cuda), valid_vox.to(cuda), pnet, dec,
+                     forward_times=3, pos_rel=pos_rel, pnet_pos_rel=pnet_pos_rel, perturb_noise=0.03, **kw)
+        (got * wgt).sum().backward()
+        grads = {"pred_pos": pp.grad, "feat_grid": fg.grad}
+        for name, mod in (("pnet", pnet), ("dec", dec)):
+            for k, p in mod.named_parameters():
+                assert p.grad is not None, k
+                grads[name + "." + k] = p.grad
+        return got.detach(), ev, grads
+
+    ref_pos, ref_ev, ref_g = run(_lidf_refine_train_composed)
+    got_pos, got_ev, got_g = run(lidf_refine_train, grid=occ if use_grid else None)
+    assert torch.equal(got_ev, ref_ev)
+    assert (got_pos - ref_pos).abs().max().item() <= 2e-5
+    for k, gr in ref_g.items():
+        err = (got_g[k] - gr).abs().max().item()
+        assert err <= 3e-4 * max(gr.abs().max().item(), 1e-3), (k, err, gr.abs().max().item())
+    again_pos, _, again_g = run(lidf_refine_train, grid=occ if use_grid else None)
+    assert torch.equal(again_pos, got_pos)
+    for k in got_g:
+        # (float atomics remain in the RoIAlign backward's border taps and in the PointNet backward's per-voxel
+        # row sums — lidf_hip.h —: everything downstream of the latter is equal to rounding, not bit for bit)
+        if k.startswith("dec."):
+            assert torch.equal(again_g[k], got_g[k]), k
+        else:
+            assert (again_g[k] - got_g[k]).abs().max().item() <= 1e-5 * max(got_g[k].abs().max().item(), 1e-3), k
