@@ -3006,12 +3006,8 @@ static PnetTrainWs pnet_train_ws(int64_t n, int64_t v) {
     return w;
 }
 
-LIDF_API size_t lidf_pointnet_train_act_floats(int64_t n_pts, int64_t n_vox) {
-    return pnet_act(n_pts, n_vox).total;
-}
-LIDF_API size_t lidf_pointnet_train_workspace_bytes(int64_t n_pts, int64_t n_vox) {
-    return pnet_train_ws(n_pts, n_vox).total;
-}
+// (lidf_pointnet_train_act_floats / _workspace_bytes: lidf_api_pointnet_train.inc — the larger of this path's and
+// the training chains' needs)
 
 // forward with the rows kept: layer by layer through lidf_linear_kernel (mode 0: pack and run, 2: streams packed
 // earlier), then the arg row of every pooled entry
@@ -3037,7 +3033,7 @@ static int pointnet_train_forward_impl(const LidfPointNet* w, const float* inp, 
     return LIDF_OK;
 }
 
-LIDF_API int lidf_pointnet_forward_train_f32(const LidfPointNet* w, const float* inp,
+static int pointnet_forward_train_layers(const LidfPointNet* w, const float* inp,
                                                const int32_t* vox, int64_t n, int64_t n_vox,
                                                float* out, float* act, void* workspace,
                                                size_t workspace_bytes, lidf_stream_t stream) {
@@ -3148,7 +3144,7 @@ static int pointnet_backward_impl(const LidfPointNet* w, const float* inp, const
 #define PNET_BWD_SLOTS 7
 static const int PNET_BWD_SLOT_K[PNET_BWD_SLOTS] = {128, 128, 128, 128, 64, 64, 32};   // contraction lengths, in launch order
 
-LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const int32_t* vox,
+static int pointnet_backward_layers(const LidfPointNet* w, const float* inp, const int32_t* vox,
                                           int64_t n, int64_t n_vox, const float* act,
                                           const float* g_out, float* d_inp,
                                           const LidfPointNetGrads* g, void* workspace,
@@ -3169,4 +3165,5 @@ LIDF_API int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp,
                                   0, cus, st);
 }
 
+#include "lidf_api_pointnet_train.inc"
 #include "lidf_api_refine_train.inc"

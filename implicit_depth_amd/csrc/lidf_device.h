@@ -71,7 +71,8 @@ enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_
        LIDF_MODE_TRAIN = 5,     // rows mode (stream of LIDF_MODE_ROWS) that keeps the activations
        LIDF_MODE_ROWS_GATHER = 6,    // rows mode whose layer-1 accumulators start from gathered rows
        LIDF_MODE_PNET_CHAIN = 7,     // pack jobs only: the per-point chain stream of a PointNet2Stage (PN_* below)
-       LIDF_MODE_IEF16 = 8 };        // pack jobs only: the stage-2 decoder's 16 x 16 x 4 stream (lidf_ief16.hip)
+       LIDF_MODE_IEF16 = 8,          // pack jobs only: the stage-2 decoder's 16 x 16 x 4 stream (lidf_ief16.hip)
+       LIDF_MODE_PNET_BWD = 9 };     // pack jobs only: the backward chains' stream of a PointNet2Stage (PNB_* below)
 #define IEF16_PASS_QUADS 168   // 2 + 1 bias quads, 4 u quads, 128 layer-2 quads, 32 layer-3 quads, 1 padding quad
 #define IEF16_AUX_FLOATS 72    // w4 [64] | b4 [1] (+ padding)
 
@@ -158,6 +159,14 @@ struct PackJobs {
 struct PnetW {
     const float *w_p1, *b_p1, *w_p2, *b_p2, *w_p3, *w_p4, *b_p4;
 };
+// ---- stream of the backward chains (lidf_pointnet_train.hip): transposed weights in the same fragment order
+//   A  64 quads  W4^T: dz4[o] += W4[k][o] dz5[k], quad = 16 T + kq (T: tile of o, kq over the 128 features k)
+//      32 quads  W3[:, 64:]^T: df2[o] += W3[k][64 + o] dz4[k], quad = 16 t + kq
+//   B   8 quads  W2^T: dz1[o] += W2[k][o] dz2[k] (kq over the 64 features k)
+//       4 quads  W1^T padded to 32 rows: d inp[o] += W1[k][o] dz1[k], o < 6
+//       4 padding quads
+#define PNB_A_QUADS 96
+#define PNB_B_QUADS 16
 #ifdef __HIPCC__
 __device__ __forceinline__ int pn_feature(int s, int half) {
     const int T = s >> 4, r = s & 15;
@@ -187,6 +196,27 @@ __device__ __forceinline__ float pn_stream_value(const PnetW& w, int e) {
         const int T = quad / 17, kq = quad % 17, s = 4 * kq + jj, out = 32 * T + c32;
         if (s < 64) v = w.w_p4[out * 128 + pn_feature(s, half)];
         else if (s == 64 && half == 0) v = w.b_p4[out];
+    }
+    return v;
+}
+// element e of the backward chains' stream ((PNB_A_QUADS + PNB_B_QUADS) * 256 floats)
+__device__ __forceinline__ float pn_bwd_stream_value(const PnetW& w, int e) {
+    const int quad = e / 256;
+    const int lane = (e % 256) / 4, jj = e & 3;
+    const int half = lane >> 5, c32 = lane & 31;
+    float v = 0.f;
+    if (quad < 64) {
+        const int T = quad / 16, kq = quad % 16;
+        v = w.w_p4[pn_feature(4 * kq + jj, half) * 128 + 32 * T + c32];
+    } else if (quad < 96) {
+        const int q = quad - 64, t = q / 16, kq = q % 16;
+        v = w.w_p3[pn_feature(4 * kq + jj, half) * 128 + 64 + 32 * t + c32];
+    } else if (quad < 104) {
+        const int kq = quad - 96;
+        v = w.w_p2[pn_feature(4 * kq + jj, half) * 32 + c32];
+    } else if (quad < 108) {
+        const int kq = quad - 104;
+        if (c32 < 6) v = w.w_p1[pn_feature(4 * kq + jj, half) * 6 + c32];
     }
     return v;
 }

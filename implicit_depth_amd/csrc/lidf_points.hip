@@ -179,6 +179,11 @@ __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& n
         if (e < lay.total) stream[e] = pn_stream_value(w, e);
         return;
     }
+    if (lay.mode == LIDF_MODE_PNET_BWD) {     // its backward chains' stream (same fields of net0)
+        const PnetW w = {net0.w1, net0.b1, net0.w2, net0.b2, net0.w3, net0.b3, net0.w4};
+        if (e < lay.total) stream[e] = pn_bwd_stream_value(w, e);
+        return;
+    }
     if (lay.mode == LIDF_MODE_IEF16) {
         if (e < lay.total) stream[e] = ief16_stream_value(net0, m, e);
         if (e < IEF16_AUX_FLOATS)

@@ -1423,6 +1423,14 @@ extern "C" size_t lidf_sort_idx_ws_bytes(long long P, long long V) {
     const SegPlan s = seg_plan(P, V);
     return s.cnt;   // hist | scanned | sums | perm
 }
+// where lidf_launch_sort_idx leaves its scan inside `ws`: scanned[v * nblk] = first sorted position of index v
+// (the PointNet's training chains turn it into per-voxel row ranges of their sorted buffers)
+extern "C" void lidf_sort_idx_layout(long long P, long long V, size_t* scanned_off, int* nblk, size_t* perm_off) {
+    const SegPlan s = seg_plan(P, V);
+    *scanned_off = s.scanned;
+    *nblk = (int)s.nblk;
+    *perm_off = s.perm;
+}
 extern "C" hipError_t lidf_launch_sort_idx(const int* idx, long long P, const int* n_dev, long long V,
                                            void* ws, const int** perm_out, const int** n_perm_out,
                                            hipStream_t st) {

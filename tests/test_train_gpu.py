@@ -298,7 +298,7 @@ def test_refine_train_fused_step_vs_composed(cuda, pos_rel, pnet_pos_rel, kind, 
     ref_pos, ref_ev, ref_g = run(_lidf_refine_train_composed)
     got_pos, got_ev, got_g = run(lidf_refine_train, grid=occ if use_grid else None)
     assert torch.equal(got_ev, ref_ev)
-    assert (got_pos - ref_pos).abs().max().item() <= 2e-5
+    assert (got_pos - ref_pos).abs().max().item() <= TOL     # (three chained iterations, factorised vs materialised layer 1)
     for k, gr in ref_g.items():
         err = (got_g[k] - gr).abs().max().item()
         assert err <= 3e-4 * max(gr.abs().max().item(), 1e-3), (k, err, gr.abs().max().item())
