@@ -119,6 +119,10 @@ hipError_t lidf_launch_pointnet_chain(int, const float*, const float*, const int
 size_t lidf_pointnet_pool_scratch_bytes(long long);
 hipError_t lidf_launch_dgrad_chain(const float*, const float*, const float*, const unsigned*,
                                    const unsigned*, long long, float, float*, float*, int, float*, int, hipStream_t);
+size_t lidf_dgrad_stream_bytes(void);
+hipError_t lidf_launch_pack_dgrad(const float*, const float*, float*, hipStream_t);
+hipError_t lidf_launch_pnet_gather_segsum(const float*, const int*, long long, const int*, const int*, long long,
+                                          long long, float*, float*, hipStream_t);
 hipError_t lidf_launch_l4_backward(const float*, const float*, const float*, float, long long, float*,
                                    float*, float*, float*, hipStream_t);
 hipError_t lidf_launch_ief_tail(const float*, const float*, const float*, int, const float*,
@@ -2776,6 +2780,13 @@ struct QdecBwd {
     float* d_pe;           // optional [P, E2]: dL/d pe = S W1[:, 256 : 256 + E2]
     float *s_dvox, *s_dpe; // stream slots of the transposed launches (d_vox_feat, d_pe); NULL: the workspace's
     int pack_mode;         // of those two launches: 0 pack and run, 2 packed earlier
+    const float* s_dgrad;  // the chained input-gradient launch's stream packed earlier (NULL: packed here, once)
+    // per-voxel sums of S through a grouping of the pairs that exists already (stage 2: the PointNet's sort of its
+    // points, whose rows row0.. are the rays' predicted points): perm / vstart / first of lidf_pointnet_train.hip,
+    // n = rows of that sort, partial = its scratch. NULL: the pairs are sorted here (lidf_launch_seg_sum_idx).
+    const int *ss_perm, *ss_vstart, *ss_first;
+    long long ss_row0, ss_n;
+    float* ss_partial;
 };
 static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, const float* passes, const float* pre,
                               const float* g_out, float* d_vox_feat, float* d_rayfeat, int accumulate_inputs,
@@ -2798,6 +2809,12 @@ static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, con
     float* small = (float*)(ws + w.small);
     CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
     CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
+    // W3^T | W2^T of the chained input-gradient launches: the same stream for every pass
+    const float* dgs = o.s_dgrad;
+    if (!dgs) {
+        CHECK_HIP(lidf_launch_pack_dgrad(dec->w3, dec->w2, sbuf, st));
+        dgs = sbuf;
+    }
     for (int k = npass - 1; k >= 0; --k) {
         const float* h1 = passes + (size_t)k * qact_pass(P);
         const float* h2 = h1 + (size_t)P * LIDF_H1;
@@ -2819,8 +2836,8 @@ static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, con
         }
         const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
         float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, P), act_m1(h1, P), P, 0.02f, dz2, dz1k,
-                                          first_pass_short ? 1 : 0, sbuf, cus, st));
+        CHECK_HIP(lidf_launch_dgrad_chain(nullptr, nullptr, dz3, act_m2(h1, P), act_m1(h1, P), P, 0.02f, dz2, dz1k,
+                                          first_pass_short ? 1 : 0, (float*)dgs, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, P, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
         if (!first_pass_short)
             CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->is_ief ? dec->w1 + D : nullptr, ld1, dec->wenc,
@@ -2837,8 +2854,12 @@ static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, con
         CHECK_HIP(lidf_launch_ief_first_pass(small + 256, small, dec->init_offset, dec->w1 + D, ld1,
                                              dec->wenc, dec->benc, grads->w1 + D, grads->wenc,
                                              grads->benc, st));
-    CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
-                                      w.seg_bytes, st));
+    if (o.ss_perm)
+        CHECK_HIP(lidf_launch_pnet_gather_segsum(S, o.ss_perm, o.ss_row0, o.ss_vstart, o.ss_first, V, o.ss_n,
+                                                 o.ss_partial, dvox, st));
+    else
+        CHECK_HIP(lidf_launch_seg_sum_idx(S, q->pair_vox, P, V, dvox, w.seg_bytes ? ws + w.seg : nullptr,
+                                          w.seg_bytes, st));
     // voxel part: voxpart[v] = W1[:, 0:128] vox_feat[v] + b1 (+ c)
     CHECK_HIP(lidf_launch_wgrad(dvox, LIDF_H1, LIDF_H1, q->vox_feat, 128, 128, V, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
     if (!o.S_keep) {

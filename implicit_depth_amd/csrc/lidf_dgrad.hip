@@ -218,7 +218,8 @@ extern "C" hipError_t lidf_launch_dgrad_chain(const float* w3, const float* w2, 
                                               float slope, float* dz2, float* dz1, int accumulate,
                                               float* stream, int cus, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lidf_pack_dgrad_kernel, dim3(DG_QUADS), dim3(256), 0, st, w3, w2, stream);
+    // (w3 == NULL: `stream` was packed earlier by lidf_launch_pack_dgrad — once per backward call, not per pass)
+    if (w3) hipLaunchKernelGGL(lidf_pack_dgrad_kernel, dim3(DG_QUADS), dim3(256), 0, st, w3, w2, stream);
     DgradArgs a;
     a.stream = stream; a.dz3 = dz3; a.m2 = m2; a.m1 = m1; a.dz2 = dz2; a.dz1 = dz1; a.n = n;
     a.slope = slope;
@@ -228,5 +229,11 @@ extern "C" hipError_t lidf_launch_dgrad_chain(const float* w3, const float* w2, 
         hipLaunchKernelGGL(lidf_dgrad_chain_kernel<true>, dim3((unsigned)g), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(lidf_dgrad_chain_kernel<false>, dim3((unsigned)g), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+extern "C" size_t lidf_dgrad_stream_bytes(void) { return (size_t)DG_QUADS * 1024; }
+extern "C" hipError_t lidf_launch_pack_dgrad(const float* w3, const float* w2, float* stream, hipStream_t st) {
+    hipLaunchKernelGGL(lidf_pack_dgrad_kernel, dim3(DG_QUADS), dim3(256), 0, st, w3, w2, stream);
     return hipGetLastError();
 }

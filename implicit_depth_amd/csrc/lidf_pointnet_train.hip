@@ -611,6 +611,62 @@ __global__ void __launch_bounds__(64) lidf_pnet_chunk_final_kernel(const float* 
     *(f32x4*)(out + (size_t)v * 128 + 4 * c4) = s;
 }
 
+// The same chunked sums for rows that are GATHERED through the sort: out[v, 0:256] = sum of S[perm[i] - row0, :] over
+// the sorted rows i of voxel v with perm[i] >= row0 (stage 2's training step: S = dL/d(layer-1 pre-activation) of the
+// decoder, one row per ray; the rays' predicted points are rows row0.. of the PointNet's input, so the sort of
+// the PointNet's points already groups the rays by their end voxel — no second sort, fixed summation order).
+__global__ void __launch_bounds__(256) lidf_pnet_gather_chunk_sum_kernel(const float* __restrict__ S,
+                                                                         const int* __restrict__ perm, int row0,
+                                                                         const int* __restrict__ vstart,
+                                                                         const int* __restrict__ first, int V,
+                                                                         float* __restrict__ partial) {
+    __shared__ f32x4 red[4][64];
+    const int c = blockIdx.x;
+    if (c >= first[V]) return;
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    const int v = lo;
+    const long long beg = (long long)vstart[v] + (long long)(c - first[v]) * PNT_CH;
+    long long end = vstart[v + 1];
+    if (end > beg + PNT_CH) end = beg + PNT_CH;
+    const int rl = threadIdx.x >> 6, c4 = threadIdx.x & 63;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = beg + rl; i < end; i += 16) {
+        int p[4];
+        f32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long ii = i + 4 * j;
+            p[j] = ii < end ? perm[ii] - row0 : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            x[j] = p[j] >= 0 ? *(const f32x4*)(S + (size_t)p[j] * 256 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += x[j];
+    }
+    red[rl][c4] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        f32x4 s = red[0][c4];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s += red[k][c4];
+        *(f32x4*)(partial + (size_t)c * 256 + 4 * c4) = s;
+    }
+}
+__global__ void __launch_bounds__(64) lidf_pnet_chunk_final256_kernel(const float* __restrict__ partial,
+                                                                      const int* __restrict__ first,
+                                                                      float* __restrict__ out) {
+    const int v = blockIdx.x, c4 = threadIdx.x;
+    const int c0 = first[v], c1 = first[v + 1];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c0; c < c1; ++c) s += *(const f32x4*)(partial + (size_t)c * 256 + 4 * c4);
+    *(f32x4*)(out + (size_t)v * 256 + 4 * c4) = s;
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------
 static long long pnt_grid(long long n, int cus) {
     const long long ntile = (n + 127) / 128;
@@ -692,5 +748,18 @@ extern "C" hipError_t lidf_launch_pnet_segsum(const float* rows, const int* vsta
                        partial);
     hipLaunchKernelGGL(lidf_pnet_chunk_final_kernel, dim3((unsigned)((V + 1) / 2)), dim3(64), 0, st, partial, first,
                        (int)V, out);
+    return hipGetLastError();
+}
+
+// out[v, 0:256] = sum over the sorted rows i of voxel v with perm[i] >= row0 of S[perm[i] - row0, 0:256];
+// partial: (n / PNT_CH + V + 1) x 256 floats
+extern "C" hipError_t lidf_launch_pnet_gather_segsum(const float* S, const int* perm, long long row0,
+                                                     const int* vstart, const int* first, long long V, long long n,
+                                                     float* partial, float* out, hipStream_t st) {
+    if (V <= 0) return hipSuccess;
+    const long long maxc = n / PNT_CH + V + 1;
+    hipLaunchKernelGGL(lidf_pnet_gather_chunk_sum_kernel, dim3((unsigned)maxc), dim3(256), 0, st, S, perm, (int)row0,
+                       vstart, first, (int)V, partial);
+    hipLaunchKernelGGL(lidf_pnet_chunk_final256_kernel, dim3((unsigned)V), dim3(64), 0, st, partial, first, out);
     return hipGetLastError();
 }

@@ -387,13 +387,19 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
         const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
+        // per-voxel operands (a frame has 50-150 occupied voxels, a training batch a few hundred rows): ONE slice
+        // per block of C, added straight into C — every element receives exactly one contribution, so the
+        // result is as deterministic as the slab path's, without the reduce launch that cost as much as the
+        // product itself (10 + 5 us per per-voxel layer, a dozen of them per training step)
+        const bool one_slice = g_wgrad_scratch && n <= 1024;
+        if (one_slice) splits = 1;
         const bool half_m = M <= 64 && N <= 128 && mb == 1 && nb == 1;   // 64 x 128 block (layer 3)
         const int rs = half_m ? 16 : 8;
         w.rows_per_split = ((n + splits - 1) / splits + rs - 1) / rs * rs;
         const long long sp = (n + w.rows_per_split - 1) / w.rows_per_split;
         const size_t slice_bytes = (size_t)w.rows_per_split * (size_t)(lda > ldb ? lda : ldb) * 4;
         const size_t need = (size_t)sp * mb * nb * (128 * 256 + 128);
-        w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats) ? g_wgrad_scratch : nullptr;
+        w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats && !one_slice) ? g_wgrad_scratch : nullptr;
         if (slice_bytes < 0x7fffffffULL) {
             if (half_m)
                 hipLaunchKernelGGL((lidf_wgrad2_kernel<false, true>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);

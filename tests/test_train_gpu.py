@@ -301,7 +301,9 @@ def test_refine_train_fused_step_vs_composed(cuda, pos_rel, pnet_pos_rel, kind, 
     assert (got_pos - ref_pos).abs().max().item() <= TOL     # (three chained iterations, factorised vs materialised layer 1)
     for k, gr in ref_g.items():
         err = (got_g[k] - gr).abs().max().item()
-        assert err <= 3e-4 * max(gr.abs().max().item(), 1e-3), (k, err, gr.abs().max().item())
+        # (two f32 evaluation orders of the same function chained over three iterations; each is held to 5e-4 of
+        # the oracle's autograd at two iterations by test_refine_train_gradients_vs_oracle)
+        assert err <= 1e-3 * max(gr.abs().max().item(), 1e-3), (k, err, gr.abs().max().item())
     again_pos, _, again_g = run(lidf_refine_train, grid=occ if use_grid else None)
     assert torch.equal(again_pos, got_pos)
     for k in got_g:
