@@ -1378,8 +1378,45 @@ __global__ void lidf_scan_final_kernel(const int* __restrict__ in, long long n,
     if (total_out && n <= 0 && blockIdx.x == 0 && threadIdx.x == 0) *total_out = 0;
 }
 
+// A short list in ONE launch: a single workgroup walks it 1024 entries at a time with a running carry
+// (out[i] = sum of in[0..i), out[n] = the total). The three-launch form costs 14 us of dispatch whatever n is;
+// up to SCAN_SMALL entries one workgroup is faster than that.
+#define SCAN_SMALL 32768
+__global__ void __launch_bounds__(1024) lidf_scan_small_kernel(const int* __restrict__ in, int n,
+                                                               int* __restrict__ out) {
+    __shared__ int s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int b = 0; b < n; b += 1024) {
+        const int k = b + threadIdx.x;
+        const int c = k < n ? in[k] : 0;
+        int inc = c;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int o = __shfl_up(inc, sft);
+            if (lane >= sft) inc += o;
+        }
+        __syncthreads();
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int wpre = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_w[w];
+            wpre += w < wave ? t : 0;
+            tot += t;
+        }
+        if (k < n) out[k] = carry + wpre + inc - c;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
 extern "C" hipError_t lidf_launch_scan(const int* in, long long n, int* out, int* sums,
                                        hipStream_t st) {
+    if (n > 0 && n <= SCAN_SMALL) {
+        hipLaunchKernelGGL(lidf_scan_small_kernel, dim3(1), dim3(1024), 0, st, in, (int)n, out);
+        return hipGetLastError();
+    }
     if (n <= 0) {
         hipLaunchKernelGGL(lidf_scan_final_kernel, dim3(1), dim3(256), 0, st, in, (long long)0,
                            sums, out, (const int*)nullptr, (int*)nullptr);

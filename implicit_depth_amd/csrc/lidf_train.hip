@@ -391,7 +391,7 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
         // per block of C, added straight into C — every element receives exactly one contribution, so the
         // result is as deterministic as the slab path's, without the reduce launch that cost as much as the
         // product itself (10 + 5 us per per-voxel layer, a dozen of them per training step)
-        const bool one_slice = g_wgrad_scratch && n <= 1024;
+        const bool one_slice = g_wgrad_scratch && n <= 320;   // (measured: 729 rows in one slice 60 us, in 12 slices + reduce 35)
         if (one_slice) splits = 1;
         const bool half_m = M <= 64 && N <= 128 && mb == 1 && nb == 1;   // 64 x 128 block (layer 3)
         const int rs = half_m ? 16 : 8;
@@ -635,6 +635,35 @@ __global__ void lidf_l4_finish_kernel(const float* __restrict__ sums, float* __r
     if (c < 64) dw4[c] += sums[c];
     if (c == 64) db4[0] += sums[64];
 }
+// lidf_colsum_reduce_kernel (ncol = 65) + lidf_l4_finish_kernel in one launch: the column's sum over the G
+// partial vectors, in the same fixed order, added straight into d w4 / d b4
+__global__ void __launch_bounds__(256) lidf_l4_reduce_finish_kernel(const float* __restrict__ part, int G,
+                                                                    float* __restrict__ dw4,
+                                                                    float* __restrict__ db4) {
+    __shared__ float red[16][16];
+    const int k = threadIdx.x >> 4, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < 65) {
+        int g = k;
+        for (; g + 112 < G; g += 128) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = part[(size_t)(g + 16 * j) * 65 + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += x[j];
+        }
+        for (; g < G; g += 16) s += part[(size_t)g * 65 + c];
+    }
+    red[k][cl] = s;
+    __syncthreads();
+    if (k == 0 && c < 65) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][cl];
+        if (c < 64) dw4[c] += t;
+        else db4[0] += t;
+    }
+}
 
 // sums = [A | B] (256 each): d W1[c, D+j] += wenc[j] A[c] + benc[j] B[c] ; d wenc[j] += W1[:, D+j] . A ;
 // d benc[j] += W1[:, D+j] . B      (one workgroup of 256 threads)
@@ -702,8 +731,8 @@ extern "C" hipError_t lidf_launch_l4_backward(const float* goff, const float* h3
     float* sums = scratch + (size_t)G * 65;
     hipLaunchKernelGGL(lidf_l4_backward_kernel, dim3(G), dim3(256), 0, st, goff, h3, w4, slope, n,
                        rows, dz3, scratch);
-    hipLaunchKernelGGL(lidf_colsum_reduce_kernel, dim3(5), dim3(256), 0, st, scratch, G, 65, sums);
-    hipLaunchKernelGGL(lidf_l4_finish_kernel, dim3(1), dim3(128), 0, st, sums, dw4, db4);
+    (void)sums;
+    hipLaunchKernelGGL(lidf_l4_reduce_finish_kernel, dim3(5), dim3(256), 0, st, scratch, G, dw4, db4);
     return hipGetLastError();
 }
 
