@@ -2640,7 +2640,7 @@ static int check_qtrain(const LidfQueryTrainArgs* q) {
 // packed earlier. parts: 1 = voxpart, 2 = raypart, 4 = chain (which of the three launches to run).
 static int qdec_forward_impl(const LidfQueryTrainArgs* q, int E2, float* out, float* voxpart, float* raypart,
                              float* passes, float* pre, float* s_vox, float* s_ray, char* s_chain, int cus,
-                             hipStream_t st, int pack_mode = 0, int parts = 7) {
+                             hipStream_t st, int pack_mode = 0, int parts = 7, int pe_ld = 0) {
     int rc;
     const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
     const LidfDecoder* dec = q->dec;
@@ -2663,8 +2663,10 @@ static int qdec_forward_impl(const LidfQueryTrainArgs* q, int E2, float* out, fl
     // layer 1 = W1[:, pe columns] PE + voxpart[voxel] + raypart[ray] (+ u * off), then the chain,
     // in registers; every pass's H1 | H2 | H3 | offset-in is kept
     if (parts & 4) {
-        if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, E2, P, q->pair_vox, q->pair_ray,
-                                  voxpart, raypart, passes, pre, out, s_chain, cus, st, LIDF_MODE_TRAIN, pack_mode)))
+        // (pe_ld: row stride of `pe` when its rows are a column window of wider rows)
+        if ((rc = run_chain_train(dec, D, rows_map(E2, 256, 0, 0, 0), q->pe, pe_ld ? pe_ld : E2, P, q->pair_vox,
+                                  q->pair_ray, voxpart, raypart, passes, pre, out, s_chain, cus, st, LIDF_MODE_TRAIN,
+                                  pack_mode)))
             return rc;
     }
     return LIDF_OK;
@@ -2781,6 +2783,12 @@ struct QdecBwd {
     float *s_dvox, *s_dpe; // stream slots of the transposed launches (d_vox_feat, d_pe); NULL: the workspace's
     int pack_mode;         // of those two launches: 0 pack and run, 2 packed earlier
     const float* s_dgrad;  // the chained input-gradient launch's stream packed earlier (NULL: packed here, once)
+    bool goff_ready;       // the caller left dL/d(pre-activation of the last pass) in the workspace's goff (g_out unused)
+    // the layer-1 weight gradient over the per-pair operand on WIDER rows than `pe`: l1rows [P, l1_cols] (row stride
+    // l1_ld) meet W1's columns [l1_c0, l1_c0 + l1_cols) — stage 2 keeps [ROI | embed(pos) | embed(dir)] rows in W1's
+    // own column order, so that one product covers all three and no sum of S over the iterations is needed
+    const float* l1rows;
+    int l1_ld, l1_cols, l1_c0;
     // per-voxel sums of S through a grouping of the pairs that exists already (stage 2: the PointNet's sort of its
     // points, whose rows row0.. are the rays' predicted points): perm / vstart / first of lidf_pointnet_train.hip,
     // n = rows of that sort, partial = its scratch. NULL: the pairs are sorted here (lidf_launch_seg_sum_idx).
@@ -2808,7 +2816,7 @@ static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, con
     float* dray = (float*)(ws + w.dray);
     float* small = (float*)(ws + w.small);
     CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
-    CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
+    if (!o.goff_ready) CHECK_HIP(lidf_launch_out_act(pre, P, dec->use_sigmoid, nullptr, g_out, goff, st));
     // W3^T | W2^T of the chained input-gradient launches: the same stream for every pass
     const float* dgs = o.s_dgrad;
     if (!dgs) {
@@ -2848,8 +2856,12 @@ static int qdec_backward_impl(const LidfQueryTrainArgs* q, const QdecBwd& o, con
     // layer 1, the pass-independent operands: S = sum over passes of dZ1
     const bool short_first = dec->is_ief && npass > 1;
     // (column sums of S through the weight-gradient launch's bias path when the first pass needs them)
-    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1,
-                                short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    if (o.l1rows)
+        CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, o.l1rows, o.l1_ld, o.l1_cols, P, grads->w1 + o.l1_c0, ld1,
+                                    short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
+    else
+        CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, q->pe, E2, E2, P, grads->w1 + 256, ld1,
+                                    short_first ? small + 256 : nullptr, wgs, WG_SCRATCH_FLOATS, st));
     if (short_first)
         CHECK_HIP(lidf_launch_ief_first_pass(small + 256, small, dec->init_offset, dec->w1 + D, ld1,
                                              dec->wenc, dec->benc, grads->w1 + D, grads->wenc,

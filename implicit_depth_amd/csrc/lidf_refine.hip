@@ -504,12 +504,27 @@ extern "C" hipError_t lidf_launch_refine_finish_dev(const float* pred_pos, const
 //   [pos - centre | rgb] of its predicted point: d pred_pos += embed'(x)^T d_pe + d_inp[:, 0:3]
 //   (the centre belongs to the end voxel, an index: no gradient).
 // ------------------------------------------------------------------------------------------------
+// (pre != NULL: also through the decoder's output activation, lidf_out_act_kernel's derivative — goff is then
+// dL/d(the last pass's pre-activation), what the decoder's backward starts from)
 __global__ void lidf_refine_train_goff_kernel(const float* __restrict__ g, const float* __restrict__ dir,
-                                              float rs, long long R, float* __restrict__ goff) {
+                                              float rs, long long R, const float* __restrict__ pre,
+                                              int use_sigmoid, float* __restrict__ goff) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const float s = g[3 * r] * dir[3 * r] + g[3 * r + 1] * dir[3 * r + 1] + g[3 * r + 2] * dir[3 * r + 2];
-    goff[r] = s * rs;
+    float v = s * rs;
+    if (pre) {
+        const float y = pre[r];
+        float d;
+        if (use_sigmoid) {
+            const float o = 1.f / (1.f + expf(-y));
+            d = o * (1.f - o);
+        } else {
+            d = (y >= 0.f && y <= 1.f) ? 1.f : 0.01f;
+        }
+        v = v * d;
+    }
+    goff[r] = v;
 }
 
 // out[r, c] = g[r, c] (+ sum_o 2^o (cos(2^o x) d_sin[o, c] - sin(2^o x) d_cos[o, c]) + d_pe[r, c]) (+ d_inp[r, c])
@@ -559,10 +574,11 @@ __global__ void lidf_iota_kernel(int* __restrict__ p, long long n) {
 }
 
 extern "C" hipError_t lidf_launch_refine_train_goff(const float* g, const float* dir, float rs, long long R,
-                                                    float* goff, hipStream_t st) {
+                                                    const float* pre, int use_sigmoid, float* goff,
+                                                    hipStream_t st) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_refine_train_goff_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, g, dir, rs,
-                       R, goff);
+                       R, pre, use_sigmoid, goff);
     return hipGetLastError();
 }
 extern "C" hipError_t lidf_launch_refine_train_dcur(const float* g, const float* cur, const int* end_voxel,
