@@ -175,15 +175,17 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
                                         const float* __restrict__ vbound,
                                         const float* __restrict__ rayfeat, int ld_rf, int Lv, int L,
                                         int pos_rel, long long R, float* __restrict__ inp_embed,
-                                        int ld_e, const int* __restrict__ R_dev, int pos_only) {
+                                        int ld_e, const int* __restrict__ R_dev, int pos_only, long long r_base) {
     if (R_dev) R = *R_dev;
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
     // pos_only: a later iteration on the same rays — only embed(pos) changed (columns 128 .. 128+E)
     const int c_lo = pos_only ? 128 : 0, ncol = pos_only ? E : 128 + E + Ed;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * ncol) return;
-    const long long r = i / ncol;
-    const int c = c_lo + (int)(i % ncol);
+    // (a 64 x 4 workgroup = 64 consecutive columns of 4 rays: no index division — with one flat index per
+    // element the 64-bit divide was most of the kernel: 120 us for 160,000 x 206 elements, 1.1 TB/s)
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    const long long r = r_base + (long long)blockIdx.y * 4 + threadIdx.y;
+    if (cc >= ncol || r >= R) return;
+    const int c = c_lo + cc;
     const float* rf = rayfeat + (size_t)r * ld_rf;
     float v;
     if (c < 128) {
@@ -418,10 +420,15 @@ extern "C" hipError_t lidf_launch_refine_rows_dev(const float* pred_pos, const i
                                                   const int* R_dev, float* inp_embed, int ld_e,
                                                   int pos_only, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    const long long total = R * (pos_only ? 3 + 6 * L : 128 + 3 + 6 * L + 3 + 6 * Lv);
-    hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev,
-                       pos_only);
+    const int ncol = pos_only ? 3 + 6 * L : 128 + 3 + 6 * L + 3 + 6 * Lv;
+    // grid.y holds the rays in groups of 4, in slabs of at most 65,535 groups
+    const long long groups = (R + 3) / 4;
+    for (long long g0 = 0; g0 < groups; g0 += 65535) {
+        const long long ng = groups - g0 < 65535 ? groups - g0 : 65535;
+        hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((ncol + 63) / 64), (unsigned)ng), dim3(64, 4), 0,
+                           st, pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev,
+                           pos_only, g0 * 4);
+    }
     return hipGetLastError();
 }
 
