@@ -489,8 +489,9 @@ def secondary(args):
                                        max_pair_id, pair_vox, vb, vbid, rgb, feat, valid_inp, valid_vox, pnet, offr,
                                        forward_times=2)
             pos.sum().backward()
-        flop_alg, bytes_alg, name = 0.0, 0.0, ("lidf_points_kernel<TRAIN> + lidf_linear_kernel (PointNet2Stage layers) "
-                                              "+ lidf_dgrad_chain_kernel + lidf_wgrad2_kernel")
+        flop_alg, bytes_alg, name = 0.0, 0.0, ("lidf_refine_train_forward_f32 / _backward_f32: lidf_points_kernel<TRAIN> + "
+                                              "lidf_pnet_train_fwd_kernel<1|2> + lidf_pnet_bwd_a|b_kernel + "
+                                              "lidf_dgrad_chain_kernel + lidf_wgrad2_kernel")
         what = ("training step of stage 2 (lidf_refine_train = RefineNet.forward 'train', trainers/train_refine.py:"
                 "393-399): 2 x get_pred_refine over %d frames x %d miss rays + %d valid points, %d voxels, forward "
                 "+ backward to every PointNet2Stage / IEF(D=334) parameter; rows = rays" % (Bt, n_miss, n_val, V))
@@ -563,6 +564,15 @@ def secondary(args):
         flop_exec, basis = 3.0 * fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_exec * P / (kern_ms * 1e-3) / 1e12)
     peak = 8000.0 if hbm else (PEAK_F16_TFLOPS if split_rows else PEAK_F32_TFLOPS)
+    # the training steps carry their own rocprofv3 leg (a child process of this same command after the timed
+    # region): launches per step, busy time per step and the kernels of a step, largest first. A step is counted by
+    # a kernel it launches a known number of times.
+    live = None
+    marker = {"train-refine": ("lidf_pnet_bwd_b_kernel", 2), "train-query": ("lidf_points_fused_train_kernel", 1),
+              "train": ("lidf_points_kernel<5>", 2)}.get(args.workload)
+    profiled = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
+    if marker and not args.no_rocprof and not profiled:
+        live = live_profile(sys.argv[1:], marker[0], steps=6, warmup=2, per_step=marker[1])
     emit({
         "metric": "Mpoints/sec, %s" % args.workload, "value": round(P * args.steps / elapsed / 1e6, 2),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -575,7 +585,9 @@ def secondary(args):
                      "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),
                      "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4),
                      "basis": "algorithmic bytes" if hbm else basis,
-                     "achieved_alg": None if hbm else round(flop_alg * P / (kern_ms * 1e-3) / 1e12, 2)}})
+                     "achieved_alg": None if hbm else round(flop_alg * P / (kern_ms * 1e-3) / 1e12, 2)},
+        "profile": ({k: live[k] for k in ("command", "steps_seen", "launches_per_step", "busy_ms_per_step",
+                                          "busy_ms_per_step_after_first", "kernels") if k in live} if live else None)})
 
 
 def e2e(args):

@@ -170,6 +170,7 @@ __global__ void lidf_refine_prep_kernel(const float* __restrict__ pred_pos,
 // inp_embed[r, 128:] = [ROI feature | embed(pos) | embed(dir)]  (pipeline.py:947-969, :1019-1026):
 // one thread per (ray, column) so that the rows leave as coalesced segments; columns 0..127 (voxel
 // feature) are filled after the PointNet pass. Same expressions as the per-ray loop it replaces.
+#define ROWS_PER_WG 32
 __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
                                         const int* __restrict__ end_voxel,
                                         const float* __restrict__ vbound,
@@ -180,33 +181,38 @@ __global__ void lidf_refine_rows_kernel(const float* __restrict__ pred_pos,
     const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
     // pos_only: a later iteration on the same rays — only embed(pos) changed (columns 128 .. 128+E)
     const int c_lo = pos_only ? 128 : 0, ncol = pos_only ? E : 128 + E + Ed;
-    // (a 64 x 4 workgroup = 64 consecutive columns of 4 rays: no index division — with one flat index per
-    // element the 64-bit divide was most of the kernel: 120 us for 160,000 x 206 elements, 1.1 TB/s)
+    // (a 64 x 4 workgroup = 64 consecutive columns of 4 rays at a time: no index division)
     const int cc = blockIdx.x * 64 + threadIdx.x;
-    const long long r = r_base + (long long)blockIdx.y * 4 + threadIdx.y;
-    if (cc >= ncol || r >= R) return;
+    if (cc >= ncol) return;
     const int c = c_lo + cc;
-    const float* rf = rayfeat + (size_t)r * ld_rf;
-    float v;
-    if (c < 128) {
-        v = rf[c];
-    } else if (c < 128 + E) {
-        const int k = c - 128;                    // index inside embed(pos)
-        const int a = k < 3 ? k : (k - 3) % 3;    // coordinate
-        float q = pred_pos[3 * r + a];
-        if (pos_rel) {
-            const float* vb = vbound + 6 * (size_t)end_voxel[r];
-            q = q - (vb[a] + vb[3 + a]) / 2.f;
-        }
-        if (k < 3) {
-            v = q;
+    // (a workgroup walks ROWS_PER_WG rays, four at a time: a workgroup per four rays was bound by its own
+    // dispatch — 160,000 workgroups of a few instructions each)
+#pragma unroll 2
+    for (int it = 0; it < ROWS_PER_WG / 4; ++it) {
+        const long long r = r_base + (long long)blockIdx.y * ROWS_PER_WG + 4 * it + threadIdx.y;
+        if (r >= R) return;
+        const float* rf = rayfeat + (size_t)r * ld_rf;
+        float v;
+        if (c < 128) {
+            v = rf[c];
+        } else if (c < 128 + E) {
+            const int k = c - 128;                    // index inside embed(pos)
+            const int a = k < 3 ? k : (k - 3) % 3;    // coordinate
+            float q = pred_pos[3 * r + a];
+            if (pos_rel) {
+                const float* vb = vbound + 6 * (size_t)end_voxel[r];
+                q = q - (vb[a] + vb[3 + a]) / 2.f;
+            }
+            if (k < 3) {
+                v = q;
+            } else {
+                v = pe_value(q, k);   // (5 VALU; |err| <= 4.2e-7 — lidf_device.h: to_rev / rev_sincos)
+            }
         } else {
-            v = pe_value(q, k);   // (5 VALU; |err| <= 4.2e-7 — lidf_device.h: to_rev / rev_sincos)
+            v = rf[128 + (c - 128 - E)];
         }
-    } else {
-        v = rf[128 + (c - 128 - E)];
+        inp_embed[(size_t)r * ld_e + 128 + c] = v;
     }
-    inp_embed[(size_t)r * ld_e + 128 + c] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -421,13 +427,13 @@ extern "C" hipError_t lidf_launch_refine_rows_dev(const float* pred_pos, const i
                                                   int pos_only, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     const int ncol = pos_only ? 3 + 6 * L : 128 + 3 + 6 * L + 3 + 6 * Lv;
-    // grid.y holds the rays in groups of 4, in slabs of at most 65,535 groups
-    const long long groups = (R + 3) / 4;
+    // grid.y holds the rays in groups of ROWS_PER_WG, in slabs of at most 65,535 groups
+    const long long groups = (R + ROWS_PER_WG - 1) / ROWS_PER_WG;
     for (long long g0 = 0; g0 < groups; g0 += 65535) {
         const long long ng = groups - g0 < 65535 ? groups - g0 : 65535;
         hipLaunchKernelGGL(lidf_refine_rows_kernel, dim3((unsigned)((ncol + 63) / 64), (unsigned)ng), dim3(64, 4), 0,
                            st, pred_pos, end_voxel, vbound, rayfeat, ld_rf, Lv, L, pos_rel, R, inp_embed, ld_e, R_dev,
-                           pos_only, g0 * 4);
+                           pos_only, g0 * ROWS_PER_WG);
     }
     return hipGetLastError();
 }
