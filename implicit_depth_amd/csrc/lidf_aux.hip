@@ -1387,10 +1387,13 @@ __global__ void __launch_bounds__(1024) lidf_scan_small_kernel(const int* __rest
     __shared__ int s_w[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int carry = 0;
-    for (int b = 0; b < n; b += 1024) {
-        const int k = b + threadIdx.x;
-        const int c = k < n ? in[k] : 0;
-        int inc = c;
+    for (int b = 0; b < n; b += 4096) {   // four consecutive entries per thread and round
+        const int k = b + 4 * threadIdx.x;
+        int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = k + j < n ? in[k + j] : 0;
+        const int mine = c[0] + c[1] + c[2] + c[3];
+        int inc = mine;
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
             const int o = __shfl_up(inc, sft);
@@ -1405,7 +1408,12 @@ __global__ void __launch_bounds__(1024) lidf_scan_small_kernel(const int* __rest
             wpre += w < wave ? t : 0;
             tot += t;
         }
-        if (k < n) out[k] = carry + wpre + inc - c;
+        int run = carry + wpre + inc - mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k + j < n) out[k + j] = run;
+            run += c[j];
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) out[n] = carry;

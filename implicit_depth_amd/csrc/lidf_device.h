@@ -287,6 +287,8 @@ struct PointsArgs {
     int* tile_counter;      // split-f16 kernel: dynamic tile hand-out (zeroed by its packer)
     int dyn_min_tiles;      // fused f32 kernel: dynamic hand-out from this many wave-tiles per wavefront (0: 32)
     int dyn_chunk;          // ... in chunks of this many wave-tiles (0: LIDF_CHUNK)
+    int tail_split;         // fused f32 kernel, static split, two nets: the tiles of the partial last round are
+                            // handed out net by net (see points_fused_body)
     // LIDF_MODE_TRAIN (one net): X = the per-pair layer-1 operand rows, voxpart[pair_vox] and
     // raypart[pair_ray] are added to layer 1; pass k keeps H1 | H2 | H3 | offset-in | sign words at
     // tr_passes + k * tr_pass_floats (the LIDF_ACT_* planes above), the pre-activation output

@@ -547,22 +547,68 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
                      nwt >= (long long)(a.dyn_min_tiles > 0 ? a.dyn_min_tiles : 32) * gridDim.x * 4;
     const long long ntile = (AN + 127) / 128;
     const long long per = ntile / gridDim.x, rem = ntile % gridDim.x;
-    const long long tb = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
-    const long long te_ = tb + per + (blockIdx.x < rem ? 1 : 0);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const long long nwaves = (long long)gridDim.x * 4;
+    // The static split's partial last round, NET BY NET (a.tail_split, two nets; round 5). ntile tiles over G
+    // workgroups are `per` full rounds and `rem` tiles more: handed out whole, rem of the G compute units run one
+    // more (tile, both nets) while the others idle — 8,736 wave-tiles of a real frame over 1,024 SIMDs are 8.53
+    // rounds in the time of 9. The two nets of a tile are independent given its geometry (1,062 and 1,716 matrix
+    // instructions: prob_dec one pass, offset_dec two), so the 4 rem wave-tiles of the last round become 8 rem
+    // one-net items over all 4 G wavefronts: wavefront g < 4 rem takes the offset net of tail wave-tile g, the
+    // others the probability net of tail wave-tiles g - 4 rem and (when there are more items than wavefronts)
+    // g - 4 rem + (4 G - 4 rem): the round then lasts max(1716, 2 x 1062) instead of 2,778 instruction times.
+    // Beyond two prob items per free wavefront (rem > 2/3 G) nothing is gained and the tiles stay whole. Same
+    // instruction sequence per (tile, net) as ever: results are bit-identical.
+    bool split = !dyn && a.tail_split && a.nets == 2 && rem > 0;
+    long long wt0 = per * gridDim.x * 4;     // first wave-tile of the partial round
+    int n_tail = 0, freew = 0;
+    if (split) {
+        n_tail = (int)(nwt - wt0);
+        freew = (int)nwaves - n_tail;
+        if (n_tail > 2 * freew) split = false;
+    }
+    const long long tb = split ? blockIdx.x * per : blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
+    const long long te_ = split ? tb + per : tb + per + (blockIdx.x < rem ? 1 : 0);
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + uwave));
     const int chunk = a.dyn_chunk > 0 ? a.dyn_chunk : LIDF_CHUNK;   // (a chunk is also the grain of the tail)
-    long long w_cur = dyn ? ((long long)blockIdx.x * 4 + uwave) * chunk : tb * 4 + uwave;
-    if (!dyn && tb >= te_) return;
+    // item q of this wavefront's static sequence: its wave-tile (>= nwt: the sequence has ended) and nets [lo, hi)
+    auto seq = [&](int q, long long& w, int& lo, int& hi) {
+        lo = 0;
+        hi = a.nets;
+        w = nwt;
+        if (q < (int)(te_ - tb)) {
+            w = (tb + q) * 4 + uwave;
+            return;
+        }
+        if (!split) return;
+        const int t = q - (int)per;
+        if (gw < n_tail) {
+            if (t == 0) { w = wt0 + gw; lo = 1; hi = 2; }
+            return;
+        }
+        const int j = gw - n_tail + t * freew;
+        if (t < 2 && j < n_tail) { w = wt0 + j; lo = 0; hi = 1; }
+    };
+    int pos = 0;
+    long long w_cur;
+    int lo_cur = 0, hi_cur = a.nets, lo_nxt = 0, hi_nxt = a.nets, lo_nx2 = 0, hi_nx2 = a.nets;
+    if (dyn) w_cur = ((long long)blockIdx.x * 4 + uwave) * chunk;
+    else seq(0, w_cur, lo_cur, hi_cur);
     if (w_cur >= nwt) return;
     int pend_raw = 0;   // lane 0: the counter value of the chunk requested ahead
     int left = chunk;   // wave-tiles left in the chunk the sequence is in (counting its head)
     auto request_chunk = [&]() {
         if (lane == 0) pend_raw = atomicAdd(a.tile_counter, 1);
     };
-    // successor of wave-tile w in this wavefront's sequence (>= nwt: the sequence has ended)
-    auto next_wt = [&](long long w) -> long long {
-        if (!dyn) return w + 4 < te_ * 4 ? w + 4 : nwt;
+    // successor of wave-tile w in this wavefront's sequence (>= nwt: the sequence has ended), with its nets
+    auto next_wt = [&](long long w, int& lo, int& hi) -> long long {
+        if (!dyn) {
+            long long s;
+            seq(++pos, s, lo, hi);
+            return s;
+        }
+        lo = 0;
+        hi = a.nets;
         if (--left > 0) return w + 1;
         left = chunk;
         const long long s = (nwaves + __builtin_amdgcn_readfirstlane(pend_raw)) * chunk;
@@ -570,12 +616,12 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
         return s;
     };
     if (dyn) request_chunk();
-    long long w_nxt = next_wt(w_cur), w_nx2 = 0;
+    long long w_nxt = next_wt(w_cur, lo_nxt, hi_nxt), w_nx2 = 0;
 
-    // the ring: next 8 quads of the stream, refilled 8 quads ahead, never drained
+    // the ring: next 8 quads of the stream (of the first item's first net), refilled 8 quads ahead, never drained
     f32x4 ring[LIDF_RING];
 #pragma unroll
-    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, i * 1024);
+    for (int i = 0; i < LIDF_RING; ++i) ring[i] = LDQ(srs, vq, lo_cur * net_bytes + i * 1024);
 
     // addresses = wave-uniform base (SGPRs) + a 32-bit lane offset: no 64-bit pointer registers
     auto load_idx = [&](long long wt, Geo& g) {
@@ -614,7 +660,7 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     // layer-1 accumulator of the first (tile, net): fetched here, in the open
     f32x16 base[8];
     {
-        const float* vp = vox_row(cur.vid, 0);
+        const float* vp = vox_row(cur.vid, lo_cur);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -627,13 +673,14 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
     }
 
     PROF_DECL
-    for (; w_cur < nwt; w_cur = w_nxt, w_nxt = w_nx2) {
+    for (; w_cur < nwt; w_cur = w_nxt, w_nxt = w_nx2, lo_cur = lo_nxt, hi_cur = hi_nxt, lo_nxt = lo_nx2,
+                       hi_nxt = hi_nx2) {
         PROF(0)
         const long long p = w_cur * 32 + col;
         const bool valid = p < AN;
 
         load_dir(nxt);
-        w_nx2 = next_wt(w_nxt);
+        w_nx2 = next_wt(w_nxt, lo_nx2, hi_nx2);
         load_idx(w_nx2, nx2);
         // this half's embedding input: lanes 0..31 embed the enter position, lanes 32..63 the
         // leave position (pipeline.py:349-360; 'rel' subtracts the voxel centre)
@@ -649,9 +696,10 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
         const Rev rx = to_rev(px), ry = to_rev(py), rz = to_rev(pz);
         PROF(1)
 
-        for (int net = 0; net < a.nets; ++net) {
+        for (int net = lo_cur; net < hi_cur; ++net) {
             const int nsb = net * net_bytes;  // byte offset of this net's block
-            const int next_blk = net + 1 < a.nets ? nsb + net_bytes : 0;
+            // (what the ring reads next: the other net of this item, or the first net of the next item)
+            const int next_blk = net + 1 < hi_cur ? nsb + net_bytes : lo_nxt * net_bytes;
 
             // ---------------- layer 1 ----------------
             // raypart[ray] is constant over the points of one ray, so it enters as a rank-1
@@ -756,9 +804,9 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
             // ---------------- passes (1 for IMNet, n_iter for IEF) ----------------
             // the last pass of the net copies the accumulator init of what runs next — the other net
             // of this tile, or the first net of the next tile — into LDS while its layer 2 runs
-            const bool last_net = net + 1 == a.nets;
+            const bool last_net = net + 1 == hi_cur;
             const unsigned vp_off =
-                (unsigned)(((last_net ? nxt.vid : cur.vid) * part_ld + part_off + (last_net ? 0 : net + 1) * 256) * 4 +
+                (unsigned)(((last_net ? nxt.vid : cur.vid) * part_ld + part_off + (last_net ? lo_nxt : net + 1) * 256) * 4 +
                            16 * h);
             float val = a.init[net];
             const int pass_base = nsb + l1_bytes;
@@ -1357,17 +1405,22 @@ extern "C" hipError_t lidf_launch_points(int mode, const PointsArgs& a, int grid
         static bool configured[64];
         hipError_t e = lidf_max_lds_once(configured, (const void*)lidf_points_fused_kernel, 131072);
         if (e != hipSuccess) return e;
-        static int env_min = -1, env_chunk = -1;   // development knobs of the tile hand-out
+        static int env_min = -1, env_chunk = -1, env_split = -1;   // development knobs of the tile hand-out
         if (env_min < 0) {
             const char* e1 = getenv("LIDF_DYN_MIN");
             const char* e2 = getenv("LIDF_DYN_CHUNK");
+            const char* e3 = getenv("LIDF_TAIL_SPLIT");   // 0: the partial last round's tiles stay whole (A/B)
             env_min = e1 ? atoi(e1) : 0;
             env_chunk = e2 ? atoi(e2) : 0;
+            env_split = (e3 && e3[0] == '0') ? 0 : 1;
         }
-        if ((env_min > 0 || env_chunk > 0) && !a.tr_passes[0] && !a.tr_passes[1]) {
+        if (!a.tr_passes[0] && !a.tr_passes[1]) {
             PointsArgs b = a;
-            b.dyn_min_tiles = env_min;
-            b.dyn_chunk = env_chunk;
+            if (env_min > 0 || env_chunk > 0) {
+                b.dyn_min_tiles = env_min;
+                b.dyn_chunk = env_chunk;
+            }
+            b.tail_split = env_split;
             hipLaunchKernelGGL(lidf_points_fused_kernel, dim3(grid), dim3(256), 131072, st, b);
             return hipGetLastError();
         }
