@@ -120,10 +120,17 @@ def test_backward_against_f64(cuda, kind, n_iter):
         assert err <= 2e-5 * scale, (k, err, scale)
 
 
-@pytest.mark.parametrize("n,v,drop", [(3000, 40, False), (257, 9, True), (5, 3, False)])
+# (70000, 300): more 128-point tiles than workgroups and voxels beyond one workgroup's 32-row pooling window;
+# (20000, 5000): a handful of points per voxel — a workgroup's run of sorted points spans far more voxels than its
+# window, most entries go through the global 64-bit maxima; (1000, 1): one voxel, one long run of rows (chunked
+# row sums); (4000, 64) with a quarter of the rows left out: the sorted buffers' dead rows are written as zeros
+@pytest.mark.parametrize("n,v,drop", [(3000, 40, False), (257, 9, True), (5, 3, False), (70000, 300, False),
+                                      (20000, 5000, False), (1000, 1, False), (4000, 64, True)])
 def test_pointnet_gradients(cuda, n, v, drop):
     """PointNet2Stage under autograd: HIP forward-with-activations + HIP backward against torch
-    autograd on the CPU oracle (scatter-max routes the gradient to one arg row per pooled entry)."""
+    autograd on the CPU oracle (scatter-max routes the gradient to one arg row per pooled entry). Round 5: the
+    register chains of lidf_pointnet_train.hip over voxel-sorted points; LIDF_PNET_TRAIN_CHAIN=0 selects the
+    layer-by-layer path of rounds 2-4 (tests/test_train_gpu.py::test_pointnet_train_paths_agree)."""
     from util import make_pointnet
     g = torch.Generator().manual_seed(n + v)
     p = orc.init_pointnet(7, 1.5)
@@ -153,6 +160,15 @@ def test_pointnet_gradients(cuda, n, v, drop):
     # and the inference kernel gives the same values
     with torch.no_grad():
         assert (m(inp.to(cuda), vox.to(cuda), n_vox=v) - out.detach()).abs().max().item() <= 1e-6
+    # the chains' sums run in a fixed order (sorted rows, slab reductions, arg rows by a 64-bit maximum): a second
+    # run gives the same bits
+    m2 = make_pointnet(p, cuda).train()
+    xd2 = inp.to(cuda).requires_grad_(True)
+    out2 = m2(xd2, vox.to(cuda), n_vox=v)
+    (out2 * wgt.to(cuda)).sum().backward()
+    assert torch.equal(out2, out) and torch.equal(xd2.grad, xd.grad)
+    for (k, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
 
 
 @pytest.mark.parametrize("multires", [0, 4, 8])
@@ -307,9 +323,48 @@ def test_refine_train_fused_step_vs_composed(cuda, pos_rel, pnet_pos_rel, kind, 
     again_pos, _, again_g = run(lidf_refine_train, grid=occ if use_grid else None)
     assert torch.equal(again_pos, got_pos)
     for k in got_g:
-        # (float atomics remain in the RoIAlign backward's border taps and in the PointNet backward's per-voxel
-        # row sums — lidf_hip.h —: everything downstream of the latter is equal to rounding, not bit for bit)
-        if k.startswith("dec."):
+        # (float atomics remain in the RoIAlign backward's border taps only — lidf_hip.h; everything else of the
+        # step is a fixed-order sum: sorted rows, slab reductions, arg rows by a 64-bit maximum)
+        if k != "feat_grid":
             assert torch.equal(again_g[k], got_g[k]), k
         else:
             assert (again_g[k] - got_g[k]).abs().max().item() <= 1e-5 * max(got_g[k].abs().max().item(), 1e-3), k
+
+
+def test_pointnet_train_paths_agree(cuda):
+    """The training chains (lidf_pointnet_train.hip) against the layer-by-layer training path of rounds 2-4
+    (LIDF_PNET_TRAIN_CHAIN=0, a separate process: the switch is read once per process): outputs and every gradient
+    within f32 re-association of each other on the same inputs."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from util import make_pointnet, orc
+g = torch.Generator().manual_seed(11)
+n, v = 30000, 120
+p = orc.init_pointnet(7, 1.5)
+inp = torch.randn(n, 6, generator=g); vox = torch.randint(0, v, (n,), generator=g); wgt = torch.randn(v, 128, generator=g)
+m = make_pointnet(p, 'cuda').train()
+x = inp.cuda().requires_grad_(True)
+out = m(x, vox.cuda(), n_vox=v)
+(out * wgt.cuda()).sum().backward()
+res = {'out': out.detach().cpu(), 'x': x.grad.cpu()}
+res.update({k: t.grad.cpu() for k, t in m.named_parameters()})
+torch.save(res, sys.argv[1])
+""" % (root, os.path.join(root, "tests"))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for flag in ("1", "0"):
+            f = os.path.join(d, "r%s.pt" % flag)
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, LIDF_PNET_TRAIN_CHAIN=flag),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append(torch.load(f))
+    a, b = outs
+    for k in a:
+        scale = max(1e-2, b[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() <= 2e-4 * scale, (k, (a[k] - b[k]).abs().max().item(), scale)
