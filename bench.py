@@ -427,6 +427,10 @@ def secondary(args):
         off.load_state_dict(scene["off_p"])
         fg = sd["feat_grid"].clone().requires_grad_(True)
         vf = sd["vox_feat"].clone().requires_grad_(True)
+        Npr = max(args.samples // 8, 1)   # (the synthetic list is dense: Npr candidates on every ray)
+        gl = torch.Generator().manual_seed(99)
+        gt_pos = (torch.rand(scene["R"], 3, generator=gl) * 2 - 1).to(dev)
+        label = torch.randint(0, Npr, (scene["R"], 1), generator=gl).to(dev)
 
         def step():
             for m in (prob, off):
@@ -436,11 +440,22 @@ def secondary(args):
             vf.grad = None
             o = lidf_query_train(sd["ray_dir"], sd["ray_pix"], sd["ray_bid"], sd["pair_off"], sd["pair_ray"],
                                  sd["pair_vox"], sd["pair_t"], fg, vf, prob, off)
-            (o["pred_pos"].sum() + o["pred_prob_end_softmax"].sum() + o["pred_offset"].sum()).backward()
+            # the reference's loss structure (models/pipeline.py:468-490): position loss on pred_pos (the selected
+            # pair of every ray), ray-wise cross-entropy of the logits at a label pair; --dense-offset-grad adds a
+            # term on pred_offset itself, which no loss of the reference has (every pair then carries a gradient)
+            pos_loss = (o["pred_pos"] - gt_pos).abs().mean()
+            lsm = torch.log_softmax(o["pred_prob_end"].view(-1, Npr), dim=1)
+            prob_loss = -lsm.gather(1, label).mean()
+            loss = pos_loss + prob_loss
+            if args.dense_offset_grad:
+                loss = loss + o["pred_offset"].sum()
+            loss.backward()
         flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_fused_train_kernel + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
         what = ("training step of the query (lidf_query_train): ROI pooling, decoder input rows, both "
-                "decoders forward + backward, gradients to feat_grid / vox_feat / parameters; "
-                "240x320 rays x %d candidates; FLOP = 3 x forward" % max(args.samples // 8, 1))
+                "decoders forward + backward, gradients to feat_grid / vox_feat / parameters; loss = L1(pred_pos, gt) + "
+                "ray-wise cross-entropy of the logits (pipeline.py:468-490)%s; 240x320 rays x %d candidates"
+                % (" + a term on pred_offset of every pair (--dense-offset-grad)" if args.dense_offset_grad else
+                   ": offset_dec's backward runs over the selected pair of every ray", max(args.samples // 8, 1)))
     elif args.workload == "train-refine":
         # one training step of stage 2 at the reference's per-GPU shape (trainers/train_refine.py:393-399,
         # train_lidf.yaml: batch 8 per GPU, 20,000 miss rays + 10,000 valid points per image): RefineNet.forward
@@ -560,8 +575,14 @@ def secondary(args):
         # voxel / ray parts are per-voxel / per-ray products; train: all 385 columns, once per net
         # for the IEF), + the IEF rank-1 term per pass
         chain, k1 = 2.0 * (256 * 128 + 128 * 64 + 64), (102 if args.workload == "train-query" else 385)
-        fwd = 2 * (2.0 * 256 * k1) + 3 * chain + 2 * (2.0 * 256)
+        fwd_prob, fwd_off = 2.0 * 256 * k1 + chain, 2.0 * 256 * k1 + 2 * chain + 2 * (2.0 * 256)
+        fwd = fwd_prob + fwd_off
         flop_exec, basis = 3.0 * fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
+        if args.workload == "train-query" and not args.dense_offset_grad:
+            # offset_dec's backward (2 x its forward) over one pair per ray instead of every pair
+            flop_exec = fwd + 2.0 * fwd_prob + 2.0 * fwd_off / max(args.samples // 8, 1)
+            basis = ("FLOP of the executed formulation: forward of both decoders on every pair, backward (2 x forward) of "
+                     "prob_dec on every pair and of offset_dec on the selected pair of every ray; not an instruction count")
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_exec * P / (kern_ms * 1e-3) / 1e12)
     peak = 8000.0 if hbm else (PEAK_F16_TFLOPS if split_rows else PEAK_F32_TFLOPS)
     # the training steps carry their own rocprofv3 leg (a child process of this same command after the timed
@@ -886,6 +907,9 @@ def main():
                          "default and what configs[2]/[4] describe); rays = ONE frame, image rows split "
                          "over the ranks (strong scaling, SURVEY 8e for fewer frames than GPUs), depth rows "
                          "all-gathered")
+    ap.add_argument("--dense-offset-grad", action="store_true",
+                    help="--workload train-query: add a loss term on pred_offset of every pair (not in the reference's "
+                         "loss): offset_dec's backward then runs over all pairs, as in rounds 1-4")
     ap.add_argument("--streams", type=int, default=1,
                     help="query workloads: consecutive steps (independent frames) alternate over this many HIP "
                          "streams, so the light kernels at the head and tail of a step (per-ray features, "

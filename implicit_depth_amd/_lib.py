@@ -15,7 +15,7 @@ LIDF_OK = 0
 # below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
 # lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
 # outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
-ABI = 8
+ABI = 9
 
 
 class LidfDecoder(C.Structure):
@@ -217,6 +217,9 @@ SIGNATURES = {
                                                _P, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
                                                   C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
+    "lidf_query_decoder_rows_workspace_bytes": (_SZ, [_I64, _I64, C.c_int32, C.c_int32]),
+    "lidf_query_decoder_backward_rows_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, C.c_float, _P, _P,
+                                                       _I, C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
     "lidf_embed_backward_f32": (C.c_int, [_P, _P, _I64, _I, _P, _P]),
     "lidf_pointnet_train_act_floats": (_SZ, [_I64, _I64]),
     "lidf_pointnet_train_workspace_bytes": (_SZ, [_I64, _I64]),

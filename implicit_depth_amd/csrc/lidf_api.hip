@@ -2938,6 +2938,79 @@ LIDF_API int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* q, const 
                               (char*)workspace, w, cus, st);
 }
 
+// The decoder's backward from ONE pair per ray (the offset decoder under the reference's losses): see
+// lidf_gather_sel_rows_kernel. The compacted problem — R pairs, pair r on ray r — goes through the same launches
+// as the dense one.
+struct QRowsWs { size_t pvox, poff, g, pe, act, inner, total; QTrainWs w; };
+static QRowsWs qrows_ws(int64_t R, int64_t V, int E2, int npass) {
+    QRowsWs l;
+    const size_t N = (size_t)(R > 0 ? R : 1);
+    size_t o = 0;
+    l.pvox = o;  o += align_up(N * 4, 256);
+    l.poff = o;  o += align_up((N + 1) * 4, 256);
+    l.g = o;     o += align_up(N * 4, 256);
+    l.pe = o;    o += align_up(N * (size_t)E2 * 4, 256);
+    l.act = o;   o += align_up(((size_t)npass * qact_pass((int64_t)N) + N) * 4, 256);
+    l.w = qtrain_ws(R, R, V);
+    l.inner = o; o += l.w.total;
+    l.total = o;
+    return l;
+}
+LIDF_API size_t lidf_query_decoder_rows_workspace_bytes(int64_t n_rays, int64_t n_vox, int32_t multires,
+                                                          int32_t n_pass) {
+    if (n_rays < 0 || n_vox < 0 || multires < 0 || multires > 16 || n_pass <= 0) return 0;
+    return qrows_ws(n_rays, n_vox, 2 * (3 + 6 * multires), n_pass).total;
+}
+extern "C" hipError_t lidf_launch_gather_sel_rows(const float*, long long, int, const long long*, long long,
+                                                  const int*, const float*, int, const float*, const float*, float,
+                                                  float*, int*, float*, float*, int*, hipStream_t);
+LIDF_API int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* q, const float* act,
+                                                    const int64_t* rows, const float* g_pred_pos,
+                                                    const float* ray_dir, float scale, float* d_vox_feat,
+                                                    float* d_rayfeat, int32_t accumulate_inputs,
+                                                    const LidfDecoderGrads* grads, void* workspace,
+                                                    size_t workspace_bytes, lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_qtrain(q))) return rc;
+    if (!grads) return LIDF_ERR_BAD_ARG;
+    const LidfDecoder* dec = q->dec;
+    if (!grads->w1 || !grads->b1 || !grads->w2 || !grads->b2 || !grads->w3 || !grads->b3 ||
+        !grads->w4 || !grads->b4 || (dec->is_ief && (!grads->wenc || !grads->benc)))
+        return LIDF_ERR_BAD_ARG;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    hipStream_t st = (hipStream_t)stream;
+    const int E2 = 2 * (3 + 6 * q->multires), Ed = 3 + 6 * q->multires_views;
+    const int D = 256 + E2 + Ed, ld1 = D + (dec->is_ief ? 16 : 0);
+    const int npass = dec->is_ief ? dec->n_iter : 1;
+    CHECK_HIP(zero_decoder_grads(grads, ld1, dec->is_ief, st));
+    if (!accumulate_inputs) {
+        if (d_vox_feat && V > 0) CHECK_HIP(hipMemsetAsync(d_vox_feat, 0, (size_t)V * 128 * 4, st));
+        if (d_rayfeat && R > 0) CHECK_HIP(hipMemsetAsync(d_rayfeat, 0, (size_t)R * (128 + Ed) * 4, st));
+    }
+    if (P == 0 || R == 0) return LIDF_OK;
+    if (!act || !rows || !g_pred_pos || !ray_dir) return LIDF_ERR_BAD_ARG;
+    const QRowsWs l = qrows_ws(R, V, E2, npass);
+    if (!workspace || workspace_bytes < l.total) return LIDF_ERR_WORKSPACE;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    char* ws = (char*)workspace;
+    int* pvox = (int*)(ws + l.pvox);
+    int* poff = (int*)(ws + l.poff);
+    float* g = (float*)(ws + l.g);
+    float* pe = (float*)(ws + l.pe);
+    float* passes = (float*)(ws + l.act);
+    const float* passes_src = act + (size_t)(V + R) * LIDF_H1;   // behind voxpart | raypart (lidf_query_decoder_act_floats)
+    CHECK_HIP(lidf_launch_gather_sel_rows(passes_src, P, npass, (const long long*)rows, R, q->pair_vox, q->pe, E2,
+                                          g_pred_pos, ray_dir, scale, passes, pvox, pe, g, poff, st));
+    LidfQueryTrainArgs qc = *q;
+    qc.n_pairs = R;
+    qc.pair_off = poff; qc.pair_ray = poff; qc.pair_vox = pvox; qc.pe = pe;   // (pair r on ray r: pair_ray = 0..R-1 = poff)
+    QdecBwd o = {};
+    o.E2 = E2; o.zero_grads = true;
+    return qdec_backward_impl(&qc, o, passes, passes + (size_t)npass * qact_pass(R), g, d_vox_feat, d_rayfeat,
+                              accumulate_inputs, grads, ws + l.inner, l.w, cus, st);
+}
+
 // ---- per-pair / per-ray tail of get_pred, forward and adjoint -------------------------------------
 LIDF_API int lidf_query_tail_f32(const float* pred_offset, const float* pred_prob,
                                    const int32_t* pair_off, const int32_t* pair_ray,

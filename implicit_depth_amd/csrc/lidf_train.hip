@@ -1573,6 +1573,74 @@ extern "C" hipError_t lidf_launch_pair_pos_backward(const float* g_pos, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// The offset decoder's backward from the selected pairs only (lidf_query_decoder_backward_rows_f32). The
+// reference's losses reach offset_dec through pred_pos = pair_pred_pos[max_pair_id] alone
+// (models/pipeline.py:437-454, 468-476): dL/d pred_offset is k (ray_dir[r] . g_pred_pos[r]) at the selected pair
+// of ray r and exactly zero at every other pair, and a row with a zero output gradient adds exactly zero to
+// every sum of the backward. This kernel forms the one-pair-per-ray problem: row r = the kept activations
+// (every plane of every pass), the pre-activation, the voxel and the position-embedding row of pair rows[r],
+// and its output gradient; a ray without a pair (rows[r] >= P) takes pair 0's rows with gradient 0.
+// 128 threads per row: float4 c of the 112 of H1 | H2 | H3, then offset-in, sign words (2 + 1 float4).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lidf_gather_sel_rows_kernel(
+    const float* __restrict__ act, long long P, int npass, const long long* __restrict__ rows, long long R,
+    const int* __restrict__ pair_vox, const float* __restrict__ pe, int E2, const float* __restrict__ g_pred,
+    const float* __restrict__ ray_dir, float k, float* __restrict__ act_dst, int* __restrict__ pvox,
+    float* __restrict__ pe_dst, float* __restrict__ g_dst, int* __restrict__ poff) {
+    const long long r = (long long)blockIdx.x * 2 + (threadIdx.x >> 7);
+    const int c = threadIdx.x & 127;
+    if (r >= R) return;
+    const long long id = rows[r];
+    const bool has = id >= 0 && id < P;
+    const size_t p = has ? (size_t)id : 0;
+    for (int ps = 0; ps < npass; ++ps) {
+        const float* src = act + (size_t)ps * P * LIDF_ACT_ROW_FLOATS;
+        float* dst = act_dst + (size_t)ps * R * LIDF_ACT_ROW_FLOATS;
+        if (c < 64) {
+            *(f32x4u*)(dst + (size_t)r * LIDF_H1 + 4 * c) = *(const f32x4u*)(src + p * LIDF_H1 + 4 * c);
+        } else if (c < 96) {
+            const int j = c - 64;
+            *(f32x4u*)(dst + (size_t)R * LIDF_H1 + (size_t)r * LIDF_H2 + 4 * j) =
+                *(const f32x4u*)(src + (size_t)P * LIDF_H1 + p * LIDF_H2 + 4 * j);
+        } else if (c < 112) {
+            const int j = c - 96;
+            *(f32x4u*)(dst + (size_t)R * (LIDF_H1 + LIDF_H2) + (size_t)r * LIDF_H3 + 4 * j) =
+                *(const f32x4u*)(src + (size_t)P * (LIDF_H1 + LIDF_H2) + p * LIDF_H3 + 4 * j);
+        } else if (c == 112) {
+            dst[(size_t)R * LIDF_ACT_OIN + r] = src[(size_t)P * LIDF_ACT_OIN + p];
+        } else if (c < 115) {
+            const int j = c - 113;
+            *(f32x4u*)(dst + (size_t)R * LIDF_ACT_M1 + (size_t)r * 8 + 4 * j) =
+                *(const f32x4u*)(src + (size_t)P * LIDF_ACT_M1 + p * 8 + 4 * j);
+        } else if (c == 115) {
+            *(f32x4u*)(dst + (size_t)R * LIDF_ACT_M2 + (size_t)r * 4) = *(const f32x4u*)(src + (size_t)P * LIDF_ACT_M2 + p * 4);
+        }
+    }
+    // the pre-activation of the last pass sits behind the passes
+    if (c == 116)
+        act_dst[(size_t)npass * R * LIDF_ACT_ROW_FLOATS + r] = act[(size_t)npass * P * LIDF_ACT_ROW_FLOATS + p];
+    if (c == 117) {
+        pvox[r] = pair_vox[p];
+        poff[r] = (int)r;
+        if (r == R - 1) poff[R] = (int)R;
+        // (the adjoint of pred_pos = enter + k off dir, as lidf_pair_pos_backward_kernel forms it)
+        g_dst[r] = has ? k * (ray_dir[3 * r] * g_pred[3 * r] + ray_dir[3 * r + 1] * g_pred[3 * r + 1] +
+                              ray_dir[3 * r + 2] * g_pred[3 * r + 2])
+                       : 0.f;
+    }
+    for (int j = c; j < E2; j += 128) pe_dst[(size_t)r * E2 + j] = pe[p * E2 + j];
+}
+extern "C" hipError_t lidf_launch_gather_sel_rows(const float* act, long long P, int npass, const long long* rows,
+                                                  long long R, const int* pair_vox, const float* pe, int E2,
+                                                  const float* g_pred, const float* ray_dir, float k, float* act_dst,
+                                                  int* pvox, float* pe_dst, float* g_dst, int* poff, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_gather_sel_rows_kernel, dim3((unsigned)((R + 1) / 2)), dim3(256), 0, st, act, P, npass,
+                       rows, R, pair_vox, pe, E2, g_pred, ray_dir, k, act_dst, pvox, pe_dst, g_dst, poff);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // PointNet2Stage training pieces (models/pointnet.py:22-38 under autograd):
 //   relu mask, arg of the per-voxel max (torch_scatter's scatter-max sends the gradient of a pooled
 //   entry to ONE source row: here the lowest row index attaining the maximum), its backward, and

@@ -982,6 +982,124 @@ class _QueryTailFn(torch.autograd.Function):
         return (d_off.reshape(shape),) + (None,) * 9
 
 
+class _QueryTrainFn(torch.autograd.Function):
+    """get_pred of the training step as ONE autograd node: both decoders (lidf_query_forward_train_f32, one launch
+    of the per-point kernel with the activations kept) and the per-pair / per-ray tail (lidf_query_tail_f32).
+    The node sees which of its outputs the loss used. The reference's losses reach offset_dec through
+    pred_pos = pair_pred_pos[max_pair_id] alone (models/pipeline.py:437-454, 468-476): when neither pred_offset
+    nor pair_pred_pos received a gradient, dL/d pred_offset is non-zero at the selected pair of every ray only,
+    and offset_dec's backward runs over those R rows (lidf_query_decoder_backward_rows_f32) — the same gradients,
+    an eighth of the rows at 8 pairs per ray. A loss that touches pred_offset or pair_pred_pos takes the dense
+    backward (lidf_query_tail_backward_f32 + lidf_query_decoder_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, prob_mod, off_mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t,
+                ray_dir, vox_center, pos_rel, multires, multires_views, r0, r1, part, mid_in, n_prob, *params):
+        from . import decoders as _dec
+        vf, rf = vox_feat.detach().contiguous(), rayfeat.detach().contiguous()
+        dev = vf.device
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        keep = []
+        dp, do = _dec._decoder_struct(prob_mod, keep), _dec._decoder_struct(off_mod, keep)
+        a = _lib.LidfQueryTrainArgs()
+        a.n_pairs, a.n_rays, a.n_vox = P, R, V
+        a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+        a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+        a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dp)
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        passes = [int(m.n_iter) if isinstance(m, _dec.IEF) else 1 for m in (prob_mod, off_mod)]
+        acts = [torch.empty((max(L.lidf_query_decoder_act_floats(P, R, V, n), 1),), **f32) for n in passes]
+        wsb = L.lidf_query_forward_train_workspace_bytes(R, V)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        prob, off = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        pos = torch.empty((P, 3), **f32)
+        sm = torch.empty((P,), **f32)
+        mid = torch.empty((R,), dtype=torch.int64, device=dev)
+        pred = torch.empty((R, 3), **f32)
+        if mid_in is not None:
+            mid_in = mid_in.to(torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            _lib.check(L.lidf_query_forward_train_f32(
+                C.byref(a), C.byref(do), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
+                _lib.ptr(prob), _lib.ptr(off), _lib.ptr(acts[0]), _lib.ptr(acts[1]), _lib.ptr(ws), wsb, st))
+            _lib.check(L.lidf_query_tail_f32(
+                _lib.ptr(off), _lib.ptr(prob), _lib.ptr(pair_off), _lib.ptr(pair_ray), _lib.ptr(pair_t),
+                _lib.ptr(ray_dir), R, P, r0, r1, part, _lib.ptr(mid_in), _lib.ptr(pos), _lib.ptr(sm),
+                _lib.ptr(mid), _lib.ptr(pred), st))
+        sel = mid_in if mid_in is not None else mid
+        ctx.mods = (prob_mod, off_mod)
+        ctx.cfg = (multires, multires_views, n_prob, r0, r1, part, passes)
+        ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
+        ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, acts[0], acts[1], *params)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(sm, mid)
+        return prob, off, pos, sm, sel if mid_in is not None else mid, pred
+
+    @staticmethod
+    def backward(ctx, g_prob, g_off, g_pos, g_sm, g_mid, g_pred):
+        from . import decoders as _dec
+        vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, act_p, act_o = ctx.saved_tensors[:10]
+        params = ctx.saved_tensors[10:]
+        multires, multires_views, n_prob, r0, r1, part, passes = ctx.cfg
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        dev = vf.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        rows_only = g_off is None and g_pos is None   # offset_dec is reached through pred_pos alone
+        wsb = L.lidf_query_decoder_workspace_bytes(P, R, V)
+        if rows_only:
+            wsb = max(wsb, L.lidf_query_decoder_rows_workspace_bytes(R, V, multires, passes[1]))
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        d_vox = torch.empty_like(vf) if ctx.needs_input_grad[2] else None
+        d_ray = torch.empty_like(rf) if ctx.needs_input_grad[3] else None
+        g_pred = g_pred.contiguous().float() if g_pred is not None else None
+        grads_out = []
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            for i, (mod, act, names, ps) in enumerate(((ctx.mods[0], act_p, ctx.names[0], params[:n_prob]),
+                                                       (ctx.mods[1], act_o, ctx.names[1], params[n_prob:]))):
+                saved = dict(zip(names, ps))
+                keep = []
+                dec = _dec._decoder_struct(mod, keep, saved)
+                a = _lib.LidfQueryTrainArgs()
+                a.n_pairs, a.n_rays, a.n_vox = P, R, V
+                a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+                a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+                a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dec)
+                gt = {k: torch.empty_like(saved[k], **f32).contiguous() for k in names}
+                gs = _lib.LidfDecoderGrads()
+                for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
+                    setattr(gs, field, gt[k].data_ptr() if k in gt else None)
+                if i == 1 and rows_only:
+                    gp = g_pred if g_pred is not None else torch.zeros((R, 3), **f32)
+                    _lib.check(L.lidf_query_decoder_backward_rows_f32(
+                        C.byref(a), _lib.ptr(act), _lib.ptr(sel), _lib.ptr(gp), _lib.ptr(ray_dir),
+                        float((r1 - r0) * 1.7320508075688772 * part), _lib.ptr(d_vox), _lib.ptr(d_ray), 1,
+                        C.byref(gs), _lib.ptr(ws), wsb, st))
+                else:
+                    if i == 0:
+                        g = g_prob if g_prob is not None else torch.zeros((P, 1), **f32)
+                    else:   # the tail's adjoint for every pair, + what the loss put on pred_offset itself
+                        g = torch.empty((P,), **f32)
+                        gpos = g_pos.contiguous().float() if g_pos is not None else None
+                        _lib.check(L.lidf_query_tail_backward_f32(
+                            _lib.ptr(gpos), _lib.ptr(g_pred), _lib.ptr(sel), _lib.ptr(pair_ray), _lib.ptr(ray_dir),
+                            R, P, r0, r1, part, _lib.ptr(g), st))
+                        if g_off is not None:
+                            g = g + g_off.reshape(-1)
+                    g = g.detach().reshape(-1).contiguous().float()
+                    _lib.check(L.lidf_query_decoder_backward_f32(
+                        C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 1 if i else 0,
+                        C.byref(gs), _lib.ptr(ws), wsb, st))
+                grads_out += [gt[k] for k in names]
+        base = 19
+        return (None, None, d_vox, d_ray) + (None,) * 15 + tuple(
+            g if ctx.needs_input_grad[base + i] else None for i, g in enumerate(grads_out))
+
+
 def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                      vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                      offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
@@ -1026,9 +1144,16 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
                 _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
                 _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
                 multires, P, _lib.ptr(pe), _lib.current_stream(ray_dir.device)))
-        pred_prob, pred_offset = _query_decoders(prob_dec, offset_dec, vox_feat, rayfeat, pe, pair_off,
-                                                 pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel,
-                                                 multires, multires_views)
+        from . import decoders as _dec
+        _dec._check_supported(prob_dec), _dec._check_supported(offset_dec)
+        pp = [_dec._get(prob_dec, k) for k in _dec._PARAM_ORDER if _dec._has(prob_dec, k)]
+        po = [_dec._get(offset_dec, k) for k in _dec._PARAM_ORDER if _dec._has(offset_dec, k)]
+        pred_prob, pred_offset, pair_pred_pos, sm, mid, pred_pos = _QueryTrainFn.apply(
+            prob_dec, offset_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t, ray_dir, vox_center,
+            pos_rel, multires, multires_views, float(offset_range[0]), float(offset_range[1]), float(part_size),
+            max_pair_id, len(pp), *pp, *po)
+        return {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
+                "pred_prob_end_softmax": sm, "max_pair_id": mid, "pred_pos": pred_pos}
     else:
         rows = _BuildRowsFn.apply(vox_feat, rayfeat, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
                                   vox_center, pos_rel, multires, multires_views)

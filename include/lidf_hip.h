@@ -33,10 +33,10 @@ enum lidf_status {
     LIDF_ERR_HIP = -4           /* a HIP runtime call failed (launch, attribute query)     */
 };
 
-/* ABI version, bumped on any signature or struct-layout change. lidf_version() returns the value the
+/* ABI version, bumped on any signature or struct-layout change and on added entry points. lidf_version() returns the value the
  * library was BUILT with; a binding compiled / written against this header must refuse a library that
  * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
-#define LIDF_ABI_VERSION 8
+#define LIDF_ABI_VERSION 9
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);
@@ -754,6 +754,23 @@ int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float*
                                     const float* g_out, float* d_vox_feat, float* d_rayfeat,
                                     int32_t accumulate_inputs, const LidfDecoderGrads* grads,
                                     void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+/* The same backward when the output gradient is non-zero at ONE pair per ray only — what the reference's
+ * losses give offset_dec: every loss term reaches it through pred_pos = pair_pred_pos[max_pair_id]
+ * (models/pipeline.py:437-454, 468-476), so dL/d pred_offset = scale * (ray_dir[r] . g_pred_pos[r]) at pair
+ * rows[r] of ray r (scale = (offset_range1 - offset_range0) * sqrt(3) * part_size) and exactly zero elsewhere.
+ * Rows with a zero output gradient add exactly zero to every sum of the backward, so the gradients equal those
+ * of lidf_query_decoder_backward_f32 for that g_out up to f32 summation order, from n_rays rows instead of
+ * n_pairs. rows [n_rays] int64: the selected pair of every ray, any value outside [0, n_pairs) for a ray
+ * without one (LidfQueryArgs.max_pair_id). g_pred_pos, ray_dir [n_rays,3]. `act` as written by the forward
+ * for ALL pairs. Workspace: lidf_query_decoder_rows_workspace_bytes(n_rays, n_vox, multires, n_pass). (ABI 9) */
+size_t lidf_query_decoder_rows_workspace_bytes(int64_t n_rays, int64_t n_vox, int32_t multires,
+                                               int32_t n_pass);
+int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* args, const float* act,
+                                         const int64_t* rows, const float* g_pred_pos,
+                                         const float* ray_dir, float scale, float* d_vox_feat,
+                                         float* d_rayfeat, int32_t accumulate_inputs,
+                                         const LidfDecoderGrads* grads, void* workspace,
+                                         size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Positional encoding and PointNet2Stage, training path ----------------------------------------
  * What autograd derives for Embedder.embed (models/implicit_net.py:9-39) and for

@@ -426,9 +426,10 @@ def build_inp_embed(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, feat_
 def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_grid, vox_feat,
           prob_p, off_p, off_kind="IEF", n_iter=2, use_sigmoid=False, multires=8, multires_views=4,
           roi_inp_bbox=8, offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-          chunk=262144, fast_roi=False, roi_out_bbox=2):
+          chunk=262144, fast_roi=False, roi_out_bbox=2, max_pair_id=None):
     """get_embedding + get_pred (models/pipeline.py:338-466) + depth z. Pairs are ray-major.
-    roi_out_bbox: model.roi_out_bbox (:387), 2 in every shipped config."""
+    roi_out_bbox: model.roi_out_bbox (:387), 2 in every shipped config. max_pair_id [R] int64: the selection by
+    ground-truth labels of training while epoch < maxpool_label_epo (:444-446) instead of the arg-max."""
     R = ray_dir.shape[0]
     P = pair_ray.shape[0]
     boxes = roi_boxes(ray_pix.long(), ray_bid.long(), feat_grid.shape[2], feat_grid.shape[3],
@@ -465,7 +466,8 @@ def query(ray_dir, ray_pix, ray_bid, pair_ray, pair_vox, pair_t, pair_off, feat_
         sm = scatter_softmax(pred_prob[:, 0], pair_ray, dim_size=R)
     else:
         sm = torch.empty(0)
-    _, max_pair_id = scatter_max(sm, pair_ray, dim_size=R)
+    if max_pair_id is None:
+        _, max_pair_id = scatter_max(sm, pair_ray, dim_size=R)
     dummy = torch.cat((pair_pred_pos, torch.zeros(1, 3)), 0)  # pipeline.py:452-454
     pred_pos = dummy[max_pair_id]
     return {

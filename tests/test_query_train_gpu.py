@@ -310,3 +310,94 @@ def test_query_gradients_three_passes(cuda):
     close(vfd.grad.cpu(), vf.grad, "vox_feat")
     for k, v in po.items():
         close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
+
+
+def _ref_loss(out, w):
+    """The shape of the reference's training loss (pipeline.py:468-490): every term on offset_dec goes through
+    pred_pos (the selected pair of every ray), the logits receive a gradient at every pair."""
+    return (out["pred_prob_end"][:, 0] * w["prob"]).sum() + (out["pred_pos"] * w["pos"]).sum()
+
+
+@pytest.mark.parametrize("labels", [False, True])
+@pytest.mark.parametrize("ragged,pos_rel,shape", [(False, False, (2, 12, 16, 8)), (True, True, (1, 48, 64, 16))])
+def test_query_gradients_offset_decoder_from_selected_rows(cuda, ragged, pos_rel, shape, labels):
+    """A loss that reaches offset_dec through pred_pos alone: its backward runs over the selected pair of every ray
+    (lidf_query_decoder_backward_rows_f32; rays without a pair, label selections of the dummy row) — gradients
+    against oracle autograd, against the dense backward of the same loss (forced by a zero-weight term on
+    pred_offset), and bit-identical run to run."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(*shape, seed=131, ragged=ragged)
+    R, P, D = scene["R"], scene["P"], scene["D"]
+    gen = torch.Generator().manual_seed(132)
+    w = {"prob": torch.randn(P, generator=gen), "pos": torch.randn(R, 3, generator=gen)}
+    kw = dict(offset_range=(-0.2, 0.2), part_size=0.25)
+    sel = None
+    if labels:   # (pipeline.py:444-446: ground-truth selection; every 7th ray selects the dummy row)
+        cnt = (scene["pair_off"][1:] - scene["pair_off"][:-1]).long()
+        pick = (torch.rand(R, generator=gen) * cnt.clamp(min=1)).long().clamp(max=(cnt - 1).clamp(min=0))
+        sel = torch.where(cnt > 0, scene["pair_off"][:-1].long() + pick, torch.full((R,), P))
+        sel[::7] = P
+    pp = {k: v.clone().requires_grad_(True) for k, v in scene["prob_p"].items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in scene["off_p"].items()}
+    fg = scene["feat_grid"].clone().requires_grad_(True)
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], fg, vf, pp, po,
+                    fast_roi=True, vox_center=scene["vox_center"], pos_rel=pos_rel, max_pair_id=sel, **kw)
+    _ref_loss(ref, w).backward()
+    s = to_dev(scene, cuda)
+    wd = {k: v.to(cuda) for k, v in w.items()}
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
+    runs = {}
+    for name in ("rows", "rows again", "dense"):
+        prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+        off = make_module("IEF", scene["off_p"], D, cuda).train()
+        fgd = s["feat_grid"].clone().requires_grad_(True)
+        vfd = s["vox_feat"].clone().requires_grad_(True)
+        out = lidf_query_train(*args, fgd, vfd, prob, off, vox_center=s["vox_center"], pos_rel=pos_rel,
+                               max_pair_id=None if sel is None else sel.to(cuda), **kw)
+        loss = _ref_loss(out, wd)
+        if name == "dense":
+            loss = loss + 0.0 * out["pred_offset"].sum()
+        loss.backward()
+        g = {"feat_grid": fgd.grad.clone(), "vox_feat": vfd.grad.clone()}
+        g.update({"prob." + k: v.grad.clone() for k, v in prob.named_parameters()})
+        g.update({"off." + k: v.grad.clone() for k, v in off.named_parameters()})
+        runs[name] = g
+    assert (out["max_pair_id"].cpu() == ref["max_pair_id"]).all()
+    differ = [k for k in runs["rows"] if k != "feat_grid" and not torch.equal(runs["rows"][k], runs["rows again"][k])]
+    assert not differ, differ
+
+    def close(a, b, what, tol):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= tol * scale, (what, (a - b).abs().max().item(), scale)
+    for k in runs["rows"]:
+        close(runs["rows"][k], runs["dense"][k], "rows vs dense " + k, 2e-5)
+    # (the larger scene has pre-activations within rounding of the leaky-relu kink — 11 M of them, min |z| 1e-7 —
+    # and a flipped slope moves the input gradient of that one ray by a few 1e-3 of the largest entry, in the dense
+    # backward of prob_dec as much as here: 1e-2 there for everything prob_dec's gradient enters, 5e-4 for offset_dec's)
+    tol_in = 5e-4 if P < 4096 else 1e-2
+    close(runs["rows"]["feat_grid"].cpu(), fg.grad, "feat_grid", tol_in)
+    close(runs["rows"]["vox_feat"].cpu(), vf.grad, "vox_feat", tol_in)
+    for k, v in pp.items():
+        close(runs["rows"]["prob." + k].cpu(), v.grad, "prob." + k, tol_in)
+    for k, v in po.items():
+        close(runs["rows"]["off." + k].cpu(), v.grad, "off." + k, 5e-4)
+    assert runs["rows"]["off.linear_4.weight"].abs().sum().item() > 0
+
+
+def test_query_train_unused_outputs(cuda):
+    """Losses that use one output only: no gradient reaches the other decoder (zeros, not None)."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(1, 8, 12, 6, seed=141)
+    s = to_dev(scene, cuda)
+    D = scene["D"]
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
+    for key, live, dead in (("pred_prob_end", "prob", "off"), ("pred_pos", "off", "prob"),
+                            ("pair_pred_pos", "off", "prob"), ("pred_offset", "off", "prob")):
+        mods = {"prob": make_module("IMNET", scene["prob_p"], D, cuda).train(),
+                "off": make_module("IEF", scene["off_p"], D, cuda).train()}
+        out = lidf_query_train(*args, s["feat_grid"], s["vox_feat"], mods["prob"], mods["off"])
+        out[key].sum().backward()
+        assert all(p.grad is not None and (p.grad == 0).all() for p in mods[dead].parameters()), key
+        assert mods[live].linear_2.weight.grad.abs().sum().item() > 0, key
