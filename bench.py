@@ -439,7 +439,7 @@ def secondary(args):
             fg.grad = None
             vf.grad = None
             o = lidf_query_train(sd["ray_dir"], sd["ray_pix"], sd["ray_bid"], sd["pair_off"], sd["pair_ray"],
-                                 sd["pair_vox"], sd["pair_t"], fg, vf, prob, off)
+                                 sd["pair_vox"], sd["pair_t"], fg, vf, prob, off, offsets=args.offsets)
             # the reference's loss structure (models/pipeline.py:468-490): position loss on pred_pos (the selected
             # pair of every ray), ray-wise cross-entropy of the logits at a label pair; --dense-offset-grad adds a
             # term on pred_offset itself, which no loss of the reference has (every pair then carries a gradient)
@@ -579,8 +579,10 @@ def secondary(args):
         fwd = fwd_prob + fwd_off
         flop_exec, basis = 3.0 * fwd, "FLOP of the executed formulation (3 x forward), not an instruction count"
         if args.workload == "train-query" and not args.dense_offset_grad:
-            # offset_dec's backward (2 x its forward) over one pair per ray instead of every pair
-            flop_exec = fwd + 2.0 * fwd_prob + 2.0 * fwd_off / max(args.samples // 8, 1)
+            # offset_dec's backward (2 x its forward) over one pair per ray instead of every pair (--offsets selected:
+            # its forward as well)
+            npr = max(args.samples // 8, 1)
+            flop_exec = fwd_prob + fwd_off / (npr if args.offsets == "selected" else 1) + 2.0 * fwd_prob + 2.0 * fwd_off / npr
             basis = ("FLOP of the executed formulation: forward of both decoders on every pair, backward (2 x forward) of "
                      "prob_dec on every pair and of offset_dec on the selected pair of every ray; not an instruction count")
     ach = (bytes_alg * P / (kern_ms * 1e-3) / 1e9) if hbm else (flop_exec * P / (kern_ms * 1e-3) / 1e12)

@@ -218,8 +218,12 @@ SIGNATURES = {
     "lidf_query_decoder_backward_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, _I,
                                                   C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
     "lidf_query_decoder_rows_workspace_bytes": (_SZ, [_I64, _I64, C.c_int32, C.c_int32]),
-    "lidf_query_decoder_backward_rows_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, _P, _P, _P, C.c_float, _P, _P,
-                                                       _I, C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
+    "lidf_query_decoder_backward_rows_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), _P, C.c_int32, _P, _P, _P, _P,
+                                                       C.c_float, _P, _P, _I, C.POINTER(LidfDecoderGrads), _P,
+                                                       C.c_size_t, _P]),
+    "lidf_query_forward_train_selected_f32": (C.c_int, [C.POINTER(LidfQueryTrainArgs), C.POINTER(LidfDecoder), _P, _P,
+                                                        _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P,
+                                                        _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "lidf_embed_backward_f32": (C.c_int, [_P, _P, _I64, _I, _P, _P]),
     "lidf_pointnet_train_act_floats": (_SZ, [_I64, _I64]),
     "lidf_pointnet_train_workspace_bytes": (_SZ, [_I64, _I64]),

@@ -2773,6 +2773,120 @@ LIDF_API int lidf_query_forward_train_f32(const LidfQueryTrainArgs* q, const Lid
     return LIDF_OK;
 }
 
+// The training forward with offset_dec on the selected pair of every ray only (the training counterpart of
+// LidfQueryArgs.offsets_selected): prob_dec on every pair with its activations kept, the per-ray softmax / arg-max,
+// offset_dec on the one-pair-per-ray list with ITS activations kept (R rows), positions.
+extern "C" hipError_t lidf_launch_sel_from_ids(const long long*, const int*, const float*, long long, long long, int*,
+                                               int*, float*, hipStream_t);
+LIDF_API int lidf_query_forward_train_selected_f32(const LidfQueryTrainArgs* q, const LidfDecoder* offset_dec,
+                                                     const float* pair_t, const float* ray_dir,
+                                                     const float* vox_center, int32_t pos_rel, float offset_range0,
+                                                     float offset_range1, float part_size,
+                                                     const int64_t* max_pair_id_in, float* out_prob, float* softmax,
+                                                     int64_t* max_pair_id, float* pred_offset, float* pair_pred_pos,
+                                                     float* pred_pos, float* act_prob, float* act_off_rows,
+                                                     void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
+    int rc;
+    if ((rc = check_qtrain(q))) return rc;
+    if ((rc = check_decoder(offset_dec))) return rc;
+    const int64_t P = q->n_pairs, R = q->n_rays, V = q->n_vox;
+    if (P > 0x7fffffffLL || R > 0x15555555LL) return LIDF_ERR_UNSUPPORTED;
+    const int L = q->multires, Lv = q->multires_views;
+    if ((rc = check_query_model(q->dec, offset_dec, L, Lv, LIDF_PRECISION_F32))) return rc;
+    if (R == 0) return LIDF_OK;
+    if (!max_pair_id || !pred_pos) return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 0) {   // every ray selects the dummy row (pipeline.py:452-454)
+        CHECK_HIP(lidf_launch_ray_reduce_dev(nullptr, nullptr, q->pair_off, R, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                                             nullptr, (long long*)max_pair_id, pred_pos, nullptr, st, nullptr, nullptr,
+                                             nullptr, nullptr, nullptr));
+        return LIDF_OK;
+    }
+    if (!pair_t || !ray_dir || !out_prob || !softmax || !pred_offset || !pair_pred_pos || !act_prob || !act_off_rows ||
+        (pos_rel && !vox_center))
+        return LIDF_ERR_BAD_ARG;
+    const QueryWs w = query_ws(R, V, L, Lv);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    if ((rc = pack_query_weights(q->dec, offset_dec, L, Lv, LIDF_PRECISION_F32, ws, st))) return rc;
+    const float* aux_pts = (const float*)(ws + w.aux_pts);
+    const float* stream_pts = (const float*)(ws + w.stream_pts);
+    float* voxpart = (float*)(ws + w.voxpart);
+    float* raypart = (float*)(ws + w.raypart);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    const int E = 3 + 6 * L, Ed = 3 + 6 * Lv;
+    L1Map mf = {};
+    mf.L = L;
+    const StreamLayout lf = lidf_make_layout(2, LIDF_MODE_FUSED, mf);
+    const L1Map mv = rows_map(128, 0, 0, 0, 1);
+    const StreamLayout lv = lidf_make_layout(2, LIDF_MODE_L1ONLY, mv);
+    const L1Map mr = rows_map(128, 128, Ed, 256 + 2 * E, 0);
+    const StreamLayout lr = lidf_make_layout(2, LIDF_MODE_L1ONLY, mr);
+    {   // per-voxel and per-ray parts of layer 1, both nets: [V,512], [R,512]
+        PointsArgs av = {};
+        av.stream = (const float*)(ws + w.stream_vox); av.aux = aux_pts;
+        av.nets = 2; av.l1_quads = lv.l1_quads; av.net_quads = lv.net_quads;
+        av.n = V; av.X = q->vox_feat; av.ldx = 128;
+        av.D = mv.D; av.KQ1 = mv.KQ1; av.has_bias = 1; av.out_base = voxpart;
+        PointsArgs a = {};
+        a.stream = (const float*)(ws + w.stream_ray); a.aux = aux_pts;
+        a.nets = 2; a.l1_quads = lr.l1_quads; a.net_quads = lr.net_quads;
+        a.n = R; a.X = q->rayfeat; a.ldx = 128 + Ed;
+        a.D = mr.D; a.KQ1 = mr.KQ1; a.has_bias = 0; a.out_base = raypart;
+        CHECK_HIP(lidf_launch_l1only_pair(a, av, nullptr, cus, st));
+    }
+    PointsArgs a = {};
+    a.stream = stream_pts; a.aux = aux_pts;
+    a.nets = 1; a.l1_quads = lf.l1_quads; a.net_quads = lf.net_quads;
+    a.part_ld = 512; a.part_off = 0;
+    a.n = P;
+    fill_net_args(a, 0, q->dec, out_prob, 0);
+    a.pair_ray = q->pair_ray; a.pair_vox = q->pair_vox; a.pair_t = pair_t;
+    a.ray_dir = ray_dir; a.voxpart = voxpart; a.raypart = raypart;
+    a.vox_center = vox_center; a.pos_rel = pos_rel; a.L = L;
+    a.r0 = offset_range0;
+    a.rscale = offset_range1 - offset_range0;
+    a.sqrt3 = (float)1.7320508075688772;
+    a.part_size = part_size;
+    a.tr_passes[0] = act_prob + (size_t)(V + R) * LIDF_H1;
+    a.tr_pre[0] = a.tr_passes[0] + qact_pass(P);
+    a.tr_pass_floats = (long long)qact_pass(P);
+    const long long nt = (P + 127) / 128;
+    CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, a, (int)(nt < cus ? nt : cus), st));
+    char* sb = ws + w.sel;
+    const size_t Rc = (size_t)R;
+    int* sel_ray = (int*)sb;
+    int* sel_vox = (int*)(sb + Rc * 4);
+    float* sel_t = (float*)(sb + Rc * 8);
+    float* off_sel = (float*)(sb + Rc * 16);
+    float* pos_sel = (float*)(sb + Rc * 20);
+    const bool given = max_pair_id_in != nullptr;
+    CHECK_HIP(lidf_launch_ray_reduce_dev(out_prob, nullptr, q->pair_off, R, P, nullptr, nullptr, nullptr, nullptr, 0,
+                                         softmax, (long long*)max_pair_id, nullptr, nullptr, st, q->pair_vox, pair_t,
+                                         given ? nullptr : sel_ray, sel_vox, sel_t));
+    if (given)
+        CHECK_HIP(lidf_launch_sel_from_ids((const long long*)max_pair_id_in, q->pair_vox, pair_t, R, P, sel_ray, sel_vox,
+                                           sel_t, st));
+    const int npo = offset_dec->is_ief ? offset_dec->n_iter : 1;
+    PointsArgs ao = a;
+    ao.stream = stream_pts + (size_t)lf.net_quads * 256; ao.aux = aux_pts + LIDF_AUX_FLOATS;
+    ao.part_off = 256;
+    ao.n = R;
+    fill_net_args(ao, 0, offset_dec, off_sel, 1);
+    ao.pair_ray = sel_ray; ao.pair_vox = sel_vox; ao.pair_t = sel_t;
+    ao.pair_pred_pos = pos_sel;
+    ao.tr_passes[0] = act_off_rows + (size_t)(V + R) * LIDF_H1;
+    ao.tr_pre[0] = ao.tr_passes[0] + (size_t)npo * qact_pass(R);
+    ao.tr_pass_floats = (long long)qact_pass(R);
+    const long long ntr = (R + 127) / 128;
+    CHECK_HIP(lidf_launch_points(LIDF_MODE_FUSED, ao, (int)(ntr < cus ? ntr : cus), st));
+    CHECK_HIP(lidf_launch_selected_finish((const long long*)(given ? max_pair_id_in : max_pair_id), off_sel, pos_sel, R, P,
+                                          nullptr, nullptr, nullptr, nullptr, 0, pred_offset, pair_pred_pos, pred_pos,
+                                          nullptr, st));
+    return LIDF_OK;
+}
+
 // The factorised decoder backward (see qdec_forward_impl for E2 and the column layout of W1).
 struct QdecBwd {
     int E2;
@@ -2962,11 +3076,12 @@ LIDF_API size_t lidf_query_decoder_rows_workspace_bytes(int64_t n_rays, int64_t 
     return qrows_ws(n_rays, n_vox, 2 * (3 + 6 * multires), n_pass).total;
 }
 extern "C" hipError_t lidf_launch_gather_sel_rows(const float*, long long, int, const long long*, long long,
-                                                  const int*, const float*, int, const float*, const float*, float,
-                                                  float*, int*, float*, float*, int*, hipStream_t);
-LIDF_API int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* q, const float* act,
+                                                  const int*, const float*, int, const float*, const float*,
+                                                  const float*, float, float*, int*, float*, float*, int*, hipStream_t);
+LIDF_API int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* q, const float* act, int32_t act_is_rows,
                                                     const int64_t* rows, const float* g_pred_pos,
-                                                    const float* ray_dir, float scale, float* d_vox_feat,
+                                                    const float* g_offset_rows, const float* ray_dir, float scale,
+                                                    float* d_vox_feat,
                                                     float* d_rayfeat, int32_t accumulate_inputs,
                                                     const LidfDecoderGrads* grads, void* workspace,
                                                     size_t workspace_bytes, lidf_stream_t stream) {
@@ -2988,7 +3103,7 @@ LIDF_API int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* q, c
         if (d_rayfeat && R > 0) CHECK_HIP(hipMemsetAsync(d_rayfeat, 0, (size_t)R * (128 + Ed) * 4, st));
     }
     if (P == 0 || R == 0) return LIDF_OK;
-    if (!act || !rows || !g_pred_pos || !ray_dir) return LIDF_ERR_BAD_ARG;
+    if (!act || !rows || !ray_dir) return LIDF_ERR_BAD_ARG;
     const QRowsWs l = qrows_ws(R, V, E2, npass);
     if (!workspace || workspace_bytes < l.total) return LIDF_ERR_WORKSPACE;
     int cus;
@@ -2998,10 +3113,12 @@ LIDF_API int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* q, c
     int* poff = (int*)(ws + l.poff);
     float* g = (float*)(ws + l.g);
     float* pe = (float*)(ws + l.pe);
-    float* passes = (float*)(ws + l.act);
     const float* passes_src = act + (size_t)(V + R) * LIDF_H1;   // behind voxpart | raypart (lidf_query_decoder_act_floats)
-    CHECK_HIP(lidf_launch_gather_sel_rows(passes_src, P, npass, (const long long*)rows, R, q->pair_vox, q->pe, E2,
-                                          g_pred_pos, ray_dir, scale, passes, pvox, pe, g, poff, st));
+    // (act_is_rows: the activations are the list's own — lidf_query_forward_train_selected_f32 — and stay where they are)
+    const float* passes = act_is_rows ? passes_src : (const float*)(ws + l.act);
+    CHECK_HIP(lidf_launch_gather_sel_rows(act_is_rows ? nullptr : passes_src, P, npass, (const long long*)rows, R,
+                                          q->pair_vox, q->pe, E2, g_pred_pos, g_offset_rows, ray_dir, scale,
+                                          (float*)(ws + l.act), pvox, pe, g, poff, st));
     LidfQueryTrainArgs qc = *q;
     qc.n_pairs = R;
     qc.pair_off = poff; qc.pair_ray = poff; qc.pair_vox = pvox; qc.pe = pe;   // (pair r on ray r: pair_ray = 0..R-1 = poff)

@@ -730,6 +730,28 @@ extern "C" hipError_t lidf_launch_selected_finish(const long long* maxid, const 
                        pred_pos, depth);
     return hipGetLastError();
 }
+// The one-pair-per-ray list of a GIVEN selection (training with ground-truth labels, pipeline.py:444-446): what
+// lidf_ray_reduce_kernel leaves for its own arg-max. A ray whose id is outside [0, P) takes voxel 0 and t = 0.
+__global__ void lidf_sel_from_ids_kernel(const long long* __restrict__ id, const int* __restrict__ pair_vox,
+                                         const float* __restrict__ pair_t, long long R, long long P,
+                                         int* __restrict__ sel_ray, int* __restrict__ sel_vox,
+                                         float* __restrict__ sel_t) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long m = id[r];
+    const bool empty = m < 0 || m >= P;
+    sel_ray[r] = (int)r;
+    sel_vox[r] = empty ? 0 : pair_vox[m];
+    *(f32x2*)(sel_t + 2 * r) = empty ? f32x2{0.f, 0.f} : *(const f32x2*)(pair_t + 2 * (size_t)m);
+}
+extern "C" hipError_t lidf_launch_sel_from_ids(const long long* id, const int* pair_vox, const float* pair_t,
+                                               long long R, long long P, int* sel_ray, int* sel_vox, float* sel_t,
+                                               hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lidf_sel_from_ids_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, id, pair_vox,
+                       pair_t, R, P, sel_ray, sel_vox, sel_t);
+    return hipGetLastError();
+}
 extern "C" hipError_t lidf_launch_ray_reduce(const float* prob, const float* pos, const int* off,
                                              long long R, long long P, const int* ray_bid,
                                              const int* ray_flat, long long hw, float* softmax,

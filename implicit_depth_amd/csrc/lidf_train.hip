@@ -1585,7 +1585,7 @@ extern "C" hipError_t lidf_launch_pair_pos_backward(const float* g_pos, const fl
 __global__ void __launch_bounds__(256) lidf_gather_sel_rows_kernel(
     const float* __restrict__ act, long long P, int npass, const long long* __restrict__ rows, long long R,
     const int* __restrict__ pair_vox, const float* __restrict__ pe, int E2, const float* __restrict__ g_pred,
-    const float* __restrict__ ray_dir, float k, float* __restrict__ act_dst, int* __restrict__ pvox,
+    const float* __restrict__ g_extra, const float* __restrict__ ray_dir, float k, float* __restrict__ act_dst, int* __restrict__ pvox,
     float* __restrict__ pe_dst, float* __restrict__ g_dst, int* __restrict__ poff) {
     const long long r = (long long)blockIdx.x * 2 + (threadIdx.x >> 7);
     const int c = threadIdx.x & 127;
@@ -1593,7 +1593,7 @@ __global__ void __launch_bounds__(256) lidf_gather_sel_rows_kernel(
     const long long id = rows[r];
     const bool has = id >= 0 && id < P;
     const size_t p = has ? (size_t)id : 0;
-    for (int ps = 0; ps < npass; ++ps) {
+    for (int ps = 0; act && ps < npass; ++ps) {   // (act == NULL: the activations are those of the list already)
         const float* src = act + (size_t)ps * P * LIDF_ACT_ROW_FLOATS;
         float* dst = act_dst + (size_t)ps * R * LIDF_ACT_ROW_FLOATS;
         if (c < 64) {
@@ -1617,26 +1617,30 @@ __global__ void __launch_bounds__(256) lidf_gather_sel_rows_kernel(
         }
     }
     // the pre-activation of the last pass sits behind the passes
-    if (c == 116)
+    if (c == 116 && act)
         act_dst[(size_t)npass * R * LIDF_ACT_ROW_FLOATS + r] = act[(size_t)npass * P * LIDF_ACT_ROW_FLOATS + p];
     if (c == 117) {
         pvox[r] = pair_vox[p];
         poff[r] = (int)r;
         if (r == R - 1) poff[R] = (int)R;
         // (the adjoint of pred_pos = enter + k off dir, as lidf_pair_pos_backward_kernel forms it)
-        g_dst[r] = has ? k * (ray_dir[3 * r] * g_pred[3 * r] + ray_dir[3 * r + 1] * g_pred[3 * r + 1] +
-                              ray_dir[3 * r + 2] * g_pred[3 * r + 2])
-                       : 0.f;
+        float gv = 0.f;
+        if (has && g_pred)
+            gv = k * (ray_dir[3 * r] * g_pred[3 * r] + ray_dir[3 * r + 1] * g_pred[3 * r + 1] +
+                      ray_dir[3 * r + 2] * g_pred[3 * r + 2]);
+        if (has && g_extra) gv += g_extra[r];
+        g_dst[r] = gv;
     }
     for (int j = c; j < E2; j += 128) pe_dst[(size_t)r * E2 + j] = pe[p * E2 + j];
 }
 extern "C" hipError_t lidf_launch_gather_sel_rows(const float* act, long long P, int npass, const long long* rows,
                                                   long long R, const int* pair_vox, const float* pe, int E2,
-                                                  const float* g_pred, const float* ray_dir, float k, float* act_dst,
-                                                  int* pvox, float* pe_dst, float* g_dst, int* poff, hipStream_t st) {
+                                                  const float* g_pred, const float* g_extra, const float* ray_dir,
+                                                  float k, float* act_dst, int* pvox, float* pe_dst, float* g_dst,
+                                                  int* poff, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(lidf_gather_sel_rows_kernel, dim3((unsigned)((R + 1) / 2)), dim3(256), 0, st, act, P, npass,
-                       rows, R, pair_vox, pe, E2, g_pred, ray_dir, k, act_dst, pvox, pe_dst, g_dst, poff);
+                       rows, R, pair_vox, pe, E2, g_pred, g_extra, ray_dir, k, act_dst, pvox, pe_dst, g_dst, poff);
     return hipGetLastError();
 }
 

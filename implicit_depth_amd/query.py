@@ -894,6 +894,7 @@ class _QueryDecodersFn(torch.autograd.Function):
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=vf.device)
         d_vox = torch.empty_like(vf) if ctx.needs_input_grad[2] else None
         d_ray = torch.empty_like(rf) if ctx.needs_input_grad[3] else None
+        g_pred = g_pred.contiguous().float() if g_pred is not None else None
         grads_out = []
         for i, (mod, act, g_out, names, ps) in enumerate((
                 (ctx.mods[0], act_p, g_prob, ctx.names[0], params[:n_prob]),
@@ -994,11 +995,16 @@ class _QueryTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob_mod, off_mod, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t,
-                ray_dir, vox_center, pos_rel, multires, multires_views, r0, r1, part, mid_in, n_prob, *params):
+                ray_dir, vox_center, pos_rel, multires, multires_views, r0, r1, part, mid_in, selected, n_prob,
+                *params):
         from . import decoders as _dec
         vf, rf = vox_feat.detach().contiguous(), rayfeat.detach().contiguous()
         dev = vf.device
         P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        if selected:
+            return _QueryTrainFn._forward_selected(ctx, prob_mod, off_mod, vf, rf, pe, pair_off, pair_ray, pair_vox,
+                                                   pair_t, ray_dir, vox_center, pos_rel, multires, multires_views,
+                                                   r0, r1, part, mid_in, n_prob, params)
         keep = []
         dp, do = _dec._decoder_struct(prob_mod, keep), _dec._decoder_struct(off_mod, keep)
         a = _lib.LidfQueryTrainArgs()
@@ -1031,9 +1037,53 @@ class _QueryTrainFn(torch.autograd.Function):
                 _lib.ptr(mid), _lib.ptr(pred), st))
         sel = mid_in if mid_in is not None else mid
         ctx.mods = (prob_mod, off_mod)
-        ctx.cfg = (multires, multires_views, n_prob, r0, r1, part, passes)
+        ctx.cfg = (multires, multires_views, n_prob, r0, r1, part, passes, False)
         ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
         ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, acts[0], acts[1], *params)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(sm, mid)
+        return prob, off, pos, sm, sel if mid_in is not None else mid, pred
+
+    @staticmethod
+    def _forward_selected(ctx, prob_mod, off_mod, vf, rf, pe, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
+                          vox_center, pos_rel, multires, multires_views, r0, r1, part, mid_in, n_prob, params):
+        """offsets="selected": offset_dec runs on the selected pair of every ray only, forward and backward
+        (lidf_query_forward_train_selected_f32); pred_offset / pair_pred_pos are zero at every other pair."""
+        from . import decoders as _dec
+        dev = vf.device
+        P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
+        keep = []
+        dp, do = _dec._decoder_struct(prob_mod, keep), _dec._decoder_struct(off_mod, keep)
+        a = _lib.LidfQueryTrainArgs()
+        a.n_pairs, a.n_rays, a.n_vox = P, R, V
+        a.pair_off, a.pair_ray, a.pair_vox = pair_off.data_ptr(), pair_ray.data_ptr(), pair_vox.data_ptr()
+        a.pe, a.multires, a.multires_views = pe.data_ptr(), multires, multires_views
+        a.vox_feat, a.rayfeat, a.dec = vf.data_ptr(), rf.data_ptr(), C.pointer(dp)
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        passes = [int(m.n_iter) if isinstance(m, _dec.IEF) else 1 for m in (prob_mod, off_mod)]
+        act_p = torch.empty((max(L.lidf_query_decoder_act_floats(P, R, V, passes[0]), 1),), **f32)
+        act_o = torch.empty((max(L.lidf_query_decoder_act_floats(R, R, V, passes[1]), 1),), **f32)
+        wsb = L.lidf_query_forward_train_workspace_bytes(R, V)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        prob = torch.empty((P, 1), **f32)
+        off, pos = torch.zeros((P, 1), **f32), torch.zeros((P, 3), **f32)
+        sm = torch.empty((P,), **f32)
+        mid = torch.empty((R,), dtype=torch.int64, device=dev)
+        pred = torch.empty((R, 3), **f32)
+        if mid_in is not None:
+            mid_in = mid_in.to(torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_query_forward_train_selected_f32(
+                C.byref(a), C.byref(do), _lib.ptr(pair_t), _lib.ptr(ray_dir),
+                _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0, r0, r1, part,
+                _lib.ptr(mid_in), _lib.ptr(prob), _lib.ptr(sm), _lib.ptr(mid), _lib.ptr(off), _lib.ptr(pos),
+                _lib.ptr(pred), _lib.ptr(act_p), _lib.ptr(act_o), _lib.ptr(ws), wsb, _lib.current_stream(dev)))
+        sel = mid_in if mid_in is not None else mid
+        ctx.mods = (prob_mod, off_mod)
+        ctx.cfg = (multires, multires_views, n_prob, r0, r1, part, passes, True)
+        ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
+        ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, act_p, act_o, *params)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(sm, mid)
         return prob, off, pos, sm, sel if mid_in is not None else mid, pred
@@ -1043,19 +1093,30 @@ class _QueryTrainFn(torch.autograd.Function):
         from . import decoders as _dec
         vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, act_p, act_o = ctx.saved_tensors[:10]
         params = ctx.saved_tensors[10:]
-        multires, multires_views, n_prob, r0, r1, part, passes = ctx.cfg
+        multires, multires_views, n_prob, r0, r1, part, passes, selected = ctx.cfg
         P, R, V = pair_ray.shape[0], rf.shape[0], vf.shape[0]
         dev = vf.device
         f32 = dict(dtype=torch.float32, device=dev)
         L = _lib.lib()
-        rows_only = g_off is None and g_pos is None   # offset_dec is reached through pred_pos alone
+        # offset_dec is reached through pred_pos alone — or ran on the selected pairs only in the forward
+        rows_only = selected or (g_off is None and g_pos is None)
+        g_off_rows = None
+        if selected and P > 0 and (g_off is not None or g_pos is not None):
+            # (gradients the loss put on the selected pairs' own slots of pair_pred_pos / pred_offset; the other
+            # entries of those outputs are constants)
+            has = (sel >= 0) & (sel < P)
+            at = sel.clamp(0, P - 1)
+            if g_pos is not None:
+                extra = torch.where(has[:, None], g_pos.reshape(P, 3)[at], torch.zeros((), **f32))
+                g_pred = extra if g_pred is None else g_pred + extra
+            if g_off is not None:
+                g_off_rows = torch.where(has, g_off.reshape(-1)[at], torch.zeros((), **f32)).contiguous().float()
         wsb = L.lidf_query_decoder_workspace_bytes(P, R, V)
         if rows_only:
             wsb = max(wsb, L.lidf_query_decoder_rows_workspace_bytes(R, V, multires, passes[1]))
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
         d_vox = torch.empty_like(vf) if ctx.needs_input_grad[2] else None
         d_ray = torch.empty_like(rf) if ctx.needs_input_grad[3] else None
-        g_pred = g_pred.contiguous().float() if g_pred is not None else None
         grads_out = []
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
@@ -1074,11 +1135,10 @@ class _QueryTrainFn(torch.autograd.Function):
                 for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
                     setattr(gs, field, gt[k].data_ptr() if k in gt else None)
                 if i == 1 and rows_only:
-                    gp = g_pred if g_pred is not None else torch.zeros((R, 3), **f32)
                     _lib.check(L.lidf_query_decoder_backward_rows_f32(
-                        C.byref(a), _lib.ptr(act), _lib.ptr(sel), _lib.ptr(gp), _lib.ptr(ray_dir),
-                        float((r1 - r0) * 1.7320508075688772 * part), _lib.ptr(d_vox), _lib.ptr(d_ray), 1,
-                        C.byref(gs), _lib.ptr(ws), wsb, st))
+                        C.byref(a), _lib.ptr(act), 1 if selected else 0, _lib.ptr(sel), _lib.ptr(g_pred),
+                        _lib.ptr(g_off_rows), _lib.ptr(ray_dir), float((r1 - r0) * 1.7320508075688772 * part),
+                        _lib.ptr(d_vox), _lib.ptr(d_ray), 1, C.byref(gs), _lib.ptr(ws), wsb, st))
                 else:
                     if i == 0:
                         g = g_prob if g_prob is not None else torch.zeros((P, 1), **f32)
@@ -1095,15 +1155,15 @@ class _QueryTrainFn(torch.autograd.Function):
                         C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 1 if i else 0,
                         C.byref(gs), _lib.ptr(ws), wsb, st))
                 grads_out += [gt[k] for k in names]
-        base = 19
-        return (None, None, d_vox, d_ray) + (None,) * 15 + tuple(
+        base = 20
+        return (None, None, d_vox, d_ray) + (None,) * 16 + tuple(
             g if ctx.needs_input_grad[base + i] else None for i, g in enumerate(grads_out))
 
 
 def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                      vox_feat, prob_dec, offset_dec, multires=8, multires_views=4, roi_inp_bbox=8,
                      offset_range=(0.0, 1.0), part_size=0.25, vox_center=None, pos_rel=False,
-                     factorised=True, max_pair_id=None):
+                     factorised=True, max_pair_id=None, offsets="all"):
     """Differentiable get_embedding + get_pred (models/pipeline.py:338-466) for training
     (train_lidf.py:393-396): gradients reach feat_grid (through RoIAlign), vox_feat and every
     decoder parameter, all through liblidf_hip — ROI pooling, the decoder input rows, the decoders'
@@ -1116,8 +1176,16 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
     per-ray partial products, only the positional encodings as per-pair rows, the layer-1 gradient
     reduced per voxel / per ray before it meets a weight; factorised=False materialises the
     reference's [P,385] decoder input rows (same results, more memory and work).
+    offsets="selected" (opt-in, as in lidf_query): offset_dec runs on the selected pair of every ray only, in the
+    forward as well — pred_offset / pair_pred_pos are zero at every other pair, which nothing in the reference reads
+    (pred_offset is a local of get_pred, pair_pred_pos is stored at pipeline.py:461 and never used); pred_pos, the
+    logits and every gradient of a loss on them are those of offsets="all".
     Returns pred_offset, pred_prob_end [P,1], pair_pred_pos [P,3], pred_prob_end_softmax [P],
     max_pair_id [R] (P for an empty ray) and pred_pos [R,3]."""
+    if offsets not in ("all", "selected"):
+        raise ValueError("offsets must be 'all' or 'selected'")
+    if offsets == "selected" and not factorised:
+        raise RuntimeError("offsets='selected' needs the factorised path")
     ray_pix, ray_bid = _as_i32(ray_pix, "ray_pix"), _as_i32(ray_bid, "ray_bid")   # int64 accepted
     _lib.require_cuda(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid,
                       vox_feat, vox_center,
@@ -1151,7 +1219,7 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
         pred_prob, pred_offset, pair_pred_pos, sm, mid, pred_pos = _QueryTrainFn.apply(
             prob_dec, offset_dec, vox_feat, rayfeat, pe, pair_off, pair_ray, pair_vox, pair_t, ray_dir, vox_center,
             pos_rel, multires, multires_views, float(offset_range[0]), float(offset_range[1]), float(part_size),
-            max_pair_id, len(pp), *pp, *po)
+            max_pair_id, offsets == "selected", len(pp), *pp, *po)
         return {"pred_offset": pred_offset, "pred_prob_end": pred_prob, "pair_pred_pos": pair_pred_pos,
                 "pred_prob_end_softmax": sm, "max_pair_id": mid, "pred_pos": pred_pos}
     else:

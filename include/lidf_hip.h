@@ -761,16 +761,36 @@ int lidf_query_decoder_backward_f32(const LidfQueryTrainArgs* args, const float*
  * Rows with a zero output gradient add exactly zero to every sum of the backward, so the gradients equal those
  * of lidf_query_decoder_backward_f32 for that g_out up to f32 summation order, from n_rays rows instead of
  * n_pairs. rows [n_rays] int64: the selected pair of every ray, any value outside [0, n_pairs) for a ray
- * without one (LidfQueryArgs.max_pair_id). g_pred_pos, ray_dir [n_rays,3]. `act` as written by the forward
- * for ALL pairs. Workspace: lidf_query_decoder_rows_workspace_bytes(n_rays, n_vox, multires, n_pass). (ABI 9) */
+ * without one (LidfQueryArgs.max_pair_id). g_pred_pos, ray_dir [n_rays,3]; g_offset_rows [n_rays] (optional):
+ * a gradient on pred_offset[rows[r]] itself, added. act_is_rows = 0: `act` as the forward wrote it for ALL pairs
+ * (lidf_query_forward_train_f32), the selected rows are gathered; 1: `act` is the one-pair-per-ray list's own
+ * (act_off_rows of lidf_query_forward_train_selected_f32).
+ * Workspace: lidf_query_decoder_rows_workspace_bytes(n_rays, n_vox, multires, n_pass). (ABI 9)              */
 size_t lidf_query_decoder_rows_workspace_bytes(int64_t n_rays, int64_t n_vox, int32_t multires,
                                                int32_t n_pass);
-int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* args, const float* act,
+int lidf_query_decoder_backward_rows_f32(const LidfQueryTrainArgs* args, const float* act, int32_t act_is_rows,
                                          const int64_t* rows, const float* g_pred_pos,
-                                         const float* ray_dir, float scale, float* d_vox_feat,
-                                         float* d_rayfeat, int32_t accumulate_inputs,
+                                         const float* g_offset_rows, const float* ray_dir, float scale,
+                                         float* d_vox_feat, float* d_rayfeat, int32_t accumulate_inputs,
                                          const LidfDecoderGrads* grads, void* workspace,
                                          size_t workspace_bytes, lidf_stream_t stream);
+/* The training forward with offset_dec on the selected pair of every ray only — the training counterpart of
+ * LidfQueryArgs.offsets_selected, opt-in: nothing in the reference reads an offset of another pair
+ * (pred_offset is a local of get_pred, pair_pred_pos is stored at pipeline.py:461 and never read). prob_dec on
+ * every pair (activations kept in act_prob, lidf_query_decoder_act_floats(n_pairs, n_rays, n_vox, 1)), per-ray
+ * softmax and arg-max (max_pair_id [R]: the arg-max also when max_pair_id_in overrides the selection,
+ * pipeline.py:444-446), offset_dec on the one-pair-per-ray list (activations kept in act_off_rows,
+ * lidf_query_decoder_act_floats(n_rays, n_rays, n_vox, n_iter)), pred_pos [R,3]; pred_offset [P] and
+ * pair_pred_pos [P,3] receive the selected pairs' values, their other entries are left as the caller set them.
+ * Workspace: lidf_query_forward_train_workspace_bytes. (ABI 9)                                                */
+int lidf_query_forward_train_selected_f32(const LidfQueryTrainArgs* args, const LidfDecoder* offset_dec,
+                                          const float* pair_t, const float* ray_dir, const float* vox_center,
+                                          int32_t pos_rel, float offset_range0, float offset_range1,
+                                          float part_size, const int64_t* max_pair_id_in, float* out_prob,
+                                          float* softmax, int64_t* max_pair_id, float* pred_offset,
+                                          float* pair_pred_pos, float* pred_pos, float* act_prob,
+                                          float* act_off_rows, void* workspace, size_t workspace_bytes,
+                                          lidf_stream_t stream);
 
 /* ---- Positional encoding and PointNet2Stage, training path ----------------------------------------
  * What autograd derives for Embedder.embed (models/implicit_net.py:9-39) and for

@@ -401,3 +401,82 @@ def test_query_train_unused_outputs(cuda):
         out[key].sum().backward()
         assert all(p.grad is not None and (p.grad == 0).all() for p in mods[dead].parameters()), key
         assert mods[live].linear_2.weight.grad.abs().sum().item() > 0, key
+
+
+@pytest.mark.parametrize("labels", [False, True])
+@pytest.mark.parametrize("ragged,pos_rel,shape", [(False, False, (2, 12, 16, 8)), (True, True, (1, 48, 64, 16))])
+def test_query_train_offsets_selected(cuda, ragged, pos_rel, shape, labels):
+    """offsets="selected" in training (lidf_query_forward_train_selected_f32): offset_dec runs on the selected pair of
+    every ray only, forward and backward. The logits, softmax, selection, pred_pos and the selected pairs' slots of
+    pred_offset / pair_pred_pos equal offsets="all" (the other slots are zero), and so do the gradients of a loss
+    on pred_pos and the logits; a loss on the selected slots of pair_pred_pos / pred_offset is differentiated too."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(*shape, seed=151, ragged=ragged)
+    R, P, D = scene["R"], scene["P"], scene["D"]
+    gen = torch.Generator().manual_seed(152)
+    w = {"prob": torch.randn(P, generator=gen).to(cuda), "pos": torch.randn(R, 3, generator=gen).to(cuda)}
+    wpp, wpo = torch.randn(P, 3, generator=gen).to(cuda), torch.randn(P, generator=gen).to(cuda)
+    kw = dict(offset_range=(-0.2, 0.2), part_size=0.25)
+    sel = None
+    if labels:
+        cnt = (scene["pair_off"][1:] - scene["pair_off"][:-1]).long()
+        pick = (torch.rand(R, generator=gen) * cnt.clamp(min=1)).long().clamp(max=(cnt - 1).clamp(min=0))
+        sel = torch.where(cnt > 0, scene["pair_off"][:-1].long() + pick, torch.full((R,), P))
+        sel[::7] = P
+        sel = sel.to(cuda)
+    s = to_dev(scene, cuda)
+    args = (s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"], s["pair_t"])
+    for extra in (False, True):   # extra: the loss also reads pair_pred_pos / pred_offset at the selected pairs
+        runs = {}
+        for mode in ("all", "selected"):
+            prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+            off = make_module("IEF", scene["off_p"], D, cuda).train()
+            fgd = s["feat_grid"].clone().requires_grad_(True)
+            vfd = s["vox_feat"].clone().requires_grad_(True)
+            out = lidf_query_train(*args, fgd, vfd, prob, off, vox_center=s["vox_center"], pos_rel=pos_rel,
+                                   max_pair_id=sel, offsets=mode, **kw)
+            loss = _ref_loss(out, w)
+            if extra:
+                used = out["max_pair_id"] if sel is None else sel
+                m = torch.zeros(P + 1, device=cuda)
+                m[used] = 1.0
+                m = m[:P]   # 1 at the selected pairs (the dummy row dropped)
+                loss = loss + (out["pair_pred_pos"] * wpp * m[:, None]).sum() + (out["pred_offset"][:, 0] * wpo * m).sum()
+            loss.backward()
+            g = {"feat_grid": fgd.grad.clone(), "vox_feat": vfd.grad.clone()}
+            g.update({"prob." + k: v.grad.clone() for k, v in prob.named_parameters()})
+            g.update({"off." + k: v.grad.clone() for k, v in off.named_parameters()})
+            runs[mode] = (out, g, m if extra else None)
+        oa, os_ = runs["all"][0], runs["selected"][0]
+        for k in ("pred_prob_end", "pred_prob_end_softmax", "max_pair_id"):
+            assert torch.equal(oa[k], os_[k]), k
+        assert (oa["pred_pos"] - os_["pred_pos"]).abs().max().item() <= 1e-6
+        used = oa["max_pair_id"] if sel is None else sel
+        live = used[used < P]
+        assert (oa["pred_offset"][live] - os_["pred_offset"][live]).abs().max().item() <= 1e-6
+        assert (oa["pair_pred_pos"][live] - os_["pair_pred_pos"][live]).abs().max().item() <= 1e-6
+        rest = torch.ones(P, dtype=torch.bool, device=cuda)
+        rest[live] = False
+        assert (os_["pred_offset"][rest] == 0).all() and (os_["pair_pred_pos"][rest] == 0).all()
+        for k in runs["all"][1]:
+            a, b = runs["selected"][1][k], runs["all"][1][k]
+            scale = max(1e-2, b.abs().max().item())
+            assert (a - b).abs().max().item() <= 5e-5 * scale, (extra, k, (a - b).abs().max().item(), scale)
+        assert runs["selected"][1]["off.linear_4.weight"].abs().sum().item() > 0
+
+
+def test_query_train_offsets_selected_no_pairs(cuda):
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(1, 8, 12, 6, seed=161)
+    s = to_dev(scene, cuda)
+    D, R = scene["D"], scene["R"]
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", scene["off_p"], D, cuda).train()
+    z = torch.zeros
+    out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], z(R + 1, dtype=torch.int32, device=cuda),
+                           z(0, dtype=torch.int32, device=cuda), z(0, dtype=torch.int32, device=cuda),
+                           z((0, 2), device=cuda), s["feat_grid"], s["vox_feat"], prob, off, offsets="selected")
+    assert out["pred_pos"].shape == (R, 3) and (out["pred_pos"] == 0).all()
+    assert (out["max_pair_id"] == 0).all()
+    out["pred_pos"].sum().backward()
+    assert all(p.grad is not None and (p.grad == 0).all() for p in list(prob.parameters()) + list(off.parameters()))
