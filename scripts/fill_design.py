@@ -64,6 +64,9 @@ def main():
     e1, e1o, e4, e3 = rec("e2e_frame_f1"), rec("e2e_frame_f1_onestream"), rec("e2e_frame_f4"), rec("e2e_frame_f1_streams3")
     v.update(e2e_f1_ms=f(e1["ms_per_frame"], 3), e2e_one_ms=f(e1o["ms_per_frame"], 3), e2e_f4_ms=f(e4["ms_per_frame"], 3),
              e2e_s3_ms=f(e3["ms_per_frame"], 3))
+    v.update(e2e_s6_ms=f(rec("e2e_frame_f1_streams6")["ms_per_frame"], 3),
+             e2e_sel6_ms=f(rec("e2e_frame_f1_selected_streams6")["ms_per_frame"], 3),
+             tq_sel_ms=f(rec("train-query_selected")["ms_per_step"], 2), tq_dense_ms=f(rec("train-query_dense")["ms_per_step"], 2))
     ie = (e1o.get("roofline_kernels") or {}).get("ief") or {}
     v["ief_frame_us"] = f(ie.get("kernel_ms", 0.0) * 1e3, 0)
     p = os.path.join(ROOT, "DESIGN.md")

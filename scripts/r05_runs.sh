@@ -6,16 +6,17 @@ R=$GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/err.txt
 for M in stepwise frame graph; do for F in 1 4; do
 python bench.py --workload e2e --e2e-mode $M --frames $F --steps $( [ $F = 1 ] && echo 300 || echo 80 ) --warmup 10 $( [ $M = frame ] && [ $F = 1 ] && echo --pmc ) > $O/bench_e2e_${M}_f$F.json 2>> $O/err.txt; done; done
-for S in 2 3; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
+for S in 2 3 6; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
 python bench.py --workload e2e --e2e-mode graph --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_graph_f1_guard32.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --frames 4 --streams 2 --steps 80 --warmup 8 > $O/bench_e2e_frame_f4_streams2.json 2>> $O/err.txt
 # variants: one stream inside the frame call; guard every 32nd frame; the offset decoder on the selected pairs only (opt-in)
 python bench.py --workload e2e --e2e-mode frame --no-side-stream --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_onestream.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_frame_f1_guard32.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --offsets selected --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_selected.json 2>> $O/err.txt
-python bench.py --workload e2e --e2e-mode frame --offsets selected --streams 3 --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_selected_streams3.json 2>> $O/err.txt
+for S in 3 6; do python bench.py --workload e2e --e2e-mode frame --offsets selected --streams $S --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_selected_streams$S.json 2>> $O/err.txt; done
 python bench.py --workload e2e --e2e-mode frame --offsets selected --frames 4 --steps 80 --warmup 8 > $O/bench_e2e_frame_f4_selected.json 2>> $O/err.txt
-for p in ragged n1 scene; do python bench.py --pairs $p --steps 20 --warmup 3 --no-cpu-baseline $( [ $p = scene ] && echo --pmc ) > $O/bench_pairs_$p.json 2>> $O/err.txt; done
+# (the scene list's launch is 0.8 ms: 200 steps, 20 steps of it are over before the clocks settle)
+for p in ragged n1 scene; do python bench.py --pairs $p --steps $( [ $p = scene ] && echo 200 || echo 20 ) --warmup $( [ $p = scene ] && echo 20 || echo 3 ) --no-cpu-baseline $( [ $p = scene ] && echo --pmc ) > $O/bench_pairs_$p.json 2>> $O/err.txt; done
 python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_config2.json 2>> $O/err.txt
 python bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --pmc > $O/bench_config3.json 2>> $O/err.txt
 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config4.json 2>> $O/err.txt
@@ -23,6 +24,8 @@ python bench.py --precision f16x3 --steps 10 --warmup 3 --no-cpu-baseline > $O/b
 python bench.py --imnet-gf 128 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gf128.json 2>> $O/err.txt
 for w in decoders embed train train-query train-refine; do python bench.py --workload $w --steps 10 --warmup 3 > $O/bench_$w.json 2>> $O/err.txt; done
 python bench.py --offsets selected --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_selected.json 2>> $O/err.txt
+python bench.py --workload train-query --offsets selected --steps 10 --warmup 3 > $O/bench_train-query_selected.json 2>> $O/err.txt
+python bench.py --workload train-query --dense-offset-grad --steps 10 --warmup 3 > $O/bench_train-query_dense.json 2>> $O/err.txt
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29654 bench.py --workload e2e --gpus 1 --steps 100 --warmup 10 --no-rocprof > $O/bench_e2e_rccl_n1.json 2>> $O/err.txt
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n1_rccl.json 2>> $O/err.txt
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29656 bench.py --gpus 1 --shard rays --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n1_rccl_rays.json 2>> $O/err.txt
