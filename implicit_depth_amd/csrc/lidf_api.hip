@@ -2092,7 +2092,7 @@ struct LinEx {
     float* out; long long ld_out; int accumulate;
 };
 
-static int nt_for(int nout) { return nout <= 32 ? 1 : nout <= 64 ? 2 : nout <= 128 ? 4 : 8; }
+static int nt_for(int nout) { const int t = (nout + 31) / 32; return t < 1 ? 1 : t > 8 ? 8 : t; }
 
 static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) / 8) * 8 * 1024, 256); }
 // NOTE: the bias / u columns exist in the stream only when the layer has them; a layer with a
@@ -2170,8 +2170,11 @@ LIDF_API int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, 
     hipStream_t st = (hipStream_t)stream;
     // 256 output columns per launch (8 accumulator tiles); the packed stream of a chunk is consumed by
     // its launch before the next chunk's pack overwrites it (same stream)
-    for (int c0 = 0; c0 < nout; c0 += 256) {
-        const int cols = nout - c0 < 256 ? nout - c0 : 256;
+    // (evenly sized launches: 385 columns are 7 + 6 tiles, not 8 + 5)
+    const int tiles_all = (nout + 31) / 32, launches = (tiles_all + 7) / 8;
+    const int cols_per = 32 * ((tiles_all + launches - 1) / launches);
+    for (int c0 = 0; c0 < nout; c0 += cols_per) {
+        const int cols = nout - c0 < cols_per ? nout - c0 : cols_per;
         const int nt = nt_for(cols);
         L1Map m = rows_map(k, 0, 0, 0, b ? 1 : 0);
         m.KQ1 = (m.D + 2 + 7) / 8;
@@ -2394,7 +2397,7 @@ LIDF_API int lidf_refine_pack_guarded_f32(const LidfDecoder* off, int32_t multir
 }
 
 struct TrainWs {
-    size_t stream, dz1, dz2, dz3, goff, wg, chain, total;
+    size_t stream, dz1, dz2, dz3, S, goff, wg, chain, small, total;
 };
 static TrainWs train_ws(int64_t n, int d) {
     TrainWs w;
@@ -2405,9 +2408,11 @@ static TrainWs train_ws(int64_t n, int d) {
     w.dz1 = o;    o += align_up(N * LIDF_H1 * 4, 256);
     w.dz2 = o;    o += align_up(N * LIDF_H2 * 4, 256);
     w.dz3 = o;    o += align_up(N * LIDF_H3 * 4, 256);
+    w.S = o;      o += align_up(N * LIDF_H1 * 4, 256);   // running sum of dZ1 over the IEF's passes
     w.goff = o;   o += align_up(N * 4, 256);
     w.wg = o;     o += align_up(WG_SCRATCH_FLOATS * 4, 256);
     w.chain = o;  o += chain_stream_bytes(d);
+    w.small = o;  o += 512 * 4;   // B sums of the passes (the IEF's first pass, lidf_ief_finish_kernel)
     w.total = o;
     return w;
 }
@@ -2474,8 +2479,20 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
     int cus;
     if ((rc = cu_count(&cus))) return rc;
     const float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;
+    float* S = (float*)(ws + w.S);
+    float* small = (float*)(ws + w.small);
+    CHECK_HIP(hipMemsetAsync(small, 0, 512 * 4, st));
     // through the output activation: goff = dL/d(off_n)
     CHECK_HIP(lidf_launch_out_act(pre, n, dec->use_sigmoid, nullptr, g_out, goff, st));
+    // W3^T | W2^T of the chained input-gradient launches: one stream for every pass
+    CHECK_HIP(lidf_launch_pack_dgrad(dec->w3, dec->w2, sbuf, st));
+    // Everything of layer 1 except the offset encoding sees the same operand in every pass of the IEF, so
+    // its weight gradient and the input gradient are ONE product each with S = the sum of dZ1 over the
+    // passes (as the factorised backward of the query does, qdec_backward_impl) instead of one per pass:
+    // the first pass processed writes its dZ1 into S, the middle ones add theirs in the sweep that handles
+    // the offset-encoding columns, and the IEF's first pass (constant offset-in: its share of those columns
+    // follows from column sums, lidf_ief_finish_kernel) is added into S by the chained launch itself.
+    if (npass == 1) S = dz1;
     for (int k = npass - 1; k >= 0; --k) {
         const float* h1 = act_h1(act, n, k);
         const float* h2 = h1 + (size_t)n * LIDF_H1;
@@ -2484,30 +2501,36 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
         // y_k = w4 . H3 + b4 ;  dL/dy_k = dL/d(off_{k+1}) = goff
         // dZ3 = (goff (x) w4) * lrelu'(Z3), d w4, d b4: one pass over H3
         CHECK_HIP(lidf_launch_l4_backward(goff, h3, dec->w4, 0.02f, n, dz3, grads->w4, grads->b4, wgs, st));
-        LinEx L = {};
-        L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
         CHECK_HIP(lidf_launch_wgrad(dz3, LIDF_H3, LIDF_H3, h2, LIDF_H2, LIDF_H2, n, grads->w3, LIDF_H2, grads->b3, wgs, WG_SCRATCH_FLOATS, st));
         // dZ2 = (dZ3 W3) * lrelu'(Z2), dZ1 = (dZ2 W2) * lrelu'(Z1): one register-chained launch
-        CHECK_HIP(lidf_launch_dgrad_chain(dec->w3, dec->w2, dz3, act_m2(h1, n), act_m1(h1, n), n, 0.02f, dz2, dz1, 0, sbuf, cus, st));
+        const bool first_pass_short = dec->is_ief && npass > 1 && k == 0;
+        float* dz1k = (k == npass - 1 || first_pass_short) ? S : dz1;
+        CHECK_HIP(lidf_launch_dgrad_chain(nullptr, nullptr, dz3, act_m2(h1, n), act_m1(h1, n), n, 0.02f, dz2, dz1k,
+                                          first_pass_short ? 1 : 0, sbuf, cus, st));
         CHECK_HIP(lidf_launch_wgrad(dz2, LIDF_H2, LIDF_H2, h1, LIDF_H1, LIDF_H1, n, grads->w2, LIDF_H1, grads->b2, wgs, WG_SCRATCH_FLOATS, st));
-        CHECK_HIP(lidf_launch_wgrad(dz1, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
-        L.mask_src = nullptr;
-        if (d_inp) {
-            // d inp (+)= dZ1 W1[:, 0:d], 256 input columns per launch
-            for (int c0 = 0; c0 < d; c0 += 256) {
-                const int cols = d - c0 < 256 ? d - c0 : 256;
-                L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = dz1; L.ldx = LIDF_H1;
-                L.out = d_inp + c0; L.ld_out = ld_dinp; L.accumulate = k < npass - 1;
-                if ((rc = run_linex(L, sbuf, cus, st))) return rc;
-            }
-            L.accumulate = 0;
-        }
-        if (dec->is_ief) {
-            // the 16 offset-encoding columns of layer 1 (enc_k = off_k wenc^T + benc): d W1[:, d:],
-            // d wenc, d benc and d off_k = d off_{k+1} + d enc . wenc in one pass over dZ1
-            CHECK_HIP(lidf_launch_ief_tail(dz1, offin, dec->w1 + d, ld1, dec->wenc, dec->benc, n, 0,
-                                           nullptr, goff, grads->w1 + d, grads->wenc, grads->benc,
-                                           nullptr, wgs, st));
+        // the 16 offset-encoding columns of layer 1 (enc_k = off_k wenc^T + benc): d W1[:, d:], d wenc,
+        // d benc and d off_k = d off_{k+1} + d enc . wenc in one sweep over this pass's dZ1
+        if (dec->is_ief && !first_pass_short)
+            CHECK_HIP(lidf_launch_ief_tail(dz1k, offin, dec->w1 + d, ld1, dec->wenc, dec->benc, n,
+                                           k == npass - 1 ? 0 : 2, S, goff, grads->w1 + d, grads->wenc,
+                                           grads->benc, npass > 1 ? small : nullptr, wgs, st));
+    }
+    // d W1[:, 0:d] = S^T inp, d b1 = column sums of S
+    CHECK_HIP(lidf_launch_wgrad(S, LIDF_H1, LIDF_H1, inp, ld_inp, d, n, grads->w1, ld1, grads->b1, wgs, WG_SCRATCH_FLOATS, st));
+    if (dec->is_ief && npass > 1)
+        CHECK_HIP(lidf_launch_ief_first_pass(grads->b1, small, dec->init_offset, dec->w1 + d, ld1, dec->wenc,
+                                             dec->benc, grads->w1 + d, grads->wenc, grads->benc, st));
+    if (d_inp) {
+        // d inp = S W1[:, 0:d], in launches of at most 8 output tiles of 32 columns, evenly sized (385 columns:
+        // 7 + 6 tiles instead of 8 + 8)
+        LinEx L = {};
+        L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
+        const int tiles = (d + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
+        for (int c0 = 0; c0 < d; c0 += 32 * per) {
+            const int cols = d - c0 < 32 * per ? d - c0 : 32 * per;
+            L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = S; L.ldx = LIDF_H1;
+            L.out = d_inp + c0; L.ld_out = ld_dinp; L.accumulate = 0;
+            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
         }
     }
     return LIDF_OK;

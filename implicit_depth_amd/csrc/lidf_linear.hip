@@ -13,6 +13,7 @@
 // (>= 0), so integer atomicMax on the bit pattern is an exact, order-independent float max, and a
 // zero-initialised pool reproduces torch_scatter's 0 for a voxel without points.
 #include "lidf_device.h"
+#include <cstdlib>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -36,58 +37,99 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     const int vq = lane * 16;
     const long long AN = a.n_dev ? (long long)*a.n_dev : a.n;   // device-side row count (frame path)
     const long long ntile = (AN + 127) / 128;
-    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        if (tile * 128 + wave * 32 >= AN) continue;
+    // k-quads below kfull hold eight real operand columns for both half-waves: one 16-byte load per lane, no
+    // condition. The k-quad(s) behind them carry the row's last columns, the bias and the u column.
+    const int kfull = a.D / 8 < a.kq1 ? a.D / 8 : a.kq1;
+    // Operand registers live across the tile loop: the next tile's first loads are issued in FRONT of this
+    // tile's stores (vector memory completes in order — a load behind 32 stores waits for their acknowledgements,
+    // docs/history.md §4.5), so the first matrix instruction of a tile waits for two loads, not for the previous
+    // tile's output to reach memory.
+    float b0[4], b1[4], b2[4], b3[4];   // operand ring: k-quads kq, kq + 1, (kq + 2, kq + 3)
+    f32x4 q0[NT], q1[NT];               // weight quads of k-quad kq, kq + 1
+    const float* xrow = nullptr;
+    long long pc = 0;
+    auto load_b_fast = [&](int kq, float (&b)[4]) {
+        const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+        b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+    };
+    auto load_b_tail = [&](int kq, float (&b)[4]) {
+        const int x0 = 8 * kq + 4 * h;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
+                                  : ((x0 + jj == a.D && a.has_bias)
+                                         ? 1.f
+                                         : ((x0 + jj == a.D + 1 && a.xoff) ? a.xoff[pc] : 0.f));
+    };
+    auto load_b = [&](int kq, float (&b)[4]) {   // (kq wave-uniform)
+        if (kq < kfull) load_b_fast(kq, b);
+        else if (kq < a.kq1) load_b_tail(kq, b);
+        else { b[0] = 0.f; b[1] = 0.f; b[2] = 0.f; b[3] = 0.f; }
+    };
+    auto load_q = [&](int kq, f32x4 (&q)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q[t] = LDQ(srs, vq, (kq * NTS + T0 + t) * 1024);
+    };
+    // rows of a tile for this lane; the tile's first requests: operands of k-quads 0 and 1, weight quads of k-quad 0
+    auto tile_begin = [&](long long tile) {
+        const long long p = tile * 128 + wave * 32 + col;
+        pc = p < AN ? p : AN - 1;
+        xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+        load_b(0, b0);
+        load_b(1, b1);
+        load_q(0, q0);
+    };
+    long long tile = blockIdx.x;
+    if (tile < ntile && tile * 128 + wave * 32 < AN) tile_begin(tile);
+    for (; tile < ntile; tile += gridDim.x) {
+        if (tile * 128 + wave * 32 >= AN) continue;   // (only the last tile can be short: no later tile for this wave)
         const long long p = tile * 128 + wave * 32 + col;
         const bool valid = p < AN;
-        const long long pc = valid ? p : AN - 1;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         }
-        // operand columns of this lane in k-quad kq: 8kq + 4h + {0..3}; column D = bias
-        const float* xrow = a.X + (size_t)pc * a.ldx + 4 * h;
-        auto load_b = [&](int kq, float (&b)[4]) {
-            const int x0 = 8 * kq + 4 * h;
-            if (x0 + 3 < a.D) {
-                const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
-                b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    b[jj] = x0 + jj < a.D ? xrow[8 * kq + jj]
-                                          : ((x0 + jj == a.D && a.has_bias)
-                                                 ? 1.f
-                                                 : ((x0 + jj == a.D + 1 && a.xoff) ? a.xoff[pc] : 0.f));
-            }
-        };
-        float bc[4];
-        f32x4 qc[NT];
-        load_b(0, bc);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) qc[t] = LDQ(srs, vq, (T0 + t) * 1024);
-        for (int kq = 0; kq < a.kq1; ++kq) {
-            float bn[4] = {0.f, 0.f, 0.f, 0.f};
-            f32x4 qn[NT];
-            if (kq + 1 < a.kq1) load_b(kq + 1, bn);
-            const int kn = kq + 1 < a.kq1 ? kq + 1 : kq;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) qn[t] = LDQ(srs, vq, (kn * NTS + T0 + t) * 1024);
+        auto mfma_quad = [&](const f32x4 (&q)[NT], const float (&b)[4]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 c = acc[t];
-                c = MFMA(qc[t][0], bc[0], c);
-                c = MFMA(qc[t][1], bc[1], c);
-                c = MFMA(qc[t][2], bc[2], c);
-                c = MFMA(qc[t][3], bc[3], c);
+                c = MFMA(q[t][0], b[0], c);
+                c = MFMA(q[t][1], b[1], c);
+                c = MFMA(q[t][2], b[2], c);
+                c = MFMA(q[t][3], b[3], c);
                 acc[t] = c;
             }
+        };
+        int kq = 0;
+        // main loop, four k-quads per trip through a ring of four operand sets and two weight sets (no copies):
+        // the operand of k-quad kq + 2 and the weight quads of kq + 1 are requested BEFORE the 4 NT matrix
+        // instructions of k-quad kq — the operand rows come from HBM (two k-quads of matrix time ahead), the
+        // weight quads from L2 (one ahead). Left to itself the compiler sinks the requests behind the products
+        // and every k-quad starts on a memory round trip.
+        for (; kq + 5 < kfull; kq += 4) {
+            load_b_fast(kq + 2, b2); load_q(kq + 1, q1); SCHED_FENCE(); mfma_quad(q0, b0); SCHED_FENCE();
+            load_b_fast(kq + 3, b3); load_q(kq + 2, q0); SCHED_FENCE(); mfma_quad(q1, b1); SCHED_FENCE();
+            load_b_fast(kq + 4, b0); load_q(kq + 3, q1); SCHED_FENCE(); mfma_quad(q0, b2); SCHED_FENCE();
+            load_b_fast(kq + 5, b1); load_q(kq + 4, q0); SCHED_FENCE(); mfma_quad(q1, b3); SCHED_FENCE();
+        }
+        // the last k-quads (at most five whole ones + the tail k-quads), one per trip with register copies
+        for (; kq < a.kq1; ++kq) {
+            load_b(kq + 2, b2);
+            load_q(kq + 1 < a.kq1 ? kq + 1 : kq, q1);
+            SCHED_FENCE();
+            mfma_quad(q0, b0);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bc[jj] = bn[jj];
+            for (int jj = 0; jj < 4; ++jj) { b0[jj] = b1[jj]; b1[jj] = b2[jj]; }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) qc[t] = qn[t];
+            for (int t = 0; t < NT; ++t) q0[t] = q1[t];
+            SCHED_FENCE();
+        }
+        // the next tile's first requests, in front of this tile's stores
+        {
+            const long long nx = tile + gridDim.x;
+            if (nx < ntile && nx * 128 + wave * 32 < AN) tile_begin(nx);
             SCHED_FENCE();
         }
         // ---- epilogue: this lane holds, per tile t and group g, features 32t + 8g + 4h + {0..3}
@@ -376,10 +418,26 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int gri
         return hipGetLastError();
     }
     dim3 g(grid), b(256);
+    // Three or more accumulator tiles: ONE workgroup per compute unit (one wavefront per SIMD). The operand rows are
+    // gathered a row stride apart (32 cache lines per wavefront and k-quad, each used by four consecutive k-quads):
+    // with two workgroups per CU the lines of eight wavefronts do not survive in the L1 between their uses and the
+    // launch runs at 0.57 of the matrix peak (614,400 x 256 -> 256) against 0.71 with one (scripts/linear_ubench.py);
+    // the k-loop hides its memory latency by itself (operands two k-quads ahead, weights one).
+    if (nt >= 3) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            (long long)g.x > cus)
+            g = dim3((unsigned)cus);
+    }
     switch (nt) {
         case 1: hipLaunchKernelGGL(lidf_linear_kernel<1>, g, b, 0, st, a); break;
         case 2: hipLaunchKernelGGL(lidf_linear_kernel<2>, g, b, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(lidf_linear_kernel<3>, g, b, 0, st, a); break;
         case 4: hipLaunchKernelGGL(lidf_linear_kernel<4>, g, b, 0, st, a); break;
+        case 5: hipLaunchKernelGGL(lidf_linear_kernel<5>, g, b, 0, st, a); break;
+        case 6: hipLaunchKernelGGL(lidf_linear_kernel<6>, g, b, 0, st, a); break;
+        case 7: hipLaunchKernelGGL(lidf_linear_kernel<7>, g, b, 0, st, a); break;
         case 8: hipLaunchKernelGGL(lidf_linear_kernel<8>, g, b, 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
