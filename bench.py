@@ -1356,9 +1356,21 @@ def main():
                 "configs[1]", "secondary (not the headline shape): %s candidate list" % args.pairs)
             line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.pairs
         if gf != 64:
-            line["roofline"] = None
+            # FLOP of the layer-by-layer formulation per pair (generic.query): layer 1 over the 2E pair columns, the IEF's
+            # 16 offset-encoding columns per pass, layers 2-4 of every pass; the per-voxel / per-ray tables are noise
+            h1, h2, h3, e2 = 4 * gf, 2 * gf, gf, 2 * (3 + 6 * 8)
+            tail = 2 * (h1 * h2 + h2 * h3 + h3)
+            fl_pt = 2 * (2 * e2 * h1) + tail + 2 * (2 * 16 * h1 + tail)
+            a_ = fl_pt * P / (elapsed / args.steps) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": round(a_, 2), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(a_ / peak, 4), "traffic": None,
+                                "kernel": "lidf_linear_kernel<NT> per layer (whole step, between the events)",
+                                "flop_per_point_exec": fl_pt,
+                                "basis": "FLOP of the executed formulation (factorised layer 1, 3 decoder passes), "
+                                         "not an instruction count; the shipped width issues %d per point" % F_EXEC}
             line["config"]["workload"] = ("secondary: imnet_gf %d (not a shipped width): get_embedding + get_pred layer by "
-                                          "layer on rows materialised in %d-pair slabs (implicit_depth_amd/generic.py), "
+                                          "layer, layer 1 factorised into per-voxel / per-ray tables + the pair's position "
+                                          "embedding, pairs in %d-pair slabs (implicit_depth_amd/generic.py), "
                                           "%d x 240x320 frame(s), %d candidates/ray" % (gf, 614400, B, N))
             line["metric"] = "Mpoints/sec implicit-MLP query at imnet_gf %d (layer by layer)" % gf
         if world == 1 and not args.no_cpu_baseline and dense and gf == 64:

@@ -15,7 +15,7 @@ LIDF_OK = 0
 # below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
 # lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
 # outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
-ABI = 9
+ABI = 10
 
 
 class LidfDecoder(C.Structure):
@@ -245,6 +245,8 @@ SIGNATURES = {
     "lidf_linear_workspace_bytes": (_SZ, [_I]),
     "lidf_linear_f32": (_I, [_P, _I64, _I64, _I, _P, _I64, _P, _I, _I, C.c_float, _P, _P, _I64, _P, _I64, _P, _P,
                             _I64, _P, _SZ, _P]),
+    "lidf_linear_gather2_f32": (_I, [_P, _I64, _I64, _I, _P, _I64, _P, _I, _I, C.c_float, _P, _P, _I64, _P, _P, _I64,
+                                    _P, _I64, _P, _SZ, _P]),
     "lidf_decoder_train_act_floats": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_train_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_forward_train_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P,

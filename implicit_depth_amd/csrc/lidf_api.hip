@@ -2150,18 +2150,48 @@ LIDF_API size_t lidf_linear_workspace_bytes(int32_t k) {
     return k > 0 ? linex_stream_bytes(k) : 0;
 }
 
+static int linear_impl(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                       const float* b, int32_t nout, int32_t act, float slope,
+                       const float* addrows, const int32_t* addidx, int64_t ld_add,
+                       const float* addrows2, const int32_t* addidx2, int64_t ld_add2, float* out,
+                       int64_t ld_out, float* pool, const int32_t* poolidx, int64_t ld_pool,
+                       void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+
 LIDF_API int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
                                const float* b, int32_t nout, int32_t act, float slope,
                                const float* addrows, const int32_t* addidx, int64_t ld_add, float* out,
                                int64_t ld_out, float* pool, const int32_t* poolidx, int64_t ld_pool,
                                void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
+    return linear_impl(x, ldx, n, k, w, ldw, b, nout, act, slope, addrows, addidx, ld_add, nullptr, nullptr, 0, out,
+                       ld_out, pool, poolidx, ld_pool, workspace, workspace_bytes, stream);
+}
+
+LIDF_API int lidf_linear_gather2_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                                       const float* b, int32_t nout, int32_t act, float slope,
+                                       const float* addrows, const int32_t* addidx, int64_t ld_add,
+                                       const float* addrows2, const int32_t* addidx2, int64_t ld_add2, float* out,
+                                       int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                       lidf_stream_t stream) {
+    if (!addrows || !addrows2) return LIDF_ERR_BAD_ARG;
+    return linear_impl(x, ldx, n, k, w, ldw, b, nout, act, slope, addrows, addidx, ld_add, addrows2, addidx2, ld_add2,
+                       out, ld_out, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+static int linear_impl(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                       const float* b, int32_t nout, int32_t act, float slope,
+                       const float* addrows, const int32_t* addidx, int64_t ld_add,
+                       const float* addrows2, const int32_t* addidx2, int64_t ld_add2, float* out,
+                       int64_t ld_out, float* pool, const int32_t* poolidx, int64_t ld_pool,
+                       void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
     if (n < 0 || k <= 0 || nout <= 0 || ldx < k || ldw < k || act < 0 || act > 1) return LIDF_ERR_BAD_ARG;
-    if (k > (1 << 20) || nout > (1 << 20) || ld_add > 0x7fffffffLL || ld_pool > 0x7fffffffLL)
+    if (k > (1 << 20) || nout > (1 << 20) || ld_add > 0x7fffffffLL || ld_add2 > 0x7fffffffLL ||
+        ld_pool > 0x7fffffffLL)
         return LIDF_ERR_UNSUPPORTED;
     if (n == 0) return LIDF_OK;
     if (!x || !w || (!out && !pool)) return LIDF_ERR_BAD_ARG;
     if (out && ld_out < nout) return LIDF_ERR_BAD_ARG;
     if (addrows && (!addidx || ld_add < nout)) return LIDF_ERR_BAD_ARG;
+    if (addrows2 && (!addidx2 || ld_add2 < nout)) return LIDF_ERR_BAD_ARG;
     // the max-pool epilogue raises whole 32-column tiles of non-negative values
     if (pool && (!poolidx || ld_pool < nout || nout % 32 != 0 || !act || slope != 0.f)) return LIDF_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < linex_stream_bytes(k)) return LIDF_ERR_WORKSPACE;
@@ -2188,6 +2218,7 @@ LIDF_API int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, 
         a.stream = (const float*)workspace; a.kq1 = m.KQ1; a.X = x; a.ldx = ldx; a.n = n;
         a.D = m.D; a.has_bias = b ? 1 : 0;
         a.addrows = addrows ? addrows + c0 : nullptr; a.addidx = addidx; a.ld_add = (int)ld_add;
+        a.addrows2 = addrows2 ? addrows2 + c0 : nullptr; a.addidx2 = addidx2; a.ld_add2 = (int)ld_add2;
         a.relu = act; a.slope = slope;
         a.out = out ? out + c0 : nullptr; a.ld_out = ld_out; a.nout = cols;
         a.pool = pool ? pool + c0 : nullptr; a.poolidx = poolidx; a.ld_pool = (int)ld_pool;

@@ -21,9 +21,20 @@ import torch
 from . import _lib
 
 
+def _rows_buffer(n, nout, dev, pad):
+    """[n, nout] f32. pad: an INTERNAL activation that the next layer gathers row by row — rows a multiple of 1 KiB
+    apart put the 32 rows of a wavefront's operand on two of the sixteen L2 channels (scripts/linear_ubench.py:
+    614,400 x 256 -> 224 in 0.79 ms at a row stride of 256 floats, 0.65 ms at 288), so such buffers get 32 floats
+    of padding per row (a view of a wider buffer; never handed to the caller)."""
+    if pad and nout % 256 == 0 and n >= 4096:
+        return torch.empty((n, nout + 32), dtype=torch.float32, device=dev)[:, :nout]
+    return torch.empty((n, nout), dtype=torch.float32, device=dev)
+
+
 def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None, out=None,
-               pool=None, poolidx=None, w_col0=0, k=None):
-    """out = act(x @ weight[:, w_col0:w_col0+k].T + bias (+ addrows[addidx])) through lidf_linear_f32.
+               pool=None, poolidx=None, w_col0=0, k=None, addrows2=None, addidx2=None, pad_out=False):
+    """out = act(x @ weight[:, w_col0:w_col0+k].T + bias (+ addrows[addidx]) (+ addrows2[addidx2])) through
+    lidf_linear_f32 / lidf_linear_gather2_f32.
     x [n, >=k] f32 (row stride free), weight [nout, ldw] f32; act 0 none / 1 max(v, slope*v).
     pool [V, nout] (zero-initialised) receives the scatter-max over poolidx instead of / beside out."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
@@ -41,11 +52,22 @@ def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None
     ldx = x.stride(0) if n > 1 else x.shape[1]   # (a single row: its real width, never a fabricated stride)
     b = bias.detach().contiguous() if bias is not None else None
     if out is None and pool is None:
-        out = torch.empty((n, nout), dtype=torch.float32, device=x.device)
+        out = _rows_buffer(n, nout, x.device, pad_out)
     L = _lib.lib()
     wsb = L.lidf_linear_workspace_bytes(k)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
     if n == 0:
+        return out
+    if addrows2 is not None:
+        if addrows is None or pool is not None:
+            raise RuntimeError("linear_hip: a second gathered term needs the first one and no pooling")
+        with torch.cuda.device(x.device):
+            _lib.check(L.lidf_linear_gather2_f32(
+                _lib.ptr(x), ldx, n, k, w.data_ptr() + 4 * w_col0, max(w.stride(0), w.shape[1]) if nout > 1 else w.shape[1],
+                _lib.ptr(b), nout, act, float(slope),
+                _lib.ptr(addrows), _lib.ptr(addidx), addrows.stride(0),
+                _lib.ptr(addrows2), _lib.ptr(addidx2), addrows2.stride(0),
+                _lib.ptr(out), out.stride(0), _lib.ptr(ws), wsb, _lib.current_stream(x.device)))
         return out
     with torch.cuda.device(x.device):
         _lib.check(L.lidf_linear_f32(
@@ -65,34 +87,45 @@ def _out_act(mod, y):
     return torch.max(torch.min(y, y * 0.01 + 0.99), y * 0.01)
 
 
-def decoder_forward(mod, x):
-    """IMNet.forward / IEF.forward (models/implicit_net.py:81-98 / :131-152) at any gf_dim / out_dim
-    on [n, inp_dim] rows."""
+def _decoder_from_layer1(mod, n, dev, layer1):
+    """The decoder behind its first layer. layer1(act) -> [n, 4 gf]: W1[:, :inp_dim] x + b1, activated (act True: the
+    IMNet's layer 1 in one launch) or not (the IEF's pass-independent part, to which every pass adds the 16
+    offset-encoding columns)."""
     from .decoders import IEF
-    x = x.detach()
-    n, d = x.shape
-    if d != mod.inp_dim:
-        raise RuntimeError("decoder inp_dim %d != input width %d" % (mod.inp_dim, d))
     l1, l2, l3, l4 = mod.linear_1, mod.linear_2, mod.linear_3, mod.linear_4
     if not isinstance(mod, IEF):
-        h = linear_hip(x, l1.weight, l1.bias, act=1, slope=0.02)
-        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
-        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
+        h = layer1(True)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02, pad_out=True)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02, pad_out=True)
         return _out_act(mod, linear_hip(h, l4.weight, l4.bias))
     if l4.out_features != 1:
         raise RuntimeError("IEF feeds its output back through offset_enc = Linear(1, 16): out_dim must be 1")
     # layer 1 = W1[:, :d] x + b1 (the same in every pass) + W1[:, d:] enc(off)
-    base = linear_hip(x, l1.weight, l1.bias, k=d)
-    rows = torch.arange(n, dtype=torch.int32, device=x.device)
+    d = mod.inp_dim
+    base = layer1(False)
+    rows = torch.arange(n, dtype=torch.int32, device=dev)
     from .decoders import _init_offset_value
-    off = torch.full((n, 1), _init_offset_value(mod), dtype=torch.float32, device=x.device)
+    off = torch.full((n, 1), _init_offset_value(mod), dtype=torch.float32, device=dev)
     for _ in range(int(mod.n_iter)):
         enc = linear_hip(off, mod.offset_enc.weight, mod.offset_enc.bias)
-        h = linear_hip(enc, l1.weight, None, act=1, slope=0.02, addrows=base, addidx=rows, w_col0=d, k=16)
-        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
-        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
+        h = linear_hip(enc, l1.weight, None, act=1, slope=0.02, addrows=base, addidx=rows, w_col0=d, k=16, pad_out=True)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02, pad_out=True)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02, pad_out=True)
         off = off + linear_hip(h, l4.weight, l4.bias)
     return _out_act(mod, off)
+
+
+def decoder_forward(mod, x):
+    """IMNet.forward / IEF.forward (models/implicit_net.py:81-98 / :131-152) at any gf_dim / out_dim
+    on [n, inp_dim] rows."""
+    x = x.detach()
+    n, d = x.shape
+    if d != mod.inp_dim:
+        raise RuntimeError("decoder inp_dim %d != input width %d" % (mod.inp_dim, d))
+    l1 = mod.linear_1
+    return _decoder_from_layer1(
+        mod, n, x.device,
+        lambda act: linear_hip(x, l1.weight, l1.bias, act=1 if act else 0, slope=0.02 if act else 0.0, k=d, pad_out=True))
 
 
 def pointnet_forward(mod, inp_feat, vox2point_idx, n_vox):
@@ -163,9 +196,23 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     if prob_dec.linear_4.out_features != 1 or offset_dec.linear_4.out_features != 1:
         raise RuntimeError("the query takes decoders with out_dim == 1 (got prob_dec %d, offset_dec %d)"
                            % (prob_dec.linear_4.out_features, offset_dec.linear_4.out_features))
-    vf = vox_feat.detach()
+    vf = vox_feat.detach().contiguous()
     pred_prob = torch.empty((P, prob_dec.linear_4.out_features), dtype=torch.float32, device=dev)
     pred_offset = torch.empty((P, offset_dec.linear_4.out_features), dtype=torch.float32, device=dev)
+    # Layer 1 in its factorised form (the algebra of the fixed-width kernels): of the D
+    # columns of a row only the 2E position-embedding columns depend on the pair — the voxel columns give one
+    # [V, 4 gf] table per decoder (with the bias), the ROI and direction columns one [R, 4 gf] table, and per pair
+    # layer 1 is W1[:, pair columns] PE(p) + the two gathered table rows (lidf_linear_gather2_f32): 2E = 102 of the
+    # 385 columns are multiplied per pair and the [P, D] rows of the reference are never formed.
+    Cv, Cr, Ed = vf.shape[1], roi.shape[1], edir.shape[1]
+    ray_rows = torch.arange(R, dtype=torch.int32, device=dev)
+    tables = []
+    for dec in (prob_dec, offset_dec):
+        l1 = dec.linear_1
+        voxpart = linear_hip(vf, l1.weight, l1.bias, k=Cv)
+        rp = linear_hip(roi, l1.weight, None, w_col0=Cv, k=Cr)
+        raypart = linear_hip(edir, l1.weight, None, w_col0=Cv + Cr + 2 * E, k=Ed, addrows=rp, addidx=ray_rows)
+        tables.append((voxpart, raypart))
     for p0 in range(0, P, QUERY_SLAB):
         p1 = min(P, p0 + QUERY_SLAB)
         n = p1 - p0
@@ -175,11 +222,15 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
             _lib.check(L.lidf_pe_rows_f32(_lib.ptr(pr_s), _lib.ptr(pv_s), _lib.ptr(pt_s), _lib.ptr(ray_dir),
                                           _lib.ptr(vox_center), 1 if pos_rel else 0, multires, n, _lib.ptr(pe),
                                           _lib.current_stream(dev)))
-        pr, pv = pr_s.long(), pv_s.long()
-        rows = torch.cat((vf[pv], roi[pr], pe, edir[pr]), 1)
-        pred_prob[p0:p1] = decoder_forward(prob_dec, rows)
-        pred_offset[p0:p1] = decoder_forward(offset_dec, rows)
-        del rows, pe
+        pr_i, pv_i = pr_s.contiguous(), pv_s.contiguous()
+        for dec, (voxpart, raypart), dst in ((prob_dec, tables[0], pred_prob), (offset_dec, tables[1], pred_offset)):
+            w1 = dec.linear_1.weight
+
+            def layer1(act, w1=w1, voxpart=voxpart, raypart=raypart):
+                return linear_hip(pe, w1, None, act=1 if act else 0, slope=0.02 if act else 0.0, w_col0=Cv + Cr,
+                                  k=2 * E, addrows=voxpart, addidx=pv_i, addrows2=raypart, addidx2=pr_i, pad_out=True)
+            dst[p0:p1] = _decoder_from_layer1(dec, n, dev, layer1)
+        del pe
     f32 = dict(dtype=torch.float32, device=dev)
     pos, sm = torch.empty((P, 3), **f32), torch.empty((P,), **f32)
     mid, pred = torch.empty((R,), dtype=torch.int64, device=dev), torch.empty((R, 3), **f32)

@@ -36,7 +36,7 @@ enum lidf_status {
 /* ABI version, bumped on any signature or struct-layout change and on added entry points. lidf_version() returns the value the
  * library was BUILT with; a binding compiled / written against this header must refuse a library that
  * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
-#define LIDF_ABI_VERSION 9
+#define LIDF_ABI_VERSION 10
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);
@@ -617,6 +617,17 @@ int lidf_linear_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const flo
                     const int32_t* addidx, int64_t ld_add, float* out, int64_t ld_out, float* pool,
                     const int32_t* poolidx, int64_t ld_pool, void* workspace, size_t workspace_bytes,
                     lidf_stream_t stream);
+
+/* The same layer with TWO gathered terms, out = act(x w^T + b + addrows[addidx[r]] + addrows2[addidx2[r]]): layer 1 of
+ * a decoder at any width in its factorised form (models/pipeline.py:431-433 concatenates per-voxel, per-ray and
+ * per-pair columns; W1 x = W1[:, voxel columns] vox_feat[v] + W1[:, ray columns] rayfeat[r] + W1[:, pair columns]
+ * PE(p)), so that only the pair columns are multiplied per pair and no [P, D] row is formed. Both terms are
+ * required (one term: lidf_linear_f32); no pooling epilogue. (ABI 10)                                          */
+int lidf_linear_gather2_f32(const float* x, int64_t ldx, int64_t n, int32_t k, const float* w, int64_t ldw,
+                            const float* b, int32_t nout, int32_t act, float slope, const float* addrows,
+                            const int32_t* addidx, int64_t ld_add, const float* addrows2,
+                            const int32_t* addidx2, int64_t ld_add2, float* out, int64_t ld_out,
+                            void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
 /* Weight gradient of such a layer: c[i, j] += sum_r a[r, i] * b[r, j] (a = dL/d(pre-activation) [n, m],
  * b = the layer's input rows [n, n_cols]: c is dL/dW in nn.Linear's [out, in] layout), db[i] += sum_r a[r, i]

@@ -12,13 +12,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port(hint):
+    """A port nobody listens on right now (the hint if it is free): launches that follow each other on one fixed
+    port meet the previous store's socket in TIME_WAIT now and then."""
+    import socket
+    for cand in (hint, 0):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            try:
+                sk.bind(("127.0.0.1", cand))
+                return sk.getsockname()[1]
+            except OSError:
+                continue
+    return hint
+
+
 def _torchrun(script_args, port, timeout=600, nproc=1, extra_env=None):
     env = dict(os.environ)
     env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    r = None
+    for attempt in range(2):   # (one more try when the rendezvous itself failed: the port was taken in between)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port(port + 40 * attempt))] + script_args
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        err = r.stderr.lower()
+        if r.returncode == 0 or not ("address already in use" in err or "eaddrinuse" in err
+                                     or "failed to bind" in err or "rendezvous" in err):
+            break
+    return r
 
 
 def test_all_gather_depth_under_nccl(cuda):
