@@ -67,6 +67,10 @@ def main():
     v.update(e2e_s6_ms=f(rec("e2e_frame_f1_streams6")["ms_per_frame"], 3),
              e2e_sel6_ms=f(rec("e2e_frame_f1_selected_streams6")["ms_per_frame"], 3),
              tq_sel_ms=f(rec("train-query_selected")["ms_per_step"], 2), tq_dense_ms=f(rec("train-query_dense")["ms_per_step"], 2))
+    g128, g32 = rec("gf128"), rec("gf32")
+    v.update(gf128_value=f(g128["value"], 1), gf128_frac=f(g128["roofline"]["frac"], 2), gf32_value=f(g32["value"], 0),
+             e2e_f8_ms=f(rec("e2e_frame_f8")["ms_per_frame"], 3), e2e_f16_ms=f(rec("e2e_frame_f16")["ms_per_frame"], 3),
+             e2e_f16sel_ms=f(rec("e2e_frame_f16_selected")["ms_per_frame"], 3), train_frac=f(tn["roofline"]["frac"], 2))
     ie = (e1o.get("roofline_kernels") or {}).get("ief") or {}
     v["ief_frame_us"] = f(ie.get("kernel_ms", 0.0) * 1e3, 0)
     p = os.path.join(ROOT, "DESIGN.md")

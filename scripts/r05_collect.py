@@ -69,6 +69,9 @@ def main():
     if os.path.exists(j(SRC, "kt_train_query.db")):
         stats(j(SRC, "kt_train_query.db"), j(OUT, "r05_kernel_stats_train_query.csv"),
               "python bench.py --workload train-query --steps 10 --warmup 3 --no-rocprof  (13 steps)")
+    if os.path.exists(j(SRC, "kt_train.db")):
+        stats(j(SRC, "kt_train.db"), j(OUT, "r05_kernel_stats_train.csv"),
+              "python bench.py --workload train --steps 10 --warmup 3 --no-rocprof  (13 steps)")
     if os.path.exists(j(SRC, "clock_e2e.db")):
         clock(j(SRC, "clock_e2e.db"), j(OUT, "r05_clock_pmc_e2e.txt"),
               "python bench.py --workload e2e --e2e-mode frame --steps 4 --warmup 2 --no-rocprof")

@@ -9,6 +9,9 @@ python bench.py --workload e2e --e2e-mode $M --frames $F --steps $( [ $F = 1 ] &
 for S in 2 3 6; do python bench.py --workload e2e --e2e-mode frame --streams $S --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_streams$S.json 2>> $O/err.txt; done
 python bench.py --workload e2e --e2e-mode graph --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_graph_f1_guard32.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --frames 4 --streams 2 --steps 80 --warmup 8 > $O/bench_e2e_frame_f4_streams2.json 2>> $O/err.txt
+# larger batches per call (the round quantisation of every kernel fades: 8.53 rounds x frames)
+for F in 8 16; do python bench.py --workload e2e --e2e-mode frame --frames $F --steps $((320 / F)) --warmup 4 --no-rocprof > $O/bench_e2e_frame_f$F.json 2>> $O/err.txt; done
+python bench.py --workload e2e --e2e-mode frame --frames 16 --offsets selected --steps 20 --warmup 4 --no-rocprof > $O/bench_e2e_frame_f16_selected.json 2>> $O/err.txt
 # variants: one stream inside the frame call; guard every 32nd frame; the offset decoder on the selected pairs only (opt-in)
 python bench.py --workload e2e --e2e-mode frame --no-side-stream --steps 300 --warmup 30 > $O/bench_e2e_frame_f1_onestream.json 2>> $O/err.txt
 python bench.py --workload e2e --e2e-mode frame --guard-every 32 --steps 320 --warmup 30 > $O/bench_e2e_frame_f1_guard32.json 2>> $O/err.txt
@@ -22,6 +25,7 @@ python bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --pmc > $O/be
 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config4.json 2>> $O/err.txt
 python bench.py --precision f16x3 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f16x3.json 2>> $O/err.txt
 python bench.py --imnet-gf 128 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gf128.json 2>> $O/err.txt
+python bench.py --imnet-gf 32 --steps 5 --warmup 2 --no-cpu-baseline --no-rocprof > $O/bench_gf32.json 2>> $O/err.txt
 for w in decoders embed train train-query train-refine; do python bench.py --workload $w --steps 10 --warmup 3 > $O/bench_$w.json 2>> $O/err.txt; done
 python bench.py --offsets selected --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_selected.json 2>> $O/err.txt
 python bench.py --workload train-query --offsets selected --steps 10 --warmup 3 > $O/bench_train-query_selected.json 2>> $O/err.txt
@@ -35,13 +39,14 @@ rocprofv3 --kernel-trace --stats -d /tmp/p_kr -o r -- python $R/bench.py --confi
 rocprofv3 --kernel-trace --stats -d /tmp/p_ke -o r -- python $R/bench.py --workload e2e --e2e-mode frame --steps 10 --warmup 3 --no-rocprof > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o r -- python $R/bench.py --workload train-refine --steps 10 --warmup 3 --no-rocprof > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/p_tq -o r -- python $R/bench.py --workload train-query --steps 10 --warmup 3 --no-rocprof > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p_tn -o r -- python $R/bench.py --workload train --steps 10 --warmup 3 --no-rocprof > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d /tmp/p_m -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d /tmp/p_ce -o r -- python $R/bench.py --workload e2e --e2e-mode frame --steps 4 --warmup 2 --no-rocprof > /dev/null 2>&1
 cd $R
 cp /tmp/p_kt/r_results.db $O/kt.db; cp /tmp/p_kr/r_results.db $O/kt_refine.db; cp /tmp/p_ke/r_results.db $O/kt_e2e.db
-cp /tmp/p_tr/r_results.db $O/kt_train_refine.db; cp /tmp/p_tq/r_results.db $O/kt_train_query.db
+cp /tmp/p_tr/r_results.db $O/kt_train_refine.db; cp /tmp/p_tq/r_results.db $O/kt_train_query.db; cp /tmp/p_tn/r_results.db $O/kt_train.db
 cp /tmp/p_f/r_results.db $O/fetch.db; cp /tmp/p_w/r_results.db $O/write.db; cp /tmp/p_m/r_results.db $O/mfma.db 2>/dev/null
 cp /tmp/p_ce/r_results.db $O/clock_e2e.db 2>/dev/null
 cp profiles/hbm_traffic.json /tmp/hbm_traffic.keep 2>/dev/null
