@@ -29,7 +29,11 @@ def _close(a, b, what):
 @pytest.mark.parametrize("kind,d,n,n_iter,sig", [("IMNET", 385, 333, 1, False), ("IEF", 385, 333, 2, False),
                                                   ("IEF", 334, 129, 3, True), ("IMNET", 265, 64, 1, True),
                                                   ("IEF", 385, 5000, 2, False), ("IEF", 385, 1, 2, False),
-                                                  ("IMNET", 27, 31, 1, False)])
+                                                  ("IMNET", 27, 31, 1, False),
+                                                  # (more than one middle pass of the IEF: the running sum of dZ1 over
+                                                  # the passes takes the first pass processed, adds the middle ones in
+                                                  # the encoding sweep and the last one in the chained launch)
+                                                  ("IEF", 385, 700, 4, False), ("IEF", 102, 2500, 3, True)])
 def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
     p = orc.randomize_biases(orc.init_decoder(kind, d, 11, 5.0), 12)
     m = make_module(kind, p, d, cuda, n_iter=n_iter, use_sigmoid=sig).train()
@@ -44,6 +48,21 @@ def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
     assert set(g_hip) == set(g_ref)
     for k in g_ref:
         _close(g_hip[k], g_ref[k], k)
+
+
+def test_rows_backward_is_run_to_run_identical(cuda):
+    """The decoders' backward on rows sums in a fixed order (slab reductions, no float atomics on the wide layers):
+    two runs of the same step give the same bits for the input gradient and every wide parameter gradient."""
+    d, n = 385, 4099
+    p = orc.randomize_biases(orc.init_decoder("IEF", d, 31, 5.0), 32)
+    m = make_module("IEF", p, d, cuda, n_iter=3).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, d, generator=g).to(cuda)
+    wgt = torch.randn(n, generator=g).to(cuda)
+    _, g1 = _grads(m, x, m, wgt)
+    _, g2 = _grads(m, x, m, wgt)
+    for k in ("input", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_3.weight"):
+        assert torch.equal(g1[k], g2[k]), k
 
 
 def test_backward_matches_cpu_oracle(cuda):
