@@ -21,18 +21,8 @@ import torch
 from . import _lib
 
 
-def _rows_buffer(n, nout, dev, pad):
-    """[n, nout] f32. pad: an INTERNAL activation that the next layer gathers row by row — rows a multiple of 1 KiB
-    apart put the 32 rows of a wavefront's operand on two of the sixteen L2 channels (scripts/linear_ubench.py:
-    614,400 x 256 -> 224 in 0.79 ms at a row stride of 256 floats, 0.65 ms at 288), so such buffers get 32 floats
-    of padding per row (a view of a wider buffer; never handed to the caller)."""
-    if pad and nout % 256 == 0 and n >= 4096:
-        return torch.empty((n, nout + 32), dtype=torch.float32, device=dev)[:, :nout]
-    return torch.empty((n, nout), dtype=torch.float32, device=dev)
-
-
 def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None, out=None,
-               pool=None, poolidx=None, w_col0=0, k=None, addrows2=None, addidx2=None, pad_out=False):
+               pool=None, poolidx=None, w_col0=0, k=None, addrows2=None, addidx2=None):
     """out = act(x @ weight[:, w_col0:w_col0+k].T + bias (+ addrows[addidx]) (+ addrows2[addidx2])) through
     lidf_linear_f32 / lidf_linear_gather2_f32.
     x [n, >=k] f32 (row stride free), weight [nout, ldw] f32; act 0 none / 1 max(v, slope*v).
@@ -52,7 +42,7 @@ def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None
     ldx = x.stride(0) if n > 1 else x.shape[1]   # (a single row: its real width, never a fabricated stride)
     b = bias.detach().contiguous() if bias is not None else None
     if out is None and pool is None:
-        out = _rows_buffer(n, nout, x.device, pad_out)
+        out = torch.empty((n, nout), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     wsb = L.lidf_linear_workspace_bytes(k)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
@@ -95,8 +85,8 @@ def _decoder_from_layer1(mod, n, dev, layer1):
     l1, l2, l3, l4 = mod.linear_1, mod.linear_2, mod.linear_3, mod.linear_4
     if not isinstance(mod, IEF):
         h = layer1(True)
-        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02, pad_out=True)
-        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02, pad_out=True)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
         return _out_act(mod, linear_hip(h, l4.weight, l4.bias))
     if l4.out_features != 1:
         raise RuntimeError("IEF feeds its output back through offset_enc = Linear(1, 16): out_dim must be 1")
@@ -108,9 +98,9 @@ def _decoder_from_layer1(mod, n, dev, layer1):
     off = torch.full((n, 1), _init_offset_value(mod), dtype=torch.float32, device=dev)
     for _ in range(int(mod.n_iter)):
         enc = linear_hip(off, mod.offset_enc.weight, mod.offset_enc.bias)
-        h = linear_hip(enc, l1.weight, None, act=1, slope=0.02, addrows=base, addidx=rows, w_col0=d, k=16, pad_out=True)
-        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02, pad_out=True)
-        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02, pad_out=True)
+        h = linear_hip(enc, l1.weight, None, act=1, slope=0.02, addrows=base, addidx=rows, w_col0=d, k=16)
+        h = linear_hip(h, l2.weight, l2.bias, act=1, slope=0.02)
+        h = linear_hip(h, l3.weight, l3.bias, act=1, slope=0.02)
         off = off + linear_hip(h, l4.weight, l4.bias)
     return _out_act(mod, off)
 
@@ -125,7 +115,7 @@ def decoder_forward(mod, x):
     l1 = mod.linear_1
     return _decoder_from_layer1(
         mod, n, x.device,
-        lambda act: linear_hip(x, l1.weight, l1.bias, act=1 if act else 0, slope=0.02 if act else 0.0, k=d, pad_out=True))
+        lambda act: linear_hip(x, l1.weight, l1.bias, act=1 if act else 0, slope=0.02 if act else 0.0, k=d))
 
 
 def pointnet_forward(mod, inp_feat, vox2point_idx, n_vox):
@@ -228,7 +218,7 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
 
             def layer1(act, w1=w1, voxpart=voxpart, raypart=raypart):
                 return linear_hip(pe, w1, None, act=1 if act else 0, slope=0.02 if act else 0.0, w_col0=Cv + Cr,
-                                  k=2 * E, addrows=voxpart, addidx=pv_i, addrows2=raypart, addidx2=pr_i, pad_out=True)
+                                  k=2 * E, addrows=voxpart, addidx=pv_i, addrows2=raypart, addidx2=pr_i)
             dst[p0:p1] = _decoder_from_layer1(dec, n, dev, layer1)
         del pe
     f32 = dict(dtype=torch.float32, device=dev)

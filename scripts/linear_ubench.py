@@ -34,9 +34,13 @@ def run(k, nout, ldx, ldo, reps=10, bias=False):
     print("k %4d nout %4d ldx %4d ldo %4d : %.3f ms  %.1f TFLOP/s issued (%.3f of 157.3)" % (k, nout, ldx, ldo, ms, tf, tf / 157.3))
 
 
+# (clocks: the first configurations of a cold process run 10-20 % slower than the same ones later — warm up first,
+# and the 256-float stride is measured again at the end)
+run(256, 256, 256, 256, reps=60)
+print("---- warm")
 for k, nout, ldx, ldo in ((256, 224, 256, 224), (256, 224, 260, 224), (256, 224, 264, 224), (256, 224, 288, 224),
                           (256, 224, 256, 385), (256, 224, 260, 388), (256, 256, 256, 256), (256, 256, 260, 256),
                           (256, 128, 256, 128), (256, 128, 260, 128), (256, 64, 256, 64), (256, 64, 260, 64),
                           (512, 256, 512, 256), (512, 256, 516, 256), (385, 256, 385, 256), (385, 256, 388, 256),
-                          (128, 256, 128, 256), (128, 256, 132, 256)):
+                          (128, 256, 128, 256), (128, 256, 132, 256), (256, 224, 256, 224), (256, 224, 288, 224)):
     run(k, nout, ldx, ldo)

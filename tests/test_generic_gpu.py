@@ -296,14 +296,13 @@ def test_linear_fuzz(cuda, seed):
     V2 = rnd.choice([1, 5, 97])
     add2 = torch.randn(V2, nout, generator=g) if use_add2 else None
     idx2 = torch.randint(0, V2, (n,), generator=g).int()
-    # operand rows / output rows with a stride of their own (the padded activations of generic.py)
+    # operand rows with a stride of their own
     xd_ = x.to(cuda)
     if rnd.random() < 0.5:
         xd_ = torch.cat((xd_, torch.full((n, 5), float("nan"), device=cuda)), 1)[:, :k]
     got = linear_hip(xd_, w.to(cuda), b.to(cuda) if use_bias else None, act=act, slope=slope,
                      addrows=add.to(cuda) if use_add else None, addidx=idx.to(cuda) if use_add else None,
-                     addrows2=add2.to(cuda) if use_add2 else None, addidx2=idx2.to(cuda) if use_add2 else None,
-                     pad_out=rnd.random() < 0.5)
+                     addrows2=add2.to(cuda) if use_add2 else None, addidx2=idx2.to(cuda) if use_add2 else None)
     ref = F.linear(x.double(), w.double(), b.double() if use_bias else None)
     if use_add:
         ref = ref + add[idx.long()].double()
