@@ -554,6 +554,17 @@ def secondary(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps  # one dominant kernel per step on torch's stream
+    # the host's share of a step (enqueue only: the device is idle at every start, nothing waits inside step()):
+    # a step whose host time approaches its device time reads the box's CPU, not the kernels
+    host = 0.0
+    nh = min(args.steps, 10)
+    for _ in range(nh):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        host += time.perf_counter() - th
+    torch.cuda.synchronize()
+    host_ms = host / max(nh, 1) * 1e3
     hbm = args.workload == "embed"
     split_rows = args.workload == "decoders" and args.precision == "f16x3"
     # frac = issued MFMA FLOP / time / peak where the instruction count is known (decoders); the
@@ -600,6 +611,7 @@ def secondary(args):
         "metric": "Mpoints/sec, %s" % args.workload, "value": round(P * args.steps / elapsed / 1e6, 2),
         "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "host_enqueue_ms_per_step": round(host_ms, 4),
         "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE_F16X3 if (args.workload == "decoders" and args.precision == "f16x3") else "f32",
         "data": "synthetic",
