@@ -15,6 +15,7 @@ gives the permutation back for code that needs the reference's order.
 All compute is in liblidf_hip.so; torch is used for device memory and the current stream only.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -551,7 +552,7 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
         _lib.require_cuda(pnet_select, names=["pnet_select"])
         if pnet_select.shape[0] != R:
             raise RuntimeError("pnet_select must have one entry per ray")
-    cells = _cell_lookup(grid, V, B, dev)
+    cells = _cell_lookup(grid, V, B, dev, voxel_bound)
     for _ in range(forward_times):
         out = torch.empty((R, 3), dtype=torch.float32, device=dev)
         q = _lib.LidfRefineArgs()
@@ -590,10 +591,17 @@ def lidf_refine(ray_dir, ray_pix, ray_bid, ray_flat, pred_pos, max_pair_id, pair
     return cur, end_voxel
 
 
-def _cell_lookup(grid, V, B, dev):
-    """LidfRefineArgs' optional cell table from get_occ_vox_bound's entries (None: every voxel is tested)."""
+def _cell_lookup(grid, V, B, dev, voxel_bound=None):
+    """LidfRefineArgs' optional cell table from get_occ_vox_bound's entries (None: every voxel is tested).
+    Contract: grid['xmin'] is the WIDENED origin get_occ_vox_bound returns (constants.XMIN - part_size / 2),
+    grid['part_size'] the cell edge and grid['voxel_coord'][v] the integer cell of voxel v, so that
+    voxel_bound[v, :3] == xmin + voxel_coord[v] * part_size. A grid dict that does not describe voxel_bound
+    (e.g. the un-widened xmin) would give other end voxels than the every-voxel test: with LIDF_VALIDATE_GRID=1
+    in the environment the relation is checked here (one host sync) and a mismatch raises."""
     if grid is None or V == 0:
         return None
+    if voxel_bound is not None and os.environ.get("LIDF_VALIDATE_GRID") == "1":
+        _validate_grid(grid, voxel_bound)
     coord = grid["voxel_coord"]
     _lib.require_cuda(coord, names=["grid['voxel_coord']"])
     _i32(coord, "grid['voxel_coord']")
@@ -607,6 +615,21 @@ def _cell_lookup(grid, V, B, dev):
     return {"coord": coord, "res": (C.c_int32 * 3)(*res), "xmin": (C.c_float * 3)(*xmin),
             "part": float(grid["part_size"]),
             "table": torch.empty((B * res[0] * res[1] * res[2],), dtype=torch.int32, device=dev)}
+
+
+def _validate_grid(grid, voxel_bound):
+    xm = grid["xmin"]
+    xm = torch.as_tensor(xm.tolist() if torch.is_tensor(xm) else list(xm), dtype=torch.float32,
+                         device=voxel_bound.device)
+    part = float(grid["part_size"])
+    coord = grid["voxel_coord"].to(torch.float32)
+    res = torch.as_tensor([int(v) for v in grid["grid_dims"]], dtype=torch.float32, device=voxel_bound.device)
+    lo = xm + coord * part
+    bad = ((voxel_bound[:, :3] - lo).abs().max() > 1e-4 * max(part, 1.0)) | (coord.min() < 0) | \
+        ((coord >= res).any())
+    if bool(bad.item()):
+        raise RuntimeError("grid dict does not describe voxel_bound: voxel_bound[:, :3] != xmin + voxel_coord * "
+                           "part_size (is grid['xmin'] the widened origin get_occ_vox_bound returns?)")
 
 
 def get_occ_vox_bound(valid_xyz, valid_bid, batch, xmin=(-1.0, -1.0, 0.0), xmax=(1.0, 1.0, 2.0),
@@ -966,8 +989,11 @@ class _QueryTailFn(torch.autograd.Function):
         sel = mid_in if mid_in is not None else mid
         ctx.save_for_backward(sel, pair_ray, ray_dir)
         ctx.cfg = (r0, r1, part, R, P, tuple(pred_offset.shape))
-        ctx.mark_non_differentiable(sm, mid)
-        return pos, sm, sel if mid_in is not None else mid, pred
+        # (exactly the returned tensors are marked; with a caller-supplied selection the output is a copy, never
+        # the caller's own tensor aliased as an output of the node)
+        mid_out = mid if mid_in is None else sel.clone()
+        ctx.mark_non_differentiable(sm, mid_out)
+        return pos, sm, mid_out, pred
 
     @staticmethod
     def backward(ctx, g_pos, g_sm, g_mid, g_pred):
@@ -1041,8 +1067,9 @@ class _QueryTrainFn(torch.autograd.Function):
         ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
         ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, acts[0], acts[1], *params)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(sm, mid)
-        return prob, off, pos, sm, sel if mid_in is not None else mid, pred
+        mid_out = mid if mid_in is None else sel.clone()   # (a copy: never the caller's tensor as an output)
+        ctx.mark_non_differentiable(sm, mid_out)
+        return prob, off, pos, sm, mid_out, pred
 
     @staticmethod
     def _forward_selected(ctx, prob_mod, off_mod, vf, rf, pe, pair_off, pair_ray, pair_vox, pair_t, ray_dir,
@@ -1085,8 +1112,9 @@ class _QueryTrainFn(torch.autograd.Function):
         ctx.names = [[k for k in _dec._PARAM_ORDER if _dec._has(m, k)] for m in (prob_mod, off_mod)]
         ctx.save_for_backward(vf, rf, pe, pair_off, pair_ray, pair_vox, ray_dir, sel, act_p, act_o, *params)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(sm, mid)
-        return prob, off, pos, sm, sel if mid_in is not None else mid, pred
+        mid_out = mid if mid_in is None else sel.clone()   # (a copy: never the caller's tensor as an output)
+        ctx.mark_non_differentiable(sm, mid_out)
+        return prob, off, pos, sm, mid_out, pred
 
     @staticmethod
     def backward(ctx, g_prob, g_off, g_pos, g_sm, g_mid, g_pred):
@@ -1098,6 +1126,12 @@ class _QueryTrainFn(torch.autograd.Function):
         dev = vf.device
         f32 = dict(dtype=torch.float32, device=dev)
         L = _lib.lib()
+        # (autograd hands expanded stride-0 gradients to a node for losses such as pred_pos.sum(): the kernels
+        # read [R,3] / [P,3] / [P,1] floats through raw pointers, so every incoming gradient is made dense first)
+        g_pred = g_pred.contiguous().float() if g_pred is not None else None
+        g_pos = g_pos.contiguous().float() if g_pos is not None else None
+        g_off = g_off.contiguous().float() if g_off is not None else None
+        g_prob = g_prob.contiguous().float() if g_prob is not None else None
         # offset_dec is reached through pred_pos alone — or ran on the selected pairs only in the forward
         rows_only = selected or (g_off is None and g_pos is None)
         g_off_rows = None
@@ -1256,6 +1290,35 @@ def refine_perturb_noise(perturb_prob=0.8):
     return np.random.random() * (0.1 - 0.05) + 0.05
 
 
+def _refine_train_args(cfg, x, rf, pn, do, out, end_voxel, ws, cells):
+    """LidfRefineArgs of one stage-2 training call from plain tensors (forward: out / end_voxel are the call's
+    outputs; backward: None — lidf_refine_train_backward_f32 writes neither)."""
+    t = cfg["tensors"]
+    B, _, h, w = t["rgb_img"].shape
+    q = _lib.LidfRefineArgs()
+    q.n_rays, q.ray_dir, q.ray_bid, q.ray_flat = x.shape[0], t["ray_dir"].data_ptr(), t["ray_bid"].data_ptr(), \
+        t["ray_flat"].data_ptr()
+    q.pred_pos, q.max_pair_id = x.data_ptr(), t["max_pair_id"].data_ptr()
+    q.pair_vox, q.n_pairs = t["pair_vox"].data_ptr(), t["pair_vox"].shape[0]
+    q.n_vox, q.voxel_bound, q.voxel_bid = t["voxel_bound"].shape[0], t["voxel_bound"].data_ptr(), \
+        t["voxel_bid"].data_ptr()
+    q.rgb_img, q.batch, q.height, q.width = t["rgb_img"].data_ptr(), B, h, w
+    q.rayfeat = rf.data_ptr()
+    q.n_valid, q.valid_inp, q.valid_vox = t["valid_inp"].shape[0], t["valid_inp"].data_ptr(), t["valid_vox"].data_ptr()
+    q.pnet, q.off = C.pointer(pn), C.pointer(do)
+    q.multires, q.multires_views = cfg["multires"], cfg["multires_views"]
+    q.pos_rel, q.pnet_pos_rel = int(bool(cfg["pos_rel"])), int(bool(cfg["pnet_pos_rel"]))
+    q.offset_range0, q.offset_range1 = float(cfg["offset_range"][0]), float(cfg["offset_range"][1])
+    q.pred_pos_out = out.data_ptr() if out is not None else None
+    q.end_voxel_id = end_voxel.data_ptr() if end_voxel is not None else None
+    q.workspace, q.workspace_bytes = ws.data_ptr(), ws.numel()
+    q.precision = PRECISIONS["f32"]
+    if cells is not None:
+        q.voxel_coord, q.cell_table = cells["coord"].data_ptr(), cells["table"].data_ptr()
+        q.grid_res, q.grid_xmin, q.grid_part = cells["res"], cells["xmin"], cells["part"]
+    return q
+
+
 class _RefineTrainFn(torch.autograd.Function):
     """RefineNet.forward 'train' as ONE autograd node: lidf_refine_train_forward_f32 keeps what
     lidf_refine_train_backward_f32 needs in one `act` buffer (weight streams of the step, the per-ray layer-1
@@ -1287,33 +1350,15 @@ class _RefineTrainFn(torch.autograd.Function):
         end_voxel = torch.empty((R,), dtype=torch.int32, device=dev)
         x = pred_pos.detach().contiguous()
         rf = rayfeat.detach().contiguous()
-        cells = _cell_lookup(cfg["grid"], V, B, dev)
-
-        def args():
-            q = _lib.LidfRefineArgs()
-            q.n_rays, q.ray_dir, q.ray_bid, q.ray_flat = R, t["ray_dir"].data_ptr(), t["ray_bid"].data_ptr(), \
-                t["ray_flat"].data_ptr()
-            q.pred_pos, q.max_pair_id = x.data_ptr(), t["max_pair_id"].data_ptr()
-            q.pair_vox, q.n_pairs = t["pair_vox"].data_ptr(), P
-            q.n_vox, q.voxel_bound, q.voxel_bid = V, t["voxel_bound"].data_ptr(), t["voxel_bid"].data_ptr()
-            q.rgb_img, q.batch, q.height, q.width = t["rgb_img"].data_ptr(), B, h, w
-            q.rayfeat = rf.data_ptr()
-            q.n_valid, q.valid_inp, q.valid_vox = Nv, t["valid_inp"].data_ptr(), t["valid_vox"].data_ptr()
-            q.pnet, q.off = C.pointer(pn), C.pointer(do)
-            q.multires, q.multires_views = L_, Lv
-            q.pos_rel, q.pnet_pos_rel = int(bool(cfg["pos_rel"])), int(bool(cfg["pnet_pos_rel"]))
-            q.offset_range0, q.offset_range1 = float(cfg["offset_range"][0]), float(cfg["offset_range"][1])
-            q.pred_pos_out, q.end_voxel_id = out.data_ptr(), end_voxel.data_ptr()
-            q.workspace, q.workspace_bytes = ws.data_ptr(), ws.numel()
-            q.precision = PRECISIONS["f32"]
-            if cells is not None:
-                q.voxel_coord, q.cell_table = cells["coord"].data_ptr(), cells["table"].data_ptr()
-                q.grid_res, q.grid_xmin, q.grid_part = cells["res"], cells["xmin"], cells["part"]
-            return q
+        cells = _cell_lookup(cfg["grid"], V, B, dev, t["voxel_bound"])
+        q = _refine_train_args(cfg, x, rf, pn, do, out, end_voxel, ws, cells)
         with torch.cuda.device(dev):
-            _lib.check(L.lidf_refine_train_forward_f32(C.byref(args()), T, _lib.ptr(act), act.numel(),
+            _lib.check(L.lidf_refine_train_forward_f32(C.byref(q), T, _lib.ptr(act), act.numel(),
                                                        _lib.current_stream(dev)))
-        ctx.cfg, ctx.args, ctx.keep, ctx.ws, ctx.cells = cfg, args, keep, ws, cells
+        # (nothing that references `out` is kept on ctx: a ctx-held closure over the output would close the cycle
+        # out -> grad_fn -> ctx -> closure -> out and keep ~1 GB of workspace alive until Python's cycle collector
+        # runs; the backward rebuilds the argument block from the saved tensors and allocates its own scratch)
+        ctx.cfg, ctx.cells = cfg, cells
         ctx.mark_non_differentiable(end_voxel)
         ctx.save_for_backward(x, rf, act, *params)   # (saved: an in-place update before backward raises)
         return out, end_voxel
@@ -1346,8 +1391,10 @@ class _RefineTrainFn(torch.autograd.Function):
         keep = []
         pn = _pn_struct_from(params[:npn], keep)
         do = _decoder_struct(cfg["offset_dec"], keep, tensors=dict(zip(cfg["dec_names"], params[npn:])))
-        q = ctx.args()
-        q.pnet, q.off = C.pointer(pn), C.pointer(do)
+        R, Nv, V = x.shape[0], cfg["tensors"]["valid_inp"].shape[0], cfg["tensors"]["voxel_bound"].shape[0]
+        ws = torch.empty((max(_lib.lib().lidf_refine_train_workspace_bytes(R, Nv, V, cfg["multires"]), 1),),
+                         dtype=torch.uint8, device=dev)
+        q = _refine_train_args(cfg, x, rf, pn, do, None, None, ws, ctx.cells)
         q.cell_table_ready = 1 if ctx.cells is not None else 0
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lidf_refine_train_backward_f32(

@@ -580,7 +580,10 @@ typedef struct LidfFrameArgs {
      * still reading feat_grid / writing rayfeat after the caller frees them).
      * fail_after (test hook, 0 = off): the call returns LIDF_ERR_HIP right after enqueuing stage k, exactly as
      * a failed launch there would — 1 frame head (second fork open), 2 pairs / PointNet rows, 3 PointNet,
-     * 4 query. tests/test_frame_gpu.py forces mid-frame failures with it.                             */
+     * 4 query. tests/test_frame_gpu.py forces mid-frame failures with it. The field is honoured ONLY in a process
+     * whose environment has LIDF_TEST_FAULTS=1; everywhere else it is ignored, so a caller compiled against an
+     * older, shorter struct that did not zero the tail cannot trip it. (General rule of this header: structs grow
+     * at the end between ABI versions — memset the whole struct to zero before filling it.)               */
     int32_t fail_after;
 } LidfFrameArgs;
 #define LIDF_FRAME_PACK_CALLER 0
@@ -854,7 +857,8 @@ int lidf_pointnet_backward_f32(const LidfPointNet* w, const float* inp, const in
  * act: lidf_refine_train_act_bytes(...) bytes, written by the forward, read by the backward (the
  * parameters must not change in between). n_pass = off->n_iter for an IEF, 1 for an IMNet.
  * backward: g_pos [R,3] = dL/d pred_pos_out; d_pred_pos [R,3] / d_rayfeat [R, 128 + 3+6*multires_views]
- * optional outputs (NULL: not formed).                                                              */
+ * optional outputs (NULL: not formed). The backward takes the forward's argument block; its workspace is pure
+ * scratch (it may be another buffer of the same size) and pred_pos_out / end_voxel_id may be NULL there.  */
 size_t lidf_refine_train_act_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox, int32_t multires,
                                    int32_t multires_views, int32_t n_pass, int32_t forward_times);
 size_t lidf_refine_train_workspace_bytes(int64_t n_rays, int64_t n_valid, int64_t n_vox, int32_t multires);

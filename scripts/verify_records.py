@@ -1,0 +1,162 @@
+"""Recompute every roofline fraction of a round's committed records from the committed rocprofv3 summaries alone.
+
+    python scripts/verify_records.py [tag]        (default tag: r06; files profiles/<tag>_*)
+
+A reader who follows the rule "F x units / the CSV's average duration / peak" must land on the number the JSON
+record states (the r05 headline CSVs mixed three launch shapes and gave 1.83 where the record
+said 0.88). Checks, each printed with its numbers:
+  * headline: `lidf_points_fused_kernel` in <tag>_kernel_stats.csv has steps + warmup calls of ONE shape;
+    frac = flop_per_point_exec x points / avg_after_first_ns / 157.3e12 equals the record's `frac_rocprof` within
+    1 % (and over all calls `frac_rocprof_all` within 2.5 %); the record's own arithmetic (value, frac) holds;
+    profile.busy_ms_per_step <= 1.03 x ms_per_step.
+  * <tag>_hbm_pmc.csv / <tag>_mfma_pmc.csv: the dominant kernel's HBM bytes (2 x FETCH + WRITE) equal
+    roofline.traffic within 3 %; the MFMA counter's FLOP per point equals flop_per_point_counter within 0.5 %.
+  * configs[3]: <tag>_kernel_stats_refine.csv holds no every-voxel end-voxel launch; its per-point fraction matches
+    <tag>_bench_config3.json.
+  * training steps: the CSV's busy time per step equals the record's live profiler leg within 6 % and is
+    <= 1.03 x ms_per_step; the chain kernels' scratch_bytes are listed.
+Exit status 0 when every check passes. tests/test_records.py runs it on the committed files (no GPU)."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEAK = 157.3e12
+
+
+def read_csv(path):
+    rows = []
+    with open(path) as f:
+        lines = [ln for ln in f if not ln.startswith("#")]
+    for r in csv.DictReader(lines):
+        rows.append(r)
+    return rows
+
+
+def find(rows, key, part):
+    return [r for r in rows if part in r[key]]
+
+
+class Report:
+    def __init__(self):
+        self.items = []
+
+    def check(self, name, ok, detail):
+        self.items.append((name, bool(ok), detail))
+
+    def close(self, name, a, b, rel, what=""):
+        ok = a is not None and b is not None and abs(a - b) <= rel * max(abs(b), 1e-30)
+        self.check(name, ok, "%s%.6g vs %.6g (tolerance %.1f %%)" % (what, a if a is not None else float("nan"),
+                                                                   b if b is not None else float("nan"), rel * 100))
+
+    @property
+    def ok(self):
+        return all(i[1] for i in self.items)
+
+
+def load(p):
+    return json.loads(open(p).read().strip().splitlines()[-1])
+
+
+def verify(tag="r06", prof=None):
+    prof = prof or os.path.join(ROOT, "profiles")
+    j = lambda n: os.path.join(prof, "%s_%s" % (tag, n))   # noqa: E731
+    rep = Report()
+    # ---------------------------------------------------------------- headline
+    rec = load(j("bench_n1.json"))
+    rl = rec["roofline"]
+    P = rec["config"]["points_per_gpu"]
+    F = rl["flop_per_point_exec"]
+    rep.close("headline: value = points x steps / time", P / (rec["ms_per_step"] * 1e-3) / 1e6, rec["value"], 1e-3)
+    rep.close("headline: frac (HIP events) = F x P / kernel_ms / peak", F * P / (rl["kernel_ms"] * 1e-3) / PEAK,
+              rl["frac"], 2e-3)
+    rep.check("headline: kernel_ms <= ms_per_step", rl["kernel_ms"] <= rec["ms_per_step"],
+              "%.4f <= %.4f" % (rl["kernel_ms"], rec["ms_per_step"]))
+    rep.check("headline: busy_ms_per_step <= 1.03 x ms_per_step",
+              rec["profile"]["busy_ms_per_step"] <= 1.03 * rec["ms_per_step"],
+              "%.4f vs %.4f" % (rec["profile"]["busy_ms_per_step"], rec["ms_per_step"]))
+    rows = read_csv(j("kernel_stats.csv"))
+    dom = find(rows, "name", "lidf_points_fused_kernel")
+    rep.check("headline CSV: one row for lidf_points_fused_kernel", len(dom) == 1, "%d rows" % len(dom))
+    if dom:
+        d = dom[0]
+        cmd = open(j("kernel_stats.csv")).readline()
+        steps = int(cmd.split("--steps")[1].split()[0]) + int(cmd.split("--warmup")[1].split()[0])
+        rep.check("headline CSV: calls = steps + warmup of one shape", int(d["calls"]) == steps,
+                  "%s calls, command has %d steps; min %.3f / max %.3f ms" % (d["calls"], steps, float(d["min_ns"]) / 1e6,
+                                                                          float(d["max_ns"]) / 1e6))
+        rep.check("headline CSV: no second launch shape (max <= 1.15 x min)",
+                  float(d["max_ns"]) <= 1.15 * float(d["min_ns"]), "min %s max %s" % (d["min_ns"], d["max_ns"]))
+        rep.check("headline CSV: no split-f16 / selected leg in the command", "lidf_points_h_kernel" not in
+                  "".join(r["name"] for r in rows), "kernels: %d" % len(rows))
+        rep.close("headline CSV: F x P / avg_after_first_ns / peak = record frac_rocprof",
+                  F * P / (float(d["avg_after_first_ns"]) * 1e-9) / PEAK, rl["frac_rocprof"], 0.01)
+        rep.close("headline CSV: F x P / avg_ns / peak = record frac_rocprof_all",
+                  F * P / (float(d["avg_ns"]) * 1e-9) / PEAK, rl["frac_rocprof_all"], 0.025)
+        rep.check("headline CSV: dominant kernel runs without scratch", int(d["scratch_bytes"]) == 0, d["scratch_bytes"])
+    # ---------------------------------------------------------------- counters
+    if os.path.exists(j("hbm_pmc.csv")):
+        h = find(read_csv(j("hbm_pmc.csv")), "kernel", "lidf_points_fused_kernel")
+        rep.check("HBM CSV: one row for the dominant kernel", len(h) == 1, "%d" % len(h))
+        if h and rl.get("traffic"):
+            rep.close("HBM CSV: 2 x FETCH + WRITE = roofline.traffic", float(h[0]["hbm_bytes_corrected"]), rl["traffic"], 0.03)
+    if os.path.exists(j("mfma_pmc.csv")):
+        m = [r for r in read_csv(j("mfma_pmc.csv")) if "lidf_points_fused_kernel" in r["kernel"]
+             and r["counter"] == "SQ_INSTS_VALU_MFMA_MOPS_F32"]
+        if m and rl.get("flop_per_point_counter"):
+            rep.close("MFMA CSV: counter x 512 / points = flop_per_point_counter", float(m[0]["avg_value"]) * 512.0 / P,
+                      rl["flop_per_point_counter"], 0.005)
+            rep.close("MFMA CSV: counter FLOP vs the instruction-stream count", float(m[0]["avg_value"]) * 512.0 / P, F, 0.015)
+    # ---------------------------------------------------------------- configs[3]
+    if os.path.exists(j("kernel_stats_refine.csv")):
+        rows = read_csv(j("kernel_stats_refine.csv"))
+        bad = [r["name"] for r in rows if "lidf_refine_endvox_kernel" in r["name"]]
+        rep.check("configs[3] CSV: end voxels through the cell table (no every-voxel launch)", not bad, str(bad))
+        if os.path.exists(j("bench_config3.json")):
+            r3 = load(j("bench_config3.json"))
+            d = find(rows, "name", "lidf_points_fused_kernel")
+            if d and r3["roofline"].get("frac_rocprof"):
+                rep.close("configs[3] CSV: per-point fraction = record frac_rocprof",
+                          F * P / (float(d[0]["avg_after_first_ns"]) * 1e-9) / PEAK, r3["roofline"]["frac_rocprof"], 0.015)
+    # ---------------------------------------------------------------- training steps
+    spills = []
+    for wl, marker, per in (("train-query", "lidf_points_fused_train_kernel", 1), ("train", "lidf_points_kernel<5>", 2),
+                            ("train-refine", "lidf_pnet_bwd_b_kernel", 2)):
+        cs, js = j("kernel_stats_%s.csv" % wl.replace("-", "_")), j("bench_%s.json" % wl)
+        if not (os.path.exists(cs) and os.path.exists(js)):
+            continue
+        rows, r = read_csv(cs), load(js)
+        mk = find(rows, "name", marker)
+        if not mk:
+            rep.check("%s CSV: marker kernel present" % wl, False, marker)
+            continue
+        nstep = sum(int(m["calls"]) for m in mk) / per
+        busy = sum(float(x["total_ns"]) for x in rows) / nstep / 1e6
+        rep.check("%s: CSV busy time per step <= 1.03 x ms_per_step" % wl, busy <= 1.03 * r["ms_per_step"],
+                  "%.4f ms busy over %.0f steps vs %.4f ms per step" % (busy, nstep, r["ms_per_step"]))
+        if r.get("profile"):
+            rep.close("%s: CSV busy time per step = the record's live profiler leg" % wl, busy,
+                      r["profile"]["busy_ms_per_step"], 0.06)
+            rep.check("%s: record busy_ms_per_step <= 1.03 x ms_per_step" % wl,
+                      r["profile"]["busy_ms_per_step"] <= 1.03 * r["ms_per_step"],
+                      "%.4f vs %.4f" % (r["profile"]["busy_ms_per_step"], r["ms_per_step"]))
+        for x in rows:
+            if int(x["scratch_bytes"] or 0) > 0 and "lidf_" in x["name"]:
+                spills.append((wl, x["name"].split("(")[0], int(x["scratch_bytes"]), float(x["pct"])))
+    return rep, spills
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+    rep, spills = verify(tag)
+    for name, ok, detail in rep.items:
+        print("%s  %s: %s" % ("ok  " if ok else "FAIL", name, detail))
+    for wl, k, b, pct in spills:
+        print("note  %s: %s uses %d B of scratch per lane (%.1f %% of the step's busy time)" % (wl, k, b, pct))
+    print("%d checks, %d failed" % (len(rep.items), sum(1 for i in rep.items if not i[1])))
+    return 0 if rep.ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

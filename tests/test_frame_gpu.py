@@ -332,7 +332,7 @@ def test_frame_with_a_side_stream(cuda, graph, offsets):
 
 
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
-def test_side_stream_is_joined_on_every_error_exit(cuda, stage):
+def test_side_stream_is_joined_on_every_error_exit(cuda, stage, monkeypatch):
     """A frame that fails between its fork and its joins (LidfFrameArgs.fail_after: the return a failed launch of
     that stage would take — stage 1: second fork just recorded, per-ray features queued on the side stream and
     no join recorded; 3: join recorded but not awaited) must leave nothing of itself running on the side
@@ -356,6 +356,7 @@ def test_side_stream_is_joined_on_every_error_exit(cuda, stage):
     ok, ref = fresh.result()
     assert ok
     runner = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4], side_stream=True)
+    monkeypatch.setenv("LIDF_TEST_FAULTS", "1")    # (the hook is ignored in a process without it)
     for rep in range(4):
         runner._fail_after = stage
         with torch.no_grad(), pytest.raises(RuntimeError):
@@ -368,6 +369,27 @@ def test_side_stream_is_joined_on_every_error_exit(cuda, stage):
         for k in ("rayfeat", "pred_prob_end", "pred_offset", "pred_pos", "pred_depth", "pred_pos_refine",
                   "pred_depth_refine", "occ_voxel_feat", "max_pair_id", "end_voxel_id"):
             assert torch.equal(dd[k], ref[k]), (k, stage, rep)
+
+
+def test_fault_hook_is_ignored_without_the_environment_switch(cuda, monkeypatch):
+    """LidfFrameArgs.fail_after only acts in a process with LIDF_TEST_FAULTS=1: a caller that left the trailing
+    field of the grown struct uninitialised gets its frame, not a spurious LIDF_ERR_HIP."""
+    from implicit_depth_amd import pipeline as pl
+    from implicit_depth_amd.synthetic import synthetic_batch
+    B, h, w = 1, 48, 64
+    models = _models(cuda)
+    opt = pl.LidfOptions(valid_stride=2)
+    batch, feat = synthetic_batch(B, h, w, seed=33)
+    batch, feat = _dev(batch, cuda), feat.to(cuda)
+    monkeypatch.delenv("LIDF_TEST_FAULTS", raising=False)
+    ref = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    runner = pl.FrameRunner(B, h, w, cuda, *models[:3], opt, models[3], models[4])
+    runner._fail_after = 3
+    with torch.no_grad():
+        ref.run(batch, feat)
+        runner.run(batch, feat)
+    (ok, a), (ok2, b) = ref.result(), runner.result()
+    assert ok and ok2 and a["counts"] == b["counts"] and torch.equal(a["pred_depth_refine"], b["pred_depth_refine"])
 
 
 @pytest.mark.parametrize("graph", [False, True])

@@ -480,3 +480,65 @@ def test_query_train_offsets_selected_no_pairs(cuda):
     assert (out["max_pair_id"] == 0).all()
     out["pred_pos"].sum().backward()
     assert all(p.grad is not None and (p.grad == 0).all() for p in list(prob.parameters()) + list(off.parameters()))
+
+
+@pytest.mark.parametrize("loss_kind", ["pred_pos_sum", "dense_sums"])
+def test_query_train_expanded_output_gradients(cuda, loss_kind):
+    """Losses whose output gradients reach the node as expanded stride-0 tensors (pred_pos.sum() hands a
+    [R,3] view of ONE element to the backward): the library reads raw pointers, so the node must
+    densify them — gradients against the oracle's autograd for the rows-only route (pred_pos alone) and the
+    dense route (pair_pred_pos / pred_offset / logits touched)."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(2, 10, 14, 6, seed=171, ragged=True)
+    D = scene["D"]
+    kw = dict(offset_range=(0.0, 1.0), part_size=0.25)
+
+    def loss(o):
+        if loss_kind == "pred_pos_sum":
+            return o["pred_pos"].sum()
+        return o["pred_pos"].sum() + o["pair_pred_pos"].sum() + o["pred_offset"].sum() + o["pred_prob_end"].sum()
+    pp = {k: v.clone().requires_grad_(True) for k, v in scene["prob_p"].items()}
+    po = {k: v.clone().requires_grad_(True) for k, v in scene["off_p"].items()}
+    fg = scene["feat_grid"].clone().requires_grad_(True)
+    vf = scene["vox_feat"].clone().requires_grad_(True)
+    ref = orc.query(scene["ray_dir"], scene["ray_pix"], scene["ray_bid"], scene["pair_ray"].long(),
+                    scene["pair_vox"].long(), scene["pair_t"], scene["pair_off"], fg, vf, pp, po, fast_roi=True, **kw)
+    loss(ref).backward()
+    s = to_dev(scene, cuda)
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", scene["off_p"], D, cuda).train()
+    fgd = s["feat_grid"].clone().requires_grad_(True)
+    vfd = s["vox_feat"].clone().requires_grad_(True)
+    out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                           s["pair_t"], fgd, vfd, prob, off, **kw)
+    loss(out).backward()
+
+    def close(a, b, what):
+        scale = max(1e-2, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 5e-4 * scale, (what, (a - b).abs().max().item(), scale)
+    close(fgd.grad.cpu(), fg.grad, "feat_grid")
+    close(vfd.grad.cpu(), vf.grad, "vox_feat")
+    for k, v in po.items():
+        close(dict(off.named_parameters())[k].grad.cpu(), v.grad, "off." + k)
+    for k, v in pp.items():
+        g = dict(prob.named_parameters())[k].grad
+        if v.grad is None:
+            assert g is None or (g == 0).all(), k
+        else:
+            close(g.cpu(), v.grad, "prob." + k)
+
+
+def test_query_train_selection_output_is_a_copy(cuda):
+    """A caller-supplied max_pair_id comes back as a tensor of the node's own (never the caller's tensor aliased
+    as an output), equal in value."""
+    from implicit_depth_amd.query import lidf_query_train
+    scene = orc.synthetic_scene(1, 8, 12, 6, seed=181)
+    s = to_dev(scene, cuda)
+    D, R = scene["D"], scene["R"]
+    prob = make_module("IMNET", scene["prob_p"], D, cuda).train()
+    off = make_module("IEF", scene["off_p"], D, cuda).train()
+    sel = (torch.arange(R) * 6).to(cuda)
+    for offsets in ("all", "selected"):
+        out = lidf_query_train(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                               s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off, max_pair_id=sel, offsets=offsets)
+        assert out["max_pair_id"].data_ptr() != sel.data_ptr() and torch.equal(out["max_pair_id"], sel)

@@ -387,3 +387,68 @@ torch.save(res, sys.argv[1])
     for k in a:
         scale = max(1e-2, b[k].abs().max().item())
         assert (a[k] - b[k]).abs().max().item() <= 2e-4 * scale, (k, (a[k] - b[k]).abs().max().item(), scale)
+
+
+def test_refine_train_node_frees_its_buffers_without_the_cycle_collector(cuda):
+    """The stage-2 training node keeps no closure over its own output (out -> grad_fn -> ctx ->
+    closure -> out kept ~1 GB of workspace per step alive until Python's cycle collector ran): with the
+    collector disabled, dropping the outputs — with or without a backward — returns the device memory."""
+    import gc
+    from implicit_depth_amd.query import get_occ_vox_bound, lidf_refine_train
+    from util import make_module, make_pointnet
+    g = torch.Generator().manual_seed(27)
+    B, h, w = 1, 16, 20
+    pts = torch.rand(300, 3, generator=g) * 1.6 + torch.tensor([-0.8, -0.8, 0.2])
+    occ = get_occ_vox_bound(pts.to(cuda), torch.zeros(300, dtype=torch.int32, device=cuda), B, res=8)
+    vb, vbid = occ["voxel_bound"], occ["occ_vox_bid"].int().contiguous()
+    V, R, P = vb.shape[0], 400, 500
+    ctr = ((vb[:, :3] + vb[:, 3:]) / 2).cpu()
+    pos0 = ctr[torch.randint(0, V, (R,), generator=g)] + (torch.rand(R, 3, generator=g) - 0.5) * 0.3
+    flat = torch.randint(0, h * w, (R,), generator=g)
+    args = dict(ray_dir=torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=1).to(cuda),
+                ray_pix=torch.stack((flat % w, flat // w), 1).int().to(cuda),
+                ray_bid=torch.zeros(R, dtype=torch.int32, device=cuda), ray_flat=flat.int().to(cuda),
+                max_pair_id=torch.randint(0, P + 1, (R,), generator=g).to(cuda),
+                pair_vox=torch.randint(0, V, (P,), generator=g).int().to(cuda), voxel_bound=vb, voxel_bid=vbid,
+                rgb_img=torch.randn(B, 3, h, w, generator=g).to(cuda),
+                feat_grid=torch.randn(B, 32, h, w, generator=g).to(cuda),
+                valid_inp=(torch.randn(200, 6, generator=g) * 0.2).to(cuda),
+                valid_vox=torch.randint(0, V, (200,), generator=g).int().to(cuda))
+    pnet = make_pointnet(orc.init_pointnet(5, 1.5), cuda).train()
+    dec = make_module("IEF", orc.randomize_biases(orc.init_decoder("IEF", 334, 77, 5.0), 78), 334, cuda).train()
+
+    def step(backward):
+        out, ev = lidf_refine_train(pred_pos=pos0.to(cuda), pnet_model=pnet, offset_dec=dec, grid=occ, **args)
+        if backward:
+            out.sum().backward()     # (an expanded stride-0 output gradient, too)
+    step(True)                       # allocator pools, gradient buffers
+    torch.cuda.synchronize()
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated(cuda)
+        for backward in (False, True, False):
+            step(backward)
+            torch.cuda.synchronize()
+            assert torch.cuda.memory_allocated(cuda) <= base + 4096, (backward, torch.cuda.memory_allocated(cuda), base)
+    finally:
+        if was:
+            gc.enable()
+
+
+def test_grid_dict_that_does_not_describe_the_voxels_is_refused_when_validated(cuda, monkeypatch):
+    """LIDF_VALIDATE_GRID=1: a grid dict whose origin is not the widened one of get_occ_vox_bound raises instead
+    of silently giving other end voxels than the every-voxel test."""
+    from implicit_depth_amd.query import _cell_lookup, get_occ_vox_bound
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(200, 3, generator=g) * 1.6 + torch.tensor([-0.8, -0.8, 0.2])
+    occ = get_occ_vox_bound(pts.to(cuda), torch.zeros(200, dtype=torch.int32, device=cuda), 1, res=8)
+    V = occ["voxel_bound"].shape[0]
+    monkeypatch.setenv("LIDF_VALIDATE_GRID", "1")
+    assert _cell_lookup(occ, V, 1, cuda, occ["voxel_bound"]) is not None
+    bad = dict(occ)
+    xm = occ["xmin"]
+    bad["xmin"] = [float(v) + 0.5 * float(occ["part_size"]) for v in (xm.tolist() if torch.is_tensor(xm) else xm)]
+    with pytest.raises(RuntimeError):
+        _cell_lookup(bad, V, 1, cuda, occ["voxel_bound"])
