@@ -853,6 +853,7 @@ def e2e(args):
                    "side_stream": (None if mode == "stepwise" else
                                    bool(side_mode or (side_mode is None and mode == "frame"))),
                    "guard_every": args.guard_every if mode != "stepwise" else None, "streams": max(1, args.streams) if mode != "stepwise" else 1,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "rays": R, "pairs": P, "pairs_per_ray": round(P / R, 3),
                    "voxels": V, "valid_points": NV,
                    "parallelism": "frames of the evaluation stream sharded over %d GPU(s), one FrameRunner per rank, "
@@ -974,6 +975,11 @@ def main():
     if args.config is not None:
         preset = {1: (1, 64, "query"), 2: (4, 64, "query"), 3: (1, 64, "query+refine"), 4: (4, 256, "query")}
         args.frames, args.samples, args.workload = preset[args.config]
+    if args.workload == "e2e" and (args.gpus > 1 or "RANK" in os.environ):
+        # A frame forks onto a side stream; RCCL brings streams of its own, and with HIP's default of 4 hardware
+        # queues the two streams of a frame can land on one queue (the frame then runs 6 % slower than without a
+        # process group: profiles/r06_ab_pg.txt). Must be in the environment before the first HIP call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # called as `python bench.py --gpus N`: become the launcher the driver would have used (one
         # process per GPU, RCCL rendezvous on the loopback address)

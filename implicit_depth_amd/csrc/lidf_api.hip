@@ -2239,7 +2239,7 @@ static int linear_impl(const float* x, int64_t ldx, int64_t n, int32_t k, const 
 }
 
 // partial blocks of the weight-gradient reduction: 512 row slices x (128 x 256 block + its bias part)
-#define WG_SCRATCH_FLOATS ((size_t)512 * (128 * 256 + 128))
+#define WG_SCRATCH_FLOATS ((size_t)512 * LIDF_WG_SLAB)
 #define ACT_ROW_FLOATS LIDF_ACT_ROW_FLOATS   // per row and pass: H1 | H2 | H3 | offset in | sign words (lidf_device.h)
 
 // ---- weight gradient of a linear layer of any width: C += A^T B, db += column sums of A -----------

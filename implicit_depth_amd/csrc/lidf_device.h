@@ -56,6 +56,10 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-
 #define LIDF_ACT_M1 (LIDF_ACT_OIN + 1)
 #define LIDF_ACT_M2 (LIDF_ACT_M1 + 8)
 #define LIDF_ACT_ROW_FLOATS (LIDF_ACT_M2 + 4)
+// partial block of the weight-gradient reduction (lidf_wgrad2_kernel / lidf_wgrad_reduce_kernel): a 128 x 256 block of
+// C and two runs of 256 sums taken through the vector unit: the bias sums (column sums of A: 128; swapped launch:
+// column sums of B: 256) and the products with ONE extra column of the other operand
+#define LIDF_WG_SLAB (128 * 256 + 512)
 #define LIDF_RING 8
 #define LIDF_L2_QUADS 33   // per output tile: (128 k-steps + 1 bias k-step) / 4, rounded up
 #define LIDF_L3_QUADS 17   // per output tile: (64 k-steps + 1 bias k-step) / 4, rounded up

@@ -131,7 +131,17 @@ struct Wgrad2Args {
     float* C; int ldc;
     float* db;
     long long rows_per_split;   // multiple of 8
-    float* part;                // optional [splits, mb, nb, 128*256 + 128] partial blocks
+    float* part;                // optional [splits, mb, nb, LIDF_WG_SLAB] partial blocks
+    int bcol0, acol0;           // B / A point at this column of their rows: the last row ends that many floats earlier
+    int swap;                   // 1 (SW instantiation): the caller handed the operands over SWAPPED — this launch's A is
+                                // the product's B (<= 128 columns), its B the product's A (<= 256 columns): a 256 x 102
+                                // or 256 x 128 gradient is ONE block of eight accumulator tiles per wavefront instead of
+                                // two single-half blocks of four. C is addressed transposed (C[col * ldc + m]), db holds
+                                // the column sums of B, xcol names an extra column of A.
+    int xcol;                   // >= 0: column xcol of B (and of C) is one more column, beyond the block's N: its
+                                // products with the block's A rows are 4 vector FMAs per row pair beside the matrix
+                                // instructions (385 = 3 x 128 + 1 columns of the decoders' input rows: the one
+                                // column would otherwise occupy a 128-column half block of its own). Not with HM.
 };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
@@ -144,13 +154,15 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 // the A columns {2c, 2c+1}, wavefront w the column 2c + (w & 1) and the two column tiles
 // {2 (w >> 1), 2 (w >> 1) + 1}: two matrix instructions per row pair instead of four on a half-empty
 // block (16 rows per step, so that a step is still 16 matrix instructions between barriers).
-template <bool TWO, bool HM>
+template <bool TWO, bool HM, bool XC = false, bool SW = false>
 __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
+    static_assert(!SW || (TWO && !HM), "the swapped form is the two-half block");
     // RS rows of A (128 columns) and of B (256 columns) per step, staged once per workgroup through
     // LDS (double-buffered): the four wavefronts read the same B rows and the same A float4
     constexpr int RS = HM ? 16 : 8;
     __shared__ f32x4w sA[2][RS][HM ? 16 : 32];   // [buffer][row][float4 column]
     __shared__ f32x4w sB[2][RS][HM ? 32 : 64];
+    __shared__ float sX[2][RS];                  // the extra column's RS values of a step
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int m0 = HM ? 0 : blockIdx.y * 128, n0 = HM ? 0 : blockIdx.z * 256;
@@ -159,9 +171,9 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
     if (r1 > a.n) r1 = a.n;
     const int nrows = r0 < r1 ? (int)(r1 - r0) : 0;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.A + (size_t)r0 * a.lda), 0, (int)((size_t)nrows * a.lda * 4), 0x00020000);
+        (void*)(a.A + (size_t)r0 * a.lda), 0, nrows > 0 ? (int)(((size_t)nrows * a.lda - a.acol0) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.B + (size_t)r0 * a.ldb), 0, (int)((size_t)nrows * a.ldb * 4), 0x00020000);
+        (void*)(a.B + (size_t)r0 * a.ldb), 0, nrows > 0 ? (int)(((size_t)nrows * a.ldb - a.bcol0) * 4) : 0, 0x00020000);
     // staging role of this thread: row tr (0..7) of the step, float4 column tc (A), tc and tc+32 (B);
     // HM: rows tr and tr + 8, A only from the threads tc < 16
     const int tr = threadIdx.x >> 5, tc = threadIdx.x & 31;
@@ -171,6 +183,11 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
     const int gb1 = second ? gb0 + 512 : 0x7ffffff0;
     const int sa = (int)(a.lda * 4 * RS), sbb = (int)(a.ldb * 4 * RS);  // RS rows
     const int ha = (int)(a.lda * 32), hb = (int)(a.ldb * 32);           // HM: the thread's second row
+    constexpr bool xc = XC && !HM;   // (a launch with xcol >= 0 takes the XC instantiation)
+    const int gx = (xc && tc == 0) ? (int)((tr * (SW ? a.lda : a.ldb) + a.xcol) * 4) : 0x7ffffff0;
+    const __amdgpu_buffer_rsrc_t rx = SW ? ra : rb;   // the extra column lives in the operand that has <= 128 columns
+    const int sx = SW ? (int)(a.lda * 4 * RS) : (int)(a.ldb * 4 * RS);
+    f32x2 bs2 = {0.f, 0.f}, xs2 = {0.f, 0.f};          // swapped form: sums over this lane's two B columns
     constexpr int NT = HM ? 2 : (TWO ? 8 : 4);
     f32x16 acc[NT];
 #pragma unroll
@@ -178,10 +195,12 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     }
-    f32x4w asum = {0.f, 0.f, 0.f, 0.f};
+    f32x4w asum = {0.f, 0.f, 0.f, 0.f}, xsum = {0.f, 0.f, 0.f, 0.f};
     float asum1 = 0.f;
     const int nstep = (nrows + RS - 1) / RS;
     f32x4w ga4 = LDX4(ra, ga, 0), gb4 = LDX4(rb, gb0, 0), gc4 = {0.f, 0.f, 0.f, 0.f};
+    float gx1 = 0.f;
+    if (xc) gx1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, gx, 0, 0));
     f32x4w ga5 = gc4, gb5 = gc4;
     if (TWO) gc4 = LDX4(rb, gb1, 0);
     if (HM) {
@@ -200,6 +219,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
             sA[buf][tr][tc] = ga4;
             sB[buf][tr][tc] = gb4;
             if (TWO) sB[buf][tr][32 + tc] = gc4;
+            if (xc && tc == 0) sX[buf][tr] = gx1;
         }
     };
     stage(0);
@@ -210,6 +230,7 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
             ga4 = LDX4(ra, ga, (st + 1) * sa);
             gb4 = LDX4(rb, gb0, (st + 1) * sbb);
             if (TWO) gc4 = LDX4(rb, gb1, (st + 1) * sbb);
+            if (xc) gx1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, gx, (st + 1) * sx, 0));
             if (HM) {
                 ga5 = LDX4(ra, ga, (st + 1) * sa + ha);
                 gb5 = LDX4(rb, gb0, (st + 1) * sbb + hb);
@@ -241,12 +262,19 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
                         acc[2 * j] = MFMA(a4[j], b2[0], acc[2 * j]);
                         acc[2 * j + 1] = MFMA(a4[j], b2[1], acc[2 * j + 1]);
                     }
+                    if constexpr (SW) {
+                        bs2 += b2;
+                        if (xc) xs2 += b2 * sX[cur][2 * u + h];
+                    }
                 } else {
                     const float b1 = fb[(2 * u + h) * 256 + 4 * c + wave];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] = MFMA(a4[j], b1, acc[j]);
                 }
-                asum += a4;
+                if constexpr (!SW) {
+                    asum += a4;
+                    if (xc) xsum += a4 * sX[cur][2 * u + h];
+                }
             }
         }
         if (st + 1 < nstep) stage(cur ^ 1);
@@ -269,13 +297,24 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
     if (a.part) {
         // deterministic path: this block's partial sums go to its own slab, summed by
         // lidf_wgrad_reduce_kernel in a fixed order
-        float* slab = a.part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 256 + 128);
+        float* slab = a.part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * LIDF_WG_SLAB;
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) slab[c_row(q, e) * 256 + c_col(e)] = acc[e][q];
         }
-        if (HM) {
+        if (SW) {   // every wavefront holds the sums of its own two B columns per lane
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = bs2[e], x = xs2[e];
+                v += __shfl_xor(v, 32);
+                x += __shfl_xor(x, 32);
+                if (h == 0) {
+                    slab[128 * 256 + c_col(e)] = v;
+                    if (xc) slab[128 * 256 + 256 + c_col(e)] = x;
+                }
+            }
+        } else if (HM) {
             if (wave < 2 && h == 0) slab[128 * 256 + 2 * c + wave] = asum1;
         } else if (wave == 0) {
 #pragma unroll
@@ -283,6 +322,13 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
                 float v = asum[e];
                 v += __shfl_xor(v, 32);
                 if (h == 0) slab[128 * 256 + 4 * c + e] = v;
+            }
+        } else if (wave == 1 && xc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = xsum[e];
+                v += __shfl_xor(v, 32);
+                if (h == 0) slab[128 * 256 + 256 + 4 * c + e] = v;
             }
         }
         return;
@@ -295,8 +341,24 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
         for (int q = 0; q < 16; ++q) {
             const int m = m0 + c_row(q, e);
             const float v = acc[e][q];
-            if (m < a.M && v != 0.f) atomicAdd(a.C + (size_t)m * a.ldc + col, v);
+            if (m < a.M && v != 0.f) atomicAdd(SW ? a.C + (size_t)col * a.ldc + m : a.C + (size_t)m * a.ldc + col, v);
         }
+    }
+    if (SW) {   // column sums of B / products with the extra column of A: first row block only
+        if (blockIdx.y == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = bs2[e], x = xs2[e];
+                v += __shfl_xor(v, 32);
+                x += __shfl_xor(x, 32);
+                const int col = n0 + c_col(e);
+                if (h == 0 && col < a.N) {
+                    if (a.db && v != 0.f) atomicAdd(a.db + col, v);
+                    if (xc && x != 0.f) atomicAdd(a.C + (size_t)col * a.ldc + a.xcol, x);
+                }
+            }
+        }
+        return;
     }
     // bias gradient: column sums of A (first column block only); lanes c and c+32 hold the two rows
     if (HM) {
@@ -311,6 +373,15 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
             if (h == 0 && m < a.M && v != 0.f) atomicAdd(a.db + m, v);
         }
     }
+    if (!HM && xc && blockIdx.z == 0 && wave == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = xsum[e];
+            v += __shfl_xor(v, 32);
+            const int m = m0 + 4 * c + e;
+            if (h == 0 && m < a.M && v != 0.f) atomicAdd(a.C + (size_t)m * a.ldc + a.xcol, v);
+        }
+    }
 }
 
 // C[m, col] += sum over the row slices of the partial blocks, in a fixed order (deterministic):
@@ -319,13 +390,13 @@ __global__ void __launch_bounds__(256, 2) lidf_wgrad2_kernel(Wgrad2Args a) {
 __global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                 int splits, int mb, int nb, int M,
                                                                 int N, float* __restrict__ C, int ldc,
-                                                                float* __restrict__ db) {
+                                                                float* __restrict__ db, int xcol, int swap) {
     __shared__ f32x4w red[8][32];
     const int blk = blockIdx.y;                  // (m block, n block)
     const int bm = blk / nb, bn = blk % nb;
-    const int e4 = blockIdx.x * 32 + (threadIdx.x & 31);   // float4 entry of the 128 x 256 (+128) slab
+    const int e4 = blockIdx.x * 32 + (threadIdx.x & 31);   // float4 entry of the 128 x 256 (+ 128 + 128) slab
     const int k = threadIdx.x >> 5;
-    constexpr int SLAB = 128 * 256 + 128;
+    constexpr int SLAB = LIDF_WG_SLAB;
     f32x4w s = {0.f, 0.f, 0.f, 0.f};
     // entries beyond the matrix (rows >= M, columns >= N of a partial block: a 64 x 128 or 256 x 102
     // operand fills a quarter or half of its slab; the single-half kernel never writes columns
@@ -334,6 +405,10 @@ __global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __r
     if (used && 4 * e4 < 128 * 256) {
         const int m = bm * 128 + (4 * e4) / 256, col = bn * 256 + (4 * e4) % 256;
         used = m < M && col < N;
+    } else if (used) {   // the bias sums, the extra column's sums: only where the producer wrote them
+        const int i = (4 * e4 - 128 * 256) % 256;
+        const bool own = swap ? (bm == 0 && bn * 256 + i < N) : (bn == 0 && i < 128 && bm * 128 + i < M);
+        used = own && (4 * e4 < 128 * 256 + 256 ? db != nullptr : xcol >= 0);
     }
     if (used) {
         const float* p = part + ((size_t)bm * nb + bn) * SLAB + 4 * (size_t)e4;
@@ -359,12 +434,82 @@ __global__ void __launch_bounds__(256) lidf_wgrad_reduce_kernel(const float* __r
         const int e = 4 * e4 + i;
         if (e < 128 * 256) {
             const int m = bm * 128 + e / 256, col = bn * 256 + e % 256;
-            if (m < M && col < N) C[(size_t)m * ldc + col] += s[i];
-        } else if (db && bn == 0) {
-            const int m = bm * 128 + (e - 128 * 256);
-            if (m < M) db[m] += s[i];
+            if (m < M && col < N) C[swap ? (size_t)col * ldc + m : (size_t)m * ldc + col] += s[i];
+        } else {
+            // (entry j of a run of sums belongs to row bm * 128 + j of C — swapped: to column bn * 256 + j of B)
+            const bool second = e >= 128 * 256 + 256;
+            const int j = e - 128 * 256 - (second ? 256 : 0);
+            const int at = swap ? bn * 256 + j : bm * 128 + j;
+            const bool own = swap ? (bm == 0 && at < N) : (bn == 0 && j < 128 && at < M);
+            if (!own) continue;
+            if (!second) {
+                if (db) db[at] += s[i];
+            } else if (xcol >= 0) {
+                C[(size_t)at * ldc + xcol] += s[i];
+            }
         }
     }
+}
+
+// One launch of the block kernel over the columns [0, N) of B / C (+ optionally the single column xcol >= N through the
+// vector unit) and its reduce. false: the operand does not fit the block kernel's 32-bit offsets.
+static bool wgrad2_launch(const float* A, long long lda, int M, const float* B, long long ldb, int bcol0, int N,
+                          int xcol, long long n, float* C, int ldc, float* db, float* g_wgrad_scratch,
+                          size_t g_wgrad_scratch_floats, hipStream_t st) {
+    Wgrad2Args w;
+    w.A = A; w.lda = lda; w.M = M; w.B = B; w.ldb = ldb; w.N = N; w.n = n; w.C = C; w.ldc = ldc;
+    w.db = db; w.xcol = xcol; w.bcol0 = bcol0; w.acol0 = 0; w.swap = 0;
+    // A gradient of more than 128 rows and at most 128 (+ 1) columns — S^T PE (256 x 102), the 128 + 1 remainder of
+    // the decoders' 385 input columns — with the operands swapped: one two-half block (eight accumulator tiles per
+    // wavefront, 24 bytes of LDS per lane and 8 matrix instructions) where the product's own orientation is two
+    // single-half blocks of four tiles (20 bytes per 4). Not for operands of a few hundred rows (one slice per block:
+    // two blocks are the parallelism there).
+    if (M > 128 && N <= 128 && n > 320) {
+        w.A = B; w.lda = ldb; w.M = N; w.acol0 = bcol0;
+        w.B = A; w.ldb = lda; w.N = M; w.bcol0 = 0;
+        w.swap = 1;
+    }
+    const int mb = (w.M + 127) / 128, nb = (w.N + 255) / 256;
+    // two workgroups per CU; with a scratch area for the partial blocks the slices are as long
+    // as possible (fewer partial sums), without it shorter slices keep the atomics spread
+    long long splits = (g_wgrad_scratch ? 512 : 1024) / (mb * nb);
+    // (slices of at least 64 rows: a per-ray or per-voxel operand of 76,800 or 729 rows still
+    // fills the chip instead of walking its rows in a few workgroups)
+    const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    // per-voxel operands (a frame has 50-150 occupied voxels, a training batch a few hundred rows): ONE slice
+    // per block of C, added straight into C — every element receives exactly one contribution, so the
+    // result is as deterministic as the slab path's, without the reduce launch that cost as much as the
+    // product itself (10 + 5 us per per-voxel layer, a dozen of them per training step)
+    const bool one_slice = g_wgrad_scratch && n <= 320;   // (measured: 729 rows in one slice 60 us, in 12 slices + reduce 35)
+    if (one_slice) splits = 1;
+    const bool half_m = !w.swap && M <= 64 && N <= 128 && mb == 1 && nb == 1 && xcol < 0;   // 64 x 128 block (layer 3)
+    const int rs = half_m ? 16 : 8;
+    w.rows_per_split = ((n + splits - 1) / splits + rs - 1) / rs * rs;
+    const long long sp = (n + w.rows_per_split - 1) / w.rows_per_split;
+    const size_t slice_bytes = (size_t)w.rows_per_split * (size_t)(lda > ldb ? lda : ldb) * 4;
+    const size_t need = (size_t)sp * mb * nb * LIDF_WG_SLAB;
+    w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats && !one_slice) ? g_wgrad_scratch : nullptr;
+    if (slice_bytes >= 0x7fffffffULL) return false;
+    const dim3 grid((unsigned)sp, mb, nb), blk(256);
+    const bool x = xcol >= 0;
+    if (w.swap) {
+        if (x) hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false, true, true>), grid, blk, 0, st, w);
+        else hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false, false, true>), grid, blk, 0, st, w);
+    } else if (half_m)
+        hipLaunchKernelGGL((lidf_wgrad2_kernel<false, true>), grid, blk, 0, st, w);
+    else if (N - (nb - 1) * 256 > 128 || nb > 1) {
+        if (x) hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false, true>), grid, blk, 0, st, w);
+        else hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false>), grid, blk, 0, st, w);
+    } else if (x)
+        hipLaunchKernelGGL((lidf_wgrad2_kernel<false, false, true>), grid, blk, 0, st, w);
+    else
+        hipLaunchKernelGGL((lidf_wgrad2_kernel<false, false>), grid, blk, 0, st, w);
+    if (w.part)
+        hipLaunchKernelGGL(lidf_wgrad_reduce_kernel, dim3((LIDF_WG_SLAB / 4 + 31) / 32, mb * nb),
+                           dim3(256), 0, st, w.part, (int)sp, mb, nb, w.M, w.N, C, ldc, db, xcol, w.swap);
+    return true;
 }
 
 extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, const float* B,
@@ -375,43 +520,29 @@ extern "C" hipError_t lidf_launch_wgrad(const float* A, long long lda, int M, co
     // the wide layers: 128 x 256 blocks (float4 loads want lda/ldb*4 within the 32-bit offsets the
     // buffer instructions take, and a slice of rows below 2 GiB)
     if (M >= 32 && N >= 4) {
-        Wgrad2Args w;
-        w.A = A; w.lda = lda; w.M = M; w.B = B; w.ldb = ldb; w.N = N; w.n = n; w.C = C; w.ldc = ldc;
-        w.db = db;
-        const int mb = (M + 127) / 128, nb = (N + 255) / 256;
-        // two workgroups per CU; with a scratch area for the partial blocks the slices are as long
-        // as possible (fewer partial sums), without it shorter slices keep the atomics spread
-        long long splits = (g_wgrad_scratch ? 512 : 1024) / (mb * nb);
-        // (slices of at least 64 rows: a per-ray or per-voxel operand of 76,800 or 729 rows still
-        // fills the chip instead of walking its rows in a few workgroups)
-        const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        // per-voxel operands (a frame has 50-150 occupied voxels, a training batch a few hundred rows): ONE slice
-        // per block of C, added straight into C — every element receives exactly one contribution, so the
-        // result is as deterministic as the slab path's, without the reduce launch that cost as much as the
-        // product itself (10 + 5 us per per-voxel layer, a dozen of them per training step)
-        const bool one_slice = g_wgrad_scratch && n <= 320;   // (measured: 729 rows in one slice 60 us, in 12 slices + reduce 35)
-        if (one_slice) splits = 1;
-        const bool half_m = M <= 64 && N <= 128 && mb == 1 && nb == 1;   // 64 x 128 block (layer 3)
-        const int rs = half_m ? 16 : 8;
-        w.rows_per_split = ((n + splits - 1) / splits + rs - 1) / rs * rs;
-        const long long sp = (n + w.rows_per_split - 1) / w.rows_per_split;
-        const size_t slice_bytes = (size_t)w.rows_per_split * (size_t)(lda > ldb ? lda : ldb) * 4;
-        const size_t need = (size_t)sp * mb * nb * (128 * 256 + 128);
-        w.part = (g_wgrad_scratch && need <= g_wgrad_scratch_floats && !one_slice) ? g_wgrad_scratch : nullptr;
-        if (slice_bytes < 0x7fffffffULL) {
-            if (half_m)
-                hipLaunchKernelGGL((lidf_wgrad2_kernel<false, true>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
-            else if (N - (nb - 1) * 256 > 128 || nb > 1)
-                hipLaunchKernelGGL((lidf_wgrad2_kernel<true, false>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
-            else
-                hipLaunchKernelGGL((lidf_wgrad2_kernel<false, false>), dim3((unsigned)sp, mb, nb), dim3(256), 0, st, w);
-            if (w.part)
-                hipLaunchKernelGGL(lidf_wgrad_reduce_kernel, dim3(((128 * 256 + 128) / 4 + 31) / 32, mb * nb),
-                                   dim3(256), 0, st, w.part, (int)sp, mb, nb, M, N, C, ldc, db);
-            return hipGetLastError();
-        }
+        // Column plan. The block kernel multiplies whole 256-column blocks (two 128-column halves per wavefront
+        // pair) or one 128-column block: columns are padded to that. Instead of ceil(N / 256) blocks of 256
+        // (385 columns of the decoders' input rows: 512 multiplied, a quarter of the matrix instructions on
+        // zeros — and 127 of the last 128 for ONE column), the full 256-column blocks go in one launch and the
+        // remainder in a second one of its own width: <= 128 columns as a single-half block, and a remainder
+        // of 128 k + 1 columns hands its last column to the vector unit (Wgrad2Args.xcol: 4 FMAs per row pair
+        // beside 16-32 matrix instructions). 385 = [256] + [128 + 1]: 384 columns multiplied.
+        const int full = (N / 256) * 256, rem = N - full;
+        const auto go = [&](const float* Bp, int Ncols, int xcol, float* Cp, float* dbp) {
+            return wgrad2_launch(A, lda, M, Bp, ldb, (int)(Bp - B), Ncols, xcol, n, Cp, ldc, dbp, g_wgrad_scratch,
+                                 g_wgrad_scratch_floats, st);
+        };
+        bool ok;
+        if (full > 0 && rem == 1)                       // 257, 513: the leftover column rides with the full blocks
+            ok = go(B, full, full, C, db);
+        else if (full > 0 && rem > 1 && rem <= 129) {   // 385 = [256] + [128 + 1], 300 = [256] + [44]
+            const bool x = rem == 129;
+            ok = go(B, full, -1, C, db) && go(B + full, x ? 128 : rem, x ? 128 : -1, C + full, nullptr);
+        } else if (full == 0 && rem == 129)             // 129 = [128 + 1]
+            ok = go(B, 128, 128, C, db);
+        else
+            ok = go(B, N, -1, C, db);
+        if (ok) return hipGetLastError();
     }
     WgradArgs a;
     a.A = A; a.lda = lda; a.M = M; a.B = B; a.ldb = ldb; a.N = N; a.n = n; a.C = C; a.ldc = ldc;

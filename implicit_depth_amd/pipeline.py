@@ -345,6 +345,11 @@ class FrameRunner:
         # bit-identical results. None (default) = for eager calls only: a replayed graph pays more for the
         # cross-stream edges than they save, and frames pipelined over several streams fill each other's gaps
         # already (FramePipeline passes False). True / False force it.
+        # In a process that also runs a process group (RCCL creates streams of its own) HIP's default of 4 hardware
+        # queues can put this side stream and the caller's stream on ONE queue: the fork then runs in sequence and a
+        # frame is 6 % slower than without the group (A/B in one session, profiles/r06_ab_pg.txt: 1.660 ms plain,
+        # 1.766 under a 1-rank nccl group, 1.675 with GPU_MAX_HW_QUEUES=8, 1.700 without the side stream). Export
+        # GPU_MAX_HW_QUEUES=8 before the first HIP call of such a process (bench.py --workload e2e --gpus N does).
         self.side_mode = side_stream
         self.side = None                           # (stream, ev_fork, ev_join): created by the first frame that forks
         self._fail_after = 0                       # LidfFrameArgs.fail_after (test hook: a mid-frame failure)

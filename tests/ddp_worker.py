@@ -70,7 +70,10 @@ def frame_inputs(scene, b, dev, gen, empty=False):
     s["valid_vox"] = torch.randint(0, Vb, (300,), generator=gen).int()
     # stage 2's inputs arrive detached from a frozen stage 1 (trainers/train_refine.py:73): positions near voxel
     # centres, a selection that names pairs of this frame's list or its dummy row
-    s["pos0"] = ctr[torch.randint(0, Vb, (hw,), generator=gen)] + (torch.rand(hw, 3, generator=gen) - 0.5) * 0.3
+    # (every position strictly inside an occupied voxel: a ray without a candidate takes its end voxel from the dummy
+    # row = voxel 0 OF THE BATCH when its point lies in no voxel, models/pipeline.py:924,942-943 — a cross-frame
+    # quirk of the reference that a per-frame shard cannot and need not reproduce)
+    s["pos0"] = ctr[torch.randint(0, Vb, (hw,), generator=gen)] + (torch.rand(hw, 3, generator=gen) - 0.5) * 0.2
     s["mid"] = torch.randint(0, s["P"] + 1, (hw,), generator=gen)
     if empty:    # no ray meets a voxel in this frame
         s["pair_off"] = torch.zeros_like(s["pair_off"])

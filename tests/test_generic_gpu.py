@@ -323,6 +323,39 @@ def test_linear_fuzz(cuda, seed):
     assert _rel(c, rc) <= 5e-6 and _rel(db, rb) <= 5e-6, (n, k, nout)
 
 
+@pytest.mark.parametrize("ncols", [64, 102, 128, 129, 257, 300, 384, 385, 386, 513, 641])
+@pytest.mark.parametrize("scratch", [True, False])
+def test_wgrad_column_plans(cuda, ncols, scratch):
+    """lidf_wgrad_f32 over the column counts that change its launch plan (round 6): whole 256-column blocks in
+    one launch, the remainder in a launch of its own width, a remainder of 128 k + 1 columns with its last column
+    through the vector unit (385 = [256] + [128 + 1] — the decoders' input rows). With the scratch area (slab
+    reduction, run-to-run identical) and without it (atomics); operands with row strides of their own; C and db
+    accumulate into what they held."""
+    from implicit_depth_amd import _lib
+    g = torch.Generator().manual_seed(ncols)
+    L = _lib.lib()
+    for m, n in ((256, 3000), (100, 517), (64, 1200)):
+        a = torch.randn(n, m, generator=g)
+        b = torch.randn(n, ncols, generator=g)
+        ad = torch.cat((a, torch.full((n, 4), float("nan"))), 1).to(cuda)          # lda = m + 4
+        bd = torch.cat((b, torch.full((n, 3), float("nan"))), 1).to(cuda)          # ldb = ncols + 3
+        ldc = ncols + 16
+        ws = torch.empty((L.lidf_wgrad_workspace_bytes() if scratch else 0,), dtype=torch.uint8, device=cuda)
+        outs = []
+        for rep in range(2):
+            c, db = torch.ones(m, ldc, device=cuda), torch.ones(m, device=cuda)
+            _lib.check(L.lidf_wgrad_f32(_lib.ptr(ad), m + 4, m, _lib.ptr(bd), ncols + 3, ncols, n, _lib.ptr(c), ldc,
+                                        _lib.ptr(db), _lib.ptr(ws) if scratch else None, ws.numel(),
+                                        _lib.current_stream(cuda)))
+            outs.append((c, db))
+        c, db = outs[0]
+        rc, rb = 1.0 + a.double().t() @ b.double(), 1.0 + a.double().sum(0)
+        assert _rel(c[:, :ncols], rc) <= 5e-6 and _rel(db, rb) <= 5e-6, (m, n, ncols)
+        assert (c[:, ncols:] == 1).all()                      # nothing beyond the matrix is touched
+        if scratch:
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_query_refuses_decoders_with_a_wide_head(cuda):
     """generic.query hands pred_prob / pred_offset to lidf_query_tail_f32 as [P] arrays (the reference reads
     pred_prob_end[:, 0] and a 1-wide offset, models/pipeline.py:437-442): an IMNet with out_dim != 1 —
