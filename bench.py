@@ -262,21 +262,33 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300, per_
         if db is None:
             return None
         cur = sqlite3.connect(db).cursor()
-        per = {}
+        per, order = {}, []
         for name, dur in cur.execute("select name, duration from kernels order by start"):
             per.setdefault(_short(name), []).append(dur)
+            order.append(_short(name))
         dom = [k for k in per if dominant in k]
         if not dom or len(per[dom[0]]) < 2:
             return None
         nstep = max(len(per[dom[0]]) // per_step, 1)   # (per_step launches of `dominant` make one step)
+        # launches of a step in the steady state: what lies between the first and the last launch of `dominant`
+        # (the process's set-up — module .to(device), synthetic inputs — issues copy / fill kernels of its own that
+        # a division of all launches by the step count books on the steps: 74 copyBuffer launches of an
+        # evaluation-path run are 74 whatever its number of frames)
+        at = [i for i, k in enumerate(order) if k == dom[0]]
+        steady = {}
+        for k in order[at[0]:at[-1]]:
+            steady[k] = steady.get(k, 0) + 1
+        nsteady = max((len(at) - 1) // per_step, 1)
         kern = {}
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
             kern[k] = {"calls_per_step": round(len(v) / nstep, 2), "avg_ms": round(sum(v) / len(v) / 1e6, 5),
-                       "avg_ms_after_first": round(sum(v[1:]) / max(len(v) - 1, 1) / 1e6, 5)}
+                       "avg_ms_after_first": round(sum(v[1:]) / max(len(v) - 1, 1) / 1e6, 5),
+                       "calls_per_step_steady": round(steady.get(k, 0) / nsteady, 2)}
         out = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d %s"
                           % (steps, warmup, " ".join(keep)),
                "steps_seen": nstep,
                "launches_per_step": round(sum(len(v) for v in per.values()) / nstep, 1),
+               "launches_per_step_steady": round(sum(steady.values()) / nsteady, 1),
                "busy_ms_per_step": round(sum(sum(v) for v in per.values()) / nstep / 1e6, 4),
                # (the same sum without every kernel's first launch — code load, cold caches, clock ramp)
                "busy_ms_per_step_after_first": round(sum(sum(v[1:]) / max(len(v) - 1, 1) * len(v) for v in per.values())
@@ -629,8 +641,8 @@ def secondary(args):
                      "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4),
                      "basis": "algorithmic bytes" if hbm else basis,
                      "achieved_alg": None if hbm else round(flop_alg * P / (kern_ms * 1e-3) / 1e12, 2)},
-        "profile": ({k: live[k] for k in ("command", "steps_seen", "launches_per_step", "busy_ms_per_step",
-                                          "busy_ms_per_step_after_first", "kernels") if k in live} if live else None)})
+        "profile": ({k: live[k] for k in ("command", "steps_seen", "launches_per_step", "launches_per_step_steady",
+                                          "busy_ms_per_step", "busy_ms_per_step_after_first", "kernels") if k in live} if live else None)})
 
 
 def e2e(args):
@@ -868,7 +880,7 @@ def e2e(args):
         "roofline_kernels_note": ("side stream: the stage-2 layer-1 table runs beside (in the tail of) the per-point "
                                   "kernel, whose duration then includes the shared rounds; per-kernel fractions of "
                                   "launches that never overlap: --no-side-stream" if side_on and roof else None),
-        "profile": ({k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step",
+        "profile": ({k: live[k] for k in ("command", "launches_per_step", "launches_per_step_steady", "busy_ms_per_step",
                                           "busy_ms_per_step_after_first", "kernels", "hbm", "mfma")
                      if k in live} if live else None),
         "metrics_frame0": {k: round(float(v), 6) for k, v in m.items()}})
@@ -1344,8 +1356,8 @@ def main():
             }
             del line["roofline_stage2"]["refine_ms_per_step"]
         if live:
-            line["profile"] = {k: live[k] for k in ("command", "launches_per_step", "busy_ms_per_step",
-                                                    "busy_ms_per_step_after_first", "kernels")}
+            line["profile"] = {k: live[k] for k in ("command", "launches_per_step", "launches_per_step_steady",
+                                                    "busy_ms_per_step", "busy_ms_per_step_after_first", "kernels")}
             if lh:
                 line["profile"]["hbm"] = lh
             if live.get("mfma"):

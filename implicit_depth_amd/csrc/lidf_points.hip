@@ -375,8 +375,17 @@ __device__ __forceinline__ float decoder_pass(const __amdgpu_buffer_rsrc_t srs, 
         {
             const int nx = s + LIDF_RING;
             const int rel = nx < LIDF_PASS_QUADS ? nx : nx - LIDF_PASS_QUADS;
+            // (the whole stream offset in the scalar operand, ONE vector offset: written as vq + k * 1024 the three
+            // lane offsets vq + 1024 / 2048 / 3072 became loop-invariant registers of their own — parked in AGPRs, a
+            // v_accvgpr_read in front of every second ring load, and in the activation-keeping variant one of them
+            // was spilled: a scratch reload + s_waitcnt vmcnt(0) in front of 37 ring loads per pass set, each
+            // draining the ring that is meant never to drain; LIDF_RING_VOFF=1 restores that form for A/B runs)
+#if defined(LIDF_RING_VOFF)
             ring[s % LIDF_RING] = LDQ(srs, vq + (rel & 3) * 1024,
                                       (nx < LIDF_PASS_QUADS ? pb : wb) + (rel >> 2) * 4096);
+#else
+            ring[s % LIDF_RING] = LDQ(srs, vq, (nx < LIDF_PASS_QUADS ? pb : wb) + rel * 1024);
+#endif
         }
         if (PF && s >= LIDF_PF_S0 && s < LIDF_PF_S0 + 64 && ((s - LIDF_PF_S0) & 1) == 0)
             dma_slot(vox_rows, vp_off, lds_addr, (s - LIDF_PF_S0) / 2);
@@ -753,7 +762,11 @@ __device__ __forceinline__ void points_fused_body(const PointsArgs& a) {
                 for (int s = 0; s < 24; ++s) {
                     const int t = s / 3, jq = s % 3;
                     const f32x4 q = ring[s % LIDF_RING];
+#if defined(LIDF_RING_VOFF)
                     ring[s % LIDF_RING] = LDQ(srs, vq + (s & 3) * 1024, qb + (s >> 2) * 4096);
+#else
+                    ring[s % LIDF_RING] = LDQ(srs, vq, qb + s * 1024);
+#endif
                     f32x16 c = base[t];
                     c = MFMA(q[0], sb[4 * jq + 0], c);
                     c = MFMA(q[1], sb[4 * jq + 1], c);
