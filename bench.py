@@ -736,7 +736,14 @@ def e2e(args):
                 if mode == "graph":
                     r.capture()
         runner = runners[0]
-        turn = {"i": 0}
+        turn = {"i": 0, "timed": False}
+        # HIP events of the library around the per-point kernel and the two stage-2 decoder launches
+        # (LidfFrameArgs.profile_events): the HIP-event clock of the fractions below, beside the profiler's.
+        # Only where the launches run alone — one stream, no side stream, eager.
+        hev, ev_sets = None, []
+        if S == 1 and mode == "frame" and side_mode is False and args.precision == "f32" and args.offsets == "all":
+            hev = HipEvents()
+            ev_sets = [[hev.create() for _ in range(6)] for _ in range(min(args.steps, 64))]
 
         gathered = torch.empty((world * B, h, w), device=dev) if use_dist else None
 
@@ -746,6 +753,10 @@ def e2e(args):
             with torch.no_grad():
                 if S == 1:
                     pl._mark(marks, "start")
+                    if ev_sets and marks is not None and (turn["i"] - 1) % args.steps < len(ev_sets) and turn["timed"]:
+                        runner.profile_events = ev_sets[(turn["i"] - 1) % args.steps]
+                    else:
+                        runner.profile_events = None
                     runner.run(batch, feat)          # input copies + the frame (+ graph replay)
                     pl._mark(marks, "frame")
                     m = runner.metrics(batch)
@@ -771,6 +782,8 @@ def e2e(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     all_marks = []
+    if mode != "stepwise":
+        turn["i"], turn["timed"] = 0, True
     for _ in range(args.steps):
         mk = []
         dd, m = step(mk)
@@ -779,6 +792,10 @@ def e2e(args):
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    hip_ms = None
+    if mode != "stepwise" and ev_sets:
+        n_ev = min(args.steps, len(ev_sets))
+        hip_ms = [sum(hev.elapsed_ms(es[2 * j], es[2 * j + 1]) for es in ev_sets[:n_ev]) / n_ev for j in range(3)]
     for mk in all_marks:
         for (n0, e0), (n1, e1) in zip(mk[:-1], mk[1:]):
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / args.steps
@@ -825,22 +842,35 @@ def e2e(args):
     roof = None
     side_on = mode != "stepwise" and bool(side_mode or (side_mode is None and mode == "frame"))
     if live and args.precision == "f32" and mode != "stepwise":
-        def frac(name, flop):
+        def frac(name, flop, hip=None):
+            """Issued FLOP of one launch / its duration / peak, on BOTH clocks where both exist: `frac_rocprof` from the
+            profiler's average duration (rocprofv3 --kernel-trace child of this command; short launches read up to
+            12 % longer there), `frac` from HIP events of the timed run itself (LidfFrameArgs.profile_events)."""
             k = live_kernel(live, name)
             if not k:
                 return None
             t = k["avg_ms_after_first"] * 1e-3
-            return {"kernel_ms": k["avg_ms_after_first"], "calls_per_step": k["calls_per_step"],
-                    "achieved": round(flop / t / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(flop / t / 1e12 / PEAK_F32_TFLOPS, 4)}
+            out = {"kernel_ms_rocprof": k["avg_ms_after_first"], "calls_per_step": k["calls_per_step"],
+                   "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                   "achieved_rocprof": round(flop / t / 1e12, 2),
+                   "frac_rocprof": round(flop / t / 1e12 / PEAK_F32_TFLOPS, 4),
+                   "clock": "frac_rocprof: rocprofv3 --kernel-trace (child run); frac: HIP events (timed run)"}
+            if hip:
+                out.update({"kernel_ms": round(hip, 5), "achieved": round(flop / (hip * 1e-3) / 1e12, 2),
+                            "frac": round(flop / (hip * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)})
+            else:   # (no HIP-event leg in this mode: side stream / several streams / graph)
+                out.update({"kernel_ms": None, "achieved": None, "frac": None})
+            return out
         npn = c["NPN"] if mode != "stepwise" else 0
         roof = {
             # (offsets='selected': two launches of one net each — P points, then R — : no single-launch fraction)
-            "points": (dict(frac("lidf_points_fused_kernel", F_EXEC * P) or {}, flop_per_point_exec=F_EXEC)
+            "points": (dict(frac("lidf_points_fused_kernel", F_EXEC * P, hip_ms[0] if hip_ms else None) or {},
+                            flop_per_point_exec=F_EXEC)
                        if args.offsets == "all" else None),
             # stage-2 decoder (lidf_ief16_kernel): per 16 rays 4 x 16 x 4 layer-1 + 2 passes x (12 bias + 16 rank-1 +
             # 512 + 128) v_mfma_f32_16x16x4_f32 of 2048 FLOP
-            "ief": dict(frac("lidf_ief16_kernel", F_IEF16 * R) or frac("lidf_points_kernel<6>", F_IEF32 * R) or {},
+            "ief": dict(frac("lidf_ief16_kernel", F_IEF16 * R, (hip_ms[1] + hip_ms[2]) / 2 if hip_ms else None)
+                        or frac("lidf_points_kernel<6>", F_IEF32 * R) or {},
                         sub_tiles=(R + 15) // 16, flop_per_ray_exec=F_IEF16),
             # PointNet2Stage chains of one refine pass: 44 (stage 1) and 444 (stage 2) matrix instructions per 32 points
             "pointnet_chain2": frac("lidf_pointnet_chain_kernel<2, true>", 444 * 4096 / 32.0 * (NV + 2 * npn) / 3.0),
@@ -1313,7 +1343,18 @@ def main():
                                               if lk and args.offsets == "all" else None),
                          "flop_per_point_exec": f_exec, "flop_per_point_alg": F_ALG,
                          "flop_per_point_counter": (round(lmk["mfma_flop"] / P, 1) if lmk and not h16 else None),
-                         "pipe": ({"ghz": lmk["ghz"], "mfma_busy": lmk["mfma_busy"]} if lmk else None),
+                         # which clock each fraction is on
+                         "clocks": {"frac": "HIP events recorded by the library on the launch stream around the kernel, "
+                                            "timed run",
+                                    "frac_rocprof": "rocprofv3 --kernel-trace child run of this command, launches "
+                                                    "after the kernel's first",
+                                    "pipe.ghz": "the rocprofv3 --pmc child run's shader clock (SQ_BUSY_CYCLES / 32 / "
+                                                "duration there), NOT the timed run's"},
+                         # (ghz_timed_implied: the clock at which the timed run's HIP-event duration holds the same
+                         # busy cycles the counter run saw — ghz x counter-run duration / HIP-event duration)
+                         "pipe": ({"ghz": lmk["ghz"], "mfma_busy": lmk["mfma_busy"], "kernel_us_pmc_run": lmk["us"],
+                                   "ghz_timed_implied": round(lmk["ghz"] * lmk["us"] / (kern_ms * 1e3), 3)}
+                                  if lmk else None),
                          "achieved_alg": round(ach_alg, 2), "frac_alg": round(ach_alg / peak, 4)},
             "hbm": {"bytes_alg": round(bytes_alg), "bytes_counter": lh["bytes_per_step"] if lh else None,
                     "gbps_alg": round(bytes_alg / (elapsed / args.steps) / 1e9, 2),

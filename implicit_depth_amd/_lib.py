@@ -15,7 +15,7 @@ LIDF_OK = 0
 # below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
 # lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
 # outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
-ABI = 10
+ABI = 11
 
 
 class LidfDecoder(C.Structure):
@@ -140,6 +140,7 @@ class LidfFrameArgs(C.Structure):
         ("pack_mode", C.c_int32), ("offsets_selected", C.c_int32),
         ("aux_stream", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
         ("fail_after", C.c_int32),
+        ("profile_events", C.POINTER(C.c_void_p)),
     ]
 
 

@@ -1905,7 +1905,9 @@ static int frame_impl(const LidfFrameArgs* a_in, lidf_stream_t stream, ForkState
     // iteration — leaves that launch and runs beside the per-point kernel: 104 registers and 17 KiB of LDS next
     // to its 220 and 128 KiB, in the matrix-pipe slots its one wavefront per SIMD leaves free, and in its tail)
     const bool xr_aside = two && rf && !split;
-    if ((rc = query_impl(&q, nullptr, nullptr, stream, counts, (rf && !split && !xr_aside) ? &xr : nullptr,
+    void* const* pev = a->profile_events;   // (benchmarks: HIP events around the matrix launches)
+    if ((rc = query_impl(&q, pev ? pev[0] : nullptr, pev ? pev[1] : nullptr, stream, counts,
+                         (rf && !split && !xr_aside) ? &xr : nullptr,
                          two ? (QP_RAYTAB | QP_MAIN) : QP_ALL, xr_aside ? a->ev_fork : nullptr)))
         return rc;
     if (xr_aside) {
@@ -1966,7 +1968,8 @@ static int frame_impl(const LidfFrameArgs* a_in, lidf_stream_t stream, ForkState
                 return rc;
             if ((rc = refine_ief_factorised(a->off_refine, D, vox_feat_r, C, inp_embed, a->end_voxel_id, N,
                                             offv, voxpart_r, (char*)a->packed_refine, st, 2,
-                                            counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX, nullptr, a->rayfeat,
+                                            counts + LIDF_FC_RAYS, counts + LIDF_FC_VOX,
+                                            (pev && it < 2) ? pev + 2 + 2 * it : nullptr, a->rayfeat,
                                             Ed, (float*)(ws + f.raypart_r), false, true)))
                 return rc;
         }

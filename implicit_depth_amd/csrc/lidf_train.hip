@@ -4,6 +4,7 @@
 // (lidf_decoder_backward_f32) runs the input-gradient chain through lidf_linear_kernel with the
 // transposed weights and the leaky-ReLU mask as epilogue, and reduces the weight gradients here.
 #include "lidf_device.h"
+#include <stdlib.h>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -472,7 +473,13 @@ static bool wgrad2_launch(const float* A, long long lda, int M, const float* B, 
     const int mb = (w.M + 127) / 128, nb = (w.N + 255) / 256;
     // two workgroups per CU; with a scratch area for the partial blocks the slices are as long
     // as possible (fewer partial sums), without it shorter slices keep the atomics spread
-    long long splits = (g_wgrad_scratch ? 512 : 1024) / (mb * nb);
+    static int slab_budget = -1;   // development knob (A/B runs): LIDF_WGRAD_SPLITS = row slices per product, <= 512
+    if (slab_budget < 0) {
+        const char* e = getenv("LIDF_WGRAD_SPLITS");
+        const int v = e ? atoi(e) : 0;
+        slab_budget = (v >= 64 && v <= 512) ? v : 512;
+    }
+    long long splits = (g_wgrad_scratch ? slab_budget : 1024) / (mb * nb);
     // (slices of at least 64 rows: a per-ray or per-voxel operand of 76,800 or 729 rows still
     // fills the chip instead of walking its rows in a few workgroups)
     const long long max_splits = g_wgrad_scratch ? (n + 63) / 64 : (n + 1023) / 1024;

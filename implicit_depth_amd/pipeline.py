@@ -353,6 +353,7 @@ class FrameRunner:
         self.side_mode = side_stream
         self.side = None                           # (stream, ev_fork, ev_join): created by the first frame that forks
         self._fail_after = 0                       # LidfFrameArgs.fail_after (test hook: a mid-frame failure)
+        self.profile_events = None                 # benchmarks: six hipEvent_t recorded around the matrix launches
         self.pack_blob = torch.empty((L.lidf_frame_pack_bytes(),), dtype=torch.uint8, device=dev)
         self.pack_guard = torch.zeros((L.lidf_frame_pack_guard_bytes(),), dtype=torch.uint8, device=dev)
         self.vidx, self.n_valid_idx = None, 0      # explicit valid points (load(valid_idx=))
@@ -489,6 +490,10 @@ class FrameRunner:
                     self.side = (torch.cuda.Stream(self.dev), _lib.hip_event(), _lib.hip_event())
             a.aux_stream, a.ev_fork, a.ev_join = self.side[0].cuda_stream, self.side[1], self.side[2]
         a.fail_after = int(self._fail_after)
+        if self.profile_events is not None:   # (benchmarks: six hipEvent_t, LidfFrameArgs.profile_events)
+            self._pev = (C.c_void_p * 6)(*[e if isinstance(e, C.c_void_p) else C.c_void_p(e)
+                                           for e in self.profile_events])
+            a.profile_events = C.cast(self._pev, C.POINTER(C.c_void_p))
         try:
             with torch.cuda.device(self.dev):
                 _lib.check(_lib.lib().lidf_frame_f32(C.byref(a), _lib.current_stream(self.dev)))

@@ -36,7 +36,7 @@ enum lidf_status {
 /* ABI version, bumped on any signature or struct-layout change and on added entry points. lidf_version() returns the value the
  * library was BUILT with; a binding compiled / written against this header must refuse a library that
  * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
-#define LIDF_ABI_VERSION 10
+#define LIDF_ABI_VERSION 11
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);
@@ -585,6 +585,12 @@ typedef struct LidfFrameArgs {
      * older, shorter struct that did not zero the tail cannot trip it. (General rule of this header: structs grow
      * at the end between ABI versions — memset the whole struct to zero before filling it.)               */
     int32_t fail_after;
+    /* profile_events (ABI 11; benchmarks only, NULL = none): six hipEvent_t recorded on `stream` around the three
+     * matrix launches of a frame whose fraction of the peak a record states — [0],[1] the per-point kernel
+     * (as lidf_query_profile_f32 does), [2],[3] / [4],[5] the stage-2 decoder of refine iterations 0 / 1 (as
+     * lidf_refine_profile_f32 does). Entries may be NULL. HIP-event durations of one-stream frames only: with
+     * the side stream the launches beside them stretch what the events bracket.                        */
+    void* const* profile_events;
 } LidfFrameArgs;
 #define LIDF_FRAME_PACK_CALLER 0
 #define LIDF_FRAME_PACK_GUARDED 1

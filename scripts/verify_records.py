@@ -149,7 +149,8 @@ def verify(tag="r06", prof=None):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
-    rep, spills = verify(tag)
+    prof = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else None
+    rep, spills = verify(tag, prof)
     for name, ok, detail in rep.items:
         print("%s  %s: %s" % ("ok  " if ok else "FAIL", name, detail))
     for wl, k, b, pct in spills:
