@@ -635,7 +635,11 @@ def secondary(args):
         "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE_F16X3 if (args.workload == "decoders" and args.precision == "f16x3") else "f32",
         "data": "synthetic",
-        "config": {"workload": "secondary: %s, P = %d rows" % (what, P)},
+        "config": {"workload": "secondary: %s, P = %d rows" % (what, P),
+                   # (train-query: offset_dec's backward over the selected rows and the forward's embedding rows run on
+                   # a side stream beside the large launches — kernels overlap, busy time per step exceeds the step)
+                   "concurrent_streams": (2 if args.workload == "train-query" and
+                                          os.environ.get("LIDF_TRAIN_STREAMS", "2") != "1" else 1)},
         "roofline": {"bound": "hbm" if hbm else "mfma", "achieved": round(ach, 2), "peak": peak,
                      "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),
                      "traffic": None, "kernel": name, "kernel_ms": round(kern_ms, 4),

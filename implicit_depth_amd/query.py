@@ -14,6 +14,7 @@ gives the permutation back for code that needs the reference's order.
 
 All compute is in liblidf_hip.so; torch is used for device memory and the current stream only.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -1009,6 +1010,17 @@ class _QueryTailFn(torch.autograd.Function):
         return (d_off.reshape(shape),) + (None,) * 9
 
 
+_TRAIN_SIDE = {}
+
+
+def _train_side_stream(dev):
+    """One side stream per device for the training steps' independent branches (created on first use)."""
+    s = _TRAIN_SIDE.get(dev.index)
+    if s is None:
+        s = _TRAIN_SIDE[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
 class _QueryTrainFn(torch.autograd.Function):
     """get_pred of the training step as ONE autograd node: both decoders (lidf_query_forward_train_f32, one launch
     of the per-point kernel with the activations kept) and the per-pair / per-ray tail (lidf_query_tail_f32).
@@ -1151,11 +1163,27 @@ class _QueryTrainFn(torch.autograd.Function):
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
         d_vox = torch.empty_like(vf) if ctx.needs_input_grad[2] else None
         d_ray = torch.empty_like(rf) if ctx.needs_input_grad[3] else None
-        grads_out = []
+        # offset_dec's backward over the selected rows is ~40 launches on R rows (76,800 where prob_dec's walk
+        # 614,400): latency, not work. The two backwards are independent until their input gradients are added, so
+        # that one runs on a side stream beside prob_dec's (its own workspace and d_vox / d_ray, added at the join;
+        # every sum keeps its fixed order). LIDF_TRAIN_STREAMS=1 keeps everything on the caller's stream.
+        two = (rows_only and P > 0 and os.environ.get("LIDF_TRAIN_STREAMS", "2") != "1"
+               and not torch.cuda.is_current_stream_capturing())
+        side = _train_side_stream(dev) if two else None
+        ws2 = d_vox2 = d_ray2 = None
+        if two:
+            ws2 = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+            d_vox2 = torch.empty_like(vf) if d_vox is not None else None
+            d_ray2 = torch.empty_like(rf) if d_ray is not None else None
+            side.wait_stream(torch.cuda.current_stream(dev))
+        grads_out = [None, None]
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            for i, (mod, act, names, ps) in enumerate(((ctx.mods[0], act_p, ctx.names[0], params[:n_prob]),
-                                                       (ctx.mods[1], act_o, ctx.names[1], params[n_prob:]))):
+            order = ((1, ctx.mods[1], act_o, ctx.names[1], params[n_prob:]),
+                     (0, ctx.mods[0], act_p, ctx.names[0], params[:n_prob]))
+            if not two:
+                order = order[::-1]
+            for i, mod, act, names, ps in order:
                 saved = dict(zip(names, ps))
                 keep = []
                 dec = _dec._decoder_struct(mod, keep, saved)
@@ -1169,10 +1197,13 @@ class _QueryTrainFn(torch.autograd.Function):
                 for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _dec._PARAM_ORDER):
                     setattr(gs, field, gt[k].data_ptr() if k in gt else None)
                 if i == 1 and rows_only:
-                    _lib.check(L.lidf_query_decoder_backward_rows_f32(
-                        C.byref(a), _lib.ptr(act), 1 if selected else 0, _lib.ptr(sel), _lib.ptr(g_pred),
-                        _lib.ptr(g_off_rows), _lib.ptr(ray_dir), float((r1 - r0) * 1.7320508075688772 * part),
-                        _lib.ptr(d_vox), _lib.ptr(d_ray), 1, C.byref(gs), _lib.ptr(ws), wsb, st))
+                    with torch.cuda.stream(side) if two else contextlib.nullcontext():
+                        _lib.check(L.lidf_query_decoder_backward_rows_f32(
+                            C.byref(a), _lib.ptr(act), 1 if selected else 0, _lib.ptr(sel), _lib.ptr(g_pred),
+                            _lib.ptr(g_off_rows), _lib.ptr(ray_dir), float((r1 - r0) * 1.7320508075688772 * part),
+                            _lib.ptr(d_vox2 if two else d_vox), _lib.ptr(d_ray2 if two else d_ray), 0 if two else 1,
+                            C.byref(gs), _lib.ptr(ws2 if two else ws), wsb,
+                            _lib.current_stream(dev) if two else st))
                 else:
                     if i == 0:
                         g = g_prob if g_prob is not None else torch.zeros((P, 1), **f32)
@@ -1188,7 +1219,14 @@ class _QueryTrainFn(torch.autograd.Function):
                     _lib.check(L.lidf_query_decoder_backward_f32(
                         C.byref(a), _lib.ptr(act), _lib.ptr(g), _lib.ptr(d_vox), _lib.ptr(d_ray), 1 if i else 0,
                         C.byref(gs), _lib.ptr(ws), wsb, st))
-                grads_out += [gt[k] for k in names]
+                grads_out[i] = [gt[k] for k in names]
+        if two:   # join: offset_dec's share of the input gradients
+            torch.cuda.current_stream(dev).wait_stream(side)
+            if d_vox is not None:
+                d_vox += d_vox2
+            if d_ray is not None:
+                d_ray += d_ray2
+        grads_out = grads_out[0] + grads_out[1]
         base = 20
         return (None, None, d_vox, d_ray) + (None,) * 16 + tuple(
             g if ctx.needs_input_grad[base + i] else None for i, g in enumerate(grads_out))
@@ -1238,14 +1276,25 @@ def lidf_query_train(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pa
     R, P = ray_dir.shape[0], pair_ray.shape[0]
     if pair_off.shape[0] != R + 1 or ray_pix.shape != (R, 2) or ray_bid.shape != (R,):
         raise RuntimeError("pair_off / ray_pix / ray_bid must be [R+1] / [R,2] / [R]")
-    rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    dev = ray_dir.device
+    two = (factorised and P > 0 and os.environ.get("LIDF_TRAIN_STREAMS", "2") != "1"
+           and not torch.cuda.is_current_stream_capturing())
     if factorised:
-        pe = torch.empty((P, 2 * (3 + 6 * multires)), dtype=torch.float32, device=ray_dir.device)
-        with torch.cuda.device(ray_dir.device):
+        # the pairs' position-embedding rows (one sweep over P x 102 floats) beside the per-ray RoIAlign features
+        # (three light launches over R rays): independent, so the rows go to the training side stream
+        pe = torch.empty((P, 2 * (3 + 6 * multires)), dtype=torch.float32, device=dev)
+        side = _train_side_stream(dev) if two else None
+        if two:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev), (torch.cuda.stream(side) if two else contextlib.nullcontext()):
             _lib.check(_lib.lib().lidf_pe_rows_f32(
                 _lib.ptr(pair_ray), _lib.ptr(pair_vox), _lib.ptr(pair_t), _lib.ptr(ray_dir),
                 _lib.ptr(vox_center) if vox_center is not None else None, 1 if pos_rel else 0,
-                multires, P, _lib.ptr(pe), _lib.current_stream(ray_dir.device)))
+                multires, P, _lib.ptr(pe), _lib.current_stream(dev)))
+    rayfeat = _RayFeaturesFn.apply(feat_grid, ray_dir, ray_pix, ray_bid, roi_inp_bbox, multires_views)
+    if factorised:
+        if two:
+            torch.cuda.current_stream(dev).wait_stream(side)
         from . import decoders as _dec
         _dec._check_supported(prob_dec), _dec._check_supported(offset_dec)
         pp = [_dec._get(prob_dec, k) for k in _dec._PARAM_ORDER if _dec._has(prob_dec, k)]

@@ -133,13 +133,15 @@ def verify(tag="r06", prof=None):
             continue
         nstep = sum(int(m["calls"]) for m in mk) / per
         busy = sum(float(x["total_ns"]) for x in rows) / nstep / 1e6
-        rep.check("%s: CSV busy time per step <= 1.03 x ms_per_step" % wl, busy <= 1.03 * r["ms_per_step"],
+        overlap = r["config"].get("concurrent_streams", 1) > 1   # (kernels of two streams overlap: busy > wall)
+        rep.check("%s: CSV busy time per step <= %s x ms_per_step" % (wl, "1.35 (two streams)" if overlap else "1.03"),
+                  busy <= (1.35 if overlap else 1.03) * r["ms_per_step"],
                   "%.4f ms busy over %.0f steps vs %.4f ms per step" % (busy, nstep, r["ms_per_step"]))
         if r.get("profile"):
             rep.close("%s: CSV busy time per step = the record's live profiler leg" % wl, busy,
                       r["profile"]["busy_ms_per_step"], 0.06)
-            rep.check("%s: record busy_ms_per_step <= 1.03 x ms_per_step" % wl,
-                      r["profile"]["busy_ms_per_step"] <= 1.03 * r["ms_per_step"],
+            rep.check("%s: record busy_ms_per_step <= %s x ms_per_step" % (wl, "1.35" if overlap else "1.03"),
+                      r["profile"]["busy_ms_per_step"] <= (1.35 if overlap else 1.03) * r["ms_per_step"],
                       "%.4f vs %.4f" % (r["profile"]["busy_ms_per_step"], r["ms_per_step"]))
         for x in rows:
             if int(x["scratch_bytes"] or 0) > 0 and "lidf_" in x["name"]:
