@@ -515,6 +515,13 @@ def secondary(args):
         offr.load_state_dict(init_decoder_params("IEF", 334, 9, 5.0))
         offr = offr.to(dev)
         P = sel.numel()                                                  # "points" of this record = rays
+        # the voxel list as cells of its grid (LIDF.get_occ_vox_bound keeps them, models/pipeline.py:167-201): the end
+        # voxels of both iterations through the cell table instead of the every-voxel test (round 6)
+        from implicit_depth_amd.synthetic import GRID_RES, GRID_XMIN, PART_SIZE
+        cell = occ % (GRID_RES ** 3)
+        coord = torch.stack((cell // (GRID_RES * GRID_RES), (cell // GRID_RES) % GRID_RES, cell % GRID_RES), 1)
+        grid = {"voxel_coord": coord.int().contiguous().to(dev), "grid_dims": (GRID_RES,) * 3,
+                "xmin": list(GRID_XMIN), "part_size": PART_SIZE}
 
         def step():
             for m in (pnet, offr):
@@ -522,7 +529,7 @@ def secondary(args):
                     p.grad = None
             pos, _ = lidf_refine_train(rays["ray_dir"], rays["ray_pix"], rays["ray_bid"], rays["ray_flat"], pred_pos,
                                        max_pair_id, pair_vox, vb, vbid, rgb, feat, valid_inp, valid_vox, pnet, offr,
-                                       forward_times=2)
+                                       forward_times=2, grid=grid)
             pos.sum().backward()
         flop_alg, bytes_alg, name = 0.0, 0.0, ("lidf_refine_train_forward_f32 / _backward_f32: lidf_points_kernel<TRAIN> + "
                                               "lidf_pnet_train_fwd_kernel<1|2> + lidf_pnet_bwd_a|b_kernel + "
