@@ -7,7 +7,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def rec(name):
@@ -71,8 +71,13 @@ def main():
     v.update(gf128_value=f(g128["value"], 1), gf128_frac=f(g128["roofline"]["frac"], 2), gf32_value=f(g32["value"], 0),
              e2e_f8_ms=f(rec("e2e_frame_f8")["ms_per_frame"], 3), e2e_f16_ms=f(rec("e2e_frame_f16")["ms_per_frame"], 3),
              e2e_f16sel_ms=f(rec("e2e_frame_f16_selected")["ms_per_frame"], 3), train_frac=f(tn["roofline"]["frac"], 2))
-    ie = (e1o.get("roofline_kernels") or {}).get("ief") or {}
-    v["ief_frame_us"] = f(ie.get("kernel_ms", 0.0) * 1e3, 0)
+    rk = e1o.get("roofline_kernels") or {}
+    ie, pt = rk.get("ief") or {}, rk.get("points") or {}
+    v["ief_frame_us"] = f((ie.get("kernel_ms") or ie.get("kernel_ms_rocprof") or 0.0) * 1e3, 0)
+    v.update(e2e_pts_frac=f(pt.get("frac") or 0.0, 3), e2e_pts_frac_rp=f(pt.get("frac_rocprof") or 0.0, 3),
+             e2e_ief_frac=f(ie.get("frac") or 0.0, 3), e2e_ief_frac_rp=f(ie.get("frac_rocprof") or 0.0, 3),
+             e2e_rccl_ms=f(rec("e2e_rccl_n1")["ms_per_frame"], 3), e2e_graph_ms=f(rec("e2e_graph_f1")["ms_per_frame"], 3),
+             e2e_launches=f((e1o.get("profile") or {}).get("launches_per_step_steady") or 0.0, 0))
     p = os.path.join(ROOT, "DESIGN.md")
     s = open(os.path.join(ROOT, "docs", "DESIGN.in.md")).read()
     missing = sorted(set(re.findall(r"@@(\w+)@@", s)) - set(v))
