@@ -557,10 +557,18 @@ def secondary(args):
                 for p in m.parameters():
                     p.grad = None
             x.grad = None
-            (prob(x).sum() + off(x).sum()).backward()
+            if args.decoder_pair:   # both decoders as one autograd node (decoders_forward_train): one product for d rows
+                from implicit_depth_amd import decoders_forward_train
+                yp, yo = decoders_forward_train(x, prob, off)
+                (yp.sum() + yo.sum()).backward()
+            else:
+                (prob(x).sum() + off(x).sum()).backward()
         flop_alg, bytes_alg, name = 3.0 * F_ALG, 0.0, "lidf_points_kernel<TRAIN> + lidf_dgrad_chain_kernel + lidf_wgrad2_kernel"
         what = ("training step of prob_dec (IMNet) + offset_dec (IEF n_iter=2) on [P,385] rows: "
-                "forward with kept activations + backward (d input, d parameters); FLOP = 3 x forward")
+                "forward with kept activations + backward (d input, d parameters); FLOP = 3 x forward"
+                + ("; both decoders as ONE autograd node (decoders_forward_train: the rows' gradient is one K = 512 "
+                   "product over both decoders, stored once)" if args.decoder_pair else
+                   "; the two modules as two autograd nodes (the drop-in of pipeline.py:434-435)"))
     else:
         x = (torch.rand(P, 3, generator=g, device=dev) - 0.5) * 4.6
         fn, dim = get_embedder(8)
@@ -933,7 +941,7 @@ def config_name(args, refine):
     """Which BASELINE.json configuration the per-GPU workload is (named in config.workload)."""
     if refine:
         return "configs[3]"
-    if args.pairs != "dense":
+    if args.decoder_pairs != "dense":
         return "configs[1]"     # replaced by the 'secondary' wording below
     shape = (args.frames, args.samples)
     return {(1, 64): "configs[1]", (4, 64): "configs[2] per-GPU shard (32 frames over 8 GPUs)",
@@ -983,6 +991,9 @@ def main():
                          "default and what configs[2]/[4] describe); rays = ONE frame, image rows split "
                          "over the ranks (strong scaling, SURVEY 8e for fewer frames than GPUs), depth rows "
                          "all-gathered")
+    ap.add_argument("--decoder-pair", action="store_true",
+                    help="--workload train: both decoders as ONE autograd node (decoders_forward_train) instead of the "
+                         "two modules' own nodes")
     ap.add_argument("--dense-offset-grad", action="store_true",
                     help="--workload train-query: add a loss term on pred_offset of every pair (not in the reference's "
                          "loss): offset_dec's backward then runs over all pairs, as in rounds 1-4")
@@ -1080,12 +1091,12 @@ def main():
     from implicit_depth_amd.synthetic import synthetic_scene
 
     h, w, N, B = 240, 320, args.samples, args.frames
-    if args.pairs == "n1":
+    if args.decoder_pairs == "n1":
         N = 1
     by_rays = args.shard == "rays"
-    if by_rays and (B != 1 or args.pairs == "scene" or args.workload != "query"):
+    if by_rays and (B != 1 or args.decoder_pairs == "scene" or args.workload != "query"):
         raise SystemExit("--shard rays splits the rows of ONE frame of the query workload")
-    scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.pairs == "ragged")
+    scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.decoder_pairs == "ragged")
     rows, row0 = (0, h), 0
     if by_rays:   # image rows [lo, hi) of the one frame; maps, voxel features and weights replicated
         from implicit_depth_amd.dist import crop_rows, shard_rays, slice_rays
@@ -1096,7 +1107,7 @@ def main():
         scene, fg_cut, row0 = crop_rows(scene, scene["feat_grid"], rows[0], rows[1], 4)
         scene["feat_grid"] = fg_cut
     s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
-    if args.pairs == "scene":
+    if args.decoder_pairs == "scene":
         # rays, voxels and pairs as the candidate generator produces them on real geometry
         from implicit_depth_amd import PointNet2Stage, pipeline as pl
         from implicit_depth_amd.synthetic import synthetic_batch
@@ -1116,7 +1127,7 @@ def main():
                   "vox_feat": dd["occ_voxel_feat"]})
         scene = dict(scene, P=int(dd["pair_ray"].shape[0]), V=int(dd["occ_voxel_feat"].shape[0]))
     P = scene["P"]
-    dense = args.pairs == "dense"
+    dense = args.decoder_pairs == "dense"
     gf = args.imnet_gf
     prob = IMNet(scene["D"], 1, gf).to(dev).eval()
     off = IEF(dev, scene["D"], 1, gf, n_iter=2).to(dev).eval()
@@ -1294,7 +1305,7 @@ def main():
         h16 = args.precision == "f16x3"
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
-        kname = "lidf_points_h_kernel" if h16 else ("lidf_points_fused_kernel" if gf == 64 else "lidf_linear_kernel<8>")
+        kname = "lidf_points_h_kernel" if h16 else ("lidf_points_fused_kernel" if gf == 64 else "lidf_linear_kernel<8, false>")
         # rocprofv3 legs of this very command (child processes after the timed region). Every N = 1 query run
         # gets the kernel trace; the HBM counter passes run for the default headline command (the line the
         # driver records) and wherever --pmc asks for them. Nothing is read from committed files.
@@ -1440,11 +1451,11 @@ def main():
                                         if lk else None),
                        "frac_rocprof_note": "issued FLOP of both launches / (their profiler average x launches per step)"})
         if not dense:
-            line["config"]["pairs"] = {"kind": args.pairs, "points": P, "rays": scene["R"],
+            line["config"]["pairs"] = {"kind": args.decoder_pairs, "points": P, "rays": scene["R"],
                                        "pairs_per_ray": round(P / scene["R"], 3)}
             line["config"]["workload"] = line["config"]["workload"].replace(
-                "configs[1]", "secondary (not the headline shape): %s candidate list" % args.pairs)
-            line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.pairs
+                "configs[1]", "secondary (not the headline shape): %s candidate list" % args.decoder_pairs)
+            line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.decoder_pairs
         if gf != 64:
             # FLOP of the layer-by-layer formulation per pair (generic.query): layer 1 over the 2E pair columns, the IEF's
             # 16 offset-encoding columns per pass, layers 2-4 of every pass; the per-voxel / per-ray tables are noise

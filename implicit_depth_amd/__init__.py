@@ -11,7 +11,9 @@ Host-side mirror of the reference interface for this path (names follow the refe
 All compute goes through csrc/liblidf_hip.so (C ABI in include/lidf_hip.h).
 """
 from . import _lib  # noqa: F401
-from .decoders import IEF, IMNet, Embedder, decoders_forward, get_embedder  # noqa: F401
+from .decoders import (IEF, IMNet, Embedder, decoders_forward, decoders_forward_train,  # noqa: F401
+                       get_embedder)
 from .pointnet import PointNet2Stage  # noqa: F401
 
-__all__ = ["IEF", "IMNet", "Embedder", "PointNet2Stage", "decoders_forward", "get_embedder"]
+__all__ = ["IEF", "IMNet", "Embedder", "PointNet2Stage", "decoders_forward", "decoders_forward_train",
+           "get_embedder"]

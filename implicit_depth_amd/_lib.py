@@ -15,7 +15,7 @@ LIDF_OK = 0
 # below follow that header's layouts; tests/test_host.py compares both with gcc's view of the header).
 # lib() refuses a liblidf_hip.so that answers another number — the library is git-ignored and travels
 # outside history, so a stale build must fail loudly, not be driven with wrong struct offsets.
-ABI = 11
+ABI = 12
 
 
 class LidfDecoder(C.Structure):
@@ -254,6 +254,11 @@ SIGNATURES = {
                                                  _P, C.c_size_t, _P]),
     "lidf_decoder_backward_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), _P, _P, _P,
                                             _I64, C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
+    "lidf_decoder_pair_workspace_bytes": (C.c_size_t, [_I64, _I]),
+    "lidf_decoder_pair_workspace_offset": (C.c_size_t, [_I64, _I, _I]),
+    "lidf_decoder_pair_backward_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), C.POINTER(LidfDecoder),
+                                                 _P, _P, _P, _P, _P, _I64, C.POINTER(LidfDecoderGrads),
+                                                 C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
 }
 
 _lib = None

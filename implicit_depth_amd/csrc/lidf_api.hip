@@ -2102,6 +2102,9 @@ struct LinEx {
     int relu; float slope;
     const float* mask_src; long long ld_mask; float mask_slope;
     float* out; long long ld_out; int accumulate;
+    // transposed launches only: operand columns [k, k + k2) come from X2 (row stride ldx2) and multiply rows
+    // [0, k2) of a SECOND weight matrix w_2 (row stride ldw_2) — one product over two decoders' S (k % 8 == 0)
+    const float* X2; long long ldx2; int k2; const float* w_2; int ldw_2;
 };
 
 static int nt_for(int nout) { const int t = (nout + 31) / 32; return t < 1 ? 1 : t > 8 ? 8 : t; }
@@ -2113,20 +2116,25 @@ static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) /
 static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st, int pack_mode = 0) {
     if (L.n <= 0 && pack_mode != 1) return LIDF_OK;
     const int nt = nt_for(L.nout);
-    L1Map m = rows_map(L.k, L.c0, L.k1, L.c1, L.b ? 1 : 0);
+    const bool two = L.X2 != nullptr;
+    if (two && (!L.transposed || L.k % 8 || L.k2 % 8 || L.k2 <= 0 || L.k1 || L.b || L.ief || !L.w_2)) return LIDF_ERR_BAD_ARG;
+    L1Map m = two ? rows_map(L.k, L.c0, L.k2, 0, 0) : rows_map(L.k, L.c0, L.k1, L.c1, L.b ? 1 : 0);
     m.KQ1 = (m.D + 2 + 7) / 8;   // room for the bias and the u column
     m.nt = nt;
     m.nout = L.nout;
-    m.transposed = L.transposed;
+    m.transposed = two ? 2 : L.transposed;
     m.add_u = L.ief ? 1 : 0;
     StreamLayout lay = lidf_make_layout(1, LIDF_MODE_LINEAR, m);
     NetW nw = {};
     nw.w1 = L.w; nw.b1 = L.b; nw.ld1 = L.ldw; nw.dcore = L.dcore ? L.dcore : L.k; nw.is_ief = 0;
     if (L.ief) { nw.is_ief = 1; nw.wenc = L.ief->wenc; nw.benc = L.ief->benc; }
-    if (pack_mode != 2) CHECK_HIP(pack_stream(lay, nw, nw, m, stream_buf, nullptr, st));
+    NetW nw2 = nw;
+    if (two) { nw2.w1 = L.w_2; nw2.ld1 = L.ldw_2; }
+    if (pack_mode != 2) CHECK_HIP(pack_stream(lay, nw, nw2, m, stream_buf, nullptr, st));
     if (pack_mode == 1) return LIDF_OK;
     LinearArgs a = {};
     a.stream = stream_buf; a.kq1 = m.KQ1; a.X = L.X; a.ldx = L.ldx; a.n = L.n;
+    if (two) { a.X2 = L.X2; a.ldx2 = L.ldx2; a.kq_split = L.k / 8; }
     a.n_dev = L.n_dev;
     a.D = m.D; a.has_bias = L.b ? 1 : 0; a.xoff = L.xoff;
     a.addrows = L.addrows; a.addidx = L.addidx; a.ld_add = L.nout;
@@ -2491,36 +2499,19 @@ LIDF_API int lidf_decoder_forward_train_f32(const float* inp, int64_t n, int32_t
     return LIDF_OK;
 }
 
-LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
-                                         const LidfDecoder* dec, const float* act,
-                                         const float* g_out, float* d_inp, int64_t ld_dinp,
-                                         const LidfDecoderGrads* grads, void* workspace,
-                                         size_t workspace_bytes, lidf_stream_t stream) {
-    if (n < 0 || d <= 0 || ld_inp < d || !dec || !grads) return LIDF_ERR_BAD_ARG;
-    int rc;
-    if ((rc = check_decoder(dec))) return rc;
-    if (!grads->w1 || !grads->b1 || !grads->w2 || !grads->b2 || !grads->w3 || !grads->b3 ||
-        !grads->w4 || !grads->b4 || (dec->is_ief && (!grads->wenc || !grads->benc)))
-        return LIDF_ERR_BAD_ARG;
-    if (d_inp && ld_dinp < d) return LIDF_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
+// The backward of one decoder up to (and without) the input gradient: every parameter gradient, and S = the sum
+// of dZ1 over the passes left in the workspace (*S_out) for the caller's input-gradient product.
+static int decoder_backward_core(const float* inp, int64_t n, int32_t d, int64_t ld_inp, const LidfDecoder* dec,
+                                 const float* act, const float* g_out, const LidfDecoderGrads* grads, char* ws,
+                                 const TrainWs& w, int cus, hipStream_t st, float** S_out) {
     const int npass = dec->is_ief ? dec->n_iter : 1;
     const int ld1 = d + (dec->is_ief ? 16 : 0);
-    // gradients start at zero (also what an empty batch returns)
-    CHECK_HIP(zero_decoder_grads(grads, ld1, dec->is_ief, st));
-    if (n == 0) return LIDF_OK;
-    if (!inp || !act || !g_out) return LIDF_ERR_BAD_ARG;
-    const TrainWs w = train_ws(n, d);
-    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
-    char* ws = (char*)workspace;
     float* sbuf = (float*)(ws + w.stream);
     float* dz1 = (float*)(ws + w.dz1);
     float* dz2 = (float*)(ws + w.dz2);
     float* dz3 = (float*)(ws + w.dz3);
     float* goff = (float*)(ws + w.goff);
     float* wgs = (float*)(ws + w.wg);
-    int cus;
-    if ((rc = cu_count(&cus))) return rc;
     const float* pre = act + (size_t)npass * n * ACT_ROW_FLOATS;
     float* S = (float*)(ws + w.S);
     float* small = (float*)(ws + w.small);
@@ -2563,19 +2554,104 @@ LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, i
     if (dec->is_ief && npass > 1)
         CHECK_HIP(lidf_launch_ief_first_pass(grads->b1, small, dec->init_offset, dec->w1 + d, ld1, dec->wenc,
                                              dec->benc, grads->w1 + d, grads->wenc, grads->benc, st));
-    if (d_inp) {
-        // d inp = S W1[:, 0:d], in launches of at most 8 output tiles of 32 columns, evenly sized (385 columns:
-        // 7 + 6 tiles instead of 8 + 8)
-        LinEx L = {};
-        L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
-        const int tiles = (d + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
-        for (int c0 = 0; c0 < d; c0 += 32 * per) {
-            const int cols = d - c0 < 32 * per ? d - c0 : 32 * per;
-            L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = S; L.ldx = LIDF_H1;
-            L.out = d_inp + c0; L.ld_out = ld_dinp; L.accumulate = 0;
-            if ((rc = run_linex(L, sbuf, cus, st))) return rc;
+    *S_out = S;
+    return LIDF_OK;
+}
+
+static int check_decoder_grads(const LidfDecoder* dec, const LidfDecoderGrads* grads) {
+    if (!grads->w1 || !grads->b1 || !grads->w2 || !grads->b2 || !grads->w3 || !grads->b3 ||
+        !grads->w4 || !grads->b4 || (dec->is_ief && (!grads->wenc || !grads->benc)))
+        return LIDF_ERR_BAD_ARG;
+    return LIDF_OK;
+}
+
+// d inp = S W1[:, 0:d] (+ S2 W1_2[:, 0:d]: the pair's joint product over K = 512), in launches of at most 8 output
+// tiles of 32 columns, evenly sized (385 columns: 7 + 6 tiles instead of 8 + 8)
+static int decoder_input_grad(const float* S, const LidfDecoder* dec, const float* S2, const LidfDecoder* dec2,
+                              int64_t n, int32_t d, float* d_inp, int64_t ld_dinp, float* sbuf, int cus,
+                              hipStream_t st) {
+    LinEx L = {};
+    L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
+    const int ld1 = d + (dec->is_ief ? 16 : 0);
+    const int tiles = (d + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
+    for (int c0 = 0; c0 < d; c0 += 32 * per) {
+        const int cols = d - c0 < 32 * per ? d - c0 : 32 * per;
+        L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = S; L.ldx = LIDF_H1;
+        if (S2) {
+            L.X2 = S2; L.ldx2 = LIDF_H1; L.k2 = LIDF_H1;
+            L.w_2 = dec2->w1 + c0; L.ldw_2 = d + (dec2->is_ief ? 16 : 0);
         }
+        L.out = d_inp + c0; L.ld_out = ld_dinp; L.accumulate = 0;
+        int rc;
+        if ((rc = run_linex(L, sbuf, cus, st))) return rc;
     }
+    return LIDF_OK;
+}
+
+LIDF_API int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                         const LidfDecoder* dec, const float* act,
+                                         const float* g_out, float* d_inp, int64_t ld_dinp,
+                                         const LidfDecoderGrads* grads, void* workspace,
+                                         size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || d <= 0 || ld_inp < d || !dec || !grads) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(dec))) return rc;
+    if ((rc = check_decoder_grads(dec, grads))) return rc;
+    if (d_inp && ld_dinp < d) return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // gradients start at zero (also what an empty batch returns)
+    CHECK_HIP(zero_decoder_grads(grads, d + (dec->is_ief ? 16 : 0), dec->is_ief, st));
+    if (n == 0) return LIDF_OK;
+    if (!inp || !act || !g_out) return LIDF_ERR_BAD_ARG;
+    const TrainWs w = train_ws(n, d);
+    if (!workspace || workspace_bytes < w.total) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    float* S = nullptr;
+    if ((rc = decoder_backward_core(inp, n, d, ld_inp, dec, act, g_out, grads, ws, w, cus, st, &S))) return rc;
+    if (d_inp) return decoder_input_grad(S, dec, nullptr, nullptr, n, d, d_inp, ld_dinp, (float*)(ws + w.stream), cus, st);
+    return LIDF_OK;
+}
+
+// ---- both decoders on the same rows (models/pipeline.py:434-435: prob_dec(inp), offset_dec(inp)) as ONE backward:
+// the two input gradients are one K = 512 product over [S_prob | S_off] and the rows' gradient is stored once —
+// not two K = 256 products, two stores of [n, d] and the accumulation autograd runs when the modules are two nodes.
+// Workspace: [decoder workspace of prob | of off | stream of the K = 512 product].
+LIDF_API size_t lidf_decoder_pair_workspace_bytes(int64_t n, int32_t d) {
+    return 2 * align_up(train_ws(n, d).total, 256) + linex_stream_bytes(2 * LIDF_H1);
+}
+LIDF_API size_t lidf_decoder_pair_workspace_offset(int64_t n, int32_t d, int32_t which) {
+    return (size_t)(which ? 1 : 0) * align_up(train_ws(n, d).total, 256);
+}
+
+LIDF_API int lidf_decoder_pair_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                              const LidfDecoder* prob, const LidfDecoder* off,
+                                              const float* act_prob, const float* act_off,
+                                              const float* g_prob, const float* g_off, float* d_inp,
+                                              int64_t ld_dinp, const LidfDecoderGrads* grads_prob,
+                                              const LidfDecoderGrads* grads_off, void* workspace,
+                                              size_t workspace_bytes, lidf_stream_t stream) {
+    if (n < 0 || d <= 0 || ld_inp < d || !prob || !off || !grads_prob || !grads_off) return LIDF_ERR_BAD_ARG;
+    int rc;
+    if ((rc = check_decoder(prob)) || (rc = check_decoder(off))) return rc;
+    if ((rc = check_decoder_grads(prob, grads_prob)) || (rc = check_decoder_grads(off, grads_off))) return rc;
+    if (d_inp && ld_dinp < d) return LIDF_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_HIP(zero_decoder_grads(grads_prob, d + (prob->is_ief ? 16 : 0), prob->is_ief, st));
+    CHECK_HIP(zero_decoder_grads(grads_off, d + (off->is_ief ? 16 : 0), off->is_ief, st));
+    if (n == 0) return LIDF_OK;
+    if (!inp || !act_prob || !act_off || !g_prob || !g_off) return LIDF_ERR_BAD_ARG;
+    const TrainWs w = train_ws(n, d);
+    const size_t one = align_up(w.total, 256);
+    if (!workspace || workspace_bytes < lidf_decoder_pair_workspace_bytes(n, d)) return LIDF_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    float *Sp = nullptr, *So = nullptr;
+    if ((rc = decoder_backward_core(inp, n, d, ld_inp, prob, act_prob, g_prob, grads_prob, ws, w, cus, st, &Sp))) return rc;
+    if ((rc = decoder_backward_core(inp, n, d, ld_inp, off, act_off, g_off, grads_off, ws + one, w, cus, st, &So))) return rc;
+    if (d_inp) return decoder_input_grad(Sp, prob, So, off, n, d, d_inp, ld_dinp, (float*)(ws + 2 * one), cus, st);
     return LIDF_OK;
 }
 

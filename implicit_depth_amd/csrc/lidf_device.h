@@ -97,7 +97,8 @@ struct L1Map {
     int add_bias;  // bias k-step carries b1 (+ IEF constant) ; else 0
     int nt;        // output tiles per k-quad in the rows modes (8 for the decoders' layer 1)
     int nout;      // rows of w1 (outputs); tiles beyond it are zero
-    int transposed;  // rows modes: weight element (out, col) is read at w1[col*ld1 + out] (dgrad)
+    int transposed;  // rows modes: weight element (out, col) is read at w1[col*ld1 + out] (dgrad); 2: operand
+                     // columns >= n0 read the SECOND net of the pack call (its own w1 / ld1) at row c1 + (x - n0)
     int add_u;       // rows modes: operand column D+1 carries the IEF vector u (operand = offset)
     // fused mode
     int L;         // octaves
@@ -332,6 +333,11 @@ struct LinearArgs {
     const float* addrows2; // optional second gathered term: += addrows2[addidx2[row]]
     const int* addidx2;
     int ld_add2;
+    // operand rows from two buffers (the decoder pair's joint input gradient): k-quads [0, kq_split) read X, the
+    // k-quads behind them X2 (row stride ldx2, its column 0 = operand column 8 kq_split); D % 8 == 0
+    int kq_split;
+    const float* X2;
+    long long ldx2;
 };
 
 // Regular voxel grid of LIDF.get_occ_vox_bound (models/pipeline.py:162-201): lower corner (already

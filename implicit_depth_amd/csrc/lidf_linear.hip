@@ -21,7 +21,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDQ(rs, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rs), (voff), (soff), 0))
 
-template <int NT>
+// SPLIT: the operand rows come from TWO buffers — k-quads [0, kq_split) from X, the ones behind them from X2 (the
+// joint input gradient of the two decoders on materialised rows: d rows = [S_prob | S_off] [W1_prob ; W1_off], one
+// K = 512 product and one store of the [n, 385] rows instead of two K = 256 products, two stores and autograd's add)
+template <int NT, bool SPLIT>
 __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -47,9 +50,12 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
     float b0[4], b1[4], b2[4], b3[4];   // operand ring: k-quads kq, kq + 1, (kq + 2, kq + 3)
     f32x4 q0[NT], q1[NT];               // weight quads of k-quad kq, kq + 1
     const float* xrow = nullptr;
+    const float* xrow2 = nullptr;   // SPLIT: the second buffer's row, biased by -8 kq_split
     long long pc = 0;
     auto load_b_fast = [&](int kq, float (&b)[4]) {
-        const f32x4u v = *(const f32x4u*)(xrow + 8 * kq);
+        const float* xr = xrow;
+        if (SPLIT) xr = kq >= a.kq_split ? xrow2 : xrow;   // (kq wave-uniform)
+        const f32x4u v = *(const f32x4u*)(xr + 8 * kq);
         b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
     };
     auto load_b_tail = [&](int kq, float (&b)[4]) {
@@ -75,6 +81,7 @@ __global__ void __launch_bounds__(256) lidf_linear_kernel(LinearArgs a) {
         const long long p = tile * 128 + wave * 32 + col;
         pc = p < AN ? p : AN - 1;
         xrow = a.X + (size_t)pc * a.ldx + 4 * h;
+        if (SPLIT) xrow2 = a.X2 + (size_t)pc * a.ldx2 + 4 * h - 8 * (long long)a.kq_split;
         load_b(0, b0);
         load_b(1, b1);
         load_q(0, q0);
@@ -411,10 +418,14 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int gri
     if (a_in.n <= 0) return hipSuccess;
     LinearArgs a = a_in;
     a.nt_total = 0;
+    // operand rows from two buffers: whole k-quads on either side of the split, no tail columns of X
+    if (a.X2 && (a.kq_split <= 0 || 8 * a.kq_split >= a.D || a.D % 8 != 0 || a.ldx2 < a.D - 8 * a.kq_split))
+        return hipErrorInvalidValue;
     const long long ntile = (a.n + 127) / 128;
     if (nt > 1 && ntile <= 16) {   // few rows: one workgroup per (row tile, output tile)
         a.nt_total = nt;
-        hipLaunchKernelGGL(lidf_linear_kernel<1>, dim3((unsigned)ntile, (unsigned)nt), dim3(256), 0, st, a);
+        if (a.X2) hipLaunchKernelGGL((lidf_linear_kernel<1, true>), dim3((unsigned)ntile, (unsigned)nt), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lidf_linear_kernel<1, false>), dim3((unsigned)ntile, (unsigned)nt), dim3(256), 0, st, a);
         return hipGetLastError();
     }
     dim3 g(grid), b(256);
@@ -430,15 +441,29 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int gri
             (long long)g.x > cus)
             g = dim3((unsigned)cus);
     }
+    if (a.X2) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((lidf_linear_kernel<1, true>), g, b, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((lidf_linear_kernel<2, true>), g, b, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((lidf_linear_kernel<3, true>), g, b, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((lidf_linear_kernel<4, true>), g, b, 0, st, a); break;
+            case 5: hipLaunchKernelGGL((lidf_linear_kernel<5, true>), g, b, 0, st, a); break;
+            case 6: hipLaunchKernelGGL((lidf_linear_kernel<6, true>), g, b, 0, st, a); break;
+            case 7: hipLaunchKernelGGL((lidf_linear_kernel<7, true>), g, b, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((lidf_linear_kernel<8, true>), g, b, 0, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (nt) {
-        case 1: hipLaunchKernelGGL(lidf_linear_kernel<1>, g, b, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(lidf_linear_kernel<2>, g, b, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(lidf_linear_kernel<3>, g, b, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(lidf_linear_kernel<4>, g, b, 0, st, a); break;
-        case 5: hipLaunchKernelGGL(lidf_linear_kernel<5>, g, b, 0, st, a); break;
-        case 6: hipLaunchKernelGGL(lidf_linear_kernel<6>, g, b, 0, st, a); break;
-        case 7: hipLaunchKernelGGL(lidf_linear_kernel<7>, g, b, 0, st, a); break;
-        case 8: hipLaunchKernelGGL(lidf_linear_kernel<8>, g, b, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((lidf_linear_kernel<1, false>), g, b, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((lidf_linear_kernel<2, false>), g, b, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((lidf_linear_kernel<3, false>), g, b, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((lidf_linear_kernel<4, false>), g, b, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((lidf_linear_kernel<5, false>), g, b, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((lidf_linear_kernel<6, false>), g, b, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((lidf_linear_kernel<7, false>), g, b, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((lidf_linear_kernel<8, false>), g, b, 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

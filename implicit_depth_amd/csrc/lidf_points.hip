@@ -104,6 +104,7 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         (void)s;
         if (x < m.D) {
             const int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
+            if (m.transposed == 2 && x >= m.n0) return nets[1].w1[(size_t)col * nets[1].ld1 + out];
             return m.transposed ? n.w1[(size_t)col * n.ld1 + out] : n.w1[(size_t)out * n.ld1 + col];
         }
         if (x == m.D && m.add_bias) {

@@ -274,10 +274,7 @@ class _DecoderTrainFn(torch.autograd.Function):
         dec = _decoder_struct(mod, keep, saved)
         f32 = dict(dtype=torch.float32, device=x.device)
         g = g_out.detach().reshape(-1).contiguous().float()
-        gtens = {k: torch.empty_like(saved[k], **f32).contiguous() for k in ctx.names}
-        gs = _lib.LidfDecoderGrads()
-        for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _PARAM_ORDER):
-            setattr(gs, field, gtens[k].data_ptr() if k in gtens else None)
+        gtens, gs = _grad_struct(ctx.names, saved, f32)
         d_inp = torch.empty((n, d), **f32) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().lidf_decoder_backward_f32(
@@ -292,6 +289,98 @@ class _DecoderTrainFn(torch.autograd.Function):
 def _has(mod, name):
     layer, _ = name.split(".")
     return hasattr(mod, layer)
+
+
+def _grad_struct(names, saved, f32):
+    gtens = {k: torch.empty_like(saved[k], **f32).contiguous() for k in names}
+    gs = _lib.LidfDecoderGrads()
+    for field, k in zip(("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wenc", "benc"), _PARAM_ORDER):
+        setattr(gs, field, gtens[k].data_ptr() if k in gtens else None)
+    return gtens, gs
+
+
+class _DecoderPairTrainFn(torch.autograd.Function):
+    """prob_dec(inp), offset_dec(inp) (models/pipeline.py:434-435) as ONE autograd node: the two forwards of
+    _DecoderTrainFn, and a backward whose rows' gradient is one K = 512 product over both decoders' summed dZ1,
+    stored once (lidf_decoder_pair_backward_f32) — two nodes run two K = 256 products, store [n, D] twice and
+    leave the sum to autograd's accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, prob, off, inp_feat, n_prob, *params):
+        x = inp_feat.detach()
+        if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+            x = x.contiguous()
+        n, d = x.shape
+        ld = x.stride(0) if n > 1 else d
+        keep = []
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        wsb = L.lidf_decoder_pair_workspace_bytes(n, d)
+        one = L.lidf_decoder_train_workspace_bytes(n, d)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=x.device)
+        outs, acts = [], []
+        with torch.cuda.device(x.device):
+            for which, mod in enumerate((prob, off)):
+                dec = _decoder_struct(mod, keep)
+                n_pass = int(mod.n_iter) if isinstance(mod, IEF) else 1
+                act = torch.empty((max(L.lidf_decoder_train_act_floats(n, n_pass), 1),), **f32)
+                out = torch.empty((n, 1), **f32)
+                _lib.check(L.lidf_decoder_forward_train_f32(
+                    _lib.ptr(x), n, d, ld, C.byref(dec), _lib.ptr(out), _lib.ptr(act),
+                    ws.data_ptr() + L.lidf_decoder_pair_workspace_offset(n, d, which), one,
+                    _lib.current_stream(x.device)))
+                outs.append(out)
+                acts.append(act)
+        ctx.prob, ctx.off, ctx.ld, ctx.ws, ctx.wsb = prob, off, ld, ws, wsb
+        ctx.names_p = [k for k in _PARAM_ORDER if _has(prob, k)]
+        ctx.names_o = [k for k in _PARAM_ORDER if _has(off, k)]
+        assert n_prob == len(ctx.names_p)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, acts[0], acts[1], *params)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, g_p, g_o):
+        x, act_p, act_o = ctx.saved_tensors[:3]
+        np_ = len(ctx.names_p)
+        saved_p = dict(zip(ctx.names_p, ctx.saved_tensors[3:3 + np_]))
+        saved_o = dict(zip(ctx.names_o, ctx.saved_tensors[3 + np_:]))
+        n, d = x.shape
+        keep = []
+        f32 = dict(dtype=torch.float32, device=x.device)
+        # an output the loss did not use: a zero gradient (every sum of that decoder's backward is then zero)
+        g_p = torch.zeros((n,), **f32) if g_p is None else g_p.detach().reshape(-1).contiguous().float()
+        g_o = torch.zeros((n,), **f32) if g_o is None else g_o.detach().reshape(-1).contiguous().float()
+        dp = _decoder_struct(ctx.prob, keep, saved_p)
+        do = _decoder_struct(ctx.off, keep, saved_o)
+        gt_p, gs_p = _grad_struct(ctx.names_p, saved_p, f32)
+        gt_o, gs_o = _grad_struct(ctx.names_o, saved_o, f32)
+        d_inp = torch.empty((n, d), **f32) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_decoder_pair_backward_f32(
+                _lib.ptr(x), n, d, ctx.ld, C.byref(dp), C.byref(do), _lib.ptr(act_p), _lib.ptr(act_o),
+                _lib.ptr(g_p), _lib.ptr(g_o), _lib.ptr(d_inp), d, C.byref(gs_p), C.byref(gs_o),
+                _lib.ptr(ctx.ws), ctx.wsb, _lib.current_stream(x.device)))
+        grads = [gt_p[k] for k in ctx.names_p] + [gt_o[k] for k in ctx.names_o]
+        return (None, None, d_inp, None) + tuple(g if ctx.needs_input_grad[4 + i] else None
+                                                 for i, g in enumerate(grads))
+
+
+def decoders_forward_train(inp_feat, prob_dec, offset_dec):
+    """(prob_dec(inp_feat), offset_dec(inp_feat)) under autograd as one node — the two lines of LIDF.get_pred
+    (models/pipeline.py:434-435) in one call. Same values and gradients as calling the two modules (the rows'
+    gradient is one product over both decoders instead of two products and an accumulation). Shipped widths;
+    other widths fall back to the modules' own calls."""
+    if not is_shipped(prob_dec) or not is_shipped(offset_dec):
+        return prob_dec(inp_feat), offset_dec(inp_feat)
+    if not inp_feat.is_cuda:
+        raise RuntimeError("decoders_forward_train: CUDA tensor required (no CPU path; " + _CPU_HINT + ")")
+    for m in (prob_dec, offset_dec):
+        if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != m.inp_dim:
+            raise RuntimeError("inp_feat must be float32 [n, %d]" % m.inp_dim)
+    pp = [_get(prob_dec, k) for k in _PARAM_ORDER if _has(prob_dec, k)]
+    po = [_get(offset_dec, k) for k in _PARAM_ORDER if _has(offset_dec, k)]
+    return _DecoderPairTrainFn.apply(prob_dec, offset_dec, inp_feat, len(pp), *pp, *po)
 
 
 class _DecoderBase(nn.Module):

@@ -36,7 +36,7 @@ enum lidf_status {
 /* ABI version, bumped on any signature or struct-layout change and on added entry points. lidf_version() returns the value the
  * library was BUILT with; a binding compiled / written against this header must refuse a library that
  * answers anything else (implicit_depth_amd/_lib.py and csrc/lidf_torch_ext.cpp do, at load). */
-#define LIDF_ABI_VERSION 11
+#define LIDF_ABI_VERSION 12
 int lidf_version(void);
 /* Static string for a status code. */
 const char* lidf_strerror(int status);
@@ -691,7 +691,7 @@ int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const
  *   g_out      [n] dL/d(output)
  *   d_inp      [n, d] (row stride ld_dinp) or NULL
  *   grads      device buffers shaped like the parameters (w1 [256, d(+16)], ...); overwritten.
- * Weight gradients are reduced with float atomics: their summation order is not fixed.        */
+ * Weight gradients are reduced slab by slab in a fixed order (run-to-run identical).            */
 typedef struct LidfDecoderGrads {
     float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
     float *wenc, *benc; /* IEF only */
@@ -705,6 +705,21 @@ int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld
                               const LidfDecoder* dec, const float* act, const float* g_out,
                               float* d_inp, int64_t ld_dinp, const LidfDecoderGrads* grads,
                               void* workspace, size_t workspace_bytes, lidf_stream_t stream);
+/* Both decoders on the SAME rows (models/pipeline.py:434-435: self.prob_dec(inp), self.offset_dec(inp)) as one
+ * backward (ABI 12): parameter gradients as lidf_decoder_backward_f32 computes them for each, and the rows'
+ * gradient d_inp = d_inp(prob) + d_inp(off) as ONE product over [S_prob | S_off] (K = 512), stored once —
+ * what two autograd nodes do with two products, two [n, d] stores and an accumulation launch. The forwards are
+ * two lidf_decoder_forward_train_f32 calls whose workspaces are the pair workspace at
+ * lidf_decoder_pair_workspace_offset(n, d, 0 | 1) (each lidf_decoder_train_workspace_bytes(n, d) long).   */
+size_t lidf_decoder_pair_workspace_bytes(int64_t n, int32_t d);
+size_t lidf_decoder_pair_workspace_offset(int64_t n, int32_t d, int32_t which);
+int lidf_decoder_pair_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
+                                   const LidfDecoder* prob, const LidfDecoder* off,
+                                   const float* act_prob, const float* act_off,
+                                   const float* g_prob, const float* g_off, float* d_inp,
+                                   int64_t ld_dinp, const LidfDecoderGrads* grads_prob,
+                                   const LidfDecoderGrads* grads_off, void* workspace,
+                                   size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Query, training path -----------------------------------------------------------------------
  * LIDF.get_embedding (models/pipeline.py:338-420) with gradients, in the reference's own

@@ -50,6 +50,62 @@ def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
         _close(g_hip[k], g_ref[k], k)
 
 
+@pytest.mark.parametrize("d,n,n_iter,sig,use", [(385, 333, 2, False, "both"), (385, 5000, 2, False, "both"),
+                                                 (334, 129, 3, True, "both"), (385, 1, 2, False, "both"),
+                                                 (385, 700, 1, False, "both"), (27, 31, 2, False, "both"),
+                                                 (385, 900, 2, False, "prob"), (385, 900, 2, False, "off")])
+def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use):
+    """decoders_forward_train (prob_dec(inp), offset_dec(inp) of pipeline.py:434-435 as ONE autograd node, the rows'
+    gradient as one K = 512 product over both decoders' summed dZ1): values equal the two modules' bit for bit, the
+    gradients equal the torch-op definition's to the tolerance of the single-module test and the two modules' own
+    sum to float noise; an output the loss does not use contributes nothing."""
+    from implicit_depth_amd import decoders_forward_train
+    pp = orc.randomize_biases(orc.init_decoder("IMNET", d, 21, 5.0), 22)
+    po = orc.randomize_biases(orc.init_decoder("IEF", d, 23, 5.0), 24)
+    prob = make_module("IMNET", pp, d, cuda, use_sigmoid=sig).train()
+    off = make_module("IEF", po, d, cuda, n_iter=n_iter, use_sigmoid=sig).train()
+    g = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, d, generator=g).to(cuda)
+    wp = torch.randn(n, generator=g).to(cuda)
+    wo = torch.randn(n, generator=g).to(cuda)
+
+    def run(fn):
+        for m in (prob, off):
+            for q in m.parameters():
+                q.grad = None
+        xg = x.clone().requires_grad_(True)
+        yp, yo = fn(xg)
+        loss = 0.0
+        if use in ("both", "prob"):
+            loss = loss + (yp.reshape(-1) * wp).sum()
+        if use in ("both", "off"):
+            loss = loss + (yo.reshape(-1) * wo).sum()
+        loss.backward()
+        gr = {"prob." + k: (q.grad.detach().clone() if q.grad is not None else torch.zeros_like(q))
+              for k, q in prob.named_parameters()}
+        gr.update({"off." + k: (q.grad.detach().clone() if q.grad is not None else torch.zeros_like(q))
+                   for k, q in off.named_parameters()})
+        gr["input"] = xg.grad.detach().clone()
+        return yp.detach(), yo.detach(), gr
+
+    yp1, yo1, g1 = run(lambda t: decoders_forward_train(t, prob, off))
+    yp2, yo2, g2 = run(lambda t: (prob(t), off(t)))
+    yp3, yo3, g3 = run(lambda t: (prob.forward_composite(t), off.forward_composite(t)))
+    assert torch.equal(yp1, yp2) and torch.equal(yo1, yo2)
+    assert set(g1) == set(g2) == set(g3)
+    for k in g3:
+        _close(g1[k], g3[k], k)
+        if k != "input":
+            assert torch.equal(g1[k], g2[k]), k      # the parameter gradients are the same launches
+    # one product over K = 512 against two over K = 256 and an add: summation order only
+    scale = max(1.0, g2["input"].abs().max().item())
+    assert (g1["input"] - g2["input"]).abs().max().item() <= 2e-6 * scale
+    # run-to-run identical
+    _, _, g1b = run(lambda t: decoders_forward_train(t, prob, off))
+    for k in g1:
+        assert torch.equal(g1[k], g1b[k]), k
+
+
 def test_rows_backward_is_run_to_run_identical(cuda):
     """The decoders' backward on rows sums in a fixed order (slab reductions, no float atomics on the wide layers):
     two runs of the same step give the same bits for the input gradient and every wide parameter gradient."""
