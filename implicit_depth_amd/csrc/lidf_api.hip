@@ -2105,6 +2105,9 @@ struct LinEx {
     // transposed launches only: operand columns [k, k + k2) come from X2 (row stride ldx2) and multiply rows
     // [0, k2) of a SECOND weight matrix w_2 (row stride ldw_2) — one product over two decoders' S (k % 8 == 0)
     const float* X2; long long ldx2; int k2; const float* w_2; int ldw_2;
+    // nout = 32 t + 1 (plain transposed products, many rows): the last column through the vector unit beside the
+    // t tiles instead of a tile of its own (LinearArgs.xcol)
+    int xcol;
 };
 
 static int nt_for(int nout) { const int t = (nout + 31) / 32; return t < 1 ? 1 : t > 8 ? 8 : t; }
@@ -2115,12 +2118,15 @@ static size_t linex_stream_bytes(int k) { return align_up((size_t)((k + 2 + 7) /
 
 static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st, int pack_mode = 0) {
     if (L.n <= 0 && pack_mode != 1) return LIDF_OK;
-    const int nt = nt_for(L.nout);
+    if (L.xcol && (L.nout % 32 != 1 || L.nout < 33 || L.nout > 257 || !L.transposed || L.b || L.ief)) return LIDF_ERR_BAD_ARG;
+    const int nt = nt_for(L.xcol ? L.nout - 1 : L.nout);
+    if (L.xcol && nt + 1 > 8) return LIDF_ERR_BAD_ARG;   // (the stream slots are sized for 8 quads per k-quad)
     const bool two = L.X2 != nullptr;
     if (two && (!L.transposed || L.k % 8 || L.k2 % 8 || L.k2 <= 0 || L.k1 || L.b || L.ief || !L.w_2)) return LIDF_ERR_BAD_ARG;
     L1Map m = two ? rows_map(L.k, L.c0, L.k2, 0, 0) : rows_map(L.k, L.c0, L.k1, L.c1, L.b ? 1 : 0);
     m.KQ1 = (m.D + 2 + 7) / 8;   // room for the bias and the u column
-    m.nt = nt;
+    m.nt = nt + (L.xcol ? 1 : 0);
+    m.xcol = L.xcol ? 1 : 0;
     m.nout = L.nout;
     m.transposed = two ? 2 : L.transposed;
     m.add_u = L.ief ? 1 : 0;
@@ -2141,7 +2147,8 @@ static int run_linex(const LinEx& L, float* stream_buf, int cus, hipStream_t st,
     a.addrows2 = L.addrows2; a.addidx2 = L.addidx2; a.ld_add2 = L.nout;
     a.relu = L.relu; a.slope = L.slope;
     a.mask_src = L.mask_src; a.ld_mask = L.ld_mask; a.mask_slope = L.mask_slope;
-    a.out = L.out; a.ld_out = L.ld_out; a.nout = L.nout; a.accumulate = L.accumulate;
+    a.out = L.out; a.ld_out = L.ld_out; a.nout = L.xcol ? L.nout - 1 : L.nout; a.accumulate = L.accumulate;
+    a.xcol = L.xcol ? 1 : 0;
     const long long nt128 = (L.n + 127) / 128;
     const int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
     CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
@@ -2573,9 +2580,20 @@ static int decoder_input_grad(const float* S, const LidfDecoder* dec, const floa
     LinEx L = {};
     L.n = n; L.transposed = 1; L.mask_slope = 0.02f;
     const int ld1 = d + (dec->is_ief ? 16 : 0);
-    const int tiles = (d + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
-    for (int c0 = 0; c0 < d; c0 += 32 * per) {
-        const int cols = d - c0 < 32 * per ? d - c0 : 32 * per;
+    // 32 t + 1 columns (385 = 12 x 32 + 1) over more than a handful of rows: the last column rides through the vector
+    // unit of the last launch (6 + 6 tiles instead of 7 + 6)
+    // (a stream slot holds 8 quads per k-quad: a launch of 8 tiles has no room for the column's quad)
+    bool xcol = d % 32 == 1 && d > 32 && n > 16 * 128;
+    if (xcol) {
+        const int t = (d - 1) / 32, l = (t + 7) / 8;
+        if ((t + l - 1) / l >= 8) xcol = false;
+    }
+    const int dt = xcol ? d - 1 : d;
+    const int tiles = (dt + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
+    for (int c0 = 0; c0 < dt; c0 += 32 * per) {
+        int cols = dt - c0 < 32 * per ? dt - c0 : 32 * per;
+        L.xcol = 0;
+        if (xcol && c0 + cols == dt) { cols += 1; L.xcol = 1; }
         L.w = dec->w1 + c0; L.ldw = ld1; L.nout = cols; L.k = LIDF_H1; L.X = S; L.ldx = LIDF_H1;
         if (S2) {
             L.X2 = S2; L.ldx2 = LIDF_H1; L.k2 = LIDF_H1;

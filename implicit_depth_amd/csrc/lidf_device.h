@@ -100,6 +100,8 @@ struct L1Map {
     int transposed;  // rows modes: weight element (out, col) is read at w1[col*ld1 + out] (dgrad); 2: operand
                      // columns >= n0 read the SECOND net of the pack call (its own w1 / ld1) at row c1 + (x - n0)
     int add_u;       // rows modes: operand column D+1 carries the IEF vector u (operand = offset)
+    int xcol;        // linear mode: the last of the nt quads per k-quad carries ONE output (index 32 (nt - 1)), the
+                     // same four weights for every row lane of a half-wave (lidf_linear_kernel<.., XCOL>)
     // fused mode
     int L;         // octaves
     int enter_c0;  // w1 column of enter-position embedding
@@ -133,7 +135,7 @@ struct LidfPackGuardState {
 };
 
 // One stream to pack (lidf_pack_multi_kernel packs up to LIDF_PACK_JOBS of them per launch).
-#define LIDF_PACK_JOBS 13   // (13 x 296 B of kernel arguments: under the 4 KiB limit; a frame with stage 2 has 22: two launches)
+#define LIDF_PACK_JOBS 13   // (13 x 304 B of kernel arguments: under the 4 KiB limit; a frame with stage 2 has 22: two launches)
 struct PackJob {
     StreamLayout lay;
     NetW n0, n1;
@@ -338,6 +340,9 @@ struct LinearArgs {
     int kq_split;
     const float* X2;
     long long ldx2;
+    // one more output column (index 32 nt) behind the nt tiles, through the vector unit: the stream carries nt + 1
+    // quads per k-quad (L1Map.xcol); plain or accumulating store only, nout = 32 nt
+    int xcol;
 };
 
 // Regular voxel grid of LIDF.get_occ_vox_bound (models/pipeline.py:162-201): lower corner (already

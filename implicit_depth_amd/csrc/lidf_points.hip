@@ -98,7 +98,7 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         }
         const int kq = quad / m.nt, t = quad % m.nt;
         const int s = 4 * kq + jj;
-        const int out = 32 * t + c32;
+        const int out = (m.xcol && t == m.nt - 1) ? 32 * t : 32 * t + c32;
         if (out >= m.nout) return 0.f;
         const int x = 8 * kq + 4 * half + jj;  // operand column
         (void)s;

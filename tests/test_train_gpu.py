@@ -33,7 +33,12 @@ def _close(a, b, what):
                                                   # (more than one middle pass of the IEF: the running sum of dZ1 over
                                                   # the passes takes the first pass processed, adds the middle ones in
                                                   # the encoding sweep and the last one in the chained launch)
-                                                  ("IEF", 385, 700, 4, False), ("IEF", 102, 2500, 3, True)])
+                                                  ("IEF", 385, 700, 4, False), ("IEF", 102, 2500, 3, True),
+                                                  # (32 t + 1 input columns over more than 2,048 rows: the input
+                                                  # gradient's last column through the vector unit — 2, 7 and 8 tiles
+                                                  # in front of it; 8 tiles leave no room for it: a ninth tile)
+                                                  ("IMNET", 65, 3000, 1, False), ("IEF", 225, 2600, 2, True),
+                                                  ("IMNET", 257, 2100, 1, False)])
 def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
     p = orc.randomize_biases(orc.init_decoder(kind, d, 11, 5.0), 12)
     m = make_module(kind, p, d, cuda, n_iter=n_iter, use_sigmoid=sig).train()
@@ -53,12 +58,15 @@ def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
 @pytest.mark.parametrize("d,n,n_iter,sig,use", [(385, 333, 2, False, "both"), (385, 5000, 2, False, "both"),
                                                  (334, 129, 3, True, "both"), (385, 1, 2, False, "both"),
                                                  (385, 700, 1, False, "both"), (27, 31, 2, False, "both"),
+                                                 (97, 2300, 2, False, "both"), (257, 2100, 2, False, "both"),
                                                  (385, 900, 2, False, "prob"), (385, 900, 2, False, "off")])
 def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use):
     """decoders_forward_train (prob_dec(inp), offset_dec(inp) of pipeline.py:434-435 as ONE autograd node, the rows'
     gradient as one K = 512 product over both decoders' summed dZ1): values equal the two modules' bit for bit, the
     gradients equal the torch-op definition's to the tolerance of the single-module test and the two modules' own
-    sum to float noise; an output the loss does not use contributes nothing."""
+    sum to float noise; an output the loss does not use contributes nothing. (Row counts are chosen away from
+    leaky-ReLU kinks: at (257, 2200) one row has a layer-3 pre-activation of 1.4e-7, whose sign — and with it that
+    row's gradient — differs between any two float32 evaluations.)"""
     from implicit_depth_amd import decoders_forward_train
     pp = orc.randomize_biases(orc.init_decoder("IMNET", d, 21, 5.0), 22)
     po = orc.randomize_biases(orc.init_decoder("IEF", d, 23, 5.0), 24)
