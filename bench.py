@@ -941,7 +941,7 @@ def config_name(args, refine):
     """Which BASELINE.json configuration the per-GPU workload is (named in config.workload)."""
     if refine:
         return "configs[3]"
-    if args.decoder_pairs != "dense":
+    if args.pairs != "dense":
         return "configs[1]"     # replaced by the 'secondary' wording below
     shape = (args.frames, args.samples)
     return {(1, 64): "configs[1]", (4, 64): "configs[2] per-GPU shard (32 frames over 8 GPUs)",
@@ -1091,12 +1091,12 @@ def main():
     from implicit_depth_amd.synthetic import synthetic_scene
 
     h, w, N, B = 240, 320, args.samples, args.frames
-    if args.decoder_pairs == "n1":
+    if args.pairs == "n1":
         N = 1
     by_rays = args.shard == "rays"
-    if by_rays and (B != 1 or args.decoder_pairs == "scene" or args.workload != "query"):
+    if by_rays and (B != 1 or args.pairs == "scene" or args.workload != "query"):
         raise SystemExit("--shard rays splits the rows of ONE frame of the query workload")
-    scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.decoder_pairs == "ragged")
+    scene = synthetic_scene(B, h, w, N, seed=1235 + (0 if by_rays else rank), ragged=args.pairs == "ragged")
     rows, row0 = (0, h), 0
     if by_rays:   # image rows [lo, hi) of the one frame; maps, voxel features and weights replicated
         from implicit_depth_amd.dist import crop_rows, shard_rays, slice_rays
@@ -1107,7 +1107,7 @@ def main():
         scene, fg_cut, row0 = crop_rows(scene, scene["feat_grid"], rows[0], rows[1], 4)
         scene["feat_grid"] = fg_cut
     s = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
-    if args.decoder_pairs == "scene":
+    if args.pairs == "scene":
         # rays, voxels and pairs as the candidate generator produces them on real geometry
         from implicit_depth_amd import PointNet2Stage, pipeline as pl
         from implicit_depth_amd.synthetic import synthetic_batch
@@ -1127,7 +1127,7 @@ def main():
                   "vox_feat": dd["occ_voxel_feat"]})
         scene = dict(scene, P=int(dd["pair_ray"].shape[0]), V=int(dd["occ_voxel_feat"].shape[0]))
     P = scene["P"]
-    dense = args.decoder_pairs == "dense"
+    dense = args.pairs == "dense"
     gf = args.imnet_gf
     prob = IMNet(scene["D"], 1, gf).to(dev).eval()
     off = IEF(dev, scene["D"], 1, gf, n_iter=2).to(dev).eval()
@@ -1451,11 +1451,11 @@ def main():
                                         if lk else None),
                        "frac_rocprof_note": "issued FLOP of both launches / (their profiler average x launches per step)"})
         if not dense:
-            line["config"]["pairs"] = {"kind": args.decoder_pairs, "points": P, "rays": scene["R"],
+            line["config"]["pairs"] = {"kind": args.pairs, "points": P, "rays": scene["R"],
                                        "pairs_per_ray": round(P / scene["R"], 3)}
             line["config"]["workload"] = line["config"]["workload"].replace(
-                "configs[1]", "secondary (not the headline shape): %s candidate list" % args.decoder_pairs)
-            line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.decoder_pairs
+                "configs[1]", "secondary (not the headline shape): %s candidate list" % args.pairs)
+            line["metric"] = "Mpoints/sec implicit-MLP query, %s candidate list" % args.pairs
         if gf != 64:
             # FLOP of the layer-by-layer formulation per pair (generic.query): layer 1 over the 2E pair columns, the IEF's
             # 16 offset-encoding columns per pass, layers 2-4 of every pass; the per-voxel / per-ray tables are noise
