@@ -45,6 +45,7 @@ hipError_t lidf_launch_miss_count(const void*, int, long long, int*, int*, int*,
 hipError_t lidf_launch_miss_fill(const void*, int, long long, const int*, const float*, int, int, int*,
                                  int*, int*, float*, long long*, long long*, long long*, hipStream_t);
 hipError_t lidf_launch_linear(int nt, const LinearArgs&, int grid, hipStream_t);
+hipError_t lidf_launch_chain16(int gf, const Chain16Args&, int cus, hipStream_t);
 hipError_t lidf_launch_wgrad(const float*, long long, int, const float*, long long, int, long long,
                              float*, int, float*, float*, size_t, hipStream_t);
 hipError_t lidf_launch_pack_pointnet(const float*, const float*, const float*, const float*, const float*,
@@ -2253,6 +2254,55 @@ static int linear_impl(const float* x, int64_t ldx, int64_t n, int32_t k, const 
         const int grid = (int)(nt128 < 4LL * cus ? nt128 : 4LL * cus);
         CHECK_HIP(lidf_launch_linear(nt, a, grid, st));
     }
+    return LIDF_OK;
+}
+
+// ---- a whole decoder at gf_dim 32 / 64 / 128 as one register-chained launch (lidf_chain16.hip) ------------
+static size_t chain16_stream_bytes(int gf, int k) {
+    const int G = gf / 16;
+    return (size_t)(((k + 15) / 16) * 4 * G + lidf_chain16_pass_quads(G)) * 1024;
+}
+LIDF_API size_t lidf_decoder_chain_workspace_bytes(int32_t gf_dim, int32_t k) {
+    if ((gf_dim != 32 && gf_dim != 64 && gf_dim != 128) || k <= 0 || k > (1 << 16)) return 0;
+    return align_up(chain16_stream_bytes(gf_dim, k), 256) + align_up((size_t)lidf_chain16_aux_floats(gf_dim / 16) * 4, 256);
+}
+
+LIDF_API int lidf_decoder_chain_f32(const LidfDecoder* dec, int32_t gf_dim, int32_t inp_dim, const float* x,
+                                      int64_t ldx, int32_t k, int32_t w1_col0, int64_t n, const float* voxpart,
+                                      const int32_t* vox_idx, const float* raypart, const int32_t* ray_idx,
+                                      float* out, void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
+    if (!dec || n < 0 || k <= 0 || ldx < k || inp_dim <= 0 || w1_col0 < 0 || w1_col0 + k > inp_dim)
+        return LIDF_ERR_BAD_ARG;
+    if (gf_dim != 32 && gf_dim != 64 && gf_dim != 128) return LIDF_ERR_UNSUPPORTED;
+    if (!dec->w1 || !dec->w2 || !dec->b2 || !dec->w3 || !dec->b3 || !dec->w4 || !dec->b4) return LIDF_ERR_BAD_ARG;
+    if (dec->is_ief && (!dec->wenc || !dec->benc || dec->n_iter < 1 || dec->n_iter > 64)) return LIDF_ERR_BAD_ARG;
+    if (n == 0) return LIDF_OK;
+    if (!x || !out || (vox_idx && !voxpart) || (ray_idx && !raypart)) return LIDF_ERR_BAD_ARG;
+    if (k > (1 << 16)) return LIDF_ERR_UNSUPPORTED;
+    const size_t need = lidf_decoder_chain_workspace_bytes(gf_dim, k);
+    if (!workspace || workspace_bytes < need) return LIDF_ERR_WORKSPACE;
+    int rc, cus;
+    if ((rc = cu_count(&cus))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = gf_dim / 16;
+    float* sbuf = (float*)workspace;
+    float* aux = (float*)((char*)workspace + align_up(chain16_stream_bytes(gf_dim, k), 256));
+    StreamLayout lay = {};
+    lay.nets = 1; lay.mode = LIDF_MODE_CHAIN16;
+    lay.total = (int)(chain16_stream_bytes(gf_dim, k) / 4);
+    L1Map m = {};
+    m.n0 = k; m.c0 = w1_col0; m.nt = G;
+    const NetW nw = to_netw(dec, inp_dim);
+    CHECK_HIP(pack_stream(lay, nw, nw, m, sbuf, aux, st));
+    Chain16Args a = {};
+    a.stream = sbuf; a.aux = aux; a.KQ = (k + 15) / 16; a.E = k; a.n = n;
+    a.X = x; a.ldx = ldx;
+    a.vox = vox_idx; a.voxpart = voxpart; a.ray = ray_idx; a.raypart = raypart;
+    a.npass = dec->is_ief ? dec->n_iter : 1;
+    a.init = dec->is_ief ? dec->init_offset : 0.f;
+    a.sigmoid = dec->use_sigmoid;
+    a.out = out;
+    CHECK_HIP(lidf_launch_chain16(gf_dim, a, cus, st));
     return LIDF_OK;
 }
 

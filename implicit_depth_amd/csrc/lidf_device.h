@@ -76,7 +76,8 @@ enum { LIDF_MODE_FUSED = 0, LIDF_MODE_ROWS = 1, LIDF_MODE_L1ONLY = 2, LIDF_MODE_
        LIDF_MODE_ROWS_GATHER = 6,    // rows mode whose layer-1 accumulators start from gathered rows
        LIDF_MODE_PNET_CHAIN = 7,     // pack jobs only: the per-point chain stream of a PointNet2Stage (PN_* below)
        LIDF_MODE_IEF16 = 8,          // pack jobs only: the stage-2 decoder's 16 x 16 x 4 stream (lidf_ief16.hip)
-       LIDF_MODE_PNET_BWD = 9 };     // pack jobs only: the backward chains' stream of a PointNet2Stage (PNB_* below)
+       LIDF_MODE_PNET_BWD = 9,       // pack jobs only: the backward chains' stream of a PointNet2Stage (PNB_* below)
+       LIDF_MODE_CHAIN16 = 10 };     // the any-width decoder chain's stream (lidf_chain16.hip; L1Map.nt = gf / 16)
 #define IEF16_PASS_QUADS 168   // 2 + 1 bias quads, 4 u quads, 128 layer-2 quads, 32 layer-3 quads, 1 padding quad
 #define IEF16_AUX_FLOATS 72    // w4 [64] | b4 [1] (+ padding)
 
@@ -409,6 +410,31 @@ struct Ief16Args {
     int sigmoid;
     float* out;            // [n]
 };
+
+// Arguments of the any-width decoder chain (lidf_chain16.hip); G = gf / 16, table rows are 4 gf = 64 G floats.
+struct Chain16Args {
+    const float* stream;   // (KQ * 4 G + lidf_chain16_pass_quads(G)) KiB
+    const float* aux;      // w4 [16 G] | b4 [1] (lidf_chain16_aux_floats(G))
+    int KQ;                // layer-1 k-quads of 16 columns
+    int E;                 // per-row operand columns (columns beyond it are zero)
+    long long n;           // rows
+    const float* X;        // [n, ldx]; readable up to column 16 KQ of every row
+    long long ldx;
+    const int* vox;        // [n] row of voxpart, or NULL (row 0 for every row)
+    const float* voxpart;  // [V, 64 G]  W1[:, per-voxel columns] f + b1 (+ c), or NULL
+    const int* ray;        // [n] row of raypart, or NULL (row r)
+    const float* raypart;  // [R, 64 G], or NULL
+    int npass;
+    float init;
+    int sigmoid;
+    float* out;            // [n]
+};
+static inline int lidf_chain16_pass_quads(int G) {
+    const int T1 = 4 * G, T2 = 2 * G, T3 = G;
+    const int raw = (T2 + 3) / 4 + T1 * T2 + T1 / 4 + (T3 + 3) / 4 + T2 * T3;
+    return (raw + 7) / 8 * 8;
+}
+static inline int lidf_chain16_aux_floats(int G) { return 16 * G + 8; }
 
 // Arguments of the two-layer per-voxel kernel (lidf_linear.hip: lidf_vox2_kernel).
 struct Vox2Args {

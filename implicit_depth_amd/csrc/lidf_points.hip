@@ -170,6 +170,46 @@ __device__ float ief16_stream_value(const NetW& n, const L1Map& m, int e) {
     return 0.f;
 }
 
+// element e of the any-width decoder chain's stream (layout: lidf_chain16.hip); G = m.nt = gf / 16, m.n0 = E per-row
+// columns starting at w1 column m.c0
+__device__ float chain16_stream_value(const NetW& n, const L1Map& m, int e) {
+    const int G = m.nt, T1 = 4 * G, T2 = 2 * G, T3 = G;
+    const int KQ = (m.n0 + 15) / 16;
+    int quad = e / 256;
+    const int lane = (e % 256) / 4, r = e & 3;
+    const int j = lane & 15, g = lane >> 4;
+    if (quad < KQ * T1) {
+        const int kq = quad / T1, To = quad % T1;
+        const int x = 16 * kq + 4 * g + r;
+        return x < m.n0 ? n.w1[(size_t)(16 * To + j) * n.ld1 + m.c0 + x] : 0.f;
+    }
+    quad -= KQ * T1;
+    const int NB2 = (T2 + 3) / 4, NB3 = (T3 + 3) / 4;
+    if (quad < NB2) {   // bias quads of layer 2: component r = b2 of output tile 4 quad + r, in group 0
+        const int tile = 4 * quad + r;
+        return (g == 0 && tile < T2) ? n.b2[16 * tile + j] : 0.f;
+    }
+    quad -= NB2;
+    const int blk_len = 1 + 4 * T2;   // a u quad in front of every fourth input tile, T2 quads per input tile
+    if (quad < (T1 / 4) * blk_len) {
+        const int blk = quad / blk_len, in = quad % blk_len;
+        if (in == 0) return (g == 0 && n.is_ief) ? ief_u(n, 16 * (4 * blk + r) + j) : 0.f;
+        const int T = 4 * blk + (in - 1) / T2, To = (in - 1) % T2;
+        return n.w2[(size_t)(16 * To + j) * (64 * G) + 16 * T + 4 * g + r];
+    }
+    quad -= (T1 / 4) * blk_len;
+    if (quad < NB3) {
+        const int tile = 4 * quad + r;
+        return (g == 0 && tile < T3) ? n.b3[16 * tile + j] : 0.f;
+    }
+    quad -= NB3;
+    if (quad < T2 * T3) {
+        const int T = quad / T3, To = quad % T3;
+        return n.w3[(size_t)(16 * To + j) * (32 * G) + 16 * T + 4 * g + r];
+    }
+    return 0.f;
+}
+
 __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& net0, const NetW& net1,
                                           const L1Map& m, float* stream, float* aux) {
     if (lay.guard && lay.guard->dirty == 0) return;   // guarded packing: fingerprint unchanged
@@ -189,6 +229,12 @@ __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& n
         if (e < lay.total) stream[e] = ief16_stream_value(net0, m, e);
         if (e < IEF16_AUX_FLOATS)
             aux[e] = e < 64 ? net0.w4[e] : (e == 64 ? net0.b4[0] : 0.f);
+        return;
+    }
+    if (lay.mode == LIDF_MODE_CHAIN16) {
+        const int gf = 16 * m.nt;
+        if (e < lay.total) stream[e] = chain16_stream_value(net0, m, e);
+        if (e < gf + 8) aux[e] = e < gf ? net0.w4[e] : (e == gf ? net0.b4[0] : 0.f);
         return;
     }
     NetW nets[2] = {net0, net1};

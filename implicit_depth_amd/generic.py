@@ -14,11 +14,83 @@ and lidf_wgrad_f32 (weight and bias gradients), the PointNet's two poolings and 
 torch indexing that autograd differentiates itself; the fused query / stage-2 calls train at the
 shipped widths only.
 
+Round 6: a decoder of gf_dim 32, 64 or 128 with a 1-wide head runs its inference as ONE register-chained launch
+(lidf_decoder_chain_f32, csrc/lidf_chain16.hip: 16-row sub-tiles of the 16 x 16 x 4 matrix instruction, activations
+in registers from layer 1 to the output) instead of one launch per layer and pass — the query and decoder_forward
+take it; LIDF_CHAIN16=0 keeps the layer-by-layer path (A/B, and the definition the chain is tested against).
+
 Nothing here is used when the widths are the shipped ones.
 """
+import os
+
 import torch
 
 from . import _lib
+
+
+def chain_ok(mod):
+    """A decoder lidf_decoder_chain_f32 is built for: gf_dim 32 / 64 / 128, the reference's 4 gf -> 2 gf -> gf -> 1."""
+    if os.environ.get("LIDF_CHAIN16", "1") == "0":
+        return False
+    gf = int(mod.gf_dim)
+    return (gf in (32, 64, 128) and mod.linear_1.out_features == 4 * gf and mod.linear_2.out_features == 2 * gf
+            and mod.linear_3.out_features == gf and mod.linear_4.out_features == 1)
+
+
+def _bias_row(mod):
+    """b1 (+ the IEF's constant W1[:, enc columns] benc) as the one-row voxpart table of a chain launch."""
+    from .decoders import IEF
+    b = mod.linear_1.bias.detach().float()
+    if isinstance(mod, IEF):
+        d = mod.inp_dim
+        b = b + mod.linear_1.weight.detach()[:, d:d + 16].float() @ mod.offset_enc.bias.detach().float()
+    return b
+
+
+def decoder_chain(mod, x, k, w1_col0=0, voxpart=None, vox_idx=None, raypart=None, ray_idx=None, out=None,
+                  padded=False):
+    """The whole decoder on per-row operand columns x[:, :k] (they multiply W1[:, w1_col0 : w1_col0 + k]) plus two
+    gathered table rows — lidf_decoder_chain_f32. voxpart must carry b1 (+ the IEF constant: _bias_row). padded: x's
+    buffer is readable up to column 16 ceil(k / 16) of its last row (otherwise the trailing rows go through a
+    padded copy). Returns [n, 1]."""
+    from .decoders import _decoder_struct
+    import ctypes as C
+    n = x.shape[0]
+    dev = x.device
+    if out is None:
+        out = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    ldx = x.stride(0) if n > 1 else x.shape[1]
+    kq16 = (k + 15) // 16 * 16
+    L = _lib.lib()
+    gf = int(mod.gf_dim)
+    wsb = L.lidf_decoder_chain_workspace_bytes(gf, k)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    keep = []
+    dec = _decoder_struct(mod, keep)
+
+    def run(xs, ld, rows, o, vi, ri, rp):
+        with torch.cuda.device(dev):
+            _lib.check(L.lidf_decoder_chain_f32(
+                C.byref(dec), gf, int(mod.inp_dim), _lib.ptr(xs), ld, k, w1_col0, rows, _lib.ptr(voxpart), _lib.ptr(vi),
+                _lib.ptr(rp), _lib.ptr(ri), _lib.ptr(o), _lib.ptr(ws), wsb, _lib.current_stream(dev)))
+
+    # rows whose 16-column groups would read past the end of x's buffer: through a padded copy
+    tail = 0 if (padded or kq16 <= k) else min(n, (kq16 - k + max(ldx, 1) - 1) // max(ldx, 1))
+    head = n - tail
+    if head:
+        run(x, ldx, head, out, vox_idx, ray_idx, raypart)
+    if tail:
+        xt = torch.zeros((tail, kq16), dtype=torch.float32, device=dev)
+        xt[:, :k] = x[head:, :k]
+        # (the tail's rows of a ray table without an index array are rows head.. of it)
+        rp_t = raypart[head:] if (raypart is not None and ray_idx is None) else raypart
+        run(xt, kq16, tail, out[head:], vox_idx[head:] if vox_idx is not None else None,
+            ray_idx[head:] if ray_idx is not None else None, rp_t)
+    return out
 
 
 def linear_hip(x, weight, bias=None, act=0, slope=0.0, addrows=None, addidx=None, out=None,
@@ -113,6 +185,8 @@ def decoder_forward(mod, x):
     if d != mod.inp_dim:
         raise RuntimeError("decoder inp_dim %d != input width %d" % (mod.inp_dim, d))
     l1 = mod.linear_1
+    if chain_ok(mod):   # one launch: every input column is a per-row operand, the bias a one-row table
+        return decoder_chain(mod, x, d, voxpart=_bias_row(mod).reshape(1, -1).contiguous())
     return _decoder_from_layer1(
         mod, n, x.device,
         lambda act: linear_hip(x, l1.weight, l1.bias, act=1 if act else 0, slope=0.02 if act else 0.0, k=d))
@@ -197,9 +271,12 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     Cv, Cr, Ed = vf.shape[1], roi.shape[1], edir.shape[1]
     ray_rows = torch.arange(R, dtype=torch.int32, device=dev)
     tables = []
+    chained = chain_ok(prob_dec) and chain_ok(offset_dec)
     for dec in (prob_dec, offset_dec):
         l1 = dec.linear_1
-        voxpart = linear_hip(vf, l1.weight, l1.bias, k=Cv)
+        # (the chain launch takes the IEF's constant W1[:, enc] benc inside the per-voxel table, as the fixed-width
+        # kernels do; the layer-by-layer path adds the encoded offset explicitly in every pass)
+        voxpart = linear_hip(vf, l1.weight, _bias_row(dec) if chained else l1.bias, k=Cv)
         rp = linear_hip(roi, l1.weight, None, w_col0=Cv, k=Cr)
         raypart = linear_hip(edir, l1.weight, None, w_col0=Cv + Cr + 2 * E, k=Ed, addrows=rp, addidx=ray_rows)
         tables.append((voxpart, raypart))
@@ -207,7 +284,8 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
         p1 = min(P, p0 + QUERY_SLAB)
         n = p1 - p0
         pr_s, pv_s, pt_s = pair_ray[p0:p1], pair_vox[p0:p1], pair_t[p0:p1]
-        pe = torch.empty((n, 2 * E), dtype=torch.float32, device=dev)
+        # (16 floats of slack behind the rows: the chain launch reads whole 16-column groups of the last row)
+        pe = torch.empty((n * 2 * E + 16,), dtype=torch.float32, device=dev)[:n * 2 * E].view(n, 2 * E)
         with torch.cuda.device(dev):
             _lib.check(L.lidf_pe_rows_f32(_lib.ptr(pr_s), _lib.ptr(pv_s), _lib.ptr(pt_s), _lib.ptr(ray_dir),
                                           _lib.ptr(vox_center), 1 if pos_rel else 0, multires, n, _lib.ptr(pe),
@@ -215,6 +293,10 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
         pr_i, pv_i = pr_s.contiguous(), pv_s.contiguous()
         for dec, (voxpart, raypart), dst in ((prob_dec, tables[0], pred_prob), (offset_dec, tables[1], pred_offset)):
             w1 = dec.linear_1.weight
+            if chained:   # the whole decoder in one launch, straight into its slab of the output
+                decoder_chain(dec, pe, 2 * E, w1_col0=Cv + Cr, voxpart=voxpart, vox_idx=pv_i, raypart=raypart,
+                              ray_idx=pr_i, out=dst[p0:p1], padded=True)
+                continue
 
             def layer1(act, w1=w1, voxpart=voxpart, raypart=raypart):
                 return linear_hip(pe, w1, None, act=1 if act else 0, slope=0.02 if act else 0.0, w_col0=Cv + Cr,

@@ -682,6 +682,21 @@ int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const
                            int32_t seg_dtype, int32_t src_h, int32_t src_w, int32_t dst_h, int32_t dst_w,
                            float* out, void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
+/* ---- A whole decoder at gf_dim 32 / 64 / 128 as ONE launch (ABI 12) ------------------------------------------
+ * IMNet / IEF (models/implicit_net.py:60-152: gf_dim is a constructor argument) with layer 1 factorised as the
+ * fixed-width kernels have it: x [n, k] (row stride ldx) are the per-row operand columns — they multiply
+ * W1[:, w1_col0 : w1_col0 + k] — and the columns that depend on a voxel / a ray alone arrive as rows of two tables
+ * of 4 gf_dim floats: voxpart[vox_idx[i]] (which carries b1, and for an IEF its constant W1[:, enc columns] benc;
+ * vox_idx NULL: row 0 for every row) and raypart[ray_idx[i]] (ray_idx NULL: row i); either table may be NULL.
+ * inp_dim = the decoder's input width (W1 has inp_dim (+ 16 for an IEF) columns). out [n].
+ * x must be readable up to column 16 ceil(k / 16) of its LAST row (the kernel reads whole 16-column groups and
+ * masks what lies beyond k). Other widths: LIDF_ERR_UNSUPPORTED (the layers run one by one, lidf_linear_f32).   */
+size_t lidf_decoder_chain_workspace_bytes(int32_t gf_dim, int32_t k);
+int lidf_decoder_chain_f32(const LidfDecoder* dec, int32_t gf_dim, int32_t inp_dim, const float* x, int64_t ldx,
+                           int32_t k, int32_t w1_col0, int64_t n, const float* voxpart, const int32_t* vox_idx,
+                           const float* raypart, const int32_t* ray_idx, float* out, void* workspace,
+                           size_t workspace_bytes, lidf_stream_t stream);
+
 /* ---- Decoders, training path (first step) -------------------------------------
  * What autograd does for models/implicit_net.py IMNet / IEF on [n, d] rows: a forward that keeps
  * the activations of every layer and pass, and a backward that returns the gradient of the input

@@ -93,6 +93,51 @@ def test_decoders_at_other_widths(cuda, kind, inp, out_dim, gf, n_iter, sig):
         assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 2e-5 * max(float(q.grad.abs().max()), 1.0), name
 
 
+@pytest.mark.parametrize("gf", [32, 64, 128])
+@pytest.mark.parametrize("kind,inp,n_iter,sig,n", [("IMNET", 385, 1, False, 1), ("IEF", 385, 2, False, 17),
+                                                   ("IEF", 48, 3, True, 2049), ("IMNET", 7, 1, True, 15),
+                                                   ("IEF", 113, 1, False, 16), ("IEF", 334, 2, False, 40000)])
+def test_decoder_chain_matches_the_layers(cuda, monkeypatch, gf, kind, inp, n_iter, sig, n):
+    """lidf_decoder_chain_f32 (csrc/lidf_chain16.hip: the whole decoder of gf_dim 32 / 64 / 128 as one
+    register-chained launch) against the layer-by-layer path of the same module (LIDF_CHAIN16=0) and the float64
+    definition: row counts around the 16-row sub-tile, input widths that are not whole 16-column groups (the trailing
+    rows go through a padded copy), more k-quads than the kernel prefetches, 1-3 passes, both output activations."""
+    from implicit_depth_amd import IEF, IMNet
+    torch.manual_seed(gf + inp + n)
+    mod = IMNet(inp, 1, gf, use_sigmoid=sig) if kind == "IMNET" else IEF("cpu", inp, 1, gf, n_iter=n_iter, use_sigmoid=sig)
+    for p in mod.parameters():
+        p.data.mul_(6.0)
+    ref_mod = copy.deepcopy(mod).double()
+    if kind == "IEF":
+        ref_mod.init_offset = ref_mod.init_offset.double()
+    x = torch.randn(n, inp)
+    with torch.no_grad():
+        ref = ref_mod.forward_composite(x.double())
+    mod = mod.to(cuda).eval()
+    if kind == "IEF":
+        mod.device, mod.init_offset = cuda, mod.init_offset.to(cuda)
+    xd = x.to(cuda)
+    with torch.no_grad():
+        got = mod(xd)
+        monkeypatch.setenv("LIDF_CHAIN16", "0")
+        layers = mod(xd)
+        monkeypatch.delenv("LIDF_CHAIN16")
+        again = mod(xd)
+    assert got.shape == (n, 1)
+    # (weights x 6 push pre-activations of the wide decoders to ~40: the layer-by-layer path's own distance from
+    # float64 is the yardstick — 1.5e-5 at gf 128 over 40,000 rows — not an absolute 1e-5)
+    e_chain = float((got.double().cpu() - ref).abs().max())
+    e_layers = float((layers.double().cpu() - ref).abs().max())
+    assert e_chain <= max(1e-5, 1.5 * e_layers), (e_chain, e_layers)
+    assert float((got - layers).abs().max()) <= 4e-5
+    assert torch.equal(got, again)
+    # a strided view of a wider buffer (row stride != inp): same rows, same values
+    wide = torch.full((n, inp + 5), float("nan"), device=cuda)
+    wide[:, :inp] = xd
+    with torch.no_grad():
+        assert torch.equal(mod(wide[:, :inp]), got)
+
+
 @pytest.mark.parametrize("cin,outc,gf,n,V", [(9, 192, 48, 5000, 40), (6, 64, 16, 700, 3), (6, 128, 64, 2000, 300)])
 def test_pointnet_at_other_widths(cuda, cin, outc, gf, n, V):
     from implicit_depth_amd import PointNet2Stage
