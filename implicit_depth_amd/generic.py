@@ -231,6 +231,7 @@ def roi_align_rays(feat_grid, ray_pix, ray_bid, roi_inp_bbox=8, roi_out_bbox=2):
 
 
 QUERY_SLAB = 614400   # pairs per slab of the layer-by-layer query (rows [slab, D]: 0.95 GB at D = 385)
+CHAIN_SLAB_FACTOR = 16
 
 
 def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_grid, vox_feat, prob_dec,
@@ -280,8 +281,13 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
         rp = linear_hip(roi, l1.weight, None, w_col0=Cv, k=Cr)
         raypart = linear_hip(edir, l1.weight, None, w_col0=Cv + Cr + 2 * E, k=Ed, addrows=rp, addidx=ray_rows)
         tables.append((voxpart, raypart))
-    for p0 in range(0, P, QUERY_SLAB):
-        p1 = min(P, p0 + QUERY_SLAB)
+    # (the chain launch keeps nothing per pair but the 2E position-embedding columns — 408 B at L = 8: the whole
+    # configs[1] frame is 2 GB. At gf 128 longer slabs pay — one pack and one ramp-up per decoder and frame: 97.8 ->
+    # 99.2 Mpoints/s —, at gf 32 they do not: 588 -> 578, a 614,400-pair slab of embedding rows is 250 MB and is
+    # read back twice out of the 256 MB last-level cache instead of HBM)
+    slab = QUERY_SLAB * (CHAIN_SLAB_FACTOR if (chained and prob_dec.gf_dim >= 128) else 1)
+    for p0 in range(0, P, slab):
+        p1 = min(P, p0 + slab)
         n = p1 - p0
         pr_s, pv_s, pt_s = pair_ray[p0:p1], pair_vox[p0:p1], pair_t[p0:p1]
         # (16 floats of slack behind the rows: the chain launch reads whole 16-column groups of the last row)

@@ -229,6 +229,7 @@ def test_query_at_other_widths_in_slabs(cuda, monkeypatch):
                               s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off)
     whole = run()
     assert scene["P"] > 300
+    monkeypatch.setattr(generic, "CHAIN_SLAB_FACTOR", 1)   # (the chain launch's slabs are a multiple of QUERY_SLAB)
     for slab in (1, 97, 128, scene["P"] - 1):
         monkeypatch.setattr(generic, "QUERY_SLAB", slab)
         part = run()
