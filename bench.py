@@ -360,6 +360,13 @@ def live_profile(argv, dominant, steps=6, warmup=2, pmc=False, timeout=300, per_
             shutil.rmtree(d, ignore_errors=True)
 
 
+def chain_launches_per_step(gf, P):
+    """Launches of lidf_chain16_kernel in one query at another decoder width: two decoders x the slabs of generic.query."""
+    from implicit_depth_amd import generic as g
+    slab = g.QUERY_SLAB * (g.CHAIN_SLAB_FACTOR if gf >= 128 else 1)
+    return 2 * ((P + slab - 1) // slab)
+
+
 def live_kernel(live, name):
     """(avg ms after the first launch, avg ms of all launches, calls per step) of the kernel whose short name
     contains `name` in a live_profile record, or None."""
@@ -1305,7 +1312,7 @@ def main():
         h16 = args.precision == "f16x3"
         peak = PEAK_F16_TFLOPS if h16 else PEAK_F32_TFLOPS
         f_exec = F_EXEC_H if h16 else F_EXEC
-        kname = "lidf_points_h_kernel" if h16 else ("lidf_points_fused_kernel" if gf == 64 else "lidf_linear_kernel<8, false>")
+        kname = "lidf_points_h_kernel" if h16 else ("lidf_points_fused_kernel" if gf == 64 else "lidf_chain16_kernel")
         # rocprofv3 legs of this very command (child processes after the timed region). Every N = 1 query run
         # gets the kernel trace; the HBM counter passes run for the default headline command (the line the
         # driver records) and wherever --pmc asks for them. Nothing is read from committed files.
@@ -1315,7 +1322,8 @@ def main():
                     and args.offsets == "all")
         if world == 1 and not use_dist and not args.no_rocprof and not profiled:
             live = live_profile(sys.argv[1:], kname, pmc=args.pmc or (headline and not args.no_cpu_baseline),
-                                per_step=2 if (args.offsets == "selected" and gf == 64 and not h16) else 1)
+                                per_step=(2 if (args.offsets == "selected" and gf == 64 and not h16) else
+                                          chain_launches_per_step(gf, P) if gf != 64 else 1))
         lk = live_kernel(live, kname)
         lh = (live or {}).get("hbm")
         lhk = None
@@ -1463,17 +1471,38 @@ def main():
             tail = 2 * (h1 * h2 + h2 * h3 + h3)
             fl_pt = 2 * (2 * e2 * h1) + tail + 2 * (2 * 16 * h1 + tail)
             a_ = fl_pt * P / (elapsed / args.steps) / 1e12
+            from implicit_depth_amd import generic as _gen
+            chained = _gen.chain_ok(prob) and _gen.chain_ok(off)
             line["roofline"] = {"bound": "mfma", "achieved": round(a_, 2), "peak": peak, "unit": "TFLOP/s",
                                 "frac": round(a_ / peak, 4), "traffic": None,
-                                "kernel": "lidf_linear_kernel<NT> per layer (whole step, between the events)",
+                                "kernel": ("lidf_chain16_kernel<gf / 16, ..> once per decoder and slab" if chained else
+                                           "lidf_linear_kernel<NT> per layer") + " (whole step, between the events)",
                                 "flop_per_point_exec": fl_pt,
+                                "clocks": "frac = the formulation's FLOP over the WHOLE step (wall clock between syncs), "
+                                          "not a kernel's duration",
                                 "basis": "FLOP of the executed formulation (factorised layer 1, 3 decoder passes), "
                                          "not an instruction count; the shipped width issues %d per point" % F_EXEC}
-            line["config"]["workload"] = ("secondary: imnet_gf %d (not a shipped width): get_embedding + get_pred layer by "
-                                          "layer, layer 1 factorised into per-voxel / per-ray tables + the pair's position "
-                                          "embedding, pairs in %d-pair slabs (implicit_depth_amd/generic.py), "
-                                          "%d x 240x320 frame(s), %d candidates/ray" % (gf, 614400, B, N))
-            line["metric"] = "Mpoints/sec implicit-MLP query at imnet_gf %d (layer by layer)" % gf
+            if chained and lk:
+                # the chain launch itself, on the profiler's clock: issued 16 x 16 x 4 matrix instructions per 16-row
+                # sub-tile (layer 1 over ceil(2E / 16) k-quads, per pass the bias / u steps and layers 2-3), both decoders
+                G = gf // 16
+                t1, t2, t3 = 4 * G, 2 * G, G
+                l1m = ((e2 + 15) // 16) * t1 * 4
+                pm = 4 * ((t2 + 3) // 4) + t1 + t1 * t2 * 4 + min(4, t3) * ((t3 + 3) // 4) + t2 * t3 * 4
+                mf = (l1m + pm) + (l1m + 2 * pm)          # IMNet + IEF n_iter 2
+                per_step_ms = lk["avg_ms_after_first"] * lk["calls_per_step"]
+                line["roofline"]["chain_kernel"] = {
+                    "mfma_16x16x4_per_16_rows_both_decoders": mf, "calls_per_step": lk["calls_per_step"],
+                    "ms_per_step_rocprof": round(per_step_ms, 4),
+                    "frac_rocprof": round(mf * 2048.0 * (P / 16.0) / (per_step_ms * 1e-3) / 1e12 / peak, 4)}
+            line["config"]["workload"] = ("secondary: imnet_gf %d (not a shipped width): get_embedding + get_pred with layer 1 "
+                                          "factorised into per-voxel / per-ray tables + the pair's position embedding, %s, "
+                                          "pairs in slabs (implicit_depth_amd/generic.py), %d x 240x320 frame(s), %d "
+                                          "candidates/ray" % (gf, "each decoder ONE register-chained launch per slab "
+                                                              "(lidf_decoder_chain_f32)" if chained else
+                                                              "the decoders layer by layer (LIDF_CHAIN16=0)", B, N))
+            line["metric"] = "Mpoints/sec implicit-MLP query at imnet_gf %d (%s)" % (gf, "chain launch" if chained
+                                                                                    else "layer by layer")
         if world == 1 and not args.no_cpu_baseline and dense and gf == 64:
             cb, ref = cpu_baseline(scene)
             line["cpu_baseline"] = cb

@@ -274,11 +274,13 @@ __global__ void __launch_bounds__(256 * SLOTS) lidf_chain16_kernel(Chain16Args a
     const long long per = nhalf / nw, rem = nhalf % nw;
     long long t = wv * per + (wv < rem ? wv : rem);
     long long te = t + per + (wv < rem ? 1 : 0);
-    if (SLOTS == 2) {
-        // (the first wavefront's share a multiple of NT: no odd sub-tile in the middle of the range)
-        long long mid = t + ((te - t + 1) / 2 + NT - 1) / NT * NT;
-        if (mid > te) mid = te;
-        if (w >> 2) t = mid; else te = mid;
+    if (SLOTS > 1) {
+        // (every wavefront's share but the last a multiple of NT: no odd sub-tile in the middle of the range)
+        const long long slot = w >> 2, cnt = te - t;
+        const long long chunk = ((cnt + SLOTS - 1) / SLOTS + NT - 1) / NT * NT;
+        const long long t0 = t + slot * chunk;
+        t = t0 < te ? t0 : te;
+        te = t0 + chunk < te ? t0 + chunk : te;
     }
     if (t >= te) return;
     const int total_bytes = (a.KQ * T1 + PASSQ) * 1024;
@@ -314,8 +316,15 @@ extern "C" hipError_t lidf_launch_chain16(int gf, const Chain16Args& a, int cus,
     // gf 32: two wavefronts per SIMD, two sub-tiles each (64 + 32 + 16 accumulator registers per pair of sub-tiles);
     // gf 64: two wavefronts, one sub-tile each (the stage-2 decoder's configuration); gf 128: one wavefront, one
     // sub-tile (128 + 64 + 32 accumulator registers, the 512-register budget of a lone wavefront)
+    static int cfg32 = -1;   // development knob (A/B runs): LIDF_CHAIN16_GF32 = <wavefronts per SIMD><sub-tiles side by side>
+    if (cfg32 < 0) { const char* e = getenv("LIDF_CHAIN16_GF32"); cfg32 = e ? atoi(e) : 22; }
     switch (gf) {
-        case 32: hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 2>), dim3((unsigned)g), dim3(512), 0, st, a); break;
+        case 32:
+            if (cfg32 == 12) hipLaunchKernelGGL((lidf_chain16_kernel<2, 1, 2>), dim3((unsigned)g), dim3(256), 0, st, a);
+            else if (cfg32 == 21) hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
+            else if (cfg32 == 41) hipLaunchKernelGGL((lidf_chain16_kernel<2, 4, 1>), dim3((unsigned)g), dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
+            break;
         case 64: hipLaunchKernelGGL((lidf_chain16_kernel<4, 2, 1>), dim3((unsigned)g), dim3(512), 0, st, a); break;
         case 128: hipLaunchKernelGGL((lidf_chain16_kernel<8, 1, 1>), dim3((unsigned)g), dim3(256), 0, st, a); break;
         default: return hipErrorInvalidValue;

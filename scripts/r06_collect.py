@@ -125,7 +125,9 @@ def main():
             ("kt_train_query.db", "kernel_stats_train_query.csv",
              "python bench.py --workload train-query --steps 10 --warmup 3 --no-rocprof  (13 steps + 10 host-timing steps)"),
             ("kt_train.db", "kernel_stats_train.csv",
-             "python bench.py --workload train --steps 10 --warmup 3 --no-rocprof  (13 steps + 10 host-timing steps)")]
+             "python bench.py --workload train --steps 10 --warmup 3 --no-rocprof  (13 steps + 10 host-timing steps)"),
+            ("kt_train_pair.db", "kernel_stats_train_pair.csv",
+             "python bench.py --workload train --decoder-pair --steps 10 --warmup 3 --no-rocprof  (13 steps + 10 host-timing steps)")]
     for db, out, cmd in runs:
         if os.path.exists(j(SRC, db)):
             stats(j(SRC, db), j(OUT, "%s_%s" % (TAG, out)), cmd)

@@ -32,13 +32,16 @@ if has e2e; then
 fi
 if has train; then
   for w in train train-query train-refine; do $B --workload $w --steps 40 --warmup 10 > $O/bench_$w.json 2>> $O/err.txt; done
+  $B --workload train --decoder-pair --steps 40 --warmup 10 > $O/bench_train_pair.json 2>> $O/err.txt
   $B --workload train-query --offsets selected --steps 40 --warmup 10 > $O/bench_train-query_selected.json 2>> $O/err.txt
   $B --workload train-query --dense-offset-grad --steps 40 --warmup 10 > $O/bench_train-query_dense.json 2>> $O/err.txt
 fi
 if has misc; then
   $B --precision f16x3 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f16x3.json 2>> $O/err.txt
   $B --imnet-gf 128 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gf128.json 2>> $O/err.txt
-  $B --imnet-gf 32 --steps 5 --warmup 2 --no-cpu-baseline --no-rocprof > $O/bench_gf32.json 2>> $O/err.txt
+  $B --imnet-gf 32 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gf32.json 2>> $O/err.txt
+  LIDF_CHAIN16=0 $B --imnet-gf 128 --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof > $O/bench_gf128_layers.json 2>> $O/err.txt
+  LIDF_CHAIN16=0 $B --imnet-gf 32 --steps 5 --warmup 2 --no-cpu-baseline --no-rocprof > $O/bench_gf32_layers.json 2>> $O/err.txt
   for w in decoders embed; do $B --workload $w --steps $( [ $w = embed ] && echo 2000 || echo 40 ) --warmup $( [ $w = embed ] && echo 300 || echo 10 ) > $O/bench_$w.json 2>> $O/err.txt; done
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n1_rccl.json 2>> $O/err.txt
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29656 bench.py --gpus 1 --shard rays --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n1_rccl_rays.json 2>> $O/err.txt
@@ -55,6 +58,7 @@ if has prof; then
   kt kt_train_refine --workload train-refine --steps 10 --warmup 3 --no-rocprof
   kt kt_train_query --workload train-query --steps 10 --warmup 3 --no-rocprof
   kt kt_train --workload train --steps 10 --warmup 3 --no-rocprof
+  kt kt_train_pair --workload train --decoder-pair --steps 10 --warmup 3 --no-rocprof
   pmc() { rm -rf /tmp/p_$1; rocprofv3 "${@:3}" -d /tmp/p_$1 -o r -- python $R/bench.py $2 > /dev/null 2>&1; cp $(find /tmp/p_$1 -name '*_results.db' | head -1) $R/$O/$1.db; }
   pmc fetch "$P" --pmc FETCH_SIZE
   pmc write "$P" --pmc WRITE_SIZE

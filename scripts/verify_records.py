@@ -125,7 +125,7 @@ def verify(tag="r06", prof=None):
     # ---------------------------------------------------------------- training steps
     spills = []
     for wl, marker, per in (("train-query", "lidf_points_fused_train_kernel", 1), ("train", "lidf_points_kernel<5>", 2),
-                            ("train-refine", "lidf_pnet_bwd_b_kernel", 2)):
+                            ("train_pair", "lidf_points_kernel<5>", 2), ("train-refine", "lidf_pnet_bwd_b_kernel", 2)):
         cs, js = j("kernel_stats_%s.csv" % wl.replace("-", "_")), j("bench_%s.json" % wl)
         if not (os.path.exists(cs) and os.path.exists(js)):
             continue
