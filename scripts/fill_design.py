@@ -55,7 +55,7 @@ def main():
     hh = rec("f16x3")
     v.update(h_value=f(hh["value"], 0), h_frac=f(hh["roofline"]["frac"], 3))
     tq, tr, tn = rec("train-query"), rec("train-refine"), rec("train")
-    v.update(tq_ms=f(tq["ms_per_step"], 2), tq_frac=f(tq["roofline"]["frac"], 2), train_ms=f(tn["ms_per_step"], 1),
+    v.update(tq_ms=f(tq["ms_per_step"], 2), tq_frac=f(tq["roofline"]["frac"], 2), train_ms=f(tn["ms_per_step"], 2),
              tr_ms=f(tr["ms_per_step"], 2), tr_frac=f(tr["roofline"]["frac"], 2),
              tr_launches="%d" % round(tr["profile"]["launches_per_step"]))
     c2, c4 = rec("config2"), rec("config4")
@@ -68,6 +68,12 @@ def main():
              e2e_sel6_ms=f(rec("e2e_frame_f1_selected_streams6")["ms_per_frame"], 3),
              tq_sel_ms=f(rec("train-query_selected")["ms_per_step"], 2), tq_dense_ms=f(rec("train-query_dense")["ms_per_step"], 2))
     g128, g32 = rec("gf128"), rec("gf32")
+    tp = rec("train_pair")
+    v.update(train_pair_ms=f(tp["ms_per_step"], 2), train_pair_frac=f(tp["roofline"]["frac"], 2),
+             gf32_frac=f(g32["roofline"]["frac"], 2),
+             gf32_chain_frac=f((g32["roofline"].get("chain_kernel") or {}).get("frac_rocprof") or 0.0, 2),
+             gf128_chain_frac=f((g128["roofline"].get("chain_kernel") or {}).get("frac_rocprof") or 0.0, 2),
+             gf32_layers_value=f(rec("gf32_layers")["value"], 0), gf128_layers_value=f(rec("gf128_layers")["value"], 1))
     v.update(gf128_value=f(g128["value"], 1), gf128_frac=f(g128["roofline"]["frac"], 2), gf32_value=f(g32["value"], 0),
              e2e_f8_ms=f(rec("e2e_frame_f8")["ms_per_frame"], 3), e2e_f16_ms=f(rec("e2e_frame_f16")["ms_per_frame"], 3),
              e2e_f16sel_ms=f(rec("e2e_frame_f16_selected")["ms_per_frame"], 3), train_frac=f(tn["roofline"]["frac"], 2))
