@@ -348,6 +348,20 @@ def test_generic_width_paths_have_no_cpu_route():
                              null, 0, null) == 0              # n == 0: nothing to do
     assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 0, 8, 3, null, 0, null) == 0
     assert L.lidf_roi_align_f32(null, 1, 4, 8, 8, null, null, 5, 8, 0, null, 0, null) == -1
+    # the chain launch of gf_dim 32 / 64 / 128 (ABI 12) and the decoder pair's backward
+    assert L.lidf_decoder_chain_workspace_bytes(32, 102) > 0 and L.lidf_decoder_chain_workspace_bytes(48, 102) == 0
+    assert L.lidf_decoder_chain_workspace_bytes(128, 385) > L.lidf_decoder_chain_workspace_bytes(32, 385)
+    d = _lib.LidfDecoder()
+    args = (8, 4, 0, 0, null, null, null, null, null, null, 0, null)      # ldx, k, w1_col0, n, tables, out, workspace
+    assert L.lidf_decoder_chain_f32(None, 32, 20, null, *args) == -1            # no decoder
+    assert L.lidf_decoder_chain_f32(C.byref(d), 48, 20, null, *args) == -2      # a width without a chain: unsupported
+    assert L.lidf_decoder_chain_f32(C.byref(d), 32, 20, null, *args) == -1      # NULL weights
+    assert L.lidf_decoder_chain_f32(C.byref(d), 32, 3, null, *args) == -1       # k columns do not fit inp_dim
+    one, two = L.lidf_decoder_train_workspace_bytes(1000, 385), L.lidf_decoder_pair_workspace_bytes(1000, 385)
+    assert two > 2 * one and L.lidf_decoder_pair_workspace_offset(1000, 385, 0) == 0
+    assert L.lidf_decoder_pair_workspace_offset(1000, 385, 1) >= one
+    assert L.lidf_decoder_pair_backward_f32(null, 0, 385, 385, None, None, null, null, null, null, null, 385, None, None,
+                                            null, 0, null) == -1
 
 
 def test_cpu_tensors_refused_unless_composite_is_allowed(monkeypatch):
