@@ -45,8 +45,9 @@ const char* lidf_strerror(int status);
  * One implicit decoder: IMNet (models/implicit_net.py:60-98) or IEF (:100-152).
  * Weights are nn.Linear storage, row-major [out,in], borrowed (never cached across calls:
  * parameters change every optimizer step). Hidden widths are fixed to gf_dim=64
- * (256 -> 128 -> 64 -> 1), the value of every shipped config; other widths run layer by layer
- * through lidf_linear_f32 (below).
+ * (256 -> 128 -> 64 -> 1), the value of every shipped config, for every entry point but
+ * lidf_decoder_chain_f32 (gf_dim 32 / 64 / 128: the array shapes below scale with gf_dim); any
+ * other width runs layer by layer through lidf_linear_f32 (below).
  */
 typedef struct LidfDecoder {
     const float* w1; /* [256, d_in]  (IEF: d_in = D + 16; IMNet: d_in = D) */
