@@ -378,6 +378,8 @@ def decoders_forward_train(inp_feat, prob_dec, offset_dec):
     for m in (prob_dec, offset_dec):
         if inp_feat.dtype != torch.float32 or inp_feat.dim() != 2 or inp_feat.shape[1] != m.inp_dim:
             raise RuntimeError("inp_feat must be float32 [n, %d]" % m.inp_dim)
+    if not (prob_dec._needs_autograd(inp_feat) or offset_dec._needs_autograd(inp_feat)):
+        return decoders_forward(inp_feat, prob_dec, offset_dec)     # nothing to differentiate: the inference launch
     pp = [_get(prob_dec, k) for k in _PARAM_ORDER if _has(prob_dec, k)]
     po = [_get(offset_dec, k) for k in _PARAM_ORDER if _has(offset_dec, k)]
     return _DecoderPairTrainFn.apply(prob_dec, offset_dec, inp_feat, len(pp), *pp, *po)

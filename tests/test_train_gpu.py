@@ -112,6 +112,20 @@ def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use)
     _, _, g1b = run(lambda t: decoders_forward_train(t, prob, off))
     for k in g1:
         assert torch.equal(g1[k], g1b[k]), k
+    # without anything to differentiate the call is the inference launch of both decoders
+    with torch.no_grad():
+        yp4, yo4 = decoders_forward_train(x, prob, off)
+    assert not yp4.requires_grad and (yp4 - yp1).abs().max().item() <= 1e-5 and (yo4 - yo1).abs().max().item() <= 1e-5
+    # frozen offset decoder (trainers/train_refine.py freezes stage 1 the same way): no gradient tensors for it
+    for q in off.parameters():
+        q.requires_grad_(False)
+    for q in prob.parameters():
+        q.grad = None
+    yp5, yo5 = decoders_forward_train(x, prob, off)
+    (yp5.reshape(-1) * wp).sum().backward()
+    assert all(q.grad is None for q in off.parameters()) and all(q.grad is not None for q in prob.parameters())
+    for q in off.parameters():
+        q.requires_grad_(True)
 
 
 def test_rows_backward_is_run_to_run_identical(cuda):
