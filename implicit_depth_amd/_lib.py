@@ -256,7 +256,7 @@ SIGNATURES = {
                                             _I64, C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),
     "lidf_decoder_chain_workspace_bytes": (C.c_size_t, [_I, _I]),
     "lidf_decoder_chain_f32": (C.c_int, [C.POINTER(LidfDecoder), _I, _I, _P, _I64, _I, _I, _I64, _P, _P, _P, _P, _P,
-                                         _P, C.c_size_t, _P]),
+                                         _I, _P, C.c_size_t, _P]),
     "lidf_decoder_pair_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_pair_workspace_offset": (C.c_size_t, [_I64, _I, _I]),
     "lidf_decoder_pair_backward_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), C.POINTER(LidfDecoder),

@@ -2270,7 +2270,8 @@ LIDF_API size_t lidf_decoder_chain_workspace_bytes(int32_t gf_dim, int32_t k) {
 LIDF_API int lidf_decoder_chain_f32(const LidfDecoder* dec, int32_t gf_dim, int32_t inp_dim, const float* x,
                                       int64_t ldx, int32_t k, int32_t w1_col0, int64_t n, const float* voxpart,
                                       const int32_t* vox_idx, const float* raypart, const int32_t* ray_idx,
-                                      float* out, void* workspace, size_t workspace_bytes, lidf_stream_t stream) {
+                                      float* out, int32_t prepacked, void* workspace, size_t workspace_bytes,
+                                      lidf_stream_t stream) {
     if (!dec || n < 0 || k <= 0 || ldx < k || inp_dim <= 0 || w1_col0 < 0 || w1_col0 + k > inp_dim)
         return LIDF_ERR_BAD_ARG;
     if (gf_dim != 32 && gf_dim != 64 && gf_dim != 128) return LIDF_ERR_UNSUPPORTED;
@@ -2293,7 +2294,8 @@ LIDF_API int lidf_decoder_chain_f32(const LidfDecoder* dec, int32_t gf_dim, int3
     L1Map m = {};
     m.n0 = k; m.c0 = w1_col0; m.nt = G;
     const NetW nw = to_netw(dec, inp_dim);
-    CHECK_HIP(pack_stream(lay, nw, nw, m, sbuf, aux, st));
+    // (prepacked: the workspace still holds this decoder's stream for this k / w1_col0 — the slabs of one query)
+    if (!prepacked) CHECK_HIP(pack_stream(lay, nw, nw, m, sbuf, aux, st));
     Chain16Args a = {};
     a.stream = sbuf; a.aux = aux; a.KQ = (k + 15) / 16; a.E = k; a.n = n;
     a.X = x; a.ldx = ldx;
@@ -2638,6 +2640,8 @@ static int decoder_input_grad(const float* S, const LidfDecoder* dec, const floa
         const int t = (d - 1) / 32, l = (t + 7) / 8;
         if ((t + l - 1) / l >= 8) xcol = false;
     }
+    // (385 columns as ONE launch of 12 tiles + the column — the operand rows read once — was measured slower: 12.03
+    // against 11.41 ms per rows step, 11.1 against 10.6 with the pair node; docs/history.md section 13)
     const int dt = xcol ? d - 1 : d;
     const int tiles = (dt + 31) / 32, launches = (tiles + 7) / 8, per = (tiles + launches - 1) / launches;
     for (int c0 = 0; c0 < dt; c0 += 32 * per) {

@@ -1272,44 +1272,31 @@ extern "C" hipError_t lidf_launch_rayfeat_backward(const float* d_rayfeat, int l
 // (+ u*off), so only the positional encodings are per-pair rows.
 // ------------------------------------------------------------------------------------------------
 // pe[p] = [ embed(enter) | embed(leave) ]  (2*(3+6L) columns)
-// Thread (pair, column): 256 / wpad pairs per workgroup (wpad = the row width rounded up to a power
-// of two: shifts instead of 64-bit divisions); sin/cos as in the inference kernel (revolutions,
-// v_sin_f32 / v_cos_f32, |err| <= 4.2e-7 at every octave — lidf_device.h).
-#define PE_UNROLL 4   // pairs per thread: their dependent index -> direction loads overlap
+// Thread (pair, end, axis): ONE coordinate value — its index -> direction loads, its product and its revolution
+// reduction happen once — and all of its 1 + 2 L row entries (x, sin / cos at every octave). Round 6: a thread per
+// (pair, column) repeated the loads and the reduction for each of the 102 columns and threw one of every
+// sin / cos pair away (128 threads per pair, 120 us per 614,400 pairs; now 8 threads per pair, 6 of them at work).
+// sin/cos as in the inference kernel (revolutions, v_sin_f32 / v_cos_f32, |err| <= 4.2e-7 at every octave —
+// lidf_device.h): the values are bit-identical to the per-column form's.
 __global__ void __launch_bounds__(256) lidf_pe_rows_kernel(
     const int* __restrict__ pair_ray, const int* __restrict__ pair_vox, const float* __restrict__ pair_t,
     const float* __restrict__ ray_dir, const float* __restrict__ vox_center, int pos_rel, int L,
-    long long P, int wshift, float* __restrict__ pe) {
+    long long P, float* __restrict__ pe) {
     const int E = 3 + 6 * L, W = 2 * E;
-    const int per = 256 >> wshift;
-    const long long p0 = (long long)blockIdx.x * (per * PE_UNROLL) + (threadIdx.x >> wshift);
-    const int j = threadIdx.x & ((1 << wshift) - 1);
-    if (j >= W) return;
-    const int k = j >= E ? j - E : j;
-    const int c = k < 3 ? k : (k - 3) % 3;
-    const float sc = k >= 3 ? (float)(1 << ((k - 3) / 6)) : 1.f;
-    const bool is_sin = k >= 3 && ((k - 3) % 6) < 3;
-    float x[PE_UNROLL];
-#pragma unroll
-    for (int u = 0; u < PE_UNROLL; ++u) {
-        const long long p = p0 + (long long)u * per;
-        x[u] = 0.f;
-        if (p < P) {
-            x[u] = __fmul_rn(ray_dir[3 * (size_t)pair_ray[p] + c], pair_t[2 * p + (j >= E ? 1 : 0)]);
-            if (pos_rel) x[u] -= vox_center[3 * (size_t)pair_vox[p] + c];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < PE_UNROLL; ++u) {
-        const long long p = p0 + (long long)u * per;
-        if (p >= P) break;
-        float val = x[u];
-        if (k >= 3) {
-            float sn, cs;
-            rev_sincos(to_rev(x[u]), sc, sn, cs);
-            val = is_sin ? sn : cs;
-        }
-        pe[(size_t)p * W + j] = val;
+    const long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int q = threadIdx.x & 7;          // 0..2: enter x y z, 3..5: leave x y z, 6..7: idle
+    if (p >= P || q >= 6) return;
+    const int end = q >= 3 ? 1 : 0, c = q - 3 * end;
+    float x = __fmul_rn(ray_dir[3 * (size_t)pair_ray[p] + c], pair_t[2 * p + end]);
+    if (pos_rel) x -= vox_center[3 * (size_t)pair_vox[p] + c];
+    float* row = pe + (size_t)p * W + end * E;
+    row[c] = x;
+    const Rev r = to_rev(x);
+    for (int o = 0; o < L; ++o) {
+        float sn, cs;
+        rev_sincos(r, (float)(1 << o), sn, cs);
+        row[3 + 6 * o + c] = sn;
+        row[6 + 6 * o + c] = cs;
     }
 }
 
@@ -1365,13 +1352,9 @@ extern "C" hipError_t lidf_launch_pe_rows(const int* pair_ray, const int* pair_v
                                           const float* vox_center, int pos_rel, int L, long long P,
                                           float* pe, hipStream_t st) {
     if (P <= 0) return hipSuccess;
-    const int W = 2 * (3 + 6 * L);
-    int wshift = 3;
-    while ((1 << wshift) < W) ++wshift;
-    if (wshift > 8) return hipErrorInvalidValue;
-    const long long per = (256 >> wshift) * PE_UNROLL;
-    hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((P + per - 1) / per)), dim3(256), 0, st,
-                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, wshift, pe);
+    if (L < 0 || L > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lidf_pe_rows_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, st,
+                       pair_ray, pair_vox, pair_t, ray_dir, vox_center, pos_rel, L, P, pe);
     return hipGetLastError();
 }
 extern "C" hipError_t lidf_launch_seg_sum_ray(const float* S, int F, const int* pair_off,

@@ -48,11 +48,12 @@ def _bias_row(mod):
 
 
 def decoder_chain(mod, x, k, w1_col0=0, voxpart=None, vox_idx=None, raypart=None, ray_idx=None, out=None,
-                  padded=False):
+                  padded=False, packed=None):
     """The whole decoder on per-row operand columns x[:, :k] (they multiply W1[:, w1_col0 : w1_col0 + k]) plus two
     gathered table rows — lidf_decoder_chain_f32. voxpart must carry b1 (+ the IEF constant: _bias_row). padded: x's
     buffer is readable up to column 16 ceil(k / 16) of its last row (otherwise the trailing rows go through a
-    padded copy). Returns [n, 1]."""
+    padded copy). packed: a dict the caller keeps over the slabs of one query — the first call leaves its workspace
+    (the packed weight stream) there, the later ones skip the pack launch. Returns [n, 1]."""
     from .decoders import _decoder_struct
     import ctypes as C
     n = x.shape[0]
@@ -68,7 +69,11 @@ def decoder_chain(mod, x, k, w1_col0=0, voxpart=None, vox_idx=None, raypart=None
     L = _lib.lib()
     gf = int(mod.gf_dim)
     wsb = L.lidf_decoder_chain_workspace_bytes(gf, k)
-    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    state = packed if packed is not None else {}
+    ws = state.get("ws")
+    if ws is None:
+        ws = state["ws"] = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        state["ready"] = 0
     keep = []
     dec = _decoder_struct(mod, keep)
 
@@ -76,7 +81,9 @@ def decoder_chain(mod, x, k, w1_col0=0, voxpart=None, vox_idx=None, raypart=None
         with torch.cuda.device(dev):
             _lib.check(L.lidf_decoder_chain_f32(
                 C.byref(dec), gf, int(mod.inp_dim), _lib.ptr(xs), ld, k, w1_col0, rows, _lib.ptr(voxpart), _lib.ptr(vi),
-                _lib.ptr(rp), _lib.ptr(ri), _lib.ptr(o), _lib.ptr(ws), wsb, _lib.current_stream(dev)))
+                _lib.ptr(rp), _lib.ptr(ri), _lib.ptr(o), state["ready"], _lib.ptr(ws), wsb,
+                _lib.current_stream(dev)))
+        state["ready"] = 1
 
     # rows whose 16-column groups would read past the end of x's buffer: through a padded copy
     tail = 0 if (padded or kq16 <= k) else min(n, (kq16 - k + max(ldx, 1) - 1) // max(ldx, 1))
@@ -273,6 +280,7 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
     ray_rows = torch.arange(R, dtype=torch.int32, device=dev)
     tables = []
     chained = chain_ok(prob_dec) and chain_ok(offset_dec)
+    packs = ({}, {})   # the chain launches' packed weight streams, one pack per decoder and query
     for dec in (prob_dec, offset_dec):
         l1 = dec.linear_1
         # (the chain launch takes the IEF's constant W1[:, enc] benc inside the per-voxel table, as the fixed-width
@@ -297,11 +305,12 @@ def query(ray_dir, ray_pix, ray_bid, pair_off, pair_ray, pair_vox, pair_t, feat_
                                           _lib.ptr(vox_center), 1 if pos_rel else 0, multires, n, _lib.ptr(pe),
                                           _lib.current_stream(dev)))
         pr_i, pv_i = pr_s.contiguous(), pv_s.contiguous()
-        for dec, (voxpart, raypart), dst in ((prob_dec, tables[0], pred_prob), (offset_dec, tables[1], pred_offset)):
+        for dec, (voxpart, raypart), dst, pk in ((prob_dec, tables[0], pred_prob, packs[0]),
+                                                  (offset_dec, tables[1], pred_offset, packs[1])):
             w1 = dec.linear_1.weight
             if chained:   # the whole decoder in one launch, straight into its slab of the output
                 decoder_chain(dec, pe, 2 * E, w1_col0=Cv + Cr, voxpart=voxpart, vox_idx=pv_i, raypart=raypart,
-                              ray_idx=pr_i, out=dst[p0:p1], padded=True)
+                              ray_idx=pr_i, out=dst[p0:p1], padded=True, packed=pk)
                 continue
 
             def layer1(act, w1=w1, voxpart=voxpart, raypart=raypart):

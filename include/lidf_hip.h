@@ -691,12 +691,14 @@ int lidf_depth_metrics_f32(const float* pred_depth, const float* gt_depth, const
  * vox_idx NULL: row 0 for every row) and raypart[ray_idx[i]] (ray_idx NULL: row i); either table may be NULL.
  * inp_dim = the decoder's input width (W1 has inp_dim (+ 16 for an IEF) columns). out [n].
  * x must be readable up to column 16 ceil(k / 16) of its LAST row (the kernel reads whole 16-column groups and
- * masks what lies beyond k). Other widths: LIDF_ERR_UNSUPPORTED (the layers run one by one, lidf_linear_f32).   */
+ * masks what lies beyond k). prepacked != 0: the workspace still holds the weight stream an earlier call packed
+ * for this decoder, k and w1_col0 (the slabs of one query; parameters unchanged in between) — no pack launch.
+ * Other widths: LIDF_ERR_UNSUPPORTED (the layers run one by one, lidf_linear_f32).                             */
 size_t lidf_decoder_chain_workspace_bytes(int32_t gf_dim, int32_t k);
 int lidf_decoder_chain_f32(const LidfDecoder* dec, int32_t gf_dim, int32_t inp_dim, const float* x, int64_t ldx,
                            int32_t k, int32_t w1_col0, int64_t n, const float* voxpart, const int32_t* vox_idx,
-                           const float* raypart, const int32_t* ray_idx, float* out, void* workspace,
-                           size_t workspace_bytes, lidf_stream_t stream);
+                           const float* raypart, const int32_t* ray_idx, float* out, int32_t prepacked,
+                           void* workspace, size_t workspace_bytes, lidf_stream_t stream);
 
 /* ---- Decoders, training path (first step) -------------------------------------
  * What autograd does for models/implicit_net.py IMNet / IEF on [n, d] rows: a forward that keeps

@@ -352,7 +352,7 @@ def test_generic_width_paths_have_no_cpu_route():
     assert L.lidf_decoder_chain_workspace_bytes(32, 102) > 0 and L.lidf_decoder_chain_workspace_bytes(48, 102) == 0
     assert L.lidf_decoder_chain_workspace_bytes(128, 385) > L.lidf_decoder_chain_workspace_bytes(32, 385)
     d = _lib.LidfDecoder()
-    args = (8, 4, 0, 0, null, null, null, null, null, null, 0, null)      # ldx, k, w1_col0, n, tables, out, workspace
+    args = (8, 4, 0, 0, null, null, null, null, null, 0, null, 0, null)   # ldx, k, w1_col0, n, tables, out, prepacked, workspace
     assert L.lidf_decoder_chain_f32(None, 32, 20, null, *args) == -1            # no decoder
     assert L.lidf_decoder_chain_f32(C.byref(d), 48, 20, null, *args) == -2      # a width without a chain: unsupported
     assert L.lidf_decoder_chain_f32(C.byref(d), 32, 20, null, *args) == -1      # NULL weights

@@ -119,6 +119,7 @@ def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use)
     # frozen offset decoder (trainers/train_refine.py freezes stage 1 the same way): no gradient tensors for it
     for q in off.parameters():
         q.requires_grad_(False)
+        q.grad = None
     for q in prob.parameters():
         q.grad = None
     yp5, yo5 = decoders_forward_train(x, prob, off)
