@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["lidf_points.hip", "lidf_points_h.hip", "lidf_rows_h.hip", "lidf_linear.hip", "lidf_linear_x.hip", "lidf_aux.hip", "lidf_frame.hip", "lidf_refine.hip", "lidf_train.hip", "lidf_dgrad.hip", "lidf_pointnet.hip", "lidf_pointnet_train.hip", "lidf_ief16.hip", "lidf_chain16.hip", "lidf_api.hip"]
+SOURCES = ["lidf_points.hip", "lidf_points_h.hip", "lidf_rows_h.hip", "lidf_linear.hip", "lidf_linear_s.hip", "lidf_linear_x.hip", "lidf_linear_sx.hip", "lidf_aux.hip", "lidf_frame.hip", "lidf_refine.hip", "lidf_train.hip", "lidf_dgrad.hip", "lidf_pointnet.hip", "lidf_pointnet_train.hip", "lidf_ief16.hip", "lidf_chain16.hip", "lidf_api.hip"]
 HEADERS = ["lidf_device.h", "lidf_linear_kernel.inc", "lidf_api_refine_train.inc", "lidf_api_pointnet_train.inc", os.path.join(ROOT, "include", "lidf_hip.h")]
 LIB = os.path.join(HERE, "liblidf_hip.so")
 

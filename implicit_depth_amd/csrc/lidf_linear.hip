@@ -155,8 +155,10 @@ extern "C" hipError_t lidf_launch_vox2(const Vox2Args& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// the SPLIT / XCOL instantiations: lidf_linear_x.hip
-extern "C" void lidf_launch_linear_x(int nt, int split, int xcol, dim3 g, dim3 b, hipStream_t st, const LinearArgs& a);
+// the SPLIT / XCOL instantiations: lidf_linear_s.hip, lidf_linear_x.hip, lidf_linear_sx.hip
+extern "C" void lidf_launch_linear_s(int nt, dim3 g, dim3 b, hipStream_t st, const LinearArgs& a);
+extern "C" void lidf_launch_linear_x(int nt, dim3 g, dim3 b, hipStream_t st, const LinearArgs& a);
+extern "C" void lidf_launch_linear_sx(int nt, dim3 g, dim3 b, hipStream_t st, const LinearArgs& a);
 
 // nt = accumulator tiles; a.xcol: the stream carries nt + 1 quads per k-quad, the last one the extra column's
 extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int grid, hipStream_t st) {
@@ -173,7 +175,7 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int gri
     const long long ntile = (a.n + 127) / 128;
     if (nt > 1 && ntile <= 16 && !a.xcol) {   // few rows: one workgroup per (row tile, output tile)
         a.nt_total = nt;
-        if (a.X2) lidf_launch_linear_x(1, 1, 0, dim3((unsigned)ntile, (unsigned)nt), dim3(256), st, a);
+        if (a.X2) lidf_launch_linear_s(1, dim3((unsigned)ntile, (unsigned)nt), dim3(256), st, a);
         else hipLaunchKernelGGL((lidf_linear_kernel<1, false, false>), dim3((unsigned)ntile, (unsigned)nt), dim3(256), 0, st, a);
         return hipGetLastError();
     }
@@ -190,7 +192,9 @@ extern "C" hipError_t lidf_launch_linear(int nt, const LinearArgs& a_in, int gri
             (long long)g.x > cus)
             g = dim3((unsigned)cus);
     }
-    if (a.X2 || a.xcol) lidf_launch_linear_x(nt, a.X2 ? 1 : 0, a.xcol ? 1 : 0, g, b, st, a);
+    if (a.X2 && a.xcol) lidf_launch_linear_sx(nt, g, b, st, a);
+    else if (a.X2) lidf_launch_linear_s(nt, g, b, st, a);
+    else if (a.xcol) lidf_launch_linear_x(nt, g, b, st, a);
     else launch_linear_nt<false, false>(nt, g, b, st, a);
     return hipGetLastError();
 }
