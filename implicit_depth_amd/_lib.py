@@ -259,8 +259,6 @@ SIGNATURES = {
                                          _I, _P, C.c_size_t, _P]),
     "lidf_decoder_pair_workspace_bytes": (C.c_size_t, [_I64, _I]),
     "lidf_decoder_pair_workspace_offset": (C.c_size_t, [_I64, _I, _I]),
-    "lidf_decoder_pair_input_grad_f32": (C.c_int, [_I64, _I, C.POINTER(LidfDecoder), C.POINTER(LidfDecoder), _P, _I64, _P,
-                                                   C.c_size_t, _P]),
     "lidf_decoder_pair_backward_f32": (C.c_int, [_P, _I64, _I, _I64, C.POINTER(LidfDecoder), C.POINTER(LidfDecoder),
                                                  _P, _P, _P, _P, _P, _I64, C.POINTER(LidfDecoderGrads),
                                                  C.POINTER(LidfDecoderGrads), _P, C.c_size_t, _P]),

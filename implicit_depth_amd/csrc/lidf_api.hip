@@ -2697,31 +2697,6 @@ LIDF_API size_t lidf_decoder_pair_workspace_offset(int64_t n, int32_t d, int32_t
     return (size_t)(which ? 1 : 0) * align_up(train_ws(n, d).total, 256);
 }
 
-// The pair's rows' gradient alone, for a caller that ran the two decoders' backwards itself — lidf_decoder_backward_f32
-// with d_inp = NULL on the two halves of the pair workspace (e.g. on two streams: one decoder's memory-bound sweeps
-// beside the other's matrix launches) — and joined them: S of each decoder is where its backward left it.
-LIDF_API int lidf_decoder_pair_input_grad_f32(int64_t n, int32_t d, const LidfDecoder* prob, const LidfDecoder* off,
-                                                float* d_inp, int64_t ld_dinp, void* workspace,
-                                                size_t workspace_bytes, lidf_stream_t stream) {
-    if (n < 0 || d <= 0 || !prob || !off || !d_inp || ld_dinp < d) return LIDF_ERR_BAD_ARG;
-    int rc;
-    if ((rc = check_decoder(prob)) || (rc = check_decoder(off))) return rc;
-    if (n == 0) return LIDF_OK;
-    const TrainWs w = train_ws(n, d);
-    const size_t one = align_up(w.total, 256);
-    if (!workspace || workspace_bytes < lidf_decoder_pair_workspace_bytes(n, d)) return LIDF_ERR_WORKSPACE;
-    char* ws = (char*)workspace;
-    int cus;
-    if ((rc = cu_count(&cus))) return rc;
-    // (decoder_backward_core: one pass -> S is the dZ1 buffer itself)
-    const auto s_of = [&](const LidfDecoder* dec, char* base) {
-        const int npass = dec->is_ief ? dec->n_iter : 1;
-        return (float*)(base + (npass == 1 ? w.dz1 : w.S));
-    };
-    return decoder_input_grad(s_of(prob, ws), prob, s_of(off, ws + one), off, n, d, d_inp, ld_dinp,
-                              (float*)(ws + 2 * one), cus, (hipStream_t)stream);
-}
-
 LIDF_API int lidf_decoder_pair_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
                                               const LidfDecoder* prob, const LidfDecoder* off,
                                               const float* act_prob, const float* act_off,

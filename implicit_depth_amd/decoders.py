@@ -15,7 +15,6 @@ Execution:
   * CPU input                           -> RuntimeError. There is no CPU product path.
 """
 import ctypes as C
-import os
 
 import torch
 import torch.nn as nn
@@ -357,44 +356,11 @@ class _DecoderPairTrainFn(torch.autograd.Function):
         gt_p, gs_p = _grad_struct(ctx.names_p, saved_p, f32)
         gt_o, gs_o = _grad_struct(ctx.names_o, saved_o, f32)
         d_inp = torch.empty((n, d), **f32) if ctx.needs_input_grad[2] else None
-        L = _lib.lib()
-        dev = x.device
-        # Two streams (LIDF_TRAIN_STREAMS=1: one): the two decoders' backwards are independent until the rows'
-        # gradient, and each alternates matrix launches (dgrad chain, weight gradients) with memory-bound sweeps
-        # (layer 4, the IEF's encoding columns, slab reductions) — offset_dec's run on a side stream beside
-        # prob_dec's, each on its half of the pair workspace, joined in front of the one K = 512 product. Every sum
-        # keeps its order: the gradients are bit-identical to the one-stream call's.
-        two = (n > 4096 and os.environ.get("LIDF_TRAIN_STREAMS", "2") != "1"
-               and not torch.cuda.is_current_stream_capturing())
-        with torch.cuda.device(dev):
-            if not two:
-                _lib.check(L.lidf_decoder_pair_backward_f32(
-                    _lib.ptr(x), n, d, ctx.ld, C.byref(dp), C.byref(do), _lib.ptr(act_p), _lib.ptr(act_o),
-                    _lib.ptr(g_p), _lib.ptr(g_o), _lib.ptr(d_inp), d, C.byref(gs_p), C.byref(gs_o),
-                    _lib.ptr(ctx.ws), ctx.wsb, _lib.current_stream(dev)))
-            else:
-                from .query import _train_side_stream
-                side, main = _train_side_stream(dev), torch.cuda.current_stream(dev)
-                one = L.lidf_decoder_train_workspace_bytes(n, d)
-                side.wait_stream(main)
-                # (the tensors the side stream reads were produced on the caller's stream: hand them over)
-                for t in (x, act_o, g_o, ctx.ws):
-                    t.record_stream(side)
-                _lib.check(L.lidf_decoder_backward_f32(
-                    _lib.ptr(x), n, d, ctx.ld, C.byref(dp), _lib.ptr(act_p), _lib.ptr(g_p), None, d, C.byref(gs_p),
-                    ctx.ws.data_ptr() + L.lidf_decoder_pair_workspace_offset(n, d, 0), one, _lib.current_stream(dev)))
-                with torch.cuda.stream(side):
-                    _lib.check(L.lidf_decoder_backward_f32(
-                        _lib.ptr(x), n, d, ctx.ld, C.byref(do), _lib.ptr(act_o), _lib.ptr(g_o), None, d, C.byref(gs_o),
-                        ctx.ws.data_ptr() + L.lidf_decoder_pair_workspace_offset(n, d, 1), one,
-                        _lib.current_stream(dev)))
-                    for t in gt_o.values():
-                        t.record_stream(main)
-                main.wait_stream(side)
-                if d_inp is not None:
-                    _lib.check(L.lidf_decoder_pair_input_grad_f32(
-                        n, d, C.byref(dp), C.byref(do), _lib.ptr(d_inp), d, _lib.ptr(ctx.ws), ctx.wsb,
-                        _lib.current_stream(dev)))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().lidf_decoder_pair_backward_f32(
+                _lib.ptr(x), n, d, ctx.ld, C.byref(dp), C.byref(do), _lib.ptr(act_p), _lib.ptr(act_o),
+                _lib.ptr(g_p), _lib.ptr(g_o), _lib.ptr(d_inp), d, C.byref(gs_p), C.byref(gs_o),
+                _lib.ptr(ctx.ws), ctx.wsb, _lib.current_stream(x.device)))
         grads = [gt_p[k] for k in ctx.names_p] + [gt_o[k] for k in ctx.names_o]
         return (None, None, d_inp, None) + tuple(g if ctx.needs_input_grad[4 + i] else None
                                                  for i, g in enumerate(grads))

@@ -731,11 +731,6 @@ int lidf_decoder_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld
  * lidf_decoder_pair_workspace_offset(n, d, 0 | 1) (each lidf_decoder_train_workspace_bytes(n, d) long).   */
 size_t lidf_decoder_pair_workspace_bytes(int64_t n, int32_t d);
 size_t lidf_decoder_pair_workspace_offset(int64_t n, int32_t d, int32_t which);
-/* The rows' gradient of the pair alone: for a caller that ran lidf_decoder_backward_f32 (d_inp = NULL) for each
- * decoder on its half of the pair workspace — on two streams if it likes — and joined them.                */
-int lidf_decoder_pair_input_grad_f32(int64_t n, int32_t d, const LidfDecoder* prob, const LidfDecoder* off,
-                                     float* d_inp, int64_t ld_dinp, void* workspace, size_t workspace_bytes,
-                                     lidf_stream_t stream);
 int lidf_decoder_pair_backward_f32(const float* inp, int64_t n, int32_t d, int64_t ld_inp,
                                    const LidfDecoder* prob, const LidfDecoder* off,
                                    const float* act_prob, const float* act_off,
