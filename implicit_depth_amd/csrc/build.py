@@ -63,6 +63,7 @@ def build(force=False, verbose=False):
         # 16k-instruction cap on `#pragma unroll` would silently leave it rolled (arrays in scratch)
         "-mllvm", "-pragma-unroll-threshold=8000000",
     ] + _probe_flags(hipcc, objdir) + ["-I", os.path.join(ROOT, "include"), "-I", HERE]
+    flags += os.environ.get("LIDF_EXTRA_HIPCC_FLAGS", "").split()   # (development builds: -DLIDF_PROFILE, A/B macros)
     hdr_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(HERE, h)) for h in HEADERS)
     hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
     jobs, objs = [], []
