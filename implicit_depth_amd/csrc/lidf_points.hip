@@ -71,10 +71,12 @@ __device__ __forceinline__ float ief_c(const NetW& n, int out) {
     return acc;
 }
 
-__device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L1Map& m, int e) {
+// (the two nets by reference, selected per element: a NetW[2] copy indexed by a runtime value lived in scratch —
+// 208 bytes per lane in every pack launch)
+__device__ float stream_value(const StreamLayout& lay, const NetW& net0, const NetW& net1, const L1Map& m, int e) {
     const int net = e / (lay.net_quads * 256);
     e %= lay.net_quads * 256;
-    const NetW& n = nets[net];
+    const NetW& n = net ? net1 : net0;
     int quad = e / 256;
     const int lane = (e % 256) / 4, jj = e & 3;
     const int half = lane >> 5, c32 = lane & 31;
@@ -104,7 +106,7 @@ __device__ float stream_value(const StreamLayout& lay, const NetW* nets, const L
         (void)s;
         if (x < m.D) {
             const int col = x < m.n0 ? m.c0 + x : m.c1 + (x - m.n0);
-            if (m.transposed == 2 && x >= m.n0) return nets[1].w1[(size_t)col * nets[1].ld1 + out];
+            if (m.transposed == 2 && x >= m.n0) return net1.w1[(size_t)col * net1.ld1 + out];
             return m.transposed ? n.w1[(size_t)col * n.ld1 + out] : n.w1[(size_t)out * n.ld1 + col];
         }
         if (x == m.D && m.add_bias) {
@@ -237,11 +239,10 @@ __device__ __forceinline__ void pack_body(const StreamLayout& lay, const NetW& n
         if (e < gf + 8) aux[e] = e < gf ? net0.w4[e] : (e == gf ? net0.b4[0] : 0.f);
         return;
     }
-    NetW nets[2] = {net0, net1};
-    if (e < lay.total) stream[e] = stream_value(lay, nets, m, e);
+    if (e < lay.total) stream[e] = stream_value(lay, net0, net1, m, e);
     if (lay.mode != LIDF_MODE_L1ONLY && lay.mode != LIDF_MODE_LINEAR && e < lay.nets * LIDF_AUX_FLOATS) {
         int sec = e / LIDF_AUX_FLOATS, i = e % LIDF_AUX_FLOATS;
-        const NetW& n = nets[sec];
+        const NetW& n = sec ? net1 : net0;
         float v = 0.f;
         if (i < 64) {
             int half = i / 32, s = i % 32;
