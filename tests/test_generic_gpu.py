@@ -138,6 +138,64 @@ def test_decoder_chain_matches_the_layers(cuda, monkeypatch, gf, kind, inp, n_it
         assert torch.equal(mod(wide[:, :inp]), got)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_decoder_chain_fuzz(cuda, seed):
+    """lidf_decoder_chain_f32 as the query uses it, on random shapes: a decoder input row is [per-voxel columns |
+    per-row columns | per-ray columns]; the middle block is the launch's operand (its own row stride, any width,
+    padded or not), the outer blocks arrive as gathered rows of two tables (either may be absent, either index array
+    may be absent) — against the module's float64 definition on the assembled rows."""
+    from implicit_depth_amd import IEF, IMNet
+    from implicit_depth_amd.generic import _bias_row, decoder_chain, linear_hip
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
+    gf = (32, 64, 128)[seed % 3]
+    kind = ("IMNET", "IEF")[(seed // 3) % 2]
+    kv, k, kr = (0, ri(1, 40))[ri(0, 1)], ri(1, 130), (0, ri(1, 40))[ri(0, 1)]
+    n, V = ri(1, 3000), ri(1, 50)
+    use_vidx, use_ridx = bool(ri(0, 1)), bool(ri(0, 1))
+    R = ri(1, 200) if use_ridx else n
+    D = kv + k + kr
+    torch.manual_seed(seed)
+    mod = IMNet(D, 1, gf, use_sigmoid=bool(seed & 1)) if kind == "IMNET" else IEF("cpu", D, 1, gf, n_iter=ri(1, 3),
+                                                                                  use_sigmoid=bool(seed & 1))
+    for p in mod.parameters():
+        p.data.mul_(5.0)
+    ref_mod = copy.deepcopy(mod).double()
+    if kind == "IEF":
+        ref_mod.init_offset = ref_mod.init_offset.double()
+    fv, gr = torch.randn(V, max(kv, 1), generator=g), torch.randn(R, max(kr, 1), generator=g)
+    x = torch.randn(n, k, generator=g)
+    vi = torch.randint(0, V, (n,), generator=g) if use_vidx else torch.zeros(n, dtype=torch.long)
+    rj = torch.randint(0, R, (n,), generator=g) if use_ridx else torch.arange(n)
+    rows = torch.cat(([fv[vi][:, :kv]] if kv else []) + [x] + ([gr[rj][:, :kr]] if kr else []), 1)
+    with torch.no_grad():
+        ref = ref_mod.forward_composite(rows.double())
+    mod = mod.to(cuda).eval()
+    if kind == "IEF":
+        mod.device, mod.init_offset = cuda, mod.init_offset.to(cuda)
+    w1 = mod.linear_1.weight
+    # per-voxel table: W1[:, vox columns] f + b1 (+ the IEF constant); without voxel columns a one-row table of the bias
+    bias = _bias_row(mod)
+    if kv:
+        voxpart = linear_hip(fv.to(cuda)[:, :kv], w1, bias, k=kv)
+        vidx = vi.int().to(cuda) if use_vidx else None
+        if not use_vidx:
+            voxpart = voxpart[:1].contiguous() if V == 1 else linear_hip(fv.to(cuda)[:1, :kv], w1, bias, k=kv)
+    else:
+        voxpart, vidx = bias.reshape(1, -1).contiguous(), None
+    raypart = linear_hip(gr.to(cuda)[:, :kr], w1, None, w_col0=kv + k, k=kr) if kr else None
+    ridx = rj.int().to(cuda) if (kr and use_ridx) else None
+    # the operand block inside a wider buffer (row stride != k), no padding behind the last row
+    wide = torch.full((n, k + ri(0, 9)), float("nan"))
+    wide[:, :k] = x
+    with torch.no_grad():
+        got = decoder_chain(mod, wide.to(cuda)[:, :k], k, w1_col0=kv, voxpart=voxpart, vox_idx=vidx, raypart=raypart,
+                            ray_idx=ridx)
+    assert got.shape == (n, 1)
+    err = float((got.double().cpu() - ref).abs().max())
+    assert err <= 3e-5, (seed, gf, kind, kv, k, kr, n, err)
+
+
 @pytest.mark.parametrize("cin,outc,gf,n,V", [(9, 192, 48, 5000, 40), (6, 64, 16, 700, 3), (6, 128, 64, 2000, 300)])
 def test_pointnet_at_other_widths(cuda, cin, outc, gf, n, V):
     from implicit_depth_amd import PointNet2Stage
