@@ -21,6 +21,9 @@ def _grads(module, x, fn, weight):
 
 
 def _close(a, b, what):
+    if b.numel() == 0:                     # (an empty batch: shapes only)
+        assert a.shape == b.shape, what
+        return
     scale = max(1.0, b.abs().max().item())
     err = (a - b).abs().max().item()
     assert err <= 2e-4 * scale, (what, err, scale)
@@ -58,7 +61,7 @@ def test_backward_matches_autograd(cuda, kind, d, n, n_iter, sig):
 @pytest.mark.parametrize("d,n,n_iter,sig,use", [(385, 333, 2, False, "both"), (385, 5000, 2, False, "both"),
                                                  (334, 129, 3, True, "both"), (385, 1, 2, False, "both"),
                                                  (385, 700, 1, False, "both"), (27, 31, 2, False, "both"),
-                                                 (97, 2300, 2, False, "both"), (257, 2100, 2, False, "both"),
+                                                 (97, 2300, 2, False, "both"), (257, 2100, 2, False, "both"), (385, 0, 2, False, "both"),
                                                  (385, 900, 2, False, "prob"), (385, 900, 2, False, "off")])
 def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use):
     """decoders_forward_train (prob_dec(inp), offset_dec(inp) of pipeline.py:434-435 as ONE autograd node, the rows'
@@ -106,8 +109,9 @@ def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use)
         if k != "input":
             assert torch.equal(g1[k], g2[k]), k      # the parameter gradients are the same launches
     # one product over K = 512 against two over K = 256 and an add: summation order only
-    scale = max(1.0, g2["input"].abs().max().item())
-    assert (g1["input"] - g2["input"]).abs().max().item() <= 2e-6 * scale
+    if n:
+        scale = max(1.0, g2["input"].abs().max().item())
+        assert (g1["input"] - g2["input"]).abs().max().item() <= 2e-6 * scale
     # run-to-run identical
     _, _, g1b = run(lambda t: decoders_forward_train(t, prob, off))
     for k in g1:
@@ -115,7 +119,9 @@ def test_decoder_pair_node_matches_the_two_modules(cuda, d, n, n_iter, sig, use)
     # without anything to differentiate the call is the inference launch of both decoders
     with torch.no_grad():
         yp4, yo4 = decoders_forward_train(x, prob, off)
-    assert not yp4.requires_grad and (yp4 - yp1).abs().max().item() <= 1e-5 and (yo4 - yo1).abs().max().item() <= 1e-5
+    assert not yp4.requires_grad and yp4.shape == yp1.shape
+    if n:
+        assert (yp4 - yp1).abs().max().item() <= 1e-5 and (yo4 - yo1).abs().max().item() <= 1e-5
     # frozen offset decoder (trainers/train_refine.py freezes stage 1 the same way): no gradient tensors for it
     for q in off.parameters():
         q.requires_grad_(False)
