@@ -98,6 +98,29 @@ def check_full_size(scene, got, cuda, rays_per_frame=96):
     assert (dsel - ref["pred_pos"][:, 2]).abs().mean().item() <= TOL            # depth L1 vs ref
 
 
+@pytest.mark.parametrize("gf", [32, 128])
+def test_config1_at_other_decoder_widths_through_the_chain_launch(cuda, gf):
+    """configs[1] (240x320x64, P = 4,915,200) with decoders of gf_dim 32 / 128 — one register-chained launch per decoder
+    and slab (lidf_decoder_chain_f32; 8 slabs at gf 32, one at gf 128): the size-independent properties over the whole
+    frame and 96 random whole rays against the oracle at that width."""
+    from implicit_depth_amd import IEF, IMNet, generic
+    from implicit_depth_amd.query import lidf_query
+    scene = dict(_scene(1, 240, 320, 64, 1235))
+    D = scene["D"]
+    scene["prob_p"], scene["off_p"] = orc.init_decoder("IMNET", D, 7, 5.0, gf=gf), orc.init_decoder("IEF", D, 8, 5.0, gf=gf)
+    prob, off = IMNet(D, 1, gf), IEF(cuda, D, 1, gf, n_iter=2)
+    prob.load_state_dict(scene["prob_p"]), off.load_state_dict(scene["off_p"])
+    prob, off = prob.to(cuda).eval(), off.to(cuda).eval()
+    assert generic.chain_ok(prob) and generic.chain_ok(off)
+    s = to_dev(scene, cuda)
+    depth = torch.zeros((1, 240, 320), device=cuda)
+    with torch.no_grad():
+        got = lidf_query(s["ray_dir"], s["ray_pix"], s["ray_bid"], s["pair_off"], s["pair_ray"], s["pair_vox"],
+                         s["pair_t"], s["feat_grid"], s["vox_feat"], prob, off, ray_flat=s["ray_flat"], depth=depth)
+    got["depth"] = depth
+    check_full_size(scene, got, cuda)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_config2_shard_4_frames(cuda, precision):
     """configs[2]: 32 frames over 8 GPUs = 4 frames of 240x320x64 per GPU (P = 19,660,800)."""
