@@ -22,7 +22,6 @@
 //            W3[16 To + j][16 T + 4 g + ..]; padding to a multiple of the ring (lidf_chain16_pass_quads).
 // aux: w4 [gf] | b4 [1].
 #include "lidf_device.h"
-#include <cstdlib>
 
 #define C16_RING 8
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -316,15 +315,10 @@ extern "C" hipError_t lidf_launch_chain16(int gf, const Chain16Args& a, int cus,
     // gf 32: two wavefronts per SIMD, two sub-tiles each (64 + 32 + 16 accumulator registers per pair of sub-tiles);
     // gf 64: two wavefronts, one sub-tile each (the stage-2 decoder's configuration); gf 128: one wavefront, one
     // sub-tile (128 + 64 + 32 accumulator registers, the 512-register budget of a lone wavefront)
-    static int cfg32 = -1;   // development knob (A/B runs): LIDF_CHAIN16_GF32 = <wavefronts per SIMD><sub-tiles side by side>
-    if (cfg32 < 0) { const char* e = getenv("LIDF_CHAIN16_GF32"); cfg32 = e ? atoi(e) : 22; }
     switch (gf) {
-        case 32:
-            if (cfg32 == 12) hipLaunchKernelGGL((lidf_chain16_kernel<2, 1, 2>), dim3((unsigned)g), dim3(256), 0, st, a);
-            else if (cfg32 == 21) hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
-            else if (cfg32 == 41) hipLaunchKernelGGL((lidf_chain16_kernel<2, 4, 1>), dim3((unsigned)g), dim3(1024), 0, st, a);
-            else hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
-            break;
+        // (gf 32 at other occupancies — two wavefronts x one sub-tile, four x one, one x two — measured the same or
+        // slower, docs/history.md section 13; those instantiations are not shipped)
+        case 32: hipLaunchKernelGGL((lidf_chain16_kernel<2, 2, 2>), dim3((unsigned)g), dim3(512), 0, st, a); break;
         case 64: hipLaunchKernelGGL((lidf_chain16_kernel<4, 2, 1>), dim3((unsigned)g), dim3(512), 0, st, a); break;
         case 128: hipLaunchKernelGGL((lidf_chain16_kernel<8, 1, 1>), dim3((unsigned)g), dim3(256), 0, st, a); break;
         default: return hipErrorInvalidValue;
